@@ -1,0 +1,55 @@
+"""Builds the HIP engine in-tree: fetalreconstruction_amd/lib/libsvr_hip.so (gfx950 only).
+
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "svr_hip.hip")
+INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
+OUT_DIR = os.path.join(HERE, "lib")
+OUT = os.path.join(OUT_DIR, "libsvr_hip.so")
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # the canonical PSF sequence must be evaluated exactly as written (oracle parity)
+    "-ffp-contract=off", "-fno-fast-math",
+    # hardware global_atomic_add_f32 for the scatter (coarse-grained hipMalloc memory)
+    "-munsafe-fp-atomics",
+]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(f) > t for f in (SRC, INC, __file__))
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = [hipcc(), *FLAGS, *extra, "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
+    print(OUT)

@@ -1,0 +1,1571 @@
+// svr_hip.hip -- MI355X (gfx950) slice-to-volume super-resolution engine behind the C-ABI of
+// include/svr_hip.h.  Written for CDNA4 only: 64-wide wavefronts, one wavefront per slice
+// pixel for the PSF kernels, LDS transposition between the "row-per-lane" PSF evaluation and
+// the "x-per-lane" coalesced volume access, hardware float atomics for the scatter.
+//
+// Reference behaviour being replaced (citations: RC.cu = source/reconstructionGPU2/
+// reconstruction_cuda2.cu, RC.cuh = include/reconstruction_cuda2.cuh, RVH =
+// include/recon_volumeHelper.cuh, RG.cc = irtkReconstructionGPU.cc).  See DESIGN.md for the
+// canonical float32 PSF sequence and the list of reproduced / not reproduced quirks.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics ... (build.py)
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/svr_hip.h"
+
+// ------------------------------------------------------------------------------------------
+// constants of the reference configuration section (RC.cuh:54-75)
+// ------------------------------------------------------------------------------------------
+#define SVR_STEP 0.0001f        // __step
+#define PSF_SUPPORT 16          // MAX_PSF_SUPPORT with USE_INFINITE_PSF_SUPPORT 1
+#define PSF_CENTRE 7            // (MAX_PSF_SUPPORT - 1) / 2   (RC.cu:219)
+// `abs(oldPSF - psfval) < PSF_EPSILON` compares a float against the double 0.00001
+// (RC.cuh:72, RC.cu:238); for a float f that is exactly  f <= 0.00001f  because 0.00001f is
+// the largest float below 1e-5.
+#define PSF_EPS_F 0.00001f
+
+#define LDS_ROW 20              // floats per PSF row in LDS (16 + pad: conflict-free b128 stores)
+#define WAVES_PER_BLOCK 4
+#define CHUNK_PIX 2048          // slice-grid pixels per block in the EM kernels
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// host float helpers with the literal operation order of RVH:134-159 (no FMA contraction)
+// ------------------------------------------------------------------------------------------
+void matmul4(const float *A, const float *B, float *C) {
+  float t[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      t[i * 4 + j] = A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j] +
+                     A[i * 4 + 2] * B[2 * 4 + j] + A[i * 4 + 3] * B[3 * 4 + j];
+  memcpy(C, t, sizeof(t));
+}
+void matvec3_host(const float *M, const float v[3], float out[3]) {
+  out[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2] + M[3];
+  out[1] = M[4] * v[0] + M[5] * v[1] + M[6] * v[2] + M[7];
+  out[2] = M[8] * v[0] + M[9] * v[1] + M[10] * v[2] + M[11];
+}
+
+// per-slice constants, 64 floats, read through the scalar cache (slice index is wave-uniform)
+struct SliceConst {
+  float I2W[12];   // rows 0..2 of sliceI2W
+  float T[12];     // slice transformation
+  float A[12];     // combInvTrans = sliceW2I * Tinv * reconI2W  (RC.cu:223)
+  float Lp[9];     // linear part of A scaled to calcPSF's argument space
+  float dim[3];    // slice voxel dims (dx, dy, thickness)
+  float kx, ky, inv2s2;
+  float pad[13];
+};
+static_assert(sizeof(SliceConst) == 256, "SliceConst layout");
+
+struct VolGeom {
+  int vx, vy, vz;
+  float W2I[12];   // rows 0..2 of reconstructedW2I
+  float c0[3];     // d_PSFI2W * ((PSFsize-1)/2)  (RC.cu:172)
+};
+
+// ------------------------------------------------------------------------------------------
+// canonical PSF (bit-identical to oracle/svr_oracle.c psf_canon: IEEE fma/mul/add/div/sqrt)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float canon_abs_sin(float R) {
+  const float INV_PI = 0.318309886183790671538f;
+  const float PI_A = 3.1414794921875f;
+  const float PI_B = 0.00011315941810607910156f;
+  const float PI_C = 1.9841872589410058936e-09f;
+  float k = __builtin_rintf(R * INV_PI);
+  float r = __builtin_fmaf(k, -PI_A, R);
+  r = __builtin_fmaf(k, -PI_B, r);
+  r = __builtin_fmaf(k, -PI_C, r);
+  float s = r * r;
+  float u = 2.6083159809786593541503e-06f;
+  u = __builtin_fmaf(u, s, -0.0001981069071916863322258f);
+  u = __builtin_fmaf(u, s, 0.00833307858556509017944336f);
+  u = __builtin_fmaf(u, s, -0.166666597127914428710938f);
+  u = __builtin_fmaf(s, u * r, r);
+  return __builtin_fabsf(u);
+}
+__device__ __forceinline__ float canon_exp_neg(float a) {
+  const float LOG2E = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+  const float L2U = 0.693145751953125f;
+  const float L2L = 1.428606765330187045e-06f;
+  float d = -a;
+  float q = __builtin_rintf(d * LOG2E);
+  float s = __builtin_fmaf(q, -L2U, d);
+  s = __builtin_fmaf(q, -L2L, s);
+  float u = 0.000198527617612853646278381f;
+  u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+  u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+  u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+  u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+  u = __builtin_fmaf(u, s, 0.5f);
+  u = __builtin_fmaf(s * s, u, s) + 1.0f;
+  float r = ldexpf(u, (int)q);
+  return (a > 87.0f) ? 0.0f : r;
+}
+// calcPSF (RC.cu:112-130) on the scaled lattice coordinates
+__device__ __forceinline__ float psf_eval(float xs, float ys, float zs, float inv2s2) {
+  float q = __builtin_fmaf(ys, ys, xs * xs);
+  float R = 3.14159265359f * __fsqrt_rn(q);
+  float si = __fdiv_rn(canon_abs_sin(R), R);
+  float gz = canon_exp_neg((zs * zs) * inv2s2);
+  return (si * si) * gz;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ void matvec3(const float *M, float x, float y, float z, float &a,
+                                        float &b, float &c) {
+  a = M[0] * x + M[1] * y + M[2] * z + M[3];
+  b = M[4] * x + M[5] * y + M[6] * z + M[7];
+  c = M[8] * x + M[9] * y + M[10] * z + M[11];
+}
+
+enum { MODE_GAUSS = 0, MODE_FWD = 1, MODE_BACK = 2 };
+
+struct PsfArgs {
+  const SliceConst *sc;
+  VolGeom vg;
+  int sx, sy;               // slice grid
+  const uint32_t *list;     // pixel indices to process
+  uint32_t n;
+  const float *slices;
+  const float *mask;
+  float *psf_sums;
+  const float *scales;        // per slice
+  // gauss
+  float *recon, *volw;
+  int *voxcount;
+  // forward
+  const float *vol;
+  float *simslices, *simweights;
+  unsigned char *siminside;
+  // back
+  const float *weights, *slice_weights;
+  float *addon, *cmap;
+};
+
+// per-pixel state shared by all modes
+struct PixelState {
+  int cxi, cyi, czi;   // rounded centre voxel psfxyz (RC.cu:225-226)
+  float bx, by, bz;    // scaled residual at the centre (canonical form)
+};
+
+__device__ __forceinline__ int clampi(float f) {
+  // |centre| beyond 2^20 is out of any volume; clamp so the int arithmetic cannot overflow
+  f = fminf(fmaxf(f, -1048576.0f), 1048576.0f);
+  return (int)f;   // NaN -> 0 after the clamp's fmin/fmax semantics
+}
+
+__device__ __forceinline__ PixelState pixel_setup(const SliceConst &S, const VolGeom &vg, int px,
+                                                  int py) {
+  PixelState P;
+  float wx, wy, wz, tx, ty, tz, vx_, vy_, vz_;
+  // d_reconstructedW2I * (slicesTransformation * (sliceI2W * slicePos))  RC.cu:225
+  matvec3(S.I2W, (float)px, (float)py, 0.0f, wx, wy, wz);
+  matvec3(S.T, wx, wy, wz, tx, ty, tz);
+  matvec3(vg.W2I, tx, ty, tz, vx_, vy_, vz_);
+  float cx = roundf(vx_), cy = roundf(vy_), cz = roundf(vz_);
+  P.cxi = clampi(cx); P.cyi = clampi(cy); P.czi = clampi(cz);
+  double d0 = (double)S.A[0] * cx + (double)S.A[1] * cy + (double)S.A[2] * cz + (double)S.A[3] - (double)(float)px;
+  double d1 = (double)S.A[4] * cx + (double)S.A[5] * cy + (double)S.A[6] * cz + (double)S.A[7] - (double)(float)py;
+  double d2 = (double)S.A[8] * cx + (double)S.A[9] * cy + (double)S.A[10] * cz + (double)S.A[11] - 0.0;
+  P.bx = (float)((d0 * S.dim[0] - vg.c0[0]) * S.kx);
+  P.by = (float)((d1 * S.dim[1] - vg.c0[1]) * S.ky);
+  P.bz = (float)(d2 * S.dim[2] - vg.c0[2]);
+  return P;
+}
+
+// hot per-slice constants held in registers (SGPRs: the slice index is wave-uniform)
+struct RowConst {
+  float Lp[9];
+  float inv2s2;
+};
+__device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
+  RowConst R;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R.Lp[i] = S.Lp[i];
+  R.inv2s2 = S.inv2s2;
+  return R;
+}
+
+// Phase 1: lane = one (y,z) row of the current quarter (4 z-planes x 16 y); walks the 16
+// x-taps sequentially with the epsilon-skip (RC.cu:233-239).  out[x] = psf, or -1 if skipped.
+__device__ __forceinline__ void eval_row(const RowConst &S, const PixelState &P, int lane, int q,
+                                         float out[16]) {
+  const float fz = (float)(4 * q + (lane >> 4) - PSF_CENTRE);
+  const float fy = (float)((lane & 15) - PSF_CENTRE);
+  const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, P.bx));
+  const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, P.by));
+  const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, P.bz));
+  float old = FLT_MAX;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) {
+    const float fx = (float)(x - PSF_CENTRE);
+    float xs = __builtin_fmaf(S.Lp[0], fx, rowx);
+    float ys = __builtin_fmaf(S.Lp[3], fx, rowy);
+    float zs = __builtin_fmaf(S.Lp[6], fx, rowz);
+    float v = psf_eval(xs, ys, zs, S.inv2s2);
+    bool skip = __builtin_fabsf(old - v) <= PSF_EPS_F;   // NaN compares false -> processed
+    out[x] = skip ? -1.0f : v;
+    old = skip ? old : v;
+  }
+}
+
+__device__ __forceinline__ uint32_t sat0(int i) { return (uint32_t)max(i, 0); }  // float->uint saturation
+
+template <int MODE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void psf_kernel(PsfArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[WAVES_PER_BLOCK][64 * LDS_ROW];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const uint32_t pi = blockIdx.x * WAVES_PER_BLOCK + wave;
+  if (pi >= a.n) return;
+  const uint32_t idx = __builtin_amdgcn_readfirstlane(a.list[pi]);
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+  const uint32_t sl = idx / n2;
+  const uint32_t rem = idx - sl * n2;
+  const int py = (int)(rem / (uint32_t)a.sx);
+  const int px = (int)(rem - (uint32_t)py * (uint32_t)a.sx);
+  const SliceConst &S = a.sc[sl];
+  const VolGeom &vg = a.vg;
+  const PixelState P = pixel_setup(S, vg, px, py);
+  const RowConst RC = load_row_const(S);
+  float *my = lds[wave];
+
+  float s = a.slices[idx];
+  float sume;
+  if (MODE == MODE_GAUSS) {
+    // pass 1 (RC.cu:228-258): sume over processed, in-bounds taps (truncating cast, no mask)
+    double acc = 0.0;
+    for (int q = 0; q < 4; ++q) {
+      float out[16];
+      eval_row(RC, P, lane, q, out);
+      const uint32_t az = sat0(P.czi + 4 * q + (lane >> 4) - PSF_CENTRE);
+      const uint32_t ay = sat0(P.cyi + (lane & 15) - PSF_CENTRE);
+      const bool rowin = az < (uint32_t)vg.vz && ay < (uint32_t)vg.vy;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const uint32_t ax = sat0(P.cxi + x - PSF_CENTRE);
+        const bool use = rowin && ax < (uint32_t)vg.vx && !(out[x] < 0.0f);
+        acc += use ? (double)out[x] : 0.0;
+      }
+    }
+    sume = (float)wave_sum(acc);
+    if (!(sume > 0.5f)) return;          // also drops NaN (RC.cu:251-258)
+    if (lane == 0) a.psf_sums[idx] = sume;
+    s = s * a.scales[sl];                // RC.cu:201
+  } else {
+    sume = a.psf_sums[idx];
+  }
+
+  float f0 = 0.0f, f1 = 0.0f;   // FWD: sim, weight partials.  BACK: (w*sw*e)/sume, (w*sw)/sume
+  if (MODE == MODE_BACK) {
+    float w = a.weights[idx];
+    float ss = a.simslices[idx];
+    float e = s * a.scales[sl];
+    e = (ss > 0.0f) ? (e - ss) : 0.0f;   // RC.cu:444-447
+    float ws = w * a.slice_weights[sl];
+    f1 = ws / sume;
+    f0 = f1 * e;
+  }
+  const float rsume = 1.0f / sume;
+  bool hit = false;
+  const int x2 = lane & 15, r4 = lane >> 4;
+  const uint32_t ax = sat0(P.cxi + x2 - PSF_CENTRE);
+  const bool xin = ax < (uint32_t)vg.vx;
+
+  for (int q = 0; q < 4; ++q) {
+    {
+      float out[16];
+      eval_row(RC, P, lane, q, out);
+      float4 *dst = reinterpret_cast<float4 *>(my + lane * LDS_ROW);
+      dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+      dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+      dst[2] = make_float4(out[8], out[9], out[10], out[11]);
+      dst[3] = make_float4(out[12], out[13], out[14], out[15]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Phase 2: lane = (x, 4 consecutive y rows): coalesced 4 x 64 B volume accesses
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int row = 4 * j + r4;
+      const float val = my[row * LDS_ROW + x2];
+      const uint32_t az = sat0(P.czi + 4 * q + (row >> 4) - PSF_CENTRE);
+      const uint32_t ay = sat0(P.cyi + (row & 15) - PSF_CENTRE);
+      const bool ok = xin && ay < (uint32_t)vg.vy && az < (uint32_t)vg.vz && !(val < 0.0f);
+      if (ok) {
+        const uint32_t vi = ax + ay * (uint32_t)vg.vx + az * (uint32_t)(vg.vx * vg.vy);
+        if (a.mask[vi] != 0.0f) {
+          if (MODE == MODE_GAUSS) {
+            float p = val / sume;                       // RC.cu:278
+            unsafeAtomicAdd(a.volw + vi, p);
+            unsafeAtomicAdd(a.recon + vi, p * s);
+          } else if (MODE == MODE_FWD) {
+            float p = val * rsume;
+            f0 += p * a.vol[vi];
+            f1 += p;
+          } else {
+            unsafeAtomicAdd(a.addon + vi, val * f0);
+            unsafeAtomicAdd(a.cmap + vi, val * f1);
+          }
+          hit = true;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (MODE == MODE_GAUSS) {
+    if (__ballot(hit) != 0ull && lane == 0) a.voxcount[idx] = 1;   // RC.cu:291-294
+  } else if (MODE == MODE_FWD) {
+    float sim = wave_sum(f0), w = wave_sum(f1);
+    bool inside = __ballot(hit) != 0ull;
+    if (lane == 0 && w > 0.0f) {                                    // RC.cu:398-403
+      a.simslices[idx] = sim / w;
+      a.simweights[idx] = w;
+      a.siminside[idx] = inside ? 1 : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// list compaction
+// ------------------------------------------------------------------------------------------
+// keep pixel i if slices[i] != -1 (and psf_sums[i] != 0 when psf_sums given)
+__global__ void k_compact(const float *slices, const float *psf_sums, uint32_t n, uint32_t *list,
+                          uint32_t *counter) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool keep = false;
+  if (i < n) {
+    keep = slices[i] != -1.0f;
+    if (keep && psf_sums) keep = psf_sums[i] != 0.0f;
+  }
+  unsigned long long b = __ballot(keep);
+  int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == 0 && b) base = atomicAdd(counter, (uint32_t)__popcll(b));
+  base = __shfl(base, 0, 64);
+  if (keep) list[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+}
+
+// ------------------------------------------------------------------------------------------
+// block reduction helpers (256 threads)
+// ------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double v[K], const int op[K], double *out) {
+  __shared__ double sm[4][K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      double y = __shfl_xor(x, o, 64);
+      x = op[k] == 0 ? x + y : (op[k] == 1 ? fmin(x, y) : fmax(x, y));
+    }
+    v[k] = x;
+  }
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    for (int k = 0; k < K; ++k) sm[w][k] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < K; ++k) {
+      double x = sm[0][k];
+      for (int i = 1; i < 4; ++i) {
+        double y = sm[i][k];
+        x = op[k] == 0 ? x + y : (op[k] == 1 ? fmin(x, y) : fmax(x, y));
+      }
+      out[k] = x;
+    }
+  }
+}
+
+// sums partial[(sl*chunks + c)*K + k] over c (per slice) -> per_slice[sl*K + k]
+__global__ void k_reduce_chunks(const double *partial, int ns, int chunks, int K, int opmask_min,
+                                int opmask_max, double *per_slice) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns * K) return;
+  int sl = i / K, k = i - sl * K;
+  bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
+  double x = partial[((size_t)sl * chunks) * K + k];
+  for (int c = 1; c < chunks; ++c) {
+    double y = partial[((size_t)sl * chunks + c) * K + k];
+    x = mn ? fmin(x, y) : (mx ? fmax(x, y) : x + y);
+  }
+  per_slice[i] = x;
+}
+// reduces per_slice[sl*K + k] over slices -> out[k]   (single block, 256 threads)
+__global__ void k_reduce_slices(const double *per_slice, int ns, int K, int opmask_min,
+                                int opmask_max, double *out) {
+  __shared__ double sm[256];
+  for (int k = 0; k < K; ++k) {
+    bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
+    double x = mn ? INFINITY : (mx ? -INFINITY : 0.0);
+    for (int s = threadIdx.x; s < ns; s += 256) {
+      double y = per_slice[(size_t)s * K + k];
+      x = mn ? fmin(x, y) : (mx ? fmax(x, y) : x + y);
+    }
+    sm[threadIdx.x] = x;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        double y = sm[threadIdx.x + o];
+        double z = sm[threadIdx.x];
+        sm[threadIdx.x] = mn ? fmin(z, y) : (mx ? fmax(z, y) : z + y);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = sm[0];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// EM kernels over the slice grid: grid = (chunks, ns), 256 threads, CHUNK_PIX pixels per block
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float G_(float x, float s) {   // RC.cu:62-65
+  return SVR_STEP * expf(-x * x / (2.0f * s)) / (sqrtf(6.28f * s));
+}
+
+// InitializeEMValuesKernel RC.cu:3241-3267
+__global__ void k_init_em(const float *slices, float *weights, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) weights[i] = (slices[i] != -1.0f) ? 1.0f : 0.0f;
+}
+
+// EStepKernel3D_tex RC.cu:2766-2813 fused with the slice-potential transform RC.cu:2816-2841
+__global__ __launch_bounds__(256) void k_estep(const float *slices, const float *simslices,
+                                               const float *simweights, const float *scales, float m_,
+                                               float sigma_, float mix_, int n2, float *weights,
+                                               double *partial) {
+  const int sl = blockIdx.y;
+  const float scale = scales[sl];
+  const float m = m_ * SVR_STEP;   // M_ RC.cu:67-70
+  double v[2] = {0.0, 0.0};
+  const size_t base = (size_t)sl * n2;
+  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
+       i += 256) {
+    float s = slices[base + i], sw = simweights[base + i];
+    float w = 0.0f;                                    // weights are cleared first RC.cu:2881
+    if (!(s == -1.0f || sw <= 0.0f)) {
+      float sliceVal = s * scale;
+      sliceVal -= simslices[base + i];
+      float g = G_(sliceVal, sigma_);
+      w = (g * mix_) / (g * mix_ + m * (1.0f - mix_));
+    }
+    weights[base + i] = w;
+    if ((double)sw > 0.99) {                           // transformSlicePotential RC.cu:2822
+      double t = 1.0 - (double)w;
+      v[0] += (double)(float)(t * t);
+      v[1] += 1.0;
+    }
+  }
+  const int op[2] = {0, 0};
+  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
+}
+// RC.cu:2903-2910
+__global__ void k_potential_finish(const double *per_slice, int ns, float *potential) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  double a = per_slice[2 * s], b = per_slice[2 * s + 1];
+  potential[s] = (b > 0) ? sqrtf((float)a / (float)b) : -1.0f;
+}
+
+// transformMStep3DNoBias RC.cu:2966-3000; reduce identity (0,0,0,0,0) RC.cu:3103
+__global__ __launch_bounds__(256) void k_mstep(const float *slices, const float *weights,
+                                               const float *simslices, const float *simweights,
+                                               const float *scales, int n2, double *partial) {
+  const int sl = blockIdx.y;
+  const float scale = scales[sl];
+  double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const size_t base = (size_t)sl * n2;
+  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
+       i += 256) {
+    float s = slices[base + i];
+    if (s != -1.0f && simweights[base + i] > 0.99f) {
+      float w = weights[base + i];
+      float e = (s * scale) - simslices[base + i];
+      v[0] += (double)(e * e * w);
+      v[1] += (double)w;
+      v[2] += 1.0;
+      v[3] = fmin(v[3], (double)e);
+      v[4] = fmax(v[4], (double)e);
+    }
+  }
+  const int op[5] = {0, 0, 0, 1, 2};
+  block_reduce_store<5>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 5);
+}
+
+// transformScalenoBias RC.cu:3142-3165
+__global__ __launch_bounds__(256) void k_scale(const float *slices, const float *weights,
+                                               const float *simslices, const float *simweights, int n2,
+                                               double *partial) {
+  const int sl = blockIdx.y;
+  double v[2] = {0.0, 0.0};
+  const size_t base = (size_t)sl * n2;
+  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
+       i += 256) {
+    float s = slices[base + i];
+    if (!(s == -1.0f || simweights[base + i] <= 0.99f)) {
+      float w = weights[base + i], ss = simslices[base + i];
+      v[0] += (double)(w * s * ss);
+      v[1] += (double)(w * s * s);
+    }
+  }
+  const int op[2] = {0, 0};
+  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
+}
+// RC.cu:3229-3236
+__global__ void k_scale_finish(const double *per_slice, int ns, float *scale_vec) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  float num = (float)per_slice[2 * s], den = (float)per_slice[2 * s + 1];
+  scale_vec[s] = (den != 0.0f) ? num / den : 1.0f;
+}
+
+// transformRS RC.cu:2243-2265
+__global__ __launch_bounds__(256) void k_robust(const float *slices, const unsigned char *siminside,
+                                                const float *simslices, const float *simweights, int n2,
+                                                double *partial) {
+  const int sl = blockIdx.y;
+  double v[2] = {0.0, 0.0};
+  const size_t base = (size_t)sl * n2;
+  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
+       i += 256) {
+    float s = slices[base + i];
+    if (s != -1.0f && siminside[base + i] == 1 && (double)simweights[base + i] > 0.99) {
+      float sval = s - simslices[base + i];
+      v[0] += (double)(sval * sval);
+      v[1] += 1.0;
+    }
+  }
+  const int op[2] = {0, 0};
+  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
+}
+
+// ScaleVolumeKernel RC.cu:3386-3413
+__global__ __launch_bounds__(256) void k_scalevol(const float *slices, const float *weights,
+                                                  const float *simslices, const float *simweights,
+                                                  const float *slice_weights, int n2, double *partial) {
+  const int sl = blockIdx.y;
+  const float slicew = slice_weights[sl];
+  double v[2] = {0.0, 0.0};
+  const size_t base = (size_t)sl * n2;
+  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
+       i += 256) {
+    float s = slices[base + i];
+    if (s == -1.0f) continue;
+    if ((double)simweights[base + i] <= 0.99) continue;
+    float ss = simslices[base + i], w = weights[base + i];
+    v[0] += (double)(w * slicew * s * ss);
+    v[1] += (double)(w * slicew * ss * ss);
+  }
+  const int op[2] = {0, 0};
+  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
+}
+
+// per-slice any(siminside == 1)  (thrust::count per slice, RC.cu:2742-2752)
+__global__ __launch_bounds__(256) void k_slice_inside(const unsigned char *siminside, int n2,
+                                                      unsigned char *slice_inside) {
+  const int sl = blockIdx.x;
+  int any = 0;
+  for (int i = threadIdx.x; i < n2; i += 256) any |= (siminside[(size_t)sl * n2 + i] == 1);
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) slice_inside[sl] = any ? 1 : 0;
+}
+// count_if(sliceVoxel_count > 0) RC.cu:2472-2474
+__global__ void k_count_positive(const int *v, size_t n, unsigned long long *out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool p = i < n && v[i] > 0;
+  unsigned long long b = __ballot(p);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+}
+// RestoreSliceIntensitiesKernel RC.cu:3349-3367
+__global__ void k_restore(float *slices, const float *stack_factors, const int *stack_index, int n2,
+                          size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float factor = stack_factors[stack_index[i / n2]];
+  float s = slices[i];
+  if (s > 0) slices[i] = s / factor;
+}
+
+// ------------------------------------------------------------------------------------------
+// volume kernels
+// ------------------------------------------------------------------------------------------
+// equalizeVol RC.cu:2312-2327
+__global__ void k_equalize(float *recon, const float *volw, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float b = volw[i];
+  float a = recon[i];
+  recon[i] = (b != 0) ? a / b : a;
+}
+// AdaptiveRegularizationPrep RC.cu:1944-1969: recon is left untouched (it is the regulariser's
+// `original`, RC.cu:2138-2141); the updated volume goes to snap.
+__global__ void k_reg_prep(int adaptive, float alpha, const float *recon, float *addon, float *cmap,
+                           float min_i, float max_i, float *snap, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float ad = addon[i];
+  if (!adaptive) {
+    float c = cmap[i];
+    if (c != 0) {
+      ad = ad / c;
+      addon[i] = ad;
+      cmap[i] = 1.0f;
+    }
+  }
+  float r = recon[i] + ad * alpha;
+  if ((double)r < (double)min_i * 0.9) r = (float)((double)min_i * 0.9);
+  if ((double)r > (double)max_i * 1.1) r = (float)((double)max_i * 1.1);
+  snap[i] = r;
+}
+
+__constant__ int c_dirs[13][3] = {{1, 0, -1}, {0, 1, -1}, {1, 1, -1}, {1, -1, -1}, {1, 0, 0},
+                                  {0, 1, 0},  {1, 1, 0},  {1, -1, 0}, {1, 0, 1},   {0, 1, 1},
+                                  {1, 1, 1},  {1, -1, 1}, {0, 0, 1}};   // RC.cu:666-680
+
+__device__ __forceinline__ float reg_b(float f, float sqf, float o_p, float o_p2, float c_p, float c_p2,
+                                       float delta) {
+  // AdaptiveRegularization1 RC.cu:2046-2057
+  if (c_p <= 0 || c_p2 <= 0) return 0.0f;
+  float diff = (o_p2 - o_p) * sqf / delta;
+  return (float)((double)f / sqrt(1.0 + (double)(diff * diff)));
+}
+// AdaptiveRegularizationKernel RC.cu:2061-2117; neighbours read `snap` (post-Prep snapshot)
+__global__ __launch_bounds__(256) void k_regularize(int vx, int vy, int vz, float delta, float alpha,
+                                                    float lambda, const float *snap,
+                                                    const float *original, const float *cmap,
+                                                    float *out) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int z = blockIdx.z;
+  if (x >= vx || y >= vy) return;
+  size_t p = (size_t)x + (size_t)y * vx + (size_t)z * vx * vy;
+  float val = 0, valW = 0, sum = 0;
+  float o_p = original[p], c_p = cmap[p], r_p = snap[p];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) {
+    const int dx = c_dirs[i][0], dy = c_dirs[i][1], dz = c_dirs[i][2];
+    const float f = 1.0f / (float)(abs(dx) + abs(dy) + abs(dz));   // RC.cu:682-692
+    const float sqf = sqrtf(f);
+    int x2 = x + dx, y2 = y + dy, z2 = z + dz;
+    bool in2 = x2 >= 0 && x2 < vx && y2 >= 0 && y2 < vy && z2 >= 0 && z2 < vz;
+    float o2 = 0, c2 = 0;
+    if (in2) {
+      size_t p2 = (size_t)x2 + (size_t)y2 * vx + (size_t)z2 * vx * vy;
+      o2 = original[p2];
+      c2 = cmap[p2];
+      float bi = reg_b(f, sqf, o_p, o2, c_p, c2, delta);
+      val += bi * snap[p2] * c2;
+      valW += bi * c2;
+      sum += bi;
+    }
+    int x3 = x - dx, y3 = y - dy, z3 = z - dz;
+    bool in3 = x3 >= 0 && x3 < vx && y3 >= 0 && y3 < vy && z3 >= 0 && z3 < vz;
+    if (in3 && in2) {
+      size_t p3 = (size_t)x3 + (size_t)y3 * vx + (size_t)z3 * vx * vy;
+      float o3 = original[p3], c3 = cmap[p3];
+      float bi = reg_b(f, sqf, o3, o2, c3, c2, delta);   // (pos3, pos2): RC.cu:2095
+      val += bi * snap[p3] * c3;
+      valW += bi * c3;
+      sum += bi;
+    }
+  }
+  val -= sum * r_p * c_p;
+  valW -= sum * c_p;
+  float k = alpha * lambda / (delta * delta);
+  val = r_p * c_p + k * val;
+  valW = c_p + k * valW;
+  out[p] = (valW > 0.0f) ? val / valW : 0.0f;
+}
+// maskVolumeKernel RC.cu:3313-3326
+__global__ void k_mask_volume(float *recon, const float *mask, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && mask[i] == 0) recon[i] = -1.0f;
+}
+// scaleVolumeKernel RC.cu:3415-3423
+__global__ void k_scale_volume(float *recon, float scale, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && recon[i] > 0) recon[i] = recon[i] * scale;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// context
+// ==========================================================================================
+struct svr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  bool disable_bias = true, debug_gpu = false;
+
+  // volume
+  uint32_t vx = 0, vy = 0, vz = 0;
+  float vdim[3] = {1, 1, 1};
+  size_t nv = 0;
+  float *d_recon_volw = nullptr;   // recon | volw
+  float *d_addon_cmap = nullptr;   // addon | cmap
+  float *d_mask = nullptr, *d_snap = nullptr, *d_recon_new = nullptr;
+  bool have_mask = false;
+
+  // slice grid
+  uint32_t sx = 0, sy = 0, ns = 0;
+  size_t np = 0;
+  float *d_slices = nullptr, *d_weights = nullptr, *d_simslices = nullptr, *d_simweights = nullptr,
+        *d_psf_sums = nullptr;
+  unsigned char *d_siminside = nullptr;
+  int *d_voxcount = nullptr;
+  bool have_slices = false;
+  float *d_scales = nullptr, *d_slice_weights = nullptr, *d_scales_host_copy = nullptr,
+        *d_tmp_ns = nullptr;
+  unsigned char *d_slice_inside = nullptr;
+  std::vector<float> h_scales, h_slice_weights;   // RC.cu:1345-1346
+  bool have_scales = false;
+
+  // geometry
+  std::vector<float> slice_dims;   // ns*3
+  std::vector<float> mI2W, mW2I, mT, mTinv;
+  float reconI2W[16], reconW2I[16];
+  float psf_c0[3] = {0, 0, 0};
+  float quality_factor = 1.0f;
+  bool have_dims = false, have_mats = false, have_psf = false, sc_dirty = true;
+  SliceConst *d_sc = nullptr;
+
+  // work lists
+  uint32_t *d_active = nullptr, *d_psf_list = nullptr, *d_counter = nullptr;
+  uint32_t n_active = 0, n_psf = 0;
+  bool psf_list_valid = false;
+
+  // reductions
+  double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
+  int chunks = 0;
+
+  // timers
+  bool timers = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double t_ms[SVR_T_COUNT] = {0};
+  long t_n[SVR_T_COUNT] = {0};
+
+  float *recon() { return d_recon_volw; }
+  float *volw() { return d_recon_volw + nv; }
+  float *addon() { return d_addon_cmap; }
+  float *cmap() { return d_addon_cmap + nv; }
+};
+
+namespace {
+
+int fail(svr_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+#define KCHK(name)                                                                          \
+  do {                                                                                      \
+    hipError_t e_ = hipGetLastError();                                                      \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, (int)e_, std::string(name) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+#define NEED(cond, what)                                                                    \
+  do {                                                                                      \
+    if (!(cond)) return fail(ctx, SVR_E_STATE, std::string(__func__) + ": " + what);      \
+  } while (0)
+
+template <class T>
+void free_dev(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+struct ScopedTimer {
+  svr_ctx *c;
+  int which;
+  ScopedTimer(svr_ctx *c_, int w) : c(c_), which(w) {
+    if (c->timers) (void)hipEventRecord(c->ev0, c->stream);
+  }
+  void stop() {
+    if (c->timers) {
+      (void)hipEventRecord(c->ev1, c->stream);
+      (void)hipEventSynchronize(c->ev1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+      c->t_ms[which] += ms;
+      c->t_n[which] += 1;
+    }
+  }
+};
+
+inline unsigned nblk(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
+
+void free_volume(svr_ctx *c) {
+  free_dev(c->d_recon_volw);
+  free_dev(c->d_addon_cmap);
+  free_dev(c->d_snap);
+  free_dev(c->d_recon_new);
+}
+void free_slices(svr_ctx *c) {
+  free_dev(c->d_slices); free_dev(c->d_weights); free_dev(c->d_simslices); free_dev(c->d_simweights);
+  free_dev(c->d_psf_sums); free_dev(c->d_siminside); free_dev(c->d_voxcount); free_dev(c->d_scales);
+  free_dev(c->d_slice_weights); free_dev(c->d_scales_host_copy); free_dev(c->d_tmp_ns);
+  free_dev(c->d_slice_inside); free_dev(c->d_sc); free_dev(c->d_active); free_dev(c->d_psf_list);
+  free_dev(c->d_partial); free_dev(c->d_per_slice);
+}
+
+// builds the per-slice constants (host float math, literal order) and uploads them
+int prepare_slice_consts(svr_ctx *ctx) {
+  NEED(ctx->have_dims && ctx->have_mats && ctx->have_slices, "slice dims / matrices / storage not set");
+  if (!ctx->sc_dirty) return SVR_OK;
+  std::vector<SliceConst> h(ctx->ns);
+  for (uint32_t s = 0; s < ctx->ns; ++s) {
+    SliceConst &S = h[s];
+    memset(&S, 0, sizeof(S));
+    memcpy(S.I2W, &ctx->mI2W[16 * s], 12 * sizeof(float));
+    memcpy(S.T, &ctx->mT[16 * s], 12 * sizeof(float));
+    float tmp[16], A[16];
+    matmul4(&ctx->mW2I[16 * s], &ctx->mTinv[16 * s], tmp);   // RC.cu:223 (left to right)
+    matmul4(tmp, ctx->reconI2W, A);
+    memcpy(S.A, A, 12 * sizeof(float));
+    for (int k = 0; k < 3; ++k) S.dim[k] = ctx->slice_dims[3 * s + k];
+    S.kx = S.dim[0] / 2.3548f;
+    S.ky = S.dim[1] / 2.3548f;
+    float sigmaz = S.dim[2] / 2.3548f;   // RC.cu:114
+    S.inv2s2 = 1.0f / (2.0f * sigmaz * sigmaz);
+    for (int j = 0; j < 3; ++j) {
+      S.Lp[0 * 3 + j] = (A[0 * 4 + j] * S.dim[0]) * S.kx;
+      S.Lp[1 * 3 + j] = (A[1 * 4 + j] * S.dim[1]) * S.ky;
+      S.Lp[2 * 3 + j] = A[2 * 4 + j] * S.dim[2];
+    }
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_sc, h.data(), h.size() * sizeof(SliceConst), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->sc_dirty = false;
+  return SVR_OK;
+}
+
+int build_list(svr_ctx *ctx, bool with_psf) {
+  HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+  uint32_t *list = with_psf ? ctx->d_psf_list : ctx->d_active;
+  hipLaunchKernelGGL(k_compact, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices,
+                     with_psf ? ctx->d_psf_sums : (const float *)nullptr, (uint32_t)ctx->np, list, ctx->d_counter);
+  KCHK("k_compact");
+  uint32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (with_psf) { ctx->n_psf = n; ctx->psf_list_valid = true; }
+  else ctx->n_active = n;
+  return SVR_OK;
+}
+
+PsfArgs make_args(svr_ctx *ctx) {
+  PsfArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sc = ctx->d_sc;
+  a.vg.vx = (int)ctx->vx; a.vg.vy = (int)ctx->vy; a.vg.vz = (int)ctx->vz;
+  memcpy(a.vg.W2I, ctx->reconW2I, 12 * sizeof(float));
+  memcpy(a.vg.c0, ctx->psf_c0, 3 * sizeof(float));
+  a.sx = (int)ctx->sx; a.sy = (int)ctx->sy;
+  a.slices = ctx->d_slices; a.mask = ctx->d_mask; a.psf_sums = ctx->d_psf_sums;
+  a.scales = ctx->d_scales;
+  a.recon = ctx->recon(); a.volw = ctx->volw(); a.voxcount = ctx->d_voxcount;
+  a.vol = ctx->recon(); a.simslices = ctx->d_simslices; a.simweights = ctx->d_simweights;
+  a.siminside = ctx->d_siminside;
+  a.weights = ctx->d_weights; a.slice_weights = ctx->d_slice_weights;
+  a.addon = ctx->addon(); a.cmap = ctx->cmap();
+  return a;
+}
+
+int ready(svr_ctx *ctx) {
+  NEED(ctx->nv > 0, "reconstruction volume not initialised");
+  NEED(ctx->have_mask, "mask not set");
+  NEED(ctx->have_slices, "slices not filled");
+  NEED(ctx->have_scales, "scale vector not set");
+  NEED(ctx->have_psf, "generatePSFVolume not called");
+  return prepare_slice_consts(ctx);
+}
+
+int ensure_psf_list(svr_ctx *ctx) {
+  if (!ctx->psf_list_valid) return build_list(ctx, true);
+  return SVR_OK;
+}
+
+// reduce partial[ns*chunks][K] -> per_slice[ns][K] (+ optionally -> d_out[K])
+int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
+  hipLaunchKernelGGL(k_reduce_chunks, dim3(nblk((size_t)ctx->ns * K)), dim3(256), 0, ctx->stream,
+                     ctx->d_partial, (int)ctx->ns, ctx->chunks, K, mn, mx, ctx->d_per_slice);
+  KCHK("k_reduce_chunks");
+  if (global) {
+    hipLaunchKernelGGL(k_reduce_slices, dim3(1), dim3(256), 0, ctx->stream, ctx->d_per_slice, (int)ctx->ns, K,
+                       mn, mx, ctx->d_out);
+    KCHK("k_reduce_slices");
+  }
+  return SVR_OK;
+}
+
+int upload_ns(svr_ctx *ctx, float *dst, const float *src) {
+  HIPCHK(hipMemcpyAsync(dst, src, ctx->ns * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" {
+
+int svr_create(int device, svr_ctx **out) {
+  if (!out) return SVR_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return (int)e;
+  if (device < 0 || device >= n) return SVR_E_ARG;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return (int)e;
+  svr_ctx *ctx = new svr_ctx();
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete ctx; return (int)e; }
+  ctx->own_stream = true;
+  (void)hipEventCreate(&ctx->ev0);
+  (void)hipEventCreate(&ctx->ev1);
+  if (hipMalloc(&ctx->d_counter, 64) != hipSuccess || hipMalloc(&ctx->d_out, 16 * sizeof(double)) != hipSuccess) {
+    svr_destroy(ctx);
+    return (int)hipErrorOutOfMemory;
+  }
+  *out = ctx;
+  return SVR_OK;
+}
+
+void svr_destroy(svr_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  free_volume(ctx);
+  free_slices(ctx);
+  free_dev(ctx->d_mask);
+  free_dev(ctx->d_counter);
+  free_dev(ctx->d_out);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *svr_last_error(const svr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu) {
+  if (!ctx) return SVR_E_ARG;
+  if (!disable_bias_correction)
+    return fail(ctx, SVR_E_ARG, "bias correction path not built (CLI default is disabled, reconstruction.cc:121,202)");
+  ctx->disable_bias = true;
+  ctx->debug_gpu = debug_gpu != 0;
+  return SVR_OK;
+}
+
+int svr_set_stream(svr_ctx *ctx, void *hip_stream) {
+  if (!ctx) return SVR_E_ARG;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return SVR_OK;
+}
+
+int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const float dim[3],
+                                   const float *data, float sigma_bias) {
+  if (!ctx || !size || !dim) return SVR_E_ARG;
+  (void)sigma_bias;
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t nv = (size_t)size[0] * size[1] * size[2];
+  if (nv == 0 || nv >= 0xFFFFFFFFull) return fail(ctx, SVR_E_ARG, "volume size out of range");
+  free_volume(ctx);
+  ctx->vx = size[0]; ctx->vy = size[1]; ctx->vz = size[2];
+  memcpy(ctx->vdim, dim, 3 * sizeof(float));
+  ctx->nv = nv;
+  HIPCHK(hipMalloc(&ctx->d_recon_volw, 2 * nv * sizeof(float)));
+  HIPCHK(hipMalloc(&ctx->d_addon_cmap, 2 * nv * sizeof(float)));
+  HIPCHK(hipMalloc(&ctx->d_snap, nv * sizeof(float)));
+  HIPCHK(hipMalloc(&ctx->d_recon_new, nv * sizeof(float)));
+  HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * nv * sizeof(float), ctx->stream));   // RC.cu:1199-1229
+  HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * nv * sizeof(float), ctx->stream));
+  if (data) HIPCHK(hipMemcpyAsync(ctx->recon(), data, nv * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const float *data,
+                 float sigma_bias) {
+  if (!ctx || !size || !data) return SVR_E_ARG;
+  (void)dim; (void)sigma_bias;   // the blurred maskC_ (RC.cu:1129-1157) only feeds NormaliseBias
+  NEED(ctx->nv > 0, "InitReconstructionVolume first");
+  if ((size_t)size[0] * size[1] * size[2] != ctx->nv || size[0] != ctx->vx || size[1] != ctx->vy)
+    return fail(ctx, SVR_E_ARG, "mask grid differs from the reconstruction volume");
+  free_dev(ctx->d_mask);
+  HIPCHK(hipMalloc(&ctx->d_mask, ctx->nv * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(ctx->d_mask, data, ctx->nv * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->have_mask = true;
+  return SVR_OK;
+}
+
+int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float dim[3]) {
+  if (!ctx || !size) return SVR_E_ARG;
+  (void)dim;
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t np = (size_t)size[0] * size[1] * size[2];
+  if (np == 0 || np >= 0xFFFFFFFFull) return fail(ctx, SVR_E_ARG, "slice grid size out of range");
+  free_slices(ctx);
+  ctx->sx = size[0]; ctx->sy = size[1]; ctx->ns = size[2];
+  ctx->np = np;
+  ctx->have_slices = false; ctx->have_scales = false; ctx->have_dims = false; ctx->have_mats = false;
+  ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->n_active = ctx->n_psf = 0;
+  const size_t fb = np * sizeof(float);
+  HIPCHK(hipMalloc(&ctx->d_slices, fb));
+  HIPCHK(hipMalloc(&ctx->d_weights, fb));
+  HIPCHK(hipMalloc(&ctx->d_simslices, fb));
+  HIPCHK(hipMalloc(&ctx->d_simweights, fb));
+  HIPCHK(hipMalloc(&ctx->d_psf_sums, fb));
+  HIPCHK(hipMalloc(&ctx->d_siminside, np));
+  HIPCHK(hipMalloc(&ctx->d_voxcount, np * sizeof(int)));
+  HIPCHK(hipMalloc(&ctx->d_active, np * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&ctx->d_psf_list, np * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&ctx->d_scales, ctx->ns * sizeof(float)));
+  HIPCHK(hipMalloc(&ctx->d_slice_weights, ctx->ns * sizeof(float)));
+  HIPCHK(hipMalloc(&ctx->d_scales_host_copy, ctx->ns * sizeof(float)));
+  HIPCHK(hipMalloc(&ctx->d_tmp_ns, ctx->ns * sizeof(float)));
+  HIPCHK(hipMalloc(&ctx->d_slice_inside, ctx->ns));
+  HIPCHK(hipMalloc(&ctx->d_sc, ctx->ns * sizeof(SliceConst)));
+  ctx->chunks = (int)(((size_t)ctx->sx * ctx->sy + CHUNK_PIX - 1) / CHUNK_PIX);
+  HIPCHK(hipMalloc(&ctx->d_partial, (size_t)ctx->ns * ctx->chunks * 5 * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_per_slice, (size_t)ctx->ns * 5 * sizeof(double)));
+  // RC.cu:1555-1568: everything cleared once at allocation (v_PSF_sums is never cleared again)
+  HIPCHK(hipMemsetAsync(ctx->d_slices, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_weights, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_simslices, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_simweights, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_psf_sums, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_siminside, 0, np, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_voxcount, 0, np * sizeof(int), ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_fill_slices(svr_ctx *ctx, const float *sdata, const int *sizes_x, const int *sizes_y) {
+  if (!ctx || !sdata) return SVR_E_ARG;
+  (void)sizes_x; (void)sizes_y;   // only used by the reference's dead code (RC.cu:3252-3253)
+  NEED(ctx->np > 0, "initStorageVolumes first");
+  HIPCHK(hipMemcpyAsync(ctx->d_slices, sdata, ctx->np * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  ctx->have_slices = true;
+  ctx->psf_list_valid = false;
+  return build_list(ctx, false);
+}
+
+int svr_set_slice_dims(svr_ctx *ctx, const float *slice_dims, float quality_factor) {
+  if (!ctx || !slice_dims) return SVR_E_ARG;
+  NEED(ctx->ns > 0, "initStorageVolumes first");
+  ctx->slice_dims.assign(slice_dims, slice_dims + 3 * (size_t)ctx->ns);
+  ctx->quality_factor = quality_factor;   // only sizes the (unused) finite-support dim, RC.cu:772-784
+  ctx->have_dims = true;
+  ctx->sc_dirty = true;
+  return SVR_OK;
+}
+
+int svr_set_slice_matrices(svr_ctx *ctx, const float *T, const float *Tinv, const float *i2w_init,
+                           const float *w2i_init, const float *i2w, const float *w2i,
+                           const float recon_i2w[16], const float recon_w2i[16]) {
+  if (!ctx || !T || !Tinv || !i2w || !w2i || !recon_i2w || !recon_w2i) return SVR_E_ARG;
+  (void)i2w_init; (void)w2i_init;   // registration-only in the reference (RC.cu:3486)
+  NEED(ctx->ns > 0, "initStorageVolumes first");
+  const size_t n = 16 * (size_t)ctx->ns;
+  ctx->mT.assign(T, T + n);
+  ctx->mTinv.assign(Tinv, Tinv + n);
+  ctx->mI2W.assign(i2w, i2w + n);
+  ctx->mW2I.assign(w2i, w2i + n);
+  memcpy(ctx->reconI2W, recon_i2w, 16 * sizeof(float));
+  memcpy(ctx->reconW2I, recon_w2i, 16 * sizeof(float));
+  ctx->have_mats = true;
+  ctx->sc_dirty = true;
+  return SVR_OK;
+}
+
+int svr_generate_psf_volume(svr_ctx *ctx, const float *cpu_psf, const uint32_t psf_size[3],
+                            const float slice_voxel_dim[3], const float psf_dim[3],
+                            const float psf_i2w[16], const float psf_w2i[16], float quality_factor) {
+  if (!ctx || !psf_size || !psf_i2w) return SVR_E_ARG;
+  (void)cpu_psf; (void)slice_voxel_dim; (void)psf_dim; (void)psf_w2i;
+  // d_PSFI2W * ((PSFsize - 1) * 0.5f)   RC.cu:172
+  float v[3] = {((float)psf_size[0] - 1) * 0.5f, ((float)psf_size[1] - 1) * 0.5f, ((float)psf_size[2] - 1) * 0.5f};
+  matvec3_host(psf_i2w, v, ctx->psf_c0);
+  ctx->quality_factor = quality_factor;
+  ctx->have_psf = true;
+  return SVR_OK;
+}
+
+int svr_update_scale_vector(svr_ctx *ctx, const float *scales, const float *slice_weights) {
+  if (!ctx || !scales || !slice_weights) return SVR_E_ARG;
+  NEED(ctx->ns > 0, "initStorageVolumes first");
+  ctx->h_scales.assign(scales, scales + ctx->ns);
+  ctx->h_slice_weights.assign(slice_weights, slice_weights + ctx->ns);
+  int r = upload_ns(ctx, ctx->d_scales, scales);
+  if (r) return r;
+  r = upload_ns(ctx, ctx->d_slice_weights, slice_weights);
+  if (r) return r;
+  ctx->have_scales = true;
+  return SVR_OK;
+}
+
+int svr_update_slice_weights(svr_ctx *ctx, const float *slice_weights) {
+  if (!ctx || !slice_weights) return SVR_E_ARG;
+  NEED(ctx->have_scales, "UpdateScaleVector first");
+  ctx->h_slice_weights.assign(slice_weights, slice_weights + ctx->ns);
+  return upload_ns(ctx, ctx->d_slice_weights, slice_weights);
+}
+
+int svr_update_reconstructed(svr_ctx *ctx, const uint32_t size[3], const float *data) {
+  if (!ctx || !size || !data) return SVR_E_ARG;
+  NEED(ctx->nv > 0, "InitReconstructionVolume first");
+  if ((size_t)size[0] * size[1] * size[2] != ctx->nv) return fail(ctx, SVR_E_ARG, "size mismatch");
+  HIPCHK(hipMemcpyAsync(ctx->recon(), data, ctx->nv * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_sync_cpu(svr_ctx *ctx, float *out) {
+  if (!ctx || !out) return SVR_E_ARG;
+  NEED(ctx->nv > 0, "InitReconstructionVolume first");
+  HIPCHK(hipMemcpyAsync(out, ctx->recon(), ctx->nv * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_get_vol_weights(svr_ctx *ctx, float *out) {
+  if (!ctx || !out) return SVR_E_ARG;
+  NEED(ctx->nv > 0, "InitReconstructionVolume first");
+  HIPCHK(hipMemcpyAsync(out, ctx->volw(), ctx->nv * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+// ---- Gaussian reconstruction -----------------------------------------------------------
+int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
+  if (!ctx) return SVR_E_ARG;
+  int r = ready(ctx);
+  if (r) return r;
+  const size_t fb = ctx->np * sizeof(float);
+  // RC.cu:2401-2411
+  HIPCHK(hipMemsetAsync(ctx->d_weights, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_simweights, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_simslices, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_siminside, 0, ctx->np, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_voxcount, 0, ctx->np * sizeof(int), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * ctx->nv * sizeof(float), ctx->stream));
+  PsfArgs a = make_args(ctx);
+  a.list = ctx->d_active;
+  a.n = ctx->n_active;
+  ScopedTimer t(ctx, SVR_T_GAUSS);
+  if (a.n) {
+    hipLaunchKernelGGL(psf_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                       ctx->stream, a);
+    KCHK("psf_kernel<GAUSS>");
+  }
+  t.stop();
+  ctx->psf_list_valid = false;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->nv > 0 && ctx->have_slices, "volume / slices not set");
+  hipLaunchKernelGGL(k_equalize, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->volw(), ctx->nv);
+  KCHK("k_equalize");
+  unsigned long long cnt = 0;
+  unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(ctx->d_out);
+  HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(cnt), ctx->stream));
+  hipLaunchKernelGGL(k_count_positive, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_voxcount, ctx->np, d_cnt);
+  KCHK("k_count_positive");
+  HIPCHK(hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (voxel_num) *voxel_num = (int)cnt;
+  return build_list(ctx, true);
+}
+
+int svr_gaussian_reconstruction(svr_ctx *ctx, int *voxel_num) {
+  int r = svr_gaussian_reconstruction_local(ctx);
+  if (r) return r;
+  return svr_gaussian_reconstruction_finish(ctx, voxel_num);
+}
+
+// ---- forward projection ----------------------------------------------------------------
+int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
+  if (!ctx) return SVR_E_ARG;
+  int r = ready(ctx);
+  if (r) return r;
+  r = ensure_psf_list(ctx);
+  if (r) return r;
+  PsfArgs a = make_args(ctx);
+  a.list = ctx->d_psf_list;
+  a.n = ctx->n_psf;
+  ScopedTimer t(ctx, SVR_T_FORWARD);
+  if (a.n) {
+    hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                       ctx->stream, a);
+    KCHK("psf_kernel<FWD>");
+  }
+  t.stop();
+  hipLaunchKernelGGL(k_slice_inside, dim3(ctx->ns), dim3(256), 0, ctx->stream, ctx->d_siminside,
+                     (int)(ctx->sx * ctx->sy), ctx->d_slice_inside);
+  KCHK("k_slice_inside");
+  if (slice_inside)
+    HIPCHK(hipMemcpyAsync(slice_inside, ctx->d_slice_inside, ctx->ns, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+// ---- EM --------------------------------------------------------------------------------
+int svr_initialize_em_values(svr_ctx *ctx) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->have_slices, "slices not filled");
+  hipLaunchKernelGGL(k_init_em, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights, ctx->np);
+  KCHK("k_init_em");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_robust_statistics_sums(svr_ctx *ctx, double out2[2]) {
+  if (!ctx || !out2) return SVR_E_ARG;
+  NEED(ctx->have_slices, "slices not filled");
+  hipLaunchKernelGGL(k_robust, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_siminside,
+                     ctx->d_simslices, ctx->d_simweights, (int)(ctx->sx * ctx->sy), ctx->d_partial);
+  KCHK("k_robust");
+  int r = reduce_partials(ctx, 2, 0, 0, true);
+  if (r) return r;
+  HIPCHK(hipMemcpyAsync(out2, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_initialize_robust_statistics(svr_ctx *ctx, float *sigma) {
+  if (!ctx || !sigma) return SVR_E_ARG;
+  double s2[2];
+  int r = svr_robust_statistics_sums(ctx, s2);
+  if (r) return r;
+  *sigma = (float)s2[0] / (float)s2[1];   // RC.cu:2301-2305
+  return SVR_OK;
+}
+
+int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potential) {
+  if (!ctx || !slice_potential) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  ScopedTimer t(ctx, SVR_T_ESTEP);
+  hipLaunchKernelGGL(k_estep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_simslices,
+                     ctx->d_simweights, ctx->d_scales, m, sigma, mix, (int)(ctx->sx * ctx->sy), ctx->d_weights,
+                     ctx->d_partial);
+  KCHK("k_estep");
+  int r = reduce_partials(ctx, 2, 0, 0, false);
+  if (r) return r;
+  hipLaunchKernelGGL(k_potential_finish, dim3(nblk(ctx->ns)), dim3(256), 0, ctx->stream, ctx->d_per_slice,
+                     (int)ctx->ns, ctx->d_tmp_ns);
+  KCHK("k_potential_finish");
+  t.stop();
+  HIPCHK(hipMemcpyAsync(slice_potential, ctx->d_tmp_ns, ctx->ns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_mstep_sums(svr_ctx *ctx, double out5[5]) {
+  if (!ctx || !out5) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  // the reference fills its per-pixel scale buffer from the HOST copy h_scales (RC.cu:3091-3094)
+  int r = upload_ns(ctx, ctx->d_scales_host_copy, ctx->h_scales.data());
+  if (r) return r;
+  ScopedTimer t(ctx, SVR_T_MSTEP);
+  hipLaunchKernelGGL(k_mstep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
+                     ctx->d_simslices, ctx->d_simweights, ctx->d_scales_host_copy, (int)(ctx->sx * ctx->sy),
+                     ctx->d_partial);
+  KCHK("k_mstep");
+  r = reduce_partials(ctx, 5, 1 << 3, 1 << 4, true);
+  if (r) return r;
+  t.stop();
+  HIPCHK(hipMemcpyAsync(out5, ctx->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma_io, float *mix_io, float *m_out) {
+  if (!ctx || !sigma_io || !mix_io || !m_out) return SVR_E_ARG;
+  double s5[5];
+  int r = svr_mstep_sums(ctx, s5);
+  if (r) return r;
+  // Reconstruction::MStep host part RC.cu:3016-3071
+  float sigma = (float)s5[0], mix = (float)s5[1], num = (float)s5[2];
+  float min_ = FLT_MAX, max_ = FLT_MIN;
+  min_ = std::min(min_, (float)s5[3]);
+  max_ = std::max(max_, (float)s5[4]);
+  if (mix > 0) *sigma_io = sigma / mix;
+  else fprintf(stderr, "Something went wrong: sigma= %f mix= %f\n", sigma, mix);
+  if (*sigma_io < step * step / 6.28f) *sigma_io = step * step / 6.28f;
+  if (iter > 1) *mix_io = mix / num;
+  *m_out = 1.0f / (max_ - min_);
+  return SVR_OK;
+}
+
+int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
+  if (!ctx || !scale_vec) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  ScopedTimer t(ctx, SVR_T_SCALE);
+  hipLaunchKernelGGL(k_scale, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
+                     ctx->d_simslices, ctx->d_simweights, (int)(ctx->sx * ctx->sy), ctx->d_partial);
+  KCHK("k_scale");
+  int r = reduce_partials(ctx, 2, 0, 0, false);
+  if (r) return r;
+  hipLaunchKernelGGL(k_scale_finish, dim3(nblk(ctx->ns)), dim3(256), 0, ctx->stream, ctx->d_per_slice, (int)ctx->ns,
+                     ctx->d_tmp_ns);
+  KCHK("k_scale_finish");
+  t.stop();
+  HIPCHK(hipMemcpyAsync(scale_vec, ctx->d_tmp_ns, ctx->ns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // Reference quirk, reproduced: CalculateScaleVectorOnX uploads h_scales -- still the PREVIOUS
+  // scale vector -- to the device (RC.cu:3238) and only afterwards h_scales = scale_vec
+  // (RC.cu:3195).  The E-step / back-projection kernels therefore see scales that lag one call
+  // behind; the M-step reads h_scales (RC.cu:3093) and sees the new ones.
+  r = upload_ns(ctx, ctx->d_scales, ctx->h_scales.data());
+  if (r) return r;
+  ctx->h_scales.assign(scale_vec, scale_vec + ctx->ns);
+  return SVR_OK;
+}
+
+// ---- super-resolution ------------------------------------------------------------------
+int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
+  if (!ctx) return SVR_E_ARG;
+  int r = ready(ctx);
+  if (r) return r;
+  if (slice_weight) {
+    r = svr_update_slice_weights(ctx, slice_weight);   // RC.cu:2123
+    if (r) return r;
+  }
+  r = ensure_psf_list(ctx);
+  if (r) return r;
+  HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream));   // RC.cu:2202-2203
+  PsfArgs a = make_args(ctx);
+  a.list = ctx->d_psf_list;
+  a.n = ctx->n_psf;
+  ScopedTimer t(ctx, SVR_T_BACKPROJECT);
+  if (a.n) {
+    hipLaunchKernelGGL(psf_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                       ctx->stream, a);
+    KCHK("psf_kernel<BACK>");
+  }
+  t.stop();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity,
+                               float max_intensity, float delta, float lambda) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->nv > 0, "volume not set");
+  if (alpha * lambda / (delta * delta) > 0.068)   // RC.cu:2124-2127
+    fprintf(stderr, "Warning: regularization might not have smoothing effect! Ensure that alpha*lambda/delta^2 is below 0.068.");
+  ScopedTimer t(ctx, SVR_T_REGULARIZE);
+  hipLaunchKernelGGL(k_reg_prep, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, adaptive, alpha, ctx->recon(),
+                     ctx->addon(), ctx->cmap(), min_intensity, max_intensity, ctx->d_snap, ctx->nv);
+  KCHK("k_reg_prep");
+  hipLaunchKernelGGL(k_regularize, dim3((ctx->vx + 63) / 64, (ctx->vy + 3) / 4, ctx->vz), dim3(256), 0, ctx->stream,
+                     (int)ctx->vx, (int)ctx->vy, (int)ctx->vz, delta, alpha, lambda, ctx->d_snap, ctx->recon(),
+                     ctx->cmap(), ctx->d_recon_new);
+  KCHK("k_regularize");
+  HIPCHK(hipMemcpyAsync(ctx->recon(), ctx->d_recon_new, ctx->nv * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  t.stop();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_superresolution(svr_ctx *ctx, int iter, const float *slice_weight, int adaptive, float alpha,
+                        float min_intensity, float max_intensity, float delta, float lambda,
+                        int global_bias_correction, float sigma_bias, float low_intensity_cutoff) {
+  (void)iter; (void)sigma_bias; (void)low_intensity_cutoff;
+  int r = svr_superresolution_backproject(ctx, slice_weight);
+  if (r) return r;
+  r = svr_superresolution_update(ctx, adaptive, alpha, min_intensity, max_intensity, delta, lambda);
+  if (r) return r;
+  if (global_bias_correction) printf("_global_bias_correction not implemented\n");   // RC.cu:2182-2185
+  return SVR_OK;
+}
+
+int svr_mask_volume(svr_ctx *ctx) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->nv > 0 && ctx->have_mask, "volume / mask not set");
+  hipLaunchKernelGGL(k_mask_volume, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_mask, ctx->nv);
+  KCHK("k_mask_volume");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_scale_volume_sums(svr_ctx *ctx, double out2[2]) {
+  if (!ctx || !out2) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  hipLaunchKernelGGL(k_scalevol, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
+                     ctx->d_simslices, ctx->d_simweights, ctx->d_slice_weights, (int)(ctx->sx * ctx->sy),
+                     ctx->d_partial);
+  KCHK("k_scalevol");
+  int r = reduce_partials(ctx, 2, 0, 0, true);
+  if (r) return r;
+  HIPCHK(hipMemcpyAsync(out2, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_scale_volume_apply(svr_ctx *ctx, float scale) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->nv > 0, "volume not set");
+  hipLaunchKernelGGL(k_scale_volume, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), scale, ctx->nv);
+  KCHK("k_scale_volume");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_scale_volume(svr_ctx *ctx) {
+  double s2[2];
+  int r = svr_scale_volume_sums(ctx, s2);
+  if (r) return r;
+  float scale = (float)(s2[0] / s2[1]);   // RC.cu:3459
+  printf("Volume scale GPU: %f\n", scale);
+  return svr_scale_volume_apply(ctx, scale);
+}
+
+int svr_restore_slice_intensities(svr_ctx *ctx, const float *stack_factors, int n_stacks,
+                                  const int *stack_index) {
+  if (!ctx || !stack_factors || !stack_index || n_stacks <= 0) return SVR_E_ARG;
+  NEED(ctx->have_slices, "slices not filled");
+  for (uint32_t i = 0; i < ctx->ns; ++i)
+    if (stack_index[i] < 0 || stack_index[i] >= n_stacks) return fail(ctx, SVR_E_ARG, "stack index out of range");
+  float *d_f = nullptr;
+  int *d_i = nullptr;
+  HIPCHK(hipMalloc(&d_f, n_stacks * sizeof(float)));
+  HIPCHK(hipMalloc(&d_i, ctx->ns * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(d_f, stack_factors, n_stacks * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_i, stack_index, ctx->ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_restore, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, d_f, d_i,
+                     (int)(ctx->sx * ctx->sy), ctx->np);
+  hipError_t e = hipGetLastError();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_f);
+  (void)hipFree(d_i);
+  if (e != hipSuccess) return fail(ctx, (int)e, "k_restore");
+  return SVR_OK;
+}
+
+// ---- buffers ---------------------------------------------------------------------------
+static int buffer_info(svr_ctx *ctx, int which, void **ptr, size_t *bytes) {
+  switch (which) {
+    case SVR_BUF_RECONSTRUCTED: *ptr = ctx->nv ? ctx->recon() : nullptr; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_VOL_WEIGHTS: *ptr = ctx->nv ? ctx->volw() : nullptr; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_ADDON: *ptr = ctx->nv ? ctx->addon() : nullptr; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_CONFIDENCE_MAP: *ptr = ctx->nv ? ctx->cmap() : nullptr; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_MASK: *ptr = ctx->d_mask; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_SLICES: *ptr = ctx->d_slices; *bytes = ctx->np * 4; break;
+    case SVR_BUF_WEIGHTS: *ptr = ctx->d_weights; *bytes = ctx->np * 4; break;
+    case SVR_BUF_SIMSLICES: *ptr = ctx->d_simslices; *bytes = ctx->np * 4; break;
+    case SVR_BUF_SIMWEIGHTS: *ptr = ctx->d_simweights; *bytes = ctx->np * 4; break;
+    case SVR_BUF_PSF_SUMS: *ptr = ctx->d_psf_sums; *bytes = ctx->np * 4; break;
+    case SVR_BUF_SIMINSIDE: *ptr = ctx->d_siminside; *bytes = ctx->np; break;
+    case SVR_BUF_VOXEL_COUNT: *ptr = ctx->d_voxcount; *bytes = ctx->np * 4; break;
+    default: return SVR_E_ARG;
+  }
+  return *ptr ? SVR_OK : SVR_E_STATE;
+}
+
+int svr_debug_get(svr_ctx *ctx, int which, void *host_out, size_t bytes) {
+  if (!ctx || !host_out) return SVR_E_ARG;
+  void *p; size_t b;
+  int r = buffer_info(ctx, which, &p, &b);
+  if (r) return fail(ctx, r, "svr_debug_get: buffer not available");
+  if (bytes != b) return fail(ctx, SVR_E_ARG, "svr_debug_get: size mismatch");
+  HIPCHK(hipMemcpyAsync(host_out, p, b, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
+  if (!ctx || !host_in) return SVR_E_ARG;
+  void *p; size_t b;
+  int r = buffer_info(ctx, which, &p, &b);
+  if (r) return fail(ctx, r, "svr_debug_set: buffer not available");
+  if (bytes != b) return fail(ctx, SVR_E_ARG, "svr_debug_set: size mismatch");
+  HIPCHK(hipMemcpyAsync(p, host_in, b, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
+  if (which == SVR_BUF_SLICES) return build_list(ctx, false);
+  return SVR_OK;
+}
+
+void *svr_device_ptr(svr_ctx *ctx, int which) {
+  if (!ctx) return nullptr;
+  void *p; size_t b;
+  if (buffer_info(ctx, which, &p, &b)) return nullptr;
+  return p;
+}
+
+size_t svr_volume_voxels(const svr_ctx *ctx) { return ctx ? ctx->nv : 0; }
+
+// ---- measurement -----------------------------------------------------------------------
+int svr_timer_enable(svr_ctx *ctx, int enable) {
+  if (!ctx) return SVR_E_ARG;
+  ctx->timers = enable != 0;
+  return SVR_OK;
+}
+int svr_timer_reset(svr_ctx *ctx) {
+  if (!ctx) return SVR_E_ARG;
+  for (int i = 0; i < SVR_T_COUNT; ++i) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
+  return SVR_OK;
+}
+int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches) {
+  if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
+  if (ms_total) *ms_total = ctx->t_ms[which];
+  if (launches) *launches = ctx->t_n[which];
+  return SVR_OK;
+}
+int svr_counters(svr_ctx *ctx, uint64_t out5[5]) {
+  if (!ctx || !out5) return SVR_E_ARG;
+  if (ctx->have_slices && !ctx->psf_list_valid) {
+    int r = build_list(ctx, true);
+    if (r) return r;
+  }
+  out5[0] = ctx->np; out5[1] = ctx->n_active; out5[2] = ctx->n_psf; out5[3] = ctx->nv; out5[4] = ctx->ns;
+  return SVR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,318 @@
+"""ctypes binding of libsvr_hip.so: `Reconstruction`, a method-for-method mirror of the reference's
+`class Reconstruction` (source/reconstructionGPU2/include/reconstruction_cuda2.cuh:92-341).
+
+Method names, argument meaning and call order are the reference's, so the parity tests read
+like irtkReconstruction's own call sequence (irtkReconstructionGPU.cc:249-401, 2695-3440).
+Errors raise `SvrError` instead of the reference's print + exit(-err).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, construction fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsvr_hip.so")
+
+# enum svr_buffer / svr_timer (include/svr_hip.h)
+BUF_RECONSTRUCTED, BUF_VOL_WEIGHTS, BUF_ADDON, BUF_CONFIDENCE_MAP, BUF_MASK = 0, 1, 2, 3, 4
+BUF_SLICES, BUF_WEIGHTS, BUF_SIMSLICES, BUF_SIMWEIGHTS, BUF_PSF_SUMS = 10, 11, 12, 13, 14
+BUF_SIMINSIDE, BUF_VOXEL_COUNT = 20, 21
+T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE = range(7)
+TIMER_NAMES = ["backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale"]
+
+EXPORTS = [
+    "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_init_reconstruction_volume",
+    "svr_set_mask", "svr_init_storage_volumes", "svr_fill_slices", "svr_set_slice_dims",
+    "svr_set_slice_matrices", "svr_generate_psf_volume", "svr_update_scale_vector",
+    "svr_update_slice_weights", "svr_update_reconstructed", "svr_sync_cpu", "svr_get_vol_weights",
+    "svr_gaussian_reconstruction", "svr_simulate_slices", "svr_initialize_em_values",
+    "svr_initialize_robust_statistics", "svr_estep", "svr_mstep", "svr_calculate_scale_vector",
+    "svr_superresolution", "svr_mask_volume", "svr_scale_volume", "svr_restore_slice_intensities",
+    "svr_debug_get", "svr_debug_set", "svr_device_ptr", "svr_volume_voxels", "svr_set_stream",
+    "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
+    "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
+    "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
+    "svr_timer_reset", "svr_timer_enable", "svr_counters",
+]
+
+
+class SvrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Load libsvr_hip.so (fails loudly if it was not built: run `python -m fetalreconstruction_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise SvrError(f"{path} not found: build the HIP engine first (fetalreconstruction_amd/build.py); "
+                           "there is no CPU fallback")
+        lib = C.CDLL(path)
+        lib.svr_last_error.restype = C.c_char_p
+        lib.svr_device_ptr.restype = C.c_void_p
+        lib.svr_volume_voxels.restype = C.c_size_t
+        lib.svr_destroy.restype = None
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u3(v):
+    return (C.c_uint32 * 3)(*[int(x) for x in v])
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Reconstruction:
+    """One GPU's SVR engine.  Mirrors `class Reconstruction` (RC.cuh:92-341)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.svr_create(int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise SvrError(f"svr_create(device={device}) failed with status {rc} (no usable MI355X / HIP device?)")
+        self._h = h
+        self.vsize = None
+        self.sgrid = None   # (ns, sy, sx)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.svr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self._lib.svr_last_error(self._h)
+            raise SvrError(f"status {rc}: {msg.decode() if msg else ''}")
+
+    # ---- state upload (names as in RC.cuh) --------------------------------------------
+    def InitReconstructionVolume(self, size, dim, data=None, sigma_bias=12.0):
+        d = _f32(data) if data is not None else None
+        self._ck(self._lib.svr_init_reconstruction_volume(self._h, _u3(size), _f3(dim), _p(d) if d is not None else None,
+                                                          C.c_float(sigma_bias)))
+        self.vsize = tuple(int(s) for s in size)
+
+    def setMask(self, size, dim, data, sigma_bias=12.0):
+        d = _f32(data)
+        self._ck(self._lib.svr_set_mask(self._h, _u3(size), _f3(dim), _p(d), C.c_float(sigma_bias)))
+
+    def initStorageVolumes(self, size, dim):
+        self._ck(self._lib.svr_init_storage_volumes(self._h, _u3(size), _f3(dim)))
+        self.sgrid = (int(size[2]), int(size[1]), int(size[0]))
+
+    def FillSlices(self, sdata, sizes_x, sizes_y):
+        d = _f32(sdata)
+        sx = np.ascontiguousarray(sizes_x, np.int32)
+        sy = np.ascontiguousarray(sizes_y, np.int32)
+        self._ck(self._lib.svr_fill_slices(self._h, _p(d), _p(sx), _p(sy)))
+
+    def setSliceDims(self, slice_dims, quality_factor):
+        d = _f32(slice_dims)
+        self._ck(self._lib.svr_set_slice_dims(self._h, _p(d), C.c_float(quality_factor)))
+
+    def SetSliceMatrices(self, slice_transforms, inv_slice_transforms, i2w_init, w2i_init, i2w, w2i, recon_i2w, recon_w2i):
+        arrs = [_f32(a) for a in (slice_transforms, inv_slice_transforms, i2w_init, w2i_init, i2w, w2i, recon_i2w, recon_w2i)]
+        self._ck(self._lib.svr_set_slice_matrices(self._h, *[_p(a) for a in arrs]))
+
+    def generatePSFVolume(self, cpu_psf, psf_size, slice_voxel_dim, psf_dim, psf_i2w, psf_w2i, quality_factor):
+        i2w, w2i = _f32(psf_i2w), _f32(psf_w2i)
+        self._ck(self._lib.svr_generate_psf_volume(self._h, None, _u3(psf_size), _f3(slice_voxel_dim), _f3(psf_dim),
+                                                   _p(i2w), _p(w2i), C.c_float(quality_factor)))
+
+    def UpdateScaleVector(self, scales, slice_weights):
+        s, w = _f32(scales), _f32(slice_weights)
+        self._ck(self._lib.svr_update_scale_vector(self._h, _p(s), _p(w)))
+
+    def UpdateSliceWeights(self, slice_weights):
+        w = _f32(slice_weights)
+        self._ck(self._lib.svr_update_slice_weights(self._h, _p(w)))
+
+    def UpdateReconstructed(self, size, data):
+        d = _f32(data)
+        self._ck(self._lib.svr_update_reconstructed(self._h, _u3(size), _p(d)))
+
+    def syncCPU(self):
+        out = np.empty(int(np.prod(self.vsize)), np.float32)
+        self._ck(self._lib.svr_sync_cpu(self._h, _p(out)))
+        return out
+
+    def getVolWeights(self):
+        out = np.empty(int(np.prod(self.vsize)), np.float32)
+        self._ck(self._lib.svr_get_vol_weights(self._h, _p(out)))
+        return out
+
+    # ---- compute ------------------------------------------------------------------------
+    def GaussianReconstruction(self):
+        n = C.c_int(0)
+        self._ck(self._lib.svr_gaussian_reconstruction(self._h, C.byref(n)))
+        return [n.value]          # voxel_num: one entry per device (RC.cu:2331)
+
+    def SimulateSlices(self):
+        inside = np.zeros(self.sgrid[0], np.uint8)
+        self._ck(self._lib.svr_simulate_slices(self._h, _p(inside)))
+        return inside.astype(bool)
+
+    def InitializeEMValues(self):
+        self._ck(self._lib.svr_initialize_em_values(self._h))
+
+    def InitializeRobustStatistics(self):
+        s = C.c_float(0)
+        self._ck(self._lib.svr_initialize_robust_statistics(self._h, C.byref(s)))
+        return s.value
+
+    def EStep(self, m, sigma, mix):
+        pot = np.zeros(self.sgrid[0], np.float32)
+        self._ck(self._lib.svr_estep(self._h, C.c_float(m), C.c_float(sigma), C.c_float(mix), _p(pot)))
+        return pot
+
+    def MStep(self, it, step, sigma, mix):
+        s, mx, m = C.c_float(sigma), C.c_float(mix), C.c_float(0)
+        self._ck(self._lib.svr_mstep(self._h, int(it), C.c_float(step), C.byref(s), C.byref(mx), C.byref(m)))
+        return s.value, mx.value, m.value
+
+    def CalculateScaleVector(self):
+        sc = np.zeros(self.sgrid[0], np.float32)
+        self._ck(self._lib.svr_calculate_scale_vector(self._h, _p(sc)))
+        return sc
+
+    def Superresolution(self, it, slice_weight, adaptive, alpha, min_intensity, max_intensity, delta, lam,
+                        global_bias_correction=False, sigma_bias=12.0, low_intensity_cutoff=0.01):
+        w = _f32(slice_weight)
+        self._ck(self._lib.svr_superresolution(self._h, int(it), _p(w), int(bool(adaptive)), C.c_float(alpha),
+                                               C.c_float(min_intensity), C.c_float(max_intensity), C.c_float(delta),
+                                               C.c_float(lam), int(bool(global_bias_correction)), C.c_float(sigma_bias),
+                                               C.c_float(low_intensity_cutoff)))
+
+    def maskVolume(self):
+        self._ck(self._lib.svr_mask_volume(self._h))
+
+    def ScaleVolume(self):
+        self._ck(self._lib.svr_scale_volume(self._h))
+
+    def RestoreSliceIntensities(self, stack_factors, stack_index):
+        f = _f32(stack_factors)
+        i = np.ascontiguousarray(stack_index, np.int32)
+        self._ck(self._lib.svr_restore_slice_intensities(self._h, _p(f), len(f), _p(i)))
+
+    # ---- sharded halves -----------------------------------------------------------------
+    def GaussianReconstructionLocal(self):
+        self._ck(self._lib.svr_gaussian_reconstruction_local(self._h))
+
+    def GaussianReconstructionFinish(self):
+        n = C.c_int(0)
+        self._ck(self._lib.svr_gaussian_reconstruction_finish(self._h, C.byref(n)))
+        return n.value
+
+    def SuperresolutionBackproject(self, slice_weight=None):
+        w = _f32(slice_weight) if slice_weight is not None else None
+        self._ck(self._lib.svr_superresolution_backproject(self._h, _p(w) if w is not None else None))
+
+    def SuperresolutionUpdate(self, adaptive, alpha, min_intensity, max_intensity, delta, lam):
+        self._ck(self._lib.svr_superresolution_update(self._h, int(bool(adaptive)), C.c_float(alpha),
+                                                      C.c_float(min_intensity), C.c_float(max_intensity),
+                                                      C.c_float(delta), C.c_float(lam)))
+
+    def RobustStatisticsSums(self):
+        o = np.zeros(2, np.float64)
+        self._ck(self._lib.svr_robust_statistics_sums(self._h, _p(o)))
+        return o
+
+    def MStepSums(self):
+        o = np.zeros(5, np.float64)
+        self._ck(self._lib.svr_mstep_sums(self._h, _p(o)))
+        return o
+
+    def ScaleVolumeSums(self):
+        o = np.zeros(2, np.float64)
+        self._ck(self._lib.svr_scale_volume_sums(self._h, _p(o)))
+        return o
+
+    def ScaleVolumeApply(self, scale):
+        self._ck(self._lib.svr_scale_volume_apply(self._h, C.c_float(scale)))
+
+    def set_stream(self, stream_handle):
+        self._ck(self._lib.svr_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def device_ptr(self, which):
+        return self._lib.svr_device_ptr(self._h, int(which))
+
+    # ---- debug getters (debugWeights/Simslices/... RC.cuh:192-207) ------------------------
+    def debug_get(self, which):
+        ns, sy, sx = self.sgrid if self.sgrid else (0, 0, 0)
+        if which < 10:
+            out = np.empty(int(np.prod(self.vsize)), np.float32)
+        elif which < 20:
+            out = np.empty((ns, sy, sx), np.float32)
+        elif which == BUF_SIMINSIDE:
+            out = np.empty((ns, sy, sx), np.uint8)
+        else:
+            out = np.empty((ns, sy, sx), np.int32)
+        self._ck(self._lib.svr_debug_get(self._h, int(which), _p(out), C.c_size_t(out.nbytes)))
+        return out
+
+    def debug_set(self, which, arr):
+        a = np.ascontiguousarray(arr)
+        self._ck(self._lib.svr_debug_set(self._h, int(which), _p(a), C.c_size_t(a.nbytes)))
+
+    # ---- measurement --------------------------------------------------------------------
+    def timer_enable(self, on=True):
+        self._ck(self._lib.svr_timer_enable(self._h, int(bool(on))))
+
+    def timer_reset(self):
+        self._ck(self._lib.svr_timer_reset(self._h))
+
+    def timers(self):
+        out = {}
+        for i, name in enumerate(TIMER_NAMES):
+            ms, n = C.c_double(0), C.c_long(0)
+            self._ck(self._lib.svr_timer_get(self._h, i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def counters(self):
+        o = (C.c_uint64 * 5)()
+        self._ck(self._lib.svr_counters(self._h, o))
+        return dict(Vs=int(o[0]), active=int(o[1]), Va=int(o[2]), Nv=int(o[3]), slices=int(o[4]))
+
+
+def sync_gpu(rec: Reconstruction, prob, quality_factor: float = 2.0):
+    """irtkReconstruction::SyncGPU + generatePSFVolume + UpdateGPUTranformationMatrices
+    (irtkReconstructionGPU.cc:249-328, 1496-1610, 372-401): upload one problem to the engine."""
+    from . import geometry as geo
+
+    vs, vd = prob.vsize, prob.vdim
+    rec.InitReconstructionVolume(vs, vd, None, 12.0)
+    rec.setMask(vs, vd, prob.mask, 12.0)
+    ns, sy, sx = prob.slices.shape
+    rec.initStorageVolumes((sx, sy, ns), tuple(prob.slice_dim[0]))
+    rec.FillSlices(prob.slices, prob.sizes_x, prob.sizes_y)
+    rec.setSliceDims(prob.slice_dim, quality_factor)
+    a = geo.ImageAttributes(128, 128, 128, *[float(d) for d in vd])   # PSF_SIZE 128, RC.cuh:56
+    rec.generatePSFVolume(None, (128, 128, 128), tuple(prob.slice_dim[0]), vd,
+                          geo.to_matrix4(geo.image_to_world(a)), geo.to_matrix4(geo.world_to_image(a)),
+                          quality_factor)
+    rec.SetSliceMatrices(prob.slice_t, prob.slice_tinv, prob.slice_i2w, prob.slice_w2i, prob.slice_i2w,
+                         prob.slice_w2i, prob.recon_i2w, prob.recon_w2i)

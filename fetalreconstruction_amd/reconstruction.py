@@ -1,0 +1,398 @@
+"""Host algorithm object: the `*GPU()` operator surface of the reference's irtkReconstruction
+(source/reconstructionGPU2/irtkReconstructionGPU.cc, "RG.cc") driving one engine per process.
+
+Method names, state names and arithmetic follow RG.cc so a reference user finds the same
+operators: InitializeEMGPU (RG.cc:2921-2953), InitializeEMValuesGPU (2905-2919),
+GaussianReconstructionGPU (2695-2762), SimulateSlicesGPU (1163-1175),
+InitializeRobustStatisticsGPU (2988-3019), EStepGPU (3184-3440), ScaleGPU (3751-3757),
+SuperresolutionGPU (4024-4036), MStepGPU (4214-4223), MaskVolumeGPU (5319-5323), and the
+reconstruction loop of reconstruction.cc:816-1140 in `reconstruct()`.
+
+Multi-GPU (no reference equivalent; replaces GPUWorker.cpp): slices are sharded over ranks, every
+rank keeps the whole volume, the volume accumulators are all-reduced once per scatter pass, the
+5 M-step scalars once per M-step, and the per-slice vectors (potentials, scales) are all-gathered
+so the slice-level EM (host code) runs identically on every rank.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+class LocalComm:
+    """Single-process communicator (world_size 1)."""
+
+    rank, world = 0, 1
+
+    def allreduce_volume_pair(self, engine, which):
+        pass
+
+    def allreduce_sum(self, a):
+        return a
+
+    def allreduce_min(self, a):
+        return a
+
+    def allreduce_max(self, a):
+        return a
+
+    def allgather_slices(self, local, counts):
+        return local
+
+
+class TorchComm:
+    """torch.distributed communicator: RCCL ("nccl") on GPUs, gloo in the CPU tests.
+
+    Volume all-reduce runs on the device buffer in place (one float[2*Nv] message per pass over
+    xGMI); small host vectors go through the same backend.
+    """
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+        self._views = {}
+
+    def _host(self, a, op):
+        t = self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+        if self.device is not None:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=op)
+        return t.cpu().numpy()
+
+    def allreduce_sum(self, a):
+        return self._host(a, self.dist.ReduceOp.SUM)
+
+    def allreduce_min(self, a):
+        return self._host(a, self.dist.ReduceOp.MIN)
+
+    def allreduce_max(self, a):
+        return self._host(a, self.dist.ReduceOp.MAX)
+
+    def allgather_slices(self, local, counts):
+        n = max(counts)
+        t = self.torch.zeros(n, dtype=self.torch.float32)
+        t[: len(local)] = self.torch.from_numpy(np.asarray(local, np.float32))
+        if self.device is not None:
+            t = t.to(self.device)
+        outs = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(outs, counts)])
+
+    def allreduce_volume_pair(self, engine, which):
+        """In-place all-reduce of {recon|volw} (which=0) or {addon|cmap} (which=2)."""
+        if hasattr(engine, "volume_pair_tensor"):      # CPU stand-in engines used by the gloo tests
+            t = engine.volume_pair_tensor(which)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            engine.volume_pair_commit(which, t)
+            return
+        key = (id(engine), which)
+        if key not in self._views:
+            self._views[key] = _device_view(self.torch, engine.device_ptr(which), 2 * int(np.prod(engine.vsize)),
+                                            self.device)
+        self.dist.all_reduce(self._views[key], op=self.dist.ReduceOp.SUM)
+        self.torch.cuda.synchronize()
+
+
+class _CAI:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def _device_view(torch, ptr, n, device):
+    """Zero-copy torch view of an engine-owned device buffer."""
+    return torch.as_tensor(_CAI(ptr, n), device=device)
+
+
+def shard_slices(active_per_slice, world):
+    """Balanced contiguous slice ranges by active-pixel count; every slice is kept
+    (the reference drops the last one and the remainder, RC.cu:1415,1440)."""
+    a = np.asarray(active_per_slice, dtype=np.float64)
+    ns = len(a)
+    cum = np.concatenate([[0.0], np.cumsum(a + 1e-9)])
+    bounds = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        b = int(np.searchsorted(cum, target, side="left"))
+        b = min(max(b, bounds[-1]), ns)
+        bounds.append(b)
+    bounds.append(ns)
+    return [(bounds[i], bounds[i + 1]) for i in range(world)]
+
+
+class irtkReconstruction:
+    """GPU-path operator surface of irtkReconstruction for one rank's shard of the slices."""
+
+    def __init__(self, engine, n_slices_global, slice_range=None, comm=None, max_intensity=1.0,
+                 min_intensity=0.0, debug=False):
+        self.reconstructionGPU = engine
+        self.comm = comm or LocalComm()
+        self.ns = int(n_slices_global)
+        self.lo, self.hi = slice_range if slice_range is not None else (0, self.ns)
+        self.counts = None
+        # RG.cc:159-221
+        self._step = 0.0001
+        self._debug = debug
+        self._quality_factor = 2
+        self._sigma_bias = 12
+        self._sigma_s_gpu = 0.025
+        self._mix_s_gpu = 0.9
+        self._mix_gpu = 0.9
+        self._delta = 1.0
+        self._lambda = 0.1
+        self._alpha = (0.05 / self._lambda) * self._delta * self._delta
+        self._low_intensity_cutoff = 0.01
+        self._global_bias_correction = False
+        self._adaptive = False
+        self._max_intensity = float(max_intensity)
+        self._min_intensity = float(min_intensity)
+        self._force_excluded = []
+        self._small_slices = []
+        self._scale_gpu = np.ones(self.ns, np.float32)
+        self._slice_weight_gpu = np.ones(self.ns, np.float32)
+        self._slice_inside_gpu = np.ones(self.ns, bool)
+        self._sigma_gpu = 0.0
+        self._m_gpu = 0.0
+        self._mean_s_gpu = 0.0
+        self._mean_s2_gpu = 0.0
+        self._sigma_s2_gpu = 0.025
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _local(self, v):
+        return np.ascontiguousarray(v[self.lo:self.hi], np.float32)
+
+    def _gather(self, local):
+        if self.comm.world == 1:
+            return np.asarray(local, np.float32)
+        if self.counts is None:
+            c = self.comm.allreduce_sum(np.eye(self.comm.world)[self.comm.rank] * (self.hi - self.lo))
+            self.counts = [int(round(x)) for x in c]
+        return self.comm.allgather_slices(local, self.counts).astype(np.float32)
+
+    def SetSmoothingParameters(self, delta, lam):
+        """RG.h:605-612"""
+        self._delta = delta
+        self._lambda = lam * delta * delta
+        self._alpha = 0.05 / lam
+        if self._alpha > 1:
+            self._alpha = 1
+
+    def SpeedupOn(self):
+        self._quality_factor = 1
+
+    def SpeedupOff(self):
+        self._quality_factor = 2
+
+    def SetForceExcludedSlices(self, force_excluded):
+        self._force_excluded = list(force_excluded)
+
+    # -- operators -------------------------------------------------------------------------
+    def InitializeEMValuesGPU(self):
+        """RG.cc:2905-2919"""
+        self._slice_weight_gpu = np.ones(self.ns, np.float32)
+        self._scale_gpu = np.ones(self.ns, np.float32)
+        self.reconstructionGPU.UpdateScaleVector(self._local(self._scale_gpu), self._local(self._slice_weight_gpu))
+        self.reconstructionGPU.InitializeEMValues()
+
+    def InitializeEMGPU(self):
+        """RG.cc:2921-2953 (the intensity range is found by the caller on the host slices)"""
+        self.InitializeEMValuesGPU()
+
+    def GaussianReconstructionGPU(self):
+        """RG.cc:2695-2762.  voxel_num has one entry per device in the reference and its median
+        indexes out of range for one device (RG.cc:2714-2726), so no slice is
+        ever classified as small on the GPU path: _small_slices stays empty."""
+        e = self.reconstructionGPU
+        if self.comm.world == 1:
+            e.GaussianReconstruction()
+        else:
+            e.GaussianReconstructionLocal()
+            self.comm.allreduce_volume_pair(e, 0)
+            e.GaussianReconstructionFinish()
+        self._small_slices = []
+
+    def SimulateSlicesGPU(self):
+        """RG.cc:1163-1175"""
+        inside = self.reconstructionGPU.SimulateSlices()
+        self._slice_inside_gpu = self._gather(np.asarray(inside, np.float32)) > 0.5
+
+    def InitializeRobustStatisticsGPU(self):
+        """RG.cc:2988-3019"""
+        e = self.reconstructionGPU
+        if self.comm.world == 1:
+            self._sigma_gpu = e.InitializeRobustStatistics()
+        else:
+            s = self.comm.allreduce_sum(e.RobustStatisticsSums())
+            self._sigma_gpu = float(np.float32(s[0]) / np.float32(s[1]))
+        self._slice_weight_gpu[~self._slice_inside_gpu] = 0
+        for i in self._force_excluded:
+            self._slice_weight_gpu[i] = 0
+        self._sigma_s_gpu = 0.025
+        self._mix_gpu = 0.9
+        self._mix_s_gpu = 0.9
+        self._m_gpu = float(np.float32(1.0 / (2.1 * self._max_intensity - 1.9 * self._min_intensity)))
+        e.UpdateScaleVector(self._local(self._scale_gpu), self._local(self._slice_weight_gpu))
+
+    def _G(self, x, s):
+        """RG.h:529-532"""
+        return self._step * math.exp(-x * x / (2 * s)) / (math.sqrt(6.28 * s))
+
+    def EStepGPU(self):
+        """RG.cc:3184-3440: voxel posteriors on the GPU, slice-level EM on the host."""
+        f32 = np.float32
+        pot = self._gather(self.reconstructionGPU.EStep(self._m_gpu, self._sigma_gpu, self._mix_gpu))
+        pot = pot.astype(np.float32).copy()
+        w = self._slice_weight_gpu
+        for i in self._force_excluded:
+            pot[i] = -1
+        for i in self._small_slices:
+            pot[i] = -1
+        for i in range(self.ns):
+            if (self._scale_gpu[i] < 0.2) or (self._scale_gpu[i] > 5):
+                pot[i] = -1
+        s = den = s2 = den2 = 0.0
+        maxs, mins = 0.0, 1.0
+        for i in range(self.ns):
+            if pot[i] >= 0:
+                p, wi = float(pot[i]), float(w[i])
+                s += p * wi
+                den += wi
+                s2 += p * (1.0 - wi)
+                den2 += (1.0 - wi)
+                maxs = max(maxs, p)
+                mins = min(mins, p)
+        mean_s = float(f32(s / den)) if den > 0 else float(f32(mins))
+        mean_s2 = float(f32(s2 / den2)) if den2 > 0 else float(f32((maxs + mean_s) / 2.0))
+        s = den = s2 = den2 = 0.0
+        for i in range(self.ns):
+            if pot[i] >= 0:
+                p, wi = float(pot[i]), float(w[i])
+                s += (p - mean_s) * (p - mean_s) * wi
+                den += wi
+                s2 += (p - mean_s2) * (p - mean_s2) * (1 - wi)
+                den2 += (1 - wi)
+        floor = self._step * self._step / 6.28
+        if s > 0 and den > 0:
+            sigma_s = float(f32(s / den))
+            if sigma_s < floor:
+                sigma_s = float(f32(floor))
+        else:
+            sigma_s = float(f32(0.025))
+        if s2 > 0 and den2 > 0:
+            sigma_s2 = float(f32(s2 / den2))
+            if sigma_s2 < floor:
+                sigma_s2 = float(f32(floor))
+        else:
+            sigma_s2 = float(f32(f32(f32(mean_s2) - f32(mean_s)) * f32(f32(mean_s2) - f32(mean_s)) / f32(4)))
+            if sigma_s2 < floor:
+                sigma_s2 = float(f32(floor))
+        mix_s = float(f32(self._mix_s_gpu))
+        for i in range(self.ns):
+            p = float(pot[i])
+            if pot[i] == -1:
+                w[i] = 0
+                continue
+            if den <= 0 or mean_s2 <= mean_s:
+                w[i] = 1
+                continue
+            gs1 = self._G(p - mean_s, sigma_s) if p < mean_s2 else 0.0
+            gs2 = self._G(p - mean_s2, sigma_s2) if p > mean_s else 0.0
+            likelihood = gs1 * mix_s + gs2 * (1 - mix_s)
+            if likelihood > 0:
+                w[i] = f32(gs1 * mix_s / likelihood)
+            else:
+                if p <= mean_s:
+                    w[i] = 1
+                if p >= mean_s2:
+                    w[i] = 0
+                if p < mean_s2 and p > mean_s:
+                    w[i] = 1
+        tot, num = 0.0, 0
+        for i in range(self.ns):
+            if pot[i] >= 0:
+                tot += float(w[i])
+                num += 1
+        self._mix_s_gpu = float(f32(tot / num)) if num > 0 else 0.9
+        self._mean_s_gpu, self._mean_s2_gpu = mean_s, mean_s2
+        self._sigma_s_gpu, self._sigma_s2_gpu = sigma_s, sigma_s2
+        self._slice_potential_gpu = pot
+        self.reconstructionGPU.UpdateSliceWeights(self._local(w))
+
+    def ScaleGPU(self):
+        """RG.cc:3751-3757"""
+        self._scale_gpu = self._gather(self.reconstructionGPU.CalculateScaleVector())
+
+    def SuperresolutionGPU(self, it):
+        """RG.cc:4024-4036"""
+        e = self.reconstructionGPU
+        if self.comm.world == 1:
+            e.Superresolution(it, self._local(self._slice_weight_gpu), self._adaptive, self._alpha,
+                              self._min_intensity, self._max_intensity, self._delta, self._lambda,
+                              self._global_bias_correction, self._sigma_bias, self._low_intensity_cutoff)
+        else:
+            e.SuperresolutionBackproject(self._local(self._slice_weight_gpu))
+            self.comm.allreduce_volume_pair(e, 2)
+            e.SuperresolutionUpdate(self._adaptive, self._alpha, self._min_intensity, self._max_intensity,
+                                    self._delta, self._lambda)
+
+    def MStepGPU(self, it):
+        """RG.cc:4214-4223 + Reconstruction::MStep host part (RC.cu:3016-3071)"""
+        e = self.reconstructionGPU
+        if self.comm.world == 1:
+            self._sigma_gpu, self._mix_gpu, self._m_gpu = e.MStep(it, self._step, self._sigma_gpu, self._mix_gpu)
+            return
+        f32 = np.float32
+        s5 = e.MStepSums()
+        tot = self.comm.allreduce_sum(s5[:3])
+        mn = self.comm.allreduce_min(s5[3:4])[0]
+        mx = self.comm.allreduce_max(s5[4:5])[0]
+        sigma, mix, num = f32(tot[0]), f32(tot[1]), f32(tot[2])
+        fmax, fmin = np.finfo(np.float32).max, np.finfo(np.float32).tiny
+        min_ = min(fmax, f32(mn))
+        max_ = max(fmin, f32(mx))
+        step = f32(self._step)
+        if mix > 0:
+            self._sigma_gpu = float(sigma / mix)
+        if f32(self._sigma_gpu) < step * step / f32(6.28):
+            self._sigma_gpu = float(step * step / f32(6.28))
+        if it > 1:
+            self._mix_gpu = float(mix / num)
+        self._m_gpu = float(f32(1.0) / (f32(max_) - f32(min_)))
+
+    def MaskVolumeGPU(self):
+        self.reconstructionGPU.maskVolume()
+
+    def ScaleVolumeGPU(self):
+        e = self.reconstructionGPU
+        if self.comm.world == 1:
+            e.ScaleVolume()
+        else:
+            s = self.comm.allreduce_sum(e.ScaleVolumeSums())
+            e.ScaleVolumeApply(float(np.float32(s[0] / s[1])))
+
+    # -- the reconstruction part of main()'s loop (reconstruction.cc:895-1140) ----------------
+    def reconstruct_iteration(self, rec_iterations, on_sr_iteration=None):
+        """One outer iteration after registration: Gaussian init, robust-statistics init and
+        `rec_iterations` super-resolution iterations.  `on_sr_iteration(i)` is a timing hook."""
+        self.InitializeEMValuesGPU()
+        self.GaussianReconstructionGPU()
+        self.SimulateSlicesGPU()
+        self.InitializeRobustStatisticsGPU()
+        self.EStepGPU()
+        for i in range(rec_iterations):
+            self.sr_iteration(i)
+            if on_sr_iteration:
+                on_sr_iteration(i)
+        self.MaskVolumeGPU()
+
+    def sr_iteration(self, i):
+        """The hot loop body, reconstruction.cc:1013-1108 with bias correction off."""
+        self.ScaleGPU()
+        self.SuperresolutionGPU(i + 1)
+        self.SimulateSlicesGPU()
+        self.MStepGPU(i + 1)
+        self.EStepGPU()

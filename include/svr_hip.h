@@ -1,0 +1,170 @@
+/*
+ * svr_hip.h -- C-ABI of the MI355X-native SVR super-resolution engine (libsvr_hip.so).
+ *
+ * Drop-in boundary for the reference's `class Reconstruction`
+ * (source/reconstructionGPU2/include/reconstruction_cuda2.cuh:92-341, "RC.cuh" below; bodies in
+ * reconstruction_cuda2.cu, "RC.cu"): one entry point per public method that
+ * irtkReconstruction actually calls (irtkReconstructionGPU.cc, "RG.cc"), with the C++ types
+ * flattened to plain pointers and sizes:
+ *     uint3 / float3            -> const uint32_t[3] / const float[3]
+ *     Matrix4 (row-major 4x4)   -> const float[16]           (recon_volumeHelper.cuh:41-46)
+ *     std::vector<Matrix4>      -> const float* (n*16)
+ *     std::vector<float|int>    -> const float* / const int* (length = number of slices)
+ *     std::vector<bool>&        -> uint8_t*
+ * Every call is blocking and takes/returns HOST memory exactly like the reference (which
+ * copies synchronously); one call in flight per context.  Instead of the reference's
+ * print-and-exit (RC.cuh:79-83) every function returns 0 on success or a non-zero status
+ * (a hipError_t value, or SVR_E_*), and svr_last_error() returns the message.
+ *
+ * One context drives ONE GPU.  Multi-GPU follows the one-process-per-GPU model: each rank
+ * creates a context for its shard of the slices and the caller all-reduces the volume
+ * accumulators between the *_local and *_finish halves (section "sharded operation").
+ */
+#ifndef SVR_HIP_H
+#define SVR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svr_ctx svr_ctx;
+
+#define SVR_OK 0
+#define SVR_E_ARG 10001     /* bad argument / call order */
+#define SVR_E_STATE 10002   /* required state (volume, slices, matrices...) not set */
+
+/* ---- lifecycle --------------------------------------------------------------------- */
+/* Reconstruction::Reconstruction(std::vector<int> dev, bool multiThreadedGPU)  RC.cuh:94, RC.cu:616-706 */
+int svr_create(int device, svr_ctx **out);
+/* Reconstruction::~Reconstruction  RC.cuh:95, RC.cu:1232-1273 */
+void svr_destroy(svr_ctx *ctx);
+const char *svr_last_error(const svr_ctx *ctx);
+/* flags  _disableBiasC / _debugGPU  (RC.cuh public members; RG.cc:227-238).  This build
+ * implements the bias-disabled path only (the CLI default, reconstruction.cc:121,202). */
+int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
+
+/* ---- geometry / state upload -------------------------------------------------------- */
+/* InitReconstructionVolume(uint3 s, float3 dim, float* data, float sigma_bias)  RC.cuh:230, RC.cu:1160-1230 */
+int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const float dim[3],
+                                   const float *data_or_null, float sigma_bias);
+/* setMask(uint3 s, float3 dim, float* data, float sigma_bias)  RC.cuh:240, RC.cu:1095-1158 */
+int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const float *data,
+                 float sigma_bias);
+/* initStorageVolumes(uint3 size, float3 dim): size = (maxX, maxY, nSlices)  RC.cuh:214, RC.cu:1408-1573 */
+int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float dim[3]);
+/* FillSlices(float* sdata, std::vector<int> sizesX, std::vector<int> sizesY)  RC.cuh:216, RC.cu:1574-1656 */
+int svr_fill_slices(svr_ctx *ctx, const float *sdata, const int *sizes_x, const int *sizes_y);
+/* setSliceDims(std::vector<float3> slice_dims, float quality_factor)  RC.cuh:220, RC.cu:772-833 */
+int svr_set_slice_dims(svr_ctx *ctx, const float *slice_dims /* n*3 */, float quality_factor);
+/* SetSliceMatrices(matSliceTransforms, matInvSliceTransforms, matsI2Winit, matsW2Iinit, matsI2W,
+ *                  matsW2I, reconI2W, reconW2I)  RC.cuh:222-224, RC.cu:835-907 */
+int svr_set_slice_matrices(svr_ctx *ctx, const float *slice_transforms, const float *inv_slice_transforms,
+                           const float *i2w_init, const float *w2i_init, const float *i2w,
+                           const float *w2i, const float recon_i2w[16], const float recon_w2i[16]);
+/* generatePSFVolume(float* CPUPSF, uint3 PSFsize, float3 sliceVoxelDim, float3 PSFdim,
+ *                   Matrix4 PSFI2W, Matrix4 PSFW2I, float quality_factor)  RC.cuh:218, RC.cu:718-750
+ * (the reference uploads only the constants; CPUPSF may be NULL) */
+int svr_generate_psf_volume(svr_ctx *ctx, const float *cpu_psf_or_null, const uint32_t psf_size[3],
+                            const float slice_voxel_dim[3], const float psf_dim[3],
+                            const float psf_i2w[16], const float psf_w2i[16], float quality_factor);
+/* UpdateScaleVector(std::vector<float> scales, std::vector<float> slices_weights)  RC.cuh:236, RC.cu:1342-1393 */
+int svr_update_scale_vector(svr_ctx *ctx, const float *scales, const float *slice_weights);
+/* UpdateSliceWeights(std::vector<float>)  RC.cuh:228, RC.cu:1312-1340 */
+int svr_update_slice_weights(svr_ctx *ctx, const float *slice_weights);
+/* UpdateReconstructed(const uint3 vsize, float* data)  RC.cuh:233, RC.cu:1658-1675 */
+int svr_update_reconstructed(svr_ctx *ctx, const uint32_t size[3], const float *data);
+/* syncCPU(float* reconstructed)  RC.cuh:213, RC.cu:2031-2037 */
+int svr_sync_cpu(svr_ctx *ctx, float *reconstructed);
+/* getVolWeights(float*)  RC.cuh:206 */
+int svr_get_vol_weights(svr_ctx *ctx, float *weights);
+
+/* ---- compute ------------------------------------------------------------------------ */
+/* GaussianReconstruction(std::vector<int>& voxel_num): voxel_num[0] = #pixels that hit the ROI
+ * RC.cuh:274, RC.cu:2329-2493 */
+int svr_gaussian_reconstruction(svr_ctx *ctx, int *voxel_num);
+/* SimulateSlices(std::vector<bool>& slice_inside)  RC.cuh:257, RC.cu:2654-2763 */
+int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside);
+/* InitializeEMValues()  RC.cuh:211, RC.cu:3241-3310 */
+int svr_initialize_em_values(svr_ctx *ctx);
+/* InitializeRobustStatistics(float& sigma)  RC.cuh:260, RC.cu:2243-2308 */
+int svr_initialize_robust_statistics(svr_ctx *ctx, float *sigma);
+/* EStep(float m, float sigma, float mix, std::vector<float>& slice_potential)  RC.cuh:253, RC.cu:2766-2925 */
+int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potential);
+/* MStep(int iter, float step, float& sigma, float& mix, float& m)  RC.cuh:255, RC.cu:2927-3112 */
+int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma, float *mix, float *m);
+/* CalculateScaleVector(std::vector<float>& scale_vec)  RC.cuh:238, RC.cu:3114-3239 */
+int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec);
+/* Superresolution(int iter, std::vector<float> slice_weight, bool adaptive, float alpha, float min_intensity,
+ *                 float max_intensity, float delta, float lambda, bool global_bias_correction,
+ *                 float sigma_bias, float low_intensity_cutoff)  RC.cuh:263-265, RC.cu:2119-2241 */
+int svr_superresolution(svr_ctx *ctx, int iter, const float *slice_weight, int adaptive, float alpha,
+                        float min_intensity, float max_intensity, float delta, float lambda,
+                        int global_bias_correction, float sigma_bias, float low_intensity_cutoff);
+/* maskVolume()  RC.cuh:270, RC.cu:3313-3347 */
+int svr_mask_volume(svr_ctx *ctx);
+/* ScaleVolume()  RC.cuh:271, RC.cu:3386-3470 */
+int svr_scale_volume(svr_ctx *ctx);
+/* RestoreSliceIntensities(std::vector<float> stack_factors, std::vector<int> stack_index)  RC.cuh:272, RC.cu:3349-3383 */
+int svr_restore_slice_intensities(svr_ctx *ctx, const float *stack_factors, int n_stacks,
+                                  const int *stack_index);
+
+/* ---- debug getters (RC.cuh:192-207): copy a device buffer to host --------------------- */
+enum svr_buffer {
+  SVR_BUF_RECONSTRUCTED = 0, /* volume-shaped float */
+  SVR_BUF_VOL_WEIGHTS = 1,
+  SVR_BUF_ADDON = 2,         /* debugAddon */
+  SVR_BUF_CONFIDENCE_MAP = 3,/* debugConfidenceMap */
+  SVR_BUF_MASK = 4,
+  SVR_BUF_SLICES = 10,       /* slice-grid-shaped float */
+  SVR_BUF_WEIGHTS = 11,      /* debugWeights */
+  SVR_BUF_SIMSLICES = 12,    /* debugSimslices */
+  SVR_BUF_SIMWEIGHTS = 13,   /* debugSimweights */
+  SVR_BUF_PSF_SUMS = 14,     /* debugv_PSF_sums */
+  SVR_BUF_SIMINSIDE = 20,    /* slice-grid-shaped char, debugSiminside */
+  SVR_BUF_VOXEL_COUNT = 21   /* slice-grid-shaped int (sliceVoxel_count_) */
+};
+int svr_debug_get(svr_ctx *ctx, int which, void *host_out, size_t bytes);
+/* test/driver hook: overwrite a device buffer from host (same enum) */
+int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes);
+
+/* ---- sharded operation (no reference equivalent: replaces GPUWorker.cpp + the peer-copy
+ * reductions RC.cu:2225-2239,2445-2460 with "local half / caller all-reduce / finish half") */
+/* device pointer of a buffer; ADDON is followed contiguously by CONFIDENCE_MAP, and
+ * RECONSTRUCTED by VOL_WEIGHTS, so each pair all-reduces as one float[2*Nvox] message */
+void *svr_device_ptr(svr_ctx *ctx, int which);
+size_t svr_volume_voxels(const svr_ctx *ctx);
+/* run all kernels on this hipStream_t (e.g. the caller's torch stream); NULL = default */
+int svr_set_stream(svr_ctx *ctx, void *hip_stream);
+int svr_gaussian_reconstruction_local(svr_ctx *ctx);            /* scatter into recon|volw */
+int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num_local); /* equalize */
+int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight); /* addon|cmap */
+int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity,
+                               float max_intensity, float delta, float lambda);
+/* partial sums for the caller to all-reduce: {sum (s-sim)^2, count} */
+int svr_robust_statistics_sums(svr_ctx *ctx, double out2[2]);
+/* {sum e^2 w, sum w, count, min e, max e} (min/max reduce with min/max) */
+int svr_mstep_sums(svr_ctx *ctx, double out5[5]);
+/* {sum w sw s sim, sum w sw sim^2} of ScaleVolume */
+int svr_scale_volume_sums(svr_ctx *ctx, double out2[2]);
+int svr_scale_volume_apply(svr_ctx *ctx, float scale);
+
+/* ---- measurement -------------------------------------------------------------------- */
+enum svr_timer {
+  SVR_T_BACKPROJECT = 0, SVR_T_FORWARD = 1, SVR_T_GAUSS = 2, SVR_T_REGULARIZE = 3,
+  SVR_T_ESTEP = 4, SVR_T_MSTEP = 5, SVR_T_SCALE = 6, SVR_T_COUNT = 7
+};
+/* accumulated HIP-event time (ms) and launch count of a hot kernel since the last reset */
+int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches);
+int svr_timer_reset(svr_ctx *ctx);
+int svr_timer_enable(svr_ctx *ctx, int enable);
+/* workload counters: [0] pixels in slice grid (Vs), [1] active pixels s!=-1,
+ * [2] pixels with v_PSF_sums!=0 (Va), [3] volume voxels (Nv), [4] slices */
+int svr_counters(svr_ctx *ctx, uint64_t out5[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVR_HIP_H */

@@ -1,0 +1,257 @@
+"""ctypes loader for the CPU oracle (oracle/svr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by fetalreconstruction_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+LITERAL, CANON = 0, 1
+
+
+class Geom(C.Structure):
+    _fields_ = [
+        ("vx", C.c_int), ("vy", C.c_int), ("vz", C.c_int),
+        ("vdim", C.c_float * 3),
+        ("reconI2W", C.c_float * 16), ("reconW2I", C.c_float * 16),
+        ("sx", C.c_int), ("sy", C.c_int), ("ns", C.c_int),
+        ("sliceI2W", C.c_void_p), ("sliceW2I", C.c_void_p),
+        ("T", C.c_void_p), ("Tinv", C.c_void_p), ("sliceDim", C.c_void_p),
+        ("psf_c0", C.c_float * 3),
+        ("psf_mode", C.c_int),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsvr_oracle.so")
+    src = os.path.join(_HERE, "svr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsvr_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_gaussian_reconstruction.restype = C.c_int
+        _LIB.orc_tap_census.restype = C.c_int
+        _LIB.orc_initialize_robust_statistics.restype = C.c_float
+        _LIB.orc_scale_volume.restype = C.c_float
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleReconstruction:
+    """CPU stand-in for `class Reconstruction` with the same method names as
+    fetalreconstruction_amd.engine.Reconstruction, so the host driver
+    (fetalreconstruction_amd.reconstruction.irtkReconstruction) can run on either and the parity
+    tests compare buffer by buffer.  Includes the reference's host-glue quirks that live below the
+    boundary (e.g. the one-call lag of the device scale vector, RC.cu:3195,3238)."""
+
+    def __init__(self, prob, mode=CANON):
+        self.prob = prob
+        self.mode = mode
+        self._keep = [_f32(prob.slice_i2w), _f32(prob.slice_w2i), _f32(prob.slice_t), _f32(prob.slice_tinv),
+                      _f32(prob.slice_dim)]
+        g = Geom()
+        g.vx, g.vy, g.vz = prob.vsize
+        g.vdim[:] = prob.vdim
+        g.reconI2W[:] = _f32(prob.recon_i2w).tolist()
+        g.reconW2I[:] = _f32(prob.recon_w2i).tolist()
+        ns, sy, sx = prob.slices.shape
+        g.sx, g.sy, g.ns = sx, sy, ns
+        g.sliceI2W, g.sliceW2I, g.T, g.Tinv, g.sliceDim = [a.ctypes.data for a in self._keep]
+        g.psf_c0[:] = _f32(prob.psf_c0).tolist()
+        g.psf_mode = mode
+        self.g = g
+        self.vsize = tuple(prob.vsize)
+        self.sgrid = (ns, sy, sx)
+        self.slices = _f32(prob.slices).copy()
+        self.mask = _f32(prob.mask).reshape(-1)
+        nv = prob.nvox
+        shp = self.slices.shape
+        self.recon_volw = np.zeros(2 * nv, np.float32)
+        self.recon, self.volw = self.recon_volw[:nv], self.recon_volw[nv:]
+        self.addon_cmap = np.zeros(2 * nv, np.float32)
+        self.addon, self.cmap = self.addon_cmap[:nv], self.addon_cmap[nv:]
+        self.psf_sums = np.zeros(shp, np.float32)
+        self.voxcount = np.zeros(shp, np.int32)
+        self.weights = np.zeros(shp, np.float32)
+        self.simslices = np.zeros(shp, np.float32)
+        self.simweights = np.zeros(shp, np.float32)
+        self.siminside = np.zeros(shp, np.uint8)
+        self.d_scales = np.ones(ns, np.float32)
+        self.h_scales = np.ones(ns, np.float32)
+        self.slice_weights = np.ones(ns, np.float32)
+
+    # ---- state -------------------------------------------------------------------------
+    def UpdateScaleVector(self, scales, slice_weights):
+        self.h_scales = _f32(scales).copy()
+        self.d_scales = _f32(scales).copy()
+        self.slice_weights = _f32(slice_weights).copy()
+
+    def UpdateSliceWeights(self, slice_weights):
+        self.slice_weights = _f32(slice_weights).copy()
+
+    def syncCPU(self):
+        return self.recon.copy()
+
+    # ---- Reconstruction::GaussianReconstruction (reconstruction_cuda2.cu:2329-2493) --------
+    def GaussianReconstructionLocal(self):
+        for a in (self.weights, self.simslices, self.simweights):   # RC.cu:2402-2409
+            a[...] = 0
+        self.siminside[...] = 0
+        self._gauss_n = lib().orc_gaussian_reconstruction(
+            C.byref(self.g), _p(self.slices), _p(self.d_scales), _p(self.mask), _p(self.recon), _p(self.volw),
+            _p(self.psf_sums), _p(self.voxcount))
+
+    def GaussianReconstructionFinish(self):
+        lib().orc_equalize(C.c_size_t(self.recon.size), _p(self.recon), _p(self.volw))
+        return self._gauss_n
+
+    def GaussianReconstruction(self):
+        self.GaussianReconstructionLocal()
+        return [self.GaussianReconstructionFinish()]
+
+    def SimulateSlices(self):
+        inside = np.zeros(self.g.ns, np.uint8)
+        lib().orc_simulate_slices(C.byref(self.g), _p(self.slices), _p(self.psf_sums), _p(self.recon), _p(self.mask),
+                                  _p(self.simslices), _p(self.simweights), _p(self.siminside), _p(inside))
+        return inside.astype(bool)
+
+    def SuperresolutionBackproject(self, slice_weight=None):
+        if slice_weight is not None:
+            self.UpdateSliceWeights(slice_weight)
+        lib().orc_superresolution_backproject(C.byref(self.g), _p(self.slices), _p(self.weights), _p(self.simslices),
+                                              _p(self.slice_weights), _p(self.d_scales), _p(self.mask),
+                                              _p(self.psf_sums), _p(self.addon), _p(self.cmap))
+
+    def SuperresolutionUpdate(self, adaptive, alpha, min_i, max_i, delta, lam):
+        vx, vy, vz = self.prob.vsize
+        original = self.recon.copy()
+        lib().orc_regularization_prep(vx, vy, vz, int(bool(adaptive)), C.c_float(alpha), C.c_float(min_i),
+                                      C.c_float(max_i), _p(self.recon), _p(self.addon), _p(self.cmap))
+        lib().orc_regularization(vx, vy, vz, C.c_float(delta), C.c_float(alpha), C.c_float(lam),
+                                 _p(self.recon), _p(original), _p(self.cmap))
+
+    def Superresolution(self, it, slice_weight, adaptive, alpha, min_i, max_i, delta, lam,
+                        global_bias_correction=False, sigma_bias=12.0, low_intensity_cutoff=0.01):
+        self.SuperresolutionBackproject(slice_weight)
+        self.SuperresolutionUpdate(adaptive, alpha, min_i, max_i, delta, lam)
+
+    def InitializeEMValues(self):
+        lib().orc_initialize_em_values(C.c_size_t(self.slices.size), _p(self.slices), _p(self.weights))
+
+    def RobustStatisticsSums(self):
+        s, n = C.c_double(0), C.c_double(0)
+        lib().orc_initialize_robust_statistics(C.c_size_t(self.slices.size), _p(self.slices), _p(self.siminside),
+                                               _p(self.simslices), _p(self.simweights), C.byref(s), C.byref(n))
+        return np.array([s.value, n.value])
+
+    def InitializeRobustStatistics(self):
+        s = self.RobustStatisticsSums()
+        return float(np.float32(s[0]) / np.float32(s[1]))
+
+    def EStep(self, m, sigma, mix):
+        pot = np.zeros(self.g.ns, np.float32)
+        lib().orc_estep(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.simslices), _p(self.simweights),
+                        _p(self.d_scales), C.c_float(m), C.c_float(sigma), C.c_float(mix), _p(self.weights), _p(pot))
+        return pot
+
+    def MStepSums(self):
+        out5 = np.zeros(5, np.float64)
+        lib().orc_mstep_sums(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.weights), _p(self.simslices),
+                             _p(self.simweights), _p(self.h_scales), _p(out5))   # h_scales: RC.cu:3093
+        return out5
+
+    def MStep(self, it, step, sigma, mix):
+        out5 = self.MStepSums()
+        s, mx, m = C.c_float(sigma), C.c_float(mix), C.c_float(0)
+        lib().orc_mstep_finish(_p(out5), int(it), C.c_float(step), C.byref(s), C.byref(mx), C.byref(m))
+        return s.value, mx.value, m.value
+
+    def CalculateScaleVector(self):
+        sc = np.zeros(self.g.ns, np.float32)
+        lib().orc_calculate_scale_vector(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.weights),
+                                         _p(self.simslices), _p(self.simweights), _p(sc))
+        self.d_scales = self.h_scales.copy()   # RC.cu:3238 uploads the PREVIOUS h_scales ...
+        self.h_scales = sc.copy()              # ... and RC.cu:3195 then replaces it
+        return sc
+
+    def maskVolume(self):
+        lib().orc_mask_volume(C.c_size_t(self.recon.size), _p(self.recon), _p(self.mask))
+
+    def ScaleVolume(self):
+        return float(lib().orc_scale_volume(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.weights),
+                                            _p(self.simslices), _p(self.simweights), _p(self.slice_weights),
+                                            C.c_size_t(self.recon.size), _p(self.recon)))
+
+    def RestoreSliceIntensities(self, stack_factors, stack_index):
+        f = _f32(stack_factors)
+        i = np.ascontiguousarray(stack_index, np.int32)
+        lib().orc_restore_slice_intensities(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(f), _p(i))
+
+    # ---- gloo test hooks (see reconstruction.TorchComm.allreduce_volume_pair) ----------------
+    def volume_pair_tensor(self, which):
+        import torch
+        return torch.from_numpy(self.recon_volw if which == 0 else self.addon_cmap)
+
+    def volume_pair_commit(self, which, t):
+        pass   # the tensor aliases the numpy buffer
+
+    def debug_get(self, which):
+        return {0: self.recon, 1: self.volw, 2: self.addon, 3: self.cmap, 4: self.mask, 10: self.slices,
+                11: self.weights, 12: self.simslices, 13: self.simweights, 14: self.psf_sums,
+                20: self.siminside, 21: self.voxcount}[which]
+
+    # ---- per-pixel probes ------------------------------------------------------------------
+    def tap_census(self, sl, px, py, with_vals=False):
+        bits = np.zeros(64, np.uint64)
+        vals = np.zeros(4096, np.float32) if with_vals else None
+        c = np.zeros(3, np.float32)
+        n = lib().orc_tap_census(C.byref(self.g), int(sl), int(px), int(py), _p(bits),
+                                 _p(vals) if with_vals else None, _p(c))
+        return n, bits, vals, c
+
+    def psf_values(self, sl, px, py):
+        v = np.zeros(4096, np.float32)
+        lib().orc_psf_values(C.byref(self.g), int(sl), int(px), int(py), _p(v))
+        return v
+
+
+def sub_problem(prob, lo, hi):
+    """The slice shard [lo, hi) of a problem (same volume), for the sharded tests."""
+    import copy
+    q = copy.copy(prob)
+    for name in ("slices", "slice_i2w", "slice_w2i", "slice_t", "slice_tinv", "slice_dim", "sizes_x", "sizes_y",
+                 "stack_index"):
+        setattr(q, name, np.ascontiguousarray(getattr(prob, name)[lo:hi]))
+    return q
+
+
+def host_estep(slice_potential, slice_weight, scale, force_excluded, small_slices, step, state5):
+    """irtkReconstruction::EStepGPU host part (irtkReconstructionGPU.cc:3203-3438)."""
+    pot = _f32(slice_potential).copy()
+    w = _f32(slice_weight).copy()
+    sc = _f32(scale)
+    fe = np.ascontiguousarray(force_excluded, np.int32)
+    ss = np.ascontiguousarray(small_slices, np.int32)
+    st = _f32(state5).copy()
+    lib().orc_host_estep(len(pot), _p(pot), _p(w), _p(sc), _p(fe), len(fe), _p(ss), len(ss), C.c_double(step), _p(st))
+    return pot, w, st

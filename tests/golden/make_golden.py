@@ -1,0 +1,69 @@
+"""Regenerates tests/golden/tiny_v1.npz from the CPU oracle (canonical mode).
+
+The reference has no tests or golden vectors for this path and cannot run
+here, so these are the oracle's own outputs on the seeded `problem_tiny` phantom: they pin the
+oracle against accidental change and give the GPU tests a fixed target that does not need the
+oracle to be rebuilt.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from fetalreconstruction_amd import phantom  # noqa: E402
+from fetalreconstruction_amd.reconstruction import irtkReconstruction  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from tests.util import run_to_state  # noqa: E402
+
+
+def main():
+    P = phantom.problem_tiny()
+    o = po.OracleReconstruction(P, po.CANON)
+    r = irtkReconstruction(o, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
+    r.SetSmoothingParameters(150, 0.02)
+    out = {"slices_sum": np.float64(P.slices.astype(np.float64).sum()), "mask_sum": np.float64(P.mask.sum())}
+    r.InitializeEMValuesGPU()
+    r.GaussianReconstructionGPU()
+    out["gauss_recon"] = o.recon.copy()
+    out["gauss_volw"] = o.volw.copy()
+    out["psf_sums"] = o.psf_sums.copy()
+    out["voxcount"] = o.voxcount.astype(np.uint8)
+    r.SimulateSlicesGPU()
+    out["simslices0"] = o.simslices.copy()
+    out["simweights0"] = o.simweights.copy()
+    out["siminside0"] = o.siminside.copy()
+    r.InitializeRobustStatisticsGPU()
+    out["sigma0"] = np.float32(r._sigma_gpu)
+    out["m0"] = np.float32(r._m_gpu)
+    r.EStepGPU()
+    out["weights0"] = o.weights.copy()
+    out["potential0"] = r._slice_potential_gpu.copy()
+    out["slice_weight0"] = r._slice_weight_gpu.copy()
+    r.ScaleGPU()
+    out["scale1"] = r._scale_gpu.copy()
+    o.SuperresolutionBackproject(r._local(r._slice_weight_gpu))
+    out["addon1"] = o.addon.copy()
+    out["cmap1"] = o.cmap.copy()
+    o.SuperresolutionUpdate(r._adaptive, r._alpha, r._min_intensity, r._max_intensity, r._delta, r._lambda)
+    out["recon1"] = o.recon.copy()
+    r.SimulateSlicesGPU()
+    r.MStepGPU(1)
+    out["mstep1"] = np.array([r._sigma_gpu, r._mix_gpu, r._m_gpu], np.float32)
+    r.EStepGPU()
+    out["slice_weight1"] = r._slice_weight_gpu.copy()
+    # a few per-pixel tap censuses (keep masks are bit-exact targets)
+    act = np.argwhere(P.slices != -1)
+    rng = np.random.default_rng(7)
+    pick = act[rng.choice(len(act), 24, replace=False)]
+    out["census_pix"] = pick.astype(np.int32)
+    out["census_bits"] = np.stack([o.tap_census(*[int(v) for v in (p[0], p[2], p[1])])[1] for p in pick])
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiny_v1.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

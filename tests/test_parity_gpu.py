@@ -1,0 +1,220 @@
+"""GPU parity: the HIP engine (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (float32 path, stated once):
+  * index work -- centre voxel, tap -> voxel mapping, epsilon-skip keep masks, hit sets
+    (psf_sums != 0, voxcount, siminside, cmap > 0, volw > 0): BIT-EXACT.
+  * v_PSF_sums: canonical double sum rounded once on both sides: rel 1e-6.
+  * scatter/gather sums (float atomics / wave partial sums vs the oracle's double accumulation):
+    |x - ref| <= 2e-5 * max|ref| per buffer (observed ~2e-6).
+  * EM scalars (double-accumulated on both sides): rel 1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from fetalreconstruction_amd import phantom
+from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from tests.util import rel_err, run_to_state
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_v1.npz")
+TOL_SUM = 2e-5
+TOL_SCALAR = 1e-5
+
+
+def _engine(prob):
+    from fetalreconstruction_amd import engine
+    rec = engine.Reconstruction(0)
+    engine.sync_gpu(rec, prob)
+    return rec
+
+
+def _drivers(prob, oracle_mod):
+    from fetalreconstruction_amd import engine as E
+    rec = _engine(prob)
+    orc = oracle_mod.OracleReconstruction(prob, oracle_mod.CANON)
+    dg = irtkReconstruction(rec, prob.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
+    do = irtkReconstruction(orc, prob.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
+    for d in (dg, do):
+        d.SetSmoothingParameters(150, 0.02)
+    return E, rec, orc, dg, do
+
+
+def test_native_library_is_loaded():
+    from fetalreconstruction_amd import engine
+    engine.Reconstruction(0).close()
+    maps = open("/proc/self/maps").read()
+    assert "libsvr_hip.so" in maps
+
+
+def test_gaussian_reconstruction_parity(tiny, oracle_mod):
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    run_to_state(dg, "gauss")
+    run_to_state(do, "gauss")
+    ps = rec.debug_get(E.BUF_PSF_SUMS)
+    assert np.array_equal(ps != 0, orc.psf_sums != 0)                       # hit set: exact
+    assert rel_err(ps, orc.psf_sums) < 1e-6
+    assert np.array_equal(rec.debug_get(E.BUF_VOXEL_COUNT), orc.voxcount)
+    vw = rec.getVolWeights()
+    assert np.array_equal(vw > 0, orc.volw > 0)
+    assert rel_err(vw, orc.volw) < TOL_SUM
+    assert rel_err(rec.syncCPU(), orc.recon) < TOL_SUM
+
+
+def test_against_committed_golden(tiny, oracle_mod):
+    """Same checks against tests/golden/tiny_v1.npz (no oracle needed at run time)."""
+    gold = np.load(GOLD)
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    run_to_state(dg, "gauss")
+    assert np.array_equal(rec.debug_get(E.BUF_PSF_SUMS) != 0, gold["psf_sums"] != 0)
+    assert rel_err(rec.debug_get(E.BUF_PSF_SUMS), gold["psf_sums"]) < 1e-6
+    assert rel_err(rec.syncCPU(), gold["gauss_recon"]) < TOL_SUM
+    dg.SimulateSlicesGPU()
+    assert rel_err(rec.debug_get(E.BUF_SIMSLICES), gold["simslices0"]) < TOL_SUM
+    assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), gold["siminside0"])
+
+
+def test_forward_projection_parity(tiny, oracle_mod):
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    run_to_state(dg, "sim")
+    run_to_state(do, "sim")
+    assert np.array_equal(dg._slice_inside_gpu, do._slice_inside_gpu)
+    assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), orc.siminside)
+    assert rel_err(rec.debug_get(E.BUF_SIMWEIGHTS), orc.simweights) < TOL_SUM
+    assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
+
+
+def test_backprojection_parity(tiny, oracle_mod):
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    run_to_state(dg, "scale")
+    run_to_state(do, "scale")
+    # identical inputs for the scatter: copy the oracle's per-pixel state onto the device
+    rec.debug_set(E.BUF_WEIGHTS, orc.weights)
+    rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+    rec.debug_set(E.BUF_PSF_SUMS, orc.psf_sums)
+    rec.UpdateScaleVector(orc.d_scales, orc.slice_weights)
+    rec.SuperresolutionBackproject(orc.slice_weights)
+    orc.SuperresolutionBackproject(orc.slice_weights)
+    cm, ad = rec.debug_get(E.BUF_CONFIDENCE_MAP), rec.debug_get(E.BUF_ADDON)
+    assert np.array_equal(cm > 0, orc.cmap > 0)                           # footprint: exact
+    assert rel_err(cm, orc.cmap) < TOL_SUM
+    assert rel_err(ad, orc.addon) < TOL_SUM
+
+
+def test_regulariser_parity(tiny, oracle_mod):
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    run_to_state(do, "scale")
+    orc.SuperresolutionBackproject(orc.slice_weights)
+    rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon)
+    rec.debug_set(E.BUF_ADDON, orc.addon)
+    rec.debug_set(E.BUF_CONFIDENCE_MAP, orc.cmap)
+    args = (do._adaptive, do._alpha, do._min_intensity, do._max_intensity, do._delta, do._lambda)
+    rec.SuperresolutionUpdate(*args)
+    orc.SuperresolutionUpdate(*args)
+    # pure elementwise / stencil float math: identical operation order -> essentially exact
+    assert rel_err(rec.syncCPU(), orc.recon) < 1e-6
+    assert rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < 1e-6
+    assert np.array_equal(rec.debug_get(E.BUF_CONFIDENCE_MAP), orc.cmap)
+
+
+def test_em_steps_parity(tiny, oracle_mod):
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    run_to_state(do, "sim")
+    run_to_state(dg, "sim")
+    for b, a in ((E.BUF_SIMSLICES, orc.simslices), (E.BUF_SIMWEIGHTS, orc.simweights), (E.BUF_SIMINSIDE, orc.siminside)):
+        rec.debug_set(b, a)
+    sg, so = rec.InitializeRobustStatistics(), orc.InitializeRobustStatistics()
+    assert abs(sg - so) <= TOL_SCALAR * abs(so)
+    m = 1.0 / (2.1 * tiny.max_intensity - 1.9 * tiny.min_intensity)
+    pg, po_ = rec.EStep(m, so, 0.9), orc.EStep(m, so, 0.9)
+    assert np.array_equal(pg < 0, po_ < 0)
+    assert rel_err(pg, po_) < TOL_SCALAR
+    assert rel_err(rec.debug_get(E.BUF_WEIGHTS), orc.weights, floor=1.0) < 1e-5
+    rec.debug_set(E.BUF_WEIGHTS, orc.weights)
+    assert rel_err(rec.CalculateScaleVector(), orc.CalculateScaleVector()) < TOL_SCALAR
+    mg, mo = rec.MStepSums(), orc.MStepSums()
+    assert np.allclose(mg, mo, rtol=TOL_SCALAR, atol=0)
+    a, b = rec.MStep(2, 1e-4, so, 0.9), orc.MStep(2, 1e-4, so, 0.9)
+    assert np.allclose(a, b, rtol=TOL_SCALAR)
+
+
+def test_full_iteration_tracks_the_oracle(tiny, oracle_mod):
+    """Gaussian init + 2 SR iterations end to end, each side on its own state."""
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    dg.reconstruct_iteration(2)
+    do.reconstruct_iteration(2)
+    assert np.allclose(dg._scale_gpu, do._scale_gpu, rtol=1e-4)
+    assert np.allclose(dg._slice_weight_gpu, do._slice_weight_gpu, atol=1e-3)
+    assert np.allclose([dg._sigma_gpu, dg._mix_gpu, dg._m_gpu], [do._sigma_gpu, do._mix_gpu, do._m_gpu], rtol=1e-4)
+    g, o = rec.syncCPU(), orc.recon
+    assert np.array_equal(g == -1, o == -1)
+    assert rel_err(g, o) < 1e-4
+
+
+def test_quirks_on_device(oracle_mod):
+    """Negative-coordinate aliasing and the stale v_PSF_sums behave like the oracle on the GPU."""
+    from fetalreconstruction_amd import geometry as geo
+    P = phantom.make_problem(1, (12, 12, 2), 1.0, 2.0, None, 1.0, 14.0, seed=5, orientations=("ax",),
+                             motion_frac=0.0, noise_sigma=0.0)
+    shift = geo.rigid_matrix(tx=-14.2, ty=-14.4, tz=-14.6)
+    for k in range(P.ns):
+        P.slice_t[k] = geo.to_matrix4(shift)
+        P.slice_tinv[k] = geo.to_matrix4(np.linalg.inv(shift))
+    P.mask[...] = 1.0
+    P.slices[...] = 100.0
+    E, rec, orc, dg, do = _drivers(P, oracle_mod)
+    run_to_state(dg, "sim")
+    run_to_state(do, "sim")
+    assert np.array_equal(rec.debug_get(E.BUF_PSF_SUMS) != 0, orc.psf_sums != 0)
+    assert rel_err(rec.getVolWeights(), orc.volw) < TOL_SUM
+    assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
+
+
+def test_ragged_and_empty_inputs(oracle_mod):
+    """Slices of different sizes padded with -1 (RG.cc:269-311), an all-padding slice and a slice
+    grid that is not a multiple of any block size."""
+    P = phantom.make_problem(2, (37, 29, 3), 1.3, 2.6, None, 1.0, 13.0, seed=9, orientations=("cor", "sag"))
+    P.slices[1, 20:, :] = -1
+    P.slices[1, :, 25:] = -1          # a smaller slice inside the padded grid
+    P.slices[4, :, :] = -1            # an empty slice
+    E, rec, orc, dg, do = _drivers(P, oracle_mod)
+    dg.reconstruct_iteration(1)
+    do.reconstruct_iteration(1)
+    assert do._slice_weight_gpu[4] == 0 and dg._slice_weight_gpu[4] == 0
+    assert rel_err(rec.syncCPU(), orc.recon) < 1e-4
+
+
+def test_adjointness_at_full_size():
+    """Size-independent property on the P4 workload (too big for the oracle): the forward
+    projection and the scatter are adjoint, <A V, e> = <V, A^T e> with unit voxel/slice weights."""
+    from fetalreconstruction_amd import engine as E
+    P = phantom.problem_p4()
+    rec = _engine(P)
+    rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+    rec.InitializeEMValues()
+    rec.GaussianReconstruction()
+    rng = np.random.default_rng(0)
+    nv = P.nvox
+    V = rng.uniform(0.5, 1.5, nv).astype(np.float32)
+    rec.debug_set(E.BUF_RECONSTRUCTED, V)
+    rec.SimulateSlices()
+    sim = rec.debug_get(E.BUF_SIMSLICES).astype(np.float64)
+    sw = rec.debug_get(E.BUF_SIMWEIGHTS).astype(np.float64)      # (A V) = sim * simweight
+    ps = rec.debug_get(E.BUF_PSF_SUMS)
+    act = (P.slices != -1) & (ps != 0)
+    s = P.slices.astype(np.float32)
+    r = rng.uniform(-1, 1, P.slices.shape).astype(np.float32)
+    simp = np.where(act, s - r, 0.0).astype(np.float32)           # residual e = s*1 - simp (RC.cu:442-447)
+    e = np.where(act & (simp > 0), s.astype(np.float64) - simp.astype(np.float64), 0.0)
+    rec.debug_set(E.BUF_SIMSLICES, simp)
+    rec.debug_set(E.BUF_WEIGHTS, np.ones(P.slices.shape, np.float32))
+    rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+    addon = rec.debug_get(E.BUF_ADDON).astype(np.float64)
+    lhs = float(np.sum(sim * sw * e))
+    rhs = float(np.sum(addon * V.astype(np.float64)))
+    scale = float(np.sum(np.abs(sim * sw * e)))                    # the sums cancel: compare against sum |terms|
+    assert abs(lhs - rhs) <= 2e-5 * scale, (lhs, rhs, scale)
+    c = rec.counters()
+    assert c["Va"] == int(act.sum()) and c["Nv"] == nv
