@@ -42,10 +42,8 @@ def cpu_baseline(prob, target_seconds=15.0):
     want = max(2000, int(target_seconds / per_pixel_s))
     step = max(1, int(np.ceil(act.sum() / want)))
     sel = np.arange(0, prob.ns, step)
-    sub = po.sub_problem(prob, 0, prob.ns)
-    for name in ("slices", "slice_i2w", "slice_w2i", "slice_t", "slice_tinv", "slice_dim", "sizes_x", "sizes_y",
-                 "stack_index"):
-        setattr(sub, name, np.ascontiguousarray(getattr(prob, name)[sel]))
+    from fetalreconstruction_amd.phantom import sub_problem
+    sub = sub_problem(prob, 0, 0, select=sel)
     o = po.OracleReconstruction(sub, po.LITERAL)
     o.InitializeEMValues()
     o.GaussianReconstruction()
@@ -97,11 +95,7 @@ def main():
         prob = phantom.problem_tiny()
     act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
     lo, hi = shard_slices(act, world)[rank]
-    if world > 1:
-        from oracle import pyoracle as _po  # sub_problem is a pure numpy helper
-        local = _po.sub_problem(prob, lo, hi)
-    else:
-        local = prob
+    local = phantom.sub_problem(prob, lo, hi) if world > 1 else prob
 
     rec = engine.Reconstruction(local_rank)
     engine.sync_gpu(rec, local)

@@ -115,8 +115,10 @@ __device__ __forceinline__ float canon_exp_neg(float a) {
 // calcPSF (RC.cu:112-130) on the scaled lattice coordinates
 __device__ __forceinline__ float psf_eval(float xs, float ys, float zs, float inv2s2) {
   float q = __builtin_fmaf(ys, ys, xs * xs);
-  float R = 3.14159265359f * __fsqrt_rn(q);
-  float si = __fdiv_rn(canon_abs_sin(R), R);
+  // plain sqrtf and '/' are IEEE correctly rounded under hipcc's default
+  // -fhip-fp32-correctly-rounded-divide-sqrt; HIP's __fsqrt_rn is NOT (it is the native v_sqrt_f32)
+  float R = 3.14159265359f * sqrtf(q);
+  float si = canon_abs_sin(R) / R;
   float gz = canon_exp_neg((zs * zs) * inv2s2);
   return (si * si) * gz;
 }
@@ -348,6 +350,27 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void psf_kernel(PsfArgs a) {
       a.siminside[idx] = inside ? 1 : 0;
     }
   }
+}
+
+// test probe: one wave evaluates one pixel; out[x + 16*y + 256*z] = psf or -1 when skipped
+__global__ __launch_bounds__(64) void k_probe_pixel(PsfArgs a, uint32_t idx, float *out, int *centre) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+  const uint32_t sl = idx / n2;
+  const uint32_t rem = idx - sl * n2;
+  const int py = (int)(rem / (uint32_t)a.sx);
+  const int px = (int)(rem - (uint32_t)py * (uint32_t)a.sx);
+  const SliceConst &S = a.sc[sl];
+  const PixelState P = pixel_setup(S, a.vg, px, py);
+  const RowConst RC = load_row_const(S);
+  for (int q = 0; q < 4; ++q) {
+    float v[16];
+    eval_row(RC, P, lane, q, v);
+    const int z = 4 * q + (lane >> 4), y = lane & 15;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) out[x + 16 * y + 256 * z] = v[x];
+  }
+  if (lane == 0) { centre[0] = P.cxi; centre[1] = P.cyi; centre[2] = P.czi; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1540,6 +1563,29 @@ void *svr_device_ptr(svr_ctx *ctx, int which) {
 }
 
 size_t svr_volume_voxels(const svr_ctx *ctx) { return ctx ? ctx->nv : 0; }
+
+int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals4096, int *centre3) {
+  if (!ctx || !vals4096 || !centre3) return SVR_E_ARG;
+  int r = ready(ctx);
+  if (r) return r;
+  if (slice < 0 || slice >= (int)ctx->ns || px < 0 || px >= (int)ctx->sx || py < 0 || py >= (int)ctx->sy)
+    return fail(ctx, SVR_E_ARG, "pixel out of range");
+  float *d_v = nullptr;
+  int *d_c = nullptr;
+  HIPCHK(hipMalloc(&d_v, 4096 * sizeof(float)));
+  HIPCHK(hipMalloc(&d_c, 3 * sizeof(int)));
+  PsfArgs a = make_args(ctx);
+  uint32_t idx = (uint32_t)px + (uint32_t)py * ctx->sx + (uint32_t)slice * ctx->sx * ctx->sy;
+  hipLaunchKernelGGL(k_probe_pixel, dim3(1), dim3(64), 0, ctx->stream, a, idx, d_v, d_c);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(vals4096, d_v, 4096 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(centre3, d_c, 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_v);
+  (void)hipFree(d_c);
+  if (e != hipSuccess) return fail(ctx, (int)e, "svr_debug_probe_pixel");
+  return SVR_OK;
+}
 
 // ---- measurement -----------------------------------------------------------------------
 int svr_timer_enable(svr_ctx *ctx, int enable) {

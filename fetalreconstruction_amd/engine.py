@@ -32,7 +32,7 @@ EXPORTS = [
     "svr_gaussian_reconstruction", "svr_simulate_slices", "svr_initialize_em_values",
     "svr_initialize_robust_statistics", "svr_estep", "svr_mstep", "svr_calculate_scale_vector",
     "svr_superresolution", "svr_mask_volume", "svr_scale_volume", "svr_restore_slice_intensities",
-    "svr_debug_get", "svr_debug_set", "svr_device_ptr", "svr_volume_voxels", "svr_set_stream",
+    "svr_debug_get", "svr_debug_set", "svr_debug_probe_pixel", "svr_device_ptr", "svr_volume_voxels", "svr_set_stream",
     "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
@@ -276,6 +276,12 @@ class Reconstruction:
     def debug_set(self, which, arr):
         a = np.ascontiguousarray(arr)
         self._ck(self._lib.svr_debug_set(self._h, int(which), _p(a), C.c_size_t(a.nbytes)))
+
+    def probe_pixel(self, sl, px, py):
+        v = np.zeros(4096, np.float32)
+        c = np.zeros(3, np.int32)
+        self._ck(self._lib.svr_debug_probe_pixel(self._h, int(sl), int(px), int(py), _p(v), _p(c)))
+        return v, c
 
     # ---- measurement --------------------------------------------------------------------
     def timer_enable(self, on=True):

@@ -186,6 +186,17 @@ def make_problem(
     )
 
 
+def sub_problem(prob: Problem, lo: int, hi: int, select=None) -> Problem:
+    """The slice shard [lo, hi) (or an explicit index list) of a problem, same volume."""
+    import copy
+    q = copy.copy(prob)
+    idx = np.arange(lo, hi) if select is None else np.asarray(select)
+    for name in ("slices", "slice_i2w", "slice_w2i", "slice_t", "slice_tinv", "slice_dim", "sizes_x", "sizes_y",
+                 "stack_index"):
+        setattr(q, name, np.ascontiguousarray(getattr(prob, name)[idx]))
+    return q
+
+
 # Named configurations (BASELINE.json `configs`, SURVEY.md section 8d)
 def problem_tiny(seed=1):
     """Oracle-sized case: 3 stacks of 32x32x8, used by CPU/GPU parity tests.  The mask radius

@@ -129,6 +129,10 @@ enum svr_buffer {
 int svr_debug_get(svr_ctx *ctx, int which, void *host_out, size_t bytes);
 /* test/driver hook: overwrite a device buffer from host (same enum) */
 int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes);
+/* test probe: the 16^3 PSF taps of one slice pixel as the kernels evaluate them
+ * (vals[x + 16*y + 256*z] = PSF value, or -1 where the epsilon-skip of RC.cu:238 drops the tap)
+ * and the rounded centre voxel (RC.cu:225-226) */
+int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals4096, int *centre3);
 
 /* ---- sharded operation (no reference equivalent: replaces GPUWorker.cpp + the peer-copy
  * reductions RC.cu:2225-2239,2445-2460 with "local half / caller all-reduce / finish half") */

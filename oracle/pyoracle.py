@@ -236,13 +236,8 @@ class OracleReconstruction:
 
 
 def sub_problem(prob, lo, hi):
-    """The slice shard [lo, hi) of a problem (same volume), for the sharded tests."""
-    import copy
-    q = copy.copy(prob)
-    for name in ("slices", "slice_i2w", "slice_w2i", "slice_t", "slice_tinv", "slice_dim", "sizes_x", "sizes_y",
-                 "stack_index"):
-        setattr(q, name, np.ascontiguousarray(getattr(prob, name)[lo:hi]))
-    return q
+    from fetalreconstruction_amd.phantom import sub_problem as _sp
+    return _sp(prob, lo, hi)
 
 
 def host_estep(slice_potential, slice_weight, scale, force_excluded, small_slices, step, state5):

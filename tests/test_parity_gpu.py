@@ -49,6 +49,28 @@ def test_native_library_is_loaded():
     assert "libsvr_hip.so" in maps
 
 
+def test_psf_taps_are_bit_identical(tiny, oracle_mod):
+    """The canonical PSF sequence on the device against the oracle: every one of the 4096 tap
+    values, the epsilon-skip keep mask and the centre voxel, bit for bit; and the keep masks
+    against the committed golden census."""
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    rec.UpdateScaleVector(np.ones(tiny.ns), np.ones(tiny.ns))
+    act = np.argwhere(tiny.slices != -1)
+    rng = np.random.default_rng(5)
+    for i in rng.choice(len(act), 150, replace=False):
+        sl, py, px = act[i]
+        v, c = rec.probe_pixel(sl, px, py)
+        n, bits, vals, cc = orc.tap_census(sl, px, py, with_vals=True)
+        assert np.array_equal(c, cc.astype(np.int32))
+        assert np.array_equal(v.view(np.uint32), vals.view(np.uint32))     # values and skips (-1)
+    gold = np.load(GOLD)
+    for p, bits in zip(gold["census_pix"], gold["census_bits"]):
+        v, _ = rec.probe_pixel(p[0], p[2], p[1])
+        kept = ~(v < 0)
+        packed = np.packbits(kept, bitorder="little").view(np.uint64)
+        assert np.array_equal(packed, bits)
+
+
 def test_gaussian_reconstruction_parity(tiny, oracle_mod):
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     run_to_state(dg, "gauss")
