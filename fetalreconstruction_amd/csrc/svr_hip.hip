@@ -11,6 +11,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -munsafe-fp-atomics ... (build.py)
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -209,27 +210,99 @@ __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
   return R;
 }
 
-// Phase 1: lane = one (y,z) row of the current quarter (4 z-planes x 16 y); walks the 16
-// x-taps sequentially with the epsilon-skip (RC.cu:233-239).  out[x] = psf, or -1 if skipped.
-__device__ __forceinline__ void eval_row(const RowConst &S, const PixelState &P, int lane, int q,
-                                         float out[16]) {
-  const float fz = (float)(4 * q + (lane >> 4) - PSF_CENTRE);
-  const float fy = (float)((lane & 15) - PSF_CENTRE);
-  const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, P.bx));
-  const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, P.by));
-  const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, P.bz));
+// One (y,z) row of a pixel's footprint: walks the 16 x-taps sequentially with the
+// epsilon-skip (RC.cu:233-239).  out[x] = psf, or -1 if skipped.  fy, fz = row offsets in
+// [-7, 8] relative to the centre voxel.
+// The PSF of the row's taps is evaluated STAGE BY STAGE over chunks of EVAL_CHUNK taps (arrays in
+// registers): every stage is EVAL_CHUNK independent instructions, which is what lets one wave
+// issue back to back -- evaluated tap after tap the dependent chains (sqrt, division, two
+// polynomials) left the SIMDs latency-bound (forward time scaled 1:1 with occupancy).  The
+// arithmetic per tap is exactly psf_eval's, so the values stay bit-identical to the oracle.
+#define EVAL_CHUNK 8
+__device__ __forceinline__ void eval_row_at(const RowConst &S, float bx, float by, float bz, float fy,
+                                            float fz, float out[16]) {
+  const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
+  const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
+  const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
+  float val[16];
+#pragma unroll
+  for (int c0 = 0; c0 < 16; c0 += EVAL_CHUNK) {
+    float R[EVAL_CHUNK], a[EVAL_CHUNK], r[EVAL_CHUNK], s[EVAL_CHUNK], u[EVAL_CHUNK], k[EVAL_CHUNK];
+#define EACH for (int i = 0; i < EVAL_CHUNK; ++i)
+#pragma unroll
+    EACH {
+      const float fx = (float)(c0 + i - PSF_CENTRE);
+      const float xs = __builtin_fmaf(S.Lp[0], fx, rowx);
+      const float ys = __builtin_fmaf(S.Lp[3], fx, rowy);
+      const float zs = __builtin_fmaf(S.Lp[6], fx, rowz);
+      R[i] = __builtin_fmaf(ys, ys, xs * xs);        // q
+      a[i] = (zs * zs) * S.inv2s2;
+    }
+#pragma unroll
+    EACH R[i] = 3.14159265359f * sqrtf(R[i]);         // correctly rounded sqrt (see psf_eval)
+    // |sin R|: canon_abs_sin
+#pragma unroll
+    EACH k[i] = __builtin_rintf(R[i] * 0.318309886183790671538f);
+#pragma unroll
+    EACH r[i] = __builtin_fmaf(k[i], -3.1414794921875f, R[i]);
+#pragma unroll
+    EACH r[i] = __builtin_fmaf(k[i], -0.00011315941810607910156f, r[i]);
+#pragma unroll
+    EACH r[i] = __builtin_fmaf(k[i], -1.9841872589410058936e-09f, r[i]);
+#pragma unroll
+    EACH s[i] = r[i] * r[i];
+#pragma unroll
+    EACH u[i] = __builtin_fmaf(2.6083159809786593541503e-06f, s[i], -0.0001981069071916863322258f);
+#pragma unroll
+    EACH u[i] = __builtin_fmaf(u[i], s[i], 0.00833307858556509017944336f);
+#pragma unroll
+    EACH u[i] = __builtin_fmaf(u[i], s[i], -0.166666597127914428710938f);
+#pragma unroll
+    EACH u[i] = __builtin_fabsf(__builtin_fmaf(s[i], u[i] * r[i], r[i]));
+#pragma unroll
+    EACH u[i] = u[i] / R[i];                          // si = |sin R| / R  (NaN at R == 0, RC.cu:129)
+#pragma unroll
+    EACH u[i] = u[i] * u[i];
+    // exp(-a): canon_exp_neg
+#pragma unroll
+    EACH k[i] = __builtin_rintf(-a[i] * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+#pragma unroll
+    EACH r[i] = __builtin_fmaf(k[i], -0.693145751953125f, -a[i]);
+#pragma unroll
+    EACH r[i] = __builtin_fmaf(k[i], -1.428606765330187045e-06f, r[i]);
+#pragma unroll
+    EACH s[i] = __builtin_fmaf(0.000198527617612853646278381f, r[i], 0.00139304355252534151077271f);
+#pragma unroll
+    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.00833336077630519866943359f);
+#pragma unroll
+    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.0416664853692054748535156f);
+#pragma unroll
+    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.166666671633720397949219f);
+#pragma unroll
+    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.5f);
+#pragma unroll
+    EACH s[i] = __builtin_fmaf(r[i] * r[i], s[i], r[i]) + 1.0f;
+#pragma unroll
+    EACH s[i] = ldexpf(s[i], (int)k[i]);
+#pragma unroll
+    EACH s[i] = (a[i] > 87.0f) ? 0.0f : s[i];
+#pragma unroll
+    EACH val[c0 + i] = u[i] * s[i];                   // (si * si) * gz
+#undef EACH
+  }
   float old = FLT_MAX;
 #pragma unroll
   for (int x = 0; x < 16; ++x) {
-    const float fx = (float)(x - PSF_CENTRE);
-    float xs = __builtin_fmaf(S.Lp[0], fx, rowx);
-    float ys = __builtin_fmaf(S.Lp[3], fx, rowy);
-    float zs = __builtin_fmaf(S.Lp[6], fx, rowz);
-    float v = psf_eval(xs, ys, zs, S.inv2s2);
-    bool skip = __builtin_fabsf(old - v) <= PSF_EPS_F;   // NaN compares false -> processed
+    const float v = val[x];
+    const bool skip = __builtin_fabsf(old - v) <= PSF_EPS_F;   // NaN compares false -> processed
     out[x] = skip ? -1.0f : v;
     old = skip ? old : v;
   }
+}
+// Phase 1 of the wave-per-pixel kernels: lane = one (y,z) row of quarter q (4 z-planes x 16 y)
+__device__ __forceinline__ void eval_row(const RowConst &S, const PixelState &P, int lane, int q,
+                                         float out[16]) {
+  eval_row_at(S, P.bx, P.by, P.bz, (float)((lane & 15) - PSF_CENTRE), (float)(4 * q + (lane >> 4) - PSF_CENTRE), out);
 }
 
 __device__ __forceinline__ uint32_t sat0(int i) { return (uint32_t)max(i, 0); }  // float->uint saturation
@@ -348,6 +421,330 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void psf_kernel(PsfArgs a) {
       a.simslices[idx] = sim / w;
       a.simweights[idx] = w;
       a.siminside[idx] = inside ? 1 : 0;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// LDS-tiled back-projection (SuperresolutionKernel3D_tex RC.cu:408-522)
+// ------------------------------------------------------------------------------------------
+// One workgroup owns a TW x TH tile of slice pixels.  The union of their 16^3 footprints (after
+// the float->uint saturation) is a small box of the volume; {addon, cmap} for that box live in
+// LDS, every wave scatters its pixels' taps with ds_add_f32 straight from the row-per-lane
+// layout (no transposition needed: LDS has no coalescing rule), and the box is flushed to HBM
+// once with the mask test applied per voxel instead of per tap.  This removes ~95 % of the
+// device-scope float atomics of the direct kernel, which are what bound it (profiles/r01_a).
+#define TILE_WAVES 16
+
+struct TileArgs {
+  const uint32_t *tiles;   // tile ids: (slice * tiles_y + ty) * tiles_x + tx
+  uint32_t ntiles;
+  int tiles_x, tiles_y;
+  int cap;                 // voxels of LDS accumulator available
+  int dbg;                 // dev experiments only (0 = production)
+  int tw, th;              // tile size in pixels, tw * th <= 64
+};
+
+__global__ void k_build_tiles(const float *slices, const float *psf_sums, int sx, int sy, int ns,
+                              int tiles_x, int tiles_y, int TILE_W, int TILE_H, uint32_t *tiles,
+                              uint32_t *counter) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t total = (uint32_t)tiles_x * tiles_y * ns;
+  if (t >= total) return;
+  const int sl = t / (tiles_x * tiles_y);
+  const int r = t - sl * tiles_x * tiles_y;
+  const int ty = r / tiles_x, tx = r - ty * tiles_x;
+  const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+  bool act = false;
+  if (lane < TILE_W * TILE_H && px < sx && py < sy) {
+    size_t idx = (size_t)px + (size_t)py * sx + (size_t)sl * sx * sy;
+    act = slices[idx] != -1.0f && psf_sums[idx] != 0.0f;
+  }
+  if (__ballot(act) != 0ull && lane == 0) tiles[atomicAdd(counter, 1u)] = t;
+}
+
+__global__ __launch_bounds__(TILE_WAVES * 64) void back_tiled_kernel(PsfArgs a, TileArgs ta) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // addon[cap] | cmap[cap]
+  __shared__ int sh_lo[3], sh_hi[3];
+  __shared__ uint32_t sh_pix[64];
+  const int TILE_W = ta.tw, TILE_H = ta.th;
+  __shared__ int sh_npix;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const VolGeom &vg = a.vg;
+  const uint32_t t = ta.tiles[blockIdx.x];
+  const int per_slice = ta.tiles_x * ta.tiles_y;
+  const uint32_t sl = t / per_slice;
+  const int r = t - sl * per_slice;
+  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
+  const SliceConst &S = a.sc[sl];
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+
+  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
+  __syncthreads();
+  if (wave == 0) {
+    // lane = pixel of the tile: activity, centre voxel, footprint bounds
+    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+    bool act = false;
+    uint32_t idx = 0;
+    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
+      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
+      act = a.slices[idx] != -1.0f && a.psf_sums[idx] != 0.0f;
+    }
+    unsigned long long b = __ballot(act);
+    if (act) {
+      sh_pix[__popcll(b & ((1ull << lane) - 1ull))] = idx;
+      PixelState P = pixel_setup(S, vg, px, py);
+      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
+      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
+      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
+    }
+    if (lane == 0) sh_npix = __popcll(b);
+  }
+  __syncthreads();
+  const int npix = sh_npix;
+  // box of saturated coordinates that can receive a tap (see DESIGN.md "tile box")
+  const int lox = max(sh_lo[0] - PSF_CENTRE, 0), hix = min(max(sh_hi[0] + 8, 0), vg.vx - 1);
+  const int loy = max(sh_lo[1] - PSF_CENTRE, 0), hiy = min(max(sh_hi[1] + 8, 0), vg.vy - 1);
+  const int loz = max(sh_lo[2] - PSF_CENTRE, 0), hiz = min(max(sh_hi[2] + 8, 0), vg.vz - 1);
+  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
+  if (Dx <= 0 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
+  // LDS pitches chosen so the 64 (y,z) rows of one ds_add hit every bank exactly twice:
+  // odd x-pitch (16 y rows -> 16 distinct banks) and plane pitch = 16 mod 32 (z planes alternate halves)
+  const int Px = Dx | 1;
+  const int Pxy = ((Px * Dy + 15) & ~31) + 16;
+  const long long vox = (long long)Pxy * Dz;
+  const bool in_lds = vox <= (long long)ta.cap;
+  float *t_addon = tile, *t_cmap = tile + ta.cap;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < (int)vox; i += TILE_WAVES * 64) { t_addon[i] = 0.0f; t_cmap[i] = 0.0f; }
+  }
+  __syncthreads();
+
+  const RowConst RC = load_row_const(S);
+  const float scale = a.scales[sl], slicew = a.slice_weights[sl];
+  for (int k = wave; k < npix; k += TILE_WAVES) {
+    const uint32_t idx = __builtin_amdgcn_readfirstlane(sh_pix[k]);
+    const uint32_t rem = idx - sl * n2;
+    const int py = (int)(rem / (uint32_t)a.sx);
+    const int px = (int)(rem - (uint32_t)py * (uint32_t)a.sx);
+    const PixelState P = pixel_setup(S, vg, px, py);
+    const float sume = a.psf_sums[idx];
+    const float w = a.weights[idx];
+    const float ss = a.simslices[idx];
+    float e = a.slices[idx] * scale;
+    e = (ss > 0.0f) ? (e - ss) : 0.0f;       // RC.cu:444-447
+    const float f1 = (w * slicew) / sume;
+    const float f0 = f1 * e;
+    for (int q = 0; q < 4; ++q) {
+      float out[16];
+      eval_row(RC, P, lane, q, out);
+      const uint32_t az = sat0(P.czi + 4 * q + (lane >> 4) - PSF_CENTRE);
+      const uint32_t ay = sat0(P.cyi + (lane & 15) - PSF_CENTRE);
+      const bool rowin = az < (uint32_t)vg.vz && ay < (uint32_t)vg.vy;
+      if (in_lds) {
+        const int rbase = ((int)ay - loy) * Px + ((int)az - loz) * Pxy - lox;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const uint32_t ax = sat0(P.cxi + x - PSF_CENTRE);
+          if (rowin && ax < (uint32_t)vg.vx && !(out[x] < 0.0f)) {
+            if (ta.dbg == 1) {
+              t_addon[rbase + (int)ax] += out[x] * f0;
+              t_cmap[rbase + (int)ax] += out[x] * f1;
+            } else if (ta.dbg == 2) {
+              if (out[x] * f0 == 123.456f) t_addon[0] = 1.0f;
+            } else {
+              atomicAdd(t_addon + rbase + (int)ax, out[x] * f0);
+              atomicAdd(t_cmap + rbase + (int)ax, out[x] * f1);
+            }
+          }
+        }
+      } else {
+        // footprint box larger than the LDS accumulator (strongly oblique tile): direct scatter
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const uint32_t ax = sat0(P.cxi + x - PSF_CENTRE);
+          if (rowin && ax < (uint32_t)vg.vx && !(out[x] < 0.0f)) {
+            const uint32_t vi = ax + ay * (uint32_t)vg.vx + az * (uint32_t)(vg.vx * vg.vy);
+            if (a.mask[vi] != 0.0f) {
+              unsafeAtomicAdd(a.addon + vi, out[x] * f0);
+              unsafeAtomicAdd(a.cmap + vi, out[x] * f1);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!in_lds || ta.dbg == 3) return;
+  __syncthreads();
+  // flush: one pair of device-scope atomics per touched, in-mask voxel of the box
+  for (int i = threadIdx.x; i < (int)vox; i += TILE_WAVES * 64) {
+    const float c = t_cmap[i], ad = t_addon[i];
+    if (c != 0.0f || ad != 0.0f) {
+      const int z = i / Pxy, rr = i - z * Pxy;
+      const int y = rr / Px, x = rr - y * Px;
+      const uint32_t vi = (uint32_t)(x + lox) + (uint32_t)(y + loy) * (uint32_t)vg.vx +
+                          (uint32_t)(z + loz) * (uint32_t)(vg.vx * vg.vy);
+      if (a.mask[vi] != 0.0f) {
+        unsafeAtomicAdd(a.addon + vi, ad);
+        unsafeAtomicAdd(a.cmap + vi, c);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Plane-owned back-projection: the production scatter (no atomics inside the tile)
+// ------------------------------------------------------------------------------------------
+// LDS float atomics (ds_add_f32) turned out to run at ~1 lane / 2.6 clk / CU on gfx950 -- barely
+// faster than device-scope atomics -- so the tile box is instead partitioned by ABSOLUTE z-plane:
+// each 16-lane "slot" owns one plane of the box, walks the (pixel, z) units of the tile that land
+// on its plane, and its 16 lanes are the 16 y-rows of that unit.  No two lanes ever touch the
+// same LDS word, so the accumulation is a plain read-add-write in a fixed order (deterministic
+// inside a tile); only the final flush uses device-scope atomics.  Tiles that touch the low
+// volume boundary (saturated, aliasing coordinates) or whose box does not fit go through
+// back_tiled_kernel's atomic path instead.
+#define PLANE_MAX_WAVES 8
+
+struct PixelRec {      // per tile pixel, in LDS
+  int cx, cy, cz;
+  float bx, by, bz;
+  float f0, f1;
+};
+
+template <int PLANE_WAVES>
+__global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a, TileArgs ta,
+                                                                       uint32_t *fallback_tiles,
+                                                                       uint32_t *fallback_count) {
+  constexpr int PLANE_SLOTS = PLANE_WAVES * 4;
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // addon[cap] | cmap[cap]
+  __shared__ int sh_lo[3], sh_hi[3];
+  __shared__ PixelRec sh_px[64];
+  __shared__ unsigned char sh_list[PLANE_SLOTS][64];
+  __shared__ int sh_cnt[PLANE_SLOTS];
+  __shared__ int sh_npix;
+  const int TILE_W = ta.tw, TILE_H = ta.th;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const VolGeom &vg = a.vg;
+  const uint32_t t = ta.tiles[blockIdx.x];
+  const int per_slice = ta.tiles_x * ta.tiles_y;
+  const uint32_t sl = t / per_slice;
+  const int r = t - sl * per_slice;
+  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
+  const SliceConst &S = a.sc[sl];
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+
+  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
+  __syncthreads();
+  if (wave == 0) {
+    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+    bool act = false;
+    uint32_t idx = 0;
+    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
+      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
+      act = a.slices[idx] != -1.0f && a.psf_sums[idx] != 0.0f;
+    }
+    unsigned long long b = __ballot(act);
+    if (act) {
+      PixelState P = pixel_setup(S, vg, px, py);
+      const float sume = a.psf_sums[idx];
+      const float ss = a.simslices[idx];
+      float e = a.slices[idx] * a.scales[sl];
+      e = (ss > 0.0f) ? (e - ss) : 0.0f;                       // RC.cu:444-447
+      const float f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
+      PixelRec R;
+      R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
+      sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
+      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
+      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
+      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
+    }
+    if (lane == 0) sh_npix = __popcll(b);
+  }
+  __syncthreads();
+  const int npix = sh_npix;
+  // The box is kept in UNSATURATED coordinates: x spans every tap position (also negative ones and
+  // ones beyond the volume), y/z are clipped at the high end only.  The float->uint saturation of
+  // the reference (negative -> 0, RC.cu:508) is applied once per box voxel at flush time, which
+  // sums exactly the taps that alias; taps beyond the high end are dropped (RC.cu:509).
+  const int lox = sh_lo[0] - PSF_CENTRE, hix = sh_hi[0] + 8;
+  const int loy = sh_lo[1] - PSF_CENTRE, hiy = min(sh_hi[1] + 8, vg.vy - 1);
+  const int loz = sh_lo[2] - PSF_CENTRE, hiz = min(sh_hi[2] + 8, vg.vz - 1);
+  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
+  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
+  const int Px = Dx | 1;                                // odd x pitch: 16 y rows -> 16 distinct banks
+  const int Pxy = Px * Dy;
+  const bool fast = Dz <= PLANE_SLOTS && (long long)Pxy * Dz <= (long long)ta.cap;
+  if (!fast) {
+    if (threadIdx.x == 0) fallback_tiles[atomicAdd(fallback_count, 1u)] = t;
+    return;
+  }
+  const int vox = Pxy * Dz;
+  float *t_addon = tile, *t_cmap = tile + ta.cap;
+  for (int i = threadIdx.x; i < vox; i += PLANE_WAVES * 64) { t_addon[i] = 0.0f; t_cmap[i] = 0.0f; }
+  if ((int)threadIdx.x < Dz) {
+    // (pixel, z) units landing on absolute plane loz + threadIdx.x, in pixel order
+    const int P = loz + (int)threadIdx.x;
+    int c = 0;
+    for (int k = 0; k < npix; ++k) {
+      const int z = P - sh_px[k].cz + PSF_CENTRE;
+      if (z >= 0 && z < PSF_SUPPORT) sh_list[threadIdx.x][c++] = (unsigned char)k;
+    }
+    sh_cnt[threadIdx.x] = c;
+  }
+  __syncthreads();
+
+  const RowConst RC = load_row_const(S);
+  const int slot = threadIdx.x >> 4;
+  const int y = lane & 15;
+  if (slot < Dz) {
+    const int P = loz + slot;                           // <= hiz < vz: plane in bounds
+    const int cnt = sh_cnt[slot];
+    float *pa = t_addon + slot * Pxy - lox, *pc = t_cmap + slot * Pxy - lox;
+    for (int i = 0; i < cnt; ++i) {
+      const PixelRec R = sh_px[sh_list[slot][i]];
+      const int z = P - R.cz + PSF_CENTRE;
+      const int ay = R.cy + y - PSF_CENTRE;             // may be negative: aliases to 0 at flush
+      const bool rowok = ay < vg.vy;
+      const int rb = rowok ? (ay - loy) * Px + R.cx - PSF_CENTRE : 0;
+      // the row's 16 accumulators are fetched before the PSF evaluation (their LDS latency hides
+      // behind ~1200 ALU instructions) and written back after it; all 16 x positions are inside the
+      // box by construction, so the read-add-write is unconditional (skipped taps add 0)
+      float va[16], vc[16];
+      if (rowok) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) { va[x] = pa[rb + x]; vc[x] = pc[rb + x]; }
+      }
+      float out[16];
+      eval_row_at(RC, R.bx, R.by, R.bz, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE), out);
+      if (rowok) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const float v = (out[x] < 0.0f) ? 0.0f : out[x];
+          pa[rb + x] = va[x] + v * R.f0;
+          pc[rb + x] = vc[x] + v * R.f1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < vox; i += PLANE_WAVES * 64) {
+    const float c = t_cmap[i], ad = t_addon[i];
+    if (c != 0.0f || ad != 0.0f) {
+      const int z = i / Pxy, rr = i - z * Pxy;
+      const int yy = rr / Px, xx = rr - yy * Px;
+      const int gx = xx + lox;
+      if (gx < vg.vx) {                                  // beyond the high end: out of bounds
+        const uint32_t vi = sat0(gx) + sat0(yy + loy) * (uint32_t)vg.vx +
+                            sat0(z + loz) * (uint32_t)(vg.vx * vg.vy);
+        if (a.mask[vi] != 0.0f) {
+          unsafeAtomicAdd(a.addon + vi, ad);
+          unsafeAtomicAdd(a.cmap + vi, c);
+        }
+      }
     }
   }
 }
@@ -781,9 +1178,20 @@ struct svr_ctx {
   SliceConst *d_sc = nullptr;
 
   // work lists
-  uint32_t *d_active = nullptr, *d_psf_list = nullptr, *d_counter = nullptr;
-  uint32_t n_active = 0, n_psf = 0;
+  uint32_t *d_active = nullptr, *d_psf_list = nullptr, *d_counter = nullptr, *d_tiles = nullptr,
+           *d_tiles_fb = nullptr;
+  uint32_t n_active = 0, n_psf = 0, n_tiles = 0;
+  int tiles_x = 0, tiles_y = 0, tile_w = 4, tile_h = 4;
+  int plane_waves = 8;      // waves per workgroup of back_plane_kernel (4 planes each)
+  int plane_cap = 9600;     // LDS accumulator voxels of back_plane_kernel: 75 KiB + 4.3 KiB static
+                            // -> exactly 2 workgroups per CU (measured: 1 per CU is 1.6x slower)
   bool psf_list_valid = false;
+  int back_mode = 2;        // 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
+                            // 0 = direct device-scope atomics per tap
+  int tile_cap = 0;         // voxels of LDS accumulator per workgroup
+  int dbg_back = 0;
+  int dbg_fwd_lds = 0;      // dev experiment: extra dynamic LDS on the forward launch (limits occupancy)
+  uint32_t n_tiles_fb = 0;
 
   // reductions
   double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
@@ -861,6 +1269,8 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_psf_sums); free_dev(c->d_siminside); free_dev(c->d_voxcount); free_dev(c->d_scales);
   free_dev(c->d_slice_weights); free_dev(c->d_scales_host_copy); free_dev(c->d_tmp_ns);
   free_dev(c->d_slice_inside); free_dev(c->d_sc); free_dev(c->d_active); free_dev(c->d_psf_list);
+  free_dev(c->d_tiles);
+  free_dev(c->d_tiles_fb);
   free_dev(c->d_partial); free_dev(c->d_per_slice);
 }
 
@@ -904,8 +1314,22 @@ int build_list(svr_ctx *ctx, bool with_psf) {
   uint32_t n = 0;
   HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (with_psf) { ctx->n_psf = n; ctx->psf_list_valid = true; }
-  else ctx->n_active = n;
+  if (with_psf) {
+    ctx->n_psf = n;
+    ctx->psf_list_valid = true;
+    // tiles of TILE_W x TILE_H pixels that hold at least one pixel of the list
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t total = (uint32_t)ctx->tiles_x * ctx->tiles_y * ctx->ns;
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
+                       (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
+                       ctx->d_tiles, ctx->d_counter);
+    KCHK("k_build_tiles");
+    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_tiles = n;
+  } else {
+    ctx->n_active = n;
+  }
   return SVR_OK;
 }
 
@@ -987,8 +1411,57 @@ int svr_create(int device, svr_ctx **out) {
     svr_destroy(ctx);
     return (int)hipErrorOutOfMemory;
   }
+  {
+    // LDS accumulator of the tiled scatter: everything the CU has minus the static part
+    int lds_max = 0;
+    (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+    if (lds_max <= 0) lds_max = 65536;
+    int dyn = lds_max - 1024;
+    dyn -= 8192;   // static LDS of back_plane_kernel (pixel table + plane lists)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(back_tiled_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<5>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<6>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<7>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) {
+      (void)hipGetLastError();
+      dyn = 65536 - 1024;
+    }
+    ctx->tile_cap = dyn / (2 * (int)sizeof(float));
+  }
   *out = ctx;
   return SVR_OK;
+}
+
+int svr_set_option(svr_ctx *ctx, const char *name, int value) {
+  if (!ctx || !name) return SVR_E_ARG;
+  if (!strcmp(name, "back_mode")) { ctx->back_mode = value; return SVR_OK; }
+  if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
+  if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
+  if (!strcmp(name, "plane_waves")) { ctx->plane_waves = std::max(4, std::min(value, PLANE_MAX_WAVES)); return SVR_OK; }
+  if (!strcmp(name, "plane_cap")) { ctx->plane_cap = std::max(4096, value); return SVR_OK; }
+  if (!strcmp(name, "tile_w") || !strcmp(name, "tile_h")) {
+    int w = !strcmp(name, "tile_w") ? value : ctx->tile_w, h = !strcmp(name, "tile_h") ? value : ctx->tile_h;
+    if (w < 1 || h < 1 || w * h > 64) return fail(ctx, SVR_E_ARG, "tile_w * tile_h must be in 1..64");
+    ctx->tile_w = w; ctx->tile_h = h;
+    if (ctx->np) {
+      free_dev(ctx->d_tiles); free_dev(ctx->d_tiles_fb);
+      ctx->tiles_x = (int)((ctx->sx + w - 1) / w);
+      ctx->tiles_y = (int)((ctx->sy + h - 1) / h);
+      const size_t nb = (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t);
+      HIPCHK(hipMalloc(&ctx->d_tiles, nb));
+      HIPCHK(hipMalloc(&ctx->d_tiles_fb, nb));
+      ctx->psf_list_valid = false;
+    }
+    return SVR_OK;
+  }
+  return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);
 }
 
 void svr_destroy(svr_ctx *ctx) {
@@ -1084,6 +1557,10 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   HIPCHK(hipMalloc(&ctx->d_voxcount, np * sizeof(int)));
   HIPCHK(hipMalloc(&ctx->d_active, np * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&ctx->d_psf_list, np * sizeof(uint32_t)));
+  ctx->tiles_x = (int)((ctx->sx + ctx->tile_w - 1) / ctx->tile_w);
+  ctx->tiles_y = (int)((ctx->sy + ctx->tile_h - 1) / ctx->tile_h);
+  HIPCHK(hipMalloc(&ctx->d_tiles, (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&ctx->d_tiles_fb, (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&ctx->d_scales, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_slice_weights, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_scales_host_copy, ctx->ns * sizeof(float)));
@@ -1263,8 +1740,8 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   a.n = ctx->n_psf;
   ScopedTimer t(ctx, SVR_T_FORWARD);
   if (a.n) {
-    hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                       ctx->stream, a);
+    hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),
+                       (size_t)ctx->dbg_fwd_lds, ctx->stream, a);
     KCHK("psf_kernel<FWD>");
   }
   t.stop();
@@ -1406,7 +1883,46 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
-  if (a.n) {
+  if (a.n && ctx->back_mode == 2) {
+    TileArgs ta;
+    ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
+    ta.cap = std::min(ctx->plane_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
+    ta.tw = ctx->tile_w; ta.th = ctx->tile_h;
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
+#define LAUNCH_PLANE(NW)                                                                                   \
+  hipLaunchKernelGGL(back_plane_kernel<NW>, dim3(ctx->n_tiles), dim3(NW * 64), lds, ctx->stream, a, ta,   \
+                     ctx->d_tiles_fb, ctx->d_counter)
+    switch (ctx->plane_waves) {
+      case 4: LAUNCH_PLANE(4); break;
+      case 5: LAUNCH_PLANE(5); break;
+      case 6: LAUNCH_PLANE(6); break;
+      case 7: LAUNCH_PLANE(7); break;
+      default: LAUNCH_PLANE(8); break;
+    }
+#undef LAUNCH_PLANE
+    KCHK("back_plane_kernel");
+    ta.cap = ctx->tile_cap;
+    uint32_t nfb = 0;
+    HIPCHK(hipMemcpyAsync(&nfb, ctx->d_counter, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_tiles_fb = nfb;
+    if (nfb) {
+      ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb;
+      hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb), dim3(TILE_WAVES * 64),
+                         (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
+      KCHK("back_tiled_kernel(fallback)");
+    }
+  } else if (a.n && ctx->back_mode == 1) {
+    TileArgs ta;
+    ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
+    ta.cap = ctx->tile_cap;
+    ta.dbg = ctx->dbg_back;
+    ta.tw = ctx->tile_w; ta.th = ctx->tile_h;
+    hipLaunchKernelGGL(back_tiled_kernel, dim3(ctx->n_tiles), dim3(TILE_WAVES * 64),
+                       (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
+    KCHK("back_tiled_kernel");
+  } else if (a.n) {
     hipLaunchKernelGGL(psf_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("psf_kernel<BACK>");
@@ -1604,13 +2120,14 @@ int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches) {
   if (launches) *launches = ctx->t_n[which];
   return SVR_OK;
 }
-int svr_counters(svr_ctx *ctx, uint64_t out5[5]) {
+int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
   if (!ctx || !out5) return SVR_E_ARG;
   if (ctx->have_slices && !ctx->psf_list_valid) {
     int r = build_list(ctx, true);
     if (r) return r;
   }
   out5[0] = ctx->np; out5[1] = ctx->n_active; out5[2] = ctx->n_psf; out5[3] = ctx->nv; out5[4] = ctx->ns;
+  out5[5] = ctx->n_tiles; out5[6] = ctx->n_tiles_fb;
   return SVR_OK;
 }
 

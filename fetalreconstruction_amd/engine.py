@@ -25,7 +25,7 @@ T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE = ran
 TIMER_NAMES = ["backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale"]
 
 EXPORTS = [
-    "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_init_reconstruction_volume",
+    "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_init_reconstruction_volume",
     "svr_set_mask", "svr_init_storage_volumes", "svr_fill_slices", "svr_set_slice_dims",
     "svr_set_slice_matrices", "svr_generate_psf_volume", "svr_update_scale_vector",
     "svr_update_slice_weights", "svr_update_reconstructed", "svr_sync_cpu", "svr_get_vol_weights",
@@ -277,6 +277,9 @@ class Reconstruction:
         a = np.ascontiguousarray(arr)
         self._ck(self._lib.svr_debug_set(self._h, int(which), _p(a), C.c_size_t(a.nbytes)))
 
+    def set_option(self, name, value):
+        self._ck(self._lib.svr_set_option(self._h, name.encode(), int(value)))
+
     def probe_pixel(self, sl, px, py):
         v = np.zeros(4096, np.float32)
         c = np.zeros(3, np.int32)
@@ -299,9 +302,10 @@ class Reconstruction:
         return out
 
     def counters(self):
-        o = (C.c_uint64 * 5)()
+        o = (C.c_uint64 * 8)()
         self._ck(self._lib.svr_counters(self._h, o))
-        return dict(Vs=int(o[0]), active=int(o[1]), Va=int(o[2]), Nv=int(o[3]), slices=int(o[4]))
+        return dict(Vs=int(o[0]), active=int(o[1]), Va=int(o[2]), Nv=int(o[3]), slices=int(o[4]),
+                    tiles=int(o[5]), fallback_tiles=int(o[6]))
 
 
 def sync_gpu(rec: Reconstruction, prob, quality_factor: float = 2.0):

@@ -45,6 +45,10 @@ const char *svr_last_error(const svr_ctx *ctx);
 /* flags  _disableBiasC / _debugGPU  (RC.cuh public members; RG.cc:227-238).  This build
  * implements the bias-disabled path only (the CLI default, reconstruction.cc:121,202). */
 int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
+/* engine tuning knobs (no reference equivalent).  "back_mode": 2 = plane-owned LDS tiles
+ * (default; no atomics inside a tile), 1 = LDS tiles with ds_add_f32, 0 = direct device-scope
+ * atomics per tap. */
+int svr_set_option(svr_ctx *ctx, const char *name, int value);
 
 /* ---- geometry / state upload -------------------------------------------------------- */
 /* InitReconstructionVolume(uint3 s, float3 dim, float* data, float sigma_bias)  RC.cuh:230, RC.cu:1160-1230 */
@@ -165,8 +169,9 @@ int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches);
 int svr_timer_reset(svr_ctx *ctx);
 int svr_timer_enable(svr_ctx *ctx, int enable);
 /* workload counters: [0] pixels in slice grid (Vs), [1] active pixels s!=-1,
- * [2] pixels with v_PSF_sums!=0 (Va), [3] volume voxels (Nv), [4] slices */
-int svr_counters(svr_ctx *ctx, uint64_t out5[5]);
+ * [2] pixels with v_PSF_sums!=0 (Va), [3] volume voxels (Nv), [4] slices,
+ * [5] pixel tiles of the scatter, [6] tiles that took the atomic fallback in the last scatter, [7] 0 */
+int svr_counters(svr_ctx *ctx, uint64_t out8[8]);
 
 #ifdef __cplusplus
 }

@@ -108,8 +108,11 @@ def test_forward_projection_parity(tiny, oracle_mod):
     assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
 
 
-def test_backprojection_parity(tiny, oracle_mod):
+@pytest.mark.parametrize("back_mode", [2, 1, 0])
+def test_backprojection_parity(tiny, oracle_mod, back_mode):
+    """back_mode 2 = plane-owned LDS tiles (default), 1 = LDS tiles with ds_add_f32, 0 = direct atomics."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    rec.set_option("back_mode", back_mode)
     run_to_state(dg, "scale")
     run_to_state(do, "scale")
     # identical inputs for the scatter: copy the oracle's per-pixel state onto the device
@@ -175,23 +178,42 @@ def test_full_iteration_tracks_the_oracle(tiny, oracle_mod):
     assert rel_err(g, o) < 1e-4
 
 
-def test_quirks_on_device(oracle_mod):
-    """Negative-coordinate aliasing and the stale v_PSF_sums behave like the oracle on the GPU."""
+@pytest.mark.parametrize("shift", [(-14.2, -14.4, -14.6), (14.3, 14.1, 13.9), (-14.2, 14.1, 0.3)])
+@pytest.mark.parametrize("back_mode", [2, 1])
+def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
+    """Slices hanging off the volume: negative coordinates alias to index 0 (float->uint
+    saturation), taps beyond the high end are dropped -- in the Gaussian scatter, the forward
+    gather and both tiled back-projections, exactly like the oracle."""
     from fetalreconstruction_amd import geometry as geo
     P = phantom.make_problem(1, (12, 12, 2), 1.0, 2.0, None, 1.0, 14.0, seed=5, orientations=("ax",),
                              motion_frac=0.0, noise_sigma=0.0)
-    shift = geo.rigid_matrix(tx=-14.2, ty=-14.4, tz=-14.6)
+    t = geo.rigid_matrix(tx=shift[0], ty=shift[1], tz=shift[2])
     for k in range(P.ns):
-        P.slice_t[k] = geo.to_matrix4(shift)
-        P.slice_tinv[k] = geo.to_matrix4(np.linalg.inv(shift))
+        P.slice_t[k] = geo.to_matrix4(t)
+        P.slice_tinv[k] = geo.to_matrix4(np.linalg.inv(t))
     P.mask[...] = 1.0
     P.slices[...] = 100.0
+    P.slices[:, ::3, ::2] = 140.0
     E, rec, orc, dg, do = _drivers(P, oracle_mod)
+    rec.set_option("back_mode", back_mode)
     run_to_state(dg, "sim")
     run_to_state(do, "sim")
+    assert (orc.psf_sums != 0).any()
     assert np.array_equal(rec.debug_get(E.BUF_PSF_SUMS) != 0, orc.psf_sums != 0)
     assert rel_err(rec.getVolWeights(), orc.volw) < TOL_SUM
     assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
+    for e in (rec, orc):
+        e.InitializeEMValues()
+    orc.simslices[...] = np.where(orc.simslices > 0, orc.simslices * 0.9, 0)   # a non-zero residual
+    rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+    rec.debug_set(E.BUF_PSF_SUMS, orc.psf_sums)
+    rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+    orc.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+    cm = rec.debug_get(E.BUF_CONFIDENCE_MAP)
+    assert (orc.cmap > 0).any()
+    assert np.array_equal(cm > 0, orc.cmap > 0)
+    assert rel_err(cm, orc.cmap) < TOL_SUM
+    assert rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < TOL_SUM
 
 
 def test_ragged_and_empty_inputs(oracle_mod):
