@@ -1,0 +1,67 @@
+"""N>1 path on CPU: world-size-2 gloo run of the sharded driver (slice sharding, volume-pair
+all-reduce, M-step scalar all-reduce, per-slice all-gathers) with the oracle as each rank's engine,
+against the single-process run of the same problem."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+
+from fetalreconstruction_amd import phantom
+from fetalreconstruction_amd.reconstruction import irtkReconstruction, shard_slices
+
+
+def _problem():
+    return phantom.make_problem(2, (18, 18, 3), 1.2, 2.4, None, 1.0, 11.5, seed=4, orientations=("ax", "cor"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    from fetalreconstruction_amd.reconstruction import TorchComm
+    from oracle import pyoracle as po
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        P = _problem()
+        act = (P.slices != -1).reshape(P.ns, -1).sum(1)
+        lo, hi = shard_slices(act, world)[rank]
+        eng = po.OracleReconstruction(phantom.sub_problem(P, lo, hi), po.CANON)
+        drv = irtkReconstruction(eng, P.ns, (lo, hi), TorchComm(), P.max_intensity, P.min_intensity)
+        drv.SetSmoothingParameters(150, 0.02)
+        drv.reconstruct_iteration(1)
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), recon=eng.recon, scale=drv._scale_gpu,
+                 sw=drv._slice_weight_gpu, em=np.array([drv._sigma_gpu, drv._mix_gpu, drv._m_gpu, drv._mix_s_gpu]),
+                 lohi=np.array([lo, hi]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world_size_2_matches_single_process(oracle_mod):
+    import torch.multiprocessing as mp
+    P = _problem()
+    eng = oracle_mod.OracleReconstruction(P, oracle_mod.CANON)
+    ref = irtkReconstruction(eng, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
+    ref.SetSmoothingParameters(150, 0.02)
+    ref.reconstruct_iteration(1)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0, r1 = np.load(os.path.join(d, "rank0.npz")), np.load(os.path.join(d, "rank1.npz"))
+    assert r0["lohi"][0] == 0 and r0["lohi"][1] == r1["lohi"][0] and r1["lohi"][1] == P.ns   # every slice kept
+    # both ranks end with the same volume and the same host state ...
+    assert np.array_equal(r0["recon"], r1["recon"])
+    assert np.array_equal(r0["scale"], r1["scale"]) and np.array_equal(r0["sw"], r1["sw"])
+    # ... which is the single-process result up to the float32 rounding of the per-rank partial sums
+    scale = np.abs(eng.recon).max()
+    assert np.max(np.abs(r0["recon"] - eng.recon)) < 2e-5 * scale
+    assert np.allclose(r0["scale"], ref._scale_gpu, rtol=1e-5)
+    assert np.allclose(r0["sw"], ref._slice_weight_gpu, atol=1e-4)
+    assert np.allclose(r0["em"], [ref._sigma_gpu, ref._mix_gpu, ref._m_gpu, ref._mix_s_gpu], rtol=1e-5)
