@@ -20,6 +20,11 @@ import math
 import numpy as np
 
 
+def _seqsum(a):
+    """Sequential (left-to-right) double sum, like a `for` loop with `sum += x`."""
+    return float(np.cumsum(a, dtype=np.float64)[-1]) if len(a) else 0.0
+
+
 class LocalComm:
     """Single-process communicator (world_size 1)."""
 
@@ -242,7 +247,10 @@ class irtkReconstruction:
         return self._step * math.exp(-x * x / (2 * s)) / (math.sqrt(6.28 * s))
 
     def EStepGPU(self):
-        """RG.cc:3184-3440: voxel posteriors on the GPU, slice-level EM on the host."""
+        """RG.cc:3184-3440: voxel posteriors on the GPU, slice-level EM on the host.
+
+        Vectorised with numpy; every reduction is a sequential double sum (`_seqsum`) like the
+        reference's `sum += ...` loops, so the result is the loop's bit for bit."""
         f32 = np.float32
         pot = self._gather(self.reconstructionGPU.EStep(self._m_gpu, self._sigma_gpu, self._mix_gpu))
         pot = pot.astype(np.float32).copy()
@@ -251,30 +259,17 @@ class irtkReconstruction:
             pot[i] = -1
         for i in self._small_slices:
             pot[i] = -1
-        for i in range(self.ns):
-            if (self._scale_gpu[i] < 0.2) or (self._scale_gpu[i] > 5):
-                pot[i] = -1
-        s = den = s2 = den2 = 0.0
-        maxs, mins = 0.0, 1.0
-        for i in range(self.ns):
-            if pot[i] >= 0:
-                p, wi = float(pot[i]), float(w[i])
-                s += p * wi
-                den += wi
-                s2 += p * (1.0 - wi)
-                den2 += (1.0 - wi)
-                maxs = max(maxs, p)
-                mins = min(mins, p)
+        pot[(self._scale_gpu < 0.2) | (self._scale_gpu > 5)] = -1           # RG.cc:3212-3215
+        ok = pot >= 0
+        p64, w64 = pot[ok].astype(np.float64), w[ok].astype(np.float64)
+        s, den = _seqsum(p64 * w64), _seqsum(w64)
+        s2, den2 = _seqsum(p64 * (1.0 - w64)), _seqsum(1.0 - w64)
+        maxs = max(0.0, float(p64.max())) if p64.size else 0.0
+        mins = min(1.0, float(p64.min())) if p64.size else 1.0
         mean_s = float(f32(s / den)) if den > 0 else float(f32(mins))
         mean_s2 = float(f32(s2 / den2)) if den2 > 0 else float(f32((maxs + mean_s) / 2.0))
-        s = den = s2 = den2 = 0.0
-        for i in range(self.ns):
-            if pot[i] >= 0:
-                p, wi = float(pot[i]), float(w[i])
-                s += (p - mean_s) * (p - mean_s) * wi
-                den += wi
-                s2 += (p - mean_s2) * (p - mean_s2) * (1 - wi)
-                den2 += (1 - wi)
+        s = _seqsum((p64 - mean_s) * (p64 - mean_s) * w64)
+        s2 = _seqsum((p64 - mean_s2) * (p64 - mean_s2) * (1 - w64))
         floor = self._step * self._step / 6.28
         if s > 0 and den > 0:
             sigma_s = float(f32(s / den))
@@ -291,32 +286,26 @@ class irtkReconstruction:
             if sigma_s2 < floor:
                 sigma_s2 = float(f32(floor))
         mix_s = float(f32(self._mix_s_gpu))
-        for i in range(self.ns):
-            p = float(pot[i])
-            if pot[i] == -1:
-                w[i] = 0
-                continue
-            if den <= 0 or mean_s2 <= mean_s:
-                w[i] = 1
-                continue
-            gs1 = self._G(p - mean_s, sigma_s) if p < mean_s2 else 0.0
-            gs2 = self._G(p - mean_s2, sigma_s2) if p > mean_s else 0.0
-            likelihood = gs1 * mix_s + gs2 * (1 - mix_s)
-            if likelihood > 0:
-                w[i] = f32(gs1 * mix_s / likelihood)
-            else:
-                if p <= mean_s:
-                    w[i] = 1
-                if p >= mean_s2:
-                    w[i] = 0
-                if p < mean_s2 and p > mean_s:
-                    w[i] = 1
-        tot, num = 0.0, 0
-        for i in range(self.ns):
-            if pot[i] >= 0:
-                tot += float(w[i])
-                num += 1
-        self._mix_s_gpu = float(f32(tot / num)) if num > 0 else 0.9
+        # slice weights, RG.cc:3365-3404
+        neg = pot == -1
+        if den <= 0 or mean_s2 <= mean_s:
+            neww = np.ones(self.ns, np.float32)
+        else:
+            p = pot.astype(np.float64)
+            with np.errstate(over="ignore", under="ignore", invalid="ignore", divide="ignore"):
+                g1 = np.where(p < mean_s2, self._step * np.exp(-(p - mean_s) ** 2 / (2 * sigma_s)) / math.sqrt(6.28 * sigma_s), 0.0)
+                g2 = np.where(p > mean_s, self._step * np.exp(-(p - mean_s2) ** 2 / (2 * sigma_s2)) / math.sqrt(6.28 * sigma_s2), 0.0)
+                like = g1 * mix_s + g2 * (1 - mix_s)
+                neww = np.where(like > 0, g1 * mix_s / np.where(like > 0, like, 1.0), w.astype(np.float64))
+            zero_like = ~(like > 0)
+            neww = np.where(zero_like & (p <= mean_s), 1.0, neww)
+            neww = np.where(zero_like & (p >= mean_s2), 0.0, neww)
+            neww = np.where(zero_like & (p < mean_s2) & (p > mean_s), 1.0, neww)
+            neww = neww.astype(np.float32)
+        neww[neg] = 0
+        w[...] = neww
+        num = int(ok.sum())
+        self._mix_s_gpu = float(f32(_seqsum(w[ok].astype(np.float64)) / num)) if num > 0 else 0.9
         self._mean_s_gpu, self._mean_s2_gpu = mean_s, mean_s2
         self._sigma_s_gpu, self._sigma_s2_gpu = sigma_s, sigma_s2
         self._slice_potential_gpu = pot
