@@ -1133,6 +1133,67 @@ __global__ void k_scale_volume(float *recon, float scale, size_t n) {
   if (i < n && recon[i] > 0) recon[i] = recon[i] * scale;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// slice-to-volume NCC cost (the CPU-default registration metric):
+// irtkImageRigidRegistrationWithPadding::Evaluate + irtkCrossCorrelationSimilarityMetric.
+// One workgroup per (target slice, candidate transform): every target pixel >= 0 is mapped into the
+// source volume, trilinearly interpolated in double in EvaluateInside's operation order, rounded
+// like IRTK's round(), and the six integer moments are accumulated exactly in int64 and reduced
+// with wavefront shuffles -- order-independent, so the moments equal the serial CPU loop's.
+// ------------------------------------------------------------------------------------------
+__global__ void k_f32_to_i16(const float *in, short *out, size_t n) {   // static_cast<short>(float): truncation
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (short)in[i];
+}
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_ncc(const short *targets, int tx, int ty, const int *target_index,
+                                             const double *mats, const short *source, int vx, int vy, int vz,
+                                             long long *sums) {
+  __shared__ long long sm[4][6];
+  const int e = blockIdx.x;
+  const short *tgt = targets + (size_t)target_index[e] * tx * ty;
+  const double *M = mats + 16 * (size_t)e;
+  const double m00 = M[0], m01 = M[1], m03 = M[3], m10 = M[4], m11 = M[5], m13 = M[7], m20 = M[8], m21 = M[9],
+               m23 = M[11];
+  const double sx2 = vx - 1, sy2 = vy - 1, sz2 = vz - 1;
+  const size_t o3 = vx, o5 = (size_t)vx * vy;
+  long long a_n = 0, a_x = 0, a_y = 0, a_x2 = 0, a_y2 = 0, a_xy = 0;
+  for (int p = threadIdx.x; p < tx * ty; p += 256) {
+    const int tv = tgt[p];
+    if (tv < 0) continue;
+    const int j = p / tx, i = p - j * tx;
+    const double X = m00 * i + m01 * j + m03, Y = m10 * i + m11 * j + m13, Z = m20 * i + m21 * j + m23;
+    if ((X > 0) && (X < sx2) && (Y > 0) && (Y < sy2) && (Z > 0) && (Z < sz2)) {
+      const int a = (int)X, b = (int)Y, c = (int)Z;
+      const double t1 = X - a, u1 = Y - b, v1 = Z - c, t2 = 1 - t1, u2 = 1 - u1, v2 = 1 - v1;
+      const short *q = source + a + (size_t)b * o3 + (size_t)c * o5;
+      const double value = (t1 * (u2 * (v2 * q[1] + v1 * q[o5 + 1]) + u1 * (v2 * q[o3 + 1] + v1 * q[o5 + o3 + 1])) +
+                            t2 * (u2 * (v2 * q[0] + v1 * q[o5]) + u1 * (v2 * q[o3] + v1 * q[o5 + o3])));
+      if (value >= 0) {
+        const int sv = value > 0 ? (int)(value + 0.5) : (int)(value - 0.5);   // irtkCommon.h:85-88
+        a_n += 1; a_x += tv; a_y += sv; a_x2 += (long long)tv * tv; a_y2 += (long long)sv * sv;
+        a_xy += (long long)tv * sv;
+      }
+    }
+  }
+  long long v[6] = {a_n, a_x, a_y, a_x2, a_y2, a_xy};
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    v[k] = wave_sum_i64(v[k]);
+    if (lane == 0) sm[w][k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) sums[6 * (size_t)e + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1196,6 +1257,11 @@ struct svr_ctx {
   // reductions
   double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
   int chunks = 0;
+
+  // registration cost (NCC)
+  short *d_reg_targets = nullptr, *d_reg_source = nullptr;
+  int reg_tx = 0, reg_ty = 0, reg_n = 0;
+  uint32_t reg_vx = 0, reg_vy = 0, reg_vz = 0;
 
   // timers
   bool timers = false;
@@ -1471,6 +1537,8 @@ void svr_destroy(svr_ctx *ctx) {
   free_volume(ctx);
   free_slices(ctx);
   free_dev(ctx->d_mask);
+  free_dev(ctx->d_reg_targets);
+  free_dev(ctx->d_reg_source);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -2100,6 +2168,77 @@ int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals40
   (void)hipFree(d_v);
   (void)hipFree(d_c);
   if (e != hipSuccess) return fail(ctx, (int)e, "svr_debug_probe_pixel");
+  return SVR_OK;
+}
+
+// ---- slice-to-volume registration cost --------------------------------------------------
+int svr_ncc_set_targets(svr_ctx *ctx, int n, int tx, int ty, const int16_t *targets) {
+  if (!ctx || !targets || n <= 0 || tx <= 0 || ty <= 0) return SVR_E_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  free_dev(ctx->d_reg_targets);
+  const size_t bytes = (size_t)n * tx * ty * sizeof(short);
+  HIPCHK(hipMalloc(&ctx->d_reg_targets, bytes));
+  HIPCHK(hipMemcpyAsync(ctx->d_reg_targets, targets, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->reg_n = n; ctx->reg_tx = tx; ctx->reg_ty = ty;
+  return SVR_OK;
+}
+
+int svr_ncc_set_source(svr_ctx *ctx, const uint32_t size[3], const int16_t *source_or_null) {
+  if (!ctx) return SVR_E_ARG;
+  if (!source_or_null) NEED(ctx->nv > 0, "no source given and no reconstruction volume");
+  uint32_t sx = source_or_null ? size[0] : ctx->vx, sy = source_or_null ? size[1] : ctx->vy,
+           sz = source_or_null ? size[2] : ctx->vz;
+  const size_t n = (size_t)sx * sy * sz;
+  if (n == 0) return SVR_E_ARG;
+  free_dev(ctx->d_reg_source);
+  HIPCHK(hipMalloc(&ctx->d_reg_source, n * sizeof(short)));
+  if (source_or_null) {
+    HIPCHK(hipMemcpyAsync(ctx->d_reg_source, source_or_null, n * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    // irtkGreyImage source = _reconstructed  (RG.cc:2031): static_cast<short> of every voxel
+    hipLaunchKernelGGL(k_f32_to_i16, dim3(nblk(n)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_reg_source, n);
+    KCHK("k_f32_to_i16");
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->reg_vx = sx; ctx->reg_vy = sy; ctx->reg_vz = sz;
+  return SVR_OK;
+}
+
+int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const double *matrices,
+                     int64_t *sums6, double *ncc) {
+  if (!ctx || n_eval <= 0 || !target_index || !matrices) return SVR_E_ARG;
+  NEED(ctx->d_reg_targets && ctx->d_reg_source, "svr_ncc_set_targets / svr_ncc_set_source first");
+  for (int i = 0; i < n_eval; ++i)
+    if (target_index[i] < 0 || target_index[i] >= ctx->reg_n) return fail(ctx, SVR_E_ARG, "target index out of range");
+  int *d_idx = nullptr;
+  double *d_m = nullptr;
+  long long *d_s = nullptr;
+  HIPCHK(hipMalloc(&d_idx, n_eval * sizeof(int)));
+  HIPCHK(hipMalloc(&d_m, (size_t)n_eval * 16 * sizeof(double)));
+  HIPCHK(hipMalloc(&d_s, (size_t)n_eval * 6 * sizeof(long long)));
+  std::vector<long long> h((size_t)n_eval * 6);
+  hipError_t e = hipMemcpyAsync(d_idx, target_index, n_eval * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_m, matrices, (size_t)n_eval * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_ncc, dim3(n_eval), dim3(256), 0, ctx->stream, ctx->d_reg_targets, ctx->reg_tx, ctx->reg_ty,
+                       d_idx, d_m, ctx->d_reg_source, (int)ctx->reg_vx, (int)ctx->reg_vy, (int)ctx->reg_vz, d_s);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_s, h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_idx); (void)hipFree(d_m); (void)hipFree(d_s);
+  if (e != hipSuccess) return fail(ctx, (int)e, "svr_ncc_evaluate");
+  for (int i = 0; i < n_eval; ++i) {
+    const long long *s = &h[6 * (size_t)i];
+    if (sums6) for (int k = 0; k < 6; ++k) sums6[6 * (size_t)i + k] = s[k];
+    if (ncc) {
+      // irtkCrossCorrelationSimilarityMetric::Evaluate (…Metric.h:158-165)
+      const double n = (double)s[0], x = (double)s[1], y = (double)s[2], x2 = (double)s[3], y2 = (double)s[4],
+                   xy = (double)s[5];
+      ncc[i] = n > 0 ? (xy - (x * y) / n) / (sqrt(x2 - x * x / n) * sqrt(y2 - y * y / n)) : 0.0;
+    }
+  }
   return SVR_OK;
 }
 

@@ -36,7 +36,8 @@ EXPORTS = [
     "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
-    "svr_timer_reset", "svr_timer_enable", "svr_counters",
+    "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_ncc_set_targets", "svr_ncc_set_source",
+    "svr_ncc_evaluate",
 ]
 
 
@@ -276,6 +277,27 @@ class Reconstruction:
     def debug_set(self, which, arr):
         a = np.ascontiguousarray(arr)
         self._ck(self._lib.svr_debug_set(self._h, int(which), _p(a), C.c_size_t(a.nbytes)))
+
+    # ---- slice-to-volume registration cost ------------------------------------------------
+    def ncc_set_targets(self, targets):
+        t = np.ascontiguousarray(targets, np.int16)
+        n, ty, tx = t.shape
+        self._ck(self._lib.svr_ncc_set_targets(self._h, n, tx, ty, _p(t)))
+
+    def ncc_set_source(self, source=None):
+        if source is None:
+            self._ck(self._lib.svr_ncc_set_source(self._h, None, None))
+        else:
+            s = np.ascontiguousarray(source, np.int16)
+            self._ck(self._lib.svr_ncc_set_source(self._h, _u3(s.shape[::-1]), _p(s)))
+
+    def ncc_evaluate(self, target_index, matrices):
+        idx = np.ascontiguousarray(target_index, np.int32)
+        m = np.ascontiguousarray(matrices, np.float64).reshape(len(idx), 16)
+        sums = np.zeros((len(idx), 6), np.int64)
+        ncc = np.zeros(len(idx), np.float64)
+        self._ck(self._lib.svr_ncc_evaluate(self._h, len(idx), _p(idx), _p(m), _p(sums), _p(ncc)))
+        return ncc, sums
 
     def set_option(self, name, value):
         self._ck(self._lib.svr_set_option(self._h, name.encode(), int(value)))

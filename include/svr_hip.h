@@ -159,6 +159,20 @@ int svr_mstep_sums(svr_ctx *ctx, double out5[5]);
 int svr_scale_volume_sums(svr_ctx *ctx, double out2[2]);
 int svr_scale_volume_apply(svr_ctx *ctx, float scale);
 
+/* ---- slice-to-volume registration cost -------------------------------------
+ * The metric of the reference's DEFAULT registration path: irtkImageRigidRegistrationWithPadding::
+ * Evaluate (IRTKSimple2/packages/registration/src/irtkImageRigidRegistrationWithPadding.cc:534-610)
+ * with irtkCrossCorrelationSimilarityMetric (.../include/irtkCrossCorrelationSimilarityMetric.h:66-165),
+ * batched over (target slice, candidate transform) pairs so an optimiser step is one call.
+ * targets: n resampled slices, short [n][ty][tx], padding < 0 (irtkReconstructionGPU.cc:2008-2016).
+ * source: the volume as short; NULL = static_cast<short> of the current reconstruction (RG.cc:2031).
+ * matrices: per evaluation a row-major double 4x4 = sourceW2I * T * targetI2W
+ * (irtkHomogeneousTransformationIterator.h:96).  sums6 = {n, sum t, sum s, sum t^2, sum s^2, sum t*s}. */
+int svr_ncc_set_targets(svr_ctx *ctx, int n, int tx, int ty, const int16_t *targets);
+int svr_ncc_set_source(svr_ctx *ctx, const uint32_t size[3], const int16_t *source_or_null);
+int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const double *matrices,
+                     int64_t *sums6_or_null, double *ncc_or_null);
+
 /* ---- measurement -------------------------------------------------------------------- */
 enum svr_timer {
   SVR_T_BACKPROJECT = 0, SVR_T_FORWARD = 1, SVR_T_GAUSS = 2, SVR_T_REGULARIZE = 3,

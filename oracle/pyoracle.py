@@ -46,6 +46,7 @@ def lib():
         _LIB.orc_tap_census.restype = C.c_int
         _LIB.orc_initialize_robust_statistics.restype = C.c_float
         _LIB.orc_scale_volume.restype = C.c_float
+        _LIB.orc_ncc_evaluate.restype = C.c_double
     return _LIB
 
 
@@ -250,3 +251,17 @@ def host_estep(slice_potential, slice_weight, scale, force_excluded, small_slice
     st = _f32(state5).copy()
     lib().orc_host_estep(len(pot), _p(pot), _p(w), _p(sc), _p(fe), len(fe), _p(ss), len(ss), C.c_double(step), _p(st))
     return pot, w, st
+
+
+def ncc_evaluate(target, M, source):
+    """irtkImageRigidRegistrationWithPadding::Evaluate on one (target slice, source volume, matrix)."""
+    t = np.ascontiguousarray(target, np.int16)
+    if t.ndim == 2:
+        t = t[None]
+    src = np.ascontiguousarray(source, np.int16)
+    m = np.ascontiguousarray(M, np.float64).reshape(16)
+    sums = np.zeros(6, np.float64)
+    tz, ty, tx = t.shape
+    vz, vy, vx = src.shape
+    v = lib().orc_ncc_evaluate(_p(t), tx, ty, tz, _p(m), _p(src), vx, vy, vz, _p(sums))
+    return float(v), sums

@@ -743,3 +743,72 @@ void orc_host_estep(int ns, float *slice_potential, float *slice_weight, const f
   mix_s = (num > 0) ? (float)(sum / num) : 0.9f;
   state5[0] = mean_s; state5[1] = mean_s2; state5[2] = sigma_s; state5[3] = sigma_s2; state5[4] = mix_s;
 }
+
+/* ============== slice-to-volume NCC cost (CPU default registration path) ===============
+ * irtkImageRigidRegistrationWithPadding::Evaluate
+ *   (IRTKSimple2/packages/registration/src/irtkImageRigidRegistrationWithPadding.cc:534-610)
+ * + irtkHomogeneousTransformationIterator (packages/transformation/include/...Iterator.h:86-174)
+ * + irtkLinearInterpolateImageFunction::EvaluateInside (image++/src/irtkLinearInterpolateImageFunction.cc:59-99)
+ * + irtkCrossCorrelationSimilarityMetric::Add/Evaluate (registration/include/...Metric.h:66-165)
+ * + irtkPadding run-length encoding of the padded target (registration/src/irtkUtil.cc:105-155).
+ * target: short [tz][ty][tx], padding = -1.  M: 4x4 row-major double = sourceW2I * T * targetI2W.
+ * source: short [vz][vy][vx].  sums6 = {n, x, y, x2, y2, xy} (integers held in doubles). */
+static int irtk_round(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); } /* irtkCommon.h:85-88 */
+
+double orc_ncc_evaluate(const short *target_in, int tx, int ty, int tz, const double *M, const short *source,
+                        int vx, int vy, int vz, double sums6[6]) {
+  size_t nt = (size_t)tx * ty * tz;
+  short *target = (short *)malloc(nt * sizeof(short));
+  memcpy(target, target_in, nt * sizeof(short));
+  /* irtkPadding: a run of -1 along x becomes -(distance to the end of the run) */
+  for (int k = 0; k < tz; k++) for (int j = 0; j < ty; j++) for (int i = 0; i < tx; i++) {
+    short *row = target + ((size_t)k * ty + j) * tx;
+    if (row[i] == -1) {
+      int l;
+      for (l = i; l < tx; l++) if (row[l] != -1) break;
+      for (int p = i; p < l; p++) row[p] = (short)(-(l - p));
+      i = l - 1;
+    }
+  }
+  double _xy = 0, _x = 0, _y = 0, _x2 = 0, _y2 = 0, _n = 0;
+  /* iterator.Initialize(target, source) at (0,0,0) */
+  double X = M[3], Y = M[7], Z = M[11];
+  double xx = X, xy = Y, xz = Z, yx = X, yy = Y, yz = Z, zx = X, zy = Y, zz = Z;
+  const double xdx = M[0], xdy = M[4], xdz = M[8], ydx = M[1], ydy = M[5], ydz = M[9], zdx = M[2], zdy = M[6],
+               zdz = M[10];
+  const double sx1 = 0, sy1 = 0, sz1 = 0, sx2 = vx - 1, sy2 = vy - 1, sz2 = vz - 1;
+  const size_t o3 = vx, o5 = (size_t)vx * vy;
+  const short *ptr = target;
+  for (int k = 0; k < tz; k++) {
+    for (int j = 0; j < ty; j++) {
+      for (int i = 0; i < tx; i++) {
+        if (*ptr >= 0) {
+          if ((X > sx1) && (X < sx2) && (Y > sy1) && (Y < sy2) && (Z > sz1) && (Z < sz2)) {
+            int a = (int)X, b = (int)Y, c = (int)Z;
+            double t1 = X - a, u1 = Y - b, v1 = Z - c, t2 = 1 - t1, u2 = 1 - u1, v2 = 1 - v1;
+            const short *q = source + a + (size_t)b * o3 + (size_t)c * o5;
+            double value = (t1 * (u2 * (v2 * q[1] + v1 * q[o5 + 1]) + u1 * (v2 * q[o3 + 1] + v1 * q[o5 + o3 + 1])) +
+                            t2 * (u2 * (v2 * q[0] + v1 * q[o5]) + u1 * (v2 * q[o3] + v1 * q[o5 + o3])));
+            if (value >= 0) {
+              int tv = *ptr, sv = irtk_round(value);
+              _xy += (double)tv * sv; _x += tv; _x2 += (double)tv * tv; _y += sv; _y2 += (double)sv * sv; _n++;
+            }
+          }
+          X = xx += xdx; Y = xy += xdy; Z = xz += xdz;                     /* NextX() */
+        } else {
+          double off = *ptr * -1;                                            /* NextX(offset) */
+          X = xx += xdx * off; Y = xy += xdy * off; Z = xz += xdz * off;
+          i -= (*ptr) + 1;
+          ptr -= (*ptr) + 1;
+        }
+        ptr++;
+      }
+      yx += ydx; yy += ydy; yz += ydz; X = xx = yx; Y = xy = yy; Z = xz = yz;  /* NextY() */
+    }
+    zx += zdx; zy += zdy; zz += zdz; X = xx = yx = zx; Y = xy = yy = zy; Z = xz = yz = zz;  /* NextZ() */
+  }
+  free(target);
+  sums6[0] = _n; sums6[1] = _x; sums6[2] = _y; sums6[3] = _x2; sums6[4] = _y2; sums6[5] = _xy;
+  if (_n > 0) return (_xy - (_x * _y) / _n) / (sqrt(_x2 - _x * _x / _n) * sqrt(_y2 - _y * _y / _n));
+  return 0;
+}
