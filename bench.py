@@ -71,7 +71,8 @@ def main():
 
     import torch
     from fetalreconstruction_amd import engine, phantom
-    from fetalreconstruction_amd.reconstruction import LocalComm, TorchComm, irtkReconstruction, shard_slices
+    from fetalreconstruction_amd.host import irtkReconstruction          # the C++ host object
+    from fetalreconstruction_amd.reconstruction import LocalComm, TorchComm, shard_slices
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +107,8 @@ def main():
 
     rec = engine.Reconstruction(local_rank)
     engine.sync_gpu(rec, local)
-    drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity)
+    drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm if world > 1 else None, prob.max_intensity,
+                             prob.min_intensity)
     drv.SetSmoothingParameters(150, 0.02)      # reconstruction.cc:99-100 defaults (delta, lambda)
 
     # untimed set-up: the part of an outer iteration before the SR loop (reconstruction.cc:930-1001)
@@ -156,9 +158,9 @@ def main():
             "value": value, "unit": "MVoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{prob.name}: {4 * world if args.workload == 'P4' else prob.ns} stacks/slices "
-                                   f"synthetic, volume {prob.vsize}, {prob.ns} slices of {prob.slices.shape[2]}x"
-                                   f"{prob.slices.shape[1]}, recon {prob.vdim[0]} mm",
+            "config": {"workload": f"{prob.name}: {int(prob.stack_index.max()) + 1} synthetic stacks, volume {prob.vsize}, "
+                                   f"{prob.ns} slices of {prob.slices.shape[2]}x{prob.slices.shape[1]}, "
+                                   f"recon {prob.vdim[0]} mm",
                        "Vs": vs, "Va_rank0": va_l, "Va_total": va, "Nv": nv, "slices": prob.ns,
                        "parallelism": f"slice-sharded x{world}, 1 volume all-reduce per scatter pass"},
             "roofline": {

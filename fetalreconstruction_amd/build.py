@@ -11,7 +11,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "svr_hip.hip")
+SRC_HOST = os.path.join(HERE, "csrc", "svr_host.cpp")     # plain host C++ (the irtkReconstruction mirror)
 INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
+INC_HOST = os.path.join(os.path.dirname(HERE), "include", "svr_host.h")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libsvr_hip.so")
 
@@ -35,14 +37,14 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, INC, __file__))
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_HOST, INC, INC_HOST, __file__))
 
 
 def build(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra, "-o", OUT, SRC]
+    cmd = [hipcc(), *FLAGS, *extra, "-o", OUT, SRC, SRC_HOST]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,355 @@
+// svr_host.cpp -- svr::irtkReconstruction: the reference's host algorithm object (GPU operator
+// surface of irtkReconstruction, irtkReconstructionGPU.cc = "RG.cc") in C++ above the C-ABI engine.
+// Plain host C++: no HIP calls here, everything device-side goes through include/svr_hip.h.
+#include <math.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/svr_host.h"
+
+namespace svr {
+
+class irtkReconstruction {
+ public:
+  // engine + sharding
+  svr_ctx *reconstructionGPU;          // RG.h: Reconstruction* reconstructionGPU
+  int ns, lo, hi;
+  svr_collectives coll;
+  bool have_coll;
+  std::string err;
+
+  // members named as in RG.h / RG.cc:159-221
+  double _step;
+  int _quality_factor;
+  float _sigma_bias;
+  float _sigma_gpu, _mix_gpu, _m_gpu;
+  float _mean_s_gpu, _mean_s2_gpu, _sigma_s_gpu, _sigma_s2_gpu, _mix_s_gpu;
+  double _delta, _lambda, _alpha;
+  float _low_intensity_cutoff;
+  bool _global_bias_correction, _adaptive;
+  double _max_intensity, _min_intensity;
+  std::vector<int> _force_excluded, _small_slices;
+  std::vector<float> _scale_gpu, _slice_weight_gpu, _slice_potential_gpu;
+  std::vector<unsigned char> _slice_inside_gpu;
+
+  irtkReconstruction(svr_ctx *engine, int n_global, int lo_, int hi_, const svr_collectives *c)
+      : reconstructionGPU(engine), ns(n_global), lo(lo_), hi(hi_), have_coll(c != nullptr && c->world > 1) {
+    if (c) coll = *c;
+    else { coll.user = nullptr; coll.rank = 0; coll.world = 1; coll.allreduce_volume_pair = nullptr;
+           coll.allreduce_host = nullptr; coll.allgather_slices = nullptr; }
+    _step = 0.0001;
+    _quality_factor = 2;
+    _sigma_bias = 12;
+    _sigma_s_gpu = 0.025f;
+    _sigma_s2_gpu = 0.025f;
+    _mix_s_gpu = 0.9f;
+    _mix_gpu = 0.9f;
+    _delta = 1;
+    _lambda = 0.1f;
+    _alpha = (0.05f / _lambda) * _delta * _delta;
+    _low_intensity_cutoff = 0.01f;
+    _global_bias_correction = false;
+    _adaptive = false;
+    _max_intensity = 1; _min_intensity = 0;
+    _sigma_gpu = 0; _m_gpu = 0; _mean_s_gpu = 0; _mean_s2_gpu = 0;
+    _scale_gpu.assign(ns, 1.0f);
+    _slice_weight_gpu.assign(ns, 1.0f);
+    _slice_potential_gpu.assign(ns, 0.0f);
+    _slice_inside_gpu.assign(ns, 1);
+  }
+
+  int fail(int rc, const char *what) {
+    err = std::string(what) + ": " + (rc >= 10000 || rc < 0 ? "" : "hip error ") + std::to_string(rc) + " " +
+          svr_last_error(reconstructionGPU);
+    return rc;
+  }
+#define ENG(call) do { int rc_ = (call); if (rc_) return fail(rc_, #call); } while (0)
+
+  // -- sharding helpers ------------------------------------------------------------------
+  const float *local(const std::vector<float> &v) const { return v.data() + lo; }
+  int gather(const std::vector<float> &loc, std::vector<float> &glob) {
+    glob.resize(ns);
+    if (!have_coll) { std::copy(loc.begin(), loc.end(), glob.begin()); return 0; }
+    return coll.allgather_slices(coll.user, loc.data(), hi - lo, glob.data(), ns);
+  }
+
+  // RG.h:605-612
+  void SetSmoothingParameters(double delta, double lambda) {
+    _delta = delta;
+    _lambda = lambda * delta * delta;
+    _alpha = 0.05 / lambda;
+    if (_alpha > 1) _alpha = 1;
+  }
+
+  // RG.cc:2905-2919
+  int InitializeEMValuesGPU() {
+    _slice_weight_gpu.assign(ns, 1);
+    _scale_gpu.assign(ns, 1);
+    ENG(svr_update_scale_vector(reconstructionGPU, local(_scale_gpu), local(_slice_weight_gpu)));
+    ENG(svr_initialize_em_values(reconstructionGPU));
+    return 0;
+  }
+
+  // RG.cc:2695-2762.  voxel_num has one entry per device and its median indexes out of range for
+  // one device (RG.cc:2714-2726), so no slice is ever "small" on the GPU path.
+  int GaussianReconstructionGPU() {
+    if (!have_coll) {
+      int n = 0;
+      ENG(svr_gaussian_reconstruction(reconstructionGPU, &n));
+    } else {
+      ENG(svr_gaussian_reconstruction_local(reconstructionGPU));
+      ENG(coll.allreduce_volume_pair(coll.user, svr_device_ptr(reconstructionGPU, SVR_BUF_RECONSTRUCTED),
+                                     2 * svr_volume_voxels(reconstructionGPU)));
+      int n = 0;
+      ENG(svr_gaussian_reconstruction_finish(reconstructionGPU, &n));
+    }
+    _small_slices.clear();
+    return 0;
+  }
+
+  // RG.cc:1163-1175
+  int SimulateSlicesGPU() {
+    std::vector<unsigned char> inside(hi - lo);
+    ENG(svr_simulate_slices(reconstructionGPU, inside.data()));
+    std::vector<float> loc(inside.begin(), inside.end()), glob;
+    ENG(gather(loc, glob));
+    for (int i = 0; i < ns; ++i) _slice_inside_gpu[i] = glob[i] > 0.5f;
+    return 0;
+  }
+
+  // RG.cc:2988-3019
+  int InitializeRobustStatisticsGPU() {
+    if (!have_coll) {
+      ENG(svr_initialize_robust_statistics(reconstructionGPU, &_sigma_gpu));
+    } else {
+      double s2[2];
+      ENG(svr_robust_statistics_sums(reconstructionGPU, s2));
+      ENG(coll.allreduce_host(coll.user, s2, 2, 0));
+      _sigma_gpu = (float)s2[0] / (float)s2[1];
+    }
+    for (int i = 0; i < ns; ++i)
+      if (!_slice_inside_gpu[i]) _slice_weight_gpu[i] = 0;
+    for (size_t i = 0; i < _force_excluded.size(); i++) _slice_weight_gpu[_force_excluded[i]] = 0;
+    _sigma_s_gpu = 0.025f;
+    _mix_gpu = 0.9f;
+    _mix_s_gpu = 0.9f;
+    _m_gpu = (float)(1.0f / (2.1f * _max_intensity - 1.9f * _min_intensity));
+    ENG(svr_update_scale_vector(reconstructionGPU, local(_scale_gpu), local(_slice_weight_gpu)));
+    return 0;
+  }
+
+  double G(double x, double s) { return _step * exp(-x * x / (2 * s)) / (sqrt(6.28 * s)); }   // RG.h:529-532
+
+  // RG.cc:3184-3440: voxel posteriors on the GPU, slice-level EM on the host
+  int EStepGPU() {
+    std::vector<float> loc(hi - lo);
+    ENG(svr_estep(reconstructionGPU, _m_gpu, _sigma_gpu, _mix_gpu, loc.data()));
+    std::vector<float> &slice_potential_gpu = _slice_potential_gpu;
+    ENG(gather(loc, slice_potential_gpu));
+    int inputIndex;
+    for (size_t i = 0; i < _force_excluded.size(); i++) slice_potential_gpu[_force_excluded[i]] = -1;
+    for (size_t i = 0; i < _small_slices.size(); i++) slice_potential_gpu[_small_slices[i]] = -1;
+    for (inputIndex = 0; inputIndex < ns; inputIndex++)
+      if ((_scale_gpu[inputIndex] < 0.2) || (_scale_gpu[inputIndex] > 5)) slice_potential_gpu[inputIndex] = -1;
+
+    double sum = 0, den = 0, sum2 = 0, den2 = 0, maxs = 0, mins = 1;
+    for (inputIndex = 0; inputIndex < ns; inputIndex++)
+      if (slice_potential_gpu[inputIndex] >= 0) {
+        sum += slice_potential_gpu[inputIndex] * _slice_weight_gpu[inputIndex];
+        den += _slice_weight_gpu[inputIndex];
+        sum2 += slice_potential_gpu[inputIndex] * (1.0 - _slice_weight_gpu[inputIndex]);
+        den2 += (1.0 - _slice_weight_gpu[inputIndex]);
+        if (slice_potential_gpu[inputIndex] > maxs) maxs = slice_potential_gpu[inputIndex];
+        if (slice_potential_gpu[inputIndex] < mins) mins = slice_potential_gpu[inputIndex];
+      }
+    if (den > 0) _mean_s_gpu = (float)(sum / den);
+    else _mean_s_gpu = (float)mins;
+    if (den2 > 0) _mean_s2_gpu = (float)(sum2 / den2);
+    else _mean_s2_gpu = (float)((maxs + _mean_s_gpu) / 2.0);
+
+    sum = 0; den = 0; sum2 = 0; den2 = 0;
+    for (inputIndex = 0; inputIndex < ns; inputIndex++)
+      if (slice_potential_gpu[inputIndex] >= 0) {
+        sum += (slice_potential_gpu[inputIndex] - _mean_s_gpu) * (slice_potential_gpu[inputIndex] - _mean_s_gpu) *
+               _slice_weight_gpu[inputIndex];
+        den += _slice_weight_gpu[inputIndex];
+        sum2 += (slice_potential_gpu[inputIndex] - _mean_s2_gpu) * (slice_potential_gpu[inputIndex] - _mean_s2_gpu) *
+                (1 - _slice_weight_gpu[inputIndex]);
+        den2 += (1 - _slice_weight_gpu[inputIndex]);
+      }
+    if ((sum > 0) && (den > 0)) {
+      _sigma_s_gpu = (float)(sum / den);
+      if (_sigma_s_gpu < _step * _step / 6.28) _sigma_s_gpu = (float)(_step * _step / 6.28);
+    } else {
+      _sigma_s_gpu = 0.025f;
+    }
+    if ((sum2 > 0) && (den2 > 0)) {
+      _sigma_s2_gpu = (float)(sum2 / den2);
+      if (_sigma_s2_gpu < _step * _step / 6.28) _sigma_s2_gpu = (float)(_step * _step / 6.28);
+    } else {
+      _sigma_s2_gpu = (_mean_s2_gpu - _mean_s_gpu) * (_mean_s2_gpu - _mean_s_gpu) / 4;
+      if (_sigma_s2_gpu < _step * _step / 6.28) _sigma_s2_gpu = (float)(_step * _step / 6.28);
+    }
+
+    double gs1, gs2;
+    for (inputIndex = 0; inputIndex < ns; inputIndex++) {
+      if (slice_potential_gpu[inputIndex] == -1) { _slice_weight_gpu[inputIndex] = 0; continue; }
+      if ((den <= 0) || (_mean_s2_gpu <= _mean_s_gpu)) { _slice_weight_gpu[inputIndex] = 1; continue; }
+      if (slice_potential_gpu[inputIndex] < _mean_s2_gpu) gs1 = G(slice_potential_gpu[inputIndex] - _mean_s_gpu, _sigma_s_gpu);
+      else gs1 = 0;
+      if (slice_potential_gpu[inputIndex] > _mean_s_gpu) gs2 = G(slice_potential_gpu[inputIndex] - _mean_s2_gpu, _sigma_s2_gpu);
+      else gs2 = 0;
+      double likelihood = gs1 * _mix_s_gpu + gs2 * (1 - _mix_s_gpu);
+      if (likelihood > 0) _slice_weight_gpu[inputIndex] = (float)(gs1 * _mix_s_gpu / likelihood);
+      else {
+        if (slice_potential_gpu[inputIndex] <= _mean_s_gpu) _slice_weight_gpu[inputIndex] = 1;
+        if (slice_potential_gpu[inputIndex] >= _mean_s2_gpu) _slice_weight_gpu[inputIndex] = 0;
+        if ((slice_potential_gpu[inputIndex] < _mean_s2_gpu) && (slice_potential_gpu[inputIndex] > _mean_s_gpu))
+          _slice_weight_gpu[inputIndex] = 1;
+      }
+    }
+    sum = 0;
+    int num = 0;
+    for (inputIndex = 0; inputIndex < ns; inputIndex++)
+      if (slice_potential_gpu[inputIndex] >= 0) { sum += _slice_weight_gpu[inputIndex]; num++; }
+    if (num > 0) _mix_s_gpu = (float)(sum / num);
+    else _mix_s_gpu = 0.9f;
+    ENG(svr_update_slice_weights(reconstructionGPU, local(_slice_weight_gpu)));
+    return 0;
+  }
+
+  // RG.cc:3751-3757
+  int ScaleGPU() {
+    std::vector<float> loc(hi - lo);
+    ENG(svr_calculate_scale_vector(reconstructionGPU, loc.data()));
+    ENG(gather(loc, _scale_gpu));
+    return 0;
+  }
+
+  // RG.cc:4024-4036
+  int SuperresolutionGPU(int iter) {
+    if (!have_coll) {
+      ENG(svr_superresolution(reconstructionGPU, iter, local(_slice_weight_gpu), _adaptive, (float)_alpha,
+                              (float)_min_intensity, (float)_max_intensity, (float)_delta, (float)_lambda,
+                              _global_bias_correction, _sigma_bias, _low_intensity_cutoff));
+    } else {
+      ENG(svr_superresolution_backproject(reconstructionGPU, local(_slice_weight_gpu)));
+      ENG(coll.allreduce_volume_pair(coll.user, svr_device_ptr(reconstructionGPU, SVR_BUF_ADDON),
+                                     2 * svr_volume_voxels(reconstructionGPU)));
+      ENG(svr_superresolution_update(reconstructionGPU, _adaptive, (float)_alpha, (float)_min_intensity,
+                                     (float)_max_intensity, (float)_delta, (float)_lambda));
+    }
+    return 0;
+  }
+
+  // RG.cc:4214-4223 + Reconstruction::MStep host part (reconstruction_cuda2.cu:3016-3071)
+  int MStepGPU(int iter) {
+    if (!have_coll) {
+      ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
+      return 0;
+    }
+    double s5[5];
+    ENG(svr_mstep_sums(reconstructionGPU, s5));
+    ENG(coll.allreduce_host(coll.user, s5, 3, 0));
+    ENG(coll.allreduce_host(coll.user, s5 + 3, 1, 1));
+    ENG(coll.allreduce_host(coll.user, s5 + 4, 1, 2));
+    float sigma = (float)s5[0], mix = (float)s5[1], num = (float)s5[2];
+    float min_ = std::min(3.402823466e+38f, (float)s5[3]);
+    float max_ = std::max(1.175494351e-38f, (float)s5[4]);
+    float step = (float)_step;
+    if (mix > 0) _sigma_gpu = sigma / mix;
+    if (_sigma_gpu < step * step / 6.28f) _sigma_gpu = step * step / 6.28f;
+    if (iter > 1) _mix_gpu = mix / num;
+    _m_gpu = 1.0f / (max_ - min_);
+    return 0;
+  }
+
+  int MaskVolumeGPU() { ENG(svr_mask_volume(reconstructionGPU)); return 0; }   // RG.cc:5319-5323
+
+  int ScaleVolumeGPU() {
+    if (!have_coll) { ENG(svr_scale_volume(reconstructionGPU)); return 0; }
+    double s2[2];
+    ENG(svr_scale_volume_sums(reconstructionGPU, s2));
+    ENG(coll.allreduce_host(coll.user, s2, 2, 0));
+    ENG(svr_scale_volume_apply(reconstructionGPU, (float)(s2[0] / s2[1])));
+    return 0;
+  }
+
+  // reconstruction.cc:1013-1108 with bias correction off
+  int sr_iteration(int i) {
+    int rc;
+    if ((rc = ScaleGPU())) return rc;
+    if ((rc = SuperresolutionGPU(i + 1))) return rc;
+    if ((rc = SimulateSlicesGPU())) return rc;
+    if ((rc = MStepGPU(i + 1))) return rc;
+    return EStepGPU();
+  }
+
+  // reconstruction.cc:930-1140 (one outer iteration after registration)
+  int reconstruct_iteration(int rec_iterations) {
+    int rc;
+    if ((rc = InitializeEMValuesGPU())) return rc;
+    if ((rc = GaussianReconstructionGPU())) return rc;
+    if ((rc = SimulateSlicesGPU())) return rc;
+    if ((rc = InitializeRobustStatisticsGPU())) return rc;
+    if ((rc = EStepGPU())) return rc;
+    for (int i = 0; i < rec_iterations; ++i)
+      if ((rc = sr_iteration(i))) return rc;
+    return MaskVolumeGPU();
+  }
+#undef ENG
+};
+
+}  // namespace svr
+
+struct svrh_recon {
+  svr::irtkReconstruction impl;
+  svrh_recon(svr_ctx *e, int n, int lo, int hi, const svr_collectives *c) : impl(e, n, lo, hi, c) {}
+};
+
+extern "C" {
+
+svrh_recon *svrh_create(svr_ctx *engine, int n_slices_global, int slice_lo, int slice_hi,
+                        const svr_collectives *coll) {
+  if (!engine || n_slices_global <= 0 || slice_lo < 0 || slice_hi > n_slices_global || slice_lo > slice_hi) return nullptr;
+  if (coll && coll->world > 1 && (!coll->allreduce_volume_pair || !coll->allreduce_host || !coll->allgather_slices))
+    return nullptr;
+  return new svrh_recon(engine, n_slices_global, slice_lo, slice_hi, coll);
+}
+void svrh_destroy(svrh_recon *r) { delete r; }
+const char *svrh_last_error(const svrh_recon *r) { return r ? r->impl.err.c_str() : "null"; }
+void svrh_set_intensity_range(svrh_recon *r, double mn, double mx) { r->impl._min_intensity = mn; r->impl._max_intensity = mx; }
+void svrh_set_smoothing_parameters(svrh_recon *r, double delta, double lambda) { r->impl.SetSmoothingParameters(delta, lambda); }
+void svrh_set_force_excluded(svrh_recon *r, const int *idx, int n) { r->impl._force_excluded.assign(idx, idx + n); }
+int svrh_initialize_em_values_gpu(svrh_recon *r) { return r->impl.InitializeEMValuesGPU(); }
+int svrh_gaussian_reconstruction_gpu(svrh_recon *r) { return r->impl.GaussianReconstructionGPU(); }
+int svrh_simulate_slices_gpu(svrh_recon *r) { return r->impl.SimulateSlicesGPU(); }
+int svrh_initialize_robust_statistics_gpu(svrh_recon *r) { return r->impl.InitializeRobustStatisticsGPU(); }
+int svrh_estep_gpu(svrh_recon *r) { return r->impl.EStepGPU(); }
+int svrh_scale_gpu(svrh_recon *r) { return r->impl.ScaleGPU(); }
+int svrh_superresolution_gpu(svrh_recon *r, int iter) { return r->impl.SuperresolutionGPU(iter); }
+int svrh_mstep_gpu(svrh_recon *r, int iter) { return r->impl.MStepGPU(iter); }
+int svrh_mask_volume_gpu(svrh_recon *r) { return r->impl.MaskVolumeGPU(); }
+int svrh_scale_volume_gpu(svrh_recon *r) { return r->impl.ScaleVolumeGPU(); }
+int svrh_sr_iteration(svrh_recon *r, int i) { return r->impl.sr_iteration(i); }
+int svrh_reconstruct_iteration(svrh_recon *r, int n) { return r->impl.reconstruct_iteration(n); }
+
+int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
+                   unsigned char *slice_inside, double s[8]) {
+  if (!r) return SVR_E_ARG;
+  svr::irtkReconstruction &m = r->impl;
+  if (scale) std::copy(m._scale_gpu.begin(), m._scale_gpu.end(), scale);
+  if (slice_weight) std::copy(m._slice_weight_gpu.begin(), m._slice_weight_gpu.end(), slice_weight);
+  if (slice_potential) std::copy(m._slice_potential_gpu.begin(), m._slice_potential_gpu.end(), slice_potential);
+  if (slice_inside) std::copy(m._slice_inside_gpu.begin(), m._slice_inside_gpu.end(), slice_inside);
+  if (s) {
+    s[0] = m._sigma_gpu; s[1] = m._mix_gpu; s[2] = m._m_gpu; s[3] = m._mean_s_gpu; s[4] = m._mean_s2_gpu;
+    s[5] = m._sigma_s_gpu; s[6] = m._sigma_s2_gpu; s[7] = m._mix_s_gpu;
+  }
+  return SVR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+"""ctypes binding of the C++ host object `svr::irtkReconstruction` (include/svr_host.h,
+csrc/svr_host.cpp): the same operator surface as reconstruction.irtkReconstruction, but the host
+logic (slice-level EM, M-step, sharding glue) runs in C++ like the reference's."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import engine as _engine
+
+_AR_PAIR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_AR_HOST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int)
+
+HOST_EXPORTS = [
+    "svrh_create", "svrh_destroy", "svrh_last_error", "svrh_set_intensity_range", "svrh_set_smoothing_parameters",
+    "svrh_set_force_excluded", "svrh_initialize_em_values_gpu", "svrh_gaussian_reconstruction_gpu",
+    "svrh_simulate_slices_gpu", "svrh_initialize_robust_statistics_gpu", "svrh_estep_gpu", "svrh_scale_gpu",
+    "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
+    "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state",
+]
+
+
+class _Coll(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("allreduce_volume_pair", _AR_PAIR),
+                ("allreduce_host", _AR_HOST), ("allgather_slices", _AG)]
+
+
+class irtkReconstruction:
+    """C++ host object over one engine; `comm` is a reconstruction.TorchComm (or None)."""
+
+    def __init__(self, rec: "_engine.Reconstruction", n_slices_global, slice_range=None, comm=None,
+                 max_intensity=1.0, min_intensity=0.0):
+        self._lib = _engine.load_library()
+        self._lib.svrh_create.restype = C.c_void_p
+        self._lib.svrh_last_error.restype = C.c_char_p
+        self._lib.svrh_destroy.restype = None
+        self._lib.svrh_set_intensity_range.restype = None
+        self._lib.svrh_set_smoothing_parameters.restype = None
+        self._lib.svrh_set_force_excluded.restype = None
+        self.reconstructionGPU = rec
+        self.ns = int(n_slices_global)
+        self.lo, self.hi = slice_range if slice_range is not None else (0, self.ns)
+        self._coll = None
+        if comm is not None and comm.world > 1:
+            self._comm = comm
+            self._views = {}
+            counts = [int(round(x)) for x in comm.allreduce_sum(np.eye(comm.world)[comm.rank] * (self.hi - self.lo))]
+
+            def ar_pair(user, ptr, n):
+                try:
+                    from .reconstruction import _device_view
+                    if ptr not in self._views:
+                        self._views[ptr] = _device_view(comm.torch, ptr, n, comm.device)
+                    comm.dist.all_reduce(self._views[ptr], op=comm.dist.ReduceOp.SUM)
+                    comm.torch.cuda.synchronize()
+                    return 0
+                except Exception as ex:      # never let an exception cross the C boundary
+                    print("allreduce_volume_pair failed:", ex)
+                    return 1
+
+            def ar_host(user, data, n, op):
+                try:
+                    a = np.ctypeslib.as_array(data, shape=(n,))
+                    r = (comm.allreduce_sum, comm.allreduce_min, comm.allreduce_max)[op](a.copy())
+                    a[:] = r
+                    return 0
+                except Exception as ex:
+                    print("allreduce_host failed:", ex)
+                    return 1
+
+            def ag(user, local, n_local, out, n_global):
+                try:
+                    loc = np.ctypeslib.as_array(local, shape=(n_local,)).copy() if n_local else np.zeros(0, np.float32)
+                    g = comm.allgather_slices(loc, counts)
+                    np.ctypeslib.as_array(out, shape=(n_global,))[:] = g
+                    return 0
+                except Exception as ex:
+                    print("allgather_slices failed:", ex)
+                    return 1
+
+            self._cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag))     # keep the thunks alive
+            self._coll = _Coll(None, comm.rank, comm.world, *self._cbs)
+        h = self._lib.svrh_create(rec._h, self.ns, int(self.lo), int(self.hi),
+                                  C.byref(self._coll) if self._coll is not None else None)
+        if not h:
+            raise _engine.SvrError("svrh_create failed")
+        self._h = C.c_void_p(h)
+        self._lib.svrh_set_intensity_range(self._h, C.c_double(min_intensity), C.c_double(max_intensity))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.svrh_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise _engine.SvrError(f"host status {rc}: {self._lib.svrh_last_error(self._h).decode()}")
+
+    def SetSmoothingParameters(self, delta, lam):
+        self._lib.svrh_set_smoothing_parameters(self._h, C.c_double(delta), C.c_double(lam))
+
+    def SetForceExcludedSlices(self, idx):
+        a = np.ascontiguousarray(idx, np.int32)
+        self._lib.svrh_set_force_excluded(self._h, a.ctypes.data_as(C.c_void_p), len(a))
+
+    def InitializeEMValuesGPU(self):
+        self._ck(self._lib.svrh_initialize_em_values_gpu(self._h))
+
+    InitializeEMGPU = InitializeEMValuesGPU
+
+    def GaussianReconstructionGPU(self):
+        self._ck(self._lib.svrh_gaussian_reconstruction_gpu(self._h))
+
+    def SimulateSlicesGPU(self):
+        self._ck(self._lib.svrh_simulate_slices_gpu(self._h))
+
+    def InitializeRobustStatisticsGPU(self):
+        self._ck(self._lib.svrh_initialize_robust_statistics_gpu(self._h))
+
+    def EStepGPU(self):
+        self._ck(self._lib.svrh_estep_gpu(self._h))
+
+    def ScaleGPU(self):
+        self._ck(self._lib.svrh_scale_gpu(self._h))
+
+    def SuperresolutionGPU(self, it):
+        self._ck(self._lib.svrh_superresolution_gpu(self._h, int(it)))
+
+    def MStepGPU(self, it):
+        self._ck(self._lib.svrh_mstep_gpu(self._h, int(it)))
+
+    def MaskVolumeGPU(self):
+        self._ck(self._lib.svrh_mask_volume_gpu(self._h))
+
+    def ScaleVolumeGPU(self):
+        self._ck(self._lib.svrh_scale_volume_gpu(self._h))
+
+    def sr_iteration(self, i):
+        self._ck(self._lib.svrh_sr_iteration(self._h, int(i)))
+
+    def reconstruct_iteration(self, rec_iterations, on_sr_iteration=None):
+        self._ck(self._lib.svrh_reconstruct_iteration(self._h, int(rec_iterations)))
+
+    def state(self):
+        sc, sw, pot = (np.zeros(self.ns, np.float32) for _ in range(3))
+        ins = np.zeros(self.ns, np.uint8)
+        s8 = np.zeros(8, np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        self._ck(self._lib.svrh_get_state(self._h, p(sc), p(sw), p(pot), p(ins), p(s8)))
+        names = ("sigma", "mix", "m", "mean_s", "mean_s2", "sigma_s", "sigma_s2", "mix_s")
+        return dict(scale=sc, slice_weight=sw, slice_potential=pot, slice_inside=ins.astype(bool),
+                    **{k: float(v) for k, v in zip(names, s8)})
+
+    # attribute-style access used by shared tests
+    @property
+    def _scale_gpu(self):
+        return self.state()["scale"]
+
+    @property
+    def _slice_weight_gpu(self):
+        return self.state()["slice_weight"]

@@ -239,7 +239,9 @@ class irtkReconstruction:
         self._sigma_s_gpu = 0.025
         self._mix_gpu = 0.9
         self._mix_s_gpu = 0.9
-        self._m_gpu = float(np.float32(1.0 / (2.1 * self._max_intensity - 1.9 * self._min_intensity)))
+        # (float)(1.0f / (2.1f * _max_intensity - 1.9f * _min_intensity)): float literals, double members
+        self._m_gpu = float(np.float32(1.0 / (float(np.float32(2.1)) * self._max_intensity -
+                                               float(np.float32(1.9)) * self._min_intensity)))
         e.UpdateScaleVector(self._local(self._scale_gpu), self._local(self._slice_weight_gpu))
 
     def _G(self, x, s):

@@ -1,0 +1,80 @@
+/*
+ * svr_host.h -- the host algorithm object above the engine, in the reference's own language.
+ *
+ * C++ class `svr::irtkReconstruction`: the GPU-path operator surface of the reference's
+ * irtkReconstruction (source/reconstructionGPU2/irtkReconstructionGPU.cc, "RG.cc";
+ * include/irtkReconstructionGPU.h, "RG.h") with the same method and member names, driving one
+ * engine context (include/svr_hip.h) per process:
+ *   InitializeEMValuesGPU RG.cc:2905-2919      InitializeEMGPU RG.cc:2921-2953
+ *   GaussianReconstructionGPU RG.cc:2695-2762  SimulateSlicesGPU RG.cc:1163-1175
+ *   InitializeRobustStatisticsGPU RG.cc:2988-3019   EStepGPU RG.cc:3184-3440
+ *   ScaleGPU RG.cc:3751-3757   SuperresolutionGPU RG.cc:4024-4036   MStepGPU RG.cc:4214-4223
+ *   MaskVolumeGPU RG.cc:5319-5323   ScaleVolumeGPU / RestoreSliceIntensitiesGPU RG.cc:4216,4653
+ *   SetSmoothingParameters RG.h:605-612
+ * and the reconstruction part of main()'s loop (reconstruction.cc:930-1140) as
+ * reconstruct_iteration() / sr_iteration().
+ *
+ * Multi-GPU: one process per GPU; the slices are sharded, the collectives are supplied by the
+ * launcher through `svr_collectives` (bench.py plugs torch.distributed/RCCL in; NULL = one rank).
+ * A plain C-ABI (svrh_*) over the class is exported for bindings and tests.
+ */
+#ifndef SVR_HOST_H
+#define SVR_HOST_H
+
+#include "svr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* collectives supplied by the launcher; every callback returns 0 on success */
+typedef struct svr_collectives {
+  void *user;
+  int rank, world;
+  /* in-place sum of the float[2*Nv] device buffer at `device_ptr` over all ranks */
+  int (*allreduce_volume_pair)(void *user, void *device_ptr, size_t n_floats);
+  /* in-place reduction of a small host vector; op: 0 sum, 1 min, 2 max */
+  int (*allreduce_host)(void *user, double *data, int n, int op);
+  /* gather the per-slice vectors of all ranks (rank order = slice order) into global[n_global] */
+  int (*allgather_slices)(void *user, const float *local, int n_local, float *global_out, int n_global);
+} svr_collectives;
+
+typedef struct svrh_recon svrh_recon;
+
+/* irtkReconstruction(std::vector<int> dev, bool useCPUReg)  RG.cc:159-221; the engine context is
+ * created and filled (SyncGPU, RG.cc:249-328) by the caller.  [slice_lo, slice_hi) = this rank's
+ * slices out of n_slices_global. */
+svrh_recon *svrh_create(svr_ctx *engine, int n_slices_global, int slice_lo, int slice_hi,
+                        const svr_collectives *coll_or_null);
+void svrh_destroy(svrh_recon *r);
+const char *svrh_last_error(const svrh_recon *r);
+
+void svrh_set_intensity_range(svrh_recon *r, double min_intensity, double max_intensity); /* RG.cc:2937-2951 */
+void svrh_set_smoothing_parameters(svrh_recon *r, double delta, double lambda);             /* RG.h:605-612 */
+void svrh_set_force_excluded(svrh_recon *r, const int *idx, int n);                         /* RG.h:614-617 */
+
+int svrh_initialize_em_values_gpu(svrh_recon *r);
+int svrh_gaussian_reconstruction_gpu(svrh_recon *r);
+int svrh_simulate_slices_gpu(svrh_recon *r);
+int svrh_initialize_robust_statistics_gpu(svrh_recon *r);
+int svrh_estep_gpu(svrh_recon *r);
+int svrh_scale_gpu(svrh_recon *r);
+int svrh_superresolution_gpu(svrh_recon *r, int iter);
+int svrh_mstep_gpu(svrh_recon *r, int iter);
+int svrh_mask_volume_gpu(svrh_recon *r);
+int svrh_scale_volume_gpu(svrh_recon *r);
+/* one SR iteration of reconstruction.cc:1013-1108 (bias off) */
+int svrh_sr_iteration(svrh_recon *r, int i);
+/* Gaussian init + robust-statistics init + rec_iterations SR iterations + MaskVolume
+ * (reconstruction.cc:930-1140) */
+int svrh_reconstruct_iteration(svrh_recon *r, int rec_iterations);
+
+/* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
+ * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s} */
+int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
+                   unsigned char *slice_inside, double scalars8[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVR_HOST_H */

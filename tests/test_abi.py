@@ -9,10 +9,10 @@ from fetalreconstruction_amd import engine
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "svr_hip.h")).read()
+def _declared(header="svr_hip.h", prefix="svr_"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(svr_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_builds_and_exports_all_declared_symbols():
@@ -27,6 +27,16 @@ def test_library_builds_and_exports_all_declared_symbols():
 
 def test_binding_lists_every_declared_symbol():
     assert sorted(engine.EXPORTS) == _declared()
+
+
+def test_host_object_exports_all_declared_symbols():
+    from fetalreconstruction_amd import host
+    lib = ctypes.CDLL(svr_build.build())
+    names = _declared("svr_host.h", "svrh_")
+    assert len(names) >= 15 and sorted(host.HOST_EXPORTS) == names
+    assert not [n for n in names if not hasattr(lib, n)]
+    lib.svrh_create.restype = ctypes.c_void_p
+    assert lib.svrh_create(None, 4, 0, 4, None) is None        # no engine -> refused
 
 
 def test_create_rejects_bad_arguments_without_gpu():

@@ -216,6 +216,28 @@ def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
     assert rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < TOL_SUM
 
 
+def test_cpp_host_object_matches_python_driver_and_oracle(tiny, oracle_mod):
+    """svr::irtkReconstruction (C++, csrc/svr_host.cpp) against the Python mirror on a second
+    engine and against the oracle-driven run: same host state, same volume."""
+    from fetalreconstruction_amd import host
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    rec2 = _engine(tiny)
+    hc = host.irtkReconstruction(rec2, tiny.ns, max_intensity=tiny.max_intensity, min_intensity=tiny.min_intensity)
+    hc.SetSmoothingParameters(150, 0.02)
+    hc.reconstruct_iteration(2)
+    dg.reconstruct_iteration(2)
+    do.reconstruct_iteration(2)
+    st = hc.state()
+    for ref, tol in ((dg, 2e-5), (do, 1e-4)):
+        assert np.allclose(st["scale"], ref._scale_gpu, rtol=tol)
+        assert np.allclose(st["slice_weight"], ref._slice_weight_gpu, atol=10 * tol)
+        assert np.allclose([st["sigma"], st["mix"], st["m"], st["mix_s"]],
+                           [ref._sigma_gpu, ref._mix_gpu, ref._m_gpu, ref._mix_s_gpu], rtol=tol)
+    assert np.array_equal(st["slice_potential"] < 0, dg._slice_potential_gpu < 0)
+    assert rel_err(rec2.syncCPU(), rec.syncCPU()) < 2e-5
+    assert rel_err(rec2.syncCPU(), orc.recon) < 1e-4
+
+
 def test_ragged_and_empty_inputs(oracle_mod):
     """Slices of different sizes padded with -1 (RG.cc:269-311), an all-padding slice and a slice
     grid that is not a multiple of any block size."""
