@@ -142,7 +142,7 @@ __device__ __forceinline__ void matvec3(const float *M, float x, float y, float 
   c = M[8] * x + M[9] * y + M[10] * z + M[11];
 }
 
-enum { MODE_GAUSS = 0, MODE_FWD = 1, MODE_BACK = 2 };
+enum { MODE_GAUSS = 0, MODE_FWD = 1, MODE_BACK = 2, MODE_BIAS = 3 };
 
 struct PsfArgs {
   const SliceConst *sc;
@@ -154,7 +154,8 @@ struct PsfArgs {
   const float *mask;
   float *psf_sums;
   const float *scales;        // per slice
-  // gauss
+  const float *bias;          // per-pixel log bias field, NULL when _disableBiasC (RC.cu:200-203)
+  // gauss (MODE_BIAS reuses recon/volw for the bias volume / its accumulated weights)
   float *recon, *volw;
   int *voxcount;
   // forward
@@ -347,16 +348,22 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void psf_kernel(PsfArgs a) {
     sume = (float)wave_sum(acc);
     if (!(sume > 0.5f)) return;          // also drops NaN (RC.cu:251-258)
     if (lane == 0) a.psf_sums[idx] = sume;
-    s = s * a.scales[sl];                // RC.cu:201
+    s = a.bias ? s * expf(-a.bias[idx]) * a.scales[sl] : s * a.scales[sl];   // RC.cu:200-203
   } else {
     sume = a.psf_sums[idx];
+  }
+  if (MODE == MODE_BIAS) {
+    // normalizeBiasKernel3D_tex RC.cu:544-550: the scattered value is the pixel's log bias
+    s = a.bias[idx];
+    const float scale = a.scales[sl];
+    if (scale > 0) s -= logf(scale);
   }
 
   float f0 = 0.0f, f1 = 0.0f;   // FWD: sim, weight partials.  BACK: (w*sw*e)/sume, (w*sw)/sume
   if (MODE == MODE_BACK) {
     float w = a.weights[idx];
     float ss = a.simslices[idx];
-    float e = s * a.scales[sl];
+    float e = a.bias ? s * expf(-a.bias[idx]) * a.scales[sl] : s * a.scales[sl];   // RC.cu:439-442
     e = (ss > 0.0f) ? (e - ss) : 0.0f;   // RC.cu:444-447
     float ws = w * a.slice_weights[sl];
     f1 = ws / sume;
@@ -392,8 +399,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void psf_kernel(PsfArgs a) {
       if (ok) {
         const uint32_t vi = ax + ay * (uint32_t)vg.vx + az * (uint32_t)(vg.vx * vg.vy);
         if (a.mask[vi] != 0.0f) {
-          if (MODE == MODE_GAUSS) {
-            float p = val / sume;                       // RC.cu:278
+          if (MODE == MODE_GAUSS || MODE == MODE_BIAS) {
+            float p = val / sume;                       // RC.cu:278, 591
             unsafeAtomicAdd(a.volw + vi, p);
             unsafeAtomicAdd(a.recon + vi, p * s);
           } else if (MODE == MODE_FWD) {
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void back_tiled_kernel(PsfArgs a, 
     const float sume = a.psf_sums[idx];
     const float w = a.weights[idx];
     const float ss = a.simslices[idx];
-    float e = a.slices[idx] * scale;
+    float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * scale : a.slices[idx] * scale;   // RC.cu:439-442
     e = (ss > 0.0f) ? (e - ss) : 0.0f;       // RC.cu:444-447
     const float f1 = (w * slicew) / sume;
     const float f0 = f1 * e;
@@ -652,8 +659,8 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
       PixelState P = pixel_setup(S, vg, px, py);
       const float sume = a.psf_sums[idx];
       const float ss = a.simslices[idx];
-      float e = a.slices[idx] * a.scales[sl];
-      e = (ss > 0.0f) ? (e - ss) : 0.0f;                       // RC.cu:444-447
+      float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * a.scales[sl] : a.slices[idx] * a.scales[sl];
+      e = (ss > 0.0f) ? (e - ss) : 0.0f;                       // RC.cu:439-447
       const float f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
       PixelRec R;
       R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
@@ -877,9 +884,9 @@ __global__ void k_init_em(const float *slices, float *weights, size_t n) {
 
 // EStepKernel3D_tex RC.cu:2766-2813 fused with the slice-potential transform RC.cu:2816-2841
 __global__ __launch_bounds__(256) void k_estep(const float *slices, const float *simslices,
-                                               const float *simweights, const float *scales, float m_,
-                                               float sigma_, float mix_, int n2, float *weights,
-                                               double *partial) {
+                                               const float *simweights, const float *scales,
+                                               const float *bias, float m_, float sigma_, float mix_, int n2,
+                                               float *weights, double *partial) {
   const int sl = blockIdx.y;
   const float scale = scales[sl];
   const float m = m_ * SVR_STEP;   // M_ RC.cu:67-70
@@ -890,7 +897,7 @@ __global__ __launch_bounds__(256) void k_estep(const float *slices, const float 
     float s = slices[base + i], sw = simweights[base + i];
     float w = 0.0f;                                    // weights are cleared first RC.cu:2881
     if (!(s == -1.0f || sw <= 0.0f)) {
-      float sliceVal = s * scale;
+      float sliceVal = bias ? s * expf(-bias[base + i]) * scale : s * scale;   // RC.cu:2792-2795
       sliceVal -= simslices[base + i];
       float g = G_(sliceVal, sigma_);
       w = (g * mix_) / (g * mix_ + m * (1.0f - mix_));
@@ -916,7 +923,8 @@ __global__ void k_potential_finish(const double *per_slice, int ns, float *poten
 // transformMStep3DNoBias RC.cu:2966-3000; reduce identity (0,0,0,0,0) RC.cu:3103
 __global__ __launch_bounds__(256) void k_mstep(const float *slices, const float *weights,
                                                const float *simslices, const float *simweights,
-                                               const float *scales, int n2, double *partial) {
+                                               const float *scales, const float *bias, int n2,
+                                               double *partial) {
   const int sl = blockIdx.y;
   const float scale = scales[sl];
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -924,9 +932,11 @@ __global__ __launch_bounds__(256) void k_mstep(const float *slices, const float 
   for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
        i += 256) {
     float s = slices[base + i];
-    if (s != -1.0f && simweights[base + i] > 0.99f) {
+    // transformMStep3D tests sw against the double 0.99, the NoBias twin against 0.99f (RC.cu:2947,2985)
+    const float sw = simweights[base + i];
+    if (s != -1.0f && (bias ? (double)sw > 0.99 : sw > 0.99f)) {
       float w = weights[base + i];
-      float e = (s * scale) - simslices[base + i];
+      float e = bias ? (s * expf(-bias[base + i]) * scale) - simslices[base + i] : (s * scale) - simslices[base + i];
       v[0] += (double)(e * e * w);
       v[1] += (double)w;
       v[2] += 1.0;
@@ -940,8 +950,8 @@ __global__ __launch_bounds__(256) void k_mstep(const float *slices, const float 
 
 // transformScalenoBias RC.cu:3142-3165
 __global__ __launch_bounds__(256) void k_scale(const float *slices, const float *weights,
-                                               const float *simslices, const float *simweights, int n2,
-                                               double *partial) {
+                                               const float *simslices, const float *simweights,
+                                               const float *bias, int n2, double *partial) {
   const int sl = blockIdx.y;
   double v[2] = {0.0, 0.0};
   const size_t base = (size_t)sl * n2;
@@ -950,8 +960,14 @@ __global__ __launch_bounds__(256) void k_scale(const float *slices, const float 
     float s = slices[base + i];
     if (!(s == -1.0f || simweights[base + i] <= 0.99f)) {
       float w = weights[base + i], ss = simslices[base + i];
-      v[0] += (double)(w * s * ss);
-      v[1] += (double)(w * s * s);
+      if (bias) {                                        // transformScale RC.cu:3133-3136
+        float eb = expf(-bias[base + i]);
+        v[0] += (double)(w * s * eb * ss);
+        v[1] += (double)(w * s * eb * s * eb);
+      } else {
+        v[0] += (double)(w * s * ss);
+        v[1] += (double)(w * s * s);
+      }
     }
   }
   const int op[2] = {0, 0};
@@ -1135,6 +1151,133 @@ __global__ void k_scale_volume(float *recon, float scale, size_t n) {
 
 
 // ------------------------------------------------------------------------------------------
+// bias correction: CorrectBias RC.cu:1837-1942, NormaliseBias RC.cu:2519-2652
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_(int M, int x) { return max(0, min(M - 1, x)); }   // RC.cu:53-56
+
+// calculateResidual3D_adv RC.cu:1687-1731
+__global__ void k_bias_residual(const float *slices, const float *bias, const float *weights,
+                                const float *simweights, const float *simslices, const float *scales, int n2,
+                                size_t n, float *wb, float *wr) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float s = slices[idx];
+  if (s == -1.0f) return;
+  float wbo = 0.0f, wro = 0.0f;
+  if ((double)simweights[idx] > 0.99) {
+    float eb = expf(-bias[idx]);
+    float sliceVal = s * (eb * scales[idx / n2]);
+    wbo = weights[idx] * sliceVal;
+    float ss = simslices[idx];
+    if (((double)ss > 1.0) && ((double)sliceVal > 1.0)) wro = logf(sliceVal / ss) * wbo;
+  }
+  if (wbo > 0) { wb[idx] = wbo; wr[idx] = wro; }
+}
+
+// GaussianConvolutionKernel<float> RC.cu:909-985: one 1-D pass (recursive Gaussian weights, border
+// repeat); the output is only written where the result != 0, so `out` keeps its previous content
+// elsewhere -- the reference relies on that when it reuses its buffer (RC.cu:1886-1891).
+__global__ void k_gauss_conv_slices(const float *in, float *out, const SliceConst *sc, int sx, int sy, int ns,
+                                    float sigma, int horizontal) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), sl = blockIdx.z;
+  if (x >= sx || y >= sy) return;
+  const size_t base = (size_t)sl * sx * sy;
+  const float sigma2 = sigma / sc[sl].dim[0];
+  int klength = 2 * (int)roundf(4 * sigma2) + 1;
+  klength -= 1 - klength % 2;
+  const int half = (klength - 1) / 2;
+  float g0 = (float)(1.0 / (sqrt(2.0 * M_PI) * sigma2));
+  float g1 = (float)exp(-0.5 / (sigma2 * sigma2));
+  const float g2 = g1 * g1;
+  const size_t idx = base + x + (size_t)y * sx;
+  float sum = g0 * in[idx];
+  float sum_coeff = g0;
+  for (int i = 1; i <= half; ++i) {
+    g0 *= g1;
+    g1 *= g2;
+    const size_t a = horizontal ? base + reflect_(sx, x + i) + (size_t)y * sx : base + x + (size_t)reflect_(sy, y + i) * sx;
+    sum += g0 * in[a];
+    const size_t b = horizontal ? base + reflect_(sx, x - i) + (size_t)y * sx : base + x + (size_t)reflect_(sy, y - i) * sx;
+    sum += g0 * in[b];
+    sum_coeff += 2 * g0;
+  }
+  const float outv = sum / sum_coeff;
+  if (outv != 0) out[idx] = outv;
+}
+
+// updateBiasField3D_adv RC.cu:1734-1758
+__global__ void k_bias_update(const float *slices, float *bias, const float *wb, const float *wr, size_t n) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  if (slices[idx] == -1.0f) return;
+  float w = wb[idx];
+  if (w > 0) bias[idx] = bias[idx] + wr[idx] / w;
+}
+// per-slice {count(s > -1), sum(bias)}  (count_if + reduce, RC.cu:1904-1909)
+__global__ __launch_bounds__(256) void k_bias_mean(const float *slices, const float *bias, int n2, double *partial) {
+  const int sl = blockIdx.y;
+  double v[2] = {0.0, 0.0};
+  const size_t base = (size_t)sl * n2;
+  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX); i += 256) {
+    if (slices[base + i] > -1.0f) v[0] += 1.0;
+    v[1] += (double)bias[base + i];
+  }
+  const int op[2] = {0, 0};
+  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
+}
+// transformBiasMean RC.cu:1760-1783 with the mean of RC.cu:1911-1921
+__global__ void k_bias_sub_mean(const float *slices, float *bias, const double *per_slice, int n2, size_t n) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  if (slices[idx] == -1.0f) return;
+  const int sl = (int)(idx / n2);
+  const double num = per_slice[2 * sl], sum = per_slice[2 * sl + 1];
+  const float mean = num > 0 ? (float)(sum / num) : -1.0f;
+  if (mean == -1.0f) return;
+  if (mean != 0) bias[idx] = bias[idx] - mean;
+}
+
+// GaussianConvolutionKernel3D RC.cu:988-1093, one direction; written unless NaN
+__global__ void k_gauss_conv3d(const float *in, float *out, float sigma, int dir, float dimd, int vx, int vy, int vz) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+  if (x >= vx || y >= vy) return;
+  const float sigma2 = sigma / dimd;
+  int klength = 2 * (int)roundf(4 * sigma2) + 1;
+  klength -= 1 - klength % 2;
+  const int half = (klength - 1) / 2;
+  float g0 = (float)(1.0 / (sqrt(2.0 * M_PI) * sigma2));
+  float g1 = (float)exp(-0.5 / (sigma2 * sigma2));
+  const float g2 = g1 * g1;
+  const size_t sxy = (size_t)vx * vy;
+  const size_t idx = x + (size_t)y * vx + (size_t)z * sxy;
+  float sum = g0 * in[idx];
+  float sum_coeff = g0;
+  for (int i = 1; i <= half; ++i) {
+    g0 *= g1;
+    g1 *= g2;
+    size_t a, b;
+    if (dir == 0) { a = reflect_(vx, x + i) + (size_t)y * vx + (size_t)z * sxy; b = reflect_(vx, x - i) + (size_t)y * vx + (size_t)z * sxy; }
+    else if (dir == 1) { a = x + (size_t)reflect_(vy, y + i) * vx + (size_t)z * sxy; b = x + (size_t)reflect_(vy, y - i) * vx + (size_t)z * sxy; }
+    else { a = x + (size_t)y * vx + (size_t)reflect_(vz, z + i) * sxy; b = x + (size_t)y * vx + (size_t)reflect_(vz, z - i) * sxy; }
+    sum += g0 * in[a];
+    sum += g0 * in[b];
+    sum_coeff += 2 * g0;
+  }
+  const float outv = sum / sum_coeff;
+  if (outv == outv) out[idx] = outv;
+}
+// divS RC.cu:1786-1797
+__global__ void k_div_s(float *a, const float *b, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { float d = b[i]; a[i] = (d != 0) ? a[i] / d : 0; }
+}
+// divexp RC.cu:2505-2516
+__global__ void k_divexp(float *recon, const float *bias, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { float a = recon[i]; if (a != -1.0f) recon[i] = a / expf(-bias[i]); }
+}
+
+// ------------------------------------------------------------------------------------------
 // slice-to-volume NCC cost (the CPU-default registration metric):
 // irtkImageRigidRegistrationWithPadding::Evaluate + irtkCrossCorrelationSimilarityMetric.
 // One workgroup per (target slice, candidate transform): every target pixel >= 0 is mapped into the
@@ -1257,6 +1400,12 @@ struct svr_ctx {
   // reductions
   double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
   int chunks = 0;
+
+  // bias correction (allocated only when bias correction is enabled)
+  float *d_bias = nullptr, *d_wb = nullptr, *d_wr = nullptr, *d_buffer = nullptr;       // slice grid
+  float *d_bias_vol = nullptr, *d_volume_weights = nullptr, *d_maskC = nullptr, *d_mbuf = nullptr;   // volume
+  float mask_sigma_bias = 12.0f;
+  bool maskC_valid = false;
 
   // registration cost (NCC)
   short *d_reg_targets = nullptr, *d_reg_source = nullptr;
@@ -1409,6 +1558,7 @@ PsfArgs make_args(svr_ctx *ctx) {
   a.sx = (int)ctx->sx; a.sy = (int)ctx->sy;
   a.slices = ctx->d_slices; a.mask = ctx->d_mask; a.psf_sums = ctx->d_psf_sums;
   a.scales = ctx->d_scales;
+  a.bias = ctx->disable_bias ? nullptr : ctx->d_bias;
   a.recon = ctx->recon(); a.volw = ctx->volw(); a.voxcount = ctx->d_voxcount;
   a.vol = ctx->recon(); a.simslices = ctx->d_simslices; a.simweights = ctx->d_simweights;
   a.siminside = ctx->d_siminside;
@@ -1417,12 +1567,56 @@ PsfArgs make_args(svr_ctx *ctx) {
   return a;
 }
 
+// bias-path buffers: slice-grid {bias, wb, wresidual, buffer} (RC.cu:1510-1539) and volume
+// {bias, volume_weights, maskC} (RC.cu:1203-1214, 1129-1157); created on first use after
+// svr_set_flags(ctx, disable_bias_correction = 0, ...)
+int ensure_bias_buffers(svr_ctx *ctx) {
+  if (ctx->disable_bias) return SVR_OK;
+  if (ctx->np && !ctx->d_bias) {
+    const size_t fb = ctx->np * sizeof(float);
+    HIPCHK(hipMalloc(&ctx->d_bias, fb)); HIPCHK(hipMalloc(&ctx->d_wb, fb));
+    HIPCHK(hipMalloc(&ctx->d_wr, fb)); HIPCHK(hipMalloc(&ctx->d_buffer, fb));
+    HIPCHK(hipMemsetAsync(ctx->d_bias, 0, fb, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_wb, 0, fb, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_wr, 0, fb, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_buffer, 0, fb, ctx->stream));
+  }
+  if (ctx->nv && !ctx->d_bias_vol) {
+    const size_t vb = ctx->nv * sizeof(float);
+    HIPCHK(hipMalloc(&ctx->d_bias_vol, vb)); HIPCHK(hipMalloc(&ctx->d_volume_weights, vb));
+    HIPCHK(hipMalloc(&ctx->d_maskC, vb)); HIPCHK(hipMalloc(&ctx->d_mbuf, vb));
+    HIPCHK(hipMemsetAsync(ctx->d_bias_vol, 0, vb, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_volume_weights, 0, vb, ctx->stream));
+    ctx->maskC_valid = false;
+  }
+  if (ctx->nv && ctx->have_mask && !ctx->maskC_valid) {
+    // maskC_ = mask blurred with sigma_bias: x into a zeroed buffer, y back, z into the buffer, copy (RC.cu:1129-1157)
+    const size_t vb = ctx->nv * sizeof(float);
+    const dim3 grid((ctx->vx + 63) / 64, (ctx->vy + 3) / 4, ctx->vz);
+    HIPCHK(hipMemcpyAsync(ctx->d_maskC, ctx->d_mask, vb, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_mbuf, 0, vb, ctx->stream));
+    hipLaunchKernelGGL(k_gauss_conv3d, grid, dim3(256), 0, ctx->stream, ctx->d_maskC, ctx->d_mbuf, ctx->mask_sigma_bias, 0,
+                       ctx->vdim[0], (int)ctx->vx, (int)ctx->vy, (int)ctx->vz);
+    hipLaunchKernelGGL(k_gauss_conv3d, grid, dim3(256), 0, ctx->stream, ctx->d_mbuf, ctx->d_maskC, ctx->mask_sigma_bias, 1,
+                       ctx->vdim[1], (int)ctx->vx, (int)ctx->vy, (int)ctx->vz);
+    hipLaunchKernelGGL(k_gauss_conv3d, grid, dim3(256), 0, ctx->stream, ctx->d_maskC, ctx->d_mbuf, ctx->mask_sigma_bias, 2,
+                       ctx->vdim[2], (int)ctx->vx, (int)ctx->vy, (int)ctx->vz);
+    KCHK("k_gauss_conv3d(mask)");
+    HIPCHK(hipMemcpyAsync(ctx->d_maskC, ctx->d_mbuf, vb, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->maskC_valid = true;
+  }
+  return SVR_OK;
+}
+
 int ready(svr_ctx *ctx) {
   NEED(ctx->nv > 0, "reconstruction volume not initialised");
   NEED(ctx->have_mask, "mask not set");
   NEED(ctx->have_slices, "slices not filled");
   NEED(ctx->have_scales, "scale vector not set");
   NEED(ctx->have_psf, "generatePSFVolume not called");
+  int r = ensure_bias_buffers(ctx);
+  if (r) return r;
   return prepare_slice_consts(ctx);
 }
 
@@ -1537,6 +1731,8 @@ void svr_destroy(svr_ctx *ctx) {
   free_volume(ctx);
   free_slices(ctx);
   free_dev(ctx->d_mask);
+  free_dev(ctx->d_bias); free_dev(ctx->d_wb); free_dev(ctx->d_wr); free_dev(ctx->d_buffer);
+  free_dev(ctx->d_bias_vol); free_dev(ctx->d_volume_weights); free_dev(ctx->d_maskC); free_dev(ctx->d_mbuf);
   free_dev(ctx->d_reg_targets);
   free_dev(ctx->d_reg_source);
   free_dev(ctx->d_counter);
@@ -1551,9 +1747,7 @@ const char *svr_last_error(const svr_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu) {
   if (!ctx) return SVR_E_ARG;
-  if (!disable_bias_correction)
-    return fail(ctx, SVR_E_ARG, "bias correction path not built (CLI default is disabled, reconstruction.cc:121,202)");
-  ctx->disable_bias = true;
+  ctx->disable_bias = disable_bias_correction != 0;
   ctx->debug_gpu = debug_gpu != 0;
   return SVR_OK;
 }
@@ -1575,6 +1769,7 @@ int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const f
   size_t nv = (size_t)size[0] * size[1] * size[2];
   if (nv == 0 || nv >= 0xFFFFFFFFull) return fail(ctx, SVR_E_ARG, "volume size out of range");
   free_volume(ctx);
+  free_dev(ctx->d_bias_vol); free_dev(ctx->d_volume_weights); free_dev(ctx->d_maskC); free_dev(ctx->d_mbuf);
   ctx->vx = size[0]; ctx->vy = size[1]; ctx->vz = size[2];
   memcpy(ctx->vdim, dim, 3 * sizeof(float));
   ctx->nv = nv;
@@ -1592,7 +1787,7 @@ int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const f
 int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const float *data,
                  float sigma_bias) {
   if (!ctx || !size || !data) return SVR_E_ARG;
-  (void)dim; (void)sigma_bias;   // the blurred maskC_ (RC.cu:1129-1157) only feeds NormaliseBias
+  (void)dim;   // the blurred maskC_ (RC.cu:1129-1157) is built lazily: it only feeds NormaliseBias
   NEED(ctx->nv > 0, "InitReconstructionVolume first");
   if ((size_t)size[0] * size[1] * size[2] != ctx->nv || size[0] != ctx->vx || size[1] != ctx->vy)
     return fail(ctx, SVR_E_ARG, "mask grid differs from the reconstruction volume");
@@ -1601,6 +1796,8 @@ int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const
   HIPCHK(hipMemcpyAsync(ctx->d_mask, data, ctx->nv * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->have_mask = true;
+  ctx->mask_sigma_bias = sigma_bias;
+  ctx->maskC_valid = false;
   return SVR_OK;
 }
 
@@ -1611,6 +1808,7 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   size_t np = (size_t)size[0] * size[1] * size[2];
   if (np == 0 || np >= 0xFFFFFFFFull) return fail(ctx, SVR_E_ARG, "slice grid size out of range");
   free_slices(ctx);
+  free_dev(ctx->d_bias); free_dev(ctx->d_wb); free_dev(ctx->d_wr); free_dev(ctx->d_buffer);
   ctx->sx = size[0]; ctx->sy = size[1]; ctx->ns = size[2];
   ctx->np = np;
   ctx->have_slices = false; ctx->have_scales = false; ctx->have_dims = false; ctx->have_mats = false;
@@ -1828,6 +2026,11 @@ int svr_initialize_em_values(svr_ctx *ctx) {
   NEED(ctx->have_slices, "slices not filled");
   hipLaunchKernelGGL(k_init_em, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights, ctx->np);
   KCHK("k_init_em");
+  if (!ctx->disable_bias) {                              // RC.cu:3305-3309
+    int r = ensure_bias_buffers(ctx);
+    if (r) return r;
+    HIPCHK(hipMemsetAsync(ctx->d_bias, 0, ctx->np * sizeof(float), ctx->stream));
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
 }
@@ -1859,8 +2062,8 @@ int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potent
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   ScopedTimer t(ctx, SVR_T_ESTEP);
   hipLaunchKernelGGL(k_estep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_simslices,
-                     ctx->d_simweights, ctx->d_scales, m, sigma, mix, (int)(ctx->sx * ctx->sy), ctx->d_weights,
-                     ctx->d_partial);
+                     ctx->d_simweights, ctx->d_scales, ctx->disable_bias ? (const float *)nullptr : ctx->d_bias, m, sigma,
+                     mix, (int)(ctx->sx * ctx->sy), ctx->d_weights, ctx->d_partial);
   KCHK("k_estep");
   int r = reduce_partials(ctx, 2, 0, 0, false);
   if (r) return r;
@@ -1881,8 +2084,8 @@ int svr_mstep_sums(svr_ctx *ctx, double out5[5]) {
   if (r) return r;
   ScopedTimer t(ctx, SVR_T_MSTEP);
   hipLaunchKernelGGL(k_mstep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
-                     ctx->d_simslices, ctx->d_simweights, ctx->d_scales_host_copy, (int)(ctx->sx * ctx->sy),
-                     ctx->d_partial);
+                     ctx->d_simslices, ctx->d_simweights, ctx->d_scales_host_copy,
+                     ctx->disable_bias ? (const float *)nullptr : ctx->d_bias, (int)(ctx->sx * ctx->sy), ctx->d_partial);
   KCHK("k_mstep");
   r = reduce_partials(ctx, 5, 1 << 3, 1 << 4, true);
   if (r) return r;
@@ -1915,7 +2118,8 @@ int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   ScopedTimer t(ctx, SVR_T_SCALE);
   hipLaunchKernelGGL(k_scale, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
-                     ctx->d_simslices, ctx->d_simweights, (int)(ctx->sx * ctx->sy), ctx->d_partial);
+                     ctx->d_simslices, ctx->d_simweights, ctx->disable_bias ? (const float *)nullptr : ctx->d_bias,
+                     (int)(ctx->sx * ctx->sy), ctx->d_partial);
   KCHK("k_scale");
   int r = reduce_partials(ctx, 2, 0, 0, false);
   if (r) return r;
@@ -2103,6 +2307,9 @@ static int buffer_info(svr_ctx *ctx, int which, void **ptr, size_t *bytes) {
     case SVR_BUF_ADDON: *ptr = ctx->nv ? ctx->addon() : nullptr; *bytes = ctx->nv * 4; break;
     case SVR_BUF_CONFIDENCE_MAP: *ptr = ctx->nv ? ctx->cmap() : nullptr; *bytes = ctx->nv * 4; break;
     case SVR_BUF_MASK: *ptr = ctx->d_mask; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_BIAS_VOLUME: *ptr = ctx->d_bias_vol; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_SMOOTH_MASK: *ptr = ctx->d_maskC; *bytes = ctx->nv * 4; break;
+    case SVR_BUF_BIAS: *ptr = ctx->d_bias; *bytes = ctx->np * 4; break;
     case SVR_BUF_SLICES: *ptr = ctx->d_slices; *bytes = ctx->np * 4; break;
     case SVR_BUF_WEIGHTS: *ptr = ctx->d_weights; *bytes = ctx->np * 4; break;
     case SVR_BUF_SIMSLICES: *ptr = ctx->d_simslices; *bytes = ctx->np * 4; break;
@@ -2169,6 +2376,104 @@ int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals40
   (void)hipFree(d_c);
   if (e != hipSuccess) return fail(ctx, (int)e, "svr_debug_probe_pixel");
   return SVR_OK;
+}
+
+// ---- bias correction --------------------------------------------------------------------
+int svr_correct_bias(svr_ctx *ctx, float sigma_bias, int global_bias_correction) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(!ctx->disable_bias, "bias correction is disabled (svr_set_flags)");
+  NEED(ctx->have_slices && ctx->have_scales && ctx->have_dims, "slices / scales / slice dims not set");
+  int r = ensure_bias_buffers(ctx);
+  if (r) return r;
+  r = prepare_slice_consts(ctx);
+  if (r) return r;
+  const size_t fb = ctx->np * sizeof(float);
+  const int n2 = (int)(ctx->sx * ctx->sy);
+  HIPCHK(hipMemsetAsync(ctx->d_wb, 0, fb, ctx->stream));       // RC.cu:1873-1875
+  HIPCHK(hipMemsetAsync(ctx->d_wr, 0, fb, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_buffer, 0, fb, ctx->stream));
+  hipLaunchKernelGGL(k_bias_residual, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_bias,
+                     ctx->d_weights, ctx->d_simweights, ctx->d_simslices, ctx->d_scales, n2, ctx->np, ctx->d_wb, ctx->d_wr);
+  KCHK("k_bias_residual");
+  const dim3 grid((ctx->sx + 63) / 64, (ctx->sy + 3) / 4, ctx->ns);
+#define CONV(in, out, horiz) \
+  hipLaunchKernelGGL(k_gauss_conv_slices, grid, dim3(256), 0, ctx->stream, in, out, ctx->d_sc, (int)ctx->sx, (int)ctx->sy, \
+                     (int)ctx->ns, sigma_bias, horiz)
+  CONV(ctx->d_wb, ctx->d_buffer, 1);       // RC.cu:1886
+  CONV(ctx->d_buffer, ctx->d_wb, 0);       // RC.cu:1888
+  CONV(ctx->d_wr, ctx->d_buffer, 1);       // RC.cu:1889 (buffer still holds the first pass where the result is 0)
+  CONV(ctx->d_buffer, ctx->d_wr, 0);       // RC.cu:1891
+#undef CONV
+  KCHK("k_gauss_conv_slices");
+  hipLaunchKernelGGL(k_bias_update, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_bias, ctx->d_wb,
+                     ctx->d_wr, ctx->np);
+  KCHK("k_bias_update");
+  if (!global_bias_correction) {
+    hipLaunchKernelGGL(k_bias_mean, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_bias, n2,
+                       ctx->d_partial);
+    KCHK("k_bias_mean");
+    r = reduce_partials(ctx, 2, 0, 0, false);
+    if (r) return r;
+    hipLaunchKernelGGL(k_bias_sub_mean, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_bias,
+                       ctx->d_per_slice, n2, ctx->np);
+    KCHK("k_bias_sub_mean");
+  } else {
+    printf("_global_bias_correction is not implemented in CUDA yet\n");   // RC.cu:1932
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_normalise_bias_local(svr_ctx *ctx) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(!ctx->disable_bias, "bias correction is disabled (svr_set_flags)");
+  int r = ready(ctx);
+  if (r) return r;
+  r = ensure_psf_list(ctx);
+  if (r) return r;
+  HIPCHK(hipMemsetAsync(ctx->d_bias_vol, 0, ctx->nv * sizeof(float), ctx->stream));   // RC.cu:2621
+  PsfArgs a = make_args(ctx);
+  a.list = ctx->d_psf_list;
+  a.n = ctx->n_psf;
+  a.recon = ctx->d_bias_vol;            // scattered value: psf/sume * (bias - log scale)
+  a.volw = ctx->d_volume_weights;       // dev_volume_weights_: accumulates, never cleared (RC.cu:2633)
+  if (a.n) {
+    hipLaunchKernelGGL(psf_kernel<MODE_BIAS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                       ctx->stream, a);
+    KCHK("psf_kernel<BIAS>");
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_normalise_bias_finish(svr_ctx *ctx, float sigma_bias) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(!ctx->disable_bias && ctx->d_bias_vol && ctx->maskC_valid, "bias buffers not ready");
+  const size_t nv = ctx->nv;
+  const dim3 grid((ctx->vx + 63) / 64, (ctx->vy + 3) / 4, ctx->vz);
+  hipLaunchKernelGGL(k_div_s, dim3(nblk(nv)), dim3(256), 0, ctx->stream, ctx->d_bias_vol, ctx->volw(), nv);   // RC.cu:2553-2556
+  // the reference's mbuf is uninitialised device memory (RC.cu:2563-2564); zero it so a NaN result is defined
+  HIPCHK(hipMemsetAsync(ctx->d_mbuf, 0, nv * sizeof(float), ctx->stream));
+  hipLaunchKernelGGL(k_gauss_conv3d, grid, dim3(256), 0, ctx->stream, ctx->d_bias_vol, ctx->d_mbuf, sigma_bias, 0,
+                     ctx->vdim[0], (int)ctx->vx, (int)ctx->vy, (int)ctx->vz);
+  hipLaunchKernelGGL(k_gauss_conv3d, grid, dim3(256), 0, ctx->stream, ctx->d_mbuf, ctx->d_bias_vol, sigma_bias, 1,
+                     ctx->vdim[1], (int)ctx->vx, (int)ctx->vy, (int)ctx->vz);
+  hipLaunchKernelGGL(k_gauss_conv3d, grid, dim3(256), 0, ctx->stream, ctx->d_bias_vol, ctx->d_mbuf, sigma_bias, 2,
+                     ctx->vdim[2], (int)ctx->vx, (int)ctx->vy, (int)ctx->vz);
+  KCHK("k_gauss_conv3d");
+  HIPCHK(hipMemcpyAsync(ctx->d_bias_vol, ctx->d_mbuf, nv * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_div_s, dim3(nblk(nv)), dim3(256), 0, ctx->stream, ctx->d_bias_vol, ctx->d_maskC, nv);   // RC.cu:2575-2577
+  hipLaunchKernelGGL(k_divexp, dim3(nblk(nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_bias_vol, nv);  // RC.cu:2579-2581
+  KCHK("k_divexp");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_normalise_bias(svr_ctx *ctx, int iter, float sigma_bias) {
+  (void)iter;
+  int r = svr_normalise_bias_local(ctx);
+  if (r) return r;
+  return svr_normalise_bias_finish(ctx, sigma_bias);
 }
 
 // ---- slice-to-volume registration cost --------------------------------------------------

@@ -29,7 +29,7 @@ class irtkReconstruction {
   float _mean_s_gpu, _mean_s2_gpu, _sigma_s_gpu, _sigma_s2_gpu, _mix_s_gpu;
   double _delta, _lambda, _alpha;
   float _low_intensity_cutoff;
-  bool _global_bias_correction, _adaptive;
+  bool _global_bias_correction, _adaptive, _disableBiasC;
   double _max_intensity, _min_intensity;
   std::vector<int> _force_excluded, _small_slices;
   std::vector<float> _scale_gpu, _slice_weight_gpu, _slice_potential_gpu;
@@ -53,6 +53,7 @@ class irtkReconstruction {
     _low_intensity_cutoff = 0.01f;
     _global_bias_correction = false;
     _adaptive = false;
+    _disableBiasC = true;   // reconstruction.cc:121,202
     _max_intensity = 1; _min_intensity = 0;
     _sigma_gpu = 0; _m_gpu = 0; _mean_s_gpu = 0; _mean_s2_gpu = 0;
     _scale_gpu.assign(ns, 1.0f);
@@ -267,6 +268,18 @@ class irtkReconstruction {
     return 0;
   }
 
+  // RG.cc:3904-3913, 4653-4655
+  int BiasGPU() { ENG(svr_correct_bias(reconstructionGPU, _sigma_bias, _global_bias_correction)); return 0; }
+  int NormaliseBiasGPU(int iter) {
+    if (!have_coll) { ENG(svr_normalise_bias(reconstructionGPU, iter, _sigma_bias)); return 0; }
+    ENG(svr_normalise_bias_local(reconstructionGPU));
+    // the bias volume is a single float[Nv] message
+    ENG(coll.allreduce_volume_pair(coll.user, svr_device_ptr(reconstructionGPU, SVR_BUF_BIAS_VOLUME),
+                                   svr_volume_voxels(reconstructionGPU)));
+    ENG(svr_normalise_bias_finish(reconstructionGPU, _sigma_bias));
+    return 0;
+  }
+
   int MaskVolumeGPU() { ENG(svr_mask_volume(reconstructionGPU)); return 0; }   // RG.cc:5319-5323
 
   int ScaleVolumeGPU() {
@@ -281,8 +294,12 @@ class irtkReconstruction {
   // reconstruction.cc:1013-1108 with bias correction off
   int sr_iteration(int i) {
     int rc;
+    if (!_disableBiasC && _sigma_bias > 0)                                   // reconstruction.cc:1032-1037
+      if ((rc = BiasGPU())) return rc;
     if ((rc = ScaleGPU())) return rc;
     if ((rc = SuperresolutionGPU(i + 1))) return rc;
+    if (!_disableBiasC && _sigma_bias > 0 && !_global_bias_correction)       // reconstruction.cc:1066-1076
+      if ((rc = NormaliseBiasGPU(i))) return rc;
     if ((rc = SimulateSlicesGPU())) return rc;
     if ((rc = MStepGPU(i + 1))) return rc;
     return EStepGPU();
@@ -324,6 +341,13 @@ const char *svrh_last_error(const svrh_recon *r) { return r ? r->impl.err.c_str(
 void svrh_set_intensity_range(svrh_recon *r, double mn, double mx) { r->impl._min_intensity = mn; r->impl._max_intensity = mx; }
 void svrh_set_smoothing_parameters(svrh_recon *r, double delta, double lambda) { r->impl.SetSmoothingParameters(delta, lambda); }
 void svrh_set_force_excluded(svrh_recon *r, const int *idx, int n) { r->impl._force_excluded.assign(idx, idx + n); }
+int svrh_set_bias_correction(svrh_recon *r, int enable, double sigma_bias) {
+  r->impl._disableBiasC = !enable;
+  r->impl._sigma_bias = (float)sigma_bias;
+  return svr_set_flags(r->impl.reconstructionGPU, !enable, 0);
+}
+int svrh_bias_gpu(svrh_recon *r) { return r->impl.BiasGPU(); }
+int svrh_normalise_bias_gpu(svrh_recon *r, int iter) { return r->impl.NormaliseBiasGPU(iter); }
 int svrh_initialize_em_values_gpu(svrh_recon *r) { return r->impl.InitializeEMValuesGPU(); }
 int svrh_gaussian_reconstruction_gpu(svrh_recon *r) { return r->impl.GaussianReconstructionGPU(); }
 int svrh_simulate_slices_gpu(svrh_recon *r) { return r->impl.SimulateSlicesGPU(); }

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsvr_hip.so")
 
 # enum svr_buffer / svr_timer (include/svr_hip.h)
 BUF_RECONSTRUCTED, BUF_VOL_WEIGHTS, BUF_ADDON, BUF_CONFIDENCE_MAP, BUF_MASK = 0, 1, 2, 3, 4
-BUF_SLICES, BUF_WEIGHTS, BUF_SIMSLICES, BUF_SIMWEIGHTS, BUF_PSF_SUMS = 10, 11, 12, 13, 14
+BUF_BIAS_VOLUME, BUF_SMOOTH_MASK = 5, 6
+BUF_SLICES, BUF_WEIGHTS, BUF_SIMSLICES, BUF_SIMWEIGHTS, BUF_PSF_SUMS, BUF_BIAS = 10, 11, 12, 13, 14, 15
 BUF_SIMINSIDE, BUF_VOXEL_COUNT = 20, 21
 T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE = range(7)
 TIMER_NAMES = ["backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale"]
@@ -37,7 +38,8 @@ EXPORTS = [
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
     "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_ncc_set_targets", "svr_ncc_set_source",
-    "svr_ncc_evaluate",
+    "svr_ncc_evaluate", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
+    "svr_normalise_bias_finish",
 ]
 
 
@@ -206,6 +208,15 @@ class Reconstruction:
                                                C.c_float(min_intensity), C.c_float(max_intensity), C.c_float(delta),
                                                C.c_float(lam), int(bool(global_bias_correction)), C.c_float(sigma_bias),
                                                C.c_float(low_intensity_cutoff)))
+
+    def set_flags(self, disable_bias_correction=True, debug_gpu=False):
+        self._ck(self._lib.svr_set_flags(self._h, int(bool(disable_bias_correction)), int(bool(debug_gpu))))
+
+    def CorrectBias(self, sigma_bias, global_bias_correction=False):
+        self._ck(self._lib.svr_correct_bias(self._h, C.c_float(sigma_bias), int(bool(global_bias_correction))))
+
+    def NormaliseBias(self, it, sigma_bias):
+        self._ck(self._lib.svr_normalise_bias(self._h, int(it), C.c_float(sigma_bias)))
 
     def maskVolume(self):
         self._ck(self._lib.svr_mask_volume(self._h))

@@ -18,7 +18,8 @@ HOST_EXPORTS = [
     "svrh_set_force_excluded", "svrh_initialize_em_values_gpu", "svrh_gaussian_reconstruction_gpu",
     "svrh_simulate_slices_gpu", "svrh_initialize_robust_statistics_gpu", "svrh_estep_gpu", "svrh_scale_gpu",
     "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
-    "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state",
+    "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state", "svrh_set_bias_correction", "svrh_bias_gpu",
+    "svrh_normalise_bias_gpu",
 ]
 
 
@@ -107,6 +108,15 @@ class irtkReconstruction:
     def SetForceExcludedSlices(self, idx):
         a = np.ascontiguousarray(idx, np.int32)
         self._lib.svrh_set_force_excluded(self._h, a.ctypes.data_as(C.c_void_p), len(a))
+
+    def set_bias_correction(self, enable, sigma_bias=12.0):
+        self._ck(self._lib.svrh_set_bias_correction(self._h, int(bool(enable)), C.c_double(sigma_bias)))
+
+    def BiasGPU(self):
+        self._ck(self._lib.svrh_bias_gpu(self._h))
+
+    def NormaliseBiasGPU(self, it):
+        self._ck(self._lib.svrh_normalise_bias_gpu(self._h, int(it)))
 
     def InitializeEMValuesGPU(self):
         self._ck(self._lib.svrh_initialize_em_values_gpu(self._h))

@@ -157,6 +157,7 @@ class irtkReconstruction:
         self._min_intensity = float(min_intensity)
         self._force_excluded = []
         self._small_slices = []
+        self._disableBiasC = True      # reconstruction.cc:121,202: the CLI can never switch it on
         self._scale_gpu = np.ones(self.ns, np.float32)
         self._slice_weight_gpu = np.ones(self.ns, np.float32)
         self._slice_inside_gpu = np.ones(self.ns, bool)
@@ -354,6 +355,14 @@ class irtkReconstruction:
             self._mix_gpu = float(mix / num)
         self._m_gpu = float(f32(1.0) / (f32(max_) - f32(min_)))
 
+    def BiasGPU(self):
+        """RG.cc:3904-3913"""
+        self.reconstructionGPU.CorrectBias(self._sigma_bias, self._global_bias_correction)
+
+    def NormaliseBiasGPU(self, it):
+        """RG.cc:4653-4655 (single rank; the sharded split is svr_normalise_bias_local/_finish)"""
+        self.reconstructionGPU.NormaliseBias(it, self._sigma_bias)
+
     def MaskVolumeGPU(self):
         self.reconstructionGPU.maskVolume()
 
@@ -382,8 +391,12 @@ class irtkReconstruction:
 
     def sr_iteration(self, i):
         """The hot loop body, reconstruction.cc:1013-1108 with bias correction off."""
+        if not self._disableBiasC and self._sigma_bias > 0:      # reconstruction.cc:1032-1037
+            self.BiasGPU()
         self.ScaleGPU()
         self.SuperresolutionGPU(i + 1)
+        if not self._disableBiasC and self._sigma_bias > 0 and not self._global_bias_correction:
+            self.NormaliseBiasGPU(i)                              # reconstruction.cc:1066-1076
         self.SimulateSlicesGPU()
         self.MStepGPU(i + 1)
         self.EStepGPU()

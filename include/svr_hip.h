@@ -42,8 +42,9 @@ int svr_create(int device, svr_ctx **out);
 /* Reconstruction::~Reconstruction  RC.cuh:95, RC.cu:1232-1273 */
 void svr_destroy(svr_ctx *ctx);
 const char *svr_last_error(const svr_ctx *ctx);
-/* flags  _disableBiasC / _debugGPU  (RC.cuh public members; RG.cc:227-238).  This build
- * implements the bias-disabled path only (the CLI default, reconstruction.cc:121,202). */
+/* flags  _disableBiasC / _debugGPU  (RC.cuh public members; RG.cc:227-238).  The default is the
+ * reference CLI's: bias correction disabled (reconstruction.cc:121,202).  Call with
+ * disable_bias_correction = 0 before the first compute call to enable the bias path. */
 int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
 /* engine tuning knobs (no reference equivalent).  "back_mode": 2 = plane-owned LDS tiles
  * (default; no atomics inside a tile), 1 = LDS tiles with ds_add_f32, 0 = direct device-scope
@@ -107,6 +108,10 @@ int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec);
 int svr_superresolution(svr_ctx *ctx, int iter, const float *slice_weight, int adaptive, float alpha,
                         float min_intensity, float max_intensity, float delta, float lambda,
                         int global_bias_correction, float sigma_bias, float low_intensity_cutoff);
+/* CorrectBias(float sigma_bias, bool global_bias_correction)  RC.cuh:261, RC.cu:1837-1942 */
+int svr_correct_bias(svr_ctx *ctx, float sigma_bias, int global_bias_correction);
+/* NormaliseBias(int iter, float sigma_bias)  RC.cuh:251, RC.cu:2519-2652 */
+int svr_normalise_bias(svr_ctx *ctx, int iter, float sigma_bias);
 /* maskVolume()  RC.cuh:270, RC.cu:3313-3347 */
 int svr_mask_volume(svr_ctx *ctx);
 /* ScaleVolume()  RC.cuh:271, RC.cu:3386-3470 */
@@ -122,11 +127,14 @@ enum svr_buffer {
   SVR_BUF_ADDON = 2,         /* debugAddon */
   SVR_BUF_CONFIDENCE_MAP = 3,/* debugConfidenceMap */
   SVR_BUF_MASK = 4,
+  SVR_BUF_BIAS_VOLUME = 5,   /* debugNormalizeBias */
+  SVR_BUF_SMOOTH_MASK = 6,   /* debugSmoothMask */
   SVR_BUF_SLICES = 10,       /* slice-grid-shaped float */
   SVR_BUF_WEIGHTS = 11,      /* debugWeights */
   SVR_BUF_SIMSLICES = 12,    /* debugSimslices */
   SVR_BUF_SIMWEIGHTS = 13,   /* debugSimweights */
   SVR_BUF_PSF_SUMS = 14,     /* debugv_PSF_sums */
+  SVR_BUF_BIAS = 15,         /* debugBias */
   SVR_BUF_SIMINSIDE = 20,    /* slice-grid-shaped char, debugSiminside */
   SVR_BUF_VOXEL_COUNT = 21   /* slice-grid-shaped int (sliceVoxel_count_) */
 };
@@ -151,6 +159,9 @@ int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num_local); /* e
 int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight); /* addon|cmap */
 int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity,
                                float max_intensity, float delta, float lambda);
+/* NormaliseBias halves: scatter into SVR_BUF_BIAS_VOLUME (all-reduce it), then normalise + apply */
+int svr_normalise_bias_local(svr_ctx *ctx);
+int svr_normalise_bias_finish(svr_ctx *ctx, float sigma_bias);
 /* partial sums for the caller to all-reduce: {sum (s-sim)^2, count} */
 int svr_robust_statistics_sums(svr_ctx *ctx, double out2[2]);
 /* {sum e^2 w, sum w, count, min e, max e} (min/max reduce with min/max) */

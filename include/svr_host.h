@@ -53,6 +53,11 @@ void svrh_set_intensity_range(svrh_recon *r, double min_intensity, double max_in
 void svrh_set_smoothing_parameters(svrh_recon *r, double delta, double lambda);             /* RG.h:605-612 */
 void svrh_set_force_excluded(svrh_recon *r, const int *idx, int n);                         /* RG.h:614-617 */
 
+/* disableBiasCorrection() RG.cc:234-238 / SetSigma RG.h:376; BiasGPU RG.cc:3904-3913, NormaliseBiasGPU RG.cc:4653 */
+int svrh_set_bias_correction(svrh_recon *r, int enable, double sigma_bias);
+int svrh_bias_gpu(svrh_recon *r);
+int svrh_normalise_bias_gpu(svrh_recon *r, int iter);
+
 int svrh_initialize_em_values_gpu(svrh_recon *r);
 int svrh_gaussian_reconstruction_gpu(svrh_recon *r);
 int svrh_simulate_slices_gpu(svrh_recon *r);

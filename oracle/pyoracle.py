@@ -27,6 +27,7 @@ class Geom(C.Structure):
         ("T", C.c_void_p), ("Tinv", C.c_void_p), ("sliceDim", C.c_void_p),
         ("psf_c0", C.c_float * 3),
         ("psf_mode", C.c_int),
+        ("bias2D", C.c_void_p),
     ]
 
 
@@ -65,9 +66,10 @@ class OracleReconstruction:
     tests compare buffer by buffer.  Includes the reference's host-glue quirks that live below the
     boundary (e.g. the one-call lag of the device scale vector, RC.cu:3195,3238)."""
 
-    def __init__(self, prob, mode=CANON):
+    def __init__(self, prob, mode=CANON, bias_correction=False):
         self.prob = prob
         self.mode = mode
+        self.bias_correction = bool(bias_correction)
         self._keep = [_f32(prob.slice_i2w), _f32(prob.slice_w2i), _f32(prob.slice_t), _f32(prob.slice_tinv),
                       _f32(prob.slice_dim)]
         g = Geom()
@@ -100,6 +102,22 @@ class OracleReconstruction:
         self.d_scales = np.ones(ns, np.float32)
         self.h_scales = np.ones(ns, np.float32)
         self.slice_weights = np.ones(ns, np.float32)
+        self.bias = None
+        if self.bias_correction:                       # _disableBiasC == false
+            self.bias = np.zeros(shp, np.float32)
+            g.bias2D = self.bias.ctypes.data
+            self.wb = np.zeros(shp, np.float32)
+            self.wr = np.zeros(shp, np.float32)
+            self.buffer = np.zeros(shp, np.float32)
+            self.bias_vol = np.zeros(nv, np.float32)
+            self.volume_weights = np.zeros(nv, np.float32)
+            self.maskC = np.zeros(nv, np.float32)
+            vx, vy, vz = prob.vsize
+            lib().orc_smooth_mask(vx, vy, vz, (C.c_float * 3)(*[float(d) for d in prob.vdim]), _p(self.mask),
+                                  C.c_float(12.0), _p(self.maskC))
+
+    def _b(self):
+        return _p(self.bias) if self.bias is not None else None
 
     # ---- state -------------------------------------------------------------------------
     def UpdateScaleVector(self, scales, slice_weights):
@@ -158,6 +176,20 @@ class OracleReconstruction:
 
     def InitializeEMValues(self):
         lib().orc_initialize_em_values(C.c_size_t(self.slices.size), _p(self.slices), _p(self.weights))
+        if self.bias is not None:
+            self.bias[...] = 0                          # RC.cu:3305-3309
+
+    # ---- bias path (RC.cu:1837-1942, 2519-2652) ---------------------------------------------
+    def CorrectBias(self, sigma_bias, global_bias_correction=False):
+        lib().orc_correct_bias(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.bias), _p(self.weights),
+                               _p(self.simweights), _p(self.simslices), _p(self.d_scales), _p(self._keep[4]),
+                               C.c_float(sigma_bias), int(bool(global_bias_correction)), _p(self.wb), _p(self.wr),
+                               _p(self.buffer))
+
+    def NormaliseBias(self, it, sigma_bias):
+        lib().orc_normalise_bias(C.byref(self.g), _p(self.slices), _p(self.d_scales), _p(self.mask),
+                                 _p(self.psf_sums), _p(self.volw), _p(self.maskC), C.c_float(sigma_bias),
+                                 _p(self.bias_vol), _p(self.volume_weights), _p(self.recon))
 
     def RobustStatisticsSums(self):
         s, n = C.c_double(0), C.c_double(0)
@@ -172,13 +204,14 @@ class OracleReconstruction:
     def EStep(self, m, sigma, mix):
         pot = np.zeros(self.g.ns, np.float32)
         lib().orc_estep(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.simslices), _p(self.simweights),
-                        _p(self.d_scales), C.c_float(m), C.c_float(sigma), C.c_float(mix), _p(self.weights), _p(pot))
+                        _p(self.d_scales), C.c_float(m), C.c_float(sigma), C.c_float(mix), _p(self.weights), _p(pot),
+                        self._b())
         return pot
 
     def MStepSums(self):
         out5 = np.zeros(5, np.float64)
         lib().orc_mstep_sums(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.weights), _p(self.simslices),
-                             _p(self.simweights), _p(self.h_scales), _p(out5))   # h_scales: RC.cu:3093
+                             _p(self.simweights), _p(self.h_scales), _p(out5), self._b())   # h_scales: RC.cu:3093
         return out5
 
     def MStep(self, it, step, sigma, mix):
@@ -190,7 +223,7 @@ class OracleReconstruction:
     def CalculateScaleVector(self):
         sc = np.zeros(self.g.ns, np.float32)
         lib().orc_calculate_scale_vector(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.weights),
-                                         _p(self.simslices), _p(self.simweights), _p(sc))
+                                         _p(self.simslices), _p(self.simweights), _p(sc), self._b())
         self.d_scales = self.h_scales.copy()   # RC.cu:3238 uploads the PREVIOUS h_scales ...
         self.h_scales = sc.copy()              # ... and RC.cu:3195 then replaces it
         return sc
@@ -219,7 +252,8 @@ class OracleReconstruction:
     def debug_get(self, which):
         return {0: self.recon, 1: self.volw, 2: self.addon, 3: self.cmap, 4: self.mask, 10: self.slices,
                 11: self.weights, 12: self.simslices, 13: self.simweights, 14: self.psf_sums,
-                20: self.siminside, 21: self.voxcount}[which]
+                15: self.bias, 20: self.siminside, 21: self.voxcount, 5: getattr(self, "bias_vol", None),
+                6: getattr(self, "maskC", None)}[which]
 
     # ---- per-pixel probes ------------------------------------------------------------------
     def tap_census(self, sl, px, py, with_vals=False):

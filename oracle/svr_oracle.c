@@ -58,6 +58,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
 #define ORC_PSF_LITERAL 0
 #define ORC_PSF_CANON 1
 
@@ -79,6 +83,7 @@ typedef struct {
   const float *sliceDim;  /* ns*3 (dx,dy,thickness) (RC.cu:772-833) */
   float psf_c0[3];        /* d_PSFI2W*((PSFsize-1)/2) (RC.cu:172) */
   int psf_mode;           /* ORC_PSF_LITERAL / ORC_PSF_CANON */
+  const float *bias2D;    /* per-pixel log bias field, NULL = _disableBiasC (RC.cu:200-203,439-442) */
 } orc_geom;
 
 /* ---- Matrix4 helpers, literal operation order of RVH:106-145 -------------- */
@@ -309,7 +314,8 @@ int orc_gaussian_reconstruction(const orc_geom *g, const float *slices, const fl
         size_t idx = (size_t)px + (size_t)py * g->sx + (size_t)sl * g->sx * g->sy;
         float s = slices[idx];
         if (s == -1.0f) continue;            /* RC.cu:195 */
-        s = s * scales[sl];                  /* RC.cu:201 */
+        if (g->bias2D) s = s * expf(-g->bias2D[idx]) * scales[sl];   /* RC.cu:203 */
+        else s = s * scales[sl];                                       /* RC.cu:201 */
         pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
         sume_ctx sc = {g, 0.0f, 0.0};
         walk_taps(g, &sp, &pp, visit_sume, &sc);
@@ -422,7 +428,7 @@ void orc_superresolution_backproject(const orc_geom *g, const float *slices, con
         if (sume == 0.0f) continue;
         float w = weights[idx];
         float ss = simslices[idx];
-        float sliceVal = s * scales[sl];
+        float sliceVal = g->bias2D ? s * expf(-g->bias2D[idx]) * scales[sl] : s * scales[sl]; /* RC.cu:439-442 */
         if (ss > 0.0f) sliceVal = sliceVal - ss; else sliceVal = 0.0f; /* RC.cu:444-447 */
         pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
         sr_ctx sc = {g, mask, sume, w, slice_weights[sl], sliceVal, addon, cmap, ad, cd};
@@ -572,7 +578,7 @@ static float G_(float x, float s) { /* RC.cu:62-65 */
  * weights: out (zeroed first, RC.cu:2881). */
 void orc_estep(int sx, int sy, int ns, const float *slices, const float *simslices,
                const float *simweights, const float *scales, float m_, float sigma_, float mix_,
-               float *weights, float *slice_potential) {
+               float *weights, float *slice_potential, const float *bias) {
   size_t n2 = (size_t)sx * sy;
   memset(weights, 0, n2 * ns * sizeof(float));
   for (int sl = 0; sl < ns; ++sl) {
@@ -580,7 +586,7 @@ void orc_estep(int sx, int sy, int ns, const float *slices, const float *simslic
       size_t idx = (size_t)sl * n2 + i;
       float s = slices[idx], sw = simweights[idx];
       if (s == -1 || sw <= 0) continue;
-      float sliceVal = s * scales[sl];
+      float sliceVal = bias ? s * expf(-bias[idx]) * scales[sl] : s * scales[sl];   /* RC.cu:2792-2795 */
       sliceVal -= simslices[idx];
       float g = G_(sliceVal, sigma_);
       float m = m_ * STEP_; /* M_ RC.cu:67-70 */
@@ -603,15 +609,17 @@ void orc_estep(int sx, int sy, int ns, const float *slices, const float *simslic
  * (reduce identity (0,0,0,0,0), per-element identity (inf, 0)). */
 void orc_mstep_sums(int sx, int sy, int ns, const float *slices, const float *weights,
                     const float *simslices, const float *simweights, const float *scales,
-                    double out5[5]) {
+                    double out5[5], const float *bias) {
   size_t n2 = (size_t)sx * sy;
   double sigma = 0, mix = 0, num = 0; float mn = 0.0f, mx = 0.0f;
   for (int sl = 0; sl < ns; ++sl)
     for (size_t i = 0; i < n2; ++i) {
       size_t idx = (size_t)sl * n2 + i;
       float s = slices[idx];
-      if (s != -1.0f && simweights[idx] > 0.99f) {
-        float e = (s * scales[sl]) - simslices[idx];
+      /* transformMStep3D compares sw with the double 0.99, ...NoBias with 0.99f (RC.cu:2947,2985) */
+      int take = bias ? (s != -1.0f && (double)simweights[idx] > 0.99) : (s != -1.0f && simweights[idx] > 0.99f);
+      if (take) {
+        float e = bias ? (s * expf(-bias[idx]) * scales[sl]) - simslices[idx] : (s * scales[sl]) - simslices[idx];
         sigma += (double)(e * e * weights[idx]);
         mix += (double)weights[idx];
         num += 1.0;
@@ -636,7 +644,8 @@ void orc_mstep_finish(const double in5[5], int iter, float step, float *sigma_io
 
 /* transformScalenoBias + CalculateScaleVector RC.cu:3142-3239 */
 void orc_calculate_scale_vector(int sx, int sy, int ns, const float *slices, const float *weights,
-                                const float *simslices, const float *simweights, float *scale_vec) {
+                                const float *simslices, const float *simweights, float *scale_vec,
+                                const float *bias) {
   size_t n2 = (size_t)sx * sy;
   for (int sl = 0; sl < ns; ++sl) {
     double num = 0, den = 0;
@@ -644,8 +653,14 @@ void orc_calculate_scale_vector(int sx, int sy, int ns, const float *slices, con
       size_t idx = (size_t)sl * n2 + i;
       float s = slices[idx];
       if (s == -1.0f || simweights[idx] <= 0.99f) continue;
-      num += (double)(weights[idx] * s * simslices[idx]);
-      den += (double)(weights[idx] * s * s);
+      if (bias) {                                 /* transformScale RC.cu:3133-3136 */
+        float eb = expf(-bias[idx]);
+        num += (double)(weights[idx] * s * eb * simslices[idx]);
+        den += (double)(weights[idx] * s * eb * s * eb);
+      } else {
+        num += (double)(weights[idx] * s * simslices[idx]);
+        den += (double)(weights[idx] * s * s);
+      }
     }
     scale_vec[sl] = ((float)den != 0.0f) ? (float)num / (float)den : 1.0f;
   }
@@ -811,4 +826,174 @@ double orc_ncc_evaluate(const short *target_in, int tx, int ty, int tz, const do
   sums6[0] = _n; sums6[1] = _x; sums6[2] = _y; sums6[3] = _x2; sums6[4] = _y2; sums6[5] = _xy;
   if (_n > 0) return (_xy - (_x * _y) / _n) / (sqrt(_x2 - _x * _x / _n) * sqrt(_y2 - _y * _y / _n));
   return 0;
+}
+
+/* ================================ bias correction ==========================================
+ * CorrectBias (RC.cu:1837-1942): calculateResidual3D_adv (1687-1731), GaussianConvolutionKernel<float>
+ * (909-985) x4 with the reference's buffer reuse, updateBiasField3D_adv (1734-1758), per-slice mean
+ * (1899-1922) and transformBiasMean (1760-1783). */
+static int reflect_(int M, int x) { return x < 0 ? 0 : (x > M - 1 ? M - 1 : x); }   /* RC.cu:53-56 */
+
+/* one 1-D pass over every slice; output written only where the result != 0 (RC.cu:980-983) */
+static void gauss_conv_slices(int sx, int sy, int ns, const float *in, float *out, const float *sliceDim,
+                              float sigma, int horizontal) {
+  size_t n2 = (size_t)sx * sy;
+  for (int sl = 0; sl < ns; ++sl) {
+    float sigma2 = sigma / sliceDim[3 * sl];
+    int klength = 2 * (int)roundf(4 * sigma2) + 1;
+    klength -= 1 - klength % 2;
+    int half = (klength - 1) / 2;
+    for (int y = 0; y < sy; ++y) for (int x = 0; x < sx; ++x) {
+      size_t idx = (size_t)x + (size_t)y * sx + sl * n2;
+      float g0 = (float)(1.0 / (sqrt(2.0 * M_PI) * sigma2));
+      float g1 = (float)exp(-0.5 / (sigma2 * sigma2));
+      float g2 = g1 * g1;
+      float sum = g0 * in[idx];
+      float sum_coeff = g0;
+      for (int i = 1; i <= half; ++i) {
+        g0 *= g1; g1 *= g2;
+        size_t a = horizontal ? (size_t)reflect_(sx, x + i) + (size_t)y * sx + sl * n2
+                              : (size_t)x + (size_t)reflect_(sy, y + i) * sx + sl * n2;
+        sum += g0 * in[a];
+        size_t b = horizontal ? (size_t)reflect_(sx, x - i) + (size_t)y * sx + sl * n2
+                              : (size_t)x + (size_t)reflect_(sy, y - i) * sx + sl * n2;
+        sum += g0 * in[b];
+        sum_coeff += 2 * g0;
+      }
+      float outv = sum / sum_coeff;
+      if (outv != 0) out[idx] = outv;
+    }
+  }
+}
+
+/* bias: in/out.  wb, wr, buffer: scratch of the slice-grid size (returned for inspection). */
+void orc_correct_bias(int sx, int sy, int ns, const float *slices, float *bias, const float *weights,
+                      const float *simweights, const float *simslices, const float *scales,
+                      const float *sliceDim, float sigma_bias, int global_bias_correction, float *wb, float *wr,
+                      float *buffer) {
+  size_t n2 = (size_t)sx * sy, n = n2 * ns;
+  memset(wb, 0, n * sizeof(float)); memset(wr, 0, n * sizeof(float)); memset(buffer, 0, n * sizeof(float));
+  for (int sl = 0; sl < ns; ++sl) for (size_t i = 0; i < n2; ++i) {
+    size_t idx = sl * n2 + i;
+    float s = slices[idx];
+    if (s == -1.0f) continue;
+    float wbo = 0.0f, wro = 0.0f;
+    if ((double)simweights[idx] > 0.99) {
+      float eb = expf(-bias[idx]);
+      float sliceVal = s * (eb * scales[sl]);
+      wbo = weights[idx] * sliceVal;
+      if (((double)simslices[idx] > 1.0) && ((double)sliceVal > 1.0)) wro = logf(sliceVal / simslices[idx]) * wbo;
+    }
+    if (wbo > 0) { wb[idx] = wbo; wr[idx] = wro; }
+  }
+  gauss_conv_slices(sx, sy, ns, wb, buffer, sliceDim, sigma_bias, 1);   /* RC.cu:1886 */
+  gauss_conv_slices(sx, sy, ns, buffer, wb, sliceDim, sigma_bias, 0);   /* RC.cu:1888 */
+  gauss_conv_slices(sx, sy, ns, wr, buffer, sliceDim, sigma_bias, 1);   /* RC.cu:1889: buffer still holds pass 1 */
+  gauss_conv_slices(sx, sy, ns, buffer, wr, sliceDim, sigma_bias, 0);   /* RC.cu:1891 */
+  for (size_t idx = 0; idx < n; ++idx) {
+    if (slices[idx] == -1.0f) continue;
+    if (wb[idx] > 0) bias[idx] = bias[idx] + wr[idx] / wb[idx];
+  }
+  if (!global_bias_correction) {
+    for (int sl = 0; sl < ns; ++sl) {
+      int num = 0; double sum = 0;
+      for (size_t i = 0; i < n2; ++i) { if (slices[sl * n2 + i] > -1) num++; sum += (double)bias[sl * n2 + i]; }
+      float mean = num > 0 ? (float)(sum / (double)num) : -1.0f;
+      if (mean == -1.0f || mean == 0) continue;
+      for (size_t i = 0; i < n2; ++i) if (slices[sl * n2 + i] != -1.0f) bias[sl * n2 + i] -= mean;
+    }
+  }
+}
+
+/* GaussianConvolutionKernel3D RC.cu:988-1093: one direction; output written unless NaN */
+static void gauss_conv3d(const float *in, float *out, float sigma, int dir, const float dim[3], int vx, int vy, int vz) {
+  float sigma2 = sigma / dim[dir];
+  int klength = 2 * (int)roundf(4 * sigma2) + 1;
+  klength -= 1 - klength % 2;
+  int half = (klength - 1) / 2;
+  int size[3] = {vx, vy, vz};
+  size_t stride[3] = {1, (size_t)vx, (size_t)vx * vy};
+  for (int z = 0; z < vz; ++z) for (int y = 0; y < vy; ++y) for (int x = 0; x < vx; ++x) {
+    int pos[3] = {x, y, z};
+    size_t idx = (size_t)x + (size_t)y * vx + (size_t)z * vx * vy;
+    float g0 = (float)(1.0 / (sqrt(2.0 * M_PI) * sigma2));
+    float g1 = (float)exp(-0.5 / (sigma2 * sigma2));
+    float g2 = g1 * g1;
+    float sum = g0 * in[idx], sum_coeff = g0;
+    for (int i = 1; i <= half; ++i) {
+      g0 *= g1; g1 *= g2;
+      size_t a = idx + ((size_t)reflect_(size[dir], pos[dir] + i) - pos[dir]) * stride[dir];
+      sum += g0 * in[a];
+      size_t b = idx - ((size_t)pos[dir] - reflect_(size[dir], pos[dir] - i)) * stride[dir];
+      sum += g0 * in[b];
+      sum_coeff += 2 * g0;
+    }
+    float outv = sum / sum_coeff;
+    if (outv == outv) out[idx] = outv;
+  }
+}
+/* maskC_ of setMask (RC.cu:1129-1157): x into a zeroed buffer, y back, z into the buffer, copy */
+void orc_smooth_mask(int vx, int vy, int vz, const float dim[3], const float *mask, float sigma_bias, float *maskC) {
+  size_t n = (size_t)vx * vy * vz;
+  float *mbuf = (float *)calloc(n, sizeof(float));
+  memcpy(maskC, mask, n * sizeof(float));
+  gauss_conv3d(maskC, mbuf, sigma_bias, 0, dim, vx, vy, vz);
+  gauss_conv3d(mbuf, maskC, sigma_bias, 1, dim, vx, vy, vz);
+  gauss_conv3d(maskC, mbuf, sigma_bias, 2, dim, vx, vy, vz);
+  memcpy(maskC, mbuf, n * sizeof(float));
+  free(mbuf);
+}
+
+/* NormaliseBias (RC.cu:2519-2652) + normalizeBiasKernel3D_tex (525-607).
+ * bias_vol: out.  volume_weights: in/out accumulator (never cleared in the reference).
+ * recon_volw: the Gaussian reconstruction's weights (the divisor, RC.cu:2553-2556). */
+typedef struct { const orc_geom *g; const float *mask; float sume, nbias; float *bias_f, *vw_f; double *bias_d, *vw_d; } nb_ctx;
+static void visit_nb(void *c, float psf, const float ofs[3]) {
+  nb_ctx *s = (nb_ctx *)c; size_t idx;
+  if (vol_index(s->g, f2u_sat(roundf(ofs[0])), f2u_sat(roundf(ofs[1])), f2u_sat(roundf(ofs[2])), &idx) &&
+      s->mask[idx] != 0) {
+    float p = psf / s->sume;
+    if (s->bias_d) { s->bias_d[idx] += (double)(p * s->nbias); s->vw_d[idx] += (double)p; }
+    else { s->bias_f[idx] += p * s->nbias; s->vw_f[idx] += p; }
+  }
+}
+void orc_normalise_bias(const orc_geom *g, const float *slices, const float *scales, const float *mask,
+                        const float *psf_sums, const float *recon_volw, const float *maskC, float sigma_bias,
+                        float *bias_vol, float *volume_weights, float *recon) {
+  size_t nv = (size_t)g->vx * g->vy * g->vz;
+  int canon = g->psf_mode == ORC_PSF_CANON;
+  double *bd = NULL, *wd = NULL;
+  memset(bias_vol, 0, nv * sizeof(float));
+  if (canon) {
+    bd = (double *)calloc(nv, sizeof(double)); wd = (double *)calloc(nv, sizeof(double));
+    for (size_t i = 0; i < nv; ++i) wd[i] = volume_weights[i];
+  }
+  for (int sl = 0; sl < g->ns; ++sl) {
+    slice_psf sp; slice_setup(g, sl, &sp);
+    for (int py = 0; py < g->sy; ++py) for (int px = 0; px < g->sx; ++px) {
+      size_t idx = (size_t)px + (size_t)py * g->sx + (size_t)sl * g->sx * g->sy;
+      if (slices[idx] == -1.0f) continue;
+      float sume = psf_sums[idx];
+      if (sume == 0.0f) continue;
+      float nbias = g->bias2D[idx];
+      if (scales[sl] > 0) nbias -= logf(scales[sl]);
+      pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
+      nb_ctx nc = {g, mask, sume, nbias, bias_vol, volume_weights, bd, wd};
+      walk_taps(g, &sp, &pp, visit_nb, &nc);
+    }
+  }
+  if (canon) {
+    for (size_t i = 0; i < nv; ++i) { bias_vol[i] = (float)bd[i]; volume_weights[i] = (float)wd[i]; }
+    free(bd); free(wd);
+  }
+  for (size_t i = 0; i < nv; ++i) bias_vol[i] = (recon_volw[i] != 0) ? bias_vol[i] / recon_volw[i] : 0;   /* divS */
+  float *mbuf = (float *)malloc(nv * sizeof(float));   /* uninitialised in the reference; every voxel is written unless NaN */
+  memset(mbuf, 0, nv * sizeof(float));
+  gauss_conv3d(bias_vol, mbuf, sigma_bias, 0, g->vdim, g->vx, g->vy, g->vz);
+  gauss_conv3d(mbuf, bias_vol, sigma_bias, 1, g->vdim, g->vx, g->vy, g->vz);
+  gauss_conv3d(bias_vol, mbuf, sigma_bias, 2, g->vdim, g->vx, g->vy, g->vz);
+  memcpy(bias_vol, mbuf, nv * sizeof(float));
+  free(mbuf);
+  for (size_t i = 0; i < nv; ++i) bias_vol[i] = (maskC[i] != 0) ? bias_vol[i] / maskC[i] : 0;             /* divS */
+  for (size_t i = 0; i < nv; ++i) if (recon[i] != -1.0f) recon[i] = recon[i] / expf(-bias_vol[i]);       /* divexp */
 }
