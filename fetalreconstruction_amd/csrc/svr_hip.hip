@@ -73,6 +73,7 @@ struct VolGeom {
   int vx, vy, vz;
   float W2I[12];   // rows 0..2 of reconstructedW2I
   float c0[3];     // d_PSFI2W * ((PSFsize-1)/2)  (RC.cu:172)
+  int pvr;         // patch-to-volume constants
 };
 
 // ------------------------------------------------------------------------------------------
@@ -155,6 +156,7 @@ struct PsfArgs {
   float *psf_sums;
   const float *scales;        // per slice
   const float *bias;          // per-pixel log bias field, NULL when _disableBiasC (RC.cu:200-203)
+  const unsigned char *spx;   // PVR superpixel masks [ns][64*64] of '0'/'1' or NULL (ImagePatch2D.cuh:51)
   // gauss (MODE_BIAS reuses recon/volw for the bias volume / its accumulated weights)
   float *recon, *volw;
   int *voxcount;
@@ -194,7 +196,7 @@ __device__ __forceinline__ PixelState pixel_setup(const SliceConst &S, const Vol
   double d2 = (double)S.A[8] * cx + (double)S.A[9] * cy + (double)S.A[10] * cz + (double)S.A[11] - 0.0;
   P.bx = (float)((d0 * S.dim[0] - vg.c0[0]) * S.kx);
   P.by = (float)((d1 * S.dim[1] - vg.c0[1]) * S.ky);
-  P.bz = (float)(d2 * S.dim[2] - vg.c0[2]);
+  P.bz = vg.pvr ? (float)(d2 * S.dim[2] / 2.5 - vg.c0[2]) : (float)(d2 * S.dim[2] - vg.c0[2]);
   return P;
 }
 
@@ -219,20 +221,25 @@ __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
 // issue back to back -- evaluated tap after tap the dependent chains (sqrt, division, two
 // polynomials) left the SIMDs latency-bound (forward time scaled 1:1 with occupancy).  The
 // arithmetic per tap is exactly psf_eval's, so the values stay bit-identical to the oracle.
-#define EVAL_CHUNK 8
-__device__ __forceinline__ void eval_row_at(const RowConst &S, float bx, float by, float bz, float fy,
-                                            float fz, float out[16]) {
+// N = PSF support (16 for SVR, 12 for PVR), CENTRE = (N-1)/2; PVR selects the patch-to-volume
+// constants (sinc_pi Taylor branch, strict float epsilon; R2/include/pointSpreadFunction.cuh:45-70,
+// R2/include/reconConfig.cuh:138).
+template <int N, bool PVR>
+__device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by, float bz, float fy,
+                                           float fz, float out[N]) {
+  constexpr int EVAL_CHUNK = N / 2;
+  constexpr int CENTRE = (N - 1) / 2;
   const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
   const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
   const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
-  float val[16];
+  float val[N];
 #pragma unroll
-  for (int c0 = 0; c0 < 16; c0 += EVAL_CHUNK) {
+  for (int c0 = 0; c0 < N; c0 += EVAL_CHUNK) {
     float R[EVAL_CHUNK], a[EVAL_CHUNK], r[EVAL_CHUNK], s[EVAL_CHUNK], u[EVAL_CHUNK], k[EVAL_CHUNK];
 #define EACH for (int i = 0; i < EVAL_CHUNK; ++i)
 #pragma unroll
     EACH {
-      const float fx = (float)(c0 + i - PSF_CENTRE);
+      const float fx = (float)(c0 + i - CENTRE);
       const float xs = __builtin_fmaf(S.Lp[0], fx, rowx);
       const float ys = __builtin_fmaf(S.Lp[3], fx, rowy);
       const float zs = __builtin_fmaf(S.Lp[6], fx, rowz);
@@ -262,6 +269,19 @@ __device__ __forceinline__ void eval_row_at(const RowConst &S, float bx, float b
     EACH u[i] = __builtin_fabsf(__builtin_fmaf(s[i], u[i] * r[i], r[i]));
 #pragma unroll
     EACH u[i] = u[i] / R[i];                          // si = |sin R| / R  (NaN at R == 0, RC.cu:129)
+    if (PVR) {
+      // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70)
+#pragma unroll
+      EACH {
+        const float x = R[i], x2 = x * x;
+        float t = 1.0f;
+        if (x >= 1.1920929e-07f) {
+          t -= x2 / 6.0f;
+          if (x >= 3.4526698300e-04f) t += (x2 * x2) / 120.0f;
+        }
+        u[i] = (x >= 1.8581361323e-02f) ? u[i] : t;
+      }
+    }
 #pragma unroll
     EACH u[i] = u[i] * u[i];
     // exp(-a): canon_exp_neg
@@ -293,12 +313,17 @@ __device__ __forceinline__ void eval_row_at(const RowConst &S, float bx, float b
   }
   float old = FLT_MAX;
 #pragma unroll
-  for (int x = 0; x < 16; ++x) {
+  for (int x = 0; x < N; ++x) {
     const float v = val[x];
-    const bool skip = __builtin_fabsf(old - v) <= PSF_EPS_F;   // NaN compares false -> processed
+    // SVR: |d| < 0.00001 (double) == |d| <= 0.00001f; PVR: |d| < 0.00001f.  NaN compares false -> processed
+    const bool skip = PVR ? (__builtin_fabsf(old - v) < PSF_EPS_F) : (__builtin_fabsf(old - v) <= PSF_EPS_F);
     out[x] = skip ? -1.0f : v;
     old = skip ? old : v;
   }
+}
+__device__ __forceinline__ void eval_row_at(const RowConst &S, float bx, float by, float bz, float fy,
+                                            float fz, float out[16]) {
+  eval_row_t<16, false>(S, bx, by, bz, fy, fz, out);
 }
 // Phase 1 of the wave-per-pixel kernels: lane = one (y,z) row of quarter q (4 z-planes x 16 y)
 __device__ __forceinline__ void eval_row(const RowConst &S, const PixelState &P, int lane, int q,
@@ -756,6 +781,131 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Patch-to-volume (PVR) PSF kernels -- first correct version
+// ------------------------------------------------------------------------------------------
+// patchBasedPSFReconstructionKernel (R2/patchBasedPSFReconstruction_gpu.cu:41-145),
+// patchBasedSimulatePatchesKernel (R2/patchBasedSimulatePatches_gpu.cu:41-125),
+// patchBasedSuperresolution_gpuKernel (R2/patchBasedSuperresolution_gpu.cu:34-111).
+// Patches are the "slices" of the padded grid [nPatches][pY][pX]; support 12^3, sigma_z = dim.z,
+// through-plane offset / 2.5, sinc_pi, pixel kept if sume > 1e-5 or NaN, optional superpixel mask.
+// One wavefront per patch pixel; lane = one of the 144 (y,z) rows (3 passes), 12 x-taps each, the
+// volume is accessed straight from the row-per-lane layout (not yet tiled like the SVR scatter).
+#define PVR_N 12
+#define PVR_CENTRE 5
+
+// getReconValueFromTexture (R2/reconVolume.cu:170-187): linear filter at the un-offset coordinate =
+// 0.125 * sum over {p-1,p}^3 with zero border
+__device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, int X, int Y, int Z) {
+  float v = 0.0f;
+#pragma unroll
+  for (int dz = -1; dz <= 0; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 0; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 0; ++dx) {
+        const int x = X + dx, y = Y + dy, z = Z + dz;
+        const float t = (x >= 0 && y >= 0 && z >= 0) ? vol[(size_t)x + (size_t)y * vg.vx + (size_t)z * vg.vx * vg.vy] : 0.0f;
+        v += 0.125f * t;
+      }
+  return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void pvr_kernel(PsfArgs a) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const uint32_t pi = blockIdx.x * WAVES_PER_BLOCK + wave;
+  if (pi >= a.n) return;
+  const uint32_t idx = __builtin_amdgcn_readfirstlane(a.list[pi]);
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+  const uint32_t sl = idx / n2;
+  const uint32_t rem = idx - sl * n2;
+  const int py = (int)(rem / (uint32_t)a.sx);
+  const int px = (int)(rem - (uint32_t)py * (uint32_t)a.sx);
+  const SliceConst &S = a.sc[sl];
+  const VolGeom &vg = a.vg;
+  const PixelState P = pixel_setup(S, vg, px, py);
+  const RowConst RC = load_row_const(S);
+  float s = a.slices[idx] * a.scales[sl];                 // s * patch.scale
+  float sume;
+  if (MODE == MODE_GAUSS) {
+    double acc = 0.0;
+    const bool spx_ok = !a.spx || a.spx[(size_t)sl * 4096 + px + 64 * py] == '1';
+    if (spx_ok) {
+      for (int p = 0; p < 3; ++p) {
+        const int r = p * 64 + lane;
+        const bool valid = r < PVR_N * PVR_N;
+        const int z = r / PVR_N, y = r - z * PVR_N;
+        float out[PVR_N];
+        eval_row_t<PVR_N, true>(RC, P.bx, P.by, P.bz, (float)(y - PVR_CENTRE), (float)(z - PVR_CENTRE), out);
+        const uint32_t az = sat0(P.czi + z - PVR_CENTRE), ay = sat0(P.cyi + y - PVR_CENTRE);
+        const bool rowin = valid && az < (uint32_t)vg.vz && ay < (uint32_t)vg.vy;
+#pragma unroll
+        for (int x = 0; x < PVR_N; ++x) {
+          const uint32_t ax = sat0(P.cxi + x - PVR_CENTRE);
+          acc += (rowin && ax < (uint32_t)vg.vx && !(out[x] < 0.0f)) ? (double)out[x] : 0.0;
+        }
+      }
+    }
+    sume = (float)wave_sum(acc);
+    if (!((sume > 0.00001f) || (sume != sume))) return;   // patchBasedPSFReconstruction_gpu.cu:110
+    if (lane == 0) a.psf_sums[idx] = sume;
+  } else {
+    sume = a.psf_sums[idx];
+  }
+  float f0 = 0.0f, f1 = 0.0f;
+  if (MODE == MODE_BACK) {
+    const float ss = a.simslices[idx];
+    const float e = (ss > 0.0f) ? (s - ss) : 0.0f;         // patchBasedSuperresolution_gpu.cu:64-67
+    f1 = a.weights[idx] * a.slice_weights[sl];             // w * patch_weight
+    f0 = f1 * e;
+  }
+  bool hit = false;
+  for (int p = 0; p < 3; ++p) {
+    const int r = p * 64 + lane;
+    const bool valid = r < PVR_N * PVR_N;
+    const int z = r / PVR_N, y = r - z * PVR_N;
+    float out[PVR_N];
+    eval_row_t<PVR_N, true>(RC, P.bx, P.by, P.bz, (float)(y - PVR_CENTRE), (float)(z - PVR_CENTRE), out);
+    const uint32_t az = sat0(P.czi + z - PVR_CENTRE), ay = sat0(P.cyi + y - PVR_CENTRE);
+    const bool rowin = valid && az < (uint32_t)vg.vz && ay < (uint32_t)vg.vy;
+    if (!rowin) continue;
+#pragma unroll
+    for (int x = 0; x < PVR_N; ++x) {
+      const uint32_t ax = sat0(P.cxi + x - PVR_CENTRE);
+      if (ax < (uint32_t)vg.vx && !(out[x] < 0.0f)) {
+        const uint32_t vi = ax + ay * (uint32_t)vg.vx + az * (uint32_t)(vg.vx * vg.vy);
+        if (a.mask[vi] != 0.0f) {
+          const float pv = out[x] / sume;
+          if (MODE == MODE_GAUSS) {
+            unsafeAtomicAdd(a.volw + vi, pv);
+            unsafeAtomicAdd(a.recon + vi, s * pv);
+          } else if (MODE == MODE_FWD) {
+            f0 += pv * pvr_tex(a.vol, vg, (int)ax, (int)ay, (int)az);
+            f1 += pv;
+          } else {
+            unsafeAtomicAdd(a.addon + vi, pv * f0);
+            unsafeAtomicAdd(a.cmap + vi, pv * f1);
+          }
+          hit = true;
+        }
+      }
+    }
+  }
+  if (MODE == MODE_GAUSS) {
+    if (__ballot(hit) != 0ull && lane == 0) a.voxcount[idx] = 1;
+  } else if (MODE == MODE_FWD) {
+    const float sim = wave_sum(f0), w = wave_sum(f1);
+    const bool inside = __ballot(hit) != 0ull;
+    if (lane == 0 && w > 0.0f) {
+      a.simslices[idx] = sim / w;
+      a.simweights[idx] = w;
+      a.siminside[idx] = inside ? 1 : 0;
+    }
+  }
+}
+
 // test probe: one wave evaluates one pixel; out[x + 16*y + 256*z] = psf or -1 when skipped
 __global__ __launch_bounds__(64) void k_probe_pixel(PsfArgs a, uint32_t idx, float *out, int *centre) {
   const int lane = threadIdx.x & 63;
@@ -767,12 +917,24 @@ __global__ __launch_bounds__(64) void k_probe_pixel(PsfArgs a, uint32_t idx, flo
   const SliceConst &S = a.sc[sl];
   const PixelState P = pixel_setup(S, a.vg, px, py);
   const RowConst RC = load_row_const(S);
-  for (int q = 0; q < 4; ++q) {
-    float v[16];
-    eval_row(RC, P, lane, q, v);
-    const int z = 4 * q + (lane >> 4), y = lane & 15;
+  if (a.vg.pvr) {
+    for (int p = 0; p < 3; ++p) {
+      const int r = p * 64 + lane;
+      if (r >= PVR_N * PVR_N) continue;
+      const int z = r / PVR_N, y = r - z * PVR_N;
+      float v[PVR_N];
+      eval_row_t<PVR_N, true>(RC, P.bx, P.by, P.bz, (float)(y - PVR_CENTRE), (float)(z - PVR_CENTRE), v);
 #pragma unroll
-    for (int x = 0; x < 16; ++x) out[x + 16 * y + 256 * z] = v[x];
+      for (int x = 0; x < PVR_N; ++x) out[x + 16 * y + 256 * z] = v[x];
+    }
+  } else {
+    for (int q = 0; q < 4; ++q) {
+      float v[16];
+      eval_row(RC, P, lane, q, v);
+      const int z = 4 * q + (lane >> 4), y = lane & 15;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) out[x + 16 * y + 256 * z] = v[x];
+    }
   }
   if (lane == 0) { centre[0] = P.cxi; centre[1] = P.cyi; centre[2] = P.czi; }
 }
@@ -1390,6 +1552,8 @@ struct svr_ctx {
   int plane_cap = 9600;     // LDS accumulator voxels of back_plane_kernel: 75 KiB + 4.3 KiB static
                             // -> exactly 2 workgroups per CU (measured: 1 per CU is 1.6x slower)
   bool psf_list_valid = false;
+  int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
+  unsigned char *d_spx = nullptr;
   int back_mode = 2;        // 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
                             // 0 = direct device-scope atomics per tap
   int tile_cap = 0;         // voxels of LDS accumulator per workgroup
@@ -1506,12 +1670,14 @@ int prepare_slice_consts(svr_ctx *ctx) {
     for (int k = 0; k < 3; ++k) S.dim[k] = ctx->slice_dims[3 * s + k];
     S.kx = S.dim[0] / 2.3548f;
     S.ky = S.dim[1] / 2.3548f;
-    float sigmaz = S.dim[2] / 2.3548f;   // RC.cu:114
+    // SVR: sigma_z = dz / 2.3548 (RC.cu:114); PVR: sigma_z = dz and the offset is divided by 2.5
+    // (pointSpreadFunction.cuh:76,112)
+    float sigmaz = ctx->pvr ? S.dim[2] : S.dim[2] / 2.3548f;
     S.inv2s2 = 1.0f / (2.0f * sigmaz * sigmaz);
     for (int j = 0; j < 3; ++j) {
       S.Lp[0 * 3 + j] = (A[0 * 4 + j] * S.dim[0]) * S.kx;
       S.Lp[1 * 3 + j] = (A[1 * 4 + j] * S.dim[1]) * S.ky;
-      S.Lp[2 * 3 + j] = A[2 * 4 + j] * S.dim[2];
+      S.Lp[2 * 3 + j] = ctx->pvr ? (A[2 * 4 + j] * S.dim[2]) / 2.5f : A[2 * 4 + j] * S.dim[2];
     }
   }
   HIPCHK(hipMemcpyAsync(ctx->d_sc, h.data(), h.size() * sizeof(SliceConst), hipMemcpyHostToDevice, ctx->stream));
@@ -1555,6 +1721,8 @@ PsfArgs make_args(svr_ctx *ctx) {
   a.vg.vx = (int)ctx->vx; a.vg.vy = (int)ctx->vy; a.vg.vz = (int)ctx->vz;
   memcpy(a.vg.W2I, ctx->reconW2I, 12 * sizeof(float));
   memcpy(a.vg.c0, ctx->psf_c0, 3 * sizeof(float));
+  a.vg.pvr = ctx->pvr;
+  a.spx = ctx->d_spx;
   a.sx = (int)ctx->sx; a.sy = (int)ctx->sy;
   a.slices = ctx->d_slices; a.mask = ctx->d_mask; a.psf_sums = ctx->d_psf_sums;
   a.scales = ctx->d_scales;
@@ -1702,6 +1870,7 @@ int svr_create(int device, svr_ctx **out) {
 int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; return SVR_OK; }
+  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; return SVR_OK; }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
   if (!strcmp(name, "plane_waves")) { ctx->plane_waves = std::max(4, std::min(value, PLANE_MAX_WAVES)); return SVR_OK; }
@@ -1735,6 +1904,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_bias_vol); free_dev(ctx->d_volume_weights); free_dev(ctx->d_maskC); free_dev(ctx->d_mbuf);
   free_dev(ctx->d_reg_targets);
   free_dev(ctx->d_reg_source);
+  free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1961,7 +2131,11 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   a.list = ctx->d_active;
   a.n = ctx->n_active;
   ScopedTimer t(ctx, SVR_T_GAUSS);
-  if (a.n) {
+  if (a.n && ctx->pvr) {
+    hipLaunchKernelGGL(pvr_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                       ctx->stream, a);
+    KCHK("pvr_kernel<GAUSS>");
+  } else if (a.n) {
     hipLaunchKernelGGL(psf_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("psf_kernel<GAUSS>");
@@ -2005,7 +2179,11 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   ScopedTimer t(ctx, SVR_T_FORWARD);
-  if (a.n) {
+  if (a.n && ctx->pvr) {
+    hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                       ctx->stream, a);
+    KCHK("pvr_kernel<FWD>");
+  } else if (a.n) {
     hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),
                        (size_t)ctx->dbg_fwd_lds, ctx->stream, a);
     KCHK("psf_kernel<FWD>");
@@ -2155,7 +2333,11 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
-  if (a.n && ctx->back_mode == 2) {
+  if (a.n && ctx->pvr) {
+    hipLaunchKernelGGL(pvr_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                       ctx->stream, a);
+    KCHK("pvr_kernel<BACK>");
+  } else if (a.n && ctx->back_mode == 2) {
     TileArgs ta;
     ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
     ta.cap = std::min(ctx->plane_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
@@ -2375,6 +2557,19 @@ int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals40
   (void)hipFree(d_v);
   (void)hipFree(d_c);
   if (e != hipSuccess) return fail(ctx, (int)e, "svr_debug_probe_pixel");
+  return SVR_OK;
+}
+
+// ---- PVR superpixel masks (ImagePatch2D::spxMask, R2/include/ImagePatch2D.cuh:51) ----------
+int svr_set_spx_masks(svr_ctx *ctx, const char *masks_or_null) {
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->ns > 0, "initStorageVolumes first");
+  free_dev(ctx->d_spx);
+  if (!masks_or_null) return SVR_OK;
+  const size_t bytes = (size_t)ctx->ns * 4096;
+  HIPCHK(hipMalloc(&ctx->d_spx, bytes));
+  HIPCHK(hipMemcpyAsync(ctx->d_spx, masks_or_null, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
 }
 

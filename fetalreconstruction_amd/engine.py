@@ -26,7 +26,7 @@ T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE = ran
 TIMER_NAMES = ["backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale"]
 
 EXPORTS = [
-    "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_init_reconstruction_volume",
+    "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_set_spx_masks", "svr_init_reconstruction_volume",
     "svr_set_mask", "svr_init_storage_volumes", "svr_fill_slices", "svr_set_slice_dims",
     "svr_set_slice_matrices", "svr_generate_psf_volume", "svr_update_scale_vector",
     "svr_update_slice_weights", "svr_update_reconstructed", "svr_sync_cpu", "svr_get_vol_weights",
@@ -309,6 +309,13 @@ class Reconstruction:
         ncc = np.zeros(len(idx), np.float64)
         self._ck(self._lib.svr_ncc_evaluate(self._h, len(idx), _p(idx), _p(m), _p(sums), _p(ncc)))
         return ncc, sums
+
+    def set_spx_masks(self, masks):
+        if masks is None:
+            self._ck(self._lib.svr_set_spx_masks(self._h, None))
+        else:
+            m = np.ascontiguousarray(masks, np.uint8)
+            self._ck(self._lib.svr_set_spx_masks(self._h, _p(m)))
 
     def set_option(self, name, value):
         self._ck(self._lib.svr_set_option(self._h, name.encode(), int(value)))

@@ -50,6 +50,12 @@ int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
  * (default; no atomics inside a tile), 1 = LDS tiles with ds_add_f32, 0 = direct device-scope
  * atomics per tap. */
 int svr_set_option(svr_ctx *ctx, const char *name, int value);
+/* "pvr" = 1 switches the PSF kernels to the patch-to-volume constants of
+ * PVRreconstructionGPU (patchBasedPSFReconstruction_gpu.cu, patchBasedSimulatePatches_gpu.cu,
+ * patchBasedSuperresolution_gpu.cu): patches are handed over as the "slices" of the padded grid,
+ * patch.scale / patch.patchWeight as the scale / slice-weight vectors.  Optional superpixel masks:
+ * ImagePatch2D::spxMask, n_patches * 64*64 chars of '0'/'1' (NULL clears them). */
+int svr_set_spx_masks(svr_ctx *ctx, const char *masks_or_null);
 
 /* ---- geometry / state upload -------------------------------------------------------- */
 /* InitReconstructionVolume(uint3 s, float3 dim, float* data, float sigma_bias)  RC.cuh:230, RC.cu:1160-1230 */

@@ -28,6 +28,8 @@ class Geom(C.Structure):
         ("psf_c0", C.c_float * 3),
         ("psf_mode", C.c_int),
         ("bias2D", C.c_void_p),
+        ("pvr", C.c_int),
+        ("spx_mask", C.c_void_p),
     ]
 
 
@@ -66,8 +68,10 @@ class OracleReconstruction:
     tests compare buffer by buffer.  Includes the reference's host-glue quirks that live below the
     boundary (e.g. the one-call lag of the device scale vector, RC.cu:3195,3238)."""
 
-    def __init__(self, prob, mode=CANON, bias_correction=False):
+    def __init__(self, prob, mode=CANON, bias_correction=False, pvr=False, spx_masks=None):
         self.prob = prob
+        self.pvr = bool(pvr)
+        self.spx_masks = None if spx_masks is None else np.ascontiguousarray(spx_masks, np.uint8)
         self.mode = mode
         self.bias_correction = bool(bias_correction)
         self._keep = [_f32(prob.slice_i2w), _f32(prob.slice_w2i), _f32(prob.slice_t), _f32(prob.slice_tinv),
@@ -82,6 +86,8 @@ class OracleReconstruction:
         g.sliceI2W, g.sliceW2I, g.T, g.Tinv, g.sliceDim = [a.ctypes.data for a in self._keep]
         g.psf_c0[:] = _f32(prob.psf_c0).tolist()
         g.psf_mode = mode
+        g.pvr = int(self.pvr)
+        g.spx_mask = self.spx_masks.ctypes.data if self.spx_masks is not None else None
         self.g = g
         self.vsize = tuple(prob.vsize)
         self.sgrid = (ns, sy, sx)

@@ -84,7 +84,19 @@ typedef struct {
   float psf_c0[3];        /* d_PSFI2W*((PSFsize-1)/2) (RC.cu:172) */
   int psf_mode;           /* ORC_PSF_LITERAL / ORC_PSF_CANON */
   const float *bias2D;    /* per-pixel log bias field, NULL = _disableBiasC (RC.cu:200-203,439-442) */
+  int pvr;                /* 1 = patch-to-volume constants (see "PVR deltas" below) */
+  const unsigned char *spx_mask; /* PVR superpixel masks [ns][64*64] of '0'/'1', or NULL (ImagePatch2D.cuh:51) */
 } orc_geom;
+
+/* PVR deltas.  R2 = /root/reference/source/reconstructionGPU2:
+ *   support 12^3 (R2/include/reconConfig.cuh:140), through-plane sigma = dim.z and offset / 2.5
+ *   (R2/include/pointSpreadFunction.cuh:76,112), sinc_pi with a Taylor branch near 0 instead of NaN
+ *   (pointSpreadFunction.cuh:45-70), float epsilon 0.00001f (reconConfig.cuh:138), pixel kept if
+ *   sume > 1e-5 or NaN and the superpixel test in pass 1 (R2/patchBasedPSFReconstruction_gpu.cu:95-110),
+ *   forward projection through a linear-filtered texture at un-offset coordinates = the 8-voxel
+ *   average of {p-1,p}^3 with zero border (R2/reconVolume.cu:150-187). */
+static int psf_support(const orc_geom *g) { return g->pvr ? 12 : 16; }
+static int psf_centre(const orc_geom *g) { return (psf_support(g) - 1) / 2; }
 
 /* ---- Matrix4 helpers, literal operation order of RVH:106-145 -------------- */
 static void matvec3(const float *M, const float v[3], float out[3]) {
@@ -174,12 +186,12 @@ static void slice_setup(const orc_geom *g, int sl, slice_psf *sp) {
   for (int k = 0; k < 3; ++k) sp->dim[k] = g->sliceDim[3 * sl + k];
   sp->kx = sp->dim[0] / 2.3548f;
   sp->ky = sp->dim[1] / 2.3548f;
-  float sigmaz = sp->dim[2] / 2.3548f;
+  float sigmaz = g->pvr ? sp->dim[2] : sp->dim[2] / 2.3548f;
   sp->inv2s2 = 1.0f / (2.0f * sigmaz * sigmaz);
   for (int j = 0; j < 3; ++j) {
     sp->Lp[0 * 3 + j] = (sp->A[0 * 4 + j] * sp->dim[0]) * sp->kx;
     sp->Lp[1 * 3 + j] = (sp->A[1 * 4 + j] * sp->dim[1]) * sp->ky;
-    sp->Lp[2 * 3 + j] = sp->A[2 * 4 + j] * sp->dim[2];
+    sp->Lp[2 * 3 + j] = g->pvr ? (sp->A[2 * 4 + j] * sp->dim[2]) / 2.5f : sp->A[2 * 4 + j] * sp->dim[2];
   }
 }
 
@@ -199,7 +211,20 @@ static void pixel_setup(const orc_geom *g, int sl, const slice_psf *sp, int px, 
            (double)sp->A[4 * k + 2] * pp->c[2] + (double)sp->A[4 * k + 3] - (double)pp->pos[k];
   pp->b[0] = (float)((d[0] * sp->dim[0] - g->psf_c0[0]) * sp->kx);
   pp->b[1] = (float)((d[1] * sp->dim[1] - g->psf_c0[1]) * sp->ky);
-  pp->b[2] = (float)(d[2] * sp->dim[2] - g->psf_c0[2]);
+  pp->b[2] = g->pvr ? (float)(d[2] * sp->dim[2] / 2.5 - g->psf_c0[2]) : (float)(d[2] * sp->dim[2] - g->psf_c0[2]);
+}
+
+/* PointSpreadFunction::sinc_pi (pointSpreadFunction.cuh:45-70), float instantiation */
+static float sinc_pi_f(float x, int canon) {
+  const float t0 = FLT_EPSILON, t2 = 3.4526698300e-04f /* sqrtf(eps) */, tn = 1.8581361323e-02f /* sqrtf(t2) */;
+  if (fabsf(x) >= tn) return canon ? canon_abs_sin(x) / x : sinf(x) / x;
+  float result = 1.0f;
+  if (fabsf(x) >= t0) {
+    float x2 = x * x;
+    result -= x2 / 6.0f;
+    if (fabsf(x) >= t2) result += (x2 * x2) / 120.0f;
+  }
+  return result;
 }
 
 /* PSF value of tap (ox,oy,oz) in [-7,8]^3 relative to the centre voxel.
@@ -213,16 +238,17 @@ static float psf_literal(const orc_geom *g, const slice_psf *sp, const pixel_psf
   matvec3(sp->A, ofs, p2);
   float q[3];
   for (int k = 0; k < 3; ++k) q[k] = (p2[k] - pp->pos[k]) * sp->dim[k];
+  if (g->pvr) q[2] = q[2] / 2.5f;                    /* pointSpreadFunction.cuh:112 */
   for (int k = 0; k < 3; ++k) q[k] = q[k] - g->psf_c0[k];
-  const float sigmaz = sp->dim[2] / 2.3548f;
+  const float sigmaz = g->pvr ? sp->dim[2] : sp->dim[2] / 2.3548f;
   float x_ = q[0] * sp->dim[0] / 2.3548f;
   float y_ = q[1] * sp->dim[1] / 2.3548f;
   float x = sqrtf(x_ * x_ + y_ * y_);
   float R = 3.14159265359f * x;
-  float si = sinf(R) / (R);
+  float si = g->pvr ? sinc_pi_f(R, 0) : sinf(R) / (R);
   return si * si * expf((-q[2] * q[2]) / (2.0f * sigmaz * sigmaz));
 }
-static float psf_canon(const slice_psf *sp, const pixel_psf *pp, int ox, int oy, int oz,
+static float psf_canon(const orc_geom *g, const slice_psf *sp, const pixel_psf *pp, int ox, int oy, int oz,
                        float ofs[3]) {
   ofs[0] = (float)ox + pp->c[0];
   ofs[1] = (float)oy + pp->c[1];
@@ -233,7 +259,7 @@ static float psf_canon(const slice_psf *sp, const pixel_psf *pp, int ox, int oy,
   float zs = fmaf(sp->Lp[6], fx, fmaf(sp->Lp[7], fy, fmaf(sp->Lp[8], fz, pp->b[2])));
   float q = fmaf(ys, ys, xs * xs);
   float R = 3.14159265359f * sqrtf(q);
-  float si = canon_abs_sin(R) / R;
+  float si = g->pvr ? sinc_pi_f(R, 1) : canon_abs_sin(R) / R;
   float gz = canon_exp_neg((zs * zs) * sp->inv2s2);
   return (si * si) * gz;
 }
@@ -243,15 +269,17 @@ static float psf_canon(const slice_psf *sp, const pixel_psf *pp, int ox, int oy,
 typedef void (*tap_fn)(void *ctx, float psf, const float ofs[3]);
 static void walk_taps(const orc_geom *g, const slice_psf *sp, const pixel_psf *pp,
                       tap_fn visit, void *ctx) {
-  for (int z = 0; z < PSF_SUPPORT; z++)
-    for (int y = 0; y < PSF_SUPPORT; y++) {
+  const int S = psf_support(g), Cn = psf_centre(g);
+  for (int z = 0; z < S; z++)
+    for (int y = 0; y < S; y++) {
       float oldPSF = FLT_MAX;
-      for (int x = 0; x < PSF_SUPPORT; x++) {
+      for (int x = 0; x < S; x++) {
         float ofs[3];
         float psfval = (g->psf_mode == ORC_PSF_LITERAL)
-                           ? psf_literal(g, sp, pp, x - PSF_CENTRE, y - PSF_CENTRE, z - PSF_CENTRE, ofs)
-                           : psf_canon(sp, pp, x - PSF_CENTRE, y - PSF_CENTRE, z - PSF_CENTRE, ofs);
-        if ((double)fabsf(oldPSF - psfval) < PSF_EPSILON) continue;
+                           ? psf_literal(g, sp, pp, x - Cn, y - Cn, z - Cn, ofs)
+                           : psf_canon(g, sp, pp, x - Cn, y - Cn, z - Cn, ofs);
+        /* SVR: double literal 0.00001 (RC.cuh:72); PVR: float literal 0.00001f (reconConfig.cuh:138) */
+        if (g->pvr ? (fabsf(oldPSF - psfval) < 0.00001f) : ((double)fabsf(oldPSF - psfval) < PSF_EPSILON)) continue;
         oldPSF = psfval;
         visit(ctx, psfval, ofs);
       }
@@ -318,9 +346,14 @@ int orc_gaussian_reconstruction(const orc_geom *g, const float *slices, const fl
         else s = s * scales[sl];                                       /* RC.cu:201 */
         pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
         sume_ctx sc = {g, 0.0f, 0.0};
-        walk_taps(g, &sp, &pp, visit_sume, &sc);
+        /* PVR superpixel mode: pass-1 taps only count when the pixel is inside its superpixel
+         * (patchBasedPSFReconstruction_gpu.cu:95-99; mask indexed pos.x + 64*pos.y) */
+        if (!(g->pvr && g->spx_mask && g->spx_mask[(size_t)sl * 4096 + px + 64 * py] != '1'))
+          walk_taps(g, &sp, &pp, visit_sume, &sc);
         float sume = canon ? (float)sc.sume_d : sc.sume_f;
-        if (sume > 0.5f) psf_sums[idx] = sume; /* RC.cu:251-258 */
+        int keep = g->pvr ? ((sume > 0.00001f) || isnan(sume)) /* patchBasedPSFReconstruction_gpu.cu:110 */
+                          : (sume > 0.5f);                      /* RC.cu:251-258 */
+        if (keep) psf_sums[idx] = sume;
         else continue;
         gauss_ctx gc = {g, mask, sume, s, recon, volw, rd, wd, 0};
         walk_taps(g, &sp, &pp, visit_gauss, &gc);
@@ -350,8 +383,20 @@ static void visit_sim(void *c, float psf, const float ofs[3]) {
   if (vol_index(s->g, f2u_sat(roundf(ofs[0])), f2u_sat(roundf(ofs[1])), f2u_sat(roundf(ofs[2])), &idx) &&
       s->mask[idx] != 0) {
     float p = psf / s->sume;
-    s->sim_f += p * s->recon[idx]; s->w_f += p;
-    s->sim_d += (double)p * (double)s->recon[idx]; s->w_d += (double)p;
+    float v = s->recon[idx];
+    if (s->g->pvr) {
+      /* getReconValueFromTexture (reconVolume.cu:170-187): linear filter at the un-offset coordinate
+       * = 0.125 * sum over {p-1,p}^3, texels outside the volume read 0 (cudaAddressModeBorder) */
+      int X = (int)(idx % s->g->vx), Y = (int)((idx / s->g->vx) % s->g->vy), Z = (int)(idx / ((size_t)s->g->vx * s->g->vy));
+      v = 0.0f;
+      for (int dz = -1; dz <= 0; ++dz) for (int dy = -1; dy <= 0; ++dy) for (int dx = -1; dx <= 0; ++dx) {
+        int x = X + dx, y = Y + dy, z = Z + dz;
+        float t = (x >= 0 && y >= 0 && z >= 0) ? s->recon[(size_t)x + (size_t)y * s->g->vx + (size_t)z * s->g->vx * s->g->vy] : 0.0f;
+        v += 0.125f * t;
+      }
+    }
+    s->sim_f += p * v; s->w_f += p;
+    s->sim_d += (double)p * (double)v; s->w_d += (double)p;
     s->inside = 1;
   }
 }
@@ -443,12 +488,12 @@ void orc_superresolution_backproject(const orc_geom *g, const float *slices, con
 
 /* tap census for one pixel: number of processed taps and a 4096-bit keep mask
  * (bit index = x + 16*y + 256*z).  Test helper for the skip/index parity checks. */
-typedef struct { int n; uint64_t *bits; const pixel_psf *pp; float *vals; } census_ctx;
+typedef struct { int n; uint64_t *bits; const pixel_psf *pp; float *vals; int centre; } census_ctx;
 static void visit_census(void *c, float psf, const float ofs[3]) {
   census_ctx *s = (census_ctx *)c;
-  int x = (int)(ofs[0] - s->pp->c[0]) + PSF_CENTRE;
-  int y = (int)(ofs[1] - s->pp->c[1]) + PSF_CENTRE;
-  int z = (int)(ofs[2] - s->pp->c[2]) + PSF_CENTRE;
+  int x = (int)(ofs[0] - s->pp->c[0]) + s->centre;
+  int y = (int)(ofs[1] - s->pp->c[1]) + s->centre;
+  int z = (int)(ofs[2] - s->pp->c[2]) + s->centre;
   int b = x + 16 * y + 256 * z;
   s->bits[b >> 6] |= (uint64_t)1 << (b & 63);
   if (s->vals) s->vals[b] = psf;
@@ -460,7 +505,7 @@ int orc_tap_census(const orc_geom *g, int sl, int px, int py, uint64_t *bits64, 
   pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
   memset(bits64, 0, 64 * sizeof(uint64_t));
   if (vals4096) for (int i = 0; i < 4096; ++i) vals4096[i] = -1.0f;
-  census_ctx cc = {0, bits64, &pp, vals4096};
+  census_ctx cc = {0, bits64, &pp, vals4096, psf_centre(g)};
   walk_taps(g, &sp, &pp, visit_census, &cc);
   if (centre3) { centre3[0] = pp.c[0]; centre3[1] = pp.c[1]; centre3[2] = pp.c[2]; }
   return cc.n;
@@ -469,11 +514,13 @@ int orc_tap_census(const orc_geom *g, int sl, int px, int py, uint64_t *bits64, 
 void orc_psf_values(const orc_geom *g, int sl, int px, int py, float *vals4096) {
   slice_psf sp; slice_setup(g, sl, &sp);
   pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
-  for (int z = 0; z < 16; ++z) for (int y = 0; y < 16; ++y) for (int x = 0; x < 16; ++x) {
+  const int S = psf_support(g), Cn = psf_centre(g);
+  for (int i = 0; i < 4096; ++i) vals4096[i] = 0.0f;
+  for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x) {
     float ofs[3];
     vals4096[x + 16 * y + 256 * z] = (g->psf_mode == ORC_PSF_LITERAL)
-        ? psf_literal(g, &sp, &pp, x - PSF_CENTRE, y - PSF_CENTRE, z - PSF_CENTRE, ofs)
-        : psf_canon(&sp, &pp, x - PSF_CENTRE, y - PSF_CENTRE, z - PSF_CENTRE, ofs);
+        ? psf_literal(g, &sp, &pp, x - Cn, y - Cn, z - Cn, ofs)
+        : psf_canon(g, &sp, &pp, x - Cn, y - Cn, z - Cn, ofs);
   }
 }
 
