@@ -156,6 +156,8 @@ struct PsfArgs {
   float *psf_sums;
   const float *scales;        // per slice
   const float *bias;          // per-pixel log bias field, NULL when _disableBiasC (RC.cu:200-203)
+  const unsigned char *flag;  // optional per-pixel activity flag replacing `v_PSF_sums != 0` (Gaussian pass 2)
+  unsigned char *flag_out;    // Gaussian pass 1: 1 where the pixel's sume passed the threshold
   const unsigned char *spx;   // PVR superpixel masks [ns][64*64] of '0'/'1' or NULL (ImagePatch2D.cuh:51)
   // gauss (MODE_BIAS reuses recon/volw for the bias volume / its accumulated weights)
   float *recon, *volw;
@@ -246,8 +248,20 @@ __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by
       R[i] = __builtin_fmaf(ys, ys, xs * xs);        // q
       a[i] = (zs * zs) * S.inv2s2;
     }
+    // correctly rounded sqrt: the core of LLVM's IEEE expansion (v_sqrt_f32, then pick among the two
+    // neighbours with exact fma residuals) without its denormal-input scaling and inf handling,
+    // which q = x'^2 + y'^2 in [0, ~1e3] never needs; sqrt(0) = 0 falls out of the residual tests.
+    // Bit-identical to sqrtf (tests/test_parity_gpu.py::test_psf_taps_are_bit_identical, tools/ulp_check.hip).
 #pragma unroll
-    EACH R[i] = 3.14159265359f * sqrtf(R[i]);         // correctly rounded sqrt (see psf_eval)
+    EACH s[i] = __builtin_amdgcn_sqrtf(R[i]);
+#pragma unroll
+    EACH {
+      const float sd = __int_as_float(__float_as_int(s[i]) - 1), su = __int_as_float(__float_as_int(s[i]) + 1);
+      const float rd = __builtin_fmaf(-sd, s[i], R[i]), ru = __builtin_fmaf(-su, s[i], R[i]);
+      float t = (0.0f >= rd) ? sd : s[i];
+      t = (0.0f < ru) ? su : t;
+      R[i] = 3.14159265359f * t;
+    }
     // |sin R|: canon_abs_sin
 #pragma unroll
     EACH k[i] = __builtin_rintf(R[i] * 0.318309886183790671538f);
@@ -267,8 +281,20 @@ __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by
     EACH u[i] = __builtin_fmaf(u[i], s[i], -0.166666597127914428710938f);
 #pragma unroll
     EACH u[i] = __builtin_fabsf(__builtin_fmaf(s[i], u[i] * r[i], r[i]));
+    // si = |sin R| / R (NaN at R == 0, RC.cu:129): correctly rounded division = LLVM's IEEE expansion
+    // (rcp, one Newton step on the reciprocal, two residual corrections of the quotient) without the
+    // v_div_scale / v_div_fmas / v_div_fixup range handling, which operands in [1e-10,1] / (0,1e2] never
+    // trigger; 0/0 still yields NaN (rcp(0) = inf, 0 * inf).  Bit-identical to '/' on these ranges.
 #pragma unroll
-    EACH u[i] = u[i] / R[i];                          // si = |sin R| / R  (NaN at R == 0, RC.cu:129)
+    EACH k[i] = __builtin_amdgcn_rcpf(R[i]);
+#pragma unroll
+    EACH k[i] = __builtin_fmaf(__builtin_fmaf(-R[i], k[i], 1.0f), k[i], k[i]);
+#pragma unroll
+    EACH s[i] = u[i] * k[i];
+#pragma unroll
+    EACH s[i] = __builtin_fmaf(__builtin_fmaf(-R[i], s[i], u[i]), k[i], s[i]);
+#pragma unroll
+    EACH u[i] = __builtin_fmaf(__builtin_fmaf(-R[i], s[i], u[i]), k[i], s[i]);
     if (PVR) {
       // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70)
 #pragma unroll
@@ -476,10 +502,19 @@ struct TileArgs {
   int cap;                 // voxels of LDS accumulator available
   int dbg;                 // dev experiments only (0 = production)
   int tw, th;              // tile size in pixels, tw * th <= 64
+  int gauss;               // scatter kernels: 1 = Gaussian-reconstruction pass 2 (recon|volw instead of addon|cmap)
 };
 
-__global__ void k_build_tiles(const float *slices, const float *psf_sums, int sx, int sy, int ns,
-                              int tiles_x, int tiles_y, int TILE_W, int TILE_H, uint32_t *tiles,
+// activity of a pixel for the tile kernels: s != -1 and (flag ? flag : v_PSF_sums != 0); both NULL: s != -1
+__device__ __forceinline__ bool pixel_active(const float *slices, const float *psf_sums, const unsigned char *flag,
+                                             size_t idx) {
+  if (slices[idx] == -1.0f) return false;
+  if (flag) return flag[idx] != 0;
+  return psf_sums ? psf_sums[idx] != 0.0f : true;
+}
+
+__global__ void k_build_tiles(const float *slices, const float *psf_sums, const unsigned char *flag, int sx, int sy,
+                              int ns, int tiles_x, int tiles_y, int TILE_W, int TILE_H, uint32_t *tiles,
                               uint32_t *counter) {
   const int lane = threadIdx.x & 63;
   const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -492,12 +527,13 @@ __global__ void k_build_tiles(const float *slices, const float *psf_sums, int sx
   bool act = false;
   if (lane < TILE_W * TILE_H && px < sx && py < sy) {
     size_t idx = (size_t)px + (size_t)py * sx + (size_t)sl * sx * sy;
-    act = slices[idx] != -1.0f && psf_sums[idx] != 0.0f;
+    act = pixel_active(slices, psf_sums, flag, idx);
   }
   if (__ballot(act) != 0ull && lane == 0) tiles[atomicAdd(counter, 1u)] = t;
 }
 
 __global__ __launch_bounds__(TILE_WAVES * 64) void back_tiled_kernel(PsfArgs a, TileArgs ta) {
+  constexpr bool GAUSS1_ACT = false;
   extern __shared__ __attribute__((aligned(16))) float tile[];   // addon[cap] | cmap[cap]
   __shared__ int sh_lo[3], sh_hi[3];
   __shared__ uint32_t sh_pix[64];
@@ -523,7 +559,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void back_tiled_kernel(PsfArgs a, 
     uint32_t idx = 0;
     if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
       idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = a.slices[idx] != -1.0f && a.psf_sums[idx] != 0.0f;
+      act = pixel_active(a.slices, GAUSS1_ACT ? (const float *)nullptr : a.psf_sums, a.flag, idx);
     }
     unsigned long long b = __ballot(act);
     if (act) {
@@ -567,9 +603,15 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void back_tiled_kernel(PsfArgs a, 
     const float w = a.weights[idx];
     const float ss = a.simslices[idx];
     float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * scale : a.slices[idx] * scale;   // RC.cu:439-442
-    e = (ss > 0.0f) ? (e - ss) : 0.0f;       // RC.cu:444-447
-    const float f1 = (w * slicew) / sume;
-    const float f0 = f1 * e;
+    float f1, f0;
+    if (ta.gauss) {                          // RC.cu:278-282: volw += psf/sume, recon += psf/sume * s
+      f1 = 1.0f / sume;
+      f0 = f1 * e;
+    } else {
+      e = (ss > 0.0f) ? (e - ss) : 0.0f;     // RC.cu:444-447
+      f1 = (w * slicew) / sume;
+      f0 = f1 * e;
+    }
     for (int q = 0; q < 4; ++q) {
       float out[16];
       eval_row(RC, P, lane, q, out);
@@ -651,6 +693,7 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
                                                                        uint32_t *fallback_tiles,
                                                                        uint32_t *fallback_count) {
   constexpr int PLANE_SLOTS = PLANE_WAVES * 4;
+  constexpr bool GAUSS1_ACT = false;
   extern __shared__ __attribute__((aligned(16))) float tile[];   // addon[cap] | cmap[cap]
   __shared__ int sh_lo[3], sh_hi[3];
   __shared__ PixelRec sh_px[64];
@@ -677,7 +720,7 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
     uint32_t idx = 0;
     if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
       idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = a.slices[idx] != -1.0f && a.psf_sums[idx] != 0.0f;
+      act = pixel_active(a.slices, GAUSS1_ACT ? (const float *)nullptr : a.psf_sums, a.flag, idx);
     }
     unsigned long long b = __ballot(act);
     if (act) {
@@ -685,8 +728,13 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
       const float sume = a.psf_sums[idx];
       const float ss = a.simslices[idx];
       float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * a.scales[sl] : a.slices[idx] * a.scales[sl];
-      e = (ss > 0.0f) ? (e - ss) : 0.0f;                       // RC.cu:439-447
-      const float f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
+      float f1;
+      if (ta.gauss) {                                          // RC.cu:278-282
+        f1 = 1.0f / sume;
+      } else {
+        e = (ss > 0.0f) ? (e - ss) : 0.0f;                     // RC.cu:439-447
+        f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
+      }
       PixelRec R;
       R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
       sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
@@ -776,6 +824,165 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
           unsafeAtomicAdd(a.addon + vi, ad);
           unsafeAtomicAdd(a.cmap + vi, c);
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-tiled forward projection (simulateSlicesKernel3D_tex RC.cu:298-404): the production gather
+// ------------------------------------------------------------------------------------------
+// Same tile box as the scatter (unsaturated coordinates, saturation applied when the box is
+// filled), holding the masked volume: V where the voxel is in bounds and mask != 0, a sentinel bit
+// pattern otherwise.  A gather has no write conflicts, so every wave takes whole pixels
+// (lane = (y,z) row, as in Phase 1) and reads its row's 16 box words straight from the
+// row-per-lane layout -- no LDS transposition, no per-tap global loads, no Phase 2.
+#define FWD_WAVES 8
+#define FWD_SENTINEL 0xFFFFFFFFu      // never produced by arithmetic (canonical NaNs are 0x7fc00000 / 0xffc00000)
+
+#define FWD_MASKED 0xFFFFFFFEu        // Gaussian pass 1: voxel in bounds but outside the mask
+// GAUSS1 = true turns the same walk into pass 1 of gaussianReconstructionKernel3D_tex (RC.cu:228-258):
+// sume over processed in-bounds taps (no mask), the `sume > 0.5` gate, v_PSF_sums, and the
+// sliceVoxel_count flag (any processed tap on an in-mask voxel, RC.cu:283-294); the box then only
+// encodes {out of bounds, masked, in mask}.
+template <bool GAUSS1>
+__global__ __launch_bounds__(FWD_WAVES * 64) void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
+  constexpr bool GAUSS1_ACT = GAUSS1;
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // masked volume box [cap]
+  __shared__ int sh_lo[3], sh_hi[3];
+  __shared__ PixelRec sh_px[64];
+  __shared__ uint32_t sh_idx[64];
+  __shared__ int sh_npix;
+  const int TILE_W = ta.tw, TILE_H = ta.th;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const VolGeom &vg = a.vg;
+  const uint32_t t = ta.tiles[blockIdx.x];
+  const int per_slice = ta.tiles_x * ta.tiles_y;
+  const uint32_t sl = t / per_slice;
+  const int r = t - sl * per_slice;
+  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
+  const SliceConst &S = a.sc[sl];
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+
+  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
+  __syncthreads();
+  if (wave == 0) {
+    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+    bool act = false;
+    uint32_t idx = 0;
+    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
+      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
+      act = pixel_active(a.slices, GAUSS1_ACT ? (const float *)nullptr : a.psf_sums, a.flag, idx);
+    }
+    unsigned long long b = __ballot(act);
+    if (act) {
+      PixelState P = pixel_setup(S, vg, px, py);
+      PixelRec R;
+      R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz;
+      R.f1 = GAUSS1 ? 0.0f : 1.0f / a.psf_sums[idx]; R.f0 = 0.0f;
+      const int k = __popcll(b & ((1ull << lane) - 1ull));
+      sh_px[k] = R;
+      sh_idx[k] = idx;
+      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
+      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
+      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
+    }
+    if (lane == 0) sh_npix = __popcll(b);
+  }
+  __syncthreads();
+  const int npix = sh_npix;
+  const int lox = sh_lo[0] - PSF_CENTRE, hix = sh_hi[0] + 8;
+  const int loy = sh_lo[1] - PSF_CENTRE, hiy = min(sh_hi[1] + 8, vg.vy - 1);
+  const int loz = sh_lo[2] - PSF_CENTRE, hiz = min(sh_hi[2] + 8, vg.vz - 1);
+  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
+  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // nothing in bounds: no pixel gets a weight > 0
+  const int Px = Dx | 1;
+  const int Pxy = Px * Dy + ((Px * Dy) & 1 ? 0 : 1);    // odd plane pitch as well: rows of 4 planes spread over banks
+  const bool in_lds = (long long)Pxy * Dz <= (long long)ta.cap;
+  const uint32_t sxy = (uint32_t)(vg.vx * vg.vy);
+  if (in_lds) {
+    const int vox = Pxy * Dz;
+    for (int i = threadIdx.x; i < vox; i += FWD_WAVES * 64) {
+      const int z = i / Pxy, rr = i - z * Pxy;
+      const int yy = rr / Px, xx = rr - yy * Px;
+      const int gx = xx + lox;
+      uint32_t bits = FWD_SENTINEL;
+      if (yy < Dy && xx < Dx && gx < vg.vx) {
+        const uint32_t vi = sat0(gx) + sat0(yy + loy) * (uint32_t)vg.vx + sat0(z + loz) * sxy;
+        if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
+        else if (a.mask[vi] != 0.0f) bits = __float_as_uint(a.vol[vi]);
+      }
+      reinterpret_cast<uint32_t *>(tile)[i] = bits;
+    }
+  }
+  __syncthreads();
+
+  const RowConst RC = load_row_const(S);
+  for (int k = wave; k < npix; k += FWD_WAVES) {
+    const PixelRec R = sh_px[k];
+    float f0 = 0.0f, f1 = 0.0f;
+    double acc = 0.0;
+    bool hit = false;
+    for (int q = 0; q < 4; ++q) {
+      const int z = 4 * q + (lane >> 4), y = lane & 15;
+      const int ay = R.cy + y - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
+      const bool rowok = ay < vg.vy && az < vg.vz;          // negatives alias to 0: always "in bounds"
+      uint32_t vb[16];
+      if (in_lds) {
+        const int rb = rowok ? (ay - loy) * Px + (az - loz) * Pxy + R.cx - PSF_CENTRE - lox : 0;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) vb[x] = reinterpret_cast<const uint32_t *>(tile)[rb + x];
+      } else {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int gx = R.cx + x - PSF_CENTRE;
+          uint32_t bits = FWD_SENTINEL;
+          if (rowok && gx < vg.vx) {
+            const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
+            if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
+            else if (a.mask[vi] != 0.0f) bits = __float_as_uint(a.vol[vi]);
+          }
+          vb[x] = bits;
+        }
+      }
+      float out[16];
+      eval_row_at(RC, R.bx, R.by, R.bz, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE), out);
+      if (rowok) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          if (GAUSS1) {
+            if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
+              acc += (double)out[x];                       // RC.cu:241-245 (no mask test)
+              hit = hit || vb[x] == 1u;
+            }
+          } else if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
+            const float p = out[x] * R.f1;               // psf / sume
+            f0 += p * __uint_as_float(vb[x]);
+            f1 += p;
+            hit = true;
+          }
+        }
+      }
+    }
+    const bool inside = __ballot(hit) != 0ull;
+    const uint32_t idx = sh_idx[k];
+    if (GAUSS1) {
+      const float sume = (float)wave_sum(acc);
+      if (lane == 0) {
+        const bool pass = sume > 0.5f;                     // also drops NaN (RC.cu:251-258)
+        a.flag_out[idx] = pass ? 1 : 0;
+        if (pass) {
+          a.psf_sums[idx] = sume;
+          if (inside) a.voxcount[idx] = 1;                 // RC.cu:291-294
+        }
+      }
+    } else {
+      const float sim = wave_sum(f0), w = wave_sum(f1);
+      if (lane == 0 && w > 0.0f) {                         // RC.cu:398-403
+        a.simslices[idx] = sim / w;
+        a.simweights[idx] = w;
+        a.siminside[idx] = inside ? 1 : 0;
       }
     }
   }
@@ -1552,6 +1759,14 @@ struct svr_ctx {
   int plane_cap = 9600;     // LDS accumulator voxels of back_plane_kernel: 75 KiB + 4.3 KiB static
                             // -> exactly 2 workgroups per CU (measured: 1 per CU is 1.6x slower)
   bool psf_list_valid = false;
+  unsigned char *d_gauss_flag = nullptr;   // pixels whose sume passed in the current Gaussian pass
+  uint32_t *d_tiles_tmp = nullptr;         // tile list of the Gaussian passes
+  int gauss_mode = 1;                      // 1 = tiled pass 1 + plane-owned scatter, 0 = psf_kernel<MODE_GAUSS>
+  uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_tile_kernel
+  uint32_t n_tiles_fwd = 0;
+  int fwd_tw = 8, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
+  int fwd_mode = 1;         // 1 = LDS-tiled gather, 0 = wave-per-pixel kernel with LDS transposition
+  int fwd_cap = 9216;       // box voxels: 36 KiB -> 4 workgroups of 8 waves per CU
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   unsigned char *d_spx = nullptr;
   int back_mode = 2;        // 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
@@ -1649,6 +1864,9 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_slice_weights); free_dev(c->d_scales_host_copy); free_dev(c->d_tmp_ns);
   free_dev(c->d_slice_inside); free_dev(c->d_sc); free_dev(c->d_active); free_dev(c->d_psf_list);
   free_dev(c->d_tiles);
+  free_dev(c->d_tiles_fwd);
+  free_dev(c->d_gauss_flag);
+  free_dev(c->d_tiles_tmp);
   free_dev(c->d_tiles_fb);
   free_dev(c->d_partial); free_dev(c->d_per_slice);
 }
@@ -1702,12 +1920,26 @@ int build_list(svr_ctx *ctx, bool with_psf) {
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t total = (uint32_t)ctx->tiles_x * ctx->tiles_y * ctx->ns;
     hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
-                       (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
+                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
                        ctx->d_tiles, ctx->d_counter);
     KCHK("k_build_tiles");
     HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->n_tiles = n;
+    // forward tiles
+    free_dev(ctx->d_tiles_fwd);
+    ctx->fwd_tiles_x = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw);
+    ctx->fwd_tiles_y = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
+    const uint32_t total_f = (uint32_t)ctx->fwd_tiles_x * ctx->fwd_tiles_y * ctx->ns;
+    HIPCHK(hipMalloc(&ctx->d_tiles_fwd, (size_t)total_f * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total_f, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
+                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->fwd_tiles_x, ctx->fwd_tiles_y, ctx->fwd_tw,
+                       ctx->fwd_th, ctx->d_tiles_fwd, ctx->d_counter);
+    KCHK("k_build_tiles(fwd)");
+    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_tiles_fwd = n;
   } else {
     ctx->n_active = n;
   }
@@ -1848,6 +2080,10 @@ int svr_create(int device, svr_ctx **out) {
     dyn -= 8192;   // static LDS of back_plane_kernel (pixel table + plane lists)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(back_tiled_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<5>),
@@ -1870,6 +2106,15 @@ int svr_create(int device, svr_ctx **out) {
 int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; return SVR_OK; }
+  if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }
+  if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
+  if (!strcmp(name, "fwd_cap")) { ctx->fwd_cap = std::max(4096, value); return SVR_OK; }
+  if (!strcmp(name, "fwd_tile_w") || !strcmp(name, "fwd_tile_h")) {
+    int w = !strcmp(name, "fwd_tile_w") ? value : ctx->fwd_tw, h = !strcmp(name, "fwd_tile_h") ? value : ctx->fwd_th;
+    if (w < 1 || h < 1 || w * h > 64) return fail(ctx, SVR_E_ARG, "fwd tile must hold 1..64 pixels");
+    ctx->fwd_tw = w; ctx->fwd_th = h; ctx->psf_list_valid = false;
+    return SVR_OK;
+  }
   if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; return SVR_OK; }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
@@ -2131,7 +2376,57 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   a.list = ctx->d_active;
   a.n = ctx->n_active;
   ScopedTimer t(ctx, SVR_T_GAUSS);
-  if (a.n && ctx->pvr) {
+  if (a.n && !ctx->pvr && ctx->gauss_mode == 1) {
+    // pass 1 (tiled walk: sume, gate, v_PSF_sums, voxel-count flag), pass 2 = the plane-owned scatter
+    // of the back-projection with {recon|volw} as targets and unit voxel/slice weights
+    if (!ctx->d_gauss_flag) HIPCHK(hipMalloc(&ctx->d_gauss_flag, ctx->np));
+    HIPCHK(hipMemsetAsync(ctx->d_gauss_flag, 0, ctx->np, ctx->stream));
+    const int ftx = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw), fty = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
+    const size_t max_tiles = std::max((size_t)ftx * fty, (size_t)ctx->tiles_x * ctx->tiles_y) * ctx->ns;
+    if (!ctx->d_tiles_tmp) HIPCHK(hipMalloc(&ctx->d_tiles_tmp, max_tiles * sizeof(uint32_t)));
+    uint32_t n1 = 0, n2 = 0, nfb = 0;
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
+                       (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
+                       fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter);
+    KCHK("k_build_tiles(gauss1)");
+    HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    TileArgs ta;
+    ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1; ta.tiles_x = ftx; ta.tiles_y = fty;
+    ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th; ta.gauss = 1;
+    a.flag = nullptr; a.flag_out = ctx->d_gauss_flag;
+    if (n1) {
+      hipLaunchKernelGGL(fwd_tile_kernel<true>, dim3(n1), dim3(FWD_WAVES * 64), (size_t)ta.cap * sizeof(float), ctx->stream,
+                         a, ta);
+      KCHK("fwd_tile_kernel<GAUSS1>");
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns, 4)), dim3(256), 0, ctx->stream,
+                       ctx->d_slices, (const float *)nullptr, ctx->d_gauss_flag, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns,
+                       ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter);
+    KCHK("k_build_tiles(gauss2)");
+    HIPCHK(hipMemcpyAsync(&n2, ctx->d_counter, sizeof(n2), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    a.flag = ctx->d_gauss_flag;
+    a.addon = ctx->recon(); a.cmap = ctx->volw();       // scatter targets of pass 2 (RC.cu:279-282)
+    ta.ntiles = n2; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.tw = ctx->tile_w; ta.th = ctx->tile_h;
+    ta.cap = std::min(ctx->plane_cap, ctx->tile_cap);
+    if (n2) {
+      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(back_plane_kernel<8>, dim3(n2), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float), ctx->stream, a, ta,
+                         ctx->d_tiles_fb, ctx->d_counter);
+      KCHK("back_plane_kernel(gauss)");
+      HIPCHK(hipMemcpyAsync(&nfb, ctx->d_counter, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (nfb) {
+        ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb; ta.cap = ctx->tile_cap;
+        hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
+                           ctx->stream, a, ta);
+        KCHK("back_tiled_kernel(gauss fallback)");
+      }
+    }
+  } else if (a.n && ctx->pvr) {
     hipLaunchKernelGGL(pvr_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("pvr_kernel<GAUSS>");
@@ -2183,6 +2478,14 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
     hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("pvr_kernel<FWD>");
+  } else if (a.n && ctx->fwd_mode == 1) {
+    TileArgs ta;
+    ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
+    ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
+    ta.gauss = 0;
+    hipLaunchKernelGGL(fwd_tile_kernel<false>, dim3(ctx->n_tiles_fwd), dim3(FWD_WAVES * 64),
+                       (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
+    KCHK("fwd_tile_kernel");
   } else if (a.n) {
     hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),
                        (size_t)ctx->dbg_fwd_lds, ctx->stream, a);
@@ -2341,7 +2644,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     TileArgs ta;
     ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
     ta.cap = std::min(ctx->plane_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
-    ta.tw = ctx->tile_w; ta.th = ctx->tile_h;
+    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
     const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
 #define LAUNCH_PLANE(NW)                                                                                   \
@@ -2372,7 +2675,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
     ta.cap = ctx->tile_cap;
     ta.dbg = ctx->dbg_back;
-    ta.tw = ctx->tile_w; ta.th = ctx->tile_h;
+    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
     hipLaunchKernelGGL(back_tiled_kernel, dim3(ctx->n_tiles), dim3(TILE_WAVES * 64),
                        (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
     KCHK("back_tiled_kernel");

@@ -48,7 +48,8 @@ const char *svr_last_error(const svr_ctx *ctx);
 int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
 /* engine tuning knobs (no reference equivalent).  "back_mode": 2 = plane-owned LDS tiles
  * (default; no atomics inside a tile), 1 = LDS tiles with ds_add_f32, 0 = direct device-scope
- * atomics per tap. */
+ * atomics per tap.  "fwd_mode": 1 = LDS-tiled forward gather (default), 0 = wave-per-pixel kernel.
+ * "tile_w"/"tile_h", "fwd_tile_w"/"fwd_tile_h", "plane_waves", "plane_cap", "fwd_cap": tile geometry. */
 int svr_set_option(svr_ctx *ctx, const char *name, int value);
 /* "pvr" = 1 switches the PSF kernels to the patch-to-volume constants of
  * PVRreconstructionGPU (patchBasedPSFReconstruction_gpu.cu, patchBasedSimulatePatches_gpu.cu,

@@ -1,68 +1,59 @@
-// dev tool: which float op differs between gfx950 device code and host code?
+// dev tool: are the engine's range-restricted exact sqrt / division bit-identical to IEEE sqrtf and '/'
+// (and to the host) on gfx950?  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/ulp_check.hip
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#define HD __host__ __device__
-HD inline float c_sin(float R) {
-  const float INV_PI = 0.318309886183790671538f, PI_A = 3.1414794921875f, PI_B = 0.00011315941810607910156f, PI_C = 1.9841872589410058936e-09f;
-  float k = rintf(R * INV_PI);
-  float r = fmaf(k, -PI_A, R); r = fmaf(k, -PI_B, r); r = fmaf(k, -PI_C, r);
-  float s = r * r;
-  float u = 2.6083159809786593541503e-06f;
-  u = fmaf(u, s, -0.0001981069071916863322258f);
-  u = fmaf(u, s, 0.00833307858556509017944336f);
-  u = fmaf(u, s, -0.166666597127914428710938f);
-  u = fmaf(s, u * r, r);
-  return fabsf(u);
+__device__ float fast_sqrt(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  float t = (0.0f >= rd) ? sd : s;
+  return (0.0f < ru) ? su : t;
 }
-HD inline float c_exp(float a) {
-  const float LOG2E = 1.442695040888963407359924681001892137426645954152985934135449406931f, L2U = 0.693145751953125f, L2L = 1.428606765330187045e-06f;
-  float d = -a;
-  float q = rintf(d * LOG2E);
-  float s = fmaf(q, -L2U, d); s = fmaf(q, -L2L, s);
-  float u = 0.000198527617612853646278381f;
-  u = fmaf(u, s, 0.00139304355252534151077271f);
-  u = fmaf(u, s, 0.00833336077630519866943359f);
-  u = fmaf(u, s, 0.0416664853692054748535156f);
-  u = fmaf(u, s, 0.166666671633720397949219f);
-  u = fmaf(u, s, 0.5f);
-  u = fmaf(s * s, u, s) + 1.0f;
-  float r = ldexpf(u, (int)q);
-  return (a > 87.0f) ? 0.0f : r;
+__device__ float fast_div(float a, float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+  float q = a * r;
+  q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
 }
-HD inline void all_ops(float x, float y, float *o) {
-  o[0] = sqrtf(x);
-  o[1] = x / y;
-  o[2] = c_sin(x);
-  o[3] = c_exp(x);
-  o[4] = fmaf(y, y, x * x);
-  o[5] = rintf(x * 0.318309886183790671538f);
-  o[6] = ldexpf(y, (int)rintf(-x));
-  o[7] = x * y + 1.0f;
-}
-__global__ void k(const float *x, const float *y, float *o, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) all_ops(x[i], y[i], o + 8 * (size_t)i);
+__global__ void k(const float *x, const float *y, float *o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  o[4 * i + 0] = fast_sqrt(x[i]);
+  o[4 * i + 1] = sqrtf(x[i]);
+  o[4 * i + 2] = fast_div(y[i], x[i]);
+  o[4 * i + 3] = y[i] / x[i];
 }
 int main() {
-  int n = 1 << 20;
-  std::vector<float> x(n), y(n), o(8 * (size_t)n), h(8);
+  size_t n = 1 << 24;
+  std::vector<float> x(n), y(n), o(4 * n);
   srand(1);
-  for (int i = 0; i < n; ++i) { x[i] = 20.0f * rand() / RAND_MAX; y[i] = 0.01f + 3.0f * rand() / RAND_MAX; }
-  float *dx, *dy, *dout;
-  hipMalloc(&dx, n * 4); hipMalloc(&dy, n * 4); hipMalloc(&dout, 8 * (size_t)n * 4);
-  hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dy, y.data(), n * 4, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(k, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, dout, n);
-  hipMemcpy(o.data(), dout, 8 * (size_t)n * 4, hipMemcpyDeviceToHost);
-  long bad[8] = {0};
-  for (int i = 0; i < n; ++i) {
-    all_ops(x[i], y[i], h.data());
-    for (int j = 0; j < 8; ++j) if (memcmp(&h[j], &o[8 * (size_t)i + j], 4)) { if (bad[j]++ < 2) printf("op %d x=%.9g y=%.9g host=%.9g dev=%.9g\n", j, x[i], y[i], h[j], o[8 * (size_t)i + j]); }
+  for (size_t i = 0; i < n; ++i) {
+    double u = rand() / (double)RAND_MAX, v = rand() / (double)RAND_MAX;
+    // q / R ranges of the PSF: log-uniform 1e-12..1e3 for the divisor / sqrt argument, 1e-12..1 numerator
+    x[i] = (float)pow(10.0, -12.0 + 15.0 * u);
+    y[i] = (float)pow(10.0, -12.0 + 12.0 * v);
+    // R == 0 only ever meets |sin R| == 0 (0/0 = NaN on both paths); a/0 with a > 0 cannot occur
+    if (i % 1024 == 0) { x[i] = 0.0f; y[i] = 0.0f; }
+    if (i % 4096 == 1) y[i] = 0.0f;
   }
-  const char *names[8] = {"sqrt", "div", "sin", "exp", "fma", "rint", "ldexp", "mul+add"};
-  for (int j = 0; j < 8; ++j) printf("%-8s mismatches %ld / %d\n", names[j], bad[j], n);
-  return 0;
+  float *dx, *dy, *dout;
+  (void)hipMalloc(&dx, n * 4); (void)hipMalloc(&dy, n * 4); (void)hipMalloc(&dout, 4 * n * 4);
+  (void)hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice); (void)hipMemcpy(dy, y.data(), n * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, dy, dout, n);
+  (void)hipMemcpy(o.data(), dout, 4 * n * 4, hipMemcpyDeviceToHost);
+  long bs = 0, bd = 0, hs = 0, hd = 0;
+  for (size_t i = 0; i < n; ++i) {
+    float hsq = sqrtf(x[i]), hdv = y[i] / x[i];
+    if (memcmp(&o[4 * i], &o[4 * i + 1], 4)) { if (bs++ < 3) printf("sqrt x=%.9g fast=%.9g ieee=%.9g\n", x[i], o[4 * i], o[4 * i + 1]); }
+    if (memcmp(&o[4 * i + 2], &o[4 * i + 3], 4) && !(o[4 * i + 2] != o[4 * i + 2] && o[4 * i + 3] != o[4 * i + 3])) { if (bd++ < 3) printf("div %.9g/%.9g fast=%.9g ieee=%.9g\n", y[i], x[i], o[4 * i + 2], o[4 * i + 3]); }
+    if (memcmp(&o[4 * i], &hsq, 4)) hs++;
+    if (memcmp(&o[4 * i + 2], &hdv, 4) && !(hdv != hdv && o[4 * i + 2] != o[4 * i + 2])) hd++;
+  }
+  printf("n=%zu  fast_sqrt!=sqrtf(dev): %ld  fast_div!=div(dev): %ld  fast_sqrt!=host: %ld  fast_div!=host: %ld\n", n, bs, bd, hs, hd);
+  return (bs || bd || hs || hd) ? 1 : 0;
 }
