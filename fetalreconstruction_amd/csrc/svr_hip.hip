@@ -1711,6 +1711,8 @@ __global__ __launch_bounds__(256) void k_ncc(const short *targets, int tx, int t
 // ==========================================================================================
 // context
 // ==========================================================================================
+struct RegState;   // GPU slice-to-volume registration state (svr_reg.inc)
+
 struct svr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -1791,6 +1793,9 @@ struct svr_ctx {
   int reg_tx = 0, reg_ty = 0, reg_n = 0;
   uint32_t reg_vx = 0, reg_vy = 0, reg_vz = 0;
 
+  // GPU slice-to-volume registration (svr_reg.inc)
+  RegState *reg = nullptr;
+
   // timers
   bool timers = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1825,6 +1830,8 @@ int fail(svr_ctx *c, int code, const std::string &msg) {
   do {                                                                                      \
     if (!(cond)) return fail(ctx, SVR_E_STATE, std::string(__func__) + ": " + what);      \
   } while (0)
+
+void reg_free(RegState *r);
 
 template <class T>
 void free_dev(T *&p) {
@@ -2149,6 +2156,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_bias_vol); free_dev(ctx->d_volume_weights); free_dev(ctx->d_maskC); free_dev(ctx->d_mbuf);
   free_dev(ctx->d_reg_targets);
   free_dev(ctx->d_reg_source);
+  reg_free(ctx->reg);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
@@ -3074,3 +3082,5 @@ int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
 }
 
 }  // extern "C"
+
+#include "svr_reg.inc"

@@ -22,7 +22,7 @@ BUF_RECONSTRUCTED, BUF_VOL_WEIGHTS, BUF_ADDON, BUF_CONFIDENCE_MAP, BUF_MASK = 0,
 BUF_BIAS_VOLUME, BUF_SMOOTH_MASK = 5, 6
 BUF_SLICES, BUF_WEIGHTS, BUF_SIMSLICES, BUF_SIMWEIGHTS, BUF_PSF_SUMS, BUF_BIAS = 10, 11, 12, 13, 14, 15
 BUF_SIMINSIDE, BUF_VOXEL_COUNT = 20, 21
-T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE = range(7)
+T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE, T_REGISTER = range(8)
 TIMER_NAMES = ["backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale"]
 
 EXPORTS = [
@@ -39,7 +39,9 @@ EXPORTS = [
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
     "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_ncc_set_targets", "svr_ncc_set_source",
     "svr_ncc_evaluate", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
-    "svr_normalise_bias_finish",
+    "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
+    "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
+    "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters",
 ]
 
 
@@ -309,6 +311,54 @@ class Reconstruction:
         ncc = np.zeros(len(idx), np.float64)
         self._ck(self._lib.svr_ncc_evaluate(self._h, len(idx), _p(idx), _p(m), _p(sums), _p(ncc)))
         return ncc, sums
+
+    # ---- GPU slice-to-volume registration (RC.cuh:326-338) ------------------------------------
+    def initRegStorageVolumes(self, W, H, ns, dim=(1.0, 1.0, 1.0)):
+        self._reg_grid = (int(ns), int(H), int(W))
+        self._ck(self._lib.svr_init_reg_storage_volumes(self._h, _u3((W, H, ns)), _f3(dim)))
+
+    def FillRegSlices(self, sdata, slices_resampled_i2w=None):
+        d = _f32(sdata)
+        if d.shape != self._reg_grid:
+            raise SvrError(f"FillRegSlices: expected {self._reg_grid}, got {d.shape}")
+        m = None if slices_resampled_i2w is None else _f32(slices_resampled_i2w).reshape(-1)
+        self._ck(self._lib.svr_fill_reg_slices(self._h, _p(d), None if m is None else _p(m)))
+
+    def updateResampledSlicesI2W(self, ofs):
+        m = _f32(ofs).reshape(-1)
+        if m.size != 16 * self._reg_grid[0]:
+            raise SvrError("updateResampledSlicesI2W: one Matrix4 per slice expected")
+        self._ck(self._lib.svr_update_resampled_slices_i2w(self._h, _p(m)))
+
+    def prepareSliceToVolumeReg(self, volume=None):
+        """Snapshots the engine's current reconstruction (`volume` is ignored; the oracle twin takes it)."""
+        self._ck(self._lib.svr_prepare_slice_to_volume_reg(self._h))
+
+    def set_schedule(self, levels=None, steps=None, iterations=None):
+        self._ck(self._lib.svr_reg_set_schedule(self._h, int(levels or 0), int(steps or 0), int(iterations or 0)))
+
+    def registerSlicesToVolume(self, transf):
+        t = _f32(transf).reshape(-1).copy()
+        if t.size != 16 * self._reg_grid[0]:
+            raise SvrError("registerSlicesToVolume: one Matrix4 per slice expected")
+        self._ck(self._lib.svr_register_slices_to_volume(self._h, _p(t)))
+        return t.reshape(-1, 4, 4)
+
+    def evaluate_costs(self, transf, level, active=None):
+        ns, H, W = self._reg_grid
+        t = _f32(transf).reshape(-1)
+        act = None if active is None else np.ascontiguousarray(active, np.int32)
+        a = ns if act is None else len(act)
+        sim = np.zeros(ns, np.float32)
+        dbg = np.zeros((3, a, H, W), np.float32)
+        self._ck(self._lib.svr_reg_evaluate_costs(self._h, _p(t), int(level), None if act is None else _p(act), a,
+                                                  _p(sim), _p(dbg)))
+        return sim, dbg
+
+    def reg_counters(self):
+        c = np.zeros(4, np.int64)
+        self._ck(self._lib.svr_reg_counters(self._h, _p(c)))
+        return c
 
     def set_spx_masks(self, masks):
         if masks is None:

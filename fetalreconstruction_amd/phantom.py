@@ -36,6 +36,7 @@ class Problem:
     min_intensity: float
     max_intensity: float
     name: str = ""
+    slice_attr: list = None  # geometry.ImageAttributes per slice (host-side registration prep)
 
     @property
     def ns(self):
@@ -125,6 +126,7 @@ def make_problem(
     m_ti = np.zeros((ns, 16), np.float32)
     sdim = np.zeros((ns, 3), np.float32)
     stack_index = np.zeros(ns, np.int32)
+    attrs = []
 
     py, px = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
     pix = np.stack([px, py, np.zeros_like(px), np.ones_like(px)], -1).astype(np.float64)
@@ -161,6 +163,7 @@ def make_problem(
             m_ti[k] = geo.to_matrix4(np.linalg.inv(t))
             sdim[k] = (in_plane, in_plane, thickness)
             stack_index[k] = st
+            attrs.append(a)
             k += 1
 
     pos = slices[slices > 0]
@@ -183,6 +186,7 @@ def make_problem(
         min_intensity=float(pos.min()) if pos.size else 0.0,   # InitializeEMGPU RG.cc:2937-2951
         max_intensity=float(pos.max()) if pos.size else 1.0,
         name=name,
+        slice_attr=attrs,
     )
 
 
@@ -194,6 +198,8 @@ def sub_problem(prob: Problem, lo: int, hi: int, select=None) -> Problem:
     for name in ("slices", "slice_i2w", "slice_w2i", "slice_t", "slice_tinv", "slice_dim", "sizes_x", "sizes_y",
                  "stack_index"):
         setattr(q, name, np.ascontiguousarray(getattr(prob, name)[idx]))
+    if prob.slice_attr is not None:
+        q.slice_attr = [prob.slice_attr[int(i)] for i in idx]
     return q
 
 

@@ -191,10 +191,38 @@ int svr_ncc_set_source(svr_ctx *ctx, const uint32_t size[3], const int16_t *sour
 int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const double *matrices,
                      int64_t *sums6_or_null, double *ncc_or_null);
 
+/* ---- GPU slice-to-volume registration (the reference's --useGPUReg path) -------
+ * One entry point per public method of `class Reconstruction` used by irtkReconstruction::
+ * PrepareRegistrationSlices / SliceToVolumeRegistrationGPU (irtkReconstructionGPU.cc:2104-2290).
+ * Matrices are row-major float[16] (Matrix4), one per slice of this context.
+ *
+ * initRegStorageVolumes(uint3 size, float3 dim)                    RC.cuh:326, RC.cu:4893-5021
+ *   size = {x, y, slices} of the slices resampled to the reconstruction's voxel size. */
+int svr_init_reg_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float dim[3]);
+/* FillRegSlices(float* sdata, vector<Matrix4> slices_resampledI2W)  RC.cuh:328, RC.cu:5023-5088
+ *   sdata [slices][y][x], padding -1.  The I2W matrices are accepted for signature parity; no
+ *   reference kernel reads them (RC.cu:3515). */
+int svr_fill_reg_slices(svr_ctx *ctx, const float *sdata, const float *slices_resampledI2W_or_null);
+/* updateResampledSlicesI2W(vector<Matrix4> ofsSlice)                RC.cuh:331, RC.cu:4707-4757 */
+int svr_update_resampled_slices_i2w(svr_ctx *ctx, const float *ofsSlice);
+/* prepareSliceToVolumeReg()                                         RC.cuh:338, RC.cu:3800-3959
+ *   snapshots the current reconstruction as the sampled volume, sets 2 levels x 4 step sizes x
+ *   <= 20 iterations, epsilon 1e-4, blurring = voxel/2 and voxel, step lengths 0.1 and 0.2. */
+int svr_prepare_slice_to_volume_reg(svr_ctx *ctx);
+/* registerSlicesToVolume(vector<Matrix4>& transf_)                  RC.cuh:333, RC.cu:4760-4867
+ *   -> registerMultipleSlicesToVolume RC.cu:4001-4141; transf [slices][16] in/out. */
+int svr_register_slices_to_volume(svr_ctx *ctx, float *transf);
+/* test / tuning hooks (no reference counterpart): shorter schedule (0 = keep), one cost evaluation,
+ * counters {cost evaluations, line-search steps, outer iterations, slice evaluations} of the last run */
+int svr_reg_set_schedule(svr_ctx *ctx, int levels, int steps, int iterations);
+int svr_reg_evaluate_costs(svr_ctx *ctx, const float *transf, int level, const int *active_or_null, int n_active,
+                           float *similarities_out, float *reg_slices_out_or_null);
+int svr_reg_counters(svr_ctx *ctx, long long out4[4]);
+
 /* ---- measurement -------------------------------------------------------------------- */
 enum svr_timer {
   SVR_T_BACKPROJECT = 0, SVR_T_FORWARD = 1, SVR_T_GAUSS = 2, SVR_T_REGULARIZE = 3,
-  SVR_T_ESTEP = 4, SVR_T_MSTEP = 5, SVR_T_SCALE = 6, SVR_T_COUNT = 7
+  SVR_T_ESTEP = 4, SVR_T_MSTEP = 5, SVR_T_SCALE = 6, SVR_T_REGISTER = 7, SVR_T_COUNT = 8
 };
 /* accumulated HIP-event time (ms) and launch count of a hot kernel since the last reset */
 int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches);

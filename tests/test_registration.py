@@ -1,0 +1,236 @@
+"""GPU slice-to-volume registration (the reference's --useGPUReg path,
+RC.cu:3504-3529, 4001-4575 + GPUGauss/gaussfilter.cu): host prep, oracle quirks, device parity."""
+import numpy as np
+import pytest
+
+from fetalreconstruction_amd import geometry as geo
+from fetalreconstruction_amd import phantom
+from fetalreconstruction_amd import registration as R
+
+
+def _analytic_volume(P, radius=14.0):
+    vx, vy, vz = P.vsize
+    kk, jj, ii = np.meshgrid(np.arange(vz), np.arange(vy), np.arange(vx), indexing="ij")
+    w = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(float) @ P.recon_i2w.reshape(4, 4).astype(float).T
+    vol = phantom.phantom_intensity(w[..., :3], radius) * 700 / 0.55
+    return np.where(P.mask > 0, vol, -1).astype(np.float32)          # as after maskVolume()
+
+
+class _Recorder:
+    def initRegStorageVolumes(self, *a):
+        self.init = a
+
+    def FillRegSlices(self, d, m):
+        self.data, self.i2w = d, m
+
+
+# ---- host prep -------------------------------------------------------------------------------
+def test_resampling_with_padding_rules():
+    a = geo.ImageAttributes(8, 6, 1, 1.5, 1.5, 3.0, origin=np.array([1.0, -2.0, 0.5]))
+    img = np.full((1, 6, 8), 10.0)
+    out, oa = R.resample_with_padding(img, a, (1.0, 1.0, 1.0), -1.0)
+    assert (oa.nx, oa.ny, oa.nz) == (12, 9, 3)                        # round(n * d_old / d_new), RWP.cc:230-232
+    assert np.allclose(oa.origin, a.origin) and oa.dx == 1.0
+    assert np.allclose(out[out != -1], 10.0)                          # renormalised weights (RWP.cc:180-181)
+    assert (out[1] != -1).all()                                       # the plane through the slice centre
+    img[0, 2:4, 3:6] = -1.0                                           # a padded hole stays padded in its interior
+    out2, _ = R.resample_with_padding(img, a, (1.0, 1.0, 1.0), -1.0)
+    assert (out2[1] == -1).any() and (out2[1] != -1).sum() < (out[1] != -1).sum()
+    assert np.allclose(out2[out2 != -1], 10.0)
+
+
+def test_prepare_registration_slices_packs_plane0(tiny):
+    rec = _Recorder()
+    rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    assert rec.init[:3] == (35, 35, tiny.ns)                          # round(32 * 1.1 / 1.0)
+    assert rs.attrs[0].nz == 2                                        # round(2.2 / 1.0): plane 0 is 0.5 mm off-plane
+    assert rec.data.shape == (tiny.ns, 35, 35) and rec.data.dtype == np.float32
+    frac = (rec.data >= 0).mean()
+    assert 0.3 < frac < 0.7
+    m_res = np.nanmean(np.where(rec.data >= 0, rec.data, np.nan))
+    m_src = np.nanmean(np.where(tiny.slices >= 0, tiny.slices, np.nan))
+    assert 0.7 * m_src < m_res < 1.05 * m_src       # the kept rim (pad < 4 rule) is darker than the interior
+
+
+# ---- oracle quirks ---------------------------------------------------------------------------
+def test_gauss_kernel_and_blur_quirks(oracle_mod):
+    k, half = oracle_mod.reg_gauss_kernel(0.5)
+    assert k == 7 and len(half) == 4                                  # max(min(int(5 sigma), 63), 7), odd
+    assert oracle_mod.reg_gauss_kernel(2.0)[0] == 9 and oracle_mod.reg_gauss_kernel(2.5)[0] == 11
+    assert oracle_mod.reg_gauss_kernel(100.0)[0] == 63
+    assert abs(half[0] + 2 * half[1:].sum() - 1.0) < 1e-6
+    C = oracle_mod.C
+    img = np.full((1, 9, 9), 100.0, np.float32)
+    img[0, 4, 4] = -1.0
+    img[0, 0, 0] = -0.5                                               # negative but not padding
+    tmp = np.zeros_like(img)
+    oracle_mod.lib().orc_reg_blur_stack(oracle_mod._p(img), oracle_mod._p(tmp), 9, 9, 1, C.c_float(1.0))
+    assert img[0, 4, 4] == -1.0                                       # padding stays (GF.cu:101)
+    assert img[0, 4, 5] < 95.0                                       # its neighbours lose that weight: no renormalisation
+    assert abs(img[0, 8, 8] - 100.0) < 1e-3                           # clamped addressing at the border
+    assert img[0, 0, 0] != -0.5                                       # -0.5 is filtered like data
+
+
+def test_tex3d_half_voxel_and_border(oracle_mod):
+    C = oracle_mod.C
+    o = oracle_mod.OracleRegistration((4, 4, 4), 1.0, np.eye(4, dtype=np.float32))
+    vol = np.arange(64, dtype=np.float32).reshape(4, 4, 4)
+    o.initRegStorageVolumes(2, 2, 1)
+    o.prepareSliceToVolumeReg(vol)
+    f = oracle_mod.lib().orc_reg_tex3d
+
+    def tex(x, y, z):
+        p = np.array([x, y, z], np.float32)
+        return f(C.byref(o.st), oracle_mod._p(p))
+    assert tex(1.5, 2.5, 3.5) == vol[3, 2, 1]                         # voxel i is centred at i + 0.5
+    assert tex(1.0, 2.5, 3.5) == 0.5 * (vol[3, 2, 0] + vol[3, 2, 1])
+    assert tex(0.0, 0.5, 0.5) == 0.5 * vol[0, 0, 0]                   # border colour 0 beyond the edge
+    assert tex(-0.6, 0.5, 0.5) == 0.0
+    assert tex(1.5 + 1.0 / 512.0, 2.5, 3.5) == tex(1.5 + 1.0 / 256.0, 2.5, 3.5)   # 8-bit filter fraction
+
+
+def test_parameter_updates_match_irtk_convention(oracle_mod):
+    m = geo.rigid_matrix(1.0, -2.0, 3.0, 4.0, -5.0, 6.0)
+    for part, kw in enumerate(("tx", "ty", "tz", "rx", "ry", "rz")):
+        p = dict(tx=1.0, ty=-2.0, tz=3.0, rx=4.0, ry=-5.0, rz=6.0)
+        p[kw] += 0.25
+        assert np.allclose(oracle_mod.reg_adjust(m, part, 0.25), geo.rigid_matrix(**p), atol=2e-6)
+    g = np.array([0.1, -0.2, 0.3, 0.4, 0.5, -0.6], np.float32)
+    want = geo.rigid_matrix(1.0 + 0.05, -2.0 - 0.1, 3.0 + 0.15, 4.0 + 0.2, -5.0 + 0.25, 6.0 - 0.3)
+    assert np.allclose(oracle_mod.reg_gradient_step(m, g, 0.5), want, atol=2e-6)
+
+
+def _oracle_reg(oracle_mod, P, rs, vol):
+    o = oracle_mod.OracleRegistration(P.vsize, P.vdim[0], P.recon_w2i)
+    o.initRegStorageVolumes(rs.combined.shape[2], rs.combined.shape[1], P.ns)
+    o.FillRegSlices(rs.combined, rs.i2w)
+    return o
+
+
+def test_oracle_registration_increases_similarity(tiny, oracle_mod):
+    vol = _analytic_volume(tiny)
+    rs = R.PrepareRegistrationSlices(_Recorder(), tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    o = _oracle_reg(oracle_mod, tiny, rs, vol)
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    T[3] = T[3] @ geo.rigid_matrix(tx=1.5, rz=2.0)                    # knock two slices off
+    T[10] = T[10] @ geo.rigid_matrix(ty=-1.0, rx=-1.5)
+    mo = [np.eye(4) for _ in range(tiny.ns)]
+    for m, a in zip(mo, rs.attrs):
+        m[:3, 3] = a.origin
+    t_in = np.stack([geo.to_matrix4(t @ m) for t, m in zip(T, mo)])
+    Tn = R.SliceToVolumeRegistrationGPU(o, rs, T, vol)
+    assert o.counters[0] > 100 and o.counters[2] >= 8                 # it really iterated
+    t_out = np.stack([geo.to_matrix4(t @ m) for t, m in zip(Tn, mo)])
+    # (per-slice monotonicity is not a property of the reference: the value of a slot depends on the
+    # size of the active set, see test_literal_temp_buffer_aliasing)
+    s0, _ = o.evaluate_costs(t_in, 0)
+    s1, _ = o.evaluate_costs(t_out, 0)
+    assert s1.sum() > s0.sum() and s1[3] > s0[3] and s1[10] > s0[10]
+    for m in Tn:                                                      # still rigid
+        assert np.allclose(m[:3, :3] @ m[:3, :3].T, np.eye(3), atol=1e-5)
+
+
+def test_literal_temp_buffer_aliasing(tiny, oracle_mod):
+    """With every slice active the accumulated NCC is wiped before offsets 0 and +1 and the moments of
+    the slots >= 2a/3 are never wiped (RC.cu:4200 clears float[2*slices, 5*slices)); with few active
+    slices nothing is wiped and the moments accumulate over the three offsets."""
+    vol = _analytic_volume(tiny)
+    rs = R.PrepareRegistrationSlices(_Recorder(), tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    o = _oracle_reg(oracle_mod, tiny, rs, vol)
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    R.SliceToVolumeRegistrationGPU(_NoRun(o), rs, T, vol)
+    t_in = o.last_transf
+    full, _ = o.evaluate_costs(t_in, 0)
+    assert (np.abs(full) <= 1.0 + 1e-5).all()                         # one NCC value per slot survives
+    few, _ = o.evaluate_costs(t_in, 0, active=[2, 5, 7])
+    assert (few[[2, 5, 7]] > 1.0).all() and (few[[2, 5, 7]] <= 3.0 + 1e-5).all()   # three values accumulate
+    assert not np.allclose(few[[2, 5, 7]], full[[2, 5, 7]])
+
+
+class _NoRun:
+    """Engine wrapper that records the matrices SliceToVolumeRegistrationGPU hands over, without running."""
+
+    def __init__(self, o):
+        self.o = o
+
+    def updateResampledSlicesI2W(self, ofs):
+        self.o.updateResampledSlicesI2W(ofs)
+
+    def prepareSliceToVolumeReg(self, volume):
+        self.o.prepareSliceToVolumeReg(volume)
+
+    def registerSlicesToVolume(self, transf):
+        self.o.last_transf = np.array(transf, np.float32)
+        return np.array(transf, np.float32).reshape(-1, 4, 4)
+
+
+# ---- device parity ---------------------------------------------------------------------------
+def _engine_with_volume(P, vol):
+    from fetalreconstruction_amd import engine as E
+    rec = E.Reconstruction(0)
+    E.sync_gpu(rec, P)
+    rec.UpdateReconstructed(P.vsize, vol)
+    return rec
+
+
+@pytest.mark.gpu
+def test_cost_evaluation_parity(tiny, oracle_mod):
+    vol = _analytic_volume(tiny)
+    rec = _engine_with_volume(tiny, vol)
+    rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    o = _oracle_reg(oracle_mod, tiny, rs, vol)
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    nr = _NoRun(o)
+    R.SliceToVolumeRegistrationGPU(nr, rs, T, vol)
+    t_in = o.last_transf
+    rec.updateResampledSlicesI2W(o._ofs)
+    rec.prepareSliceToVolumeReg()
+    for level in (1, 0):
+        for active in (None, [2, 5, 7], list(range(0, tiny.ns, 2)), list(range(tiny.ns - 1, -1, -1)), [23]):
+            so, do_ = o.evaluate_costs(t_in, level, active)
+            sg, dg = rec.evaluate_costs(t_in, level, active)
+            assert np.array_equal(dg.view(np.uint32), do_.view(np.uint32))      # sampled + blurred slices: bit-exact
+            assert np.allclose(sg, so, rtol=0, atol=2e-6)
+            assert (sg != 0).sum() == (tiny.ns if active is None else len(active))
+
+
+@pytest.mark.gpu
+def test_registration_parity(tiny, oracle_mod):
+    vol = _analytic_volume(tiny)
+    rec = _engine_with_volume(tiny, vol)
+    rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    o = _oracle_reg(oracle_mod, tiny, rs, vol)
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    T[3] = T[3] @ geo.rigid_matrix(tx=1.5, rz=2.0)
+    T[10] = T[10] @ geo.rigid_matrix(ty=-1.0, rx=-1.5)
+    To = R.SliceToVolumeRegistrationGPU(o, rs, T, vol)
+    Tg = R.SliceToVolumeRegistrationGPU(rec, rs, T)
+    assert np.array_equal(rec.reg_counters(), o.counters)             # same decisions at every step
+    assert np.allclose(Tg, To, rtol=0, atol=1e-5)
+    assert np.abs(Tg - T).max() > 0.1
+
+
+@pytest.mark.gpu
+def test_registration_on_a_reconstructed_volume(tiny, oracle_mod):
+    """End to end on the engine's own reconstruction: reconstruct, register, push the new matrices."""
+    from fetalreconstruction_amd import engine as E
+    from fetalreconstruction_amd.reconstruction import irtkReconstruction
+    rec = E.Reconstruction(0)
+    E.sync_gpu(rec, tiny)
+    d = irtkReconstruction(rec, tiny.ns, max_intensity=tiny.max_intensity, min_intensity=tiny.min_intensity)
+    d.SetSmoothingParameters(150, 0.02)
+    d.reconstruct_iteration(2)
+    vol = rec.syncCPU()
+    rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    o = _oracle_reg(oracle_mod, tiny, rs, vol)
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    To = R.SliceToVolumeRegistrationGPU(o, rs, T, vol)
+    Tg = R.SliceToVolumeRegistrationGPU(rec, rs, T)
+    assert np.array_equal(rec.reg_counters(), o.counters)
+    assert np.allclose(Tg, To, rtol=0, atol=1e-5)
+    ti = np.stack([np.linalg.inv(t) for t in Tg])
+    rec.SetSliceMatrices(np.stack([geo.to_matrix4(t) for t in Tg]), np.stack([geo.to_matrix4(t) for t in ti]),
+                         tiny.slice_i2w, tiny.slice_w2i, tiny.slice_i2w, tiny.slice_w2i, tiny.recon_i2w,
+                         tiny.recon_w2i)                               # UpdateGPUTranformationMatrices RG.cc:372-401
+    d.reconstruct_iteration(1)
+    assert np.isfinite(rec.syncCPU()).all()
