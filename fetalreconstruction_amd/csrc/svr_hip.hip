@@ -1246,18 +1246,50 @@ __device__ __forceinline__ float G_(float x, float s) {   // RC.cu:62-65
 }
 
 // InitializeEMValuesKernel RC.cu:3241-3267
-__global__ void k_init_em(const float *slices, float *weights, size_t n) {
+// pvr: InitializeEMValuesKernel of R2/patchBasedRobustStatistics_gpu.cu:55-76 also zeroes s == 0
+__global__ void k_init_em(const float *slices, float *weights, size_t n, int pvr) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) weights[i] = (slices[i] != -1.0f) ? 1.0f : 0.0f;
+  if (i < n) {
+    const float s = slices[i];
+    weights[i] = (s != -1.0f && !(pvr && s == 0.0f)) ? 1.0f : 0.0f;
+  }
 }
 
 // EStepKernel3D_tex RC.cu:2766-2813 fused with the slice-potential transform RC.cu:2816-2841
 __global__ __launch_bounds__(256) void k_estep(const float *slices, const float *simslices,
                                                const float *simweights, const float *scales,
                                                const float *bias, float m_, float sigma_, float mix_, int n2,
-                                               float *weights, double *partial) {
+                                               float *weights, double *partial, int pvr) {
   const int sl = blockIdx.y;
   const float scale = scales[sl];
+  if (pvr) {
+    // EStepKernel of R2/patchBasedRobustStatistics_gpu.cu:106-150: gated on the pixel's current WEIGHT
+    // (not the simulated weight), weights are not cleared first, __step = 1e-5f (reconConfig.cuh:120),
+    // the mixture in double through the `1.0 - _mix` literal
+    const float step = 0.00001f;
+    const float m = m_ * step;
+    double v[2] = {0.0, 0.0};
+    const size_t base = (size_t)sl * n2;
+    for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX); i += 256) {
+      const float s = slices[base + i];
+      float w = weights[base + i];
+      if (!(s == -1.0f || w <= 0.0f)) {
+        float patchVal = s * scale;
+        patchVal -= simslices[base + i];
+        const float g = step * expf(-patchVal * patchVal / (2.0f * sigma_)) / (sqrtf(6.28f * sigma_));
+        w = (float)((double)(g * mix_) / ((double)(g * mix_) + (double)m * (1.0 - (double)mix_)));
+        weights[base + i] = w;
+      }
+      if ((double)simweights[base + i] > 0.99) {        // transformPatchPotential :152-168
+        const double t = 1.0 - (double)w;
+        v[0] += (double)(float)(t * t);
+        v[1] += 1.0;
+      }
+    }
+    const int op[2] = {0, 0};
+    block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
+    return;
+  }
   const float m = m_ * SVR_STEP;   // M_ RC.cu:67-70
   double v[2] = {0.0, 0.0};
   const size_t base = (size_t)sl * n2;
@@ -2373,11 +2405,14 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   int r = ready(ctx);
   if (r) return r;
   const size_t fb = ctx->np * sizeof(float);
-  // RC.cu:2401-2411
-  HIPCHK(hipMemsetAsync(ctx->d_weights, 0, fb, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_simweights, 0, fb, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_simslices, 0, fb, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_siminside, 0, ctx->np, ctx->stream));
+  // RC.cu:2401-2411.  PVR: ReconVolume::reset() clears only the volume and its weights
+  // (R2/include/reconVolume.cuh:93-98); the patch buffers keep their values between outer iterations.
+  if (!ctx->pvr) {
+    HIPCHK(hipMemsetAsync(ctx->d_weights, 0, fb, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_simweights, 0, fb, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_simslices, 0, fb, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_siminside, 0, ctx->np, ctx->stream));
+  }
   HIPCHK(hipMemsetAsync(ctx->d_voxcount, 0, ctx->np * sizeof(int), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * ctx->nv * sizeof(float), ctx->stream));
   PsfArgs a = make_args(ctx);
@@ -2513,7 +2548,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
 int svr_initialize_em_values(svr_ctx *ctx) {
   if (!ctx) return SVR_E_ARG;
   NEED(ctx->have_slices, "slices not filled");
-  hipLaunchKernelGGL(k_init_em, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights, ctx->np);
+  hipLaunchKernelGGL(k_init_em, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights, ctx->np, ctx->pvr);
   KCHK("k_init_em");
   if (!ctx->disable_bias) {                              // RC.cu:3305-3309
     int r = ensure_bias_buffers(ctx);
@@ -2552,7 +2587,7 @@ int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potent
   ScopedTimer t(ctx, SVR_T_ESTEP);
   hipLaunchKernelGGL(k_estep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_simslices,
                      ctx->d_simweights, ctx->d_scales, ctx->disable_bias ? (const float *)nullptr : ctx->d_bias, m, sigma,
-                     mix, (int)(ctx->sx * ctx->sy), ctx->d_weights, ctx->d_partial);
+                     mix, (int)(ctx->sx * ctx->sy), ctx->d_weights, ctx->d_partial, ctx->pvr);
   KCHK("k_estep");
   int r = reduce_partials(ctx, 2, 0, 0, false);
   if (r) return r;

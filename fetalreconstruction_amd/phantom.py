@@ -190,6 +190,37 @@ def make_problem(
     )
 
 
+def make_stacks(n_stacks=3, stack_shape=(32, 32, 8), in_plane=1.1, spacing=2.2, thickness=None, recon_res=1.0,
+                mask_radius=14.0, noise_sigma=5.0, average=700.0, seed=3, orientations=("ax", "cor", "sag"),
+                stack_offsets_mm=0.37, stack_motion_mm=0.5, stack_motion_deg=1.0):
+    """Whole stacks (3-D images + one rigid transformation each) for the patch-based path: what
+    irtkPatchBasedReconstruction holds in m_stacks / m_stack_transformations / m_mask before patch
+    extraction.  Returns (stacks, mask [z][y][x] uint8, mask_attr, recon_attr, recon_mask)."""
+    from .pvr import Stack
+    rng = np.random.default_rng(seed)
+    nx, ny, nsl = stack_shape
+    thickness = float(thickness if thickness is not None else spacing)
+    radius = float(mask_radius)
+    n_v = int(np.ceil((2.0 * radius + 6.0 * recon_res) / recon_res))
+    vattr = geo.ImageAttributes(n_v, n_v, n_v, recon_res, recon_res, recon_res)
+    c1 = ((np.arange(n_v) - (n_v - 1) / 2.0) * recon_res) ** 2
+    recon_mask = ((c1[:, None, None] + c1[None, :, None] + c1[None, None, :]) < radius * radius).astype(np.float32)
+    stacks = []
+    kk, jj, ii = np.meshgrid(np.arange(nsl), np.arange(ny), np.arange(nx), indexing="ij")
+    pix = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(np.float64)
+    for st in range(n_stacks):
+        axes = _ORIENT[orientations[st % len(orientations)]]
+        off = stack_offsets_mm * np.array([1.0 + 0.31 * st, 0.77 - 0.23 * st, 0.53 + 0.19 * st])
+        sattr = geo.ImageAttributes(nx, ny, nsl, in_plane, in_plane, spacing, *axes, origin=off)
+        p = np.concatenate([rng.uniform(-stack_motion_mm, stack_motion_mm, 3),
+                            rng.uniform(-stack_motion_deg, stack_motion_deg, 3)])
+        t = geo.rigid_matrix(*p)
+        w = (pix @ geo.image_to_world(sattr).T) @ t.T
+        val = phantom_intensity(w[..., :3], radius) * average / 0.55 + rng.normal(0.0, noise_sigma, w.shape[:-1])
+        stacks.append(Stack(np.maximum(val, 0.0).astype(np.float32), sattr, t, thickness))
+    return stacks, (recon_mask > 0).astype(np.uint8), vattr, vattr, recon_mask
+
+
 def sub_problem(prob: Problem, lo: int, hi: int, select=None) -> Problem:
     """The slice shard [lo, hi) (or an explicit index list) of a problem, same volume."""
     import copy

@@ -1,0 +1,264 @@
+"""Host side of the patch-to-volume reconstruction (PVR): patch extraction and the
+reconstruction loop of irtkPatchBasedReconstruction, driving one engine context with option pvr=1.
+
+Mirrors (R2 = /root/reference/source/reconstructionGPU2):
+  * PatchBasedObject<T>::generate2DPatches           R2/include/patchBasedObject.cuh:176-342
+  * irtkPatchBasedReconstruction<T>::run (the loop)  R2/irtkPatchBasedReconstruction.cpp:426-593
+  * patchBasedRobustStatistics_gpu<T>::{initializeEMValues, InitializeRobustStatistics, EStep, MStep,
+    Scale}                                            R2/patchBasedRobustStatistics_gpu.cu:78-95, 224-556,
+                                                      570-640, 672-745, 793-845
+  * patchBasedSuperresolution_gpu<T>::{run, regularize} with its fixed delta = 1, lambda = 0.1,
+    alpha = 0.05 / lambda * delta^2                   R2/patchBasedSuperresolution_gpu.cu:113-336
+Patches are handed to the engine as the slices of its padded grid `[nPatches][pY][pX]`
+(R2/include/patchBasedVolume.cuh:108-194); per-patch scale and patchWeight are the engine's scale /
+slice-weight vectors.  Patch-to-volume registration (runHybrid) is not part of this module.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import geometry as geo
+from .phantom import Problem
+
+
+@dataclass
+class Stack:
+    data: np.ndarray                 # [nz][ny][nx]
+    attr: geo.ImageAttributes
+    transformation: np.ndarray       # 4x4 float64 (m_stack_transformations[i])
+    thickness: float
+
+
+def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttributes, pbbsize, stride):
+    """patchBasedObject.cuh:176-342.  Returns (patches float32 [n][pY][pX], I2W [n][16], W2I [n][16],
+    total_pixels).  A patch starts as an all-zero image (irtkGenericImage(sattr)); pixels whose position
+    is inside the slice and inside the mask (mask > 0, no stack transformation applied) are copied; the
+    patch is kept when more than a third of its pixels are set to something other than 0 / -1."""
+    a = stack.attr
+    px, py = int(pbbsize[0]), int(pbbsize[1])
+    sx, sy = int(stride[0]), int(stride[1])
+    s_i2w = geo.image_to_world(a)
+    m_w2i = geo.world_to_image(mask_attr)
+    mz, my, mx = mask.shape
+    jj, ii = np.meshgrid(np.arange(py), np.arange(px), indexing="ij")
+    pix = np.stack([ii, jj, np.zeros_like(ii), np.ones_like(ii)], -1).astype(np.float64)   # [pY][pX][4]
+    out, i2ws, w2is = [], [], []
+    total = 0
+    for z in range(a.nz):
+        centre = s_i2w @ np.array([(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, float(z), 1.0])
+        sl_attr = geo.ImageAttributes(a.nx, a.ny, 1, a.dx, a.dy, stack.thickness * 2, a.xaxis, a.yaxis, a.zaxis,
+                                      origin=centre[:3])                       # GetRegion + PutPixelSize :204-205
+        sl_i2w, sl_w2i = geo.image_to_world(sl_attr), geo.world_to_image(sl_attr)
+        p0 = geo.ImageAttributes(px, py, 1, a.dx, a.dy, stack.thickness * 2, a.xaxis, a.yaxis, a.zaxis)
+        p0_first = geo.image_to_world(p0) @ np.array([0.0, 0.0, 0.0, 1.0])
+        for y in range(0, a.ny + py, sy):
+            for x in range(0, a.nx + px, sx):
+                first = sl_i2w @ np.array([float(x), float(y), 0.0, 1.0])
+                pa = copy.copy(p0)
+                pa.origin = (first - p0_first)[:3]                              # :232-246
+                p_i2w = geo.image_to_world(pa)
+                w = pix @ p_i2w.T
+                q = w @ sl_w2i.T
+                xx, yy = q[..., 0], q[..., 1]
+                qm = w @ m_w2i.T
+                x1, y1, z1 = qm[..., 0], qm[..., 1], qm[..., 2]
+                ok = (xx >= 0) & (yy >= 0) & (xx < a.nx) & (yy < a.ny)
+                ok &= (x1 >= 0) & (y1 >= 0) & (z1 >= 0) & (x1 < mx) & (y1 < my) & (z1 < mz)
+                xi, yi = np.clip(xx.astype(int), 0, a.nx - 1), np.clip(yy.astype(int), 0, a.ny - 1)   # int truncation
+                mi = mask[np.clip(z1.astype(int), 0, mz - 1), np.clip(y1.astype(int), 0, my - 1),
+                          np.clip(x1.astype(int), 0, mx - 1)]
+                ok &= mi > 0
+                patch = np.where(ok, stack.data[z][yi, xi], 0.0)
+                set_count = int((ok & (patch != 0) & (patch != -1)).sum())
+                if set_count > np.float32(1.0) / np.float32(3.0) * (py * px):    # :318
+                    total += set_count
+                    out.append(patch.astype(np.float32))
+                    i2ws.append(geo.to_matrix4(p_i2w))
+                    w2is.append(geo.to_matrix4(geo.world_to_image(pa)))
+    n = len(out)
+    return (np.stack(out) if n else np.zeros((0, py, px), np.float32),
+            np.stack(i2ws) if n else np.zeros((0, 16), np.float32),
+            np.stack(w2is) if n else np.zeros((0, 16), np.float32), total)
+
+
+def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(32, 32), stride=(16, 16), name="pvr"):
+    """PatchBasedVolume<T>::init for every stack (irtkPatchBasedReconstruction.cpp:385-399) packed into
+    one Problem: slices = patches, slice dims = the stack's voxel size `getDim()` (z = stack spacing,
+    R2/patchBasedPSFReconstruction_gpu.cu:67), T = the stack transformation."""
+    P, I, W, T, TI, D, SI, counts = [], [], [], [], [], [], [], []
+    for k, st in enumerate(stacks):
+        p, i2w, w2i, _ = generate2DPatches(st, mask, mask_attr, pbbsize, stride)
+        n = len(p)
+        counts.append(n)
+        P.append(p); I.append(i2w); W.append(w2i)
+        T.append(np.tile(geo.to_matrix4(st.transformation), (n, 1)))
+        TI.append(np.tile(geo.to_matrix4(np.linalg.inv(st.transformation)), (n, 1)))
+        D.append(np.tile(np.array([st.attr.dx, st.attr.dy, st.attr.dz], np.float32), (n, 1)))
+        SI.append(np.full(n, k, np.int32))
+    patches = np.concatenate(P)
+    n = len(patches)
+    pos = patches[patches > 0]
+    rd = (recon_attr.dx, recon_attr.dy, recon_attr.dz)
+    prob = Problem(
+        vsize=(recon_attr.nx, recon_attr.ny, recon_attr.nz), vdim=rd,
+        recon_i2w=geo.to_matrix4(geo.image_to_world(recon_attr)),
+        recon_w2i=geo.to_matrix4(geo.world_to_image(recon_attr)),
+        mask=np.ascontiguousarray(recon_mask, np.float32), slices=patches, slice_i2w=np.concatenate(I), slice_w2i=np.concatenate(W),
+        slice_t=np.concatenate(T), slice_tinv=np.concatenate(TI), slice_dim=np.concatenate(D),
+        sizes_x=np.full(n, patches.shape[2], np.int32), sizes_y=np.full(n, patches.shape[1], np.int32),
+        stack_index=np.concatenate(SI), psf_c0=geo.psf_centre_offset(rd),
+        min_intensity=float(pos.min()) if pos.size else 0.0, max_intensity=float(pos.max()) if pos.size else 1.0,
+        name=name)
+    prob.patches_per_stack = counts
+    return prob
+
+
+def _G(x, s, step=np.float32(0.00001)):
+    """G_<float> of patchBasedRobustStatistics_gpu.cu:97-101 with __step = 0.00001f, evaluated in float."""
+    x, s = np.float32(x), np.float32(s)
+    return np.float32(step * np.exp(np.float32(-x * x / (np.float32(2.0) * s))) / np.sqrt(np.float32(6.28) * s))
+
+
+class irtkPatchBasedReconstruction:
+    """The reconstruction part of irtkPatchBasedReconstruction<T>::run
+    (irtkPatchBasedReconstruction.cpp:445-593) on one engine (`engine.Reconstruction` with option pvr=1,
+    or the oracle twin).  Members carry the reference's names (m_sigma_gpu ...)."""
+
+    def __init__(self, engine, patches_per_stack, min_intensity, max_intensity, adaptive=False):
+        self.e = engine
+        self.counts = [int(c) for c in patches_per_stack]
+        self.n = int(sum(self.counts))
+        self.m_min_intensity, self.m_max_intensity = float(min_intensity), float(max_intensity)
+        self.m_adaptive = bool(adaptive)
+        self.m_delta = np.float32(1.0)                                   # patchBasedSuperresolution_gpu.cu:291-295
+        self.m_lambda = np.float32(0.1)
+        self.m_alpha = np.float32(np.float32(0.05) / self.m_lambda) * self.m_delta * self.m_delta
+        self.m_step = 0.0001                                              # patchBasedRobustStatistics_gpu.cu:877
+        self.scale = np.ones(self.n, np.float32)
+        self.patch_weight = np.ones(self.n, np.float32)
+        self.m_sigma_gpu = self.m_mix_gpu = self.m_m_gpu = np.float32(0)
+        self.m_sigma_s_gpu = self.m_mix_s_gpu = np.float32(0)
+        self.m_mean_s_gpu = self.m_mean_s2_gpu = self.m_sigma_s2_gpu = np.float32(0)
+        self.patch_potential = np.zeros(self.n, np.float32)
+
+    # ---- robust statistics ---------------------------------------------------------------
+    def initializeEMValues(self):                                         # :78-95
+        self.scale[:] = 1.0
+        self.patch_weight[:] = 1.0
+        self.e.UpdateScaleVector(self.scale, self.patch_weight)
+        self.e.InitializeEMValues()
+
+    def InitializeRobustStatistics(self):                                 # :793-845
+        sa, sb = self.e.RobustStatisticsSums()
+        if sb == 0:
+            raise RuntimeError("ERROR: sb = 0!! no sigma computed!")      # the reference exits here
+        self.m_sigma_gpu = np.float32(np.float32(sa) / np.float32(sb))
+        self.m_sigma_s_gpu = np.float32(0.025)
+        self.m_mix_gpu = np.float32(0.9)
+        self.m_mix_s_gpu = np.float32(0.9)
+        self.m_m_gpu = np.float32(np.float32(1.0) / (np.float32(2.1) * np.float32(self.m_max_intensity)
+                                                    - np.float32(1.9) * np.float32(self.m_min_intensity)))
+
+    def EStep(self):                                                      # :224-556
+        pot_dev = self.e.EStep(float(self.m_m_gpu), float(self.m_sigma_gpu), float(self.m_mix_gpu))
+        # the reference writes stack i's potentials to patch_potential[j], j = index within the stack,
+        # without the stack offset (:256-276): later stacks overwrite the head, the tail stays 0
+        pp = np.zeros(self.n, np.float32)
+        ofs = 0
+        for c in self.counts:
+            pp[:c] = pot_dev[ofs:ofs + c]
+            ofs += c
+        sc, pw = self.scale, self.patch_weight.copy()
+        pp[(sc < 0.2) | (sc > 5)] = -1                                    # :307-311
+        valid = pp >= 0
+        ppd, pwd = pp.astype(np.float64), pw.astype(np.float64)
+        s, d = ((pp * pw).astype(np.float64))[valid].sum(), pwd[valid].sum()
+        s2, d2 = (ppd * (1.0 - pwd))[valid].sum(), (1.0 - pwd)[valid].sum()
+        maxs, mins = 0.0, 1.0
+        if valid.any():
+            maxs, mins = max(0.0, float(ppd[valid].max())), min(1.0, float(ppd[valid].min()))
+        self.m_mean_s_gpu = np.float32(s / d) if d > 0 else np.float32(mins)
+        self.m_mean_s2_gpu = np.float32(s2 / d2) if d2 > 0 else np.float32((maxs + float(self.m_mean_s_gpu)) / 2.0)
+        # (pp - mean) products are float expressions widened on accumulation (:364-372)
+        dv = (pp - self.m_mean_s_gpu)
+        dv2 = (pp - self.m_mean_s2_gpu)
+        s = ((dv * dv * pw).astype(np.float64))[valid].sum()
+        d = pwd[valid].sum()
+        s2 = ((dv2 * dv2 * (np.float32(1) - pw)).astype(np.float64))[valid].sum()
+        d2 = (1 - pwd)[valid].sum()
+        floor = self.m_step * self.m_step / 6.28
+        if s > 0 and d > 0:
+            self.m_sigma_s_gpu = np.float32(s / d)
+            if self.m_sigma_s_gpu < floor:
+                self.m_sigma_s_gpu = np.float32(floor)
+        else:
+            self.m_sigma_s_gpu = np.float32(0.025)
+        if s2 > 0 and d2 > 0:
+            self.m_sigma_s2_gpu = np.float32(s2 / d2)
+            if self.m_sigma_s2_gpu < floor:
+                self.m_sigma_s2_gpu = np.float32(floor)
+        else:
+            dm = self.m_mean_s2_gpu - self.m_mean_s_gpu
+            self.m_sigma_s2_gpu = np.float32(dm * dm / np.float32(4))
+            if self.m_sigma_s2_gpu < floor:
+                self.m_sigma_s2_gpu = np.float32(floor)
+        for i in range(self.n):                                           # :415-452
+            p = pp[i]
+            if p == -1:
+                pw[i] = 0
+                continue
+            if d <= 0 or self.m_mean_s2_gpu <= self.m_mean_s_gpu:
+                pw[i] = 1
+                continue
+            gs1 = float(_G(p - self.m_mean_s_gpu, self.m_sigma_s_gpu)) if p < self.m_mean_s2_gpu else 0.0
+            gs2 = float(_G(p - self.m_mean_s2_gpu, self.m_sigma_s2_gpu)) if p > self.m_mean_s_gpu else 0.0
+            lik = gs1 * float(self.m_mix_s_gpu) + gs2 * (1 - float(self.m_mix_s_gpu))
+            if lik > 0:
+                pw[i] = np.float32(gs1 * float(self.m_mix_s_gpu) / lik)
+            else:
+                if p <= self.m_mean_s_gpu:
+                    pw[i] = 1
+                if p >= self.m_mean_s2_gpu:
+                    pw[i] = 0
+                if self.m_mean_s_gpu < p < self.m_mean_s2_gpu:
+                    pw[i] = 1
+        num = int(valid.sum())                                            # :455-468
+        self.m_mix_s_gpu = np.float32(pw.astype(np.float64)[valid].sum() / num) if num > 0 else np.float32(0.9)
+        self.patch_potential = pp
+        self.patch_weight = pw
+        self.e.UpdateScaleVector(self.scale, self.patch_weight)           # copyToWeightsAndScales :486-491
+
+    def MStep(self, it):                                                  # :570-640
+        sigma, mix, num, mn, mx = [np.float32(v) for v in self.e.MStepSums()]
+        if mix > 0:
+            self.m_sigma_gpu = np.float32(sigma / mix)
+        floor = np.float32(np.float32(self.m_step * self.m_step) / np.float32(6.28))
+        if self.m_sigma_gpu < floor:
+            self.m_sigma_gpu = floor
+        if it > 1:
+            self.m_mix_gpu = np.float32(mix / num)
+        self.m_m_gpu = np.float32(np.float32(1.0) / (mx - mn))
+
+    def Scale(self):                                                      # :672-745
+        self.scale = np.asarray(self.e.CalculateScaleVector(), np.float32).copy()
+        self.e.UpdateScaleVector(self.scale, self.patch_weight)           # copyToScales: no lag
+
+    # ---- the loop ------------------------------------------------------------------------
+    def reconstruct_iteration(self, rec_iterations):
+        """One outer iteration without the patch registration (PBR.cpp:490-548)."""
+        self.initializeEMValues()
+        self.e.GaussianReconstruction()        # reset + patchBasedPSFReconstruction_gpu + equalize
+        self.e.SimulateSlices()
+        self.InitializeRobustStatistics()
+        self.EStep()
+        for i in range(rec_iterations):
+            self.Scale()
+            self.e.Superresolution(i + 1, self.patch_weight, self.m_adaptive, float(self.m_alpha),
+                                   self.m_min_intensity, self.m_max_intensity, float(self.m_delta),
+                                   float(self.m_lambda))                  # resetAddonCmap + run + regularize
+            self.e.SimulateSlices()
+            self.MStep(i + 1)
+            self.EStep()

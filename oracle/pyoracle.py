@@ -141,9 +141,10 @@ class OracleReconstruction:
 
     # ---- Reconstruction::GaussianReconstruction (reconstruction_cuda2.cu:2329-2493) --------
     def GaussianReconstructionLocal(self):
-        for a in (self.weights, self.simslices, self.simweights):   # RC.cu:2402-2409
-            a[...] = 0
-        self.siminside[...] = 0
+        if not self.pvr:     # PVR: ReconVolume::reset() leaves the patch buffers alone (reconVolume.cuh:93-98)
+            for a in (self.weights, self.simslices, self.simweights):   # RC.cu:2402-2409
+                a[...] = 0
+            self.siminside[...] = 0
         self._gauss_n = lib().orc_gaussian_reconstruction(
             C.byref(self.g), _p(self.slices), _p(self.d_scales), _p(self.mask), _p(self.recon), _p(self.volw),
             _p(self.psf_sums), _p(self.voxcount))
@@ -183,7 +184,8 @@ class OracleReconstruction:
         self.SuperresolutionUpdate(adaptive, alpha, min_i, max_i, delta, lam)
 
     def InitializeEMValues(self):
-        lib().orc_initialize_em_values(C.c_size_t(self.slices.size), _p(self.slices), _p(self.weights))
+        f = lib().orc_initialize_em_values_pvr if self.pvr else lib().orc_initialize_em_values
+        f(C.c_size_t(self.slices.size), _p(self.slices), _p(self.weights))
         if self.bias is not None:
             self.bias[...] = 0                          # RC.cu:3305-3309
 
@@ -211,6 +213,11 @@ class OracleReconstruction:
 
     def EStep(self, m, sigma, mix):
         pot = np.zeros(self.g.ns, np.float32)
+        if self.pvr:
+            lib().orc_estep_pvr(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.simslices),
+                                _p(self.simweights), _p(self.d_scales), C.c_float(m), C.c_float(sigma),
+                                C.c_float(mix), _p(self.weights), _p(pot))
+            return pot
         lib().orc_estep(self.g.sx, self.g.sy, self.g.ns, _p(self.slices), _p(self.simslices), _p(self.simweights),
                         _p(self.d_scales), C.c_float(m), C.c_float(sigma), C.c_float(mix), _p(self.weights), _p(pot),
                         self._b())

@@ -651,6 +651,42 @@ void orc_estep(int sx, int sy, int ns, const float *slices, const float *simslic
   }
 }
 
+/* PVR twins (R2 = /root/reference/source/reconstructionGPU2):
+ * InitializeEMValuesKernel R2/patchBasedRobustStatistics_gpu.cu:55-76 -- s == 0 also gets weight 0 */
+void orc_initialize_em_values_pvr(size_t n, const float *patches, float *weights) {
+  for (size_t i = 0; i < n; ++i) weights[i] = (patches[i] != -1 && patches[i] != 0) ? 1.0f : 0.0f;
+}
+/* EStepKernel R2/patchBasedRobustStatistics_gpu.cu:106-150 + patch potentials :152-168,256-276:
+ * gated on the pixel's current weight, weights not cleared, __step = 0.00001f (R2/include/reconConfig.cuh:120),
+ * `1.0 - _mix` makes the mixture a double expression. */
+void orc_estep_pvr(int sx, int sy, int ns, const float *patches, const float *simpatches,
+                   const float *simweights, const float *scales, float m_, float sigma_, float mix_,
+                   float *weights, float *patch_potential) {
+  const float step = 0.00001f;
+  size_t n2 = (size_t)sx * sy;
+  for (int sl = 0; sl < ns; ++sl) {
+    for (size_t i = 0; i < n2; ++i) {
+      size_t idx = (size_t)sl * n2 + i;
+      float s = patches[idx], sw = weights[idx];
+      if (s == -1 || sw <= 0) continue;
+      float patchVal = s * scales[sl];
+      patchVal -= simpatches[idx];
+      float g = step * expf(-patchVal * patchVal / (2.0f * sigma_)) / (sqrtf(6.28f * sigma_));
+      float m = m_ * step;
+      weights[idx] = (float)((double)(g * mix_) / ((double)(g * mix_) + (double)m * (1.0 - (double)mix_)));
+    }
+    double a = 0, b = 0;
+    for (size_t i = 0; i < n2; ++i) {
+      size_t idx = (size_t)sl * n2 + i;
+      if ((double)simweights[idx] > 0.99) {
+        double t = 1.0 - (double)weights[idx];
+        a += (double)(float)(t * t); b += 1.0;
+      }
+    }
+    patch_potential[sl] = (b > 0) ? sqrtf((float)a / (float)b) : -1.0f;
+  }
+}
+
 /* transformMStep3DNoBias / reduceMStep / MStep RC.cu:2966-3072.
  * out5 = {sum e^2 w, sum w, count, min e, max e} as the reduce returns them
  * (reduce identity (0,0,0,0,0), per-element identity (inf, 0)). */

@@ -111,3 +111,71 @@ def test_pvr_psf_kernels_parity(tiny, oracle_mod, use_spx):
     assert np.array_equal(cm > 0, orc.cmap > 0)
     assert rel_err(cm, orc.cmap) < 2e-5
     assert rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < 2e-5
+
+
+# ---- patch extraction + the PVR loop (host side: fetalreconstruction_amd/pvr.py) ----------------
+def _small_pvr():
+    from fetalreconstruction_amd import pvr
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(2, (24, 24, 5), 1.1, 2.2, None, 1.0, 11.0, seed=4,
+                                                            orientations=("ax", "sag"))
+    return pvr, stacks, pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (16, 16), (8, 8))
+
+
+def test_generate_2d_patches_rules():
+    from fetalreconstruction_amd import pvr
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(1, (24, 24, 3), 1.1, 2.2, None, 1.0, 11.0, seed=4,
+                                                            orientations=("ax",))
+    st = stacks[0]
+    p, i2w, w2i, total = pvr.generate2DPatches(st, mask, mattr, (16, 16), (8, 8))
+    cand = len(range(0, 24 + 16, 8)) ** 2 * 3                          # patchBasedObject.cuh:210-212
+    assert 0 < len(p) < cand
+    assert (p >= 0).all() and (p == 0).any()                            # patches start as zero images, never -1
+    assert all(((q != 0) & (q != -1)).sum() > 16 * 16 / 3 for q in p)   # the keep rule :318
+    assert total == sum(int((q != 0).sum()) for q in p)
+    # patch pixel (i, j) sits on stack pixel (x + i, y + j): same world position, same value
+    s_w2i = geo.world_to_image(st.attr)
+    for k in (0, len(p) // 2, len(p) - 1):
+        m = i2w[k].reshape(4, 4).astype(np.float64)
+        for (i, j) in ((0, 0), (5, 9), (15, 15)):
+            q = s_w2i @ (m @ np.array([i, j, 0, 1.0]))
+            xi, yi, zi = [int(round(v)) for v in q[:3]]
+            assert np.allclose(q[:3], (xi, yi, zi), atol=1e-4)
+            if 0 <= xi < 24 and 0 <= yi < 24 and p[k][j, i] != 0:
+                assert p[k][j, i] == st.data[zi, yi, xi]
+        assert np.allclose(w2i[k].reshape(4, 4) @ i2w[k].reshape(4, 4), np.eye(4), atol=1e-4)
+
+
+def test_pvr_loop_on_the_oracle(oracle_mod):
+    pvr, stacks, P = _small_pvr()
+    assert (P.slice_dim == np.array([1.1, 1.1, 2.2], np.float32)).all()        # getDim(): z = stack spacing
+    o = oracle_mod.OracleReconstruction(P, oracle_mod.CANON, pvr=True)
+    d = pvr.irtkPatchBasedReconstruction(o, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    assert float(d.m_alpha) == pytest.approx(0.5) and float(d.m_delta) == 1.0 and float(d.m_lambda) == pytest.approx(0.1)
+    d.reconstruct_iteration(1)
+    assert np.isfinite(o.recon).all() and o.recon[P.mask.reshape(-1) > 0].mean() > 100
+    assert (o.weights[P.slices == 0] == 0).all()                                # InitializeEMValues: s == 0 -> 0
+    assert 0 < d.m_mix_gpu <= 1 and d.m_sigma_gpu > 0 and d.m_m_gpu > 0
+    # the potentials of stack 1 overwrite the head of the table, its tail keeps the initial 0 (:256-276)
+    n0, n1 = P.patches_per_stack
+    assert (d.patch_potential[max(n0, n1):] == 0).all()
+    assert ((d.scale > 0.2) & (d.scale < 5)).all()
+
+
+@pytest.mark.gpu
+def test_pvr_loop_parity(oracle_mod):
+    from fetalreconstruction_amd import engine as E
+    pvr, stacks, P = _small_pvr()
+    rec = E.Reconstruction(0)
+    rec.set_option("pvr", 1)
+    E.sync_gpu(rec, P, quality_factor=1.0)                                       # m_quality_factor = 1 (PBR.cpp:415)
+    orc = oracle_mod.OracleReconstruction(P, oracle_mod.CANON, pvr=True)
+    dg = pvr.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    do = pvr.irtkPatchBasedReconstruction(orc, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    for d in (dg, do):
+        d.reconstruct_iteration(2)
+    assert np.allclose([dg.m_sigma_gpu, dg.m_mix_gpu, dg.m_m_gpu], [do.m_sigma_gpu, do.m_mix_gpu, do.m_m_gpu], rtol=1e-4)
+    assert np.allclose(dg.scale, do.scale, rtol=1e-4)
+    assert np.allclose(dg.patch_weight, do.patch_weight, atol=1e-3)
+    assert np.allclose(dg.patch_potential, do.patch_potential, atol=1e-4)
+    assert rel_err(rec.debug_get(E.BUF_WEIGHTS), orc.weights, floor=1.0) < 1e-4
+    assert rel_err(rec.syncCPU(), orc.recon) < 1e-4
