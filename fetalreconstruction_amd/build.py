@@ -11,6 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "svr_hip.hip")
+SRC_REG = os.path.join(HERE, "csrc", "svr_reg.inc")       # GPU registration, #included by svr_hip.hip
 SRC_HOST = os.path.join(HERE, "csrc", "svr_host.cpp")     # plain host C++ (the irtkReconstruction mirror)
 INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
 INC_HOST = os.path.join(os.path.dirname(HERE), "include", "svr_host.h")
@@ -37,21 +38,28 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_HOST, INC, INC_HOST, __file__))
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, INC, INC_HOST, __file__))
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra=(), variant=None):
+    """variant: tuning builds `lib/libsvr_hip_<variant>.so` with extra -D flags (tools/exp_*.py pick one
+    through the SVR_HIP_LIB environment variable); the product is always the un-suffixed library."""
+    out = OUT if not variant else os.path.join(OUT_DIR, f"libsvr_hip_{variant}.so")
+    if not variant and not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra, "-o", OUT, SRC, SRC_HOST]
+    cmd = [hipcc(), *FLAGS, *extra, "-o", out, SRC, SRC_HOST]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True,
-          extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
-    print(OUT)
+    variant = None
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else []
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        variant = sys.argv[i + 1]
+        extra += [a for a in sys.argv[i + 2:] if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, verbose=True, extra=extra, variant=variant))

@@ -226,116 +226,147 @@ __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
 // N = PSF support (16 for SVR, 12 for PVR), CENTRE = (N-1)/2; PVR selects the patch-to-volume
 // constants (sinc_pi Taylor branch, strict float epsilon; R2/include/pointSpreadFunction.cuh:45-70,
 // R2/include/reconConfig.cuh:138).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 bc2(float c) { return (f2)(c); }
+
 template <int N, bool PVR>
 __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by, float bz, float fy,
                                            float fz, float out[N]) {
+  // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage below compiles
+  // to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one issue slot for two taps -- the packed rate is
+  // what the 157 TFLOP/s f32 peak of gfx950 is quoted on); sqrt, rcp, rint, ldexp and the selects
+  // stay per component.  Per component the operation sequence is exactly psf_eval's.
   constexpr int EVAL_CHUNK = N / 2;
+  constexpr int H = EVAL_CHUNK / 2;
   constexpr int CENTRE = (N - 1) / 2;
+  static_assert(EVAL_CHUNK % 2 == 0, "taps are processed in pairs");
   const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
   const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
   const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
   float val[N];
 #pragma unroll
   for (int c0 = 0; c0 < N; c0 += EVAL_CHUNK) {
-    float R[EVAL_CHUNK], a[EVAL_CHUNK], r[EVAL_CHUNK], s[EVAL_CHUNK], u[EVAL_CHUNK], k[EVAL_CHUNK];
-#define EACH for (int i = 0; i < EVAL_CHUNK; ++i)
+    f2 R[H], a[H], r[H], s[H], u[H], k[H];
+#define EACH for (int i = 0; i < H; ++i)
+#define PERC(dst, expr_x, expr_y) dst = (f2){(expr_x), (expr_y)}
 #pragma unroll
     EACH {
-      const float fx = (float)(c0 + i - CENTRE);
-      const float xs = __builtin_fmaf(S.Lp[0], fx, rowx);
-      const float ys = __builtin_fmaf(S.Lp[3], fx, rowy);
-      const float zs = __builtin_fmaf(S.Lp[6], fx, rowz);
-      R[i] = __builtin_fmaf(ys, ys, xs * xs);        // q
-      a[i] = (zs * zs) * S.inv2s2;
+      const f2 fx = (f2){(float)(c0 + 2 * i - CENTRE), (float)(c0 + 2 * i + 1 - CENTRE)};
+      const f2 xs = fma2(bc2(S.Lp[0]), fx, bc2(rowx));
+      const f2 ys = fma2(bc2(S.Lp[3]), fx, bc2(rowy));
+      const f2 zs = fma2(bc2(S.Lp[6]), fx, bc2(rowz));
+      R[i] = fma2(ys, ys, xs * xs);        // q
+      a[i] = (zs * zs) * bc2(S.inv2s2);
     }
     // correctly rounded sqrt: the core of LLVM's IEEE expansion (v_sqrt_f32, then pick among the two
     // neighbours with exact fma residuals) without its denormal-input scaling and inf handling,
     // which q = x'^2 + y'^2 in [0, ~1e3] never needs; sqrt(0) = 0 falls out of the residual tests.
     // Bit-identical to sqrtf (tests/test_parity_gpu.py::test_psf_taps_are_bit_identical, tools/ulp_check.hip).
 #pragma unroll
-    EACH s[i] = __builtin_amdgcn_sqrtf(R[i]);
+    EACH PERC(s[i], __builtin_amdgcn_sqrtf(R[i].x), __builtin_amdgcn_sqrtf(R[i].y));
 #pragma unroll
     EACH {
-      const float sd = __int_as_float(__float_as_int(s[i]) - 1), su = __int_as_float(__float_as_int(s[i]) + 1);
-      const float rd = __builtin_fmaf(-sd, s[i], R[i]), ru = __builtin_fmaf(-su, s[i], R[i]);
-      float t = (0.0f >= rd) ? sd : s[i];
-      t = (0.0f < ru) ? su : t;
-      R[i] = 3.14159265359f * t;
+      const f2 sd = (f2){__int_as_float(__float_as_int(s[i].x) - 1), __int_as_float(__float_as_int(s[i].y) - 1)};
+      const f2 su = (f2){__int_as_float(__float_as_int(s[i].x) + 1), __int_as_float(__float_as_int(s[i].y) + 1)};
+      const f2 rd = fma2(-sd, s[i], R[i]), ru = fma2(-su, s[i], R[i]);
+      f2 t;
+      t.x = (0.0f >= rd.x) ? sd.x : s[i].x;
+      t.y = (0.0f >= rd.y) ? sd.y : s[i].y;
+      t.x = (0.0f < ru.x) ? su.x : t.x;
+      t.y = (0.0f < ru.y) ? su.y : t.y;
+      R[i] = bc2(3.14159265359f) * t;
     }
-    // |sin R|: canon_abs_sin
+    // sin R by canon_abs_sin without the final fabs: the value is only used squared below and every
+    // operation in between is sign-symmetric, so the squares are bit-identical
 #pragma unroll
-    EACH k[i] = __builtin_rintf(R[i] * 0.318309886183790671538f);
+    EACH {
+      const f2 t = R[i] * bc2(0.318309886183790671538f);
+      PERC(k[i], __builtin_rintf(t.x), __builtin_rintf(t.y));
+    }
 #pragma unroll
-    EACH r[i] = __builtin_fmaf(k[i], -3.1414794921875f, R[i]);
+    EACH r[i] = fma2(k[i], bc2(-3.1414794921875f), R[i]);
 #pragma unroll
-    EACH r[i] = __builtin_fmaf(k[i], -0.00011315941810607910156f, r[i]);
+    EACH r[i] = fma2(k[i], bc2(-0.00011315941810607910156f), r[i]);
 #pragma unroll
-    EACH r[i] = __builtin_fmaf(k[i], -1.9841872589410058936e-09f, r[i]);
+    EACH r[i] = fma2(k[i], bc2(-1.9841872589410058936e-09f), r[i]);
 #pragma unroll
     EACH s[i] = r[i] * r[i];
 #pragma unroll
-    EACH u[i] = __builtin_fmaf(2.6083159809786593541503e-06f, s[i], -0.0001981069071916863322258f);
+    EACH u[i] = fma2(bc2(2.6083159809786593541503e-06f), s[i], bc2(-0.0001981069071916863322258f));
 #pragma unroll
-    EACH u[i] = __builtin_fmaf(u[i], s[i], 0.00833307858556509017944336f);
+    EACH u[i] = fma2(u[i], s[i], bc2(0.00833307858556509017944336f));
 #pragma unroll
-    EACH u[i] = __builtin_fmaf(u[i], s[i], -0.166666597127914428710938f);
+    EACH u[i] = fma2(u[i], s[i], bc2(-0.166666597127914428710938f));
 #pragma unroll
-    EACH u[i] = __builtin_fabsf(__builtin_fmaf(s[i], u[i] * r[i], r[i]));
-    // si = |sin R| / R (NaN at R == 0, RC.cu:129): correctly rounded division = LLVM's IEEE expansion
+    EACH u[i] = fma2(s[i], u[i] * r[i], r[i]);
+    // si = sin R / R (NaN at R == 0, RC.cu:129): correctly rounded division = LLVM's IEEE expansion
     // (rcp, one Newton step on the reciprocal, two residual corrections of the quotient) without the
     // v_div_scale / v_div_fmas / v_div_fixup range handling, which operands in [1e-10,1] / (0,1e2] never
     // trigger; 0/0 still yields NaN (rcp(0) = inf, 0 * inf).  Bit-identical to '/' on these ranges.
 #pragma unroll
-    EACH k[i] = __builtin_amdgcn_rcpf(R[i]);
+    EACH PERC(k[i], __builtin_amdgcn_rcpf(R[i].x), __builtin_amdgcn_rcpf(R[i].y));
 #pragma unroll
-    EACH k[i] = __builtin_fmaf(__builtin_fmaf(-R[i], k[i], 1.0f), k[i], k[i]);
+    EACH k[i] = fma2(fma2(-R[i], k[i], bc2(1.0f)), k[i], k[i]);
 #pragma unroll
     EACH s[i] = u[i] * k[i];
 #pragma unroll
-    EACH s[i] = __builtin_fmaf(__builtin_fmaf(-R[i], s[i], u[i]), k[i], s[i]);
+    EACH s[i] = fma2(fma2(-R[i], s[i], u[i]), k[i], s[i]);
 #pragma unroll
-    EACH u[i] = __builtin_fmaf(__builtin_fmaf(-R[i], s[i], u[i]), k[i], s[i]);
+    EACH u[i] = fma2(fma2(-R[i], s[i], u[i]), k[i], s[i]);
     if (PVR) {
-      // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70)
+      // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70);
+      // above it sin(x)/x with x > 0, i.e. |sin x| / x up to the sign that the square removes
 #pragma unroll
       EACH {
-        const float x = R[i], x2 = x * x;
-        float t = 1.0f;
-        if (x >= 1.1920929e-07f) {
-          t -= x2 / 6.0f;
-          if (x >= 3.4526698300e-04f) t += (x2 * x2) / 120.0f;
+        for (int c = 0; c < 2; ++c) {
+          const float x = c ? R[i].y : R[i].x, x2 = x * x;
+          float t = 1.0f;
+          if (x >= 1.1920929e-07f) {
+            t -= x2 / 6.0f;
+            if (x >= 3.4526698300e-04f) t += (x2 * x2) / 120.0f;
+          }
+          if (c) u[i].y = (x >= 1.8581361323e-02f) ? u[i].y : t;
+          else u[i].x = (x >= 1.8581361323e-02f) ? u[i].x : t;
         }
-        u[i] = (x >= 1.8581361323e-02f) ? u[i] : t;
       }
     }
 #pragma unroll
     EACH u[i] = u[i] * u[i];
     // exp(-a): canon_exp_neg
 #pragma unroll
-    EACH k[i] = __builtin_rintf(-a[i] * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    EACH {
+      const f2 t = -a[i] * bc2(1.442695040888963407359924681001892137426645954152985934135449406931f);
+      PERC(k[i], __builtin_rintf(t.x), __builtin_rintf(t.y));
+    }
 #pragma unroll
-    EACH r[i] = __builtin_fmaf(k[i], -0.693145751953125f, -a[i]);
+    EACH r[i] = fma2(k[i], bc2(-0.693145751953125f), -a[i]);
 #pragma unroll
-    EACH r[i] = __builtin_fmaf(k[i], -1.428606765330187045e-06f, r[i]);
+    EACH r[i] = fma2(k[i], bc2(-1.428606765330187045e-06f), r[i]);
 #pragma unroll
-    EACH s[i] = __builtin_fmaf(0.000198527617612853646278381f, r[i], 0.00139304355252534151077271f);
+    EACH s[i] = fma2(bc2(0.000198527617612853646278381f), r[i], bc2(0.00139304355252534151077271f));
 #pragma unroll
-    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.00833336077630519866943359f);
+    EACH s[i] = fma2(s[i], r[i], bc2(0.00833336077630519866943359f));
 #pragma unroll
-    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.0416664853692054748535156f);
+    EACH s[i] = fma2(s[i], r[i], bc2(0.0416664853692054748535156f));
 #pragma unroll
-    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.166666671633720397949219f);
+    EACH s[i] = fma2(s[i], r[i], bc2(0.166666671633720397949219f));
 #pragma unroll
-    EACH s[i] = __builtin_fmaf(s[i], r[i], 0.5f);
+    EACH s[i] = fma2(s[i], r[i], bc2(0.5f));
 #pragma unroll
-    EACH s[i] = __builtin_fmaf(r[i] * r[i], s[i], r[i]) + 1.0f;
+    EACH s[i] = fma2(r[i] * r[i], s[i], r[i]) + bc2(1.0f);
 #pragma unroll
-    EACH s[i] = ldexpf(s[i], (int)k[i]);
+    EACH PERC(s[i], ldexpf(s[i].x, (int)k[i].x), ldexpf(s[i].y, (int)k[i].y));
 #pragma unroll
-    EACH s[i] = (a[i] > 87.0f) ? 0.0f : s[i];
+    EACH PERC(s[i], (a[i].x > 87.0f) ? 0.0f : s[i].x, (a[i].y > 87.0f) ? 0.0f : s[i].y);
 #pragma unroll
-    EACH val[c0 + i] = u[i] * s[i];                   // (si * si) * gz
+    EACH {
+      const f2 v = u[i] * s[i];                       // (si * si) * gz
+      val[c0 + 2 * i] = v.x;
+      val[c0 + 2 * i + 1] = v.y;
+    }
 #undef EACH
+#undef PERC
   }
   float old = FLT_MAX;
 #pragma unroll
@@ -948,6 +979,8 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void fwd_tile_kernel(PsfArgs a, Til
       }
       float out[16];
       eval_row_at(RC, R.bx, R.by, R.bz, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE), out);
+      // the per-tap branch pays: most taps are epsilon-skipped and the whole wave jumps over the body
+      // (a branch-free version measured 6.7 vs 5.9 ms on P4)
       if (rowok) {
 #pragma unroll
         for (int x = 0; x < 16; ++x) {

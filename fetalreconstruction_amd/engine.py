@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsvr_hip.so")
+# SVR_HIP_LIB: tuning builds made by `build.py --variant` (tools/exp_*.py); the product is lib/libsvr_hip.so
+LIB_PATH = os.environ.get("SVR_HIP_LIB") or os.path.join(_HERE, "lib", "libsvr_hip.so")
 
 # enum svr_buffer / svr_timer (include/svr_hip.h)
 BUF_RECONSTRUCTED, BUF_VOL_WEIGHTS, BUF_ADDON, BUF_CONFIDENCE_MAP, BUF_MASK = 0, 1, 2, 3, 4
