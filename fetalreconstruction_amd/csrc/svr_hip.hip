@@ -230,34 +230,19 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 bc2(float c) { return (f2)(c); }
 
-template <int N, bool PVR>
-__device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by, float bz, float fy,
-                                           float fz, float out[N]) {
-  // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage below compiles
-  // to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one issue slot for two taps -- the packed rate is
-  // what the 157 TFLOP/s f32 peak of gfx950 is quoted on); sqrt, rcp, rint, ldexp and the selects
-  // stay per component.  Per component the operation sequence is exactly psf_eval's.
-  constexpr int EVAL_CHUNK = N / 2;
-  constexpr int H = EVAL_CHUNK / 2;
-  constexpr int CENTRE = (N - 1) / 2;
-  static_assert(EVAL_CHUNK % 2 == 0, "taps are processed in pairs");
-  const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
-  const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
-  const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
-  float val[N];
-#pragma unroll
-  for (int c0 = 0; c0 < N; c0 += EVAL_CHUNK) {
-    f2 R[H], a[H], r[H], s[H], u[H], k[H];
+// H pairs of consecutive x-taps of one (y,z) row, first tap at lattice offset fx0: val2[i] = psf of taps
+// (fx0 + 2i, fx0 + 2i + 1).  rowx/rowy/rowz = the row's part of the scaled lattice coordinates.
+// psf of 2H taps given their scaled lattice coordinates (x', y', z') two per lane-op
+template <int H, bool PVR>
+__device__ __forceinline__ void eval_pairs_xyz(const RowConst &S, const f2 xs[H], const f2 ys[H], const f2 zs[H],
+                                               f2 val2[H]) {
 #define EACH for (int i = 0; i < H; ++i)
 #define PERC(dst, expr_x, expr_y) dst = (f2){(expr_x), (expr_y)}
+    f2 R[H], a[H], r[H], s[H], u[H], k[H];
 #pragma unroll
     EACH {
-      const f2 fx = (f2){(float)(c0 + 2 * i - CENTRE), (float)(c0 + 2 * i + 1 - CENTRE)};
-      const f2 xs = fma2(bc2(S.Lp[0]), fx, bc2(rowx));
-      const f2 ys = fma2(bc2(S.Lp[3]), fx, bc2(rowy));
-      const f2 zs = fma2(bc2(S.Lp[6]), fx, bc2(rowz));
-      R[i] = fma2(ys, ys, xs * xs);        // q
-      a[i] = (zs * zs) * bc2(S.inv2s2);
+      R[i] = fma2(ys[i], ys[i], xs[i] * xs[i]);        // q
+      a[i] = (zs[i] * zs[i]) * bc2(S.inv2s2);
     }
     // correctly rounded sqrt: the core of LLVM's IEEE expansion (v_sqrt_f32, then pick among the two
     // neighbours with exact fma residuals) without its denormal-input scaling and inf handling,
@@ -360,13 +345,46 @@ __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by
 #pragma unroll
     EACH PERC(s[i], (a[i].x > 87.0f) ? 0.0f : s[i].x, (a[i].y > 87.0f) ? 0.0f : s[i].y);
 #pragma unroll
-    EACH {
-      const f2 v = u[i] * s[i];                       // (si * si) * gz
-      val[c0 + 2 * i] = v.x;
-      val[c0 + 2 * i + 1] = v.y;
-    }
+    EACH val2[i] = u[i] * s[i];                       // (si * si) * gz
 #undef EACH
 #undef PERC
+}
+
+template <int H, bool PVR>
+__device__ __forceinline__ void eval_pairs(const RowConst &S, float rowx, float rowy, float rowz, float fx0,
+                                           f2 val2[H]) {
+  f2 xs[H], ys[H], zs[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const f2 fx = (f2){fx0 + (float)(2 * i), fx0 + (float)(2 * i + 1)};
+    xs[i] = fma2(bc2(S.Lp[0]), fx, bc2(rowx));
+    ys[i] = fma2(bc2(S.Lp[3]), fx, bc2(rowy));
+    zs[i] = fma2(bc2(S.Lp[6]), fx, bc2(rowz));
+  }
+  eval_pairs_xyz<H, PVR>(S, xs, ys, zs, val2);
+}
+
+template <int N, bool PVR>
+__device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by, float bz, float fy,
+                                           float fz, float out[N]) {
+  // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage of eval_pairs
+  // compiles to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (half the issue slots for the same cycles);
+  // sqrt, rcp, rint, ldexp and the selects stay per component.  Per component the operation sequence
+  // is exactly psf_eval's.
+  constexpr int EVAL_CHUNK = N / 2;
+  constexpr int H = EVAL_CHUNK / 2;
+  constexpr int CENTRE = (N - 1) / 2;
+  static_assert(EVAL_CHUNK % 2 == 0, "taps are processed in pairs");
+  const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
+  const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
+  const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
+  float val[N];
+#pragma unroll
+  for (int c0 = 0; c0 < N; c0 += EVAL_CHUNK) {
+    f2 v2[H];
+    eval_pairs<H, PVR>(S, rowx, rowy, rowz, (float)(c0 - CENTRE), v2);
+#pragma unroll
+    for (int i = 0; i < H; ++i) { val[c0 + 2 * i] = v2[i].x; val[c0 + 2 * i + 1] = v2[i].y; }
   }
   float old = FLT_MAX;
 #pragma unroll
@@ -378,6 +396,40 @@ __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by
     old = skip ? old : v;
   }
 }
+// Can every tap of the (fy, fz) row be proven to lie below the epsilon of the skip test?  Then the
+// reference processes only the row's first tap (oldPSF starts at FLT_MAX) and skips the other 15:
+// |v0 - v| <= max(v0, v) < 1e-5.  Upper bound of the canonical value over the row:
+//   exp(-a_min) * min(1, 1 / (pi^2 q_min)),
+// a_min from the end taps (z' is monotone in x, and so is its rounded fma), q_min from the vertex of the
+// quadratic x'^2 + y'^2 shrunk by 1 % (covers the roundings of x', y', q), both with the polynomial errors
+// of the canonical sin / exp (< 1e-6) far inside the 2 % margin of the threshold.  A row that may contain
+// the R = 0 tap (NaN, RC.cu:129) is never declared dead.
+__host__ __device__ __forceinline__ bool row_is_dead(const RowConst &S, float bx, float by, float bz, float fy, float fz) {
+  const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
+  const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
+  const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
+  const float z0 = __builtin_fmaf(S.Lp[6], (float)(-PSF_CENTRE), rowz);
+  const float z1 = __builtin_fmaf(S.Lp[6], (float)(PSF_SUPPORT - 1 - PSF_CENTRE), rowz);
+  const float zmin = (z0 > 0.0f) == (z1 > 0.0f) && z0 != 0.0f && z1 != 0.0f ? fminf(fabsf(z0), fabsf(z1)) : 0.0f;
+  const float amin = (zmin * zmin) * S.inv2s2;
+  const float qa = S.Lp[0] * S.Lp[0] + S.Lp[3] * S.Lp[3];
+  const float qb = 2.0f * (S.Lp[0] * rowx + S.Lp[3] * rowy);
+  const float qc = rowx * rowx + rowy * rowy;
+  float fx = qa > 1e-12f ? -qb / (2.0f * qa) : 0.0f;
+  fx = fminf(fmaxf(fx, (float)(-PSF_CENTRE)), (float)(PSF_SUPPORT - 1 - PSF_CENTRE));
+  const float qe0 = (qa * (float)(PSF_CENTRE * PSF_CENTRE) - qb * (float)PSF_CENTRE) + qc;
+  const float e1 = (float)(PSF_SUPPORT - 1 - PSF_CENTRE);
+  const float qe1 = (qa * (e1 * e1) + qb * e1) + qc;
+  const float qv = (qa * (fx * fx) + qb * fx) + qc;
+  const float qmin = fmaxf(fminf(qv, fminf(qe0, qe1)), 0.0f) * 0.99f - 1e-5f;
+  if (!(qmin > 1e-6f)) return false;   // may contain the R = 0 tap: keep the row live
+  // ln(1e5 / 0.98) = 11.533
+#ifndef SVR_DEAD_THR
+#define SVR_DEAD_THR 11.56f
+#endif
+  return amin + logf(fmaxf(1.0f, 9.8696044f * qmin)) > SVR_DEAD_THR;
+}
+
 __device__ __forceinline__ void eval_row_at(const RowConst &S, float bx, float by, float bz, float fy,
                                             float fz, float out[16]) {
   eval_row_t<16, false>(S, bx, by, bz, fy, fz, out);
@@ -546,12 +598,13 @@ __device__ __forceinline__ bool pixel_active(const float *slices, const float *p
 
 __global__ void k_build_tiles(const float *slices, const float *psf_sums, const unsigned char *flag, int sx, int sy,
                               int ns, int tiles_x, int tiles_y, int TILE_W, int TILE_H, uint32_t *tiles,
-                              uint32_t *counter) {
+                              uint32_t *counter, const unsigned char *slice_sel = nullptr, int want = 0) {
   const int lane = threadIdx.x & 63;
   const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t total = (uint32_t)tiles_x * tiles_y * ns;
   if (t >= total) return;
   const int sl = t / (tiles_x * tiles_y);
+  if (slice_sel && slice_sel[sl] != want) return;
   const int r = t - sl * tiles_x * tiles_y;
   const int ty = r / tiles_x, tx = r - ty * tiles_x;
   const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
@@ -876,10 +929,17 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
 // sume over processed in-bounds taps (no mask), the `sume > 0.5` gate, v_PSF_sums, and the
 // sliceVoxel_count flag (any processed tap on an in-mask voxel, RC.cu:283-294); the box then only
 // encodes {out of bounds, masked, in mask}.
-template <bool GAUSS1>
-__global__ __launch_bounds__(FWD_WAVES * 64) void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
+// ROWS = true: per pixel the 256 (y,z) rows are first classified (row_is_dead); rows outside the volume
+// are dropped, dead rows get only their first tap evaluated, live rows all 16.  A wavefront then works
+// on FOUR pixels at once, 16 lanes each, every lane group walking its pixel's compacted row lists --
+// so the work per pixel is (live rows) x 16 + (dead rows) x 2 taps instead of 256 x 16.
+// register budget: 8 waves per SIMD for the plain gather (64 VGPRs, what it needs anyway), 6 for the
+// row-list variant, whose per-lane pixel state does not fit 64 (measured: 8 -> 9.7 ms, 6 -> 5.4, 5 -> 5.5, 4 -> 6.0)
+template <bool GAUSS1, bool ROWS>
+__global__ __launch_bounds__(FWD_WAVES * 64) __attribute__((amdgpu_waves_per_eu(ROWS ? 6 : 8, ROWS ? 6 : 8)))
+void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
   constexpr bool GAUSS1_ACT = GAUSS1;
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // masked volume box [cap]
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // masked volume box [cap] (+ row lists)
   __shared__ int sh_lo[3], sh_hi[3];
   __shared__ PixelRec sh_px[64];
   __shared__ uint32_t sh_idx[64];
@@ -950,6 +1010,155 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void fwd_tile_kernel(PsfArgs a, Til
   __syncthreads();
 
   const RowConst RC = load_row_const(S);
+  if (ROWS) {
+    unsigned char *rowlist = reinterpret_cast<unsigned char *>(tile + ta.cap);   // [tw*th][256]: live from the front, dead from the back
+    const int g = lane >> 4, i = lane & 15;
+    for (int base = 4 * wave; base < npix; base += 4 * FWD_WAVES) {
+      const int k = base + g;
+      const bool pix = k < npix;
+      const PixelRec R = sh_px[pix ? k : base];
+      unsigned char *mine = rowlist + 256 * (pix ? k : base);
+      int nl = 0, nd = 0;
+      for (int z = 0; z < 16; ++z) {                      // lane i classifies row (y = i, z)
+        const int ay = R.cy + i - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
+        const bool inb = pix && ay < vg.vy && az < vg.vz;  // negatives alias to 0: always "in bounds"
+        const bool dead = inb && row_is_dead(RC, R.bx, R.by, R.bz, (float)(i - PSF_CENTRE), (float)(z - PSF_CENTRE));
+        const bool live = inb && !dead;
+        const uint32_t ml = (uint32_t)(__ballot(live) >> (16 * g)) & 0xFFFFu;
+        const uint32_t md = (uint32_t)(__ballot(dead) >> (16 * g)) & 0xFFFFu;
+        const uint32_t below = (1u << i) - 1u;
+        if (live) mine[nl + __popc(ml & below)] = (unsigned char)(16 * z + i);
+        if (dead) mine[255 - (nd + __popc(md & below))] = (unsigned char)(16 * z + i);
+        nl += __popc(ml);
+        nd += __popc(md);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int nlmax = max(max(__shfl(nl, 0), __shfl(nl, 16)), max(__shfl(nl, 32), __shfl(nl, 48)));
+      const int ndmax = max(max(__shfl(nd, 0), __shfl(nd, 16)), max(__shfl(nd, 32), __shfl(nd, 48)));
+      float f0 = 0.0f, f1 = 0.0f;
+      double acc = 0.0;
+      bool hit = false;
+      const int cb = R.cx - PSF_CENTRE - lox;
+      for (int r0 = 0; r0 < nlmax; r0 += 16) {            // live rows: all 16 taps
+        const bool valid = r0 + i < nl;
+        const int row = valid ? mine[r0 + i] : 0;
+        const int y = row & 15, z = row >> 4;
+        const int ay = R.cy + y - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
+        uint32_t vb[16];
+        if (in_lds) {
+          const int rb = valid ? (ay - loy) * Px + (az - loz) * Pxy + cb : 0;
+#pragma unroll
+          for (int x = 0; x < 16; ++x) vb[x] = reinterpret_cast<const uint32_t *>(tile)[rb + x];
+        } else {
+#pragma unroll
+          for (int x = 0; x < 16; ++x) {
+            const int gx = R.cx + x - PSF_CENTRE;
+            uint32_t bits = FWD_SENTINEL;
+            if (valid && gx < vg.vx) {
+              const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
+              if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
+              else if (a.mask[vi] != 0.0f) bits = __float_as_uint(a.vol[vi]);
+            }
+            vb[x] = bits;
+          }
+        }
+        float out[16];
+        eval_row_at(RC, R.bx, R.by, R.bz, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE), out);
+        if (valid) {
+#pragma unroll
+          for (int x = 0; x < 16; ++x) {
+            if (GAUSS1) {
+              if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
+                acc += (double)out[x];
+                hit = hit || vb[x] == 1u;
+              }
+            } else if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
+              const float p = out[x] * R.f1;
+              f0 += p * __uint_as_float(vb[x]);
+              f1 += p;
+              hit = true;
+            }
+          }
+        }
+      }
+      for (int r0 = 0; r0 < ndmax; r0 += 128) {           // dead rows: only the first tap is processed, 8 rows per lane
+        f2 xs[4], ys[4], zs[4], t0[4];
+        uint32_t v0[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int p = r0 + 16 * j + i;
+          const bool valid = p < nd;
+          const int row = valid ? mine[255 - p] : 0;
+          const int y = row & 15, z = row >> 4;
+          const int ay = R.cy + y - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
+          uint32_t v = FWD_SENTINEL;
+          if (valid) {
+            if (in_lds) {
+              v = reinterpret_cast<const uint32_t *>(tile)[(ay - loy) * Px + (az - loz) * Pxy + cb];
+            } else if (R.cx - PSF_CENTRE < vg.vx) {
+              const uint32_t vi = sat0(R.cx - PSF_CENTRE) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
+              if (GAUSS1) v = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
+              else if (a.mask[vi] != 0.0f) v = __float_as_uint(a.vol[vi]);
+            }
+          }
+          v0[j] = v;
+          const float fy = (float)(y - PSF_CENTRE), fz = (float)(z - PSF_CENTRE);
+          const float rowx = __builtin_fmaf(RC.Lp[1], fy, __builtin_fmaf(RC.Lp[2], fz, R.bx));
+          const float rowy = __builtin_fmaf(RC.Lp[4], fy, __builtin_fmaf(RC.Lp[5], fz, R.by));
+          const float rowz = __builtin_fmaf(RC.Lp[7], fy, __builtin_fmaf(RC.Lp[8], fz, R.bz));
+          const float x1 = __builtin_fmaf(RC.Lp[0], (float)(-PSF_CENTRE), rowx);
+          const float y1 = __builtin_fmaf(RC.Lp[3], (float)(-PSF_CENTRE), rowy);
+          const float z1 = __builtin_fmaf(RC.Lp[6], (float)(-PSF_CENTRE), rowz);
+          if (j & 1) { xs[j >> 1].y = x1; ys[j >> 1].y = y1; zs[j >> 1].y = z1; }
+          else { xs[j >> 1].x = x1; ys[j >> 1].x = y1; zs[j >> 1].x = z1; }
+        }
+        eval_pairs_xyz<4, false>(RC, xs, ys, zs, t0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float o0 = (j & 1) ? t0[j >> 1].y : t0[j >> 1].x;   // always processed: |FLT_MAX - v| is not <= eps
+          if (v0[j] != FWD_SENTINEL) {
+            if (GAUSS1) {
+              acc += (double)o0;
+              hit = hit || v0[j] == 1u;
+            } else {
+              const float p = o0 * R.f1;
+              f0 += p * __uint_as_float(v0[j]);
+              f1 += p;
+              hit = true;
+            }
+          }
+        }
+      }
+      // reduce over the 16 lanes of the pixel's group
+      const bool inside = ((uint32_t)(__ballot(hit) >> (16 * g)) & 0xFFFFu) != 0u;
+      if (GAUSS1) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        const float sume = (float)acc;
+        if (pix && i == 0) {
+          const uint32_t idx = sh_idx[k];
+          const bool pass = sume > 0.5f;
+          a.flag_out[idx] = pass ? 1 : 0;
+          if (pass) {
+            a.psf_sums[idx] = sume;
+            if (inside) a.voxcount[idx] = 1;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { f0 += __shfl_xor(f0, off); f1 += __shfl_xor(f1, off); }
+        if (pix && i == 0 && f1 > 0.0f) {
+          const uint32_t idx = sh_idx[k];
+          a.simslices[idx] = f0 / f1;
+          a.simweights[idx] = f1;
+          a.siminside[idx] = inside ? 1 : 0;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   for (int k = wave; k < npix; k += FWD_WAVES) {
     const PixelRec R = sh_px[k];
     float f0 = 0.0f, f1 = 0.0f;
@@ -1831,8 +2040,12 @@ struct svr_ctx {
   int gauss_mode = 1;                      // 1 = tiled pass 1 + plane-owned scatter, 0 = psf_kernel<MODE_GAUSS>
   uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_tile_kernel
   uint32_t n_tiles_fwd = 0;
+  uint32_t n_tiles_fwd_plain = 0;    // fwd_mode 3: d_tiles_fwd = [plain-gather tiles | row-list tiles]
+  std::vector<unsigned char> h_rows_sel;   // per slice: 1 = enough provably dead rows for the row-list gather
+  unsigned char *d_rows_sel = nullptr;
   int fwd_tw = 8, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
-  int fwd_mode = 1;         // 1 = LDS-tiled gather, 0 = wave-per-pixel kernel with LDS transposition
+  int fwd_mode = 3;         // 3 = per slice: row-list gather where >= 25 % of the rows are epsilon-dead, else the
+                            // plain LDS-tiled gather; 2 / 1 = one of the two for every slice; 0 = wave-per-pixel kernel
   int fwd_cap = 9216;       // box voxels: 36 KiB -> 4 workgroups of 8 waves per CU
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   unsigned char *d_spx = nullptr;
@@ -1937,6 +2150,7 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_slice_inside); free_dev(c->d_sc); free_dev(c->d_active); free_dev(c->d_psf_list);
   free_dev(c->d_tiles);
   free_dev(c->d_tiles_fwd);
+  free_dev(c->d_rows_sel);
   free_dev(c->d_gauss_flag);
   free_dev(c->d_tiles_tmp);
   free_dev(c->d_tiles_fb);
@@ -1970,8 +2184,23 @@ int prepare_slice_consts(svr_ctx *ctx) {
       S.Lp[2 * 3 + j] = ctx->pvr ? (A[2 * 4 + j] * S.dim[2]) / 2.5f : A[2 * 4 + j] * S.dim[2];
     }
   }
+  // which gather suits a slice: share of provably epsilon-dead rows of a pixel that sits on a voxel centre
+  ctx->h_rows_sel.assign(ctx->ns, 0);
+  for (uint32_t s = 0; s < ctx->ns && !ctx->pvr; ++s) {
+    RowConst R;
+    for (int i = 0; i < 9; ++i) R.Lp[i] = h[s].Lp[i];
+    R.inv2s2 = h[s].inv2s2;
+    int dead = 0;
+    for (int z = 0; z < PSF_SUPPORT; ++z)
+      for (int y = 0; y < PSF_SUPPORT; ++y)
+        dead += row_is_dead(R, 0.0f, 0.0f, 0.0f, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE)) ? 1 : 0;
+    ctx->h_rows_sel[s] = dead * 4 >= PSF_SUPPORT * PSF_SUPPORT ? 1 : 0;
+  }
+  if (!ctx->d_rows_sel) HIPCHK(hipMalloc(&ctx->d_rows_sel, ctx->ns));
+  HIPCHK(hipMemcpyAsync(ctx->d_rows_sel, ctx->h_rows_sel.data(), ctx->ns, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_sc, h.data(), h.size() * sizeof(SliceConst), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->psf_list_valid = false;          // the forward tile lists are split by h_rows_sel
   ctx->sc_dirty = false;
   return SVR_OK;
 }
@@ -2004,14 +2233,20 @@ int build_list(svr_ctx *ctx, bool with_psf) {
     ctx->fwd_tiles_y = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
     const uint32_t total_f = (uint32_t)ctx->fwd_tiles_x * ctx->fwd_tiles_y * ctx->ns;
     HIPCHK(hipMalloc(&ctx->d_tiles_fwd, (size_t)total_f * sizeof(uint32_t)));
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total_f, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
-                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->fwd_tiles_x, ctx->fwd_tiles_y, ctx->fwd_tw,
-                       ctx->fwd_th, ctx->d_tiles_fwd, ctx->d_counter);
-    KCHK("k_build_tiles(fwd)");
-    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_tiles_fwd = n;
+    // segment 0: slices for the plain gather, segment 1: slices for the row-list gather
+    uint32_t seg[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) {
+      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total_f, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
+                         (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->fwd_tiles_x,
+                         ctx->fwd_tiles_y, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_fwd + seg[0], ctx->d_counter,
+                         (const unsigned char *)ctx->d_rows_sel, w);
+      KCHK("k_build_tiles(fwd)");
+      HIPCHK(hipMemcpyAsync(&seg[w], ctx->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->n_tiles_fwd_plain = seg[0];
+    ctx->n_tiles_fwd = seg[0] + seg[1];
   } else {
     ctx->n_active = n;
   }
@@ -2152,9 +2387,13 @@ int svr_create(int device, svr_ctx **out) {
     dyn -= 8192;   // static LDS of back_plane_kernel (pixel table + plane lists)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(back_tiled_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
@@ -2461,20 +2700,30 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     const size_t max_tiles = std::max((size_t)ftx * fty, (size_t)ctx->tiles_x * ctx->tiles_y) * ctx->ns;
     if (!ctx->d_tiles_tmp) HIPCHK(hipMalloc(&ctx->d_tiles_tmp, max_tiles * sizeof(uint32_t)));
     uint32_t n1 = 0, n2 = 0, nfb = 0;
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
-                       (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
-                       fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter);
-    KCHK("k_build_tiles(gauss1)");
-    HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     TileArgs ta;
-    ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1; ta.tiles_x = ftx; ta.tiles_y = fty;
+    ta.tiles_x = ftx; ta.tiles_y = fty;
     ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th; ta.gauss = 1;
     a.flag = nullptr; a.flag_out = ctx->d_gauss_flag;
-    if (n1) {
-      hipLaunchKernelGGL(fwd_tile_kernel<true>, dim3(n1), dim3(FWD_WAVES * 64), (size_t)ta.cap * sizeof(float), ctx->stream,
-                         a, ta);
+    // pass 1 per slice group: plain gather walk / row-list walk (fwd_mode 3 splits by h_rows_sel)
+    for (int w = 0; w < 2; ++w) {
+      const bool rows = w == 1;
+      if ((ctx->fwd_mode == 2 && !rows) || (ctx->fwd_mode != 2 && ctx->fwd_mode != 3 && rows)) continue;
+      const unsigned char *sel = ctx->fwd_mode == 3 ? ctx->d_rows_sel : nullptr;
+      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
+                         (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
+                         fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter, sel, w);
+      KCHK("k_build_tiles(gauss1)");
+      HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1;
+      if (!n1) continue;
+      if (rows)
+        hipLaunchKernelGGL((fwd_tile_kernel<true, true>), dim3(n1), dim3(FWD_WAVES * 64),
+                           (size_t)ta.cap * sizeof(float) + (size_t)ta.tw * ta.th * 256, ctx->stream, a, ta);
+      else
+        hipLaunchKernelGGL((fwd_tile_kernel<true, false>), dim3(n1), dim3(FWD_WAVES * 64), (size_t)ta.cap * sizeof(float),
+                           ctx->stream, a, ta);
       KCHK("fwd_tile_kernel<GAUSS1>");
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
@@ -2554,13 +2803,23 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
     hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("pvr_kernel<FWD>");
-  } else if (a.n && ctx->fwd_mode == 1) {
+  } else if (a.n && ctx->fwd_mode >= 1) {
     TileArgs ta;
     ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
     ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
     ta.gauss = 0;
-    hipLaunchKernelGGL(fwd_tile_kernel<false>, dim3(ctx->n_tiles_fwd), dim3(FWD_WAVES * 64),
-                       (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
+    const uint32_t n_plain = ctx->fwd_mode == 1 ? ctx->n_tiles_fwd : ctx->fwd_mode == 2 ? 0u : ctx->n_tiles_fwd_plain;
+    const uint32_t n_rows = ctx->n_tiles_fwd - n_plain;
+    if (n_plain) {
+      ta.ntiles = n_plain;
+      hipLaunchKernelGGL((fwd_tile_kernel<false, false>), dim3(n_plain), dim3(FWD_WAVES * 64),
+                         (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
+    }
+    if (n_rows) {
+      ta.tiles = ctx->d_tiles_fwd + n_plain; ta.ntiles = n_rows;
+      hipLaunchKernelGGL((fwd_tile_kernel<false, true>), dim3(n_rows), dim3(FWD_WAVES * 64),
+                         (size_t)ta.cap * sizeof(float) + (size_t)ta.tw * ta.th * 256, ctx->stream, a, ta);
+    }
     KCHK("fwd_tile_kernel");
   } else if (a.n) {
     hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),

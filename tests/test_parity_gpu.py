@@ -71,11 +71,13 @@ def test_psf_taps_are_bit_identical(tiny, oracle_mod):
         assert np.array_equal(packed, bits)
 
 
-@pytest.mark.parametrize("gauss_mode", [1, 0])
-def test_gaussian_reconstruction_parity(tiny, oracle_mod, gauss_mode):
-    """gauss_mode 1 = tiled pass 1 + plane-owned scatter (default), 0 = wave-per-pixel kernel with atomics."""
+@pytest.mark.parametrize("gauss_mode,fwd_mode", [(1, 3), (1, 2), (1, 1), (0, 1)])
+def test_gaussian_reconstruction_parity(tiny, oracle_mod, gauss_mode, fwd_mode):
+    """gauss_mode 1 = tiled pass 1 (row-skipping with fwd_mode 2) + plane-owned scatter, 0 = wave-per-pixel
+    kernel with atomics."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("gauss_mode", gauss_mode)
+    rec.set_option("fwd_mode", fwd_mode)
     run_to_state(dg, "gauss")
     run_to_state(do, "gauss")
     ps = rec.debug_get(E.BUF_PSF_SUMS)
@@ -101,9 +103,10 @@ def test_against_committed_golden(tiny, oracle_mod):
     assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), gold["siminside0"])
 
 
-@pytest.mark.parametrize("fwd_mode", [1, 0])
+@pytest.mark.parametrize("fwd_mode", [3, 2, 1, 0])
 def test_forward_projection_parity(tiny, oracle_mod, fwd_mode):
-    """fwd_mode 1 = LDS-tiled gather (default), 0 = wave-per-pixel kernel with LDS transposition."""
+    """fwd_mode 2 = LDS-tiled gather over row lists (provably epsilon-dead rows get only their first tap),
+    1 = plain LDS-tiled gather, 3 = per slice whichever suits (default), 0 = wave-per-pixel kernel."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("fwd_mode", fwd_mode)
     run_to_state(dg, "sim")
@@ -202,7 +205,7 @@ def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
     P.slices[:, ::3, ::2] = 140.0
     E, rec, orc, dg, do = _drivers(P, oracle_mod)
     rec.set_option("back_mode", back_mode)
-    rec.set_option("fwd_mode", 1 if back_mode == 2 else 0)
+    rec.set_option("fwd_mode", 2 if back_mode == 2 else 0)
     rec.set_option("gauss_mode", 1 if back_mode == 2 else 0)
     run_to_state(dg, "sim")
     run_to_state(do, "sim")

@@ -4,6 +4,9 @@ import os, sys; sys.path.insert(0, '/root/repo')
 from fetalreconstruction_amd import phantom, engine
 from fetalreconstruction_amd.reconstruction import irtkReconstruction
 P = phantom.problem_p4()
+if os.environ.get('STACK'):
+    import numpy as np
+    P = phantom.sub_problem(P, 0, 0, select=np.where(P.stack_index == int(os.environ['STACK']))[0])
 rec = engine.Reconstruction(0); engine.sync_gpu(rec, P)
 for a in sys.argv[1:]:
     k, v = a.split('='); rec.set_option(k, int(v))
