@@ -42,7 +42,7 @@ EXPORTS = [
     "svr_ncc_evaluate", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
-    "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters",
+    "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches",
 ]
 
 
@@ -355,6 +355,17 @@ class Reconstruction:
         self._ck(self._lib.svr_reg_evaluate_costs(self._h, _p(t), int(level), None if act is None else _p(act), a,
                                                   _p(sim), _p(dbg)))
         return sim, dbg
+
+    def cc_patches(self, ri2w, tmats, level, buffers=None):
+        """computeCCpatch for every patch (patchBased2D3DRegistration_gpu2.cu:130-190)."""
+        n = self.sgrid[0]
+        r, t = _f32(ri2w).reshape(n, 16), _f32(tmats).reshape(n, 16)
+        b = None if buffers is None else _f32(buffers)
+        out = np.zeros(n, np.float32)
+        sums = np.zeros((n, 6), np.float64)
+        self._ck(self._lib.svr_pvr_cc_patches(self._h, None if b is None else _p(b), _p(r), _p(t), int(level), _p(out),
+                                              _p(sums)))
+        return out, sums
 
     def reg_counters(self):
         c = np.zeros(4, np.int64)

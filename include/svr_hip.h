@@ -219,6 +219,16 @@ int svr_reg_evaluate_costs(svr_ctx *ctx, const float *transf, int level, const i
                            float *similarities_out, float *reg_slices_out_or_null);
 int svr_reg_counters(svr_ctx *ctx, long long out4[4]);
 
+/* PVR patch-to-volume registration cost (second variant): computeCCpatch
+ * (patchBased2D3DRegistration_gpu2.cu:130-190) for every patch of the slice grid with its own
+ * candidate matrix: raw-moment NCC against the current reconstruction through the software trilinear
+ * interpolation of include/interpFunctions.cuh:81-96, offsets z = -1, 0, 1, every (level+1)-th pixel.
+ * buffer: the (blurred) patches [n][pY][pX] (`getBufferValue`), NULL = the uploaded patches;
+ * RI2W[i] = patch.RI2W, Tmats[i] = the candidate transformation * Mo (patchBasedObject.cuh:297-304).
+ * sums6 = {n, sum a, sum b, sum a^2, sum b^2, sum a*b} (double). */
+int svr_pvr_cc_patches(svr_ctx *ctx, const float *buffer_or_null, const float *RI2W, const float *Tmats, int level,
+                       float *ncc_out, double *sums6_or_null);
+
 /* ---- measurement -------------------------------------------------------------------- */
 enum svr_timer {
   SVR_T_BACKPROJECT = 0, SVR_T_FORWARD = 1, SVR_T_GAUSS = 2, SVR_T_REGULARIZE = 3,

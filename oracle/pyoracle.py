@@ -52,6 +52,7 @@ def lib():
         _LIB.orc_ncc_evaluate.restype = C.c_double
         _LIB.orc_reg_gauss_kernel.restype = C.c_int
         _LIB.orc_reg_tex3d.restype = C.c_float
+        _LIB.orc_cc_patch.restype = C.c_float
     return _LIB
 
 
@@ -425,3 +426,18 @@ def reg_gradient_step(m, g, step):
     out = _f32(m).reshape(16).copy()
     lib().orc_reg_gradient_step(_p(out), _p(_f32(g)), C.c_float(step))
     return out.reshape(4, 4)
+
+
+def cc_patches(buffers, ri2w, tmats, recon_w2i, volume, level):
+    """computeCCpatch for every patch i with its own matrix: buffers [n][pY][pX], ri2w / tmats [n][16],
+    volume [vz][vy][vx].  Returns (ncc[n] float32, sums [n][6] = n, sum a, sum b, sum a^2, sum b^2, sum ab)."""
+    b = _f32(buffers)
+    n, py, px = b.shape
+    r, t, w, v = _f32(ri2w).reshape(n, 16), _f32(tmats).reshape(n, 16), _f32(recon_w2i).reshape(16), _f32(volume)
+    vz, vy, vx = v.shape
+    out = np.zeros(n, np.float32)
+    sums = np.zeros((n, 6), np.float32)
+    for i in range(n):
+        out[i] = lib().orc_cc_patch(_p(b[i]), px, py, _p(r[i]), _p(t[i]), _p(w), _p(v), vx, vy, vz, int(level),
+                                    _p(sums[i]))
+    return out, sums

@@ -409,3 +409,62 @@ void orc_reg_register(orc_reg *r, float *transf, long long *counters) {
   memcpy(transf, r->matrices, sizeof(float) * 16 * s);
   if (counters) { counters[0] = n_eval; counters[1] = n_ls; counters[2] = n_it; counters[3] = n_slot; }
 }
+
+/* ---- PVR patch-to-volume registration cost (second variant) ------------------------
+ * computeCCpatch, R2/patchBased2D3DRegistration_gpu2.cu:130-190 (R2 = /root/reference/source/
+ * reconstructionGPU2): raw-moment NCC in float of one (blurred) patch against the volume sampled with
+ * the software trilinear `interp` of R2/include/interpFunctions.cuh:81-96 at the three through-plane
+ * offsets z = -1, 0, 1 of the patch grid, every (level+1)-th pixel.  Sequential float sums, like the
+ * single thread per patch of the reference (parallelPatchRegOptimization :199-). */
+static float interp_sw(const float p[3], const float *data, int sx, int sy, int sz) {
+  /* lower = max(floor, 0), upper = min(floor + 1, size - 1); v() reads 0 for an index that is out of
+   * range as an unsigned number -- so a negative `upper` reads 0 while `lower` clamps to voxel 0 */
+  int b[3] = {(int)floorf(p[0]), (int)floorf(p[1]), (int)floorf(p[2])};
+  float f[3] = {p[0] - floorf(p[0]), p[1] - floorf(p[1]), p[2] - floorf(p[2])};
+  int size[3] = {sx, sy, sz}, lo[3], up[3];
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = b[k] > 0 ? b[k] : 0;
+    up[k] = b[k] + 1 < size[k] - 1 ? b[k] + 1 : size[k] - 1;
+  }
+#define V(X, Y, Z) (((unsigned)(X) < (unsigned)sx && (unsigned)(Y) < (unsigned)sy && (unsigned)(Z) < (unsigned)sz) \
+                        ? data[(size_t)(X) + (size_t)(Y) * sx + (size_t)(Z) * sx * sy] : 0.0f)
+  return V(lo[0], lo[1], lo[2]) * (1 - f[0]) * (1 - f[1]) * (1 - f[2])
+       + V(up[0], lo[1], lo[2]) * f[0] * (1 - f[1]) * (1 - f[2])
+       + V(lo[0], up[1], lo[2]) * (1 - f[0]) * f[1] * (1 - f[2])
+       + V(up[0], up[1], lo[2]) * f[0] * f[1] * (1 - f[2])
+       + V(lo[0], lo[1], up[2]) * (1 - f[0]) * (1 - f[1]) * f[2]
+       + V(up[0], lo[1], up[2]) * f[0] * (1 - f[1]) * f[2]
+       + V(lo[0], up[1], up[2]) * (1 - f[0]) * f[1] * f[2]
+       + V(up[0], up[1], up[2]) * f[0] * f[1] * f[2];
+#undef V
+}
+
+static void matmul4f(const float *A, const float *B, float *C) {   /* Matrix4 * Matrix4, RVH:148-159 order */
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      C[4 * i + j] = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j] + A[4 * i + 3] * B[12 + j];
+}
+
+float orc_cc_patch(const float *buffer, int px, int py, const float *RI2W, const float *Tmat, const float *reconW2I,
+                   const float *vol, int vx, int vy, int vz, int level, float sums6[6]) {
+  float M[16];
+  matmul4f(Tmat, RI2W, M);                       /* Tmat * patch.RI2W * patchPos (:152) */
+  float xy = 0, y_ = 0, x_ = 0, y2 = 0, x2 = 0;
+  unsigned n = 0;
+  const int z0 = (int)(-(3 + 0.5f)) / 2, z1 = (int)((3 + 0.5f) / 2 + 1);   /* psize.z = 3 (:208): z = -1, 0, 1 */
+  for (int y = 0; y < py; y += level + 1)
+    for (int x = 0; x < px; x += level + 1)
+      for (int z = z0; z < z1; ++z) {
+        float a = buffer[y * px + x];
+        float pos[3] = {(float)x, (float)y, (float)z}, w[3], vp[3];
+        matvec3(M, pos, w);
+        matvec3(reconW2I, w, vp);
+        float b = interp_sw(vp, vol, vx, vy, vz);
+        if (a >= 0.0f && b >= 0.0f && a == a && b == b) {
+          xy += a * b; x_ += a; y_ += b; x2 += a * a; y2 += b * b; n++;
+        }
+      }
+  if (sums6) { sums6[0] = (float)n; sums6[1] = x_; sums6[2] = y_; sums6[3] = x2; sums6[4] = y2; sums6[5] = xy; }
+  if (n > 0) return (xy - (x_ * y_) / n) / (sqrtf(x2 - x_ * x_ / n) * sqrtf(y2 - y_ * y_ / n));
+  return 0.0f;
+}

@@ -179,3 +179,52 @@ def test_pvr_loop_parity(oracle_mod):
     assert np.allclose(dg.patch_potential, do.patch_potential, atol=1e-4)
     assert rel_err(rec.debug_get(E.BUF_WEIGHTS), orc.weights, floor=1.0) < 1e-4
     assert rel_err(rec.syncCPU(), orc.recon) < 1e-4
+
+
+# ---- computeCCpatch: the patch-to-volume registration cost (a17, second variant) -----------------
+def _cc_inputs():
+    pvr, stacks, P = _small_pvr()
+    vx, vy, vz = P.vsize
+    kk, jj, ii = np.meshgrid(np.arange(vz), np.arange(vy), np.arange(vx), indexing="ij")
+    w = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(float) @ P.recon_i2w.reshape(4, 4).astype(float).T
+    vol = (phantom.phantom_intensity(w[..., :3], 11.0) * 700 / 0.55).astype(np.float32)
+    rng = np.random.default_rng(3)
+    tm = []
+    for k in range(P.ns):                                   # the true matrix, nudged differently per patch
+        d = geo.rigid_matrix(*(rng.uniform(-1, 1, 3)), *(rng.uniform(-2, 2, 3)))
+        tm.append(geo.to_matrix4(P.slice_t[k].reshape(4, 4).astype(np.float64) @ d))
+    return P, vol, np.stack(tm)
+
+
+def test_cc_patch_oracle_properties(oracle_mod):
+    P, vol, tm = _cc_inputs()
+    true_t = P.slice_t
+    n0, s0 = oracle_mod.cc_patches(P.slices, P.slice_i2w, true_t, P.recon_w2i, vol, 0)
+    n1, s1 = oracle_mod.cc_patches(P.slices, P.slice_i2w, tm, P.recon_w2i, vol, 0)
+    assert (np.abs(n0) <= 1.0 + 1e-4).all() and n0.mean() > n1.mean() and n0.mean() > 0.5
+    assert (s0[:, 0] <= 3 * 16 * 16).all() and (s0[:, 0] > 0).all()          # 3 offsets x patch pixels
+    _, s2 = oracle_mod.cc_patches(P.slices, P.slice_i2w, true_t, P.recon_w2i, vol, 1)
+    assert (s2[:, 0] <= 3 * 8 * 8).all()                                      # every 2nd pixel in x and y
+    # software interpolation quirk: below 0 the lower corner clamps to voxel 0, the upper one reads 0
+    C = oracle_mod.C
+    far = np.eye(4, dtype=np.float32)
+    far[0, 3] = -1000.0
+    nf, sf = oracle_mod.cc_patches(P.slices[:1], P.slice_i2w[:1], far.reshape(1, 16), P.recon_w2i, vol, 0)
+    assert np.isfinite(nf).all()
+
+
+@pytest.mark.gpu
+def test_cc_patch_parity(oracle_mod):
+    from fetalreconstruction_amd import engine as E
+    P, vol, tm = _cc_inputs()
+    rec = E.Reconstruction(0)
+    rec.set_option("pvr", 1)
+    E.sync_gpu(rec, P, quality_factor=1.0)
+    rec.UpdateReconstructed(P.vsize, vol)
+    blurred = np.where(P.slices > 0, P.slices * 0.97 + 3.0, P.slices).astype(np.float32)
+    for level, buf in ((0, None), (1, None), (0, blurred)):
+        no, so = oracle_mod.cc_patches(P.slices if buf is None else buf, P.slice_i2w, tm, P.recon_w2i, vol, level)
+        ng, sg = rec.cc_patches(P.slice_i2w, tm, level, buf)
+        assert np.array_equal(sg[:, 0], so[:, 0].astype(np.float64))          # the sample set: exact
+        assert np.allclose(sg[:, 1:], so[:, 1:], rtol=2e-5)                   # float-sequential vs double sums
+        assert np.allclose(ng, no, atol=2e-4)
