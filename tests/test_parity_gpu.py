@@ -205,8 +205,8 @@ def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
     P.slices[:, ::3, ::2] = 140.0
     E, rec, orc, dg, do = _drivers(P, oracle_mod)
     rec.set_option("back_mode", back_mode)
-    rec.set_option("fwd_mode", 2 if back_mode == 2 else 0)
-    rec.set_option("gauss_mode", 1 if back_mode == 2 else 0)
+    rec.set_option("fwd_mode", 3 if back_mode == 2 else 0)
+    rec.set_option("gauss_mode", 1 if back_mode >= 2 else 0)
     run_to_state(dg, "sim")
     run_to_state(do, "sim")
     assert (orc.psf_sums != 0).any()

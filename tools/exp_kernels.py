@@ -21,4 +21,6 @@ def best(f, name, n=6):
 sw = d._local(d._slice_weight_gpu)
 res = dict(fwd=best(rec.SimulateSlices, 'forward'), back=best(lambda: rec.SuperresolutionBackproject(sw), 'backproject'),
            gauss=best(rec.GaussianReconstruction, 'gauss', 3))
+c = rec.counters()
+print('tiles', c['tiles'], 'fallback', c['fallback_tiles'])
 print(os.path.basename(os.environ.get('SVR_HIP_LIB', 'libsvr_hip.so')), ' '.join(sys.argv[1:]), ' '.join(f'{k} {v:.2f}' for k, v in res.items()))
