@@ -228,3 +228,31 @@ def test_cc_patch_parity(oracle_mod):
         assert np.array_equal(sg[:, 0], so[:, 0].astype(np.float64))          # the sample set: exact
         assert np.allclose(sg[:, 1:], so[:, 1:], rtol=2e-5)                   # float-sequential vs double sums
         assert np.allclose(ng, no, atol=2e-4)
+
+
+# ---- committed golden vectors (tests/golden/tiny_v2_reg_pvr.npz, made by make_golden_v2.py) -----------
+import os
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_v2_reg_pvr.npz")
+
+
+def test_pvr_patch_extraction_against_golden():
+    g = np.load(GOLD2)
+    pvr, stacks, P = _small_pvr()
+    assert list(P.patches_per_stack) == list(g["pvr_patches_per_stack"])
+    assert abs(P.slices.astype(np.float64).sum() - g["pvr_patch_sum"]) < 1e-6 * g["pvr_patch_sum"]
+
+
+@pytest.mark.gpu
+def test_pvr_loop_against_golden():
+    from fetalreconstruction_amd import engine as E
+    g = np.load(GOLD2)
+    pvr, stacks, P = _small_pvr()
+    rec = E.Reconstruction(0)
+    rec.set_option("pvr", 1)
+    E.sync_gpu(rec, P, quality_factor=1.0)
+    d = pvr.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    d.reconstruct_iteration(1)
+    assert np.allclose([d.m_sigma_gpu, d.m_mix_gpu, d.m_m_gpu, d.m_mix_s_gpu], g["pvr_em"], rtol=1e-4)
+    assert np.allclose(d.scale, g["pvr_scale"], rtol=1e-4)
+    assert np.allclose(d.patch_weight, g["pvr_patch_weight"], atol=1e-3)
+    assert rel_err(rec.syncCPU(), g["pvr_recon"]) < 1e-4

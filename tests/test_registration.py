@@ -234,3 +234,45 @@ def test_registration_on_a_reconstructed_volume(tiny, oracle_mod):
                          tiny.recon_w2i)                               # UpdateGPUTranformationMatrices RG.cc:372-401
     d.reconstruct_iteration(1)
     assert np.isfinite(rec.syncCPU()).all()
+
+
+# ---- committed golden vectors (tests/golden/tiny_v2_reg_pvr.npz, made by make_golden_v2.py) -----------
+import os
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_v2_reg_pvr.npz")
+
+
+def _golden_inputs(tiny):
+    vol = _analytic_volume(tiny)
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    T[3] = T[3] @ geo.rigid_matrix(tx=1.5, rz=2.0)
+    T[10] = T[10] @ geo.rigid_matrix(ty=-1.0, rx=-1.5)
+    return vol, T
+
+
+def test_oracle_registration_against_golden(tiny, oracle_mod):
+    g = np.load(GOLD2)
+    vol, T = _golden_inputs(tiny)
+    rs = R.PrepareRegistrationSlices(_Recorder(), tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    assert abs(rs.combined.astype(np.float64).sum() - g["reg_combined_sum"]) < 1e-6 * abs(g["reg_combined_sum"])
+    o = _oracle_reg(oracle_mod, tiny, rs, vol)
+    Tn = R.SliceToVolumeRegistrationGPU(o, rs, T, vol)
+    assert np.array_equal(o.counters, g["reg_counters"])
+    assert np.allclose(Tn, g["reg_t_out"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_device_registration_against_golden(tiny):
+    g = np.load(GOLD2)
+    vol, T = _golden_inputs(tiny)
+    rec = _engine_with_volume(tiny, vol)
+    rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    Tg = R.SliceToVolumeRegistrationGPU(rec, rs, T)
+    assert np.array_equal(rec.reg_counters(), g["reg_counters"])
+    assert np.allclose(Tg, g["reg_t_out"], rtol=0, atol=1e-5)
+    mo = [np.eye(4) for _ in range(tiny.ns)]
+    for m, a in zip(mo, rs.attrs):
+        m[:3, 3] = a.origin
+    t_in = np.stack([geo.to_matrix4(t @ m) for t, m in zip(T, mo)])
+    for lv in (0, 1):
+        assert np.allclose(rec.evaluate_costs(t_in, lv)[0], g["reg_sims_all"][lv], rtol=0, atol=2e-6)
+    assert np.allclose(rec.evaluate_costs(t_in, 0, [2, 5, 7])[0], g["reg_sims_few"], rtol=0, atol=2e-6)
