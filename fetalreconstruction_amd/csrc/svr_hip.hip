@@ -772,11 +772,14 @@ struct PixelRec {      // per tile pixel, in LDS
   float f0, f1;
 };
 
-template <int PLANE_WAVES>
+// NS = PSF support (16 SVR, 12 PVR), PVR = patch-to-volume constants of the evaluator and of the residual
+// (R2/patchBasedSuperresolution_gpu.cu:34-111, R2/patchBasedPSFReconstruction_gpu.cu:112-139)
+template <int PLANE_WAVES, int NS = PSF_SUPPORT, bool PVR = false>
 __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a, TileArgs ta,
                                                                        uint32_t *fallback_tiles,
                                                                        uint32_t *fallback_count) {
   constexpr int PLANE_SLOTS = PLANE_WAVES * 4;
+  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
   constexpr bool GAUSS1_ACT = false;
   extern __shared__ __attribute__((aligned(16))) float tile[];   // addon[cap] | cmap[cap]
   __shared__ int sh_lo[3], sh_hi[3];
@@ -834,9 +837,9 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
   // ones beyond the volume), y/z are clipped at the high end only.  The float->uint saturation of
   // the reference (negative -> 0, RC.cu:508) is applied once per box voxel at flush time, which
   // sums exactly the taps that alias; taps beyond the high end are dropped (RC.cu:509).
-  const int lox = sh_lo[0] - PSF_CENTRE, hix = sh_hi[0] + 8;
-  const int loy = sh_lo[1] - PSF_CENTRE, hiy = min(sh_hi[1] + 8, vg.vy - 1);
-  const int loz = sh_lo[2] - PSF_CENTRE, hiz = min(sh_hi[2] + 8, vg.vz - 1);
+  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
+  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vg.vy - 1);
+  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vg.vz - 1);
   const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
   if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
   const int Px = Dx | 1;                                // odd x pitch: 16 y rows -> 16 distinct banks
@@ -854,8 +857,8 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
     const int P = loz + (int)threadIdx.x;
     int c = 0;
     for (int k = 0; k < npix; ++k) {
-      const int z = P - sh_px[k].cz + PSF_CENTRE;
-      if (z >= 0 && z < PSF_SUPPORT) sh_list[threadIdx.x][c++] = (unsigned char)k;
+      const int z = P - sh_px[k].cz + NC;
+      if (z >= 0 && z < NS) sh_list[threadIdx.x][c++] = (unsigned char)k;
     }
     sh_cnt[threadIdx.x] = c;
   }
@@ -870,23 +873,23 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
     float *pa = t_addon + slot * Pxy - lox, *pc = t_cmap + slot * Pxy - lox;
     for (int i = 0; i < cnt; ++i) {
       const PixelRec R = sh_px[sh_list[slot][i]];
-      const int z = P - R.cz + PSF_CENTRE;
-      const int ay = R.cy + y - PSF_CENTRE;             // may be negative: aliases to 0 at flush
-      const bool rowok = ay < vg.vy;
-      const int rb = rowok ? (ay - loy) * Px + R.cx - PSF_CENTRE : 0;
+      const int z = P - R.cz + NC;
+      const int ay = R.cy + y - NC;                     // may be negative: aliases to 0 at flush
+      const bool rowok = y < NS && ay < vg.vy;
+      const int rb = rowok ? (ay - loy) * Px + R.cx - NC : 0;
       // the row's 16 accumulators are fetched before the PSF evaluation (their LDS latency hides
       // behind ~1200 ALU instructions) and written back after it; all 16 x positions are inside the
       // box by construction, so the read-add-write is unconditional (skipped taps add 0)
-      float va[16], vc[16];
+      float va[NS], vc[NS];
       if (rowok) {
 #pragma unroll
-        for (int x = 0; x < 16; ++x) { va[x] = pa[rb + x]; vc[x] = pc[rb + x]; }
+        for (int x = 0; x < NS; ++x) { va[x] = pa[rb + x]; vc[x] = pc[rb + x]; }
       }
-      float out[16];
-      eval_row_at(RC, R.bx, R.by, R.bz, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE), out);
+      float out[NS];
+      eval_row_t<NS, PVR>(RC, R.bx, R.by, R.bz, (float)(y - NC), (float)(z - NC), out);
       if (rowok) {
 #pragma unroll
-        for (int x = 0; x < 16; ++x) {
+        for (int x = 0; x < NS; ++x) {
           const float v = (out[x] < 0.0f) ? 0.0f : out[x];
           pa[rb + x] = va[x] + v * R.f0;
           pc[rb + x] = vc[x] + v * R.f1;
@@ -929,16 +932,37 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
 // sume over processed in-bounds taps (no mask), the `sume > 0.5` gate, v_PSF_sums, and the
 // sliceVoxel_count flag (any processed tap on an in-mask voxel, RC.cu:283-294); the box then only
 // encodes {out of bounds, masked, in mask}.
+// getReconValueFromTexture (R2/reconVolume.cu:170-187): linear filter at the un-offset coordinate =
+// 0.125 * sum over {p-1,p}^3 with zero border
+__device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, int X, int Y, int Z) {
+  float v = 0.0f;
+#pragma unroll
+  for (int dz = -1; dz <= 0; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 0; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 0; ++dx) {
+        const int x = X + dx, y = Y + dy, z = Z + dz;
+        const float t = (x >= 0 && y >= 0 && z >= 0) ? vol[(size_t)x + (size_t)y * vg.vx + (size_t)z * vg.vx * vg.vy] : 0.0f;
+        v += 0.125f * t;
+      }
+  return v;
+}
+
 // ROWS = true: per pixel the 256 (y,z) rows are first classified (row_is_dead); rows outside the volume
 // are dropped, dead rows get only their first tap evaluated, live rows all 16.  A wavefront then works
 // on FOUR pixels at once, 16 lanes each, every lane group walking its pixel's compacted row lists --
 // so the work per pixel is (live rows) x 16 + (dead rows) x 2 taps instead of 256 x 16.
 // register budget: 8 waves per SIMD for the plain gather (64 VGPRs, what it needs anyway), 6 for the
 // row-list variant, whose per-lane pixel state does not fit 64 (measured: 8 -> 9.7 ms, 6 -> 5.4, 5 -> 5.5, 4 -> 6.0)
-template <bool GAUSS1, bool ROWS>
+// NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: evaluator, texture-averaged volume read
+// (R2/reconVolume.cu:170-187), pass-1 gate sume > 1e-5 or NaN and superpixel test (R2/patchBasedPSFReconstruction_gpu.cu:95-110)
+template <bool GAUSS1, bool ROWS, int NS = PSF_SUPPORT, bool PVR = false>
 __global__ __launch_bounds__(FWD_WAVES * 64) __attribute__((amdgpu_waves_per_eu(ROWS ? 6 : 8, ROWS ? 6 : 8)))
 void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
   constexpr bool GAUSS1_ACT = GAUSS1;
+  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
+  static_assert(!ROWS || (NS == PSF_SUPPORT && !PVR), "row lists are built for the SVR support");
   extern __shared__ __attribute__((aligned(16))) float tile[];   // masked volume box [cap] (+ row lists)
   __shared__ int sh_lo[3], sh_hi[3];
   __shared__ PixelRec sh_px[64];
@@ -983,9 +1007,9 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
   }
   __syncthreads();
   const int npix = sh_npix;
-  const int lox = sh_lo[0] - PSF_CENTRE, hix = sh_hi[0] + 8;
-  const int loy = sh_lo[1] - PSF_CENTRE, hiy = min(sh_hi[1] + 8, vg.vy - 1);
-  const int loz = sh_lo[2] - PSF_CENTRE, hiz = min(sh_hi[2] + 8, vg.vz - 1);
+  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
+  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vg.vy - 1);
+  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vg.vz - 1);
   const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
   if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // nothing in bounds: no pixel gets a weight > 0
   const int Px = Dx | 1;
@@ -1002,7 +1026,8 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
       if (yy < Dy && xx < Dx && gx < vg.vx) {
         const uint32_t vi = sat0(gx) + sat0(yy + loy) * (uint32_t)vg.vx + sat0(z + loz) * sxy;
         if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
-        else if (a.mask[vi] != 0.0f) bits = __float_as_uint(a.vol[vi]);
+        else if (a.mask[vi] != 0.0f)
+          bits = __float_as_uint(PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(yy + loy), (int)sat0(z + loz)) : a.vol[vi]);
       }
       reinterpret_cast<uint32_t *>(tile)[i] = bits;
     }
@@ -1164,35 +1189,36 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
     float f0 = 0.0f, f1 = 0.0f;
     double acc = 0.0;
     bool hit = false;
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (NS + 3) / 4; ++q) {
       const int z = 4 * q + (lane >> 4), y = lane & 15;
-      const int ay = R.cy + y - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
-      const bool rowok = ay < vg.vy && az < vg.vz;          // negatives alias to 0: always "in bounds"
-      uint32_t vb[16];
+      const int ay = R.cy + y - NC, az = R.cz + z - NC;
+      const bool rowok = y < NS && z < NS && ay < vg.vy && az < vg.vz;   // negatives alias to 0: always "in bounds"
+      uint32_t vb[NS];
       if (in_lds) {
-        const int rb = rowok ? (ay - loy) * Px + (az - loz) * Pxy + R.cx - PSF_CENTRE - lox : 0;
+        const int rb = rowok ? (ay - loy) * Px + (az - loz) * Pxy + R.cx - NC - lox : 0;
 #pragma unroll
-        for (int x = 0; x < 16; ++x) vb[x] = reinterpret_cast<const uint32_t *>(tile)[rb + x];
+        for (int x = 0; x < NS; ++x) vb[x] = reinterpret_cast<const uint32_t *>(tile)[rb + x];
       } else {
 #pragma unroll
-        for (int x = 0; x < 16; ++x) {
-          const int gx = R.cx + x - PSF_CENTRE;
+        for (int x = 0; x < NS; ++x) {
+          const int gx = R.cx + x - NC;
           uint32_t bits = FWD_SENTINEL;
           if (rowok && gx < vg.vx) {
             const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
             if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
-            else if (a.mask[vi] != 0.0f) bits = __float_as_uint(a.vol[vi]);
+            else if (a.mask[vi] != 0.0f)
+              bits = __float_as_uint(PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(ay), (int)sat0(az)) : a.vol[vi]);
           }
           vb[x] = bits;
         }
       }
-      float out[16];
-      eval_row_at(RC, R.bx, R.by, R.bz, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE), out);
+      float out[NS];
+      eval_row_t<NS, PVR>(RC, R.bx, R.by, R.bz, (float)(y - NC), (float)(z - NC), out);
       // the per-tap branch pays: most taps are epsilon-skipped and the whole wave jumps over the body
       // (a branch-free version measured 6.7 vs 5.9 ms on P4)
       if (rowok) {
 #pragma unroll
-        for (int x = 0; x < 16; ++x) {
+        for (int x = 0; x < NS; ++x) {
           if (GAUSS1) {
             if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
               acc += (double)out[x];                       // RC.cu:241-245 (no mask test)
@@ -1210,9 +1236,15 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
     const bool inside = __ballot(hit) != 0ull;
     const uint32_t idx = sh_idx[k];
     if (GAUSS1) {
-      const float sume = (float)wave_sum(acc);
+      float sume = (float)wave_sum(acc);
+      bool pass = sume > 0.5f;                             // also drops NaN (RC.cu:251-258)
+      if (PVR) {
+        const uint32_t rem = idx % (uint32_t)(a.sx * a.sy);
+        const uint32_t ppx = rem % (uint32_t)a.sx, ppy = rem / (uint32_t)a.sx;
+        if (a.spx && a.spx[(size_t)sl * 4096 + ppx + 64 * ppy] != '1') sume = 0.0f;   // superpixel test of pass 1
+        pass = (sume > 0.00001f) || (sume != sume);
+      }
       if (lane == 0) {
-        const bool pass = sume > 0.5f;                     // also drops NaN (RC.cu:251-258)
         a.flag_out[idx] = pass ? 1 : 0;
         if (pass) {
           a.psf_sums[idx] = sume;
@@ -1243,30 +1275,9 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
 #define PVR_N 12
 #define PVR_CENTRE 5
 
-// getReconValueFromTexture (R2/reconVolume.cu:170-187): linear filter at the un-offset coordinate =
-// 0.125 * sum over {p-1,p}^3 with zero border
-__device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, int X, int Y, int Z) {
-  float v = 0.0f;
-#pragma unroll
-  for (int dz = -1; dz <= 0; ++dz)
-#pragma unroll
-    for (int dy = -1; dy <= 0; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 0; ++dx) {
-        const int x = X + dx, y = Y + dy, z = Z + dz;
-        const float t = (x >= 0 && y >= 0 && z >= 0) ? vol[(size_t)x + (size_t)y * vg.vx + (size_t)z * vg.vx * vg.vy] : 0.0f;
-        v += 0.125f * t;
-      }
-  return v;
-}
-
+#define MODE_GAUSS2 4      // pass 2 of the Gaussian reconstruction only (v_PSF_sums from the tiled pass 1)
 template <int MODE>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void pvr_kernel(PsfArgs a) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const uint32_t pi = blockIdx.x * WAVES_PER_BLOCK + wave;
-  if (pi >= a.n) return;
-  const uint32_t idx = __builtin_amdgcn_readfirstlane(a.list[pi]);
+__device__ __forceinline__ void pvr_pixel(const PsfArgs &a, uint32_t idx, int lane) {
   const uint32_t n2 = (uint32_t)(a.sx * a.sy);
   const uint32_t sl = idx / n2;
   const uint32_t rem = idx - sl * n2;
@@ -1327,7 +1338,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void pvr_kernel(PsfArgs a) {
         const uint32_t vi = ax + ay * (uint32_t)vg.vx + az * (uint32_t)(vg.vx * vg.vy);
         if (a.mask[vi] != 0.0f) {
           const float pv = out[x] / sume;
-          if (MODE == MODE_GAUSS) {
+          if (MODE == MODE_GAUSS || MODE == MODE_GAUSS2) {
             unsafeAtomicAdd(a.volw + vi, pv);
             unsafeAtomicAdd(a.recon + vi, s * pv);
           } else if (MODE == MODE_FWD) {
@@ -1352,6 +1363,33 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void pvr_kernel(PsfArgs a) {
       a.simweights[idx] = w;
       a.siminside[idx] = inside ? 1 : 0;
     }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void pvr_kernel(PsfArgs a) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const uint32_t pi = blockIdx.x * WAVES_PER_BLOCK + wave;
+  if (pi >= a.n) return;
+  pvr_pixel<MODE>(a, __builtin_amdgcn_readfirstlane(a.list[pi]), lane);
+}
+
+// fallback of the tiled PVR scatter: the pixels of the listed tiles with device atomics (MODE_BACK / MODE_GAUSS2)
+template <int MODE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void pvr_tiles_kernel(PsfArgs a, TileArgs ta) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const uint32_t t = ta.tiles[blockIdx.x];
+  const int per_slice = ta.tiles_x * ta.tiles_y;
+  const uint32_t sl = t / per_slice;
+  const int r = t - sl * per_slice;
+  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
+  for (int k = wave; k < ta.tw * ta.th; k += WAVES_PER_BLOCK) {
+    const int px = tx * ta.tw + k % ta.tw, py = ty * ta.th + k / ta.tw;
+    if (px >= a.sx || py >= a.sy) continue;
+    const uint32_t idx = (uint32_t)px + (uint32_t)py * a.sx + sl * (uint32_t)(a.sx * a.sy);
+    if (pixel_active(a.slices, a.psf_sums, a.flag, idx)) pvr_pixel<MODE>(a, idx, lane);
   }
 }
 
@@ -2048,6 +2086,7 @@ struct svr_ctx {
                             // plain LDS-tiled gather; 2 / 1 = one of the two for every slice; 0 = wave-per-pixel kernel
   int fwd_cap = 9216;       // box voxels: 36 KiB -> 4 workgroups of 8 waves per CU
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
+  int pvr_mode = 1;         // PVR kernels: 1 = the LDS-tiled gather / plane-owned scatter with support 12, 0 = wave-per-pixel
   unsigned char *d_spx = nullptr;
   int back_mode = 2;        // 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
                             // 0 = direct device-scope atomics per tap
@@ -2395,6 +2434,12 @@ int svr_create(int device, svr_ctx **out) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false, false, PVR_N, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true, false, PVR_N, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<8, PVR_N, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<5>),
@@ -2418,6 +2463,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }
+  if (!strcmp(name, "pvr_mode")) { ctx->pvr_mode = value; return SVR_OK; }
   if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_cap")) { ctx->fwd_cap = std::max(4096, value); return SVR_OK; }
   if (!strcmp(name, "fwd_tile_w") || !strcmp(name, "fwd_tile_h")) {
@@ -2691,7 +2737,8 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   a.list = ctx->d_active;
   a.n = ctx->n_active;
   ScopedTimer t(ctx, SVR_T_GAUSS);
-  if (a.n && !ctx->pvr && ctx->gauss_mode == 1) {
+  const bool pvr_tiled = ctx->pvr && ctx->pvr_mode == 1;
+  if (a.n && ctx->gauss_mode == 1 && (!ctx->pvr || pvr_tiled)) {
     // pass 1 (tiled walk: sume, gate, v_PSF_sums, voxel-count flag), pass 2 = the plane-owned scatter
     // of the back-projection with {recon|volw} as targets and unit voxel/slice weights
     if (!ctx->d_gauss_flag) HIPCHK(hipMalloc(&ctx->d_gauss_flag, ctx->np));
@@ -2707,8 +2754,9 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     // pass 1 per slice group: plain gather walk / row-list walk (fwd_mode 3 splits by h_rows_sel)
     for (int w = 0; w < 2; ++w) {
       const bool rows = w == 1;
-      if ((ctx->fwd_mode == 2 && !rows) || (ctx->fwd_mode != 2 && ctx->fwd_mode != 3 && rows)) continue;
-      const unsigned char *sel = ctx->fwd_mode == 3 ? ctx->d_rows_sel : nullptr;
+      const int fm = pvr_tiled ? 1 : ctx->fwd_mode;       // row lists exist for the SVR support only
+      if ((fm == 2 && !rows) || (fm != 2 && fm != 3 && rows)) continue;
+      const unsigned char *sel = fm == 3 ? ctx->d_rows_sel : nullptr;
       HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
       hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
                          (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
@@ -2718,7 +2766,10 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
       ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1;
       if (!n1) continue;
-      if (rows)
+      if (pvr_tiled)
+        hipLaunchKernelGGL((fwd_tile_kernel<true, false, PVR_N, true>), dim3(n1), dim3(FWD_WAVES * 64),
+                           (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
+      else if (rows)
         hipLaunchKernelGGL((fwd_tile_kernel<true, true>), dim3(n1), dim3(FWD_WAVES * 64),
                            (size_t)ta.cap * sizeof(float) + (size_t)ta.tw * ta.th * 256, ctx->stream, a, ta);
       else
@@ -2739,15 +2790,24 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     ta.cap = std::min(ctx->plane_cap, ctx->tile_cap);
     if (n2) {
       HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(back_plane_kernel<8>, dim3(n2), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float), ctx->stream, a, ta,
-                         ctx->d_tiles_fb, ctx->d_counter);
+      if (pvr_tiled)
+        hipLaunchKernelGGL((back_plane_kernel<8, PVR_N, true>), dim3(n2), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float),
+                           ctx->stream, a, ta, ctx->d_tiles_fb, ctx->d_counter);
+      else
+        hipLaunchKernelGGL(back_plane_kernel<8>, dim3(n2), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float), ctx->stream, a, ta,
+                           ctx->d_tiles_fb, ctx->d_counter);
       KCHK("back_plane_kernel(gauss)");
       HIPCHK(hipMemcpyAsync(&nfb, ctx->d_counter, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
       if (nfb) {
         ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb; ta.cap = ctx->tile_cap;
-        hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
-                           ctx->stream, a, ta);
+        if (pvr_tiled) {
+          a.recon = ctx->recon(); a.volw = ctx->volw();
+          hipLaunchKernelGGL(pvr_tiles_kernel<MODE_GAUSS2>, dim3(nfb), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
+        } else {
+          hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
+                             ctx->stream, a, ta);
+        }
         KCHK("back_tiled_kernel(gauss fallback)");
       }
     }
@@ -2799,7 +2859,15 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   ScopedTimer t(ctx, SVR_T_FORWARD);
-  if (a.n && ctx->pvr) {
+  if (a.n && ctx->pvr && ctx->pvr_mode == 1) {
+    TileArgs ta;                                         // all forward tiles (h_rows_sel is all 0 for PVR)
+    ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
+    ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
+    ta.gauss = 0;
+    hipLaunchKernelGGL((fwd_tile_kernel<false, false, PVR_N, true>), dim3(ta.ntiles), dim3(FWD_WAVES * 64),
+                       (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
+    KCHK("fwd_tile_kernel<PVR>");
+  } else if (a.n && ctx->pvr) {
     hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("pvr_kernel<FWD>");
@@ -2971,7 +3039,25 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
-  if (a.n && ctx->pvr) {
+  if (a.n && ctx->pvr && ctx->pvr_mode == 1) {
+    TileArgs ta;
+    ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
+    ta.cap = std::min(ctx->plane_cap, ctx->tile_cap); ta.dbg = 0;
+    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL((back_plane_kernel<8, PVR_N, true>), dim3(ctx->n_tiles), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float),
+                       ctx->stream, a, ta, ctx->d_tiles_fb, ctx->d_counter);
+    KCHK("back_plane_kernel<PVR>");
+    uint32_t nfb = 0;
+    HIPCHK(hipMemcpyAsync(&nfb, ctx->d_counter, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_tiles_fb = nfb;
+    if (nfb) {
+      ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb;
+      hipLaunchKernelGGL(pvr_tiles_kernel<MODE_BACK>, dim3(nfb), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
+      KCHK("pvr_tiles_kernel<BACK>");
+    }
+  } else if (a.n && ctx->pvr) {
     hipLaunchKernelGGL(pvr_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("pvr_kernel<BACK>");

@@ -54,10 +54,11 @@ def test_pvr_keeps_voxel_aligned_pixels(oracle_mod):
     assert o.GaussianReconstruction()[0] == P.slices.size and np.isfinite(o.recon).all()
 
 
-def _pair(prob, oracle_mod, spx=None):
+def _pair(prob, oracle_mod, spx=None, pvr_mode=1):
     from fetalreconstruction_amd import engine as E
     rec = E.Reconstruction(0)
     rec.set_option("pvr", 1)
+    rec.set_option("pvr_mode", pvr_mode)
     E.sync_gpu(rec, prob)
     if spx is not None:
         rec.set_spx_masks(spx)
@@ -84,10 +85,12 @@ def test_pvr_taps_are_bit_identical(tiny, oracle_mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pvr_mode", [1, 0])
 @pytest.mark.parametrize("use_spx", [False, True])
-def test_pvr_psf_kernels_parity(tiny, oracle_mod, use_spx):
+def test_pvr_psf_kernels_parity(tiny, oracle_mod, use_spx, pvr_mode):
+    """pvr_mode 1 = LDS-tiled gather / plane-owned scatter with support 12 (default), 0 = wave-per-pixel kernels."""
     spx = _spx(tiny) if use_spx else None
-    E, rec, orc = _pair(tiny, oracle_mod, spx)
+    E, rec, orc = _pair(tiny, oracle_mod, spx, pvr_mode)
     ng, no = rec.GaussianReconstruction(), orc.GaussianReconstruction()
     ps = rec.debug_get(E.BUF_PSF_SUMS)
     assert np.array_equal(ps != 0, orc.psf_sums != 0) and ng == no

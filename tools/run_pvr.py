@@ -1,0 +1,26 @@
+"""P4-scale PVR run: patch extraction (32x32 stride 16), one outer iteration with 3 SR iterations; kernel times."""
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from fetalreconstruction_amd import phantom, engine, pvr
+
+t0 = time.time()
+stacks, mask, mattr, rattr, rmask = phantom.make_stacks(4, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, seed=1,
+                                                        orientations=("ax", "cor", "sag", "ax"))
+P = pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (32, 32), (16, 16))
+print("patch extraction s:", round(time.time() - t0, 1), "patches", P.slices.shape, P.patches_per_stack,
+      "non-zero px", int((P.slices > 0).sum()))
+rec = engine.Reconstruction(0)
+rec.set_option("pvr", 1)
+engine.sync_gpu(rec, P, quality_factor=1.0)
+d = pvr.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity)
+rec.timer_enable(True)
+t0 = time.time()
+d.reconstruct_iteration(3)
+print("outer iteration wall s:", round(time.time() - t0, 2))
+for k, (ms, n) in rec.timers().items():
+    if n:
+        print(f"  {k}: {ms / n:.2f} ms x {n}")
+c = rec.counters()
+print("Va", c["Va"], "-> MVox/s per SR iteration (fwd+back):",
+      round(c["Va"] / ((rec.timers()['backproject'][0] / rec.timers()['backproject'][1] + rec.timers()['forward'][0] / rec.timers()['forward'][1]) * 1e-3) / 1e6, 1))
