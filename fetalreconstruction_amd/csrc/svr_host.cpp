@@ -305,6 +305,137 @@ class irtkReconstruction {
     return EStepGPU();
   }
 
+  // ---- GPU slice-to-volume registration, host side ------------------------------------------
+  struct M4 { double m[16]; };
+  static M4 mul(const M4 &a, const M4 &b) {
+    M4 c;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double t = 0;
+        for (int k = 0; k < 4; ++k) t += a.m[4 * i + k] * b.m[4 * k + j];
+        c.m[4 * i + j] = t;
+      }
+    return c;
+  }
+  static M4 ident() { M4 c; for (int i = 0; i < 16; ++i) c.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return c; }
+  // irtkBaseImage::GetImageToWorldMatrix / GetWorldToImageMatrix (irtkBaseImage.cc:79-147)
+  static M4 image_to_world(const svr_image_attr &a) {
+    M4 t1 = ident(), sc = ident(), rot = ident(), t2 = ident();
+    t1.m[3] = -(a.nx - 1) / 2.0; t1.m[7] = -(a.ny - 1) / 2.0; t1.m[11] = -(a.nz - 1) / 2.0;
+    sc.m[0] = a.dx; sc.m[5] = a.dy; sc.m[10] = a.dz;
+    for (int k = 0; k < 3; ++k) { rot.m[4 * k] = a.xaxis[k]; rot.m[4 * k + 1] = a.yaxis[k]; rot.m[4 * k + 2] = a.zaxis[k]; }
+    for (int k = 0; k < 3; ++k) t2.m[4 * k + 3] = a.origin[k];
+    return mul(t2, mul(rot, mul(sc, t1)));
+  }
+  static M4 world_to_image(const svr_image_attr &a) {
+    M4 t1 = ident(), rot = ident(), sc = ident(), t2 = ident();
+    for (int k = 0; k < 3; ++k) t1.m[4 * k + 3] = -a.origin[k];
+    for (int k = 0; k < 3; ++k) { rot.m[k] = a.xaxis[k]; rot.m[4 + k] = a.yaxis[k]; rot.m[8 + k] = a.zaxis[k]; }
+    sc.m[0] = 1.0 / a.dx; sc.m[5] = 1.0 / a.dy; sc.m[10] = 1.0 / a.dz;
+    t2.m[3] = (a.nx - 1) / 2.0; t2.m[7] = (a.ny - 1) / 2.0; t2.m[11] = (a.nz - 1) / 2.0;
+    return mul(t2, mul(sc, mul(rot, t1)));
+  }
+  static int irtk_round(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }   // irtkCommon.h:85-88
+
+  std::vector<svr_image_attr> _slices_resampled_attr;   // attributes of `_slices_resampled` (RG.cc:2104-2119)
+  std::vector<float> _reg_combined;                     // combinedStacks (RG.cc:2134-2160)
+  int _reg_size[3] = {0, 0, 0};
+
+  // irtkResamplingWithPadding<irtkRealPixel>(d, d, d, -1).Run() on one slice, plane 0 of the result
+  // (IRTKSimple2/image++/src/irtkResamplingWithPadding.cc:198-252, 254-443)
+  static void resample_plane0(const float *img, int row_pitch, const svr_image_attr &a, double d, svr_image_attr &oa,
+                              std::vector<double> &out) {
+    oa = a;
+    oa.nx = irtk_round(a.nx * a.dx / d); oa.ny = irtk_round(a.ny * a.dy / d); oa.nz = irtk_round(a.nz * a.dz / d);
+    oa.dx = oa.dy = oa.dz = d;
+    if (oa.nx < 1) { oa.nx = 1; oa.dx = a.dx; }
+    if (oa.ny < 1) { oa.ny = 1; oa.dy = a.dy; }
+    if (oa.nz < 1) { oa.nz = 1; oa.dz = a.dz; }
+    const M4 m = mul(world_to_image(a), image_to_world(oa));
+    out.assign((size_t)oa.nx * oa.ny, -1.0);
+    for (int j = 0; j < oa.ny; ++j)
+      for (int i = 0; i < oa.nx; ++i) {
+        const double x = m.m[0] * i + m.m[1] * j + m.m[3], y = m.m[4] * i + m.m[5] * j + m.m[7],
+                     z = m.m[8] * i + m.m[9] * j + m.m[11];               // output k = 0
+        const int u = (int)floor(x), v = (int)floor(y), w = (int)floor(z);
+        const double fx = x - u, fy = y - v, fz = z - w;
+        double val = 0, sum = 0;
+        int pad = 8;
+        for (int du = 0; du < 2; ++du)                                     // the reference's order w1..w8
+          for (int dv = 0; dv < 2; ++dv)
+            for (int dw = 0; dw < 2; ++dw) {
+              const double wt = (du ? fx : 1 - fx) * (dv ? fy : 1 - fy) * (dw ? fz : 1 - fz);
+              const int p = u + du, q = v + dv, r = w + dw;
+              if (p >= 0 && p < a.nx && q >= 0 && q < a.ny && r >= 0 && r < a.nz) {
+                const double g = img[(size_t)q * row_pitch + p];            // nz == 1
+                if (g != -1.0) { --pad; val += g * wt; sum += wt; }
+              } else {
+                --pad;
+              }
+            }
+        if (pad < 4 && sum > 0) out[(size_t)j * oa.nx + i] = val / sum;
+      }
+  }
+
+  // PrepareRegistrationSlices RG.cc:2104-2181
+  int PrepareRegistrationSlices(const float *slices, int sx, int sy, const svr_image_attr *attrs, double d) {
+    const int n = hi - lo;
+    _slices_resampled_attr.resize(n);
+    std::vector<std::vector<double>> res(n);
+    int mx = 0, my = 0;
+    for (int i = 0; i < n; ++i) {
+      if (attrs[i].nz != 1) { err = "PrepareRegistrationSlices: slices must have one plane"; return SVR_E_ARG; }
+      resample_plane0(slices + (size_t)i * sx * sy, sx, attrs[i], d, _slices_resampled_attr[i], res[i]);
+      mx = std::max(mx, _slices_resampled_attr[i].nx);
+      my = std::max(my, _slices_resampled_attr[i].ny);
+    }
+    _reg_size[0] = mx; _reg_size[1] = my; _reg_size[2] = n;
+    _reg_combined.assign((size_t)n * mx * my, -1.0f);                       // combinedStacks = -1 (RG.cc:2143)
+    std::vector<float> i2w(16 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+      const svr_image_attr &a = _slices_resampled_attr[i];
+      for (int y = 0; y < a.ny; ++y)
+        for (int x = 0; x < a.nx; ++x)
+          _reg_combined[((size_t)i * my + y) * mx + x] = (float)res[i][(size_t)y * a.nx + x];
+      const M4 m = image_to_world(a);
+      for (int k = 0; k < 16; ++k) i2w[16 * (size_t)i + k] = (float)m.m[k];
+    }
+    const uint32_t size[3] = {(uint32_t)mx, (uint32_t)my, (uint32_t)n};
+    const float dim[3] = {(float)d, (float)d, (float)d};
+    ENG(svr_init_reg_storage_volumes(reconstructionGPU, size, dim));
+    ENG(svr_fill_reg_slices(reconstructionGPU, _reg_combined.data(), i2w.data()));
+    return 0;
+  }
+
+  // SliceToVolumeRegistrationGPU RG.cc:2214-2290
+  int SliceToVolumeRegistrationGPU(double *transformations) {
+    const int n = hi - lo;
+    if ((int)_slices_resampled_attr.size() != n) { err = "SliceToVolumeRegistrationGPU: PrepareRegistrationSlices first"; return SVR_E_STATE; }
+    std::vector<float> transf(16 * (size_t)n), ofs(16 * (size_t)n);
+    std::vector<M4> mos(n);
+    for (int i = 0; i < n; ++i) {
+      svr_image_attr a0 = _slices_resampled_attr[i];
+      M4 mo = ident();
+      for (int k = 0; k < 3; ++k) { mo.m[4 * k + 3] = a0.origin[k]; a0.origin[k] = 0.0; }   // RG.cc:2226-2236
+      mos[i] = mo;
+      M4 t;
+      for (int k = 0; k < 16; ++k) t.m[k] = transformations[16 * (size_t)i + k];
+      const M4 tm = mul(t, mo), o = image_to_world(a0);
+      for (int k = 0; k < 16; ++k) { transf[16 * (size_t)i + k] = (float)tm.m[k]; ofs[16 * (size_t)i + k] = (float)o.m[k]; }
+    }
+    ENG(svr_update_resampled_slices_i2w(reconstructionGPU, ofs.data()));
+    ENG(svr_prepare_slice_to_volume_reg(reconstructionGPU));
+    ENG(svr_register_slices_to_volume(reconstructionGPU, transf.data()));
+    for (int i = 0; i < n; ++i) {                                            // mat * mo^-1 (RG.cc:2262-2267)
+      M4 t, moi = ident();
+      for (int k = 0; k < 16; ++k) t.m[k] = (double)transf[16 * (size_t)i + k];
+      for (int k = 0; k < 3; ++k) moi.m[4 * k + 3] = -mos[i].m[4 * k + 3];
+      const M4 rres = mul(t, moi);
+      for (int k = 0; k < 16; ++k) transformations[16 * (size_t)i + k] = rres.m[k];
+    }
+    return 0;
+  }
+
   // reconstruction.cc:930-1140 (one outer iteration after registration)
   int reconstruct_iteration(int rec_iterations) {
     int rc;
@@ -360,6 +491,22 @@ int svrh_mask_volume_gpu(svrh_recon *r) { return r->impl.MaskVolumeGPU(); }
 int svrh_scale_volume_gpu(svrh_recon *r) { return r->impl.ScaleVolumeGPU(); }
 int svrh_sr_iteration(svrh_recon *r, int i) { return r->impl.sr_iteration(i); }
 int svrh_reconstruct_iteration(svrh_recon *r, int n) { return r->impl.reconstruct_iteration(n); }
+
+int svrh_prepare_registration_slices(svrh_recon *r, const float *slices, int sx, int sy, const svr_image_attr *attrs,
+                                     double recon_voxel) {
+  if (!r || !slices || !attrs || sx <= 0 || sy <= 0 || !(recon_voxel > 0)) return SVR_E_ARG;
+  return r->impl.PrepareRegistrationSlices(slices, sx, sy, attrs, recon_voxel);
+}
+int svrh_slice_to_volume_registration_gpu(svrh_recon *r, double *transformations) {
+  if (!r || !transformations) return SVR_E_ARG;
+  return r->impl.SliceToVolumeRegistrationGPU(transformations);
+}
+int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_null) {
+  if (!r || !size3) return SVR_E_ARG;
+  for (int k = 0; k < 3; ++k) size3[k] = r->impl._reg_size[k];
+  if (data_or_null) std::copy(r->impl._reg_combined.begin(), r->impl._reg_combined.end(), data_or_null);
+  return 0;
+}
 
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
                    unsigned char *slice_inside, double s[8]) {

@@ -19,8 +19,23 @@ HOST_EXPORTS = [
     "svrh_simulate_slices_gpu", "svrh_initialize_robust_statistics_gpu", "svrh_estep_gpu", "svrh_scale_gpu",
     "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
     "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state", "svrh_set_bias_correction", "svrh_bias_gpu",
-    "svrh_normalise_bias_gpu",
+    "svrh_normalise_bias_gpu", "svrh_prepare_registration_slices", "svrh_slice_to_volume_registration_gpu",
+    "svrh_get_registration_slices",
 ]
+
+
+class ImageAttr(C.Structure):
+    """struct svr_image_attr (include/svr_host.h)"""
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("dx", C.c_double), ("dy", C.c_double),
+                ("dz", C.c_double), ("xaxis", C.c_double * 3), ("yaxis", C.c_double * 3), ("zaxis", C.c_double * 3),
+                ("origin", C.c_double * 3)]
+
+    @classmethod
+    def of(cls, a):
+        """from a geometry.ImageAttributes"""
+        return cls(int(a.nx), int(a.ny), int(a.nz), float(a.dx), float(a.dy), float(a.dz),
+                   (C.c_double * 3)(*[float(v) for v in a.xaxis]), (C.c_double * 3)(*[float(v) for v in a.yaxis]),
+                   (C.c_double * 3)(*[float(v) for v in a.zaxis]), (C.c_double * 3)(*[float(v) for v in a.origin]))
 
 
 class _Coll(C.Structure):
@@ -149,6 +164,27 @@ class irtkReconstruction:
 
     def ScaleVolumeGPU(self):
         self._ck(self._lib.svrh_scale_volume_gpu(self._h))
+
+    def PrepareRegistrationSlices(self, slices, slice_attrs, recon_voxel):
+        """irtkReconstruction::PrepareRegistrationSlices (RG.cc:2104-2181) in the C++ host; returns the packed
+        resampled slices [n][y][x] it handed to the engine."""
+        sl = np.ascontiguousarray(slices, np.float32)
+        n, sy, sx = sl.shape
+        attrs = (ImageAttr * n)(*[ImageAttr.of(a) for a in slice_attrs])
+        self._ck(self._lib.svrh_prepare_registration_slices(self._h, sl.ctypes.data_as(C.c_void_p), sx, sy, attrs,
+                                                            C.c_double(recon_voxel)))
+        size = (C.c_int * 3)()
+        self._ck(self._lib.svrh_get_registration_slices(self._h, size, None))
+        out = np.zeros((size[2], size[1], size[0]), np.float32)
+        self._ck(self._lib.svrh_get_registration_slices(self._h, size, out.ctypes.data_as(C.c_void_p)))
+        self.reconstructionGPU._reg_grid = (size[2], size[1], size[0])
+        return out
+
+    def SliceToVolumeRegistrationGPU(self, transformations):
+        """irtkReconstruction::SliceToVolumeRegistrationGPU (RG.cc:2214-2290) in the C++ host."""
+        t = np.ascontiguousarray(transformations, np.float64).reshape(-1, 16).copy()
+        self._ck(self._lib.svrh_slice_to_volume_registration_gpu(self._h, t.ctypes.data_as(C.c_void_p)))
+        return t.reshape(-1, 4, 4)
 
     def sr_iteration(self, i):
         self._ck(self._lib.svrh_sr_iteration(self._h, int(i)))

@@ -74,6 +74,25 @@ int svrh_sr_iteration(svrh_recon *r, int i);
  * (reconstruction.cc:930-1140) */
 int svrh_reconstruct_iteration(svrh_recon *r, int rec_iterations);
 
+/* ---- GPU slice-to-volume registration, host side (irtkReconstructionGPU.cc:2104-2290) ------------
+ * irtkImageAttributes subset of one slice (z size 1): voxel counts and sizes, axes, origin = world
+ * position of the image centre (IRTKSimple2/image++/src/irtkBaseImage.cc:79-147). */
+typedef struct svr_image_attr {
+  int nx, ny, nz;
+  double dx, dy, dz;
+  double xaxis[3], yaxis[3], zaxis[3], origin[3];
+} svr_image_attr;
+/* PrepareRegistrationSlices RG.cc:2104-2181: resample this rank's slices to the reconstruction's voxel
+ * size with irtkResamplingWithPadding (padding -1), pack plane 0 of each into the padded grid and hand it
+ * to the engine (initRegStorageVolumes + FillRegSlices).  slices [n_local][sy][sx]. */
+int svrh_prepare_registration_slices(svrh_recon *r, const float *slices, int sx, int sy, const svr_image_attr *attrs,
+                                     double recon_voxel);
+/* SliceToVolumeRegistrationGPU RG.cc:2214-2290: transformations = row-major double 4x4 per local slice
+ * (`_transformations_gpu`), updated in place; the engine registers against its current reconstruction. */
+int svrh_slice_to_volume_registration_gpu(svrh_recon *r, double *transformations);
+/* resampled grid of the last svrh_prepare_registration_slices: {x, y, slices} and a copy of the packed data */
+int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_null);
+
 /* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
  * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s} */
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,

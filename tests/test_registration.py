@@ -276,3 +276,22 @@ def test_device_registration_against_golden(tiny):
     for lv in (0, 1):
         assert np.allclose(rec.evaluate_costs(t_in, lv)[0], g["reg_sims_all"][lv], rtol=0, atol=2e-6)
     assert np.allclose(rec.evaluate_costs(t_in, 0, [2, 5, 7])[0], g["reg_sims_few"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_cpp_host_registration_matches_python_host(tiny):
+    """svr::irtkReconstruction::{PrepareRegistrationSlices, SliceToVolumeRegistrationGPU} (csrc/svr_host.cpp)
+    against registration.py on a second engine: same packed slices, same matrices."""
+    from fetalreconstruction_amd import host
+    vol, T = _golden_inputs(tiny)
+    rec_py, rec_cc = _engine_with_volume(tiny, vol), _engine_with_volume(tiny, vol)
+    rs = R.PrepareRegistrationSlices(rec_py, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    hc = host.irtkReconstruction(rec_cc, tiny.ns, max_intensity=tiny.max_intensity, min_intensity=tiny.min_intensity)
+    packed = hc.PrepareRegistrationSlices(tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    assert packed.shape == rs.combined.shape
+    assert np.array_equal(packed == -1, rs.combined == -1)
+    assert np.allclose(packed, rs.combined, rtol=0, atol=1e-3)
+    Tp = R.SliceToVolumeRegistrationGPU(rec_py, rs, T)
+    Tc = hc.SliceToVolumeRegistrationGPU(T)
+    assert np.allclose(Tc, Tp, rtol=0, atol=1e-5)
+    assert np.array_equal(rec_cc.reg_counters(), rec_py.reg_counters())
