@@ -295,3 +295,42 @@ def test_adjointness_at_full_size():
     assert abs(lhs - rhs) <= 2e-5 * scale, (lhs, rhs, scale)
     c = rec.counters()
     assert c["Va"] == int(act.sum()) and c["Nv"] == nv
+
+
+def test_kernel_variants_agree_at_full_size():
+    """P4 (too big for the oracle): the production kernels against their simpler variants on the device --
+    row-list gather vs plain gather (any row wrongly declared epsilon-dead would lose >= 1e-5 of a pixel's
+    weight), tiled two-pass Gaussian reconstruction vs the wave-per-pixel kernel, plane-owned scatter vs
+    direct atomics.  Hit sets exact, sums to float round-off."""
+    from fetalreconstruction_amd import engine as E
+    P = phantom.problem_p4()
+    rec = _engine(P)
+    rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+    rec.InitializeEMValues()
+    out = {}
+    for name, opts in (("tiled_rows", dict(gauss_mode=1, fwd_mode=3)), ("tiled_plain", dict(gauss_mode=1, fwd_mode=1)),
+                       ("simple", dict(gauss_mode=0, fwd_mode=0))):
+        for k, v in opts.items():
+            rec.set_option(k, v)
+        rec.GaussianReconstruction()
+        ps = rec.debug_get(E.BUF_PSF_SUMS).copy()
+        vol, vw = rec.syncCPU().copy(), rec.getVolWeights().copy()
+        rec.SimulateSlices()
+        out[name] = (ps, vol, vw, rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy(),
+                     rec.debug_get(E.BUF_SIMINSIDE).copy(), rec.debug_get(E.BUF_VOXEL_COUNT).copy())
+    ref = out["simple"]
+    for name in ("tiled_rows", "tiled_plain"):
+        ps, vol, vw, sim, sw, si, vc = out[name]
+        assert np.array_equal(ps != 0, ref[0] != 0) and np.array_equal(vc, ref[6]) and np.array_equal(si, ref[5])
+        assert np.allclose(ps, ref[0], rtol=2e-6, atol=0)
+        assert rel_err(vol, ref[1]) < 5e-6 and rel_err(vw, ref[2]) < 5e-6
+        assert np.abs(sw - ref[4]).max() < 3e-6 and rel_err(sim, ref[3]) < 5e-6
+    rec.set_option("fwd_mode", 3)
+    rec.set_option("gauss_mode", 1)
+    res = {}
+    for bm in (2, 0):
+        rec.set_option("back_mode", bm)
+        rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+        res[bm] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
+    assert np.array_equal(res[2][1] > 0, res[0][1] > 0)
+    assert rel_err(res[2][1], res[0][1]) < 5e-6 and rel_err(res[2][0], res[0][0]) < 5e-6
