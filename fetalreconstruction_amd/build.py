@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "svr_hip.hip")
 SRC_REG = os.path.join(HERE, "csrc", "svr_reg.inc")       # GPU registration, #included by svr_hip.hip
 SRC_HOST = os.path.join(HERE, "csrc", "svr_host.cpp")     # plain host C++ (the irtkReconstruction mirror)
+SRC_IO = os.path.join(HERE, "csrc", "svr_io.cpp")         # NIfTI-1 reader / writer (zlib)
 INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
 INC_HOST = os.path.join(os.path.dirname(HERE), "include", "svr_host.h")
 OUT_DIR = os.path.join(HERE, "lib")
@@ -38,7 +39,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, INC, INC_HOST, __file__))
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, INC, INC_HOST, __file__))
 
 
 def build(force=False, verbose=False, extra=(), variant=None):
@@ -48,7 +49,7 @@ def build(force=False, verbose=False, extra=(), variant=None):
     if not variant and not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra, "-o", out, SRC, SRC_HOST]
+    cmd = [hipcc(), *FLAGS, *extra, "-o", out, SRC, SRC_HOST, SRC_IO, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

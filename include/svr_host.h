@@ -93,6 +93,18 @@ int svrh_slice_to_volume_registration_gpu(svrh_recon *r, double *transformations
 /* resampled grid of the last svrh_prepare_registration_slices: {x, y, slices} and a copy of the packed data */
 int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_null);
 
+/* ---- NIfTI-1 I/O with the reference's image conventions (csrc/svr_io.cpp) ------------
+ * read : .nii / .nii.gz, any of uint8/int8/int16/uint16/int32/uint32/float32/float64, either byte order,
+ *        scl_slope/scl_inter applied; geometry from the qform, else the sform, else the default matrix, as
+ *        irtkFileNIFTIToImage::ReadHeader does (irtkFileNIFTIToImage.cc:168-345): axes = matrix columns /
+ *        voxel size, origin = world position of the centre voxel.  *data is malloc'ed float[nx*ny*nz*nt]
+ *        (x fastest), release with svr_free.
+ * write: float32 single-file NIfTI-1, qform_code 1 from the image-to-world matrix, sform_code 0
+ *        (irtkImageToFileNIFTI.cc:65-145, irtkNIFTI.h:84-160); ".gz" suffix = gzip. */
+int svr_nifti_read(const char *path, svr_image_attr *attr, int *nt_or_null, float **data, char err[256]);
+int svr_nifti_write(const char *path, const svr_image_attr *attr, const float *data, char err[256]);
+void svr_free(void *p);
+
 /* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
  * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s} */
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,

@@ -1,0 +1,112 @@
+"""NIfTI-1 I/O of the engine library (csrc/svr_io.cpp) with the reference's image conventions
+(irtkFileNIFTIToImage.cc:168-345, irtkImageToFileNIFTI.cc:65-145).  No GPU needed."""
+import gzip
+import struct
+
+import numpy as np
+import pytest
+
+from fetalreconstruction_amd import geometry as geo
+from fetalreconstruction_amd import nifti
+from fetalreconstruction_amd.engine import SvrError
+
+
+def _attr():
+    r = geo.rigid_matrix(rx=20, ry=-35, rz=50)[:3, :3]
+    return geo.ImageAttributes(7, 5, 3, 1.2, 0.9, 2.5, r[:, 0], r[:, 1], r[:, 2], origin=np.array([3.0, -4.5, 10.25]))
+
+
+def _header(dim, pixdim, datatype, bitpix, endian="<", qform=None, sform=None, slope=0.0, inter=0.0, vox_offset=352.0):
+    """A raw 348-byte NIfTI-1 header built field by field from the standard's layout."""
+    h = bytearray(348)
+    struct.pack_into(endian + "i", h, 0, 348)
+    struct.pack_into(endian + "8h", h, 40, *dim)
+    struct.pack_into(endian + "hh", h, 70, datatype, bitpix)
+    struct.pack_into(endian + "8f", h, 76, *pixdim)
+    struct.pack_into(endian + "fff", h, 108, vox_offset, slope, inter)
+    if qform is not None:
+        struct.pack_into(endian + "h", h, 252, 1)
+        struct.pack_into(endian + "6f", h, 256, *qform)
+    if sform is not None:
+        struct.pack_into(endian + "h", h, 254, 1)
+        struct.pack_into(endian + "12f", h, 280, *np.asarray(sform, np.float32).reshape(-1)[:12])
+    h[344:348] = b"n+1\0"
+    return bytes(h) + b"\0\0\0\0"
+
+
+@pytest.mark.parametrize("ext", [".nii", ".nii.gz"])
+def test_write_read_round_trip(tmp_path, ext):
+    a = _attr()
+    d = np.random.default_rng(0).normal(size=(3, 5, 7)).astype(np.float32)
+    p = tmp_path / ("img" + ext)
+    nifti.write(p, d, a)
+    r, ra = nifti.read(p)
+    assert np.array_equal(r, d)
+    assert (ra.nx, ra.ny, ra.nz) == (7, 5, 3)
+    assert np.allclose(geo.image_to_world(ra), geo.image_to_world(a), atol=2e-6)       # float32 header fields
+    assert np.allclose(ra.origin, a.origin, atol=2e-6)
+    raw = (gzip.open(p) if ext.endswith("gz") else open(p, "rb")).read()
+    assert len(raw) == 352 + d.nbytes and raw[344:347] == b"n+1"
+    assert struct.unpack_from("<i", raw, 0)[0] == 348 and struct.unpack_from("<f", raw, 108)[0] == 352.0
+    assert struct.unpack_from("<hh", raw, 252) == (1, 0)                                 # qform only (irtkNIFTI.h:135-145)
+    assert struct.unpack_from("<h", raw, 70)[0] == 16                                    # float32
+
+
+def test_left_handed_axes_use_qfac(tmp_path):
+    a = _attr()
+    a.zaxis = -a.zaxis                                                                   # det < 0
+    d = np.arange(105, dtype=np.float32).reshape(3, 5, 7)
+    nifti.write(tmp_path / "l.nii", d, a)
+    raw = open(tmp_path / "l.nii", "rb").read()
+    assert struct.unpack_from("<f", raw, 76)[0] == -1.0                                  # pixdim[0] = qfac
+    r, ra = nifti.read(tmp_path / "l.nii")
+    assert np.allclose(ra.zaxis, a.zaxis, atol=1e-6) and np.allclose(ra.origin, a.origin, atol=2e-6)
+
+
+def test_sform_only_big_endian_int16_with_scaling(tmp_path):
+    a = _attr()
+    m = geo.image_to_world(a)
+    vals = np.arange(105, dtype=np.int16).reshape(3, 5, 7) - 20
+    raw = _header((3, 7, 5, 3, 1, 1, 1, 1), (1, 1.2, 0.9, 2.5, 1, 1, 1, 1), 4, 16, endian=">", sform=m[:3], slope=0.5,
+                  inter=10.0) + vals.astype(">i2").tobytes()
+    p = tmp_path / "s.nii"
+    p.write_bytes(raw)
+    d, ra = nifti.read(p)
+    assert np.array_equal(d, vals.astype(np.float32) * 0.5 + 10.0)                       # scl_slope / scl_inter
+    assert np.allclose(geo.image_to_world(ra), m, atol=2e-6)
+    # origin = world position of the centre voxel (irtkFileNIFTIToImage.cc:309-325)
+    assert np.allclose(ra.origin, (m @ np.array([3.0, 2.0, 1.0, 1.0]))[:3], atol=2e-6)
+
+
+def test_no_transform_gives_the_default_radiological_frame(tmp_path):
+    raw = _header((3, 4, 3, 2, 1, 1, 1, 1), (1, 2.0, 3.0, 4.0, 1, 1, 1, 1), 2, 8) + bytes(range(24))
+    p = tmp_path / "d.nii"
+    p.write_bytes(raw)
+    d, ra = nifti.read(p)
+    assert d.shape == (2, 3, 4) and d[1, 2, 3] == 23
+    assert np.allclose(ra.xaxis, [-1, 0, 0]) and np.allclose(ra.yaxis, [0, 1, 0]) and np.allclose(ra.zaxis, [0, 0, 1])
+    assert np.allclose(ra.origin, 0)                                                     # :262-289: centred on (0,0,0)
+    assert (ra.dx, ra.dy, ra.dz) == (2.0, 3.0, 4.0)
+
+
+def test_quaternion_of_a_half_turn(tmp_path):
+    a = geo.ImageAttributes(4, 4, 2, 1, 1, 1, np.array([-1.0, 0, 0]), np.array([0, -1.0, 0]), np.array([0, 0, 1.0]),
+                            origin=np.array([1.0, 2.0, 3.0]))                           # rotation by pi about z: a = 0
+    d = np.ones((2, 4, 4), np.float32)
+    nifti.write(tmp_path / "h.nii", d, a)
+    _, ra = nifti.read(tmp_path / "h.nii")
+    assert np.allclose(geo.image_to_world(ra), geo.image_to_world(a), atol=2e-6)
+
+
+def test_errors_are_loud(tmp_path):
+    with pytest.raises(SvrError):
+        nifti.read(tmp_path / "missing.nii")
+    (tmp_path / "junk.nii").write_bytes(b"\0" * 400)
+    with pytest.raises(SvrError):
+        nifti.read(tmp_path / "junk.nii")
+    raw = _header((3, 4, 3, 2, 1, 1, 1, 1), (1, 1, 1, 1, 1, 1, 1, 1), 16, 32) + b"\0" * 10     # truncated data
+    (tmp_path / "short.nii").write_bytes(raw)
+    with pytest.raises(SvrError):
+        nifti.read(tmp_path / "short.nii")
+    with pytest.raises(SvrError):
+        nifti.write(tmp_path / "x.nii", np.zeros((2, 2, 2), np.float32), _attr())               # shape mismatch
