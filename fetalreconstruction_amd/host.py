@@ -20,8 +20,9 @@ HOST_EXPORTS = [
     "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
     "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state", "svrh_set_bias_correction", "svrh_bias_gpu",
     "svrh_normalise_bias_gpu", "svrh_prepare_registration_slices", "svrh_slice_to_volume_registration_gpu",
-    "svrh_get_registration_slices", "svr_nifti_read", "svr_nifti_write", "svr_free",
+    "svrh_get_registration_slices",
 ]
+IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free"]      # csrc/svr_io.cpp, declared in svr_host.h
 
 
 class ImageAttr(C.Structure):
