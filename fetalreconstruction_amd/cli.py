@@ -1,0 +1,145 @@
+"""`SVRreconstructionGPU`-style command line over the MI355X engine: NIfTI stacks + mask in,
+reconstructed volume out.  Mirrors main() of source/reconstructionGPU2/reconstruction.cc ("main.cc"):
+option names and defaults of main.cc:164-211, the set-up of main.cc:386-815 (template, mask, cropping,
+intensity matching, slices, masking) and the registration-reconstruction loop of main.cc:816-1237 with its
+smoothing schedule.
+
+    python -m fetalreconstruction_amd.cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz s3.nii.gz -m mask.nii.gz \\
+        [--thickness 2.5 2.5 2.5] [--resolution 0.75] [--iterations 4] [--useGPUReg]
+
+Differences from the reference CLI, all loud: stack transformations are 4x4 text matrices or `id` (IRTK `dof`
+files and the stack-to-stack registration that refines them are not built); slice-to-volume registration runs
+only with --useGPUReg (the default CPU/IRTK registration is not built: without the flag the slices keep their
+stack transformations); packages, superpixels and the CPU path are refused.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+
+import numpy as np
+
+from . import engine, nifti
+from . import preprocess as pp
+from . import registration as reg
+from .reconstruction import irtkReconstruction
+
+
+def _parser():
+    p = argparse.ArgumentParser(prog="SVRreconstructionGPU (MI355X)", description=__doc__.split("\n\n")[0])
+    p.add_argument("-o", "--output", required=True)
+    p.add_argument("-m", "--mask")
+    p.add_argument("-i", "--input", nargs="+", required=True)
+    p.add_argument("-t", "--transformation", nargs="+")
+    p.add_argument("--thickness", nargs="+", type=float)
+    p.add_argument("--iterations", type=int, default=4)
+    p.add_argument("--sigma", type=float, default=12.0)
+    p.add_argument("--resolution", type=float, default=0.75)
+    p.add_argument("--multires", type=int, default=3)
+    p.add_argument("--average", type=float, default=700.0)
+    p.add_argument("--delta", type=float, default=150.0)
+    p.add_argument("--lambda", dest="lam", type=float, default=0.02)
+    p.add_argument("--lastIterLambda", type=float, default=0.01)
+    p.add_argument("--smooth_mask", type=float, default=4.0)
+    p.add_argument("--no_intensity_matching", action="store_true")
+    p.add_argument("--force_exclude", nargs="+", type=int, default=[])
+    p.add_argument("--rec_iterations_first", type=int, default=4)
+    p.add_argument("--rec_iterations_last", type=int, default=13)
+    p.add_argument("--useGPUReg", action="store_true")
+    p.add_argument("--disableBiasCorrection", action="store_true", default=True)
+    p.add_argument("-d", "--devices", nargs="+", type=int, default=[0])
+    p.add_argument("--debug", action="store_true")
+    for refused in ("--packages", "--useCPU", "--patchBased", "--superpixelBased", "--tfolder", "--sfolder"):
+        p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
+    return p
+
+
+def _load_transformation(spec):
+    if spec == "id":
+        return np.eye(4)
+    m = np.loadtxt(spec, dtype=np.float64)
+    if m.shape != (4, 4):
+        raise SystemExit(f"transformation {spec}: expected a 4x4 text matrix or 'id' (IRTK dof files are not supported)")
+    return m
+
+
+def main(argv=None):
+    a = _parser().parse_args(argv)
+    for refused in ("packages", "useCPU", "patchBased", "superpixelBased", "tfolder", "sfolder"):
+        if getattr(a, refused) is not None:
+            raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/cli.py)")
+    n = len(a.input)
+    stacks = []
+    for path in a.input:                                                    # main.cc:386-430
+        d, at = nifti.read(path)
+        if d.ndim != 3:
+            raise SystemExit(f"{path}: 3-D stacks expected")
+        stacks.append(pp.Image(d.astype(np.float64), at))
+    transformations = [_load_transformation(s) for s in (a.transformation or ["id"] * n)]
+    if len(transformations) != n:
+        raise SystemExit("one transformation per stack expected")
+    thickness = a.thickness or [2.0 * s.attr.dz for s in stacks]           # main.cc:422-431: twice the z spacing
+    if len(thickness) != n:
+        raise SystemExit("one thickness per stack expected")
+    template = next((k for k, s in enumerate(a.transformation or ["id"] * n) if s == "id"), 0)   # first 'id' stack
+    mask = None
+    if a.mask:
+        md, mat = nifti.read(a.mask)
+        mask = pp.Image(md.astype(np.float64), mat)
+
+    # template stack: mask onto its grid, crop (main.cc:583-584)
+    if mask is not None:
+        m = pp.TransformMask(stacks[template].attr, mask, transformations[template])
+        stacks[template] = pp.CropImage(stacks[template], m)
+    tattr, resolution = pp.CreateTemplate(stacks[template].attr, a.resolution)                   # main.cc:607
+    vol_mask = pp.SetMask(tattr, mask, a.smooth_mask)                                            # main.cc:610
+    for k in range(n):                                                                           # main.cc:645-662
+        if k == template:
+            continue
+        m = pp.TransformMask(stacks[k].attr, vol_mask, transformations[k])
+        stacks[k] = pp.CropImage(stacks[k], m)
+    factors = pp.MatchStackIntensitiesWithMasking(stacks, transformations, vol_mask, a.average,
+                                                  together=a.no_intensity_matching)              # main.cc:676-679
+    slices, attrs, slice_t, stack_index = pp.CreateSlicesAndTransformations(stacks, transformations, thickness)
+    slices = pp.MaskSlices(slices, attrs, slice_t, vol_mask)                                     # main.cc:700
+    prob = pp.build_problem(tattr, vol_mask, slices, attrs, slice_t, stack_index)
+    print(f"{n} stacks, {prob.ns} slices of up to {prob.slices.shape[2]}x{prob.slices.shape[1]}, volume {prob.vsize} "
+          f"at {resolution} mm, stack factors {np.round(factors, 3)}", file=sys.stderr)
+
+    rec = engine.Reconstruction(a.devices[0])
+    engine.sync_gpu(rec, prob)                                                                   # SyncGPU, main.cc:722
+    drv = irtkReconstruction(rec, prob.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
+    drv.SetForceExcludedSlices(a.force_exclude)
+    rs = reg.PrepareRegistrationSlices(rec, prob.slices, prob.slice_attr, resolution) if a.useGPUReg else None
+    T = np.stack(slice_t)
+    for it in range(a.iterations):                                                               # main.cc:816-1237
+        if it > 0 and a.useGPUReg:
+            T = reg.SliceToVolumeRegistrationGPU(rec, rs, T)
+            ti = np.stack([np.linalg.inv(t) for t in T])
+            rec.SetSliceMatrices(np.stack([t.astype(np.float32).reshape(16) for t in T]),
+                                 np.stack([t.astype(np.float32).reshape(16) for t in ti]), prob.slice_i2w, prob.slice_w2i,
+                                 prob.slice_i2w, prob.slice_w2i, prob.recon_i2w, prob.recon_w2i)  # UpdateGPUTranformationMatrices
+        if it == a.iterations - 1:                                                               # main.cc:884-896
+            drv.SetSmoothingParameters(a.delta, a.lastIterLambda)
+        else:
+            lam = a.lam
+            for i in range(a.multires):
+                if it == a.iterations * (a.multires - i - 1) // a.multires:
+                    drv.SetSmoothingParameters(a.delta, lam)
+                lam *= 2
+        (drv.SpeedupOn if it < a.iterations - 1 else drv.SpeedupOff)()
+        rec_it = a.rec_iterations_last if it == a.iterations - 1 else a.rec_iterations_first    # main.cc:1001-1012
+        drv.reconstruct_iteration(rec_it)
+        print(f"iteration {it}: sigma {drv._sigma_gpu:.4g} mix {drv._mix_gpu:.3f} "
+              f"excluded slices {int((drv._slice_weight_gpu < 0.5).sum())}", file=sys.stderr)
+    rec.RestoreSliceIntensities(factors, prob.stack_index)                                       # main.cc:1189-1193
+    drv.ScaleVolumeGPU()
+    out = rec.syncCPU().reshape(tattr.nz, tattr.ny, tattr.nx)
+    nifti.write(a.output, out, tattr)
+    if a.debug:
+        np.save(a.output + ".transformations.npy", T)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
