@@ -77,8 +77,9 @@ class OracleReconstruction:
         self.spx_masks = None if spx_masks is None else np.ascontiguousarray(spx_masks, np.uint8)
         self.mode = mode
         self.bias_correction = bool(bias_correction)
-        self._keep = [_f32(prob.slice_i2w), _f32(prob.slice_w2i), _f32(prob.slice_t), _f32(prob.slice_tinv),
-                      _f32(prob.slice_dim)]
+        # private copies: tests edit these through `_keep` and must not touch the (session-wide) problem
+        self._keep = [_f32(prob.slice_i2w).copy(), _f32(prob.slice_w2i).copy(), _f32(prob.slice_t).copy(),
+                      _f32(prob.slice_tinv).copy(), _f32(prob.slice_dim).copy()]
         g = Geom()
         g.vx, g.vy, g.vz = prob.vsize
         g.vdim[:] = prob.vdim
