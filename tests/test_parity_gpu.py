@@ -323,7 +323,7 @@ def test_kernel_variants_agree_at_full_size():
         ps, vol, vw, sim, sw, si, vc = out[name]
         assert np.array_equal(ps != 0, ref[0] != 0) and np.array_equal(vc, ref[6]) and np.array_equal(si, ref[5])
         assert np.allclose(ps, ref[0], rtol=2e-6, atol=0)
-        assert rel_err(vol, ref[1]) < 5e-6 and rel_err(vw, ref[2]) < 5e-6
+        assert rel_err(vol, ref[1]) < TOL_SUM and rel_err(vw, ref[2]) < TOL_SUM     # float atomics in run-dependent order
         assert np.abs(sw - ref[4]).max() < 3e-6 and rel_err(sim, ref[3]) < 5e-6
     rec.set_option("fwd_mode", 3)
     rec.set_option("gauss_mode", 1)
@@ -333,4 +333,4 @@ def test_kernel_variants_agree_at_full_size():
         rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
         res[bm] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
     assert np.array_equal(res[2][1] > 0, res[0][1] > 0)
-    assert rel_err(res[2][1], res[0][1]) < 5e-6 and rel_err(res[2][0], res[0][0]) < 5e-6
+    assert rel_err(res[2][1], res[0][1]) < TOL_SUM and rel_err(res[2][0], res[0][0]) < TOL_SUM
