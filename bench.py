@@ -155,7 +155,7 @@ def main():
         b_back = 4.0 * vs + 12.0 * va_l + 12.0 * nv
         flops = float(va_l) * TAPS * FLOPS_PER_TAP
         out = {
-            "metric": "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR",
+            "metric": "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR, 1/2/4/8 GPU",
             "value": value, "unit": "MVoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
