@@ -18,6 +18,9 @@ INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
 INC_HOST = os.path.join(os.path.dirname(HERE), "include", "svr_host.h")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libsvr_hip.so")
+SRC_CLI = os.path.join(HERE, "csrc", "svr_cli.cpp")       # the SVRreconstructionGPU command line (host C++)
+BIN_DIR = os.path.join(HERE, "bin")
+CLI = os.path.join(BIN_DIR, "SVRreconstructionGPU")
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -39,7 +42,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, INC, INC_HOST, __file__))
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, SRC_CLI, INC, INC_HOST, __file__)) or not os.path.exists(CLI)
 
 
 def build(force=False, verbose=False, extra=(), variant=None):
@@ -53,7 +56,20 @@ def build(force=False, verbose=False, extra=(), variant=None):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if not variant:
+        build_cli(verbose)
     return out
+
+
+def build_cli(verbose=False):
+    """SVRreconstructionGPU: plain host C++ linked against the engine library (found through its rpath)."""
+    os.makedirs(BIN_DIR, exist_ok=True)
+    cxx = shutil.which("g++") or hipcc()
+    cmd = [cxx, "-O2", "-std=c++17", "-o", CLI, SRC_CLI, "-L" + OUT_DIR, "-lsvr_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":
