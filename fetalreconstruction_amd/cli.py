@@ -7,8 +7,8 @@ smoothing schedule.
     python -m fetalreconstruction_amd.cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz s3.nii.gz -m mask.nii.gz \\
         [--thickness 2.5 2.5 2.5] [--resolution 0.75] [--iterations 4] [--useGPUReg]
 
-Differences from the reference CLI, all loud: stack transformations are 4x4 text matrices or `id` (IRTK `dof`
-files and the stack-to-stack registration that refines them are not built); slice-to-volume registration runs
+Differences from the reference CLI, all loud: stack transformations are `id`, IRTK rigid `dof` files or 4x4 text
+matrices, used as given (the stack-to-stack registration that refines them is not built); slice-to-volume registration runs
 only with --useGPUReg (the default CPU/IRTK registration is not built: without the flag the slices keep their
 stack transformations); packages, superpixels and the CPU path are refused.
 """
@@ -57,9 +57,13 @@ def _parser():
 def _load_transformation(spec):
     if spec == "id":
         return np.eye(4)
+    try:
+        return nifti.read_dof(spec)[1]                  # IRTK rigid dof file
+    except engine.SvrError:
+        pass
     m = np.loadtxt(spec, dtype=np.float64)
     if m.shape != (4, 4):
-        raise SystemExit(f"transformation {spec}: expected a 4x4 text matrix or 'id' (IRTK dof files are not supported)")
+        raise SystemExit(f"transformation {spec}: expected 'id', an IRTK rigid dof file or a 4x4 text matrix")
     return m
 
 

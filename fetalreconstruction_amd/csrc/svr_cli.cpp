@@ -12,8 +12,8 @@
 // (irtkReconstructionGPU.cc = "RG.cc"; the line ranges are on each function) and agree with the Python
 // mirror fetalreconstruction_amd/preprocess.py, which the tests compare them with.
 //
-// Not built, refused loudly: IRTK `dof` files (transformations are 4x4 text matrices or `id`), the
-// stack-to-stack registration that refines them (RG.cc:849-1001), the CPU/IRTK slice registration (slice
+// Transformations (-t) are `id`, IRTK rigid `dof` files or 4x4 text matrices, used as given.  Not built, refused
+// loudly: the stack-to-stack registration that refines them (RG.cc:849-1001), the CPU/IRTK slice registration (slice
 // registration runs with --useGPUReg only), packages, patch/superpixel modes, the CPU path.
 #include <math.h>
 #include <stdio.h>
@@ -244,10 +244,13 @@ std::vector<float> match_stack_intensities(std::vector<Image> &stacks, const std
 
 M4 load_transformation(const std::string &spec) {
   if (spec == "id") return ident();
-  std::ifstream f(spec.c_str());
   M4 m;
+  double p6[6];
+  char err[256];
+  if (svr_dof_read(spec.c_str(), p6, m.m, err) == 0) return m;          // IRTK rigid dof file
+  std::ifstream f(spec.c_str());
   for (int i = 0; i < 16; ++i)
-    if (!(f >> m.m[i])) die("transformation " + spec + ": expected a 4x4 text matrix or 'id' (IRTK dof files are not supported)");
+    if (!(f >> m.m[i])) die("transformation " + spec + ": expected 'id', an IRTK rigid dof file or a 4x4 text matrix");
   return m;
 }
 

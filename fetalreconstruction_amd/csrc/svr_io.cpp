@@ -275,6 +275,56 @@ int svr_nifti_write(const char *path, const svr_image_attr *attr, const float *d
   return ok ? SVR_OK : set_err(err, "write failed");
 }
 
+// IRTK rigid `dof` files (irtkRigidTransformation::Read / Write, IRTKSimple2/packages/transformation/src/
+// irtkRigidTransformation.cc:392-451): big-endian (irtkCifstream.cc:18-22), through zlib: uint32 magic 815007,
+// uint32 type 2 (rigid), uint32 dofs 6, then tx ty tz rx ry rz as doubles (mm, degrees).  matrix16 = the
+// homogeneous matrix of irtkRigidTransformation::UpdateMatrix (irtkRigidTransformation.cc:26-53), row-major.
+int svr_dof_read(const char *path, double params6[6], double matrix16[16], char err[256]) {
+  if (!path || !params6) return SVR_E_ARG;
+  gzFile f = gzopen(path, "rb");
+  if (!f) return set_err(err, std::string("cannot open ") + path);
+  unsigned char buf[12 + 48];
+  const int got = gzread(f, buf, sizeof(buf));
+  gzclose(f);
+  if (got != (int)sizeof(buf)) return set_err(err, "short dof file");
+  auto be32 = [&](int o) { return ((uint32_t)buf[o] << 24) | ((uint32_t)buf[o + 1] << 16) | ((uint32_t)buf[o + 2] << 8) | buf[o + 3]; };
+  if (be32(0) != 815007u) return set_err(err, "not an IRTK transformation file (magic != 815007)");
+  if (be32(4) != 2u || be32(8) != 6u) return set_err(err, "only rigid transformations (type 2, 6 dofs) are supported");
+  for (int i = 0; i < 6; ++i) {
+    unsigned char t[8];
+    for (int k = 0; k < 8; ++k) t[k] = buf[12 + 8 * i + 7 - k];
+    memcpy(&params6[i], t, 8);
+  }
+  if (matrix16) {
+    const double k = M_PI / 180.0;
+    const double cx = cos(params6[3] * k), cy = cos(params6[4] * k), cz = cos(params6[5] * k);
+    const double sx = sin(params6[3] * k), sy = sin(params6[4] * k), sz = sin(params6[5] * k);
+    const double m[16] = {cy * cz, cy * sz, -sy, params6[0],
+                          sx * sy * cz - cx * sz, sx * sy * sz + cx * cz, sx * cy, params6[1],
+                          cx * sy * cz + sx * sz, cx * sy * sz - sx * cz, cx * cy, params6[2],
+                          0, 0, 0, 1};
+    memcpy(matrix16, m, sizeof(m));
+  }
+  return SVR_OK;
+}
+
+int svr_dof_write(const char *path, const double params6[6], char err[256]) {
+  if (!path || !params6) return SVR_E_ARG;
+  unsigned char buf[12 + 48];
+  const uint32_t head[3] = {815007u, 2u, 6u};
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 4; ++k) buf[4 * i + k] = (unsigned char)(head[i] >> (24 - 8 * k));
+  for (int i = 0; i < 6; ++i) {
+    unsigned char t[8];
+    memcpy(t, &params6[i], 8);
+    for (int k = 0; k < 8; ++k) buf[12 + 8 * i + k] = t[7 - k];
+  }
+  FILE *f = fopen(path, "wb");
+  if (!f) return set_err(err, std::string("cannot create ") + path);
+  const bool ok = fwrite(buf, 1, sizeof(buf), f) == sizeof(buf);
+  return (fclose(f) == 0 && ok) ? SVR_OK : set_err(err, "write failed");
+}
+
 void svr_free(void *p) { free(p); }
 
 }  // extern "C"

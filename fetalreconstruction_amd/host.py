@@ -22,7 +22,7 @@ HOST_EXPORTS = [
     "svrh_normalise_bias_gpu", "svrh_prepare_registration_slices", "svrh_slice_to_volume_registration_gpu",
     "svrh_get_registration_slices",
 ]
-IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free"]      # csrc/svr_io.cpp, declared in svr_host.h
+IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write"]      # csrc/svr_io.cpp, declared in svr_host.h
 
 
 class ImageAttr(C.Structure):

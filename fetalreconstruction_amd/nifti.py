@@ -44,3 +44,19 @@ def write(path, data, attr):
     rc = _lib().svr_nifti_write(str(path).encode(), C.byref(a), d.ctypes.data_as(C.c_void_p), err)
     if rc != 0:
         raise _engine.SvrError(f"svr_nifti_write({path}): {err.value.decode()}")
+
+
+def read_dof(path):
+    """IRTK rigid `dof` file -> (params [tx ty tz rx ry rz], 4x4 matrix)  (irtkRigidTransformation.cc:26-53, 392-426)"""
+    p6, m = (C.c_double * 6)(), (C.c_double * 16)()
+    err = C.create_string_buffer(256)
+    if _lib().svr_dof_read(str(path).encode(), p6, m, err) != 0:
+        raise _engine.SvrError(f"svr_dof_read({path}): {err.value.decode()}")
+    return np.array(p6[:]), np.array(m[:]).reshape(4, 4)
+
+
+def write_dof(path, params6):
+    err = C.create_string_buffer(256)
+    p6 = (C.c_double * 6)(*[float(v) for v in params6])
+    if _lib().svr_dof_write(str(path).encode(), p6, err) != 0:
+        raise _engine.SvrError(f"svr_dof_write({path}): {err.value.decode()}")

@@ -104,6 +104,10 @@ int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_nul
 int svr_nifti_read(const char *path, svr_image_attr *attr, int *nt_or_null, float **data, char err[256]);
 int svr_nifti_write(const char *path, const svr_image_attr *attr, const float *data, char err[256]);
 void svr_free(void *p);
+/* IRTK rigid transformation files (`dof`, the reference's -t option): big-endian {815007, 2, 6} + tx ty tz rx ry rz
+ * as doubles (irtkRigidTransformation.cc:392-451); matrix16_or_null = UpdateMatrix's 4x4 (:26-53), row-major. */
+int svr_dof_read(const char *path, double params6[6], double *matrix16_or_null, char err[256]);
+int svr_dof_write(const char *path, const double params6[6], char err[256]);
 
 /* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
  * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s} */

@@ -110,3 +110,19 @@ def test_errors_are_loud(tmp_path):
         nifti.read(tmp_path / "short.nii")
     with pytest.raises(SvrError):
         nifti.write(tmp_path / "x.nii", np.zeros((2, 2, 2), np.float32), _attr())               # shape mismatch
+
+
+def test_irtk_dof_files(tmp_path):
+    """Rigid dof: big-endian {815007, 2, 6} + six doubles (irtkRigidTransformation.cc:392-451)."""
+    p = [1.5, -2.25, 3.0, 10.0, -20.0, 30.0]
+    nifti.write_dof(tmp_path / "t.dof", p)
+    raw = (tmp_path / "t.dof").read_bytes()
+    assert len(raw) == 60 and struct.unpack(">III", raw[:12]) == (815007, 2, 6)
+    assert struct.unpack(">6d", raw[12:]) == tuple(p)
+    q, m = nifti.read_dof(tmp_path / "t.dof")
+    assert np.array_equal(q, p) and np.allclose(m, geo.rigid_matrix(*p), atol=1e-15)
+    (tmp_path / "t.dof.gz").write_bytes(gzip.compress(raw))                    # irtkCifstream reads through zlib
+    assert np.array_equal(nifti.read_dof(tmp_path / "t.dof.gz")[0], p)
+    (tmp_path / "bad.dof").write_bytes(struct.pack(">III", 815007, 3, 12) + b"\\0" * 48)
+    with pytest.raises(SvrError):
+        nifti.read_dof(tmp_path / "bad.dof")
