@@ -1,0 +1,147 @@
+"""`PVRreconstructionGPU`-style command line over the MI355X engine (patch-to-volume reconstruction).
+Mirrors main() of source/reconstructionGPU2/patchBasedReconMain.cpp ("pvrmain", options :108-131) and
+irtkPatchBasedReconstruction<T>::run (irtkPatchBasedReconstruction.cpp = "PBR.cpp" :193-593): binarise the mask,
+crop the stacks to it, resample the mask to the isotropic voxel size, match the stack intensities
+(PBR.cpp:656-790: the target is the mean of all positive voxels), create the template (PBR.cpp:941-965: the
+template stack's grid resampled, no extra slices), extract the patches, then `iterations + 1` passes of
+Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
+
+    python -m fetalreconstruction_amd.pvr_cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz -m mask.nii.gz \\
+        [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7] [--sr_iterations 7]
+
+Not built, refused loudly: the stack-to-stack and the patch-to-volume registration (the patches keep their
+stack transformations, so every outer pass after the first repeats it -- `--iterations 0` is the useful
+setting), superpixels / hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import sys
+
+import numpy as np
+
+from . import engine, nifti, pvr
+from . import geometry as geo
+from . import preprocess as pp
+from .cli import _load_transformation
+
+
+def _parser():
+    p = argparse.ArgumentParser(prog="PVRreconstructionGPU (MI355X)", description=__doc__.split("\n\n")[0])
+    p.add_argument("-o", "--output", required=True)
+    p.add_argument("-m", "--mask", required=True)
+    p.add_argument("-i", "--input", nargs="+", required=True)
+    p.add_argument("-t", "--transformation", nargs="+")
+    p.add_argument("--patchSize", nargs=2, type=int, default=[32, 32])
+    p.add_argument("--patchStride", nargs=2, type=int, default=[16, 16])
+    p.add_argument("--resolution", type=float, default=0.75)
+    p.add_argument("--noMatchIntensities", action="store_true")
+    p.add_argument("--iterations", type=int, default=7)
+    p.add_argument("--sr_iterations", type=int, default=7)
+    p.add_argument("--thickness", nargs="+", type=float)
+    p.add_argument("-d", "--devices", nargs="+", type=int, default=[0])
+    for refused in ("--superpixel", "--hierarchical", "--packages", "--existingReconTarget", "--resample", "--dilateMask",
+                    "--useFullSlices"):
+        p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
+    return p
+
+
+def resample_attr(a, d):
+    """irtkResampling::Initialize (irtkResampling.cc:74-130): int(n * d_old / d) voxels of size d, same origin."""
+    r = copy.copy(a)
+    n = [int(a.nx * a.dx / d), int(a.ny * a.dy / d), int(a.nz * a.dz / d)]
+    size = [d, d, d]
+    for k, old in enumerate((a.dx, a.dy, a.dz)):
+        if n[k] < 1:
+            n[k], size[k] = 1, old
+    r.nx, r.ny, r.nz = n
+    r.dx, r.dy, r.dz = size
+    return r
+
+
+def match_stack_intensities_pvr(stacks, transformations, mask, together=False):
+    """PBR.cpp:656-790: like the SVR one, but the target average is the mean of all positive voxels of all stacks
+    and a stack's own average counts only its positive voxels inside the mask."""
+    total, count = np.float32(0), 0                      # m_average_value is a float accumulated voxel by voxel
+    for s in stacks:
+        pos = s.data[s.data > 0].astype(np.float32)
+        if pos.size:
+            total = np.cumsum(np.concatenate([[total], pos]), dtype=np.float32)[-1]
+            count += pos.size
+    average_value = float(np.float32(total / np.float32(count))) if count else 0.0
+    m_w2i, ma = geo.world_to_image(mask.attr), mask.attr
+    averages = []
+    for st, t in zip(stacks, transformations):
+        q = pp._grid(st.attr) @ (m_w2i @ np.asarray(t, np.float64) @ geo.image_to_world(st.attr)).T
+        idx = pp._round_half_away(q[..., :3]).astype(np.int64)
+        ok = ((idx[..., 0] >= 0) & (idx[..., 0] < ma.nx) & (idx[..., 1] >= 0) & (idx[..., 1] < ma.ny) &
+              (idx[..., 2] >= 0) & (idx[..., 2] < ma.nz))
+        mv = mask.data[np.clip(idx[..., 2], 0, ma.nz - 1), np.clip(idx[..., 1], 0, ma.ny - 1),
+                       np.clip(idx[..., 0], 0, ma.nx - 1)]
+        sel = ok & (mv == 1) & (st.data > 0)
+        if not sel.any():
+            raise SystemExit("a stack has no overlap with the ROI")
+        averages.append(float(st.data[sel].sum() / sel.sum()))
+    glob = float(np.mean(averages))
+    for st, av in zip(stacks, averages):
+        f = average_value / (glob if together else av)
+        st.data = np.where(st.data > 0, st.data * f, st.data)
+    return average_value
+
+
+def prepare(stacks, transformations, mask, resolution, template, no_match):
+    """PBR.cpp:197-310 without the stack registration.  Returns (stacks, iso mask, template attributes, recon mask)."""
+    mask = pp.Image((mask.data != 0).astype(np.float64), mask.attr)                      # :201-209
+    for k in range(len(stacks)):                                                          # :229-236
+        m = pp.TransformMask(stacks[k].attr, mask, transformations[k])
+        stacks[k] = pp.CropImage(stacks[k], m)
+    iso_mask = pp.transform_nn(mask, resample_attr(mask.attr, resolution))               # :258-266
+    if not no_match:
+        match_stack_intensities_pvr(stacks, transformations, iso_mask)                   # :291
+    tattr = resample_attr(stacks[template].attr, resolution)                              # CreateTemplate :941-965
+    recon_mask = pp.TransformMask(tattr, iso_mask, transformations[template])            # :303-304
+    return stacks, iso_mask, tattr, recon_mask
+
+
+def _hip_engine(prob, device):
+    rec = engine.Reconstruction(device)                  # raises when the HIP library is missing: no CPU path
+    rec.set_option("pvr", 1)
+    engine.sync_gpu(rec, prob, quality_factor=1.0)       # m_quality_factor = 1 (PBR.cpp:415)
+    return rec
+
+
+def main(argv=None, _engine_factory=_hip_engine):
+    """`_engine_factory` exists for the CPU tests, which drive the same pipeline over the test oracle."""
+    a = _parser().parse_args(argv)
+    for refused in ("superpixel", "hierarchical", "packages", "existingReconTarget", "resample", "dilateMask", "useFullSlices"):
+        if getattr(a, refused) is not None:
+            raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/pvr_cli.py)")
+    n = len(a.input)
+    stacks = []
+    for path in a.input:
+        d, at = nifti.read(path)
+        stacks.append(pp.Image(d.astype(np.float64), at))
+    specs = a.transformation or ["id"] * n
+    ts = [_load_transformation(s) for s in specs]
+    thickness = a.thickness or [2.0 * s.attr.dz for s in stacks]                          # pvrmain: twice the z spacing
+    template = next((k for k, s in enumerate(specs) if s == "id"), 0)
+    md, mat = nifti.read(a.mask)
+    stacks, iso_mask, tattr, recon_mask = prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), a.resolution, template,
+                                                  a.noMatchIntensities)
+    pstacks = [pvr.Stack(s.data.astype(np.float32), s.attr, t, th / 2.0) for s, t, th in zip(stacks, ts, thickness)]
+    prob = pvr.make_pvr_problem(pstacks, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, a.patchSize, a.patchStride)
+    print(f"{n} stacks, {prob.ns} patches of {a.patchSize[0]}x{a.patchSize[1]} {prob.patches_per_stack}, volume {prob.vsize} at "
+          f"{a.resolution} mm", file=sys.stderr)
+    rec = _engine_factory(prob, a.devices[0])
+    drv = pvr.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, prob.min_intensity, prob.max_intensity)
+    for it in range(a.iterations + 1):                                                    # PBR.cpp:445
+        drv.reconstruct_iteration(a.sr_iterations)
+        print(f"iteration {it}: sigma {float(drv.m_sigma_gpu):.4g} mix {float(drv.m_mix_gpu):.3f}", file=sys.stderr)
+    out = rec.syncCPU().reshape(tattr.nz, tattr.ny, tattr.nx)
+    nifti.write(a.output, out, tattr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -259,3 +259,96 @@ def test_pvr_loop_against_golden():
     assert np.allclose(d.scale, g["pvr_scale"], rtol=1e-4)
     assert np.allclose(d.patch_weight, g["pvr_patch_weight"], atol=1e-3)
     assert rel_err(rec.syncCPU(), g["pvr_recon"]) < 1e-4
+
+
+# ---- the PVRreconstructionGPU command line (pvr_cli.py) -------------------------------------------
+def _write_pvr_case(tmp_path):
+    from fetalreconstruction_amd import nifti
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(2, (30, 30, 7), 1.1, 2.2, None, 1.0, 11.0, seed=4,
+                                                            orientations=("ax", "sag"), stack_motion_mm=0.0, stack_motion_deg=0.0)
+    paths = []
+    for k, st in enumerate(stacks):
+        nifti.write(tmp_path / f"s{k}.nii.gz", st.data, st.attr)
+        paths.append(str(tmp_path / f"s{k}.nii.gz"))
+    m = rmask.copy()
+    m[m > 0] = 3                                                             # any non-zero label: run() binarises it
+    nifti.write(tmp_path / "mask.nii.gz", m, rattr)
+    return paths, str(tmp_path / "mask.nii.gz"), stacks
+
+
+def _check_pvr_volume(path, stacks):
+    from fetalreconstruction_amd import nifti
+    vol, va = nifti.read(path)
+    assert abs(va.dx - 1.0) < 1e-6 and abs(va.dz - 1.0) < 1e-6
+    # CreateTemplate (PBR.cpp:941-965): the cropped template stack's box at the new voxel size, no extra slices
+    kk, jj, ii = np.meshgrid(np.arange(va.nz), np.arange(va.ny), np.arange(va.nx), indexing="ij")
+    w = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(float) @ geo.image_to_world(va).T
+    truth = phantom.phantom_intensity(w[..., :3], 11.0)
+    inside = (np.sum(w[..., :3] ** 2, -1) < 9.0 ** 2) & (vol > 0)
+    assert inside.sum() > 1500
+    cc = np.corrcoef(vol[inside], truth[inside])[0, 1]
+    print('correlation with the phantom', cc)
+    assert cc > 0.6             # coarse case (4.4 mm thick patches of two 7-slice stacks): the same stacks fed straight
+                                # to make_pvr_problem on the phantom's own grid reach 0.74
+    return vol, va
+
+
+def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
+    """File reading, mask handling, cropping, intensity matching, template, patches and the loop, with the test
+    oracle standing in for the engine (CPU suite)."""
+    from fetalreconstruction_amd import nifti, pvr_cli
+    from fetalreconstruction_amd import preprocess as pp
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    seen = {}
+
+    def factory(prob, device):
+        seen["prob"] = prob
+        return oracle_mod.OracleReconstruction(prob, oracle_mod.CANON, pvr=True)
+
+    out = tmp_path / "o.nii.gz"
+    assert pvr_cli.main(["-o", str(out), "-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8",
+                         "--resolution", "1.0", "--iterations", "0", "--sr_iterations", "2"], _engine_factory=factory) == 0
+    vol, va = _check_pvr_volume(out, stacks)
+    P = seen["prob"]
+    assert P.vsize == (va.nx, va.ny, va.nz) and len(P.patches_per_stack) == 2 and min(P.patches_per_stack) > 10
+    # intensity matching (PBR.cpp:656-790): every stack's in-mask average becomes the same value
+    means = [P.slices[P.stack_index == k][P.slices[P.stack_index == k] > 0].mean() for k in range(2)]
+    assert abs(means[0] / means[1] - 1) < 0.05
+    with pytest.raises(SystemExit, match="not supported"):
+        pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--superpixel"], _engine_factory=factory)
+
+
+def test_pvr_intensity_matching_rules():
+    from fetalreconstruction_amd import pvr_cli
+    from fetalreconstruction_amd import preprocess as pp
+    a = geo.ImageAttributes(8, 8, 4, 1.0, 1.0, 2.0)
+    rng = np.random.default_rng(0)
+    s0 = pp.Image(rng.uniform(50, 150, (4, 8, 8)), a)
+    s1 = pp.Image(rng.uniform(200, 400, (4, 8, 8)), a)
+    s1.data[0] = -1.0                                                        # padding stays untouched
+    s0.data[1, 2, 3] = 0.0
+    mask = pp.Image(np.zeros((8, 8, 8)), geo.ImageAttributes(8, 8, 8, 1.0, 1.0, 1.0))
+    mask.data[2:6, 2:6, 2:6] = 1
+    before = [s0.data.copy(), s1.data.copy()]
+    av = pvr_cli.match_stack_intensities_pvr([s0, s1], [np.eye(4)] * 2, mask)
+    allpos = np.concatenate([b[b > 0] for b in before])
+    assert av == pytest.approx(allpos.mean(), rel=1e-5)
+    assert (s1.data[0] == -1).all() and s0.data[1, 2, 3] == 0
+    for st, b in zip((s0, s1), before):
+        f = st.data[b > 0] / b[b > 0]
+        assert np.allclose(f, f[0])                                          # one factor per stack
+    # resample_attr: int(n d / iso) voxels, same origin and axes
+    r = pvr_cli.resample_attr(a, 0.75)
+    assert (r.nx, r.ny, r.nz) == (10, 10, 10) and r.dx == 0.75 and np.allclose(r.origin, a.origin)
+    r = pvr_cli.resample_attr(geo.ImageAttributes(8, 8, 1, 1.0, 1.0, 0.5), 0.75)
+    assert r.nz == 1 and r.dz == 0.5                                         # a dimension never drops below one voxel
+
+
+@pytest.mark.gpu
+def test_pvr_command_line_end_to_end(tmp_path):
+    from fetalreconstruction_amd import pvr_cli
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    out = tmp_path / "o.nii.gz"
+    assert pvr_cli.main(["-o", str(out), "-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8",
+                         "--resolution", "1.0", "--iterations", "1", "--sr_iterations", "3"]) == 0
+    _check_pvr_volume(out, stacks)
