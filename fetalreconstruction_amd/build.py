@@ -14,13 +14,17 @@ SRC = os.path.join(HERE, "csrc", "svr_hip.hip")
 SRC_REG = os.path.join(HERE, "csrc", "svr_reg.inc")       # GPU registration, #included by svr_hip.hip
 SRC_HOST = os.path.join(HERE, "csrc", "svr_host.cpp")     # plain host C++ (the irtkReconstruction mirror)
 SRC_IO = os.path.join(HERE, "csrc", "svr_io.cpp")         # NIfTI-1 reader / writer (zlib)
+SRC_PVR_HOST = os.path.join(HERE, "csrc", "pvr_host.cpp")  # the irtkPatchBasedReconstruction loop (host C++)
+SRC_PREP = os.path.join(HERE, "csrc", "svr_prep.h")       # pre-processing shared by the two command lines
 INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
 INC_HOST = os.path.join(os.path.dirname(HERE), "include", "svr_host.h")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libsvr_hip.so")
 SRC_CLI = os.path.join(HERE, "csrc", "svr_cli.cpp")       # the SVRreconstructionGPU command line (host C++)
+SRC_PVR_CLI = os.path.join(HERE, "csrc", "pvr_cli.cpp")   # the PVRreconstructionGPU command line (host C++)
 BIN_DIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BIN_DIR, "SVRreconstructionGPU")
+PVR_CLI = os.path.join(BIN_DIR, "PVRreconstructionGPU")
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -42,7 +46,8 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, SRC_CLI, INC, INC_HOST, __file__)) or not os.path.exists(CLI)
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_PREP, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
+                                               __file__)) or not (os.path.exists(CLI) and os.path.exists(PVR_CLI))
 
 
 def build(force=False, verbose=False, extra=(), variant=None):
@@ -52,7 +57,7 @@ def build(force=False, verbose=False, extra=(), variant=None):
     if not variant and not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra, "-o", out, SRC, SRC_HOST, SRC_IO, "-lz"]
+    cmd = [hipcc(), *FLAGS, *extra, "-o", out, SRC, SRC_HOST, SRC_PVR_HOST, SRC_IO, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -62,13 +67,14 @@ def build(force=False, verbose=False, extra=(), variant=None):
 
 
 def build_cli(verbose=False):
-    """SVRreconstructionGPU: plain host C++ linked against the engine library (found through its rpath)."""
+    """SVRreconstructionGPU and PVRreconstructionGPU: plain host C++ linked against the engine library (found through its rpath)."""
     os.makedirs(BIN_DIR, exist_ok=True)
     cxx = shutil.which("g++") or hipcc()
-    cmd = [cxx, "-O2", "-std=c++17", "-o", CLI, SRC_CLI, "-L" + OUT_DIR, "-lsvr_hip", "-Wl,-rpath,$ORIGIN/../lib"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    for exe, src in ((CLI, SRC_CLI), (PVR_CLI, SRC_PVR_CLI)):
+        cmd = [cxx, "-O2", "-std=c++17", "-o", exe, src, "-L" + OUT_DIR, "-lsvr_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return CLI
 
 

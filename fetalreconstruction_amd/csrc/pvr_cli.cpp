@@ -1,0 +1,273 @@
+// pvr_cli.cpp -- `PVRreconstructionGPU`: the reference's patch-to-volume command line (source/reconstructionGPU2/
+// patchBasedReconMain.cpp, "pvrmain") over the MI355X engine, in C++ like the reference's own main().
+//
+//   PVRreconstructionGPU -o recon.nii.gz -i s1.nii.gz s2.nii.gz ... -m mask.nii.gz [--patchSize 32 32]
+//                        [--patchStride 16 16] [--resolution 0.75] [--iterations 7] [--sr_iterations 7] ...
+//
+// Option names and defaults: pvrmain:108-131.  Set-up (irtkPatchBasedReconstruction<T>::run,
+// irtkPatchBasedReconstruction.cpp = "PBR.cpp" :193-310): binarise the mask, crop every stack to it, resample the
+// mask to the isotropic voxel size (nearest neighbour), match the stack intensities (:656-790, target = mean of all
+// positive voxels), min/max intensities (:792-814), CreateTemplate (:941-965), the reconstruction mask (:303-304);
+// then PatchBasedVolume::generate2DPatches per stack (patchBasedObject.cuh:176-342) and `iterations + 1` passes of
+// the loop in csrc/pvr_host.cpp (PBR.cpp:445-593).  The Python twin is fetalreconstruction_amd/pvr_cli.py.
+//
+// Not built, refused loudly: stack-to-stack and patch-to-volume registration (patches keep their stack
+// transformations, so the passes after the first repeat it), superpixels / hierarchical mode, packages,
+// --existingReconTarget, --resample, --dilateMask, --useFullSlices.
+#include "svr_prep.h"
+
+namespace {
+
+// irtkResampling::Initialize (irtkResampling.cc:74-130): int(n d_old / d) voxels of size d, same axes and origin
+svr_image_attr resample_attr(const svr_image_attr &in, double d) {
+  svr_image_attr a = in;
+  int n[3] = {(int)(a.nx * a.dx / d), (int)(a.ny * a.dy / d), (int)(a.nz * a.dz / d)};
+  double s[3] = {d, d, d};
+  const double old[3] = {a.dx, a.dy, a.dz};
+  for (int k = 0; k < 3; ++k) if (n[k] < 1) { n[k] = 1; s[k] = old[k]; }
+  a.nx = n[0]; a.ny = n[1]; a.nz = n[2]; a.dx = s[0]; a.dy = s[1]; a.dz = s[2];
+  return a;
+}
+
+// MatchStackIntensitiesWithMasking PBR.cpp:656-790
+void match_stack_intensities_pvr(std::vector<Image> &stacks, const std::vector<M4> &ts, const Image &mask) {
+  float average = 0;                                    // T m_average_value, accumulated voxel by voxel
+  unsigned long long count = 0;
+  for (const Image &s : stacks)
+    for (double v : s.d)
+      if (v > 0) { average += (float)v; count++; }
+  if (count) average /= count;
+  const M4 mw2i = world_to_image(mask.a);
+  std::vector<double> avg;
+  for (size_t s = 0; s < stacks.size(); ++s) {
+    const Image &st = stacks[s];
+    const M4 m = mul(mw2i, mul(ts[s], image_to_world(st.a)));
+    double sum = 0, num = 0;
+    for (int z = 0; z < st.a.nz; ++z)
+      for (int y = 0; y < st.a.ny; ++y)
+        for (int x = 0; x < st.a.nx; ++x) {
+          const long i = (long)irtk_round(m.m[0] * x + m.m[1] * y + m.m[2] * z + m.m[3]);
+          const long j = (long)irtk_round(m.m[4] * x + m.m[5] * y + m.m[6] * z + m.m[7]);
+          const long k = (long)irtk_round(m.m[8] * x + m.m[9] * y + m.m[10] * z + m.m[11]);
+          if (i >= 0 && i < mask.a.nx && j >= 0 && j < mask.a.ny && k >= 0 && k < mask.a.nz &&
+              mask.at((int)i, (int)j, (int)k) == 1 && st.at(x, y, z) > 0) {
+            sum += st.at(x, y, z);
+            num += 1;
+          }
+        }
+    if (!(num > 0)) die("a stack has no overlap with the ROI");
+    avg.push_back(sum / num);
+  }
+  for (size_t s = 0; s < stacks.size(); ++s) {
+    const double f = average / avg[s];
+    for (double &v : stacks[s].d) if (v > 0) v = (double)(float)(v * f);      // float voxels times a double factor
+  }
+}
+
+struct Patches {
+  std::vector<float> data, i2w, w2i;                   // [n][py][px], [n][16], [n][16]
+  int n = 0;
+};
+
+// PatchBasedVolume<T>::generate2DPatches, patchBasedObject.cuh:176-342
+void generate_2d_patches(const Image &stack, double thickness, const Image &mask, int px, int py, int sx, int sy, Patches &out) {
+  const svr_image_attr &a = stack.a;
+  const M4 s_i2w = image_to_world(a), m_w2i = world_to_image(mask.a);
+  std::vector<float> patch((size_t)px * py);
+  for (int z = 0; z < a.nz; ++z) {
+    svr_image_attr sl = a;                               // GetRegion(0, 0, z, x, y, z + 1) + PutPixelSize :202-203
+    sl.nz = 1;
+    sl.dz = thickness * 2;
+    const double c[3] = {(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, (double)z};
+    for (int k = 0; k < 3; ++k) sl.origin[k] = s_i2w.m[4 * k] * c[0] + s_i2w.m[4 * k + 1] * c[1] + s_i2w.m[4 * k + 2] * c[2] + s_i2w.m[4 * k + 3];
+    const M4 sl_i2w = image_to_world(sl), sl_w2i = world_to_image(sl);
+    svr_image_attr p0 = sl;
+    p0.nx = px; p0.ny = py;
+    p0.origin[0] = p0.origin[1] = p0.origin[2] = 0;
+    const M4 p0_i2w = image_to_world(p0);
+    for (int y = 0; y < a.ny + py; y += sy)
+      for (int x = 0; x < a.nx + px; x += sx) {
+        svr_image_attr pa = p0;                          // shift the origin so that pixel (0,0) sits on slice pixel (x,y) :232-246
+        for (int k = 0; k < 3; ++k) pa.origin[k] = (sl_i2w.m[4 * k] * x + sl_i2w.m[4 * k + 1] * y + sl_i2w.m[4 * k + 3]) - p0_i2w.m[4 * k + 3];
+        const M4 p_i2w = image_to_world(pa);
+        const M4 to_slice = mul(sl_w2i, p_i2w), to_mask = mul(m_w2i, p_i2w);
+        int set_count = 0;
+        for (int j = 0; j < py; ++j)
+          for (int i = 0; i < px; ++i) {
+            const double xx = to_slice.m[0] * i + to_slice.m[1] * j + to_slice.m[3], yy = to_slice.m[4] * i + to_slice.m[5] * j + to_slice.m[7];
+            const double x1 = to_mask.m[0] * i + to_mask.m[1] * j + to_mask.m[3], y1 = to_mask.m[4] * i + to_mask.m[5] * j + to_mask.m[7],
+                         z1 = to_mask.m[8] * i + to_mask.m[9] * j + to_mask.m[11];
+            float v = 0;                                 // a patch starts as an all-zero image
+            if (xx >= 0 && yy >= 0 && xx < a.nx && yy < a.ny && x1 >= 0 && y1 >= 0 && z1 >= 0 && x1 < mask.a.nx && y1 < mask.a.ny &&
+                z1 < mask.a.nz && mask.at((int)x1, (int)y1, (int)z1) > 0) {
+              v = (float)stack.at((int)xx, (int)yy, z);
+              if (v != 0 && v != -1) set_count++;
+            }
+            patch[(size_t)j * px + i] = v;
+          }
+        if (set_count > 1.0f / 3.0f * py * px) {         // :318
+          out.data.insert(out.data.end(), patch.begin(), patch.end());
+          float f[16];
+          to_f16(p_i2w, f); out.i2w.insert(out.i2w.end(), f, f + 16);
+          to_f16(world_to_image(pa), f); out.w2i.insert(out.w2i.end(), f, f + 16);
+          out.n++;
+        }
+      }
+  }
+}
+
+#define PVRH(call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + pvrh_last_error(host)); } while (0)
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  prog_name = "PVRreconstructionGPU";
+  std::string output, mask_name;
+  std::vector<std::string> inputs, tspecs;
+  std::vector<double> thickness;
+  std::vector<int> devices, psize, pstride;
+  int iterations = 7, sr_iterations = 7;
+  double resolution = 0.75;
+  bool no_matching = false, dry_run = false;
+  std::string dump_name;                                 // test hooks: --dumpProblem <file> [--dryRun]
+  // ---- options (pvrmain:108-131) ---------------------------------------------------------------------
+  auto is_opt = [](const char *s) { return s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.'; };
+  for (int i = 1; i < argc; ++i) {
+    const std::string o = argv[i];
+    auto multi = [&](std::vector<std::string> &dst) { while (i + 1 < argc && !is_opt(argv[i + 1])) dst.push_back(argv[++i]); };
+    auto ints = [&](std::vector<int> &dst) { std::vector<std::string> v; multi(v); for (auto &s : v) dst.push_back(atoi(s.c_str())); };
+    auto one = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + o); return argv[++i]; };
+    if (o == "-o" || o == "--output") output = one();
+    else if (o == "-m" || o == "--mask") mask_name = one();
+    else if (o == "-i" || o == "--input") multi(inputs);
+    else if (o == "-t" || o == "--transformation") multi(tspecs);
+    else if (o == "--thickness") { std::vector<std::string> v; multi(v); for (auto &s : v) thickness.push_back(atof(s.c_str())); }
+    else if (o == "--patchSize") ints(psize);
+    else if (o == "--patchStride") ints(pstride);
+    else if (o == "--resolution") resolution = atof(one().c_str());
+    else if (o == "--iterations") iterations = atoi(one().c_str());
+    else if (o == "--sr_iterations") sr_iterations = atoi(one().c_str());
+    else if (o == "--noMatchIntensities") no_matching = true;
+    else if (o == "-d" || o == "--devices") ints(devices);
+    else if (o == "--dumpProblem") dump_name = one();
+    else if (o == "--dryRun") dry_run = true;
+    else if (o == "-h" || o == "--help") {
+      printf("usage: PVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> -m <mask> [-t id|<dof>|<4x4.txt> ..]\n"
+             "       [--thickness th_1 ..] [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7]\n"
+             "       [--sr_iterations 7] [--noMatchIntensities] [-d device]\n");
+      return 0;
+    } else {
+      die("option " + o + " is not supported by this build (see csrc/pvr_cli.cpp)");
+    }
+  }
+  if (output.empty() || inputs.empty() || mask_name.empty()) die("-o, -i and -m are required (try --help)");
+  if (psize.empty()) psize = {32, 32};
+  if (pstride.empty()) pstride = {16, 16};
+  if (psize.size() != 2 || pstride.size() != 2 || psize[0] < 1 || psize[1] < 1 || pstride[0] < 1 || pstride[1] < 1)
+    die("--patchSize and --patchStride take two positive integers");
+  const size_t n = inputs.size();
+  if (tspecs.empty()) tspecs.assign(n, "id");
+  if (tspecs.size() != n) die("one transformation per stack expected");
+
+  // ---- set-up (pvrmain:184-257, PBR.cpp:193-310) --------------------------------------------------------
+  std::vector<Image> stacks;
+  std::vector<M4> ts;
+  for (size_t k = 0; k < n; ++k) { stacks.push_back(read_image(inputs[k])); ts.push_back(load_transformation(tspecs[k])); }
+  std::vector<double> half_thickness;                    // m_thickness: dz, or the given thickness / 2 (pvrmain:209-217)
+  if (thickness.empty()) for (auto &s : stacks) half_thickness.push_back(s.a.dz);
+  else { if (thickness.size() != n) die("one thickness per stack expected"); for (double t : thickness) half_thickness.push_back(t / 2.0); }
+  size_t tmpl = 0;
+  for (size_t k = 0; k < n; ++k) if (tspecs[k] == "id") { tmpl = k; break; }
+  Image mask = read_image(mask_name);
+  for (double &v : mask.d) v = ((long long)v == 0) ? 0.0 : 1.0;                               // PBR.cpp:201-209
+  for (size_t k = 0; k < n; ++k) {                                                               // :229-236
+    const Image m = transform_nn(mask, stacks[k].a, ts[k], 0.0);
+    stacks[k] = crop_image(stacks[k], m);
+  }
+  const Image iso_mask = transform_nn(mask, resample_attr(mask.a, resolution), ident(), 0.0);    // :258-266
+  if (!no_matching) match_stack_intensities_pvr(stacks, ts, iso_mask);                           // :288-294
+  float vmin = 3.402823466e38f, vmax = 1.175494351e-38f;                                         // computeMinMaxIntensities :792-814
+  for (const Image &s : stacks)
+    for (double v : s.d)
+      if (v > 0) { vmax = std::max(vmax, (float)v); vmin = std::min(vmin, (float)v); }
+  const svr_image_attr tattr = resample_attr(stacks[tmpl].a, resolution);                        // CreateTemplate :941-965
+  const Image recon_mask = transform_nn(iso_mask, tattr, ts[tmpl], 0.0);                         // :303-304
+
+  // ---- patches (PBR.cpp:385-399) -----------------------------------------------------------------------
+  const int px = psize[0], py = psize[1];
+  Patches P;
+  std::vector<int> counts;
+  std::vector<float> st, sti, dims;
+  for (size_t k = 0; k < n; ++k) {
+    const int before = P.n;
+    generate_2d_patches(stacks[k], half_thickness[k], iso_mask, px, py, pstride[0], pstride[1], P);
+    counts.push_back(P.n - before);
+    float t[16], ti[16];
+    to_f16(ts[k], t); to_f16(inverse_rigid_or_affine(ts[k]), ti);
+    for (int q = before; q < P.n; ++q) {
+      st.insert(st.end(), t, t + 16); sti.insert(sti.end(), ti, ti + 16);
+      dims.push_back((float)stacks[k].a.dx); dims.push_back((float)stacks[k].a.dy); dims.push_back((float)stacks[k].a.dz);   // getDim()
+    }
+  }
+  const int ns = P.n;
+  if (ns == 0) die("no patch overlaps the mask");
+  fprintf(stderr, "%zu stacks, %d patches of %dx%d, volume %dx%dx%d at %g mm\n", n, ns, px, py, tattr.nx, tattr.ny, tattr.nz, resolution);
+
+  if (!dump_name.empty()) {                              // what the engine is about to receive, for the CPU tests
+    FILE *f = fopen(dump_name.c_str(), "wb");
+    if (!f) die("cannot write " + dump_name);
+    const int hdr[8] = {ns, px, py, (int)n, tattr.nx, tattr.ny, tattr.nz, 0};
+    const float mm[2] = {vmin, vmax};
+    std::vector<float> mf(recon_mask.d.begin(), recon_mask.d.end());
+    fwrite(hdr, sizeof(int), 8, f); fwrite(counts.data(), sizeof(int), n, f); fwrite(mm, sizeof(float), 2, f);
+    fwrite(P.data.data(), sizeof(float), P.data.size(), f); fwrite(P.i2w.data(), sizeof(float), P.i2w.size(), f);
+    fwrite(mf.data(), sizeof(float), mf.size(), f);
+    fclose(f);
+  }
+  if (dry_run) return 0;
+
+  // ---- upload (the engine in PVR mode; m_quality_factor = 1, PBR.cpp:415) -----------------------------------
+  svr_ctx *ctx = nullptr;
+  if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
+  ENG(svr_set_option(ctx, "pvr", 1));
+  const uint32_t vsize[3] = {(uint32_t)tattr.nx, (uint32_t)tattr.ny, (uint32_t)tattr.nz};
+  const float vdim[3] = {(float)tattr.dx, (float)tattr.dy, (float)tattr.dz};
+  std::vector<float> maskf(recon_mask.d.begin(), recon_mask.d.end());
+  float ri2w[16], rw2i[16];
+  to_f16(image_to_world(tattr), ri2w); to_f16(world_to_image(tattr), rw2i);
+  ENG(svr_init_reconstruction_volume(ctx, vsize, vdim, nullptr, 12.0f));
+  ENG(svr_set_mask(ctx, vsize, vdim, maskf.data(), 12.0f));
+  const uint32_t ssize[3] = {(uint32_t)px, (uint32_t)py, (uint32_t)ns};
+  std::vector<int> sizes_x(ns, px), sizes_y(ns, py);
+  ENG(svr_init_storage_volumes(ctx, ssize, &dims[0]));
+  ENG(svr_fill_slices(ctx, P.data.data(), sizes_x.data(), sizes_y.data()));
+  ENG(svr_set_slice_dims(ctx, dims.data(), 1.0f));
+  {
+    svr_image_attr pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.nx = pa.ny = pa.nz = 128; pa.dx = tattr.dx; pa.dy = tattr.dy; pa.dz = tattr.dz;
+    pa.xaxis[0] = pa.yaxis[1] = pa.zaxis[2] = 1.0;
+    float pi2w[16], pw2i[16];
+    to_f16(image_to_world(pa), pi2w); to_f16(world_to_image(pa), pw2i);
+    const uint32_t psz[3] = {128, 128, 128};
+    ENG(svr_generate_psf_volume(ctx, nullptr, psz, &dims[0], vdim, pi2w, pw2i, 1.0f));
+  }
+  ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), P.i2w.data(), P.w2i.data(), P.i2w.data(), P.w2i.data(), ri2w, rw2i));
+
+  // ---- the loop (PBR.cpp:445-593) ----------------------------------------------------------------------------
+  pvrh_recon *host = pvrh_create(ctx, counts.data(), (int)counts.size(), vmin, vmax);
+  if (!host) die("pvrh_create failed");
+  for (int it = 0; it < iterations + 1; ++it) {
+    PVRH(pvrh_reconstruct_iteration(host, sr_iterations));
+    double sc[8];
+    pvrh_get_state(host, nullptr, nullptr, nullptr, sc);
+    fprintf(stderr, "iteration %d: sigma %.4g mix %.3f\n", it, sc[0], sc[1]);
+  }
+  std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
+  ENG(svr_sync_cpu(ctx, vol.data()));
+  char err[256] = {0};
+  if (svr_nifti_write(output.c_str(), &tattr, vol.data(), err)) die(output + ": " + err);
+  pvrh_destroy(host);
+  svr_destroy(ctx);
+  return 0;
+}

@@ -15,251 +15,8 @@
 // Transformations (-t) are `id`, IRTK rigid `dof` files or 4x4 text matrices, used as given.  Not built, refused
 // loudly: the stack-to-stack registration that refines them (RG.cc:849-1001), the CPU/IRTK slice registration (slice
 // registration runs with --useGPUReg only), packages, patch/superpixel modes, the CPU path.
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
+#include "svr_prep.h"
 
-#include <algorithm>
-#include <fstream>
-#include <string>
-#include <vector>
-
-#include "../../include/svr_host.h"
-
-namespace {
-
-struct M4 { double m[16]; };
-M4 ident() { M4 c; for (int i = 0; i < 16; ++i) c.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return c; }
-M4 mul(const M4 &a, const M4 &b) {
-  M4 c;
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
-      double t = 0;
-      for (int k = 0; k < 4; ++k) t += a.m[4 * i + k] * b.m[4 * k + j];
-      c.m[4 * i + j] = t;
-    }
-  return c;
-}
-M4 image_to_world(const svr_image_attr &a) {          // irtkBaseImage.cc:79-111
-  M4 t1 = ident(), sc = ident(), rot = ident(), t2 = ident();
-  t1.m[3] = -(a.nx - 1) / 2.0; t1.m[7] = -(a.ny - 1) / 2.0; t1.m[11] = -(a.nz - 1) / 2.0;
-  sc.m[0] = a.dx; sc.m[5] = a.dy; sc.m[10] = a.dz;
-  for (int k = 0; k < 3; ++k) { rot.m[4 * k] = a.xaxis[k]; rot.m[4 * k + 1] = a.yaxis[k]; rot.m[4 * k + 2] = a.zaxis[k]; }
-  for (int k = 0; k < 3; ++k) t2.m[4 * k + 3] = a.origin[k];
-  return mul(t2, mul(rot, mul(sc, t1)));
-}
-M4 world_to_image(const svr_image_attr &a) {          // irtkBaseImage.cc:113-147
-  M4 t1 = ident(), rot = ident(), sc = ident(), t2 = ident();
-  for (int k = 0; k < 3; ++k) t1.m[4 * k + 3] = -a.origin[k];
-  for (int k = 0; k < 3; ++k) { rot.m[k] = a.xaxis[k]; rot.m[4 + k] = a.yaxis[k]; rot.m[8 + k] = a.zaxis[k]; }
-  sc.m[0] = 1.0 / a.dx; sc.m[5] = 1.0 / a.dy; sc.m[10] = 1.0 / a.dz;
-  t2.m[3] = (a.nx - 1) / 2.0; t2.m[7] = (a.ny - 1) / 2.0; t2.m[11] = (a.nz - 1) / 2.0;
-  return mul(t2, mul(sc, mul(rot, t1)));
-}
-M4 inverse_rigid_or_affine(const M4 &a) {             // Gauss-Jordan on the 4x4
-  double w[4][8];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) { w[i][j] = a.m[4 * i + j]; w[i][4 + j] = (i == j) ? 1.0 : 0.0; }
-  for (int c = 0; c < 4; ++c) {
-    int p = c;
-    for (int r = c + 1; r < 4; ++r) if (fabs(w[r][c]) > fabs(w[p][c])) p = r;
-    for (int j = 0; j < 8; ++j) std::swap(w[c][j], w[p][j]);
-    const double d = w[c][c];
-    for (int j = 0; j < 8; ++j) w[c][j] /= d;
-    for (int r = 0; r < 4; ++r)
-      if (r != c) { const double f = w[r][c]; for (int j = 0; j < 8; ++j) w[r][j] -= f * w[c][j]; }
-  }
-  M4 o;
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) o.m[4 * i + j] = w[i][4 + j];
-  return o;
-}
-double irtk_round(double x) { return x > 0 ? floor(x + 0.5) : ceil(x - 0.5); }   // irtkCommon.h:85-88
-
-struct Image {
-  svr_image_attr a;
-  std::vector<double> d;                              // [z][y][x]
-  double &at(int x, int y, int z) { return d[((size_t)z * a.ny + y) * a.nx + x]; }
-  double at(int x, int y, int z) const { return d[((size_t)z * a.ny + y) * a.nx + x]; }
-};
-
-void die(const std::string &m) { fprintf(stderr, "SVRreconstructionGPU: %s\n", m.c_str()); exit(1); }
-
-Image read_image(const std::string &path) {
-  Image im;
-  float *data = nullptr;
-  int nt = 1;
-  char err[256] = {0};
-  if (svr_nifti_read(path.c_str(), &im.a, &nt, &data, err)) die(path + ": " + err);
-  if (nt != 1) die(path + ": 3-D image expected");
-  const size_t n = (size_t)im.a.nx * im.a.ny * im.a.nz;
-  im.d.assign(data, data + n);
-  svr_free(data);
-  return im;
-}
-
-// CreateTemplate RG.cc:648-694 (+ irtkResampling::Initialize, irtkResampling.cc:74-130)
-svr_image_attr create_template(const svr_image_attr &stack, double &resolution) {
-  svr_image_attr a = stack;
-  a.nz += 2;
-  double d = resolution;
-  if (resolution <= 0) d = (a.dx <= a.dy && a.dx <= a.dz) ? a.dx : (a.dy <= a.dz ? a.dy : a.dz);
-  int n[3] = {(int)(a.nx * a.dx / d), (int)(a.ny * a.dy / d), (int)(a.nz * a.dz / d)};
-  double s[3] = {d, d, d};
-  const double old[3] = {a.dx, a.dy, a.dz};
-  for (int k = 0; k < 3; ++k) if (n[k] < 1) { n[k] = 1; s[k] = old[k]; }
-  a.nx = n[0]; a.ny = n[1]; a.nz = n[2]; a.dx = s[0]; a.dy = s[1]; a.dz = s[2];
-  resolution = d;
-  return a;
-}
-
-// irtkGaussianBlurring<irtkRealPixel>(sigma).Run() (irtkGaussianBlurring.cc:40-125, irtkConvolution_1D.cc:42-90)
-void gaussian_blur(Image &im, double sigma) {
-  const svr_image_attr &a = im.a;
-  const int n[3] = {a.nx, a.ny, a.nz};
-  const double vs[3] = {a.dx, a.dy, a.dz};
-  const size_t stride[3] = {1, (size_t)a.nx, (size_t)a.nx * a.ny};
-  for (int axis = 0; axis < 3; ++axis) {
-    if (axis == 2 && a.nz == 1) continue;
-    const double s = sigma / vs[axis];
-    const int half = (int)irtk_round(4 * sigma / vs[axis]);
-    std::vector<double> k(2 * half + 1);
-    for (int t = -half; t <= half; ++t) k[t + half] = exp(-(double)(t * t) / (2.0 * s * s));
-    std::vector<double> out(im.d.size());
-    for (int z = 0; z < a.nz; ++z)
-      for (int y = 0; y < a.ny; ++y)
-        for (int x = 0; x < a.nx; ++x) {
-          const int p[3] = {x, y, z};
-          const size_t base = ((size_t)z * a.ny + y) * a.nx + x;
-          double val = 0, sum = 0;
-          for (int t = -half; t <= half; ++t) {
-            const int q = p[axis] + t;
-            if (q < 0 || q >= n[axis]) continue;
-            val += k[t + half] * im.d[base + (ptrdiff_t)t * (ptrdiff_t)stride[axis]];
-            sum += k[t + half];
-          }
-          out[base] = sum > 0 ? val / sum : 0.0;
-        }
-    im.d.swap(out);
-  }
-}
-
-// irtkImageTransformation + nearest neighbour, target padding -1 on an all-zero target (RG.cc:782-793, 808-819)
-Image transform_nn(const Image &src, const svr_image_attr &target, const M4 &t, double source_padding) {
-  Image out;
-  out.a = target;
-  out.d.assign((size_t)target.nx * target.ny * target.nz, source_padding);
-  const M4 m = mul(world_to_image(src.a), mul(t, image_to_world(target)));
-  for (int z = 0; z < target.nz; ++z)
-    for (int y = 0; y < target.ny; ++y)
-      for (int x = 0; x < target.nx; ++x) {
-        const double q[3] = {m.m[0] * x + m.m[1] * y + m.m[2] * z + m.m[3], m.m[4] * x + m.m[5] * y + m.m[6] * z + m.m[7],
-                             m.m[8] * x + m.m[9] * y + m.m[10] * z + m.m[11]};
-        const long i = (long)irtk_round(q[0]), j = (long)irtk_round(q[1]), k = (long)irtk_round(q[2]);
-        if (i >= 0 && i < src.a.nx && j >= 0 && j < src.a.ny && k >= 0 && k < src.a.nz)
-          out.at(x, y, z) = src.at((int)i, (int)j, (int)k);
-      }
-  return out;
-}
-
-// SetMask RG.cc:750-803
-Image set_mask(const svr_image_attr &tmpl, const Image *mask, double sigma, double threshold = 0.5) {
-  if (!mask) {
-    Image o;
-    o.a = tmpl;
-    o.d.assign((size_t)tmpl.nx * tmpl.ny * tmpl.nz, 1.0);
-    return o;
-  }
-  Image m = *mask;
-  if (sigma > 0) {
-    gaussian_blur(m, sigma);
-    for (double &v : m.d) v = v > threshold ? 1.0 : 0.0;
-  }
-  return transform_nn(m, tmpl, ident(), 0.0);
-}
-
-// irtkGenericImage::GetRegion(i1, j1, k1, i2, j2, k2)
-Image get_region(const Image &im, int x1, int y1, int z1, int x2, int y2, int z2) {
-  Image o;
-  o.a = im.a;
-  o.a.nx = x2 - x1; o.a.ny = y2 - y1; o.a.nz = z2 - z1;
-  const M4 i2w = image_to_world(im.a);
-  const double c[3] = {x1 + (o.a.nx - 1) / 2.0, y1 + (o.a.ny - 1) / 2.0, z1 + (o.a.nz - 1) / 2.0};
-  for (int k = 0; k < 3; ++k) o.a.origin[k] = i2w.m[4 * k] * c[0] + i2w.m[4 * k + 1] * c[1] + i2w.m[4 * k + 2] * c[2] + i2w.m[4 * k + 3];
-  o.d.resize((size_t)o.a.nx * o.a.ny * o.a.nz);
-  for (int z = z1; z < z2; ++z)
-    for (int y = y1; y < y2; ++y)
-      for (int x = x1; x < x2; ++x) o.at(x - x1, y - y1, z - z1) = im.at(x, y, z);
-  return o;
-}
-
-// CropImage RG.cc:5205-5306
-Image crop_image(const Image &im, const Image &mask) {
-  int lo[3] = {im.a.nx, im.a.ny, im.a.nz}, hi[3] = {-1, -1, -1};
-  for (int z = 0; z < im.a.nz; ++z)
-    for (int y = 0; y < im.a.ny; ++y)
-      for (int x = 0; x < im.a.nx; ++x)
-        if (mask.at(x, y, z) > 0) {
-          const int p[3] = {x, y, z};
-          for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
-        }
-  if (hi[0] < 0) die("CropImage: the mask does not overlap a stack");
-  return get_region(im, lo[0], lo[1], lo[2], hi[0] + 1, hi[1] + 1, hi[2] + 1);
-}
-
-// MatchStackIntensitiesWithMasking RG.cc:1375-1493
-std::vector<float> match_stack_intensities(std::vector<Image> &stacks, const std::vector<M4> &ts, const Image &mask,
-                                           double average_value, bool together) {
-  const M4 mw2i = world_to_image(mask.a);
-  std::vector<double> avg;
-  for (size_t s = 0; s < stacks.size(); ++s) {
-    const Image &st = stacks[s];
-    const M4 m = mul(mw2i, mul(ts[s], image_to_world(st.a)));
-    double sum = 0, num = 0;
-    for (int z = 0; z < st.a.nz; ++z)
-      for (int y = 0; y < st.a.ny; ++y)
-        for (int x = 0; x < st.a.nx; ++x) {
-          const long i = (long)irtk_round(m.m[0] * x + m.m[1] * y + m.m[2] * z + m.m[3]);
-          const long j = (long)irtk_round(m.m[4] * x + m.m[5] * y + m.m[6] * z + m.m[7]);
-          const long k = (long)irtk_round(m.m[8] * x + m.m[9] * y + m.m[10] * z + m.m[11]);
-          if (i >= 0 && i < mask.a.nx && j >= 0 && j < mask.a.ny && k >= 0 && k < mask.a.nz && mask.at((int)i, (int)j, (int)k) == 1) {
-            sum += st.at(x, y, z);
-            num += 1;
-          }
-        }
-    if (!(num > 0)) die("a stack has no overlap with the ROI");
-    avg.push_back(sum / num);
-  }
-  double glob = 0;
-  for (double v : avg) glob += v;
-  glob /= (double)avg.size();
-  std::vector<float> factors;
-  for (size_t s = 0; s < stacks.size(); ++s) {
-    const double f = average_value / (together ? glob : avg[s]);
-    factors.push_back((float)f);
-    for (double &v : stacks[s].d) if (v > 0) v *= f;
-  }
-  return factors;
-}
-
-M4 load_transformation(const std::string &spec) {
-  if (spec == "id") return ident();
-  M4 m;
-  double p6[6];
-  char err[256];
-  if (svr_dof_read(spec.c_str(), p6, m.m, err) == 0) return m;          // IRTK rigid dof file
-  std::ifstream f(spec.c_str());
-  for (int i = 0; i < 16; ++i)
-    if (!(f >> m.m[i])) die("transformation " + spec + ": expected 'id', an IRTK rigid dof file or a 4x4 text matrix");
-  return m;
-}
-
-void to_f16(const M4 &m, float *out) { for (int i = 0; i < 16; ++i) out[i] = (float)m.m[i]; }
-
-#define ENG(call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + svr_last_error(ctx)); } while (0)
-#define HOST(call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + svrh_last_error(host)); } while (0)
-
-}  // namespace
 
 int main(int argc, char **argv) {
   std::string output, mask_name;

@@ -22,6 +22,8 @@ HOST_EXPORTS = [
     "svrh_normalise_bias_gpu", "svrh_prepare_registration_slices", "svrh_slice_to_volume_registration_gpu",
     "svrh_get_registration_slices",
 ]
+PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_initialize_em_values", "pvrh_initialize_robust_statistics",
+                    "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_get_state"]      # csrc/pvr_host.cpp
 IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write"]      # csrc/svr_io.cpp, declared in svr_host.h
 
 
@@ -211,3 +213,59 @@ class irtkReconstruction:
     @property
     def _slice_weight_gpu(self):
         return self.state()["slice_weight"]
+
+
+class irtkPatchBasedReconstruction:
+    """The C++ patch-to-volume loop (csrc/pvr_host.cpp) over one engine with option pvr=1; same member names as
+    the Python mirror pvr.irtkPatchBasedReconstruction."""
+
+    def __init__(self, rec: "_engine.Reconstruction", patches_per_stack, min_intensity, max_intensity):
+        self._lib = _engine.load_library()
+        self._lib.pvrh_create.restype = C.c_void_p
+        self._lib.pvrh_last_error.restype = C.c_char_p
+        self._lib.pvrh_destroy.restype = None
+        self.e = rec
+        c = np.ascontiguousarray(patches_per_stack, np.int32)
+        self.n = int(c.sum())
+        h = self._lib.pvrh_create(rec._h, c.ctypes.data_as(C.c_void_p), len(c), C.c_float(min_intensity), C.c_float(max_intensity))
+        if not h:
+            raise _engine.SvrError("pvrh_create failed")
+        self._h = C.c_void_p(h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.pvrh_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise _engine.SvrError(f"host status {rc}: {self._lib.pvrh_last_error(self._h).decode()}")
+
+    def initializeEMValues(self):
+        self._ck(self._lib.pvrh_initialize_em_values(self._h))
+
+    def InitializeRobustStatistics(self):
+        self._ck(self._lib.pvrh_initialize_robust_statistics(self._h))
+
+    def EStep(self):
+        self._ck(self._lib.pvrh_estep(self._h))
+
+    def MStep(self, it):
+        self._ck(self._lib.pvrh_mstep(self._h, int(it)))
+
+    def Scale(self):
+        self._ck(self._lib.pvrh_scale(self._h))
+
+    def reconstruct_iteration(self, rec_iterations):
+        self._ck(self._lib.pvrh_reconstruct_iteration(self._h, int(rec_iterations)))
+
+    def state(self):
+        sc, pw, pot = (np.zeros(self.n, np.float32) for _ in range(3))
+        s8 = np.zeros(8, np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        self._ck(self._lib.pvrh_get_state(self._h, p(sc), p(pw), p(pot), p(s8)))
+        names = ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu", "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu", "m_mix_s_gpu")
+        return dict(scale=sc, patch_weight=pw, patch_potential=pot, **{k: float(v) for k, v in zip(names, s8)})

@@ -73,7 +73,7 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
                 ok &= mi > 0
                 patch = np.where(ok, stack.data[z][yi, xi], 0.0)
                 set_count = int((ok & (patch != 0) & (patch != -1)).sum())
-                if set_count > np.float32(1.0) / np.float32(3.0) * (py * px):    # :318
+                if set_count > np.float32(1.0) / np.float32(3.0) * np.float32(py) * np.float32(px):    # :318
                     total += set_count
                     out.append(patch.astype(np.float32))
                     i2ws.append(geo.to_matrix4(p_i2w))
@@ -136,7 +136,7 @@ class irtkPatchBasedReconstruction:
         self.m_delta = np.float32(1.0)                                   # patchBasedSuperresolution_gpu.cu:291-295
         self.m_lambda = np.float32(0.1)
         self.m_alpha = np.float32(np.float32(0.05) / self.m_lambda) * self.m_delta * self.m_delta
-        self.m_step = 0.0001                                              # patchBasedRobustStatistics_gpu.cu:877
+        self.m_step = np.float32(0.0001)                                  # T m_step, patchBasedRobustStatistics_gpu.cu:877
         self.scale = np.ones(self.n, np.float32)
         self.patch_weight = np.ones(self.n, np.float32)
         self.m_sigma_gpu = self.m_mix_gpu = self.m_m_gpu = np.float32(0)
@@ -189,7 +189,7 @@ class irtkPatchBasedReconstruction:
         d = pwd[valid].sum()
         s2 = ((dv2 * dv2 * (np.float32(1) - pw)).astype(np.float64))[valid].sum()
         d2 = (1 - pwd)[valid].sum()
-        floor = self.m_step * self.m_step / 6.28
+        floor = float(self.m_step * self.m_step) / 6.28                  # float product over a double literal
         if s > 0 and d > 0:
             self.m_sigma_s_gpu = np.float32(s / d)
             if self.m_sigma_s_gpu < floor:
@@ -235,7 +235,7 @@ class irtkPatchBasedReconstruction:
         sigma, mix, num, mn, mx = [np.float32(v) for v in self.e.MStepSums()]
         if mix > 0:
             self.m_sigma_gpu = np.float32(sigma / mix)
-        floor = np.float32(np.float32(self.m_step * self.m_step) / np.float32(6.28))
+        floor = np.float32(self.m_step * self.m_step) / np.float32(6.28)
         if self.m_sigma_gpu < floor:
             self.m_sigma_gpu = floor
         if it > 1:

@@ -92,7 +92,7 @@ def match_stack_intensities_pvr(stacks, transformations, mask, together=False):
 
 def prepare(stacks, transformations, mask, resolution, template, no_match):
     """PBR.cpp:197-310 without the stack registration.  Returns (stacks, iso mask, template attributes, recon mask)."""
-    mask = pp.Image((mask.data != 0).astype(np.float64), mask.attr)                      # :201-209
+    mask = pp.Image((np.trunc(mask.data) != 0).astype(np.float64), mask.attr)            # :201-209, (unsigned int) cast
     for k in range(len(stacks)):                                                          # :229-236
         m = pp.TransformMask(stacks[k].attr, mask, transformations[k])
         stacks[k] = pp.CropImage(stacks[k], m)
@@ -134,7 +134,9 @@ def main(argv=None, _engine_factory=_hip_engine):
     print(f"{n} stacks, {prob.ns} patches of {a.patchSize[0]}x{a.patchSize[1]} {prob.patches_per_stack}, volume {prob.vsize} at "
           f"{a.resolution} mm", file=sys.stderr)
     rec = _engine_factory(prob, a.devices[0])
-    drv = pvr.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, prob.min_intensity, prob.max_intensity)
+    pos = np.concatenate([s.data[s.data > 0].astype(np.float32) for s in stacks])          # computeMinMaxIntensities :792-814:
+    vmin, vmax = float(pos.min()), float(pos.max())                                       # over the whole (cropped) stacks
+    drv = pvr.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, vmin, vmax)
     for it in range(a.iterations + 1):                                                    # PBR.cpp:445
         drv.reconstruct_iteration(a.sr_iterations)
         print(f"iteration {it}: sigma {float(drv.m_sigma_gpu):.4g} mix {float(drv.m_mix_gpu):.3f}", file=sys.stderr)

@@ -114,6 +114,26 @@ int svr_dof_write(const char *path, const double params6[6], char err[256]);
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
                    unsigned char *slice_inside, double scalars8[8]);
 
+/* ---- patch-to-volume reconstruction loop (csrc/pvr_host.cpp) ---------------------------
+ * svr::irtkPatchBasedReconstruction: the reconstruction part of irtkPatchBasedReconstruction<T>::run
+ * (irtkPatchBasedReconstruction.cpp:445-593) and the host halves of patchBasedRobustStatistics_gpu<T>
+ * (patchBasedRobustStatistics_gpu.cu: initializeEMValues :78-95, EStep :224-556, MStep :570-640, Scale :672-745,
+ * InitializeRobustStatistics :793-845).  The engine must have the option "pvr" set and the patches uploaded
+ * as its slices; patches_per_stack is PatchBasedVolume::getXYZPatchGridSize().z per stack. */
+typedef struct pvrh_recon pvrh_recon;
+pvrh_recon *pvrh_create(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_intensity, float max_intensity);
+void pvrh_destroy(pvrh_recon *r);
+const char *pvrh_last_error(const pvrh_recon *r);
+int pvrh_initialize_em_values(pvrh_recon *r);
+int pvrh_initialize_robust_statistics(pvrh_recon *r);
+int pvrh_estep(pvrh_recon *r);
+int pvrh_mstep(pvrh_recon *r, int iter);
+int pvrh_scale(pvrh_recon *r);
+/* one outer iteration without the patch registration (irtkPatchBasedReconstruction.cpp:490-548) */
+int pvrh_reconstruct_iteration(pvrh_recon *r, int rec_iterations);
+/* scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s}; vectors of length sum(patches_per_stack) */
+int pvrh_get_state(pvrh_recon *r, float *scale, float *patch_weight, float *patch_potential, double scalars8[8]);
+
 #ifdef __cplusplus
 }
 #endif

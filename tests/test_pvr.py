@@ -352,3 +352,94 @@ def test_pvr_command_line_end_to_end(tmp_path):
     assert pvr_cli.main(["-o", str(out), "-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8",
                          "--resolution", "1.0", "--iterations", "1", "--sr_iterations", "3"]) == 0
     _check_pvr_volume(out, stacks)
+
+
+def _python_pvr_problem(paths, mpath, psize, pstride, resolution):
+    """What pvr_cli.main builds before it touches the engine."""
+    from fetalreconstruction_amd import nifti, pvr, pvr_cli
+    from fetalreconstruction_amd import preprocess as pp
+    stacks = []
+    for p in paths:
+        d, at = nifti.read(p)
+        stacks.append(pp.Image(d.astype(np.float64), at))
+    md, mat = nifti.read(mpath)
+    ts = [np.eye(4)] * len(stacks)
+    stacks, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False)
+    pst = [pvr.Stack(s.data.astype(np.float32), s.attr, t, s.attr.dz) for s, t in zip(stacks, ts)]
+    prob = pvr.make_pvr_problem(pst, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, psize, pstride)
+    pos = np.concatenate([s.data[s.data > 0].astype(np.float32) for s in stacks])
+    return prob, float(pos.min()), float(pos.max())
+
+
+def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path):
+    """bin/PVRreconstructionGPU --dumpProblem --dryRun (csrc/pvr_cli.cpp: mask, cropping, intensity matching,
+    template, patch extraction in C++) against the Python twin; no GPU involved."""
+    import subprocess
+    from fetalreconstruction_amd import build
+    build.build()
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    dump = tmp_path / "problem.bin"
+    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", mpath, "--patchSize", "16", "16",
+                        "--patchStride", "8", "8", "--resolution", "1.0", "--dumpProblem", str(dump), "--dryRun"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = dump.read_bytes()
+    hdr = np.frombuffer(raw, np.int32, 8)
+    ns, px, py, nst, vx, vy, vz = [int(v) for v in hdr[:7]]
+    o = 32
+    counts = np.frombuffer(raw, np.int32, nst, o); o += 4 * nst
+    vmin, vmax = np.frombuffer(raw, np.float32, 2, o); o += 8
+    patches = np.frombuffer(raw, np.float32, ns * py * px, o).reshape(ns, py, px); o += 4 * ns * py * px
+    i2w = np.frombuffer(raw, np.float32, ns * 16, o).reshape(ns, 16); o += 64 * ns
+    mask = np.frombuffer(raw, np.float32, vx * vy * vz, o)
+    P, pmin, pmax = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0)
+    assert (vx, vy, vz) == P.vsize and list(counts) == list(P.patches_per_stack) and ns == P.ns
+    assert np.array_equal(mask, P.mask.reshape(-1))
+    assert np.array_equal(patches, P.slices)                      # same float arithmetic, same rounding
+    assert np.allclose(i2w, P.slice_i2w, atol=1e-5)
+    assert vmin == np.float32(pmin) and vmax == np.float32(pmax)
+    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--superpixel"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "not supported" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_pvr_loop_matches_the_python_loop():
+    """svr::irtkPatchBasedReconstruction (csrc/pvr_host.cpp) against pvr.irtkPatchBasedReconstruction, same engine calls."""
+    from fetalreconstruction_amd import engine as E, host
+    pvr, stacks, P = _small_pvr()
+    out = []
+    for make in (lambda r: pvr.irtkPatchBasedReconstruction(r, P.patches_per_stack, P.min_intensity, P.max_intensity),
+                 lambda r: host.irtkPatchBasedReconstruction(r, P.patches_per_stack, P.min_intensity, P.max_intensity)):
+        rec = E.Reconstruction(0)
+        rec.set_option("pvr", 1)
+        E.sync_gpu(rec, P, quality_factor=1.0)
+        d = make(rec)
+        d.reconstruct_iteration(2)
+        st = d.state() if hasattr(d, "state") else dict(scale=d.scale, patch_weight=d.patch_weight, patch_potential=d.patch_potential,
+                                                        **{k: float(getattr(d, k)) for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu",
+                                                                                            "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu", "m_mix_s_gpu")})
+        out.append((st, rec.syncCPU().copy()))
+    (a, va), (b, vb) = out
+    for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu", "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu", "m_mix_s_gpu"):
+        assert a[k] == pytest.approx(b[k], rel=1e-4), k
+    assert np.allclose(a["scale"], b["scale"], rtol=1e-5)
+    assert np.allclose(a["patch_weight"], b["patch_weight"], atol=1e-4)      # expf of glibc vs numpy's float32 exp
+    assert np.allclose(a["patch_potential"], b["patch_potential"], atol=1e-6)
+    assert rel_err(vb, va) < 1e-4
+
+
+@pytest.mark.gpu
+def test_cpp_pvr_command_line_matches_the_python_one(tmp_path):
+    import subprocess
+    from fetalreconstruction_amd import build, nifti, pvr_cli
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    common = ["-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8", "--resolution", "1.0",
+              "--iterations", "1", "--sr_iterations", "3"]
+    assert pvr_cli.main(["-o", str(tmp_path / "py.nii.gz"), *common]) == 0
+    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "cc.nii.gz"), *common], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vp, ap = nifti.read(tmp_path / "py.nii.gz")
+    vc, ac = nifti.read(tmp_path / "cc.nii.gz")
+    assert vp.shape == vc.shape and np.allclose(geo.image_to_world(ap), geo.image_to_world(ac), atol=1e-6)
+    assert np.abs(vp - vc).max() <= 2e-4 * np.abs(vp).max()
+    _check_pvr_volume(tmp_path / "cc.nii.gz", stacks)
