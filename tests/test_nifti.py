@@ -126,3 +126,112 @@ def test_irtk_dof_files(tmp_path):
     (tmp_path / "bad.dof").write_bytes(struct.pack(">III", 815007, 3, 12) + b"\\0" * 48)
     with pytest.raises(SvrError):
         nifti.read_dof(tmp_path / "bad.dof")
+
+
+# ---- pinned against the reference's own NIfTI-1 library (oracle/_ref/libnifti_ref.so) -------------------
+# oracle/Makefile compiles source/IRTKSimple2/nifti/{niftilib/nifti1_io.c, znzlib/znzlib.c} where they lie
+# (plain C + system zlib) with the flat-argument harness oracle/nifti_ref_driver.c.
+def _ref():
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libnifti_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libnifti_ref.so not built (needs /root/reference; `make -C oracle`)")
+    return C.CDLL(path), C
+
+
+def _ref_read(path, with_data=True, dtype=np.float32):
+    lib, C = _ref()
+    dims, pix, codes = (C.c_int * 5)(), (C.c_float * 4)(), (C.c_int * 4)()
+    qto, sto, scl = (C.c_float * 16)(), (C.c_float * 16)(), (C.c_float * 2)()
+    assert lib.ref_nifti_read(str(path).encode(), dims, pix, codes, qto, sto, scl, None, 0) == 0
+    n = dims[1] * dims[2] * dims[3] * max(dims[4], 1)
+    buf = np.zeros(n * codes[3], np.uint8)
+    if with_data:
+        assert lib.ref_nifti_read(str(path).encode(), dims, pix, codes, qto, sto, scl, buf.ctypes.data_as(C.c_void_p),
+                                  C.c_long(buf.nbytes)) == 0
+    return dict(dims=list(dims), pix=list(pix), qform=codes[0], sform=codes[1], datatype=codes[2],
+                qto=np.array(qto[:]).reshape(4, 4), sto=np.array(sto[:]).reshape(4, 4), scl=list(scl),
+                data=buf.view(dtype) if with_data else None)
+
+
+def _ref_write(path, data, pix, datatype, qto=None, sto=None, slope=1.0, inter=0.0, nt=1):
+    lib, C = _ref()
+    d = np.ascontiguousarray(data)
+    nz, ny, nx = d.shape[-3:]
+    f16 = lambda m: None if m is None else (C.c_float * 16)(*np.asarray(m, np.float32).reshape(-1))   # noqa: E731
+    rc = lib.ref_nifti_write(str(path).encode(), (C.c_int * 3)(nx, ny, nz), nt, (C.c_float * 3)(*pix), datatype, f16(qto), f16(sto),
+                             C.c_float(slope), C.c_float(inter), d.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+
+
+@pytest.mark.parametrize("ext", [".nii", ".nii.gz"])
+@pytest.mark.parametrize("left_handed", [False, True])
+def test_written_files_parse_in_the_reference_library(tmp_path, ext, left_handed):
+    """svr_nifti_write -> nifti_image_read of the reference: the header irtkNIFTIHeader::Initialize would produce
+    (irtkNIFTI.h:84-160: float32, qform_code 1 = the image-to-world matrix, sform_code 0)."""
+    a = _attr()
+    if left_handed:
+        a.yaxis = -a.yaxis
+    d = np.random.default_rng(1).normal(size=(3, 5, 7)).astype(np.float32)
+    p = tmp_path / ("w" + ext)
+    nifti.write(p, d, a)
+    r = _ref_read(p)
+    assert r["dims"] == [3, 7, 5, 3, 1] and r["datatype"] == 16 and (r["qform"], r["sform"]) == (1, 0)
+    assert np.allclose(r["pix"][:3], [1.2, 0.9, 2.5], atol=1e-6) and r["pix"][3] == (-1.0 if left_handed else 1.0)
+    assert np.allclose(r["qto"], geo.image_to_world(a), atol=2e-5)              # through the float32 quaternion
+    assert np.array_equal(r["data"].reshape(3, 5, 7), d)
+    assert r["scl"][0] in (0.0, 1.0) and r["scl"][1] == 0.0
+
+
+def test_quaternion_matches_the_reference_library(tmp_path):
+    lib, C = _ref()
+    for seed, flip in ((0, False), (1, True), (2, False)):
+        rng = np.random.default_rng(seed)
+        rot = geo.rigid_matrix(rx=rng.uniform(-170, 170), ry=rng.uniform(-80, 80), rz=rng.uniform(-170, 170))[:3, :3]
+        a = geo.ImageAttributes(6, 4, 5, 0.8, 1.3, 2.0, rot[:, 0], rot[:, 1], -rot[:, 2] if flip else rot[:, 2],
+                                origin=rng.uniform(-50, 50, 3))
+        nifti.write(tmp_path / "q.nii", np.zeros((5, 4, 6), np.float32), a)
+        raw = open(tmp_path / "q.nii", "rb").read()
+        mine = struct.unpack_from("<6f", raw, 256)                               # quatern b c d, qoffset x y z
+        qfac = struct.unpack_from("<f", raw, 76)[0]
+        q, out = (C.c_float * 10)(), (C.c_float * 16)()
+        lib.ref_quatern_round_trip((C.c_float * 16)(*geo.image_to_world(a).astype(np.float32).reshape(-1)), out, q)
+        assert np.allclose(mine, q[:6], atol=2e-6) and qfac == q[9]
+        assert np.allclose(np.array(out[:]).reshape(4, 4), geo.image_to_world(a), atol=2e-5)
+
+
+@pytest.mark.parametrize("case", ["int16_scaled_gz", "uint8", "float64", "sform_only", "both_forms", "float32_4d"])
+def test_reference_written_files_read_back(tmp_path, case):
+    """nifti_image_write of the reference -> svr_nifti_read: voxels (with scl_slope / scl_inter) and the geometry rule of
+    irtkFileNIFTIToImage::ReadHeader (qform first, then sform; axes = matrix columns / voxel size, origin = centre)."""
+    a = _attr()
+    m = geo.image_to_world(a)
+    rng = np.random.default_rng(3)
+    other = geo.image_to_world(geo.ImageAttributes(7, 5, 3, 1.2, 0.9, 2.5, origin=np.array([1.0, 2.0, 3.0])))
+    pix = (1.2, 0.9, 2.5)
+    kw, nt, expect_m = dict(qto=m), 1, m
+    if case == "int16_scaled_gz":
+        raw, dt, path = rng.integers(-3000, 3000, (3, 5, 7)).astype(np.int16), 4, tmp_path / "r.nii.gz"
+        kw.update(slope=0.5, inter=-7.0)
+        expect = raw.astype(np.float32) * np.float32(0.5) + np.float32(-7.0)
+    elif case == "uint8":
+        raw, dt, path = rng.integers(0, 255, (3, 5, 7)).astype(np.uint8), 2, tmp_path / "r.nii"
+        expect = raw.astype(np.float32)
+    elif case == "float64":
+        raw, dt, path = rng.normal(size=(3, 5, 7)), 64, tmp_path / "r.nii"
+        expect = raw.astype(np.float32)
+    elif case == "sform_only":
+        raw, dt, path = rng.normal(size=(3, 5, 7)).astype(np.float32), 16, tmp_path / "r.nii"
+        kw, expect = dict(sto=m), raw
+    elif case == "both_forms":
+        raw, dt, path = rng.normal(size=(3, 5, 7)).astype(np.float32), 16, tmp_path / "r.nii.gz"
+        kw, expect = dict(qto=m, sto=other), raw                                  # the qform wins
+    else:
+        raw, dt, path, nt = rng.normal(size=(2, 3, 5, 7)).astype(np.float32), 16, tmp_path / "r.nii", 2
+        expect = raw
+    _ref_write(path, raw, pix, dt, nt=nt, **kw)
+    d, ra = nifti.read(path)
+    assert d.shape == expect.shape and np.allclose(d, expect, rtol=1e-6, atol=1e-6)
+    assert (ra.nx, ra.ny, ra.nz) == (7, 5, 3) and np.allclose([ra.dx, ra.dy, ra.dz], pix, atol=1e-6)
+    assert np.allclose(geo.image_to_world(ra), expect_m, atol=3e-5)
