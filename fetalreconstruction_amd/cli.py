@@ -7,10 +7,11 @@ smoothing schedule.
     python -m fetalreconstruction_amd.cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz s3.nii.gz -m mask.nii.gz \\
         [--thickness 2.5 2.5 2.5] [--resolution 0.75] [--iterations 4] [--useGPUReg]
 
-Differences from the reference CLI, all loud: stack transformations are `id`, IRTK rigid `dof` files or 4x4 text
-matrices, used as given (the stack-to-stack registration that refines them is not built); slice-to-volume registration runs
-only with --useGPUReg (the default CPU/IRTK registration is not built: without the flag the slices keep their
-stack transformations); packages, superpixels and the CPU path are refused.
+Stack transformations (`id`, IRTK rigid `dof` files or 4x4 text matrices) start the stack-to-stack registration
+(StackRegistrations, before and after the other stacks are cropped, main.cc:661,711); slice-to-volume registration is
+the reference's default IRTK schedule with every similarity evaluated on the GPU (csrc/irtk_reg.cpp) or, with
+--useGPUReg, the reference's GPU registration.  --no_registration (not a reference option) skips both.  Packages,
+superpixels and the CPU reconstruction path are refused, loudly.
 """
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ import sys
 
 import numpy as np
 
-from . import engine, nifti
+from . import engine, host, nifti
 from . import preprocess as pp
 from . import registration as reg
 from .reconstruction import irtkReconstruction
@@ -46,6 +47,7 @@ def _parser():
     p.add_argument("--rec_iterations_first", type=int, default=4)
     p.add_argument("--rec_iterations_last", type=int, default=13)
     p.add_argument("--useGPUReg", action="store_true")
+    p.add_argument("--no_registration", action="store_true")
     p.add_argument("--disableBiasCorrection", action="store_true", default=True)
     p.add_argument("-d", "--devices", nargs="+", type=int, default=[0])
     p.add_argument("--debug", action="store_true")
@@ -97,11 +99,23 @@ def main(argv=None):
         stacks[template] = pp.CropImage(stacks[template], m)
     tattr, resolution = pp.CreateTemplate(stacks[template].attr, a.resolution)                   # main.cc:607
     vol_mask = pp.SetMask(tattr, mask, a.smooth_mask)                                            # main.cc:610
-    for k in range(n):                                                                           # main.cc:645-662
+    rec = engine.Reconstruction(a.devices[0])
+
+    def stack_registrations(ts):                                                                 # StackRegistrations, RG.cc:849-1001
+        if a.no_registration or n < 2:
+            return ts
+        out, evals = host.StackRegistrations(rec, [s.data for s in stacks], [s.attr for s in stacks], ts, template,
+                                             mask=vol_mask.data if mask is not None else None, mask_attr=vol_mask.attr)
+        print(f"stack-to-stack registration: {evals} similarity evaluations", file=sys.stderr)
+        return list(out)
+
+    transformations = stack_registrations(transformations)                                       # main.cc:657-662
+    for k in range(n):                                                                           # main.cc:676-700
         if k == template:
             continue
         m = pp.TransformMask(stacks[k].attr, vol_mask, transformations[k])
         stacks[k] = pp.CropImage(stacks[k], m)
+    transformations = stack_registrations(transformations)                                       # main.cc:707-713
     factors = pp.MatchStackIntensitiesWithMasking(stacks, transformations, vol_mask, a.average,
                                                   together=a.no_intensity_matching)              # main.cc:676-679
     slices, attrs, slice_t, stack_index = pp.CreateSlicesAndTransformations(stacks, transformations, thickness)
@@ -110,15 +124,19 @@ def main(argv=None):
     print(f"{n} stacks, {prob.ns} slices of up to {prob.slices.shape[2]}x{prob.slices.shape[1]}, volume {prob.vsize} "
           f"at {resolution} mm, stack factors {np.round(factors, 3)}", file=sys.stderr)
 
-    rec = engine.Reconstruction(a.devices[0])
     engine.sync_gpu(rec, prob)                                                                   # SyncGPU, main.cc:722
     drv = irtkReconstruction(rec, prob.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
     drv.SetForceExcludedSlices(a.force_exclude)
     rs = reg.PrepareRegistrationSlices(rec, prob.slices, prob.slice_attr, resolution) if a.useGPUReg else None
     T = np.stack(slice_t)
     for it in range(a.iterations):                                                               # main.cc:816-1237
-        if it > 0 and a.useGPUReg:
-            T = reg.SliceToVolumeRegistrationGPU(rec, rs, T)
+        if it > 0 and not a.no_registration:                                                     # main.cc:829-880
+            if a.useGPUReg:
+                T = reg.SliceToVolumeRegistrationGPU(rec, rs, T)
+            else:                                                                                # SliceToVolumeRegistration, RG.cc:2291-2303
+                vol = rec.syncCPU().reshape(tattr.nz, tattr.ny, tattr.nx)                        # _reconstructed after SyncCPU, main.cc:1189
+                T, evals = host.SliceToVolumeRegistration(rec, prob.slices, prob.slice_attr, T, tattr, vol)
+                print(f"slice-to-volume registration: {evals} similarity evaluations", file=sys.stderr)
             ti = np.stack([np.linalg.inv(t) for t in T])
             rec.SetSliceMatrices(np.stack([t.astype(np.float32).reshape(16) for t in T]),
                                  np.stack([t.astype(np.float32).reshape(16) for t in ti]), prob.slice_i2w, prob.slice_w2i,

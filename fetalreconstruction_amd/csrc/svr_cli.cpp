@@ -12,9 +12,11 @@
 // (irtkReconstructionGPU.cc = "RG.cc"; the line ranges are on each function) and agree with the Python
 // mirror fetalreconstruction_amd/preprocess.py, which the tests compare them with.
 //
-// Transformations (-t) are `id`, IRTK rigid `dof` files or 4x4 text matrices, used as given.  Not built, refused
-// loudly: the stack-to-stack registration that refines them (RG.cc:849-1001), the CPU/IRTK slice registration (slice
-// registration runs with --useGPUReg only), packages, patch/superpixel modes, the CPU path.
+// Transformations (-t) are `id`, IRTK rigid `dof` files or 4x4 text matrices; like the reference they are the start of the
+// stack-to-stack registration (StackRegistrations, before and after the other stacks are cropped, main.cc:661,711).
+// Slice-to-volume registration is the reference's default IRTK schedule (csrc/irtk_reg.cpp, every similarity evaluation
+// on the GPU) or, with --useGPUReg, the reference's GPU registration.  --no_registration (not a reference option) skips
+// both.  Not built, refused loudly: packages, patch/superpixel modes, the CPU reconstruction path.
 #include "svr_prep.h"
 
 
@@ -25,7 +27,7 @@ int main(int argc, char **argv) {
   std::vector<int> force_excluded, devices;
   int iterations = 4, levels = 3, rec_first = 4, rec_last = 13;
   double resolution = 0.75, average = 700, delta = 150, lambda = 0.02, last_lambda = 0.01, smooth_mask = 4;
-  bool no_matching = false, use_gpu_reg = false;
+  bool no_matching = false, use_gpu_reg = false, no_registration = false;
   // ---- options (main.cc:164-211) ---------------------------------------------------------------------
   auto is_opt = [](const char *s) { return s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.'; };
   for (int i = 1; i < argc; ++i) {
@@ -51,13 +53,14 @@ int main(int argc, char **argv) {
     else if (o == "--rec_iterations_first") rec_first = atoi(one().c_str());
     else if (o == "--rec_iterations_last") rec_last = atoi(one().c_str());
     else if (o == "--useGPUReg") use_gpu_reg = true;
+    else if (o == "--no_registration") no_registration = true;
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
     else if (o == "-d" || o == "--devices") { std::vector<std::string> v; multi(v); for (auto &s : v) devices.push_back(atoi(s.c_str())); }
     else if (o == "-h" || o == "--help") {
       printf("usage: SVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> [-m <mask>] [-t id|<4x4.txt> ..] [--thickness th_1 ..]\n"
              "       [--iterations 4] [--resolution 0.75] [--multires 3] [--average 700] [--delta 150] [--lambda 0.02]\n"
              "       [--lastIterLambda 0.01] [--smooth_mask 4] [--no_intensity_matching] [--force_exclude i ..]\n"
-             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--useGPUReg] [-d device]\n");
+             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--useGPUReg] [--no_registration] [-d device]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/svr_cli.cpp)");
@@ -67,6 +70,9 @@ int main(int argc, char **argv) {
   const size_t n = inputs.size();
   if (tspecs.empty()) tspecs.assign(n, "id");
   if (tspecs.size() != n) die("one transformation per stack expected");
+
+  svr_ctx *ctx = nullptr;
+  if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
 
   // ---- set-up (main.cc:386-815) ----------------------------------------------------------------------
   std::vector<Image> stacks;
@@ -85,11 +91,27 @@ int main(int argc, char **argv) {
   }
   const svr_image_attr tattr = create_template(stacks[tmpl].a, resolution);
   const Image vol_mask = set_mask(tattr, have_mask ? &mask_img : nullptr, smooth_mask);
-  for (size_t k = 0; k < n; ++k) {                                                               // main.cc:645-662
+  auto stack_registrations = [&]() {                                                             // StackRegistrations, RG.cc:849-1001
+    if (no_registration || n < 2) return;
+    std::vector<svr_image_attr> at(n);
+    std::vector<const double *> ptr(n);
+    std::vector<double> tm(16 * n);
+    for (size_t k = 0; k < n; ++k) { at[k] = stacks[k].a; ptr[k] = stacks[k].d.data(); for (int q = 0; q < 16; ++q) tm[16 * k + q] = ts[k].m[q]; }
+    long evals = 0;
+    char e[256] = {0};
+    if (svrh_stack_registrations(ctx, nullptr, (int)n, at.data(), ptr.data(), tm.data(), (int)tmpl, have_mask ? &vol_mask.a : nullptr,
+                                 have_mask ? vol_mask.d.data() : nullptr, &evals, e))
+      die(std::string("stack registration: ") + e);
+    for (size_t k = 0; k < n; ++k) for (int q = 0; q < 16; ++q) ts[k].m[q] = tm[16 * k + q];
+    fprintf(stderr, "stack-to-stack registration: %ld similarity evaluations\n", evals);
+  };
+  stack_registrations();                                                                         // main.cc:657-662
+  for (size_t k = 0; k < n; ++k) {                                                               // main.cc:676-700
     if (k == tmpl) continue;
     const Image m = transform_nn(vol_mask, stacks[k].a, ts[k], 0.0);
     stacks[k] = crop_image(stacks[k], m);
   }
+  stack_registrations();                                                                         // main.cc:707-713
   const std::vector<float> factors = match_stack_intensities(stacks, ts, vol_mask, average, no_matching);
   // CreateSlicesAndTransformations RG.cc:1835-1880 + MaskSlices RG.cc:1940-1988 + the packing of SyncGPU RG.cc:249-328
   int ns = 0, mx = 0, my = 0;
@@ -130,8 +152,6 @@ int main(int argc, char **argv) {
           resolution);
 
   // ---- SyncGPU + generatePSFVolume + UpdateGPUTranformationMatrices (RG.cc:249-401, 1496-1610) ----------
-  svr_ctx *ctx = nullptr;
-  if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
   const uint32_t vsize[3] = {(uint32_t)tattr.nx, (uint32_t)tattr.ny, (uint32_t)tattr.nz};
   const float vdim[3] = {(float)tattr.dx, (float)tattr.dy, (float)tattr.dz};
   std::vector<float> maskf(vol_mask.d.begin(), vol_mask.d.end());
@@ -163,8 +183,18 @@ int main(int argc, char **argv) {
 
   // ---- registration-reconstruction loop (main.cc:816-1237) ---------------------------------------------
   for (int it = 0; it < iterations; ++it) {
-    if (it > 0 && use_gpu_reg) {
-      HOST(svrh_slice_to_volume_registration_gpu(host, T.data()));
+    if (it > 0 && !no_registration) {                                     // main.cc:829-880
+      if (use_gpu_reg) {
+        HOST(svrh_slice_to_volume_registration_gpu(host, T.data()));
+      } else {                                                            // SliceToVolumeRegistration, RG.cc:2291-2303
+        std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
+        ENG(svr_sync_cpu(ctx, vol.data()));                               // _reconstructed after SyncCPU, main.cc:1189
+        long evals = 0;
+        char e[256] = {0};
+        if (svrh_slice_to_volume_registration(ctx, nullptr, ns, grid.data(), mx, my, sattr.data(), T.data(), &tattr, vol.data(), &evals, e))
+          die(std::string("slice-to-volume registration: ") + e);
+        fprintf(stderr, "slice-to-volume registration: %ld similarity evaluations\n", evals);
+      }
       for (int s = 0; s < ns; ++s) {                                      // UpdateGPUTranformationMatrices RG.cc:372-401
         M4 t;
         for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];

@@ -24,6 +24,8 @@ HOST_EXPORTS = [
 ]
 PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_initialize_em_values", "pvrh_initialize_robust_statistics",
                     "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_get_state"]      # csrc/pvr_host.cpp
+IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_irtk_resample_with_padding",
+                "svrh_irtk_blur_with_padding", "svrh_irtk_rigid_parameters"]                                  # csrc/irtk_reg.cpp
 IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write"]      # csrc/svr_io.cpp, declared in svr_host.h
 
 
@@ -269,3 +271,116 @@ class irtkPatchBasedReconstruction:
         self._ck(self._lib.pvrh_get_state(self._h, p(sc), p(pw), p(pot), p(s8)))
         names = ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu", "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu", "m_mix_s_gpu")
         return dict(scale=sc, patch_weight=pw, patch_potential=pot, **{k: float(v) for k, v in zip(names, s8)})
+
+
+# ---- the IRTK registration schedule around the batched NCC cost (csrc/irtk_reg.cpp) -----------------------------------
+_SET_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16))
+_SET_S = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int16))
+_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double))
+
+
+class _NccBackend(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("set_targets", _SET_T), ("set_source", _SET_S), ("evaluate", _EVAL)]
+
+
+class NccBackend:
+    """struct svr_ncc_backend over a Python evaluator `fn(target int16 [ty][tx], M float64 [4][4], source int16 [z][y][x]) ->
+    six integer moments`: how the CPU tests put the oracle's restatement of irtkImageRigidRegistrationWithPadding::Evaluate
+    behind the C++ schedule.  The product path passes no backend (the engine evaluates)."""
+
+    def __init__(self, fn):
+        self.fn, self.targets, self.source, self.calls = fn, None, None, 0
+
+        def set_targets(user, n, tx, ty, t):
+            self.targets = np.ctypeslib.as_array(t, shape=(n, ty, tx)).copy()
+            return 0
+
+        def set_source(user, size, s):
+            self.source = np.ctypeslib.as_array(s, shape=(size[2], size[1], size[0])).copy()
+            return 0
+
+        def evaluate(user, n, idx, mats, sums, ncc):
+            try:
+                i = np.ctypeslib.as_array(idx, shape=(n,))
+                m = np.ctypeslib.as_array(mats, shape=(n, 4, 4))
+                out = np.ctypeslib.as_array(sums, shape=(n, 6))
+                for e in range(n):
+                    out[e] = np.asarray(self.fn(self.targets[i[e]], m[e], self.source), np.int64)
+                self.calls += 1
+                return 0
+            except Exception as ex:      # never let an exception cross the C boundary
+                print("ncc backend failed:", ex)
+                return 1
+
+        self._cbs = (_SET_T(set_targets), _SET_S(set_source), _EVAL(evaluate))
+        self.struct = _NccBackend(None, *self._cbs)
+
+
+def _reg_lib():
+    lib = _engine.load_library()
+    lib.svrh_irtk_rigid_parameters.restype = None
+    return lib
+
+
+def StackRegistrations(rec, stacks, attrs, transformations, template_number, mask=None, mask_attr=None, backend=None):
+    """irtkReconstruction::StackRegistrations (RG.cc:849-1001) -> (new transformations [n][4][4], number of evaluations).
+    stacks[i]: float64 [nz][ny][nx]; `rec` is the engine (None only with a `backend`)."""
+    lib = _reg_lib()
+    n = len(stacks)
+    data = [np.ascontiguousarray(s, np.float64) for s in stacks]
+    ptrs = (C.c_void_p * n)(*[d.ctypes.data for d in data])
+    at = (ImageAttr * n)(*[ImageAttr.of(a) for a in attrs])
+    t = np.ascontiguousarray(transformations, np.float64).reshape(n, 16).copy()
+    m = None if mask is None else np.ascontiguousarray(mask, np.float64)
+    ma = None if mask is None else ImageAttr.of(mask_attr)
+    nev, err = C.c_long(0), C.create_string_buffer(256)
+    rc = lib.svrh_stack_registrations(rec._h if rec is not None else None, C.byref(backend.struct) if backend else None, n, at, ptrs,
+                                      t.ctypes.data_as(C.c_void_p), int(template_number), C.byref(ma) if ma is not None else None,
+                                      m.ctypes.data_as(C.c_void_p) if m is not None else None, C.byref(nev), err)
+    if rc != 0:
+        raise _engine.SvrError(f"svrh_stack_registrations: {err.value.decode()}")
+    return t.reshape(n, 4, 4), nev.value
+
+
+def SliceToVolumeRegistration(rec, slices, slice_attrs, transformations, recon_attr, reconstructed, backend=None):
+    """irtkReconstruction::SliceToVolumeRegistration (RG.cc:1991-2059, 2291-2303), the reference's default registration
+    -> (new transformations [n][4][4], number of evaluations).  slices: the padded float32 grid [n][sy][sx]."""
+    lib = _reg_lib()
+    g = np.ascontiguousarray(slices, np.float32)
+    n, sy, sx = g.shape
+    at = (ImageAttr * n)(*[ImageAttr.of(a) for a in slice_attrs])
+    t = np.ascontiguousarray(transformations, np.float64).reshape(n, 16).copy()
+    vol = np.ascontiguousarray(reconstructed, np.float32)
+    ra = ImageAttr.of(recon_attr)
+    nev, err = C.c_long(0), C.create_string_buffer(256)
+    rc = lib.svrh_slice_to_volume_registration(rec._h if rec is not None else None, C.byref(backend.struct) if backend else None, n,
+                                               g.ctypes.data_as(C.c_void_p), sx, sy, at, t.ctypes.data_as(C.c_void_p), C.byref(ra),
+                                               vol.ctypes.data_as(C.c_void_p), C.byref(nev), err)
+    if rc != 0:
+        raise _engine.SvrError(f"svrh_slice_to_volume_registration: {err.value.decode()}")
+    return t.reshape(n, 4, 4), nev.value
+
+
+def irtk_resample_with_padding(data, attr, size3, padding):
+    lib = _reg_lib()
+    d = np.ascontiguousarray(data, np.int16)
+    oa = ImageAttr()
+    lib.svrh_irtk_resample_with_padding(C.byref(ImageAttr.of(attr)), d.ctypes.data_as(C.c_void_p), C.c_double(size3[0]), C.c_double(size3[1]),
+                                        C.c_double(size3[2]), int(padding), C.byref(oa), None, 0)
+    out = np.zeros((oa.nz, oa.ny, oa.nx), np.int16)
+    lib.svrh_irtk_resample_with_padding(C.byref(ImageAttr.of(attr)), d.ctypes.data_as(C.c_void_p), C.c_double(size3[0]), C.c_double(size3[1]),
+                                        C.c_double(size3[2]), int(padding), C.byref(oa), out.ctypes.data_as(C.c_void_p), C.c_long(out.size))
+    return out, oa
+
+
+def irtk_blur_with_padding(data, attr, sigma, padding):
+    d = np.ascontiguousarray(data, np.int16).copy()
+    _reg_lib().svrh_irtk_blur_with_padding(C.byref(ImageAttr.of(attr)), d.ctypes.data_as(C.c_void_p), C.c_double(sigma), int(padding))
+    return d
+
+
+def irtk_rigid_parameters(matrix):
+    m = np.ascontiguousarray(matrix, np.float64).reshape(16)
+    p, r = np.zeros(6), np.zeros(16)
+    _reg_lib().svrh_irtk_rigid_parameters(m.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+    return p, r.reshape(4, 4)

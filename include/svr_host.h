@@ -114,6 +114,34 @@ int svr_dof_write(const char *path, const double params6[6], char err[256]);
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
                    unsigned char *slice_inside, double scalars8[8]);
 
+/* ---- the reference's default (CPU / IRTK) registration schedule around the batched NCC cost (csrc/irtk_reg.cpp) ----
+ * irtkImageRigidRegistrationWithPadding::Run (3 levels, Gaussian blurring + resampling with padding per level, gradient
+ * descent with 4 step halvings and up to 20 iterations per step, cross correlation) restated on the host, with every
+ * similarity evaluation going through svr_ncc_evaluate -- all targets that share a source advance in lock step, one
+ * batched call per optimiser step.  `backend` NULL = the engine `ctx`; tests pass the CPU oracle's evaluator instead. */
+typedef struct svr_ncc_backend {
+  void *user;
+  int (*set_targets)(void *user, int n, int tx, int ty, const int16_t *targets);
+  int (*set_source)(void *user, const uint32_t size[3], const int16_t *source);
+  int (*evaluate)(void *user, int n_eval, const int *target_index, const double *matrices, int64_t *sums6, double *ncc_or_null);
+} svr_ncc_backend;
+/* irtkReconstruction::StackRegistrations (irtkReconstructionGPU.cc:849-1001): every stack against the (masked) template
+ * stack; transformations: row-major double [n][16], in/out.  stacks[i]: double [nz][ny][nx] of attrs[i]. */
+int svrh_stack_registrations(svr_ctx *ctx, const svr_ncc_backend *backend, int n_stacks, const svr_image_attr *attrs,
+                             const double *const *stacks, double *transformations, int template_number,
+                             const svr_image_attr *mask_attr, const double *mask_or_null, long *n_evaluations_or_null, char err[256]);
+/* irtkReconstruction::SliceToVolumeRegistration (irtkReconstructionGPU.cc:1991-2059, 2291-2303): every slice against the
+ * current reconstruction.  slices: the padded grid float [n][sy][sx] (-1 = padding), attrs[i]: slice i's attributes. */
+int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backend, int n_slices, const float *slices, int sx, int sy,
+                                      const svr_image_attr *attrs, double *transformations, const svr_image_attr *recon_attr,
+                                      const float *reconstructed, long *n_evaluations_or_null, char err[256]);
+/* building blocks (irtkResamplingWithPadding<short>, irtkGaussianBlurringWithPadding<short>, irtkRigidTransformation::
+ * Matrix2Parameters / UpdateMatrix), exported for the tests */
+int svrh_irtk_resample_with_padding(const svr_image_attr *attr, const int16_t *data, double rx, double ry, double rz, int padding,
+                                    svr_image_attr *out_attr, int16_t *out_or_null, long capacity);
+int svrh_irtk_blur_with_padding(const svr_image_attr *attr, int16_t *data, double sigma, int padding);
+void svrh_irtk_rigid_parameters(const double matrix16[16], double params6[6], double *rebuilt16_or_null);
+
 /* ---- patch-to-volume reconstruction loop (csrc/pvr_host.cpp) ---------------------------
  * svr::irtkPatchBasedReconstruction: the reconstruction part of irtkPatchBasedReconstruction<T>::run
  * (irtkPatchBasedReconstruction.cpp:445-593) and the host halves of patchBasedRobustStatistics_gpu<T>

@@ -33,12 +33,13 @@ def test_host_object_exports_all_declared_symbols():
     from fetalreconstruction_amd import host
     lib = ctypes.CDLL(svr_build.build())
     names = _declared("svr_host.h", "svrh_")
-    assert len(names) >= 15 and sorted(host.HOST_EXPORTS) == names
+    assert len(names) >= 15 and sorted(host.HOST_EXPORTS + host.IRTK_EXPORTS) == names
     assert not [n for n in names if not hasattr(lib, n)]
     pv = _declared("svr_host.h", "pvrh_")
     assert sorted(host.PVR_HOST_EXPORTS) == pv and not [n for n in pv if not hasattr(lib, n)]
     lib.pvrh_create.restype = ctypes.c_void_p
     assert lib.pvrh_create(None, None, 0, ctypes.c_float(0), ctypes.c_float(1)) is None
+    assert not [n for n in host.IRTK_EXPORTS if not hasattr(lib, n)]
     io = [n for n in _declared("svr_host.h", "svr_") if not n.startswith("svrh_") and n != "svr_collectives"]
     assert sorted(host.IO_EXPORTS) == sorted(n for n in io if hasattr(lib, n)) == sorted(io)
     lib.svrh_create.restype = ctypes.c_void_p

@@ -121,14 +121,15 @@ def test_command_line_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gpu_reg", [False, True])
-def test_cpp_command_line_matches_the_python_one(tmp_path, gpu_reg):
+@pytest.mark.parametrize("registration", ["none", "irtk", "gpu"])
+def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
     """bin/SVRreconstructionGPU (csrc/svr_cli.cpp: C++ pre-processing + the C++ host object) against cli.py."""
     import subprocess
     from fetalreconstruction_amd import build, cli, nifti
     paths, mpath, rattr, rmask = _write_case(tmp_path)
     common = ["-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "2",
-              "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2"] + (["--useGPUReg"] if gpu_reg else [])
+              "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2"] + {"none": ["--no_registration"], "irtk": [],
+                                                                                                  "gpu": ["--useGPUReg"]}[registration]
     assert cli.main(["-o", str(tmp_path / "py.nii.gz"), *common]) == 0
     r = subprocess.run([build.CLI, "-o", str(tmp_path / "cc.nii.gz"), *common], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -136,8 +137,10 @@ def test_cpp_command_line_matches_the_python_one(tmp_path, gpu_reg):
     vc, ac = nifti.read(tmp_path / "cc.nii.gz")
     assert vp.shape == vc.shape and np.allclose(geo.image_to_world(ap), geo.image_to_world(ac), atol=1e-6)
     assert np.array_equal(vp == -1, vc == -1)
-    if gpu_reg:
-        # the optimiser amplifies last-bit differences of the resampled slices (numpy vs C++ summation order)
+    if registration == "irtk":
+        assert "stack-to-stack registration" in r.stderr and "slice-to-volume registration" in r.stderr
+    if registration != "none":
+        # the optimisers amplify last-bit differences of their inputs (numpy vs C++ summation order in the pre-processing)
         # into different accept/reject decisions: compare the volumes as images
         ok = (vp > 0) & (vc > 0)
         print("max diff", np.abs(vp - vc).max() / np.abs(vp).max(), "corr", np.corrcoef(vp[ok], vc[ok])[0, 1])
