@@ -23,9 +23,22 @@
 #include <float.h>
 #include <stdint.h>
 
+#include <thread>
+
 #include "svr_prep.h"
 
 namespace {
+
+// rows of an image are independent in every filter below: split them over the host cores (results do not depend on it)
+template <class F> void parallel_rows(int n, size_t work_per_row, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 32u), (size_t)n * work_per_row / 200000 + 1);
+  if (nt <= 1 || n < 2) { fn(0, n); return; }
+  nt = std::min(nt, n);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back(fn, (int)((long)n * t / nt), (int)((long)n * (t + 1) / nt));
+  for (auto &x : th) x.join();
+}
 
 template <class T> struct Vol {
   svr_image_attr a;
@@ -61,8 +74,9 @@ template <class T> Vol<T> resample_with_padding(const Vol<T> &in, double rx, dou
   out.d.assign(out.n(), pad);
   const M4 o_i2w = image_to_world(out.a), i_w2i = world_to_image(in.a);
   const int X = in.a.nx, Y = in.a.ny, Z = in.a.nz;
-  for (int k = 0; k < out.a.nz; ++k)
-    for (int j = 0; j < out.a.ny; ++j)
+  parallel_rows(out.a.nz * out.a.ny, (size_t)out.a.nx * 40, [&](int r0, int r1) {
+  for (int r = r0; r < r1; ++r) {
+      const int k = r / out.a.ny, j = r % out.a.ny;
       for (int i = 0; i < out.a.nx; ++i) {
         // ImageToWorld then WorldToImage, two separate matrix applications like the reference
         const double wx = o_i2w.m[0] * i + o_i2w.m[1] * j + o_i2w.m[2] * k + o_i2w.m[3];
@@ -89,6 +103,8 @@ template <class T> Vol<T> resample_with_padding(const Vol<T> &in, double rx, dou
         }
         if (npad < 4 && sum > 0) out.at(i, j, k) = put_as_double<T>(val / sum);
       }
+  }
+  });
   return out;
 }
 
@@ -109,8 +125,9 @@ void blur_with_padding(Vol<short> &im, double sigma, short pad) {
       if (fabs(ker[i]) < FLT_MIN) ker[i] = 0;             // irtkScalarFunctionToImage.cc:89-92
     }
     std::vector<short> out(im.d.size());
-    for (int z = 0; z < n[2]; ++z)
-      for (int y = 0; y < n[1]; ++y)
+    parallel_rows(n[2] * n[1], (size_t)n[0] * size, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r) {
+        const int z = r / n[1], y = r % n[1];
         for (int x = 0; x < n[0]; ++x) {
           const int p[3] = {x, y, z};
           const size_t base = ((size_t)z * n[1] + y) * n[0] + x;
@@ -124,6 +141,8 @@ void blur_with_padding(Vol<short> &im, double sigma, short pad) {
           }
           out[base] = put_as_double<short>(sum > 0 ? val / sum : 0.0);
         }
+    }
+    });
     im.d.swap(out);
   }
 }
@@ -270,14 +289,25 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
     const Schedule ps = guess_parameters(targets[0].full->a, source.a, slice_to_volume);
     if (prepare_level(source, ps.s_blur[level], ps.s_res[level], ps.s_res[0], level, source_padding, src, err)) return 1;
     int tx = 0, ty = 0, planes = 0;
-    for (Target &t : targets) {
-      const Schedule p = guess_parameters(t.full->a, source.a, slice_to_volume);
-      if (prepare_level(*t.full, p.t_blur[level], p.t_res[level], p.t_res[0], level, target_padding, t.lvl, err)) return 1;
+    std::vector<int> bad(targets.size(), 0);
+    std::vector<std::string> errs(targets.size());
+    size_t pixels = 0;
+    for (const Target &t : targets) pixels += t.full->n();
+    parallel_rows((int)targets.size(), pixels / targets.size() * 60, [&](int r0, int r1) {
+      for (int r = r0; r < r1; ++r) {
+        Target &t = targets[r];
+        const Schedule p = guess_parameters(t.full->a, source.a, slice_to_volume);
+        bad[r] = prepare_level(*t.full, p.t_blur[level], p.t_res[level], p.t_res[0], level, target_padding, t.lvl, errs[r]);
+        t.phase = PH_START; t.step_i = 0; t.iter_j = 0; t.done = false;
+        t.step = p.length[level]; t.delta = p.delta[level];
+      }
+    });
+    for (size_t r = 0; r < targets.size(); ++r) {
+      if (bad[r]) { err = errs[r]; return 1; }
+      Target &t = targets[r];
       tx = std::max(tx, t.lvl.a.nx); ty = std::max(ty, t.lvl.a.ny);
       t.first_plane = planes;
       planes += t.lvl.a.nz;
-      t.phase = PH_START; t.step_i = 0; t.iter_j = 0; t.done = false;
-      t.step = p.length[level]; t.delta = p.delta[level];
     }
     std::vector<int16_t> packed((size_t)planes * tx * ty, (int16_t)-1);
     for (const Target &t : targets)
