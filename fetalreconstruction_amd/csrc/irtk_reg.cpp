@@ -425,7 +425,8 @@ extern "C" {
 
 int svrh_stack_registrations(svr_ctx *ctx, const svr_ncc_backend *backend, int n_stacks, const svr_image_attr *attrs,
                              const double *const *stacks, double *transformations, int template_number,
-                             const svr_image_attr *mask_attr, const double *mask_or_null, long *n_evaluations_or_null, char err[256]) {
+                             const svr_image_attr *mask_attr, const double *mask_or_null, int flags, long *n_evaluations_or_null,
+                             char err[256]) {
   if ((!ctx && !backend) || n_stacks < 1 || !attrs || !stacks || !transformations || template_number < 0 || template_number >= n_stacks) {
     set_err(err, "svrh_stack_registrations: bad arguments");
     return 1;
@@ -459,8 +460,10 @@ int svrh_stack_registrations(svr_ctx *ctx, const svr_ncc_backend *backend, int n
           }
         }
   }
-  M4 mo;
-  reset_origin(target.a, mo);                                             // RG.cc:987-988
+  M4 mo = ident();
+  // irtkStack3D3DRegistration<T>::ResetOrigin takes its arguments by value (irtkStack3D3DRegistration.cpp:151-162): the
+  // patch-based command line registers with the target's origin in place and an identity offset
+  if (!(flags & SVRH_STACKREG_KEEP_ORIGIN)) reset_origin(target.a, mo);   // RG.cc:987-988
   const M4 mo_inv = inverse_rigid_or_affine(mo);
   for (int s = 0; s < n_stacks; ++s) {                                    // ParallelStackRegistrations, RG.cc:877-911
     if (s == template_number) continue;

@@ -11,9 +11,10 @@
 // then PatchBasedVolume::generate2DPatches per stack (patchBasedObject.cuh:176-342) and `iterations + 1` passes of
 // the loop in csrc/pvr_host.cpp (PBR.cpp:445-593).  The Python twin is fetalreconstruction_amd/pvr_cli.py.
 //
-// Not built, refused loudly: stack-to-stack and patch-to-volume registration (patches keep their stack
-// transformations, so the passes after the first repeat it), superpixels / hierarchical mode, packages,
-// --existingReconTarget, --resample, --dilateMask, --useFullSlices.
+// The stack-to-stack registration (irtkStack3D3DRegistration, :280-285) runs through csrc/irtk_reg.cpp with every similarity
+// on the GPU; --no_registration (not a reference option) skips it.  Not built, refused loudly: the patch-to-volume
+// registration (patches keep their stack transformations, so the passes after the first repeat it), superpixels /
+// hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask, --useFullSlices.
 #include "svr_prep.h"
 
 namespace {
@@ -128,7 +129,7 @@ int main(int argc, char **argv) {
   std::vector<int> devices, psize, pstride;
   int iterations = 7, sr_iterations = 7;
   double resolution = 0.75;
-  bool no_matching = false, dry_run = false;
+  bool no_matching = false, dry_run = false, no_registration = false;
   std::string dump_name;                                 // test hooks: --dumpProblem <file> [--dryRun]
   // ---- options (pvrmain:108-131) ---------------------------------------------------------------------
   auto is_opt = [](const char *s) { return s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.'; };
@@ -151,10 +152,11 @@ int main(int argc, char **argv) {
     else if (o == "-d" || o == "--devices") ints(devices);
     else if (o == "--dumpProblem") dump_name = one();
     else if (o == "--dryRun") dry_run = true;
+    else if (o == "--no_registration") no_registration = true;
     else if (o == "-h" || o == "--help") {
       printf("usage: PVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> -m <mask> [-t id|<dof>|<4x4.txt> ..]\n"
              "       [--thickness th_1 ..] [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7]\n"
-             "       [--sr_iterations 7] [--noMatchIntensities] [-d device]\n");
+             "       [--sr_iterations 7] [--noMatchIntensities] [--no_registration] [-d device]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/pvr_cli.cpp)");
@@ -185,6 +187,22 @@ int main(int argc, char **argv) {
     stacks[k] = crop_image(stacks[k], m);
   }
   const Image iso_mask = transform_nn(mask, resample_attr(mask.a, resolution), ident(), 0.0);    // :258-266
+  if (!no_registration && n > 1) {                       // irtkStack3D3DRegistration<T>::run, :280-285
+    svr_ctx *rctx = nullptr;
+    if (svr_create(devices.empty() ? 0 : devices[0], &rctx) || !rctx) die("no usable HIP device (svr_create failed)");
+    std::vector<svr_image_attr> at(n);
+    std::vector<const double *> ptr(n);
+    std::vector<double> tm(16 * n);
+    for (size_t k = 0; k < n; ++k) { at[k] = stacks[k].a; ptr[k] = stacks[k].d.data(); for (int q = 0; q < 16; ++q) tm[16 * k + q] = ts[k].m[q]; }
+    long evals = 0;
+    char e[256] = {0};
+    if (svrh_stack_registrations(rctx, nullptr, (int)n, at.data(), ptr.data(), tm.data(), (int)tmpl, &iso_mask.a, iso_mask.d.data(),
+                                 SVRH_STACKREG_KEEP_ORIGIN, &evals, e))
+      die(std::string("stack registration: ") + e);
+    for (size_t k = 0; k < n; ++k) for (int q = 0; q < 16; ++q) ts[k].m[q] = tm[16 * k + q];
+    fprintf(stderr, "stack-to-stack registration: %ld similarity evaluations\n", evals);
+    svr_destroy(rctx);
+  }
   if (!no_matching) match_stack_intensities_pvr(stacks, ts, iso_mask);                           // :288-294
   float vmin = 3.402823466e38f, vmax = 1.175494351e-38f;                                         // computeMinMaxIntensities :792-814
   for (const Image &s : stacks)

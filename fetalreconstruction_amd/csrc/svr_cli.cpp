@@ -100,7 +100,7 @@ int main(int argc, char **argv) {
     long evals = 0;
     char e[256] = {0};
     if (svrh_stack_registrations(ctx, nullptr, (int)n, at.data(), ptr.data(), tm.data(), (int)tmpl, have_mask ? &vol_mask.a : nullptr,
-                                 have_mask ? vol_mask.d.data() : nullptr, &evals, e))
+                                 have_mask ? vol_mask.d.data() : nullptr, 0, &evals, e))
       die(std::string("stack registration: ") + e);
     for (size_t k = 0; k < n; ++k) for (int q = 0; q < 16; ++q) ts[k].m[q] = tm[16 * k + q];
     fprintf(stderr, "stack-to-stack registration: %ld similarity evaluations\n", evals);

@@ -322,9 +322,10 @@ def _reg_lib():
     return lib
 
 
-def StackRegistrations(rec, stacks, attrs, transformations, template_number, mask=None, mask_attr=None, backend=None):
+def StackRegistrations(rec, stacks, attrs, transformations, template_number, mask=None, mask_attr=None, backend=None, keep_origin=False):
     """irtkReconstruction::StackRegistrations (RG.cc:849-1001) -> (new transformations [n][4][4], number of evaluations).
-    stacks[i]: float64 [nz][ny][nx]; `rec` is the engine (None only with a `backend`)."""
+    stacks[i]: float64 [nz][ny][nx]; `rec` is the engine (None only with a `backend`); keep_origin: the variant of the
+    patch-based command line (irtkStack3D3DRegistration.cpp:164-228)."""
     lib = _reg_lib()
     n = len(stacks)
     data = [np.ascontiguousarray(s, np.float64) for s in stacks]
@@ -336,7 +337,7 @@ def StackRegistrations(rec, stacks, attrs, transformations, template_number, mas
     nev, err = C.c_long(0), C.create_string_buffer(256)
     rc = lib.svrh_stack_registrations(rec._h if rec is not None else None, C.byref(backend.struct) if backend else None, n, at, ptrs,
                                       t.ctypes.data_as(C.c_void_p), int(template_number), C.byref(ma) if ma is not None else None,
-                                      m.ctypes.data_as(C.c_void_p) if m is not None else None, C.byref(nev), err)
+                                      m.ctypes.data_as(C.c_void_p) if m is not None else None, 1 if keep_origin else 0, C.byref(nev), err)
     if rc != 0:
         raise _engine.SvrError(f"svrh_stack_registrations: {err.value.decode()}")
     return t.reshape(n, 4, 4), nev.value

@@ -9,9 +9,11 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
     python -m fetalreconstruction_amd.pvr_cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz -m mask.nii.gz \\
         [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7] [--sr_iterations 7]
 
-Not built, refused loudly: the stack-to-stack and the patch-to-volume registration (the patches keep their
-stack transformations, so every outer pass after the first repeats it -- `--iterations 0` is the useful
-setting), superpixels / hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.
+The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
+similarity on the GPU; --no_registration (not a reference option) skips it.  Not built, refused loudly: the
+patch-to-volume registration (the patches keep their stack transformations, so every outer pass after the first repeats
+it -- `--iterations 0` is the useful setting), superpixels / hierarchical mode, packages, --existingReconTarget,
+--resample, --dilateMask.
 """
 from __future__ import annotations
 
@@ -37,6 +39,7 @@ def _parser():
     p.add_argument("--patchStride", nargs=2, type=int, default=[16, 16])
     p.add_argument("--resolution", type=float, default=0.75)
     p.add_argument("--noMatchIntensities", action="store_true")
+    p.add_argument("--no_registration", action="store_true")
     p.add_argument("--iterations", type=int, default=7)
     p.add_argument("--sr_iterations", type=int, default=7)
     p.add_argument("--thickness", nargs="+", type=float)
@@ -90,18 +93,21 @@ def match_stack_intensities_pvr(stacks, transformations, mask, together=False):
     return average_value
 
 
-def prepare(stacks, transformations, mask, resolution, template, no_match):
-    """PBR.cpp:197-310 without the stack registration.  Returns (stacks, iso mask, template attributes, recon mask)."""
+def prepare(stacks, transformations, mask, resolution, template, no_match, register=None):
+    """PBR.cpp:197-310.  `register(stacks, transformations, iso_mask) -> transformations` is the stack-to-stack registration
+    (irtkStack3D3DRegistration, :280-285) or None.  Returns (stacks, transformations, iso mask, template attributes, recon mask)."""
     mask = pp.Image((np.trunc(mask.data) != 0).astype(np.float64), mask.attr)            # :201-209, (unsigned int) cast
     for k in range(len(stacks)):                                                          # :229-236
         m = pp.TransformMask(stacks[k].attr, mask, transformations[k])
         stacks[k] = pp.CropImage(stacks[k], m)
     iso_mask = pp.transform_nn(mask, resample_attr(mask.attr, resolution))               # :258-266
+    if register is not None and len(stacks) > 1:
+        transformations = register(stacks, transformations, iso_mask)                    # :280-285
     if not no_match:
         match_stack_intensities_pvr(stacks, transformations, iso_mask)                   # :291
     tattr = resample_attr(stacks[template].attr, resolution)                              # CreateTemplate :941-965
     recon_mask = pp.TransformMask(tattr, iso_mask, transformations[template])            # :303-304
-    return stacks, iso_mask, tattr, recon_mask
+    return stacks, transformations, iso_mask, tattr, recon_mask
 
 
 def _hip_engine(prob, device):
@@ -111,8 +117,8 @@ def _hip_engine(prob, device):
     return rec
 
 
-def main(argv=None, _engine_factory=_hip_engine):
-    """`_engine_factory` exists for the CPU tests, which drive the same pipeline over the test oracle."""
+def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
+    """`_engine_factory` / `_ncc_backend` exist for the CPU tests, which drive the same pipeline over the test oracle."""
     a = _parser().parse_args(argv)
     for refused in ("superpixel", "hierarchical", "packages", "existingReconTarget", "resample", "dilateMask", "useFullSlices"):
         if getattr(a, refused) is not None:
@@ -127,8 +133,16 @@ def main(argv=None, _engine_factory=_hip_engine):
     thickness = a.thickness or [2.0 * s.attr.dz for s in stacks]                          # pvrmain: twice the z spacing
     template = next((k for k, s in enumerate(specs) if s == "id"), 0)
     md, mat = nifti.read(a.mask)
-    stacks, iso_mask, tattr, recon_mask = prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), a.resolution, template,
-                                                  a.noMatchIntensities)
+    def register(st, tr, iso):                                                            # irtkStack3D3DRegistration<T>::run
+        from . import host
+        rec = engine.Reconstruction(a.devices[0]) if _engine_factory is _hip_engine else None
+        out, evals = host.StackRegistrations(rec, [s.data for s in st], [s.attr for s in st], tr, template, mask=iso.data,
+                                             mask_attr=iso.attr, keep_origin=True, backend=_ncc_backend)
+        print(f"stack-to-stack registration: {evals} similarity evaluations", file=sys.stderr)
+        return list(out)
+
+    stacks, ts, iso_mask, tattr, recon_mask = prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), a.resolution, template,
+                                                      a.noMatchIntensities, None if a.no_registration else register)
     pstacks = [pvr.Stack(s.data.astype(np.float32), s.attr, t, th / 2.0) for s, t, th in zip(stacks, ts, thickness)]
     prob = pvr.make_pvr_problem(pstacks, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, a.patchSize, a.patchStride)
     print(f"{n} stacks, {prob.ns} patches of {a.patchSize[0]}x{a.patchSize[1]} {prob.patches_per_stack}, volume {prob.vsize} at "

@@ -126,10 +126,14 @@ typedef struct svr_ncc_backend {
   int (*evaluate)(void *user, int n_eval, const int *target_index, const double *matrices, int64_t *sums6, double *ncc_or_null);
 } svr_ncc_backend;
 /* irtkReconstruction::StackRegistrations (irtkReconstructionGPU.cc:849-1001): every stack against the (masked) template
- * stack; transformations: row-major double [n][16], in/out.  stacks[i]: double [nz][ny][nx] of attrs[i]. */
+ * stack; transformations: row-major double [n][16], in/out.  stacks[i]: double [nz][ny][nx] of attrs[i].
+ * flags: SVRH_STACKREG_KEEP_ORIGIN = irtkStack3D3DRegistration<T>::run of the patch-based command line
+ * (irtkStack3D3DRegistration.cpp:164-228), whose ResetOrigin is a no-op (arguments by value). */
+#define SVRH_STACKREG_KEEP_ORIGIN 1
 int svrh_stack_registrations(svr_ctx *ctx, const svr_ncc_backend *backend, int n_stacks, const svr_image_attr *attrs,
                              const double *const *stacks, double *transformations, int template_number,
-                             const svr_image_attr *mask_attr, const double *mask_or_null, long *n_evaluations_or_null, char err[256]);
+                             const svr_image_attr *mask_attr, const double *mask_or_null, int flags, long *n_evaluations_or_null,
+                             char err[256]);
 /* irtkReconstruction::SliceToVolumeRegistration (irtkReconstructionGPU.cc:1991-2059, 2291-2303): every slice against the
  * current reconstruction.  slices: the padded grid float [n][sy][sx] (-1 = padding), attrs[i]: slice i's attributes. */
 int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backend, int n_slices, const float *slices, int sx, int sy,

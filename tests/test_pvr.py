@@ -296,10 +296,11 @@ def _check_pvr_volume(path, stacks):
 def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
     """File reading, mask handling, cropping, intensity matching, template, patches and the loop, with the test
     oracle standing in for the engine (CPU suite)."""
-    from fetalreconstruction_amd import nifti, pvr_cli
+    from fetalreconstruction_amd import host, nifti, pvr_cli
     from fetalreconstruction_amd import preprocess as pp
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     seen = {}
+    ncc = host.NccBackend(lambda target, M, source: oracle_mod.ncc_evaluate(target, M, source)[1])   # stack registration on the CPU
 
     def factory(prob, device):
         seen["prob"] = prob
@@ -307,7 +308,8 @@ def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
 
     out = tmp_path / "o.nii.gz"
     assert pvr_cli.main(["-o", str(out), "-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8",
-                         "--resolution", "1.0", "--iterations", "0", "--sr_iterations", "2"], _engine_factory=factory) == 0
+                         "--resolution", "1.0", "--iterations", "0", "--sr_iterations", "2"], _engine_factory=factory, _ncc_backend=ncc) == 0
+    assert ncc.calls > 20                                                      # irtkStack3D3DRegistration ran (PBR.cpp:280-285)
     vol, va = _check_pvr_volume(out, stacks)
     P = seen["prob"]
     assert P.vsize == (va.nx, va.ny, va.nz) and len(P.patches_per_stack) == 2 and min(P.patches_per_stack) > 10
@@ -364,7 +366,7 @@ def _python_pvr_problem(paths, mpath, psize, pstride, resolution):
         stacks.append(pp.Image(d.astype(np.float64), at))
     md, mat = nifti.read(mpath)
     ts = [np.eye(4)] * len(stacks)
-    stacks, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False)
+    stacks, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False)
     pst = [pvr.Stack(s.data.astype(np.float32), s.attr, t, s.attr.dz) for s, t in zip(stacks, ts)]
     prob = pvr.make_pvr_problem(pst, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, psize, pstride)
     pos = np.concatenate([s.data[s.data > 0].astype(np.float32) for s in stacks])
@@ -380,7 +382,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path):
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     dump = tmp_path / "problem.bin"
     r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", mpath, "--patchSize", "16", "16",
-                        "--patchStride", "8", "8", "--resolution", "1.0", "--dumpProblem", str(dump), "--dryRun"],
+                        "--patchStride", "8", "8", "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     raw = dump.read_bytes()
