@@ -33,6 +33,12 @@
 // (RC.cuh:72, RC.cu:238); for a float f that is exactly  f <= 0.00001f  because 0.00001f is
 // the largest float below 1e-5.
 #define PSF_EPS_F 0.00001f
+#ifndef SVR_WPE_PLAIN
+#define SVR_WPE_PLAIN 7
+#endif
+#ifndef SVR_WPE_ROWS
+#define SVR_WPE_ROWS 5
+#endif
 
 #define LDS_ROW 20              // floats per PSF row in LDS (16 + pad: conflict-free b128 stores)
 #define WAVES_PER_BLOCK 4
@@ -65,7 +71,8 @@ struct SliceConst {
   float Lp[9];     // linear part of A scaled to calcPSF's argument space
   float dim[3];    // slice voxel dims (dx, dy, thickness)
   float kx, ky, inv2s2;
-  float pad[13];
+  float dd, w;     // Gaussian recurrence along a row: (z' step)^2, and exp(-2 dd inv2s2) or -1 (see gauss_pairs)
+  float pad[11];
 };
 static_assert(sizeof(SliceConst) == 256, "SliceConst layout");
 
@@ -96,7 +103,7 @@ __device__ __forceinline__ float canon_abs_sin(float R) {
   u = __builtin_fmaf(s, u * r, r);
   return __builtin_fabsf(u);
 }
-__device__ __forceinline__ float canon_exp_neg(float a) {
+__host__ __device__ __forceinline__ float canon_exp_neg(float a) {
   const float LOG2E = 1.442695040888963407359924681001892137426645954152985934135449406931f;
   const float L2U = 0.693145751953125f;
   const float L2L = 1.428606765330187045e-06f;
@@ -206,12 +213,15 @@ __device__ __forceinline__ PixelState pixel_setup(const SliceConst &S, const Vol
 struct RowConst {
   float Lp[9];
   float inv2s2;
+  float dd, w;
 };
 __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
   RowConst R;
 #pragma unroll
   for (int i = 0; i < 9; ++i) R.Lp[i] = S.Lp[i];
   R.inv2s2 = S.inv2s2;
+  R.dd = S.dd;
+  R.w = S.w;
   return R;
 }
 
@@ -233,16 +243,103 @@ __device__ __forceinline__ f2 bc2(float c) { return (f2)(c); }
 // H pairs of consecutive x-taps of one (y,z) row, first tap at lattice offset fx0: val2[i] = psf of taps
 // (fx0 + 2i, fx0 + 2i + 1).  rowx/rowy/rowz = the row's part of the scaled lattice coordinates.
 // psf of 2H taps given their scaled lattice coordinates (x', y', z') two per lane-op
+// exp(-a) of two values: canon_exp_neg per component
+__device__ __forceinline__ f2 exp_neg2(f2 a) {
+  const f2 t = -a * bc2(1.442695040888963407359924681001892137426645954152985934135449406931f);
+  const f2 k = (f2){__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  f2 r = fma2(k, bc2(-0.693145751953125f), -a);
+  r = fma2(k, bc2(-1.428606765330187045e-06f), r);
+  f2 s = fma2(bc2(0.000198527617612853646278381f), r, bc2(0.00139304355252534151077271f));
+  s = fma2(s, r, bc2(0.00833336077630519866943359f));
+  s = fma2(s, r, bc2(0.0416664853692054748535156f));
+  s = fma2(s, r, bc2(0.166666671633720397949219f));
+  s = fma2(s, r, bc2(0.5f));
+  s = fma2(r * r, s, r) + bc2(1.0f);
+  s = (f2){ldexpf(s.x, (int)k.x), ldexpf(s.y, (int)k.y)};
+  return (f2){(a.x > 87.0f) ? 0.0f : s.x, (a.y > 87.0f) ? 0.0f : s.y};
+}
+
+// The Gaussian factor exp(-z'^2 inv2s2) of a row's taps, canonical definition (oracle: canon_gauss_row).  z' is
+// linear along the row, so the factor of neighbouring taps differs by a ratio that itself changes by the constant
+// w = exp(-2 dd inv2s2): from the two central taps (lattice offsets 0 and 1, where |z'| is smallest for every row
+// that matters) the factors are stepped outwards,
+//     g(-j) = g(-j+1) * rl,  rl *= w      g(1+j) = g(j) * rr,  rr *= w,
+// two multiplications per tap instead of an exponential.  g[j] = {factor of tap -j, factor of tap 1+j}.
+// A row whose central factors are too small to start from (a > GAUSS_AMAX: thin slices seen obliquely, far from
+// the slice plane), and every row of a slice whose first ratio could overflow (S.w < 0, set by the host), takes
+// the exponential per tap instead; which rows do is part of the definition, and the oracle applies the same test.
+#define GAUSS_AMAX 60.0f
+// the rare path of gauss_pairs, out of line so that it costs the common path no registers
+__device__ __attribute__((noinline)) f2 gauss_direct2(float dz, float rowz, float inv2s2, float j, bool keep, f2 g) {
+  const f2 z = fma2(bc2(dz), (f2){-j, 1.0f + j}, bc2(rowz));
+  const f2 e = exp_neg2((z * z) * bc2(inv2s2));
+  return keep ? g : e;
+}
+struct GaussStep {        // state of the recurrence between two chunks of pairs
+  f2 g, r;
+  bool ok;
+};
+__device__ __forceinline__ GaussStep gauss_start(const RowConst &S, float rowz) {
+  const f2 zc = fma2(bc2(S.Lp[6]), (f2){0.0f, 1.0f}, bc2(rowz));
+  const f2 ac = (zc * zc) * bc2(S.inv2s2);
+  const f2 t = fma2(((f2){-2.0f, 2.0f}) * zc, bc2(S.Lp[6]), bc2(S.dd)) * bc2(S.inv2s2);
+  GaussStep st;
+  st.r = exp_neg2(t);
+  st.g = exp_neg2(ac);
+  st.ok = ac.x <= GAUSS_AMAX && ac.y <= GAUSS_AMAX && S.w >= 0.0f;
+  return st;
+}
+// factors of pairs j0 .. j0 + H - 1
+template <int H>
+__device__ __forceinline__ void gauss_pairs(const RowConst &S, float rowz, GaussStep &st, int j0, f2 g[H]) {
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    if (j0 + i > 0) {
+      st.g = st.g * st.r;
+      st.r = st.r * bc2(S.w);
+    }
+    g[i] = st.g;
+  }
+#ifndef SVR_NO_GAUSS_FALLBACK
+  if (!__all(st.ok)) {
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+      if (j0 + i > 0) g[i] = gauss_direct2(S.Lp[6], rowz, S.inv2s2, (float)(j0 + i), st.ok, g[i]);
+  }
+#endif
+}
+// the same for the first tap (lattice offset -CENTRE) of two rows at once: x = row A, y = row B
+template <int CENTRE>
+__device__ __forceinline__ f2 gauss_first_tap2(const RowConst &S, f2 rowz) {
+  const f2 zl = fma2(bc2(S.Lp[6]), bc2(0.0f), rowz), zr = fma2(bc2(S.Lp[6]), bc2(1.0f), rowz);
+  const f2 al = (zl * zl) * bc2(S.inv2s2), ar = (zr * zr) * bc2(S.inv2s2);
+  const f2 t = fma2(bc2(-2.0f) * zl, bc2(S.Lp[6]), bc2(S.dd)) * bc2(S.inv2s2);
+  f2 r = exp_neg2(t), g = exp_neg2(al);
+#pragma unroll
+  for (int j = 1; j <= CENTRE; ++j) {
+    g = g * r;
+    r = r * bc2(S.w);
+  }
+  const bool okx = al.x <= GAUSS_AMAX && ar.x <= GAUSS_AMAX && S.w >= 0.0f;
+  const bool oky = al.y <= GAUSS_AMAX && ar.y <= GAUSS_AMAX && S.w >= 0.0f;
+  if (!__all(okx && oky)) {
+    const f2 z = fma2(bc2(S.Lp[6]), bc2((float)(-CENTRE)), rowz);
+    const f2 e = exp_neg2((z * z) * bc2(S.inv2s2));
+    g.x = okx ? g.x : e.x;
+    g.y = oky ? g.y : e.y;
+  }
+  return g;
+}
+
+// in-plane factor sinc^2 of 2H taps given their scaled in-plane lattice coordinates (x', y'), two per lane-op
 template <int H, bool PVR>
-__device__ __forceinline__ void eval_pairs_xyz(const RowConst &S, const f2 xs[H], const f2 ys[H], const f2 zs[H],
-                                               f2 val2[H]) {
+__device__ __forceinline__ void eval_pairs_xyz(const RowConst &S, const f2 xs[H], const f2 ys[H], f2 val2[H]) {
 #define EACH for (int i = 0; i < H; ++i)
 #define PERC(dst, expr_x, expr_y) dst = (f2){(expr_x), (expr_y)}
-    f2 R[H], a[H], r[H], s[H], u[H], k[H];
+    f2 R[H], r[H], s[H], u[H], k[H];
 #pragma unroll
     EACH {
       R[i] = fma2(ys[i], ys[i], xs[i] * xs[i]);        // q
-      a[i] = (zs[i] * zs[i]) * bc2(S.inv2s2);
     }
     // correctly rounded sqrt: the core of LLVM's IEEE expansion (v_sqrt_f32, then pick among the two
     // neighbours with exact fma residuals) without its denormal-input scaling and inf handling,
@@ -318,73 +415,45 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst &S, const f2 xs[H]
     }
 #pragma unroll
     EACH u[i] = u[i] * u[i];
-    // exp(-a): canon_exp_neg
 #pragma unroll
-    EACH {
-      const f2 t = -a[i] * bc2(1.442695040888963407359924681001892137426645954152985934135449406931f);
-      PERC(k[i], __builtin_rintf(t.x), __builtin_rintf(t.y));
-    }
-#pragma unroll
-    EACH r[i] = fma2(k[i], bc2(-0.693145751953125f), -a[i]);
-#pragma unroll
-    EACH r[i] = fma2(k[i], bc2(-1.428606765330187045e-06f), r[i]);
-#pragma unroll
-    EACH s[i] = fma2(bc2(0.000198527617612853646278381f), r[i], bc2(0.00139304355252534151077271f));
-#pragma unroll
-    EACH s[i] = fma2(s[i], r[i], bc2(0.00833336077630519866943359f));
-#pragma unroll
-    EACH s[i] = fma2(s[i], r[i], bc2(0.0416664853692054748535156f));
-#pragma unroll
-    EACH s[i] = fma2(s[i], r[i], bc2(0.166666671633720397949219f));
-#pragma unroll
-    EACH s[i] = fma2(s[i], r[i], bc2(0.5f));
-#pragma unroll
-    EACH s[i] = fma2(r[i] * r[i], s[i], r[i]) + bc2(1.0f);
-#pragma unroll
-    EACH PERC(s[i], ldexpf(s[i].x, (int)k[i].x), ldexpf(s[i].y, (int)k[i].y));
-#pragma unroll
-    EACH PERC(s[i], (a[i].x > 87.0f) ? 0.0f : s[i].x, (a[i].y > 87.0f) ? 0.0f : s[i].y);
-#pragma unroll
-    EACH val2[i] = u[i] * s[i];                       // (si * si) * gz
+    EACH val2[i] = u[i];                              // si * si; the caller multiplies by the Gaussian factor
 #undef EACH
 #undef PERC
-}
-
-template <int H, bool PVR>
-__device__ __forceinline__ void eval_pairs(const RowConst &S, float rowx, float rowy, float rowz, float fx0,
-                                           f2 val2[H]) {
-  f2 xs[H], ys[H], zs[H];
-#pragma unroll
-  for (int i = 0; i < H; ++i) {
-    const f2 fx = (f2){fx0 + (float)(2 * i), fx0 + (float)(2 * i + 1)};
-    xs[i] = fma2(bc2(S.Lp[0]), fx, bc2(rowx));
-    ys[i] = fma2(bc2(S.Lp[3]), fx, bc2(rowy));
-    zs[i] = fma2(bc2(S.Lp[6]), fx, bc2(rowz));
-  }
-  eval_pairs_xyz<H, PVR>(S, xs, ys, zs, val2);
 }
 
 template <int N, bool PVR>
 __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by, float bz, float fy,
                                            float fz, float out[N]) {
-  // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage of eval_pairs
+  // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage of eval_pairs_xyz
   // compiles to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (half the issue slots for the same cycles);
-  // sqrt, rcp, rint, ldexp and the selects stay per component.  Per component the operation sequence
-  // is exactly psf_eval's.
-  constexpr int EVAL_CHUNK = N / 2;
-  constexpr int H = EVAL_CHUNK / 2;
+  // sqrt, rcp, rint and the selects stay per component.  Pair j holds the taps at lattice offsets -j and 1 + j
+  // (the order of the Gaussian recurrence, gauss_pairs); the in-plane part is evaluated in two chunks of N/4 pairs.
+  constexpr int NP = N / 2;
+  constexpr int H = NP / 2;
   constexpr int CENTRE = (N - 1) / 2;
-  static_assert(EVAL_CHUNK % 2 == 0, "taps are processed in pairs");
+  static_assert(NP % 2 == 0 && CENTRE == NP - 1, "pairs (-j, 1 + j) around the central taps");
   const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
   const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
   const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
+  GaussStep st = gauss_start(S, rowz);
   float val[N];
 #pragma unroll
-  for (int c0 = 0; c0 < N; c0 += EVAL_CHUNK) {
-    f2 v2[H];
-    eval_pairs<H, PVR>(S, rowx, rowy, rowz, (float)(c0 - CENTRE), v2);
+  for (int c0 = 0; c0 < NP; c0 += H) {
+    f2 xs[H], ys[H], v2[H], g[H];
 #pragma unroll
-    for (int i = 0; i < H; ++i) { val[c0 + 2 * i] = v2[i].x; val[c0 + 2 * i + 1] = v2[i].y; }
+    for (int i = 0; i < H; ++i) {
+      const f2 fx = (f2){(float)(-(c0 + i)), (float)(1 + c0 + i)};
+      xs[i] = fma2(bc2(S.Lp[0]), fx, bc2(rowx));
+      ys[i] = fma2(bc2(S.Lp[3]), fx, bc2(rowy));
+    }
+    eval_pairs_xyz<H, PVR>(S, xs, ys, v2);
+    gauss_pairs<H>(S, rowz, st, c0, g);
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const f2 v = v2[i] * g[i];                        // (si * si) * gz
+      val[CENTRE - (c0 + i)] = v.x;
+      val[CENTRE + 1 + c0 + i] = v.y;
+    }
   }
   float old = FLT_MAX;
 #pragma unroll
@@ -982,7 +1051,7 @@ __device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, in
 // NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: evaluator, texture-averaged volume read
 // (R2/reconVolume.cu:170-187), pass-1 gate sume > 1e-5 or NaN and superpixel test (R2/patchBasedPSFReconstruction_gpu.cu:95-110)
 template <bool GAUSS1, bool ROWS, int NS = PSF_SUPPORT, bool PVR = false>
-__global__ __launch_bounds__(FWD_WAVES * 64) __attribute__((amdgpu_waves_per_eu(ROWS ? 6 : 8, ROWS ? 6 : 8)))
+__global__ __launch_bounds__(FWD_WAVES * 64) __attribute__((amdgpu_waves_per_eu(ROWS ? SVR_WPE_ROWS : SVR_WPE_PLAIN, ROWS ? SVR_WPE_ROWS : SVR_WPE_PLAIN)))
 void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
   constexpr bool GAUSS1_ACT = GAUSS1;
   constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
@@ -1159,11 +1228,12 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
           const float rowz = __builtin_fmaf(RC.Lp[7], fy, __builtin_fmaf(RC.Lp[8], fz, R.bz));
           const float x1 = __builtin_fmaf(RC.Lp[0], (float)(-PSF_CENTRE), rowx);
           const float y1 = __builtin_fmaf(RC.Lp[3], (float)(-PSF_CENTRE), rowy);
-          const float z1 = __builtin_fmaf(RC.Lp[6], (float)(-PSF_CENTRE), rowz);
-          if (j & 1) { xs[j >> 1].y = x1; ys[j >> 1].y = y1; zs[j >> 1].y = z1; }
-          else { xs[j >> 1].x = x1; ys[j >> 1].x = y1; zs[j >> 1].x = z1; }
+          if (j & 1) { xs[j >> 1].y = x1; ys[j >> 1].y = y1; zs[j >> 1].y = rowz; }
+          else { xs[j >> 1].x = x1; ys[j >> 1].x = y1; zs[j >> 1].x = rowz; }
         }
-        eval_pairs_xyz<4, false>(RC, xs, ys, zs, t0);
+        eval_pairs_xyz<4, false>(RC, xs, ys, t0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t0[q] = t0[q] * gauss_first_tap2<PSF_CENTRE>(RC, zs[q]);   // zs holds the rows' z'_0
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float o0 = (j & 1) ? t0[j >> 1].y : t0[j >> 1].x;   // always processed: |FLT_MAX - v| is not <= eps
@@ -2247,6 +2317,11 @@ int prepare_slice_consts(svr_ctx *ctx) {
       S.Lp[1 * 3 + j] = (A[1 * 4 + j] * S.dim[1]) * S.ky;
       S.Lp[2 * 3 + j] = ctx->pvr ? (A[2 * 4 + j] * S.dim[2]) / 2.5f : A[2 * 4 + j] * S.dim[2];
     }
+    // Gaussian recurrence (gauss_pairs): the ratio of ratios, or -1 where the first ratio exp(+-2 z' dz' c - dd c)
+    // of a row that passes the central test (a <= GAUSS_AMAX) could leave the float range
+    S.dd = S.Lp[6] * S.Lp[6];
+    const double tmax = 2.0 * sqrt((double)GAUSS_AMAX * (double)S.inv2s2) * fabs((double)S.Lp[6]) + (double)S.dd * (double)S.inv2s2;
+    S.w = tmax <= 80.0 ? canon_exp_neg((2.0f * S.dd) * S.inv2s2) : -1.0f;
   }
   // which gather suits a slice: share of provably epsilon-dead rows of a pixel that sits on a voxel centre
   ctx->h_rows_sel.assign(ctx->ns, 0);
@@ -2254,6 +2329,8 @@ int prepare_slice_consts(svr_ctx *ctx) {
     RowConst R;
     for (int i = 0; i < 9; ++i) R.Lp[i] = h[s].Lp[i];
     R.inv2s2 = h[s].inv2s2;
+    R.dd = h[s].dd;
+    R.w = h[s].w;
     int dead = 0;
     for (int z = 0; z < PSF_SUPPORT; ++z)
       for (int y = 0; y < PSF_SUPPORT; ++y)

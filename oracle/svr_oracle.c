@@ -127,6 +127,7 @@ static uint32_t f2u_sat(float f) {
 /* ---- canonical sin / exp: IEEE-only building blocks ----------------------- */
 /* |sin(R)| for R>=0; polynomial on [-pi/2,pi/2] after Cody-Waite reduction.  The
  * sign is irrelevant because the PSF squares it (RC.cu:129-130). */
+#define GAUSS_AMAX 60.0f
 static float canon_abs_sin(float R) {
   const float INV_PI = 0.318309886183790671538f;
   const float PI_A = 3.1414794921875f;            /* 3-term split of pi, exact for k < 2^11 */
@@ -171,6 +172,7 @@ typedef struct {
   /* canonical-mode constants */
   float kx, ky, inv2s2;
   float Lp[9];      /* scaled linear part */
+  float dd, w;      /* Gaussian recurrence along a row (canon_gauss_row) */
 } slice_psf;
 
 typedef struct {
@@ -193,6 +195,43 @@ static void slice_setup(const orc_geom *g, int sl, slice_psf *sp) {
     sp->Lp[1 * 3 + j] = (sp->A[1 * 4 + j] * sp->dim[1]) * sp->ky;
     sp->Lp[2 * 3 + j] = g->pvr ? (sp->A[2 * 4 + j] * sp->dim[2]) / 2.5f : sp->A[2 * 4 + j] * sp->dim[2];
   }
+  /* constants of canon_gauss_row: w = exp(-2 dz'^2 / 2 sigma^2), or -1 where the first ratio of a row that passes
+   * the central test could leave the float range (then every row of the slice takes the exponential per tap) */
+  sp->dd = sp->Lp[6] * sp->Lp[6];
+  const double tmax = 2.0 * sqrt((double)GAUSS_AMAX * (double)sp->inv2s2) * fabs((double)sp->Lp[6]) + (double)sp->dd * (double)sp->inv2s2;
+  sp->w = tmax <= 80.0 ? canon_exp_neg((2.0f * sp->dd) * sp->inv2s2) : -1.0f;
+}
+
+/* The canonical Gaussian factor exp(-z'^2 / 2 sigma_z^2) of the N taps of one (y,z) row.  z' is linear along the row,
+ * so neighbouring factors differ by a ratio that itself changes by the constant w: from the two central taps
+ * (lattice offsets 0 and 1) the factors are stepped outwards, g(-j) = g(-j+1) rl, rl *= w; g(1+j) = g(j) rr, rr *= w --
+ * two multiplications per tap instead of an exponential (the device: gauss_pairs in csrc/svr_hip.hip).  Rows whose
+ * central factors are too small to start from (a > GAUSS_AMAX) and slices with w < 0 use canon_exp_neg per tap. */
+static void canon_gauss_row(const slice_psf *sp, float rowz, int N, float *gz) {
+  const int cl = (N - 1) / 2;
+  const float dz = sp->Lp[6], inv = sp->inv2s2;
+  const float zl = fmaf(dz, 0.0f, rowz), zr = fmaf(dz, 1.0f, rowz);
+  const float al = (zl * zl) * inv, ar = (zr * zr) * inv;
+  const float tl = fmaf(-2.0f * zl, dz, sp->dd) * inv, tr = fmaf(2.0f * zr, dz, sp->dd) * inv;
+  float gl = canon_exp_neg(al), gr = canon_exp_neg(ar), rl = canon_exp_neg(tl), rr = canon_exp_neg(tr);
+  const int ok = al <= GAUSS_AMAX && ar <= GAUSS_AMAX && sp->w >= 0.0f;
+  gz[cl] = gl;
+  gz[cl + 1] = gr;
+  for (int j = 1; j < N / 2; ++j) {
+    gl = gl * rl; rl = rl * sp->w;
+    gr = gr * rr; rr = rr * sp->w;
+    if (ok) {
+      gz[cl - j] = gl;
+      gz[cl + 1 + j] = gr;
+    } else {
+      const float a = fmaf(dz, (float)(-j), rowz), b = fmaf(dz, (float)(1 + j), rowz);
+      gz[cl - j] = canon_exp_neg((a * a) * inv);
+      gz[cl + 1 + j] = canon_exp_neg((b * b) * inv);
+    }
+  }
+}
+static float canon_rowz(const slice_psf *sp, const pixel_psf *pp, int oy, int oz) {
+  return fmaf(sp->Lp[7], (float)oy, fmaf(sp->Lp[8], (float)oz, pp->b[2]));
 }
 
 static void pixel_setup(const orc_geom *g, int sl, const slice_psf *sp, int px, int py,
@@ -249,19 +288,17 @@ static float psf_literal(const orc_geom *g, const slice_psf *sp, const pixel_psf
   return si * si * expf((-q[2] * q[2]) / (2.0f * sigmaz * sigmaz));
 }
 static float psf_canon(const orc_geom *g, const slice_psf *sp, const pixel_psf *pp, int ox, int oy, int oz,
-                       float ofs[3]) {
+                       float gz, float ofs[3]) {
   ofs[0] = (float)ox + pp->c[0];
   ofs[1] = (float)oy + pp->c[1];
   ofs[2] = (float)oz + pp->c[2];
   float fx = (float)ox, fy = (float)oy, fz = (float)oz;
   float xs = fmaf(sp->Lp[0], fx, fmaf(sp->Lp[1], fy, fmaf(sp->Lp[2], fz, pp->b[0])));
   float ys = fmaf(sp->Lp[3], fx, fmaf(sp->Lp[4], fy, fmaf(sp->Lp[5], fz, pp->b[1])));
-  float zs = fmaf(sp->Lp[6], fx, fmaf(sp->Lp[7], fy, fmaf(sp->Lp[8], fz, pp->b[2])));
   float q = fmaf(ys, ys, xs * xs);
   float R = 3.14159265359f * sqrtf(q);
   float si = g->pvr ? sinc_pi_f(R, 1) : canon_abs_sin(R) / R;
-  float gz = canon_exp_neg((zs * zs) * sp->inv2s2);
-  return (si * si) * gz;
+  return (si * si) * gz;                               /* gz: the row's canon_gauss_row factor of this tap */
 }
 
 /* One pixel's 16^3 tap walk with the epsilon-skip; calls `visit` for every tap
@@ -273,11 +310,13 @@ static void walk_taps(const orc_geom *g, const slice_psf *sp, const pixel_psf *p
   for (int z = 0; z < S; z++)
     for (int y = 0; y < S; y++) {
       float oldPSF = FLT_MAX;
+      float gz[16];
+      if (g->psf_mode != ORC_PSF_LITERAL) canon_gauss_row(sp, canon_rowz(sp, pp, y - Cn, z - Cn), S, gz);
       for (int x = 0; x < S; x++) {
         float ofs[3];
         float psfval = (g->psf_mode == ORC_PSF_LITERAL)
                            ? psf_literal(g, sp, pp, x - Cn, y - Cn, z - Cn, ofs)
-                           : psf_canon(g, sp, pp, x - Cn, y - Cn, z - Cn, ofs);
+                           : psf_canon(g, sp, pp, x - Cn, y - Cn, z - Cn, gz[x], ofs);
         /* SVR: double literal 0.00001 (RC.cuh:72); PVR: float literal 0.00001f (reconConfig.cuh:138) */
         if (g->pvr ? (fabsf(oldPSF - psfval) < 0.00001f) : ((double)fabsf(oldPSF - psfval) < PSF_EPSILON)) continue;
         oldPSF = psfval;
@@ -516,11 +555,15 @@ void orc_psf_values(const orc_geom *g, int sl, int px, int py, float *vals4096) 
   pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
   const int S = psf_support(g), Cn = psf_centre(g);
   for (int i = 0; i < 4096; ++i) vals4096[i] = 0.0f;
-  for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x) {
-    float ofs[3];
-    vals4096[x + 16 * y + 256 * z] = (g->psf_mode == ORC_PSF_LITERAL)
-        ? psf_literal(g, &sp, &pp, x - Cn, y - Cn, z - Cn, ofs)
-        : psf_canon(g, &sp, &pp, x - Cn, y - Cn, z - Cn, ofs);
+  for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) {
+    float gz[16];
+    if (g->psf_mode != ORC_PSF_LITERAL) canon_gauss_row(&sp, canon_rowz(&sp, &pp, y - Cn, z - Cn), S, gz);
+    for (int x = 0; x < S; ++x) {
+      float ofs[3];
+      vals4096[x + 16 * y + 256 * z] = (g->psf_mode == ORC_PSF_LITERAL)
+          ? psf_literal(g, &sp, &pp, x - Cn, y - Cn, z - Cn, ofs)
+          : psf_canon(g, &sp, &pp, x - Cn, y - Cn, z - Cn, gz[x], ofs);
+    }
   }
 }
 

@@ -71,6 +71,36 @@ def test_psf_taps_are_bit_identical(tiny, oracle_mod):
         assert np.array_equal(packed, bits)
 
 
+@pytest.mark.parametrize("thickness", [1.0, 0.3])
+def test_thin_slices_take_the_exponential_per_tap(oracle_mod, thickness):
+    """The Gaussian factor of a row is stepped outwards from its two central taps (gauss_pairs / canon_gauss_row); rows whose
+    central factors are too small to start from (thickness 1.0: thin slices seen obliquely) and slices whose first ratio
+    could overflow (thickness 0.3: w < 0) evaluate the exponential per tap instead.  Same rows on both sides, bit for bit,
+    and the kernels that consume them agree."""
+    from fetalreconstruction_amd import phantom
+    prob = phantom.make_problem(3, (24, 24, 6), 1.1, 2.2, thickness, 1.0, 11.0, seed=3, orientations=("ax", "cor", "sag"), name="thin")
+    E, rec, orc, dg, do = _drivers(prob, oracle_mod)
+    rec.UpdateScaleVector(np.ones(prob.ns), np.ones(prob.ns))
+    act = np.argwhere(prob.slices != -1)
+    rng = np.random.default_rng(6)
+    direct_rows = 0
+    for i in rng.choice(len(act), 60, replace=False):
+        sl, py, px = act[i]
+        v, c = rec.probe_pixel(sl, px, py)
+        n, bits, vals, cc = orc.tap_census(sl, px, py, with_vals=True)
+        assert np.array_equal(c, cc.astype(np.int32))
+        assert np.array_equal(v.view(np.uint32), vals.view(np.uint32))
+        raw = orc.psf_values(sl, px, py).reshape(16, 16, 16)
+        direct_rows += int(((raw[:, :, 7] == 0) & (raw[:, :, 8] == 0)).sum())          # central factors flushed to 0: rows that start too far out
+    assert direct_rows > 0
+    for d in (dg, do):
+        d.InitializeEMValuesGPU()
+        d.GaussianReconstructionGPU()
+        d.SimulateSlicesGPU()
+    assert rel_err(rec.syncCPU(), orc.recon) < TOL_SUM
+    assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
+
+
 @pytest.mark.parametrize("gauss_mode,fwd_mode", [(1, 3), (1, 2), (1, 1), (0, 1)])
 def test_gaussian_reconstruction_parity(tiny, oracle_mod, gauss_mode, fwd_mode):
     """gauss_mode 1 = tiled pass 1 (row-skipping with fwd_mode 2) + plane-owned scatter, 0 = wave-per-pixel
