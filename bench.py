@@ -23,7 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC_BACK_P4 = (103919.5 + 3574979.1) * 1024.0   # bytes per back_plane_kernel launch, see roofline.traffic
+PMC_TRAFFIC_BACK_P4 = (110879.0 + 3789632.0) * 1024.0   # bytes per back_plane_kernel launch, see roofline.traffic
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F32_PEAK_TFLOPS = 157.3      # f32 MFMA dense peak == f32 vector peak on gfx950 (same guide)
 # algorithmic flops of one PSF tap of the canonical float32 sequence:
@@ -190,12 +190,12 @@ def main():
                 "bound": "mfma", "achieved": flops / bp_avg / 1e12 if bp_n else None, "peak": F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": (flops / bp_avg / 1e12 / F32_PEAK_TFLOPS) if bp_n else None,
                 # bytes per launch through the L2's memory side on P4 (FETCH_SIZE + WRITE_SIZE, separate
-                # rocprofv3 --pmc passes, KB -> B; profiles/r01_c_pmc_back_fwd.txt).  Not measured live.
+                # rocprofv3 --pmc passes, KB -> B; profiles/r01_f_pmc_back_fwd.txt).  Not measured live.
                 "traffic": PMC_TRAFFIC_BACK_P4 if (prob.name == "P4" and world == 1) else None,
                 "note": "f32 VALU bound: 4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; peak = dense f32 "
                         "MFMA peak = f32 vector FMA peak on gfx950; `achieved` counts the 49 algorithmic flops per "
-                        "tap, the kernel issues ~58 VALU instructions per tap and keeps the VALU 77 % active "
-                        "(forward gather: 50 per tap, 92 %; SQ_ACTIVE_INST_VALU, profiles/r01_c_pmc_back_fwd.txt); "
+                        "tap, the kernel issues ~47 VALU instructions per tap and keeps the VALU 70 % active "
+                        "(forward gather: 38 per tap; SQ_ACTIVE_INST_VALU, profiles/r01_f_pmc_back_fwd.txt); "
                         "the HBM view follows",
                 "hbm": {"bound": "hbm", "achieved": b_back / bp_avg / 1e9 if bp_n else None, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": (b_back / bp_avg / 1e9 / HBM_PEAK_GBS) if bp_n else None,
