@@ -486,7 +486,7 @@ int svrh_stack_registrations(svr_ctx *ctx, const svr_ncc_backend *backend, int n
 
 int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backend, int n_slices, const float *slices, int sx, int sy,
                                       const svr_image_attr *attrs, double *transformations, const svr_image_attr *recon_attr,
-                                      const float *reconstructed, long *n_evaluations_or_null, char err[256]) {
+                                      const float *reconstructed, int flags, long *n_evaluations_or_null, char err[256]) {
   if ((!ctx && !backend) || n_slices < 1 || !slices || !attrs || !transformations || !recon_attr || !reconstructed) {
     set_err(err, "svrh_slice_to_volume_registration: bad arguments");
     return 1;
@@ -508,7 +508,9 @@ int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backe
     sl.d.resize(sl.n());
     for (int y = 0; y < sl.a.ny; ++y)
       for (int x = 0; x < sl.a.nx; ++x) sl.at(x, y, 0) = slices[((size_t)s * sy + y) * sx + x];
-    const Vol<double> t = resample_with_padding<double>(sl, recon_attr->dx, recon_attr->dx, recon_attr->dx, -1.0);
+    // the patch-based caller (ParallelPatchToVolumeRegistration, patchBased2D3DRegistration.cpp:113-122) resamples into a variable
+    // that shadows the patch and goes out of scope: its targets are registered as they are
+    const Vol<double> t = (flags & SVRH_S2V_NO_RESAMPLE) ? sl : resample_with_padding<double>(sl, recon_attr->dx, recon_attr->dx, recon_attr->dx, -1.0);
     grey[s].a = t.a;
     grey[s].d.resize(t.d.size());
     short smax = -32768;

@@ -12,8 +12,8 @@
 // the loop in csrc/pvr_host.cpp (PBR.cpp:445-593).  The Python twin is fetalreconstruction_amd/pvr_cli.py.
 //
 // The stack-to-stack registration (irtkStack3D3DRegistration, :280-285) runs through csrc/irtk_reg.cpp with every similarity
-// on the GPU; --no_registration (not a reference option) skips it.  Not built, refused loudly: the patch-to-volume
-// registration (patches keep their stack transformations, so the passes after the first repeat it), superpixels /
+// on the GPU; between the outer passes every patch is registered to the volume with the same schedule
+// (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly: superpixels /
 // hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask, --useFullSlices.
 #include "svr_prep.h"
 
@@ -67,6 +67,8 @@ void match_stack_intensities_pvr(std::vector<Image> &stacks, const std::vector<M
 
 struct Patches {
   std::vector<float> data, i2w, w2i;                   // [n][py][px], [n][16], [n][16]
+  std::vector<float> ri2w, mo, invmo;                  // the origin-reset matrices (patchBasedObject.cuh:285-304), [n][16] each
+  std::vector<svr_image_attr> attr;                    // the patches as images (targets of the patch-to-volume registration)
   int n = 0;
 };
 
@@ -111,6 +113,12 @@ void generate_2d_patches(const Image &stack, double thickness, const Image &mask
           float f[16];
           to_f16(p_i2w, f); out.i2w.insert(out.i2w.end(), f, f + 16);
           to_f16(world_to_image(pa), f); out.w2i.insert(out.w2i.end(), f, f + 16);
+          to_f16(p0_i2w, f); out.ri2w.insert(out.ri2w.end(), f, f + 16);           // RI2W: the patch with its origin at 0
+          M4 mo = ident();
+          for (int k = 0; k < 3; ++k) mo.m[4 * k + 3] = pa.origin[k];
+          to_f16(mo, f); out.mo.insert(out.mo.end(), f, f + 16);
+          to_f16(inverse_rigid_or_affine(mo), f); out.invmo.insert(out.invmo.end(), f, f + 16);
+          out.attr.push_back(pa);
           out.n++;
         }
       }
@@ -216,6 +224,7 @@ int main(int argc, char **argv) {
   Patches P;
   std::vector<int> counts;
   std::vector<float> st, sti, dims;
+  std::vector<double> Td;                                // the registrators' m_transformations, one per patch
   for (size_t k = 0; k < n; ++k) {
     const int before = P.n;
     generate_2d_patches(stacks[k], half_thickness[k], iso_mask, px, py, pstride[0], pstride[1], P);
@@ -224,6 +233,7 @@ int main(int argc, char **argv) {
     to_f16(ts[k], t); to_f16(inverse_rigid_or_affine(ts[k]), ti);
     for (int q = before; q < P.n; ++q) {
       st.insert(st.end(), t, t + 16); sti.insert(sti.end(), ti, ti + 16);
+      Td.insert(Td.end(), ts[k].m, ts[k].m + 16);
       dims.push_back((float)stacks[k].a.dx); dims.push_back((float)stacks[k].a.dy); dims.push_back((float)stacks[k].a.dz);   // getDim()
     }
   }
@@ -276,6 +286,22 @@ int main(int argc, char **argv) {
   pvrh_recon *host = pvrh_create(ctx, counts.data(), (int)counts.size(), vmin, vmax);
   if (!host) die("pvrh_create failed");
   for (int it = 0; it < iterations + 1; ++it) {
+    if (it > 0 && !no_registration) {                    // PBR.cpp:452-489: runHybrid, the IRTK schedule on every patch
+      std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
+      ENG(svr_sync_cpu(ctx, vol.data()));                // m_GPURecon.copyToHost
+      long evals = 0;
+      char e[256] = {0};
+      if (svrh_slice_to_volume_registration(ctx, nullptr, ns, P.data.data(), px, py, P.attr.data(), Td.data(), &tattr, vol.data(),
+                                            SVRH_S2V_NO_RESAMPLE, &evals, e))
+        die(std::string("patch-to-volume registration: ") + e);
+      for (int q = 0; q < ns; ++q) {                     // updateTransformationMatrices (patchBasedObject.cuh:151-169)
+        M4 t;
+        for (int k = 0; k < 16; ++k) t.m[k] = Td[16 * (size_t)q + k];
+        to_f16(t, &st[16 * (size_t)q]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)q]);
+      }
+      ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), P.i2w.data(), P.w2i.data(), P.i2w.data(), P.w2i.data(), ri2w, rw2i));
+      fprintf(stderr, "patch-to-volume registration: %ld similarity evaluations\n", evals);
+    }
     PVRH(pvrh_reconstruct_iteration(host, sr_iterations));
     double sc[8];
     pvrh_get_state(host, nullptr, nullptr, nullptr, sc);

@@ -158,6 +158,15 @@ class irtkPatchBasedReconstruction {
     return 0;
   }
 
+  // patchBased2D3DRegistration<T>::run for all patches (PBR.cpp:452-489): registers them against the current reconstruction and
+  // hands the new transformations back to the engine.  T / Tinv [n][16] in/out, the other matrices as uploaded.
+  int registerPatches(const float *ri2w, const float *mo, const float *invmo, float *T, float *Tinv, const float *i2w, const float *w2i,
+                      const float *recon_i2w, const float *recon_w2i, long long counters3[3]) {
+    PENG(svr_pvr_register_patches(e, ri2w, mo, invmo, T, Tinv, counters3));
+    PENG(svr_set_slice_matrices(e, T, Tinv, i2w, w2i, i2w, w2i, recon_i2w, recon_w2i));
+    return 0;
+  }
+
   // one outer iteration without the patch registration (PBR.cpp:490-548)
   int reconstruct_iteration(int rec_iterations) {
     int rc;
@@ -202,6 +211,10 @@ int pvrh_estep(pvrh_recon *r) { return r->impl.EStep(); }
 int pvrh_mstep(pvrh_recon *r, int iter) { return r->impl.MStep(iter); }
 int pvrh_scale(pvrh_recon *r) { return r->impl.Scale(); }
 int pvrh_reconstruct_iteration(pvrh_recon *r, int rec_iterations) { return r->impl.reconstruct_iteration(rec_iterations); }
+int pvrh_register_patches(pvrh_recon *r, const float *ri2w, const float *mo, const float *invmo, float *T, float *Tinv, const float *i2w,
+                          const float *w2i, const float *recon_i2w, const float *recon_w2i, long long counters3[3]) {
+  return r->impl.registerPatches(ri2w, mo, invmo, T, Tinv, i2w, w2i, recon_i2w, recon_w2i, counters3);
+}
 int pvrh_get_state(pvrh_recon *r, float *scale, float *patch_weight, float *patch_potential, double scalars8[8]) {
   svr::irtkPatchBasedReconstruction &p = r->impl;
   if (scale) std::copy(p.scale.begin(), p.scale.end(), scale);

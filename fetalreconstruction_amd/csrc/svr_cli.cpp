@@ -191,7 +191,7 @@ int main(int argc, char **argv) {
         ENG(svr_sync_cpu(ctx, vol.data()));                               // _reconstructed after SyncCPU, main.cc:1189
         long evals = 0;
         char e[256] = {0};
-        if (svrh_slice_to_volume_registration(ctx, nullptr, ns, grid.data(), mx, my, sattr.data(), T.data(), &tattr, vol.data(), &evals, e))
+        if (svrh_slice_to_volume_registration(ctx, nullptr, ns, grid.data(), mx, my, sattr.data(), T.data(), &tattr, vol.data(), 0, &evals, e))
           die(std::string("slice-to-volume registration: ") + e);
         fprintf(stderr, "slice-to-volume registration: %ld similarity evaluations\n", evals);
       }

@@ -2166,6 +2166,7 @@ struct svr_ctx {
   int tiles_x = 0, tiles_y = 0, tile_w = 4, tile_h = 4;
   int plane_waves = 8;      // waves per workgroup of back_plane_kernel (4 planes each)
   int plane_cap = 9600;     // LDS accumulator voxels of back_plane_kernel: 75 KiB + 4.3 KiB static
+  int pvr_reg_levels = 3, pvr_reg_steps = 4, pvr_reg_iterations = 20;   // PatchBased2D3DRegistration_gpu2 schedule (tests shorten it)
                             // -> exactly 2 workgroups per CU (measured: 1 per CU is 1.6x slower)
   bool psf_list_valid = false;
   unsigned char *d_gauss_flag = nullptr;   // pixels whose sume passed in the current Gaussian pass
@@ -2579,6 +2580,9 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
   if (!strcmp(name, "plane_waves")) { ctx->plane_waves = std::max(4, std::min(value, PLANE_MAX_WAVES)); return SVR_OK; }
   if (!strcmp(name, "plane_cap")) { ctx->plane_cap = std::max(4096, value); return SVR_OK; }
+  if (!strcmp(name, "pvr_reg_levels")) { ctx->pvr_reg_levels = std::min(3, std::max(1, value)); return SVR_OK; }
+  if (!strcmp(name, "pvr_reg_steps")) { ctx->pvr_reg_steps = std::max(1, value); return SVR_OK; }
+  if (!strcmp(name, "pvr_reg_iterations")) { ctx->pvr_reg_iterations = std::max(1, value); return SVR_OK; }
   if (!strcmp(name, "tile_w") || !strcmp(name, "tile_h")) {
     int w = !strcmp(name, "tile_w") ? value : ctx->tile_w, h = !strcmp(name, "tile_h") ? value : ctx->tile_h;
     if (w < 1 || h < 1 || w * h > 64) return fail(ctx, SVR_E_ARG, "tile_w * tile_h must be in 1..64");

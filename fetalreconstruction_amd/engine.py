@@ -42,7 +42,7 @@ EXPORTS = [
     "svr_ncc_evaluate", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
-    "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches",
+    "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches", "svr_pvr_register_patches",
 ]
 
 
@@ -366,6 +366,17 @@ class Reconstruction:
         self._ck(self._lib.svr_pvr_cc_patches(self._h, None if b is None else _p(b), _p(r), _p(t), int(level), _p(out),
                                               _p(sums)))
         return out, sums
+
+    def register_patches(self, ri2w, mo, invmo, transformations):
+        """PatchBased2D3DRegistration_gpu2<T>::run (patchBased2D3DRegistration_gpu2.cu:450-566) -> (T [n][16], Tinv [n][16],
+        counters {launches, evaluations, patches})."""
+        n = self.sgrid[0]
+        r, m, mi = (_f32(a).reshape(n, 16) for a in (ri2w, mo, invmo))
+        t = _f32(transformations).reshape(n, 16).copy()
+        ti = np.zeros((n, 16), np.float32)
+        c = np.zeros(3, np.int64)
+        self._ck(self._lib.svr_pvr_register_patches(self._h, _p(r), _p(m), _p(mi), _p(t), _p(ti), _p(c)))
+        return t, ti, c
 
     def reg_counters(self):
         c = np.zeros(4, np.int64)

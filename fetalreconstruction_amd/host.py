@@ -23,7 +23,7 @@ HOST_EXPORTS = [
     "svrh_get_registration_slices",
 ]
 PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_initialize_em_values", "pvrh_initialize_robust_statistics",
-                    "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_get_state"]      # csrc/pvr_host.cpp
+                    "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_register_patches", "pvrh_get_state"]      # csrc/pvr_host.cpp
 IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_irtk_resample_with_padding",
                 "svrh_irtk_blur_with_padding", "svrh_irtk_rigid_parameters"]                                  # csrc/irtk_reg.cpp
 IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write"]      # csrc/svr_io.cpp, declared in svr_host.h
@@ -343,9 +343,10 @@ def StackRegistrations(rec, stacks, attrs, transformations, template_number, mas
     return t.reshape(n, 4, 4), nev.value
 
 
-def SliceToVolumeRegistration(rec, slices, slice_attrs, transformations, recon_attr, reconstructed, backend=None):
+def SliceToVolumeRegistration(rec, slices, slice_attrs, transformations, recon_attr, reconstructed, backend=None, no_resample=False):
     """irtkReconstruction::SliceToVolumeRegistration (RG.cc:1991-2059, 2291-2303), the reference's default registration
-    -> (new transformations [n][4][4], number of evaluations).  slices: the padded float32 grid [n][sy][sx]."""
+    -> (new transformations [n][4][4], number of evaluations).  slices: the padded float32 grid [n][sy][sx].
+    no_resample: the patch-to-volume registration of the patch-based command line (patchBased2D3DRegistration.cpp:88-225)."""
     lib = _reg_lib()
     g = np.ascontiguousarray(slices, np.float32)
     n, sy, sx = g.shape
@@ -356,7 +357,7 @@ def SliceToVolumeRegistration(rec, slices, slice_attrs, transformations, recon_a
     nev, err = C.c_long(0), C.create_string_buffer(256)
     rc = lib.svrh_slice_to_volume_registration(rec._h if rec is not None else None, C.byref(backend.struct) if backend else None, n,
                                                g.ctypes.data_as(C.c_void_p), sx, sy, at, t.ctypes.data_as(C.c_void_p), C.byref(ra),
-                                               vol.ctypes.data_as(C.c_void_p), C.byref(nev), err)
+                                               vol.ctypes.data_as(C.c_void_p), 1 if no_resample else 0, C.byref(nev), err)
     if rc != 0:
         raise _engine.SvrError(f"svrh_slice_to_volume_registration: {err.value.decode()}")
     return t.reshape(n, 4, 4), nev.value

@@ -32,7 +32,7 @@ class Stack:
     thickness: float
 
 
-def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttributes, pbbsize, stride):
+def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttributes, pbbsize, stride, with_origins=False):
     """patchBasedObject.cuh:176-342.  Returns (patches float32 [n][pY][pX], I2W [n][16], W2I [n][16],
     total_pixels).  A patch starts as an all-zero image (irtkGenericImage(sattr)); pixels whose position
     is inside the slice and inside the mask (mask > 0, no stack transformation applied) are copied; the
@@ -45,7 +45,7 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
     mz, my, mx = mask.shape
     jj, ii = np.meshgrid(np.arange(py), np.arange(px), indexing="ij")
     pix = np.stack([ii, jj, np.zeros_like(ii), np.ones_like(ii)], -1).astype(np.float64)   # [pY][pX][4]
-    out, i2ws, w2is = [], [], []
+    out, i2ws, w2is, origins = [], [], [], []
     total = 0
     for z in range(a.nz):
         centre = s_i2w @ np.array([(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, float(z), 1.0])
@@ -78,20 +78,34 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
                     out.append(patch.astype(np.float32))
                     i2ws.append(geo.to_matrix4(p_i2w))
                     w2is.append(geo.to_matrix4(geo.world_to_image(pa)))
+                    origins.append(np.asarray(pa.origin, np.float64).copy())
     n = len(out)
-    return (np.stack(out) if n else np.zeros((0, py, px), np.float32),
-            np.stack(i2ws) if n else np.zeros((0, 16), np.float32),
-            np.stack(w2is) if n else np.zeros((0, 16), np.float32), total)
+    res = (np.stack(out) if n else np.zeros((0, py, px), np.float32),
+           np.stack(i2ws) if n else np.zeros((0, 16), np.float32),
+           np.stack(w2is) if n else np.zeros((0, 16), np.float32), total)
+    return res + (np.stack(origins) if n else np.zeros((0, 3)),) if with_origins else res
 
 
 def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(32, 32), stride=(16, 16), name="pvr"):
     """PatchBasedVolume<T>::init for every stack (irtkPatchBasedReconstruction.cpp:385-399) packed into
     one Problem: slices = patches, slice dims = the stack's voxel size `getDim()` (z = stack spacing,
     R2/patchBasedPSFReconstruction_gpu.cu:67), T = the stack transformation."""
-    P, I, W, T, TI, D, SI, counts = [], [], [], [], [], [], [], []
+    P, I, W, T, TI, D, SI, counts, RI, MO, MI, AT = [], [], [], [], [], [], [], [], [], [], [], []
     for k, st in enumerate(stacks):
-        p, i2w, w2i, _ = generate2DPatches(st, mask, mask_attr, pbbsize, stride)
+        p, i2w, w2i, _, org = generate2DPatches(st, mask, mask_attr, pbbsize, stride, with_origins=True)
         n = len(p)
+        # the origin-reset matrices of a patch (patchBasedObject.cuh:285-304): Mo = translation by the patch origin,
+        # RI2W = the image-to-world matrix of the same patch with its origin at 0
+        a0 = geo.ImageAttributes(int(pbbsize[0]), int(pbbsize[1]), 1, st.attr.dx, st.attr.dy, st.thickness * 2, st.attr.xaxis, st.attr.yaxis,
+                                 st.attr.zaxis)
+        ri = geo.to_matrix4(geo.image_to_world(a0))
+        for o in org:
+            mo = np.eye(4)
+            mo[:3, 3] = o
+            RI.append(ri); MO.append(geo.to_matrix4(mo)); MI.append(geo.to_matrix4(np.linalg.inv(mo)))
+            at = copy.copy(a0)
+            at.origin = np.asarray(o, np.float64).copy()
+            AT.append(at)
         counts.append(n)
         P.append(p); I.append(i2w); W.append(w2i)
         T.append(np.tile(geo.to_matrix4(st.transformation), (n, 1)))
@@ -113,6 +127,10 @@ def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(3
         min_intensity=float(pos.min()) if pos.size else 0.0, max_intensity=float(pos.max()) if pos.size else 1.0,
         name=name)
     prob.patches_per_stack = counts
+    prob.patch_ri2w = np.stack(RI) if RI else np.zeros((0, 16), np.float32)
+    prob.patch_mo = np.stack(MO) if MO else np.zeros((0, 16), np.float32)
+    prob.patch_invmo = np.stack(MI) if MI else np.zeros((0, 16), np.float32)
+    prob.slice_attr = AT                                   # the patches as images (the targets of the patch-to-volume registration)
     return prob
 
 
@@ -245,6 +263,33 @@ class irtkPatchBasedReconstruction:
     def Scale(self):                                                      # :672-745
         self.scale = np.asarray(self.e.CalculateScaleVector(), np.float32).copy()
         self.e.UpdateScaleVector(self.scale, self.patch_weight)           # copyToScales: no lag
+
+    # ---- patch-to-volume registration (PBR.cpp:452-489) ----------------------------------------
+    def registerPatches(self, prob):
+        """PatchBased2D3DRegistration_gpu2<T>::run -- the reference's GPU variant, which its command line does not call (PBR.cpp:
+        472-476 runs runHybrid, see PatchToVolumeRegistration below) -- for every stack's patches (one call: the engine holds all
+        of them) against the current reconstruction, then the new transformations go back into the engine; updates
+        prob.slice_t / slice_tinv."""
+        t, ti, counters = self.e.register_patches(prob.patch_ri2w, prob.patch_mo, prob.patch_invmo, prob.slice_t)
+        prob.slice_t, prob.slice_tinv = t, ti
+        self.e.SetSliceMatrices(t, ti, prob.slice_i2w, prob.slice_w2i, prob.slice_i2w, prob.slice_w2i, prob.recon_i2w, prob.recon_w2i)
+        return counters
+
+    def PatchToVolumeRegistration(self, prob, T, recon_attr, backend=None):
+        """patchBased2D3DRegistration<T>::runHybrid (patchBased2D3DRegistration.cpp:184-225), what PBR.cpp:452-489 runs between the
+        outer iterations: the IRTK slice-to-volume schedule on every patch (csrc/irtk_reg.cpp, similarities on the GPU) against
+        the host copy of the reconstruction.  T: float64 [n][4][4], the registrator's own transformations; returns the new ones
+        and the number of similarity evaluations, and hands them to the engine."""
+        from . import host
+        vx, vy, vz = prob.vsize
+        vol = np.asarray(self.e.syncCPU(), np.float32).reshape(vz, vy, vx)                 # m_GPURecon.copyToHost
+        hip = self.e if hasattr(self.e, "_h") else None
+        T, evals = host.SliceToVolumeRegistration(hip, prob.slices, prob.slice_attr, T, recon_attr, vol, backend=backend, no_resample=True)
+        t = np.stack([geo.to_matrix4(m) for m in T])
+        ti = np.stack([geo.to_matrix4(np.linalg.inv(m)) for m in T])                       # updateTransformationMatrices
+        prob.slice_t, prob.slice_tinv = t, ti
+        self.e.SetSliceMatrices(t, ti, prob.slice_i2w, prob.slice_w2i, prob.slice_i2w, prob.slice_w2i, prob.recon_i2w, prob.recon_w2i)
+        return T, evals
 
     # ---- the loop ------------------------------------------------------------------------
     def reconstruct_iteration(self, rec_iterations):

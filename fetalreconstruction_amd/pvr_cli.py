@@ -10,10 +10,9 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
         [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7] [--sr_iterations 7]
 
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
-similarity on the GPU; --no_registration (not a reference option) skips it.  Not built, refused loudly: the
-patch-to-volume registration (the patches keep their stack transformations, so every outer pass after the first repeats
-it -- `--iterations 0` is the useful setting), superpixels / hierarchical mode, packages, --existingReconTarget,
---resample, --dilateMask.
+similarity on the GPU; between the outer passes every patch is registered to the volume with the same schedule
+(patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly:
+superpixels / hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.
 """
 from __future__ import annotations
 
@@ -151,7 +150,11 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     pos = np.concatenate([s.data[s.data > 0].astype(np.float32) for s in stacks])          # computeMinMaxIntensities :792-814:
     vmin, vmax = float(pos.min()), float(pos.max())                                       # over the whole (cropped) stacks
     drv = pvr.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, vmin, vmax)
+    T = np.stack([np.asarray(ts[int(k)], np.float64) for k in prob.stack_index])          # the registrators' m_transformations
     for it in range(a.iterations + 1):                                                    # PBR.cpp:445
+        if it > 0 and not a.no_registration:                                              # PBR.cpp:452-489 (runHybrid)
+            T, evals = drv.PatchToVolumeRegistration(prob, T, tattr, backend=_ncc_backend)
+            print(f"patch-to-volume registration: {evals} similarity evaluations", file=sys.stderr)
         drv.reconstruct_iteration(a.sr_iterations)
         print(f"iteration {it}: sigma {float(drv.m_sigma_gpu):.4g} mix {float(drv.m_mix_gpu):.3f}", file=sys.stderr)
     out = rec.syncCPU().reshape(tattr.nz, tattr.ny, tattr.nx)

@@ -228,6 +228,13 @@ int svr_reg_counters(svr_ctx *ctx, long long out4[4]);
  * sums6 = {n, sum a, sum b, sum a^2, sum b^2, sum a*b} (double). */
 int svr_pvr_cc_patches(svr_ctx *ctx, const float *buffer_or_null, const float *RI2W, const float *Tmats, int level,
                        float *ncc_out, double *sums6_or_null);
+/* PatchBased2D3DRegistration_gpu2<T>::run (patchBased2D3DRegistration_gpu2.cu:450-566): the patch-to-volume registration of
+ * the patch-based path, every patch of the slice grid against the current reconstruction; parallelPatchRegOptimization
+ * (:198-291) with a workgroup per patch instead of a thread.  T [n][16] in/out = the patches' transformations, Tinv_out their
+ * inverses; Mo / InvMo / RI2W = the origin-reset matrices of the patches (patchBasedObject.cuh:285-304).
+ * counters3 = {kernel launches, cost evaluations, patches}. */
+int svr_pvr_register_patches(svr_ctx *ctx, const float *RI2W, const float *Mo, const float *InvMo, float *T, float *Tinv_out,
+                             long long *counters3_or_null);
 
 /* ---- measurement -------------------------------------------------------------------- */
 enum svr_timer {

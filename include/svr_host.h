@@ -135,10 +135,14 @@ int svrh_stack_registrations(svr_ctx *ctx, const svr_ncc_backend *backend, int n
                              const svr_image_attr *mask_attr, const double *mask_or_null, int flags, long *n_evaluations_or_null,
                              char err[256]);
 /* irtkReconstruction::SliceToVolumeRegistration (irtkReconstructionGPU.cc:1991-2059, 2291-2303): every slice against the
- * current reconstruction.  slices: the padded grid float [n][sy][sx] (-1 = padding), attrs[i]: slice i's attributes. */
+ * current reconstruction.  slices: the padded grid float [n][sy][sx] (-1 = padding), attrs[i]: slice i's attributes.
+ * flags: SVRH_S2V_NO_RESAMPLE = the patch-to-volume registration the patch-based command line actually runs
+ * (patchBased2D3DRegistration<T>::runHybrid + ParallelPatchToVolumeRegistration, patchBased2D3DRegistration.cpp:88-225): the
+ * same schedule on the patches as they are. */
+#define SVRH_S2V_NO_RESAMPLE 1
 int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backend, int n_slices, const float *slices, int sx, int sy,
                                       const svr_image_attr *attrs, double *transformations, const svr_image_attr *recon_attr,
-                                      const float *reconstructed, long *n_evaluations_or_null, char err[256]);
+                                      const float *reconstructed, int flags, long *n_evaluations_or_null, char err[256]);
 /* building blocks (irtkResamplingWithPadding<short>, irtkGaussianBlurringWithPadding<short>, irtkRigidTransformation::
  * Matrix2Parameters / UpdateMatrix), exported for the tests */
 int svrh_irtk_resample_with_padding(const svr_image_attr *attr, const int16_t *data, double rx, double ry, double rz, int padding,
@@ -163,6 +167,10 @@ int pvrh_mstep(pvrh_recon *r, int iter);
 int pvrh_scale(pvrh_recon *r);
 /* one outer iteration without the patch registration (irtkPatchBasedReconstruction.cpp:490-548) */
 int pvrh_reconstruct_iteration(pvrh_recon *r, int rec_iterations);
+/* the patch-to-volume registration between the outer iterations (irtkPatchBasedReconstruction.cpp:452-489): svr_pvr_register_patches,
+ * then the new transformations go to the engine.  T / Tinv [n][16] in/out; counters3 = {launches, evaluations, patches} */
+int pvrh_register_patches(pvrh_recon *r, const float *ri2w, const float *mo, const float *invmo, float *T, float *Tinv, const float *i2w,
+                          const float *w2i, const float *recon_i2w, const float *recon_w2i, long long counters3[3]);
 /* scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s}; vectors of length sum(patches_per_stack) */
 int pvrh_get_state(pvrh_recon *r, float *scale, float *patch_weight, float *patch_potential, double scalars8[8]);
 

@@ -138,6 +138,17 @@ class OracleReconstruction:
     def UpdateSliceWeights(self, slice_weights):
         self.slice_weights = _f32(slice_weights).copy()
 
+    def SetSliceMatrices(self, slice_transforms, inv_slice_transforms, i2w_init, w2i_init, i2w, w2i, recon_i2w, recon_w2i):
+        """UpdateGPUTranformationMatrices: new slice transformations (the geometry struct points at the kept arrays)"""
+        self._keep[2][:] = _f32(slice_transforms).reshape(self._keep[2].shape)
+        self._keep[3][:] = _f32(inv_slice_transforms).reshape(self._keep[3].shape)
+
+    def register_patches(self, ri2w, mo, invmo, transformations, levels=3, steps=4, iterations=20):
+        """the engine's svr_pvr_register_patches on the oracle's patches and current reconstruction"""
+        vx, vy, vz = self.vsize
+        return pvr_register_patches(self.slices, ri2w, mo, invmo, transformations, self.prob.recon_w2i, self.recon.reshape(vz, vy, vx),
+                                    float(self.prob.vdim[0]), levels, steps, iterations)
+
     def syncCPU(self):
         return self.recon.copy()
 
@@ -427,6 +438,36 @@ def reg_gradient_step(m, g, step):
     out = _f32(m).reshape(16).copy()
     lib().orc_reg_gradient_step(_p(out), _p(_f32(g)), C.c_float(step))
     return out.reshape(4, 4)
+
+
+def pvr_register_patches(patches, ri2w, mo, invmo, transformations, recon_w2i, volume, recon_dim_x, levels=3, steps=4, iterations=20):
+    """PatchBased2D3DRegistration_gpu2<T>::run restated (reg_oracle.c: orc_pvr_register_patches) -> (T, Tinv, counters3)."""
+    b = _f32(patches)
+    n, py, px = b.shape
+    r, m, mi = (_f32(a).reshape(n, 16) for a in (ri2w, mo, invmo))
+    t = _f32(transformations).reshape(n, 16).copy()
+    ti = np.zeros((n, 16), np.float32)
+    w, v = _f32(recon_w2i).reshape(16), _f32(volume)
+    vz, vy, vx = v.shape
+    c = np.zeros(3, np.int64)
+    lib().orc_pvr_register_patches(_p(b), px, py, n, _p(r), _p(m), _p(mi), _p(t), _p(ti), _p(w), _p(v), vx, vy, vz,
+                                   C.c_float(recon_dim_x), int(levels), int(steps), int(iterations), _p(c))
+    return t, ti, c
+
+
+def pvr_blur_patches(patches, sigma):
+    b = _f32(patches)
+    n, py, px = b.shape
+    out = np.zeros_like(b)
+    lib().orc_pvr_blur_patches(_p(b), _p(out), px, py, n, C.c_float(sigma))
+    return out
+
+
+def pvr_params(matrix):
+    m = _f32(matrix).reshape(16)
+    p, r = np.zeros(6, np.float32), np.zeros(16, np.float32)
+    lib().orc_pvr_params(_p(m), _p(p), _p(r))
+    return p, r.reshape(4, 4)
 
 
 def cc_patches(buffers, ri2w, tmats, recon_w2i, volume, level):

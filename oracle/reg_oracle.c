@@ -468,3 +468,205 @@ float orc_cc_patch(const float *buffer, int px, int py, const float *RI2W, const
   if (n > 0) return (xy - (x_ * y_) / n) / (sqrtf(x2 - x_ * x_ / n) * sqrtf(y2 - y_ * y_ / n));
   return 0.0f;
 }
+
+/* ===================== patch-to-volume registration of the patch-based path =====================
+ * PatchBased2D3DRegistration_gpu2<T>::run (R2/patchBased2D3DRegistration_gpu2.cu:450-566) with parallelPatchRegOptimization
+ * (:198-291), Matrix2Parameters / Parameters2Matrix (R2/include/matrix4.cuh:189-260) and patchBasedFilterGaussStack
+ * (R2/GPUGauss/patchBasedGaussfilter.cu:88-335).  The similarity of an evaluation is computeCCpatch with the six moments
+ * accumulated in double in the order of the device's workgroup (256 strided partial sums, the wave's shuffle-down tree, four
+ * waves added left to right) so that both sides take the same optimiser decisions; orc_cc_patch above is the reference's
+ * sequential float accumulation, and tests compare the two. */
+static void pvr_m2p(const float *m, float p[6]) {
+  const float TOL = 0.000001f;
+  p[0] = m[3]; p[1] = m[7]; p[2] = m[11];
+  const float tmp = f_asin(-1.0f * m[2]);
+  if (fabsf(f_cos(tmp)) > TOL) {
+    p[3] = f_atan2(m[6], m[10]);
+    p[4] = tmp;
+    p[5] = f_atan2(m[1], m[0]);
+  } else {
+    p[3] = f_atan2(-1.0f * m[2] * m[4], -1.0f * m[2] * m[8]);
+    p[4] = tmp;
+    p[5] = 0;
+  }
+  for (int k = 3; k < 6; ++k) p[k] = (float)((double)p[k] * (180.0 / 3.14159265358979323846));
+}
+static void pvr_p2m(const float p[6], float *m) {
+  const double k = 3.14159265358979323846 / 180.0;
+  const float cosrx = (float)cos((double)p[3] * k), cosry = (float)cos((double)p[4] * k), cosrz = (float)cos((double)p[5] * k);
+  const float sinrx = (float)sin((double)p[3] * k), sinry = (float)sin((double)p[4] * k), sinrz = (float)sin((double)p[5] * k);
+  m[0] = cosry * cosrz; m[1] = cosry * sinrz; m[2] = -sinry; m[3] = p[0];
+  m[4] = (sinrx * sinry * cosrz - cosrx * sinrz); m[5] = (sinrx * sinry * sinrz + cosrx * cosrz); m[6] = sinrx * cosry; m[7] = p[1];
+  m[8] = (cosrx * sinry * cosrz + sinrx * sinrz); m[9] = (cosrx * sinry * sinrz - sinrx * cosrz); m[10] = cosrx * cosry; m[11] = p[2];
+  m[12] = 0; m[13] = 0; m[14] = 0; m[15] = 1.0f;
+}
+void orc_pvr_params(const float *m, float p6[6], float *rebuilt16) { pvr_m2p(m, p6); pvr_p2m(p6, rebuilt16); }
+
+/* GaussXKernel / GaussYKernel of the patch-based filter: a neighbour outside the patch contributes 0 (PGF.cu:107-111), -1 is
+ * left alone, negative neighbours count as 0.  (The reference launches 32x32 thread blocks over each patch and lets the threads
+ * beyond the patch width wrap into other rows: patch sizes that are not a multiple of 32 race there.) */
+void orc_pvr_blur_patches(const float *in, float *out, int px, int py, int n, float sigma) {
+  float half[40];
+  memset(half, 0, sizeof(half));
+  const int klen = orc_reg_gauss_kernel(sigma, half);
+  int nh = (klen + 1) / 2, nh_y = nh;
+  if (klen == 13) { half[nh] = half[nh - 1]; nh_y = nh + 1; }      /* GaussYKernel<14> for klength 13 (PGF.cu:311) */
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)px * py);
+  for (int p = 0; p < n; ++p) {
+    const float *src = in + (size_t)p * px * py;
+    float *dst = out + (size_t)p * px * py;
+    for (int y = 0; y < py; ++y)
+      for (int x = 0; x < px; ++x) {
+        float v = src[y * px + x];
+        if (v != -1) {
+          v = v * half[0];
+          for (int i = 1; i < nh; ++i) {
+            const float a = (x + i) < px ? max0(src[y * px + x + i]) : 0.0f;
+            const float b = (x - i) >= 0 ? max0(src[y * px + x - i]) : 0.0f;
+            v = v + half[i] * (a + b);
+          }
+        }
+        tmp[y * px + x] = v;
+      }
+    for (int y = 0; y < py; ++y)
+      for (int x = 0; x < px; ++x) {
+        float v = tmp[y * px + x];
+        if (v != -1) {
+          v = v * half[0];
+          for (int i = 1; i < nh_y; ++i) {
+            const float a = (y + i) < py ? max0(tmp[(y + i) * px + x]) : 0.0f;
+            const float b = (y - i) >= 0 ? max0(tmp[(y - i) * px + x]) : 0.0f;
+            v = v + half[i] * (a + b);
+          }
+        }
+        dst[y * px + x] = v;
+      }
+  }
+  free(tmp);
+}
+
+/* computeCCpatch with the moments summed like the device's workgroup */
+static float cc_patch_tree(const float *buf, int px, int py, const float *ri2w, const float *tmat, const float *reconW2I,
+                           const float *vol, int vx, int vy, int vz, int level) {
+  float M[16];
+  matmul4f(tmat, ri2w, M);
+  const int st = level + 1, nx = (px + st - 1) / st, ny = (py + st - 1) / st, total = nx * ny * 3;
+  static double part[6][256];
+  for (int k = 0; k < 6; ++k) for (int t = 0; t < 256; ++t) part[k][t] = 0;
+  for (int t = 0; t < 256; ++t)
+    for (int i = t; i < total; i += 256) {
+      const int z = i % 3 - 1, r = i / 3;
+      const int x = (r % nx) * st, y = (r / nx) * st;
+      const float a = buf[y * px + x];
+      float pos[3] = {(float)x, (float)y, (float)z}, w[3], vp[3];
+      matvec3(M, pos, w);
+      matvec3(reconW2I, w, vp);
+      const float b = interp_sw(vp, vol, vx, vy, vz);
+      if (a >= 0.0f && b >= 0.0f && a == a && b == b) {
+        part[0][t] += 1.0; part[1][t] += (double)a; part[2][t] += (double)b;
+        part[3][t] += (double)(a * a); part[4][t] += (double)(b * b); part[5][t] += (double)(a * b);
+      }
+    }
+  double s[6];
+  for (int k = 0; k < 6; ++k) {
+    double wsum[4];
+    for (int w = 0; w < 4; ++w) {
+      double v[64];
+      for (int l = 0; l < 64; ++l) v[l] = part[k][64 * w + l];
+      for (int off = 32; off > 0; off >>= 1)
+        for (int l = 0; l + off < 64; ++l) v[l] = v[l] + v[l + off];     /* lane l reads the old value of lane l + off: ascending l */
+      wsum[w] = v[0];
+    }
+    s[k] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  const float cnt = (float)s[0], x = (float)s[1], y = (float)s[2], x2 = (float)s[3], y2 = (float)s[4], xy = (float)s[5];
+  return s[0] > 0 ? (xy - (x * y) / cnt) / (sqrtf(x2 - x * x / cnt) * sqrtf(y2 - y * y / cnt)) : 0.0f;
+}
+
+/* one parallelPatchRegOptimization run of one patch; returns the number of evaluations */
+static int pvr_patch_opt(const float *buf, int px, int py, const float *ri2w, float *mat, const float *reconW2I, const float *vol,
+                         int vx, int vy, int vz, int level, float step) {
+  float params[6], dxt[6], cur[16];
+  memcpy(cur, mat, sizeof(cur));
+  pvr_m2p(cur, params);
+  int n_eval = 0;
+  for (int i = 0; i < 6; ++i) {
+    const float pv = params[i];
+    params[i] = pv + step; pvr_p2m(params, cur);
+    const float s1 = cc_patch_tree(buf, px, py, ri2w, cur, reconW2I, vol, vx, vy, vz, level);
+    params[i] = pv - step; pvr_p2m(params, cur);
+    const float s2 = cc_patch_tree(buf, px, py, ri2w, cur, reconW2I, vol, vx, vy, vz, level);
+    dxt[i] = s1 - s2;
+    params[i] = pv; pvr_p2m(params, cur);
+    n_eval += 2;
+  }
+  float norm = 0;
+  for (int i = 0; i < 6; ++i) norm += dxt[i] * dxt[i];
+  norm = sqrtf(norm);
+  for (int i = 0; i < 6; ++i) dxt[i] = norm > 0.0f ? dxt[i] / norm : 0.0f;
+  float similarity = cc_patch_tree(buf, px, py, ri2w, cur, reconW2I, vol, vx, vy, vz, level), new_similarity;
+  int count = 0;
+  n_eval += 1;
+  do {
+    new_similarity = similarity;
+    for (int i = 0; i < 6; ++i) params[i] = params[i] + step * dxt[i];
+    pvr_p2m(params, cur);
+    similarity = cc_patch_tree(buf, px, py, ri2w, cur, reconW2I, vol, vx, vy, vz, level);
+    count++;
+    n_eval += 1;
+  } while (similarity > new_similarity + 0.0001f && count < 50);
+  for (int i = 0; i < 6; ++i) params[i] = params[i] - step * dxt[i];
+  pvr_p2m(params, cur);
+  memcpy(mat, cur, sizeof(cur));
+  return n_eval;
+}
+
+static void invert4d(const double *a, double *out) {
+  double w[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) { w[i][j] = a[4 * i + j]; w[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 4; ++r) if (fabs(w[r][c]) > fabs(w[p][c])) p = r;
+    for (int j = 0; j < 8; ++j) { const double t = w[c][j]; w[c][j] = w[p][j]; w[p][j] = t; }
+    const double d = w[c][c];
+    for (int j = 0; j < 8; ++j) w[c][j] /= d;
+    for (int r = 0; r < 4; ++r)
+      if (r != c) { const double f = w[r][c]; for (int j = 0; j < 8; ++j) w[r][j] -= f * w[c][j]; }
+  }
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = w[i][4 + j];
+}
+
+/* levels, steps, iterations: 3, 4, 20 in the reference (its run() also iterates an undefined fourth level, see the engine) */
+void orc_pvr_register_patches(const float *patches, int px, int py, int n, const float *RI2W, const float *Mo, const float *InvMo,
+                              float *T, float *Tinv_out, const float *reconW2I, const float *vol, int vx, int vy, int vz,
+                              float recon_dim_x, int levels, int steps, int iterations, long long *counters3) {
+  float *M = (float *)malloc(sizeof(float) * 16 * (size_t)n);
+  float *buf = (float *)malloc(sizeof(float) * (size_t)n * px * py);
+  long long evals = 0, launches = 0;
+  for (int i = 0; i < n; ++i) matmul4f(T + 16 * (size_t)i, Mo + 16 * (size_t)i, M + 16 * (size_t)i);
+  for (int level = levels - 1; level >= 0; --level) {
+    const float sigma = (recon_dim_x / 2.0f) * (float)(1 << level);
+    orc_pvr_blur_patches(patches, buf, px, py, n, sigma);
+    float step = 2.0f * (float)(1 << level);
+    for (int st = 0; st < steps; ++st) {
+      for (int it = 0; it < iterations; ++it) {
+        for (int i = 0; i < n; ++i)
+          evals += pvr_patch_opt(buf + (size_t)i * px * py, px, py, RI2W + 16 * (size_t)i, M + 16 * (size_t)i, reconW2I, vol, vx, vy,
+                                 vz, level, step);
+        ++launches;
+      }
+      step /= 2.0f;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    matmul4f(M + 16 * (size_t)i, InvMo + 16 * (size_t)i, T + 16 * (size_t)i);
+    double a[16], inv[16];
+    for (int k = 0; k < 16; ++k) a[k] = T[16 * (size_t)i + k];
+    invert4d(a, inv);
+    for (int k = 0; k < 16; ++k) Tinv_out[16 * (size_t)i + k] = (float)inv[k];
+  }
+  if (counters3) { counters3[0] = launches; counters3[1] = evals; counters3[2] = n; }
+  free(M);
+  free(buf);
+}
