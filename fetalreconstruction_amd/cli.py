@@ -10,8 +10,8 @@ smoothing schedule.
 Stack transformations (`id`, IRTK rigid `dof` files or 4x4 text matrices) start the stack-to-stack registration
 (StackRegistrations, before and after the other stacks are cropped, main.cc:661,711); slice-to-volume registration is
 the reference's default IRTK schedule with every similarity evaluated on the GPU (csrc/irtk_reg.cpp) or, with
---useGPUReg, the reference's GPU registration.  --no_registration (not a reference option) skips both.  Packages,
-superpixels and the CPU reconstruction path are refused, loudly.
+--useGPUReg, the reference's GPU registration.  --no_registration (not a reference option) skips both.  --packages runs PackageToVolume
+with the schedule of main.cc:832-864.  Superpixels and the CPU reconstruction path are refused, loudly.
 """
 from __future__ import annotations
 
@@ -51,7 +51,8 @@ def _parser():
     p.add_argument("--disableBiasCorrection", action="store_true", default=True)
     p.add_argument("-d", "--devices", nargs="+", type=int, default=[0])
     p.add_argument("--debug", action="store_true")
-    for refused in ("--packages", "--useCPU", "--patchBased", "--superpixelBased", "--tfolder", "--sfolder"):
+    p.add_argument("--packages", nargs="+", type=int)
+    for refused in ("--useCPU", "--patchBased", "--superpixelBased", "--tfolder", "--sfolder"):
         p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
     return p
 
@@ -71,7 +72,7 @@ def _load_transformation(spec):
 
 def main(argv=None):
     a = _parser().parse_args(argv)
-    for refused in ("packages", "useCPU", "patchBased", "superpixelBased", "tfolder", "sfolder"):
+    for refused in ("useCPU", "patchBased", "superpixelBased", "tfolder", "sfolder"):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/cli.py)")
     n = len(a.input)
@@ -87,6 +88,8 @@ def main(argv=None):
     thickness = a.thickness or [2.0 * s.attr.dz for s in stacks]           # main.cc:422-431: twice the z spacing
     if len(thickness) != n:
         raise SystemExit("one thickness per stack expected")
+    if a.packages and len(a.packages) != n:
+        raise SystemExit("one package count per stack expected")
     template = next((k for k, s in enumerate(a.transformation or ["id"] * n) if s == "id"), 0)   # first 'id' stack
     mask = None
     if a.mask:
@@ -130,7 +133,20 @@ def main(argv=None):
     rs = reg.PrepareRegistrationSlices(rec, prob.slices, prob.slice_attr, resolution) if a.useGPUReg else None
     T = np.stack(slice_t)
     for it in range(a.iterations):                                                               # main.cc:816-1237
-        if it > 0 and not a.no_registration:                                                     # main.cc:829-880
+        slice_reg = it > 0 and not a.no_registration
+        if slice_reg and a.packages and it <= a.iterations * (a.multires - 1) // a.multires and it < a.iterations - 1:
+            # packages first (main.cc:832-864): plain, even/odd, even/odd halves; from iteration 4 on also the slices
+            vol = rec.syncCPU().reshape(tattr.nz, tattr.ny, tattr.nx)
+            T, evals = host.PackageToVolume(rec, [s.data for s in stacks], [s.attr for s in stacks], a.packages, T, tattr, vol,
+                                            evenodd=it >= 2, half=it >= 3, half_iter=max(1, it - 2) if it >= 4 else 1)
+            print(f"package-to-volume registration: {evals} similarity evaluations", file=sys.stderr)
+            slice_reg = it >= 4
+            if not slice_reg:
+                ti = np.stack([np.linalg.inv(t) for t in T])
+                rec.SetSliceMatrices(np.stack([t.astype(np.float32).reshape(16) for t in T]),
+                                     np.stack([t.astype(np.float32).reshape(16) for t in ti]), prob.slice_i2w, prob.slice_w2i,
+                                     prob.slice_i2w, prob.slice_w2i, prob.recon_i2w, prob.recon_w2i)
+        if slice_reg:                                                                            # main.cc:829-880
             if a.useGPUReg:
                 T = reg.SliceToVolumeRegistrationGPU(rec, rs, T)
             else:                                                                                # SliceToVolumeRegistration, RG.cc:2291-2303

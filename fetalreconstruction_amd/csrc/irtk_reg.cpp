@@ -248,6 +248,8 @@ struct Target {                                            // one registration: 
   const Vol<short> *full;                                  // the unprocessed target
   Vol<short> lvl;                                          // this level's image
   int first_plane = 0;                                     // index of its plane 0 among the backend's targets
+  int own_padding = 0;                                     // 1: `padding` replaces the call's target padding (GuessParameter's corner rule)
+  short padding = 0;
   M4 matrix;                                               // irtkRigidTransformation::_matrix
   double p[6];                                             // ... and its parameters
   // optimiser state (irtkImageRegistration::Run + irtkGradientDescentOptimizer::Run)
@@ -297,7 +299,8 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
       for (int r = r0; r < r1; ++r) {
         Target &t = targets[r];
         const Schedule p = guess_parameters(t.full->a, source.a, slice_to_volume);
-        bad[r] = prepare_level(*t.full, p.t_blur[level], p.t_res[level], p.t_res[0], level, target_padding, t.lvl, errs[r]);
+        bad[r] = prepare_level(*t.full, p.t_blur[level], p.t_res[level], p.t_res[0], level, t.own_padding ? t.padding : target_padding, t.lvl,
+                               errs[r]);
         t.phase = PH_START; t.step_i = 0; t.iter_j = 0; t.done = false;
         t.step = p.length[level]; t.delta = p.delta[level];
       }
@@ -533,6 +536,127 @@ int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backe
   for (size_t k = 0; k < targets.size(); ++k) {
     const M4 m = mul(params_to_matrix(targets[k].p), mo_inv[which[k]]);
     for (int q = 0; q < 16; ++q) transformations[16 * which[k] + q] = m.m[q];
+  }
+  return 0;
+}
+
+// SplitImage, RG.cc:4979-5035: every `packages`-th slice, starting at l = 0 .. packages-1
+static void split_image(const Vol<double> &image, int packages, std::vector<Vol<double>> &out) {
+  const int pkg_z = image.a.nz / packages;
+  const M4 i2w = image_to_world(image.a);
+  for (int l = 0; l < packages; ++l) {
+    Vol<double> st;
+    st.a = image.a;
+    st.a.nz = (pkg_z * packages + l) < image.a.nz ? pkg_z + 1 : pkg_z;
+    st.a.dz = image.a.dz * packages;
+    st.d.resize(st.n());
+    for (int k = 0; k < st.a.nz; ++k)
+      for (int j = 0; j < st.a.ny; ++j)
+        for (int i = 0; i < st.a.nx; ++i) st.at(i, j, k) = image.at(i, j, k * packages + l);
+    // adjust the origin so that voxel (0,0,0) of the package sits on voxel (0,0,l) of the image
+    const double x = i2w.m[2] * l + i2w.m[3], y = i2w.m[6] * l + i2w.m[7], z = i2w.m[10] * l + i2w.m[11];
+    const M4 s = image_to_world(st.a);
+    st.a.origin[0] += x - s.m[3]; st.a.origin[1] += y - s.m[7]; st.a.origin[2] += z - s.m[11];
+    out.push_back(st);
+  }
+}
+static Vol<double> z_region(const Vol<double> &im, int z1, int z2) {     // GetRegion(0, 0, z1, nx, ny, z2)
+  Vol<double> o;
+  o.a = im.a;
+  o.a.nz = z2 - z1;
+  const M4 i2w = image_to_world(im.a);
+  const double c[3] = {(im.a.nx - 1) / 2.0, (im.a.ny - 1) / 2.0, z1 + (o.a.nz - 1) / 2.0};
+  for (int k = 0; k < 3; ++k) o.a.origin[k] = i2w.m[4 * k] * c[0] + i2w.m[4 * k + 1] * c[1] + i2w.m[4 * k + 2] * c[2] + i2w.m[4 * k + 3];
+  o.d.assign(im.d.begin() + (size_t)z1 * im.a.nx * im.a.ny, im.d.begin() + (size_t)z2 * im.a.nx * im.a.ny);
+  return o;
+}
+static void split_even_odd(const Vol<double> &image, int packages, std::vector<Vol<double>> &out) {      // RG.cc:5037-5055
+  std::vector<Vol<double>> packs;
+  split_image(image, packages, packs);
+  for (const Vol<double> &p : packs) split_image(p, 2, out);
+}
+static void split_even_odd_half(const Vol<double> &image, int packages, std::vector<Vol<double>> &out, int iter) {   // RG.cc:5057-5093
+  std::vector<Vol<double>> packs;
+  if (iter > 1) split_even_odd_half(image, packages, packs, iter - 1);
+  else split_even_odd(image, packages, packs);
+  for (const Vol<double> &p : packs) {
+    if (p.a.nz >= 4) { out.push_back(z_region(p, 0, p.a.nz / 2)); out.push_back(z_region(p, p.a.nz / 2, p.a.nz)); }   // HalfImage
+    else out.push_back(p);
+  }
+}
+
+// irtkReconstruction::PackageToVolume, RG.cc:5096-5192: every package of every stack is registered to the reconstruction as
+// one 3-D target (GuessParameterSliceToVolume; the target padding is the corner guess, no SetTargetPadding) and its
+// transformation is given to all of its slices.  transformations: one per slice, stacks in order.
+int svrh_package_to_volume(svr_ctx *ctx, const svr_ncc_backend *backend, int n_stacks, const svr_image_attr *attrs, const double *const *stacks,
+                           const int *pack_num, int evenodd, int half, int half_iter, double *transformations,
+                           const svr_image_attr *recon_attr, const float *reconstructed, long *n_evaluations_or_null, char err[256]) {
+  if ((!ctx && !backend) || n_stacks < 1 || !attrs || !stacks || !pack_num || !transformations || !recon_attr || !reconstructed) {
+    set_err(err, "svrh_package_to_volume: bad arguments");
+    return 1;
+  }
+  if (n_evaluations_or_null) *n_evaluations_or_null = 0;
+  const Backend be{ctx, backend};
+  Vol<short> source;
+  source.a = *recon_attr;
+  source.d.resize(source.n());
+  for (size_t i = 0; i < source.d.size(); ++i) source.d[i] = (short)reconstructed[i];
+  struct Pack { Vol<short> grey; M4 mo_inv; int first; std::vector<int> slices; };
+  std::vector<Pack> packs;
+  int first_slice = 0;
+  for (int s = 0; s < n_stacks; ++s) {
+    if (pack_num[s] < 1) { set_err(err, "svrh_package_to_volume: package counts must be positive"); return 1; }
+    Vol<double> st;
+    st.a = attrs[s];
+    st.d.assign(stacks[s], stacks[s] + st.n());
+    std::vector<Vol<double>> pk;
+    if (evenodd) { if (half) split_even_odd_half(st, pack_num[s], pk, half_iter); else split_even_odd(st, pack_num[s], pk); }
+    else split_image(st, pack_num[s], pk);
+    const M4 s_w2i = world_to_image(st.a);
+    for (const Vol<double> &p : pk) {
+      if (p.a.nz < 1) continue;
+      Pack q;
+      const M4 p_i2w = image_to_world(p.a);
+      for (int k = 0; k < p.a.nz; ++k) {                                    // which slices of the stack the package holds
+        const double wx = p_i2w.m[2] * k + p_i2w.m[3], wy = p_i2w.m[6] * k + p_i2w.m[7], wz = p_i2w.m[10] * k + p_i2w.m[11];
+        const double z = s_w2i.m[8] * wx + s_w2i.m[9] * wy + s_w2i.m[10] * wz + s_w2i.m[11];
+        q.slices.push_back((int)irtk_round(z) + first_slice);
+      }
+      q.first = q.slices[0];
+      q.grey.a = p.a;
+      q.grey.d.resize(p.d.size());
+      for (size_t i = 0; i < p.d.size(); ++i) q.grey.d[i] = (short)p.d[i];
+      packs.push_back(q);
+    }
+    first_slice += st.a.nz;
+  }
+  std::vector<Target> targets(packs.size());
+  for (size_t k = 0; k < packs.size(); ++k) {
+    Pack &q = packs[k];
+    Target &tg = targets[k];
+    tg.own_padding = 1;
+    tg.padding = guess_padding(q.grey);                                    // before ResetOrigin: values only
+    M4 mo, m;
+    reset_origin(q.grey.a, mo);
+    q.mo_inv = inverse_rigid_or_affine(mo);
+    for (int c = 0; c < 16; ++c) m.m[c] = transformations[16 * (size_t)q.first + c];
+    tg.full = &q.grey;
+    tg.matrix = mul(m, mo);
+    matrix_to_params(tg.matrix, tg.p);
+  }
+  std::string e;
+  const int rc = run_registrations(be, targets, source, 1, (short)0, n_evaluations_or_null, e);
+  if (rc) { set_err(err, e); return rc; }
+  for (size_t k = 0; k < packs.size(); ++k) {
+    const M4 m = mul(params_to_matrix(targets[k].p), packs[k].mo_inv);      // PutMatrix: the first slice keeps this matrix
+    double p6[6];
+    matrix_to_params(m, p6);
+    const M4 rebuilt = params_to_matrix(p6);                                // the other slices: parameters copied, UpdateMatrix
+    for (size_t j = 0; j < packs[k].slices.size(); ++j) {
+      const int sl = packs[k].slices[j];
+      const M4 &use = sl == packs[k].first ? m : rebuilt;
+      for (int c = 0; c < 16; ++c) transformations[16 * (size_t)sl + c] = use.m[c];
+    }
   }
   return 0;
 }

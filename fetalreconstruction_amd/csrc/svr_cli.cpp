@@ -16,7 +16,8 @@
 // stack-to-stack registration (StackRegistrations, before and after the other stacks are cropped, main.cc:661,711).
 // Slice-to-volume registration is the reference's default IRTK schedule (csrc/irtk_reg.cpp, every similarity evaluation
 // on the GPU) or, with --useGPUReg, the reference's GPU registration.  --no_registration (not a reference option) skips
-// both.  Not built, refused loudly: packages, patch/superpixel modes, the CPU reconstruction path.
+// both.  --packages runs PackageToVolume with the schedule of main.cc:832-864.  Not built, refused loudly: patch/superpixel
+// modes, the CPU reconstruction path.
 #include "svr_prep.h"
 
 
@@ -24,7 +25,7 @@ int main(int argc, char **argv) {
   std::string output, mask_name;
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
-  std::vector<int> force_excluded, devices;
+  std::vector<int> force_excluded, devices, packages;
   int iterations = 4, levels = 3, rec_first = 4, rec_last = 13;
   double resolution = 0.75, average = 700, delta = 150, lambda = 0.02, last_lambda = 0.01, smooth_mask = 4;
   bool no_matching = false, use_gpu_reg = false, no_registration = false;
@@ -53,6 +54,7 @@ int main(int argc, char **argv) {
     else if (o == "--rec_iterations_first") rec_first = atoi(one().c_str());
     else if (o == "--rec_iterations_last") rec_last = atoi(one().c_str());
     else if (o == "--useGPUReg") use_gpu_reg = true;
+    else if (o == "-p" || o == "--packages") { std::vector<std::string> v; multi(v); for (auto &x : v) packages.push_back(atoi(x.c_str())); }
     else if (o == "--no_registration") no_registration = true;
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
     else if (o == "-d" || o == "--devices") { std::vector<std::string> v; multi(v); for (auto &s : v) devices.push_back(atoi(s.c_str())); }
@@ -60,7 +62,7 @@ int main(int argc, char **argv) {
       printf("usage: SVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> [-m <mask>] [-t id|<4x4.txt> ..] [--thickness th_1 ..]\n"
              "       [--iterations 4] [--resolution 0.75] [--multires 3] [--average 700] [--delta 150] [--lambda 0.02]\n"
              "       [--lastIterLambda 0.01] [--smooth_mask 4] [--no_intensity_matching] [--force_exclude i ..]\n"
-             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--useGPUReg] [--no_registration] [-d device]\n");
+             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [-d device]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/svr_cli.cpp)");
@@ -70,6 +72,7 @@ int main(int argc, char **argv) {
   const size_t n = inputs.size();
   if (tspecs.empty()) tspecs.assign(n, "id");
   if (tspecs.size() != n) die("one transformation per stack expected");
+  if (!packages.empty() && packages.size() != n) die("one package count per stack expected");
 
   svr_ctx *ctx = nullptr;
   if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
@@ -183,7 +186,31 @@ int main(int argc, char **argv) {
 
   // ---- registration-reconstruction loop (main.cc:816-1237) ---------------------------------------------
   for (int it = 0; it < iterations; ++it) {
-    if (it > 0 && !no_registration) {                                     // main.cc:829-880
+    bool slice_reg = it > 0 && !no_registration;
+    if (slice_reg && !packages.empty() && it <= iterations * (levels - 1) / levels && it < iterations - 1) {
+      // packages first (main.cc:832-864): plain, even/odd, even/odd halves; from iteration 4 on also the slices
+      std::vector<svr_image_attr> at(n);
+      std::vector<const double *> ptr(n);
+      for (size_t k = 0; k < n; ++k) { at[k] = stacks[k].a; ptr[k] = stacks[k].d.data(); }
+      std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
+      ENG(svr_sync_cpu(ctx, vol.data()));
+      long evals = 0;
+      char e[256] = {0};
+      if (svrh_package_to_volume(ctx, nullptr, (int)n, at.data(), ptr.data(), packages.data(), it >= 2, it >= 3, it >= 4 ? it - 2 : 1, T.data(),
+                                 &tattr, vol.data(), &evals, e))
+        die(std::string("package-to-volume registration: ") + e);
+      fprintf(stderr, "package-to-volume registration: %ld similarity evaluations\n", evals);
+      slice_reg = it >= 4;
+      if (!slice_reg) {
+        for (int s = 0; s < ns; ++s) {
+          M4 t;
+          for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];
+          to_f16(t, &st[16 * (size_t)s]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)s]);
+        }
+        ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), i2w.data(), w2i.data(), i2w.data(), w2i.data(), ri2w, rw2i));
+      }
+    }
+    if (slice_reg) {                                                      // main.cc:829-880
       if (use_gpu_reg) {
         HOST(svrh_slice_to_volume_registration_gpu(host, T.data()));
       } else {                                                            // SliceToVolumeRegistration, RG.cc:2291-2303

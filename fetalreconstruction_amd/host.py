@@ -24,7 +24,7 @@ HOST_EXPORTS = [
 ]
 PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_initialize_em_values", "pvrh_initialize_robust_statistics",
                     "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_register_patches", "pvrh_get_state"]      # csrc/pvr_host.cpp
-IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_irtk_resample_with_padding",
+IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_package_to_volume", "svrh_irtk_resample_with_padding",
                 "svrh_irtk_blur_with_padding", "svrh_irtk_rigid_parameters"]                                  # csrc/irtk_reg.cpp
 IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write"]      # csrc/svr_io.cpp, declared in svr_host.h
 
@@ -361,6 +361,28 @@ def SliceToVolumeRegistration(rec, slices, slice_attrs, transformations, recon_a
     if rc != 0:
         raise _engine.SvrError(f"svrh_slice_to_volume_registration: {err.value.decode()}")
     return t.reshape(n, 4, 4), nev.value
+
+
+def PackageToVolume(rec, stacks, attrs, pack_num, transformations, recon_attr, reconstructed, evenodd=False, half=False, half_iter=1,
+                    backend=None):
+    """irtkReconstruction::PackageToVolume (RG.cc:5096-5192) -> (new per-slice transformations [n][4][4], evaluations)."""
+    lib = _reg_lib()
+    n = len(stacks)
+    data = [np.ascontiguousarray(s, np.float64) for s in stacks]
+    ptrs = (C.c_void_p * n)(*[d.ctypes.data for d in data])
+    at = (ImageAttr * n)(*[ImageAttr.of(a) for a in attrs])
+    pk = (C.c_int * n)(*[int(p) for p in pack_num])
+    t = np.ascontiguousarray(transformations, np.float64).reshape(-1, 16).copy()
+    assert len(t) == sum(int(a.nz) for a in attrs), "one transformation per slice"
+    vol = np.ascontiguousarray(reconstructed, np.float32)
+    ra = ImageAttr.of(recon_attr)
+    nev, err = C.c_long(0), C.create_string_buffer(256)
+    rc = lib.svrh_package_to_volume(rec._h if rec is not None else None, C.byref(backend.struct) if backend else None, n, at, ptrs, pk,
+                                    int(bool(evenodd)), int(bool(half)), int(half_iter), t.ctypes.data_as(C.c_void_p), C.byref(ra),
+                                    vol.ctypes.data_as(C.c_void_p), C.byref(nev), err)
+    if rc != 0:
+        raise _engine.SvrError(f"svrh_package_to_volume: {err.value.decode()}")
+    return t.reshape(-1, 4, 4), nev.value
 
 
 def irtk_resample_with_padding(data, attr, size3, padding):

@@ -143,6 +143,13 @@ int svrh_stack_registrations(svr_ctx *ctx, const svr_ncc_backend *backend, int n
 int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backend, int n_slices, const float *slices, int sx, int sy,
                                       const svr_image_attr *attrs, double *transformations, const svr_image_attr *recon_attr,
                                       const float *reconstructed, int flags, long *n_evaluations_or_null, char err[256]);
+/* irtkReconstruction::PackageToVolume (irtkReconstructionGPU.cc:5096-5192) with SplitImage / SplitImageEvenOdd /
+ * SplitImageEvenOddHalf / HalfImage (:4979-5094): the packages (interleaved sub-stacks) of every stack are registered to
+ * the reconstruction as 3-D targets and their transformations handed to their slices.  pack_num[i]: packages of stack i;
+ * transformations: one per slice, double [n_slices][16], in/out. */
+int svrh_package_to_volume(svr_ctx *ctx, const svr_ncc_backend *backend, int n_stacks, const svr_image_attr *attrs, const double *const *stacks,
+                           const int *pack_num, int evenodd, int half, int half_iter, double *transformations,
+                           const svr_image_attr *recon_attr, const float *reconstructed, long *n_evaluations_or_null, char err[256]);
 /* building blocks (irtkResamplingWithPadding<short>, irtkGaussianBlurringWithPadding<short>, irtkRigidTransformation::
  * Matrix2Parameters / UpdateMatrix), exported for the tests */
 int svrh_irtk_resample_with_padding(const svr_image_attr *attr, const int16_t *data, double rx, double ry, double rz, int padding,

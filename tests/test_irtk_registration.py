@@ -177,3 +177,44 @@ def test_engine_and_oracle_evaluators_give_the_same_trajectory(tiny, oracle_mod)
     dev, nev_d = host.StackRegistrations(rec, *sargs)
     cpu, nev_c = host.StackRegistrations(None, *sargs, backend=_oracle_backend(oracle_mod))
     assert nev_d == nev_c and np.array_equal(dev, cpu)
+
+
+# ---- packages (interleaved sub-stacks): PackageToVolume ------------------------------------------------------------------------
+def _package_case():
+    """one axial stack acquired as 2 interleaved packages that moved differently, and the analytic volume"""
+    R = 13.0
+    a = geo.ImageAttributes(36, 36, 14, 1.1, 1.1, 2.2)
+    t_pack = [geo.rigid_matrix(1.2, -0.8, 0.5, 1.5, -2.0, 1.0), geo.rigid_matrix(-1.0, 0.9, -0.6, -1.0, 1.5, -2.0)]
+    kk, jj, ii = np.meshgrid(np.arange(a.nz), np.arange(a.ny), np.arange(a.nx), indexing="ij")
+    pix = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(np.float64)
+    data = np.zeros((a.nz, a.ny, a.nx))
+    for k in range(a.nz):
+        w = (pix[k] @ geo.image_to_world(a).T) @ t_pack[k % 2].T
+        data[k] = phantom.phantom_intensity(w[..., :3], R) * 700 / 0.55
+    ra = geo.ImageAttributes(34, 34, 34, 1.0, 1.0, 1.0)
+    kk, jj, ii = np.meshgrid(np.arange(34), np.arange(34), np.arange(34), indexing="ij")
+    w = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(np.float64) @ geo.image_to_world(ra).T
+    vol = (phantom.phantom_intensity(w[..., :3], R) * 700 / 0.55).astype(np.float32)
+    return a, data, t_pack, ra, vol
+
+
+def test_package_to_volume_recovers_package_motion(oracle_mod):
+    a, data, t_pack, ra, vol = _package_case()
+    start = np.tile(np.eye(4), (a.nz, 1, 1))
+    be = _oracle_backend(oracle_mod)
+    t, nev = host.PackageToVolume(None, [data], [a], [2], start, ra, vol, backend=be)
+    err = [_max_error_mm(t[k], t_pack[k % 2], 10.0) for k in range(a.nz)]
+    before = [_max_error_mm(np.eye(4), t_pack[k % 2], 10.0) for k in range(a.nz)]
+    print("package registration: error before", np.round(before[:2], 2), "after", np.round(err[:2], 2), "evaluations", nev, "calls", be.calls)
+    assert max(err) < 0.5 * min(before)
+    for k in range(2, a.nz):                                    # every slice of a package carries its package's transformation
+        assert np.allclose(t[k], t[k % 2], atol=1e-12)
+    assert not np.allclose(t[0], t[1], atol=1e-3)
+    assert be.calls < nev                                        # the two packages advance in lock step
+    # even/odd splitting: 2 x 2 sub-packages, slices 0,4,8,.. / 2,6,.. / 1,5,.. / 3,7,..
+    t2, _ = host.PackageToVolume(None, [data], [a], [2], start, ra, vol, evenodd=True, backend=_oracle_backend(oracle_mod))
+    groups = {tuple(np.round(m.reshape(-1), 9)) for m in t2}
+    assert len(groups) == 4 and np.allclose(t2[0], t2[4]) and np.allclose(t2[1], t2[5]) and not np.allclose(t2[0], t2[2])
+    # halves of the even/odd packages (HalfImage: packages of >= 4 slices are cut in two)
+    t3, _ = host.PackageToVolume(None, [data], [a], [1], start, ra, vol, evenodd=True, half=True, half_iter=1, backend=_oracle_backend(oracle_mod))
+    assert len({tuple(np.round(m.reshape(-1), 9)) for m in t3}) == 4          # 1 package -> even/odd (7 + 7 slices) -> halves (3 + 4 each)

@@ -152,7 +152,7 @@ def test_command_line_registration_recovers_stack_motion(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("registration", ["none", "irtk", "gpu"])
+@pytest.mark.parametrize("registration", ["none", "irtk", "gpu", "packages"])
 def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
     """bin/SVRreconstructionGPU (csrc/svr_cli.cpp: C++ pre-processing + the C++ host object) against cli.py."""
     import subprocess
@@ -160,7 +160,10 @@ def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
     paths, mpath, rattr, rmask = _write_case(tmp_path)
     common = ["-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "2",
               "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2"] + {"none": ["--no_registration"], "irtk": [],
-                                                                                                  "gpu": ["--useGPUReg"]}[registration]
+                                                                                                  "gpu": ["--useGPUReg"],
+                                                                                                  "packages": ["--packages", "2", "2", "2"]}[registration]
+    if registration == "packages":
+        common[common.index("--iterations") + 1] = "3"            # iteration 1 registers the packages, iteration 2 the slices
     assert cli.main(["-o", str(tmp_path / "py.nii.gz"), *common]) == 0
     r = subprocess.run([build.CLI, "-o", str(tmp_path / "cc.nii.gz"), *common], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -170,6 +173,8 @@ def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
     assert np.array_equal(vp == -1, vc == -1)
     if registration == "irtk":
         assert "stack-to-stack registration" in r.stderr and "slice-to-volume registration" in r.stderr
+    if registration == "packages":
+        assert "package-to-volume registration" in r.stderr and "slice-to-volume registration" in r.stderr
     if registration != "none":
         # the optimisers amplify last-bit differences of their inputs (numpy vs C++ summation order in the pre-processing)
         # into different accept/reject decisions: compare the volumes as images
@@ -178,5 +183,5 @@ def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
         assert np.corrcoef(vp[ok], vc[ok])[0, 1] > 0.98
     else:
         assert np.abs(vp - vc).max() <= 2e-4 * np.abs(vp).max()
-    bad = subprocess.run([build.CLI, "-o", "x.nii", "-i", paths[0], "--packages", "2"], capture_output=True, text=True)
+    bad = subprocess.run([build.CLI, "-o", "x.nii", "-i", paths[0], "--useCPU"], capture_output=True, text=True)
     assert bad.returncode != 0 and "not supported" in bad.stderr
