@@ -86,17 +86,24 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
     return res + (np.stack(origins) if n else np.zeros((0, 3)),) if with_origins else res
 
 
-def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(32, 32), stride=(16, 16), name="pvr"):
+def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(32, 32), stride=(16, 16), name="pvr", superpixel=False):
     """PatchBasedVolume<T>::init for every stack (irtkPatchBasedReconstruction.cpp:385-399) packed into
     one Problem: slices = patches, slice dims = the stack's voxel size `getDim()` (z = stack spacing,
     R2/patchBasedPSFReconstruction_gpu.cu:67), T = the stack transformation."""
-    P, I, W, T, TI, D, SI, counts, RI, MO, MI, AT = [], [], [], [], [], [], [], [], [], [], [], []
+    P, I, W, T, TI, D, SI, counts, RI, MO, MI, AT, SM = [], [], [], [], [], [], [], [], [], [], [], [], []
     for k, st in enumerate(stacks):
-        p, i2w, w2i, _, org = generate2DPatches(st, mask, mask_attr, pbbsize, stride, with_origins=True)
+        if superpixel:      # pbbsize = --spxSize, stride = --spxExtend (pvrmain:291-296); patches of 64x64 with a mask each
+            from . import slic
+            p, i2w, w2i, sm, org, _ = slic.generate2DSuperpixelPatches(st, mask, mask_attr, pbbsize, stride[0])
+            SM.append(sm)
+            pbb = (p.shape[2], p.shape[1])
+        else:
+            p, i2w, w2i, _, org = generate2DPatches(st, mask, mask_attr, pbbsize, stride, with_origins=True)
+            pbb = pbbsize
         n = len(p)
         # the origin-reset matrices of a patch (patchBasedObject.cuh:285-304): Mo = translation by the patch origin,
         # RI2W = the image-to-world matrix of the same patch with its origin at 0
-        a0 = geo.ImageAttributes(int(pbbsize[0]), int(pbbsize[1]), 1, st.attr.dx, st.attr.dy, st.thickness * 2, st.attr.xaxis, st.attr.yaxis,
+        a0 = geo.ImageAttributes(int(pbb[0]), int(pbb[1]), 1, st.attr.dx, st.attr.dy, st.thickness * 2, st.attr.xaxis, st.attr.yaxis,
                                  st.attr.zaxis)
         ri = geo.to_matrix4(geo.image_to_world(a0))
         for o in org:
@@ -131,6 +138,7 @@ def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(3
     prob.patch_mo = np.stack(MO) if MO else np.zeros((0, 16), np.float32)
     prob.patch_invmo = np.stack(MI) if MI else np.zeros((0, 16), np.float32)
     prob.slice_attr = AT                                   # the patches as images (the targets of the patch-to-volume registration)
+    prob.spx_masks = np.concatenate(SM) if SM else None    # [n][4096] '1' / 0, 64 wide (ImagePatch2D.cuh:51)
     return prob
 
 

@@ -12,7 +12,8 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
 similarity on the GPU; between the outer passes every patch is registered to the volume with the same schedule
 (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly:
-superpixels / hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.
+hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.  -s/--superpixel cuts SLICO superpixel patches
+(slic.py) instead of square ones; the patch-to-volume registration is skipped in that mode (undefined in the reference).
 """
 from __future__ import annotations
 
@@ -43,8 +44,10 @@ def _parser():
     p.add_argument("--sr_iterations", type=int, default=7)
     p.add_argument("--thickness", nargs="+", type=float)
     p.add_argument("-d", "--devices", nargs="+", type=int, default=[0])
-    for refused in ("--superpixel", "--hierarchical", "--packages", "--existingReconTarget", "--resample", "--dilateMask",
-                    "--useFullSlices"):
+    p.add_argument("-s", "--superpixel", action="store_true")
+    p.add_argument("--spxSize", type=int, default=16)
+    p.add_argument("--spxExtend", type=int, default=50)
+    for refused in ("--hierarchical", "--packages", "--existingReconTarget", "--resample", "--dilateMask", "--useFullSlices"):
         p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
     return p
 
@@ -113,13 +116,15 @@ def _hip_engine(prob, device):
     rec = engine.Reconstruction(device)                  # raises when the HIP library is missing: no CPU path
     rec.set_option("pvr", 1)
     engine.sync_gpu(rec, prob, quality_factor=1.0)       # m_quality_factor = 1 (PBR.cpp:415)
+    if getattr(prob, "spx_masks", None) is not None:
+        rec.set_spx_masks(prob.spx_masks)                # ImagePatch2D::spxMask of every patch
     return rec
 
 
 def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     """`_engine_factory` / `_ncc_backend` exist for the CPU tests, which drive the same pipeline over the test oracle."""
     a = _parser().parse_args(argv)
-    for refused in ("superpixel", "hierarchical", "packages", "existingReconTarget", "resample", "dilateMask", "useFullSlices"):
+    for refused in ("hierarchical", "packages", "existingReconTarget", "resample", "dilateMask", "useFullSlices"):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/pvr_cli.py)")
     n = len(a.input)
@@ -143,8 +148,11 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     stacks, ts, iso_mask, tattr, recon_mask = prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), a.resolution, template,
                                                       a.noMatchIntensities, None if a.no_registration else register)
     pstacks = [pvr.Stack(s.data.astype(np.float32), s.attr, t, th / 2.0) for s, t, th in zip(stacks, ts, thickness)]
-    prob = pvr.make_pvr_problem(pstacks, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, a.patchSize, a.patchStride)
-    print(f"{n} stacks, {prob.ns} patches of {a.patchSize[0]}x{a.patchSize[1]} {prob.patches_per_stack}, volume {prob.vsize} at "
+    if a.superpixel:                                                                      # pvrmain:291-296
+        a.patchSize, a.patchStride = [a.spxSize, a.spxSize], [a.spxExtend, a.spxExtend]
+    prob = pvr.make_pvr_problem(pstacks, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, a.patchSize, a.patchStride,
+                                superpixel=a.superpixel)
+    print(f"{n} stacks, {prob.ns} patches of {prob.slices.shape[2]}x{prob.slices.shape[1]} {prob.patches_per_stack}, volume {prob.vsize} at "
           f"{a.resolution} mm", file=sys.stderr)
     rec = _engine_factory(prob, a.devices[0])
     pos = np.concatenate([s.data[s.data > 0].astype(np.float32) for s in stacks])          # computeMinMaxIntensities :792-814:
@@ -152,7 +160,12 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     drv = pvr.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, vmin, vmax)
     T = np.stack([np.asarray(ts[int(k)], np.float64) for k in prob.stack_index])          # the registrators' m_transformations
     for it in range(a.iterations + 1):                                                    # PBR.cpp:445
-        if it > 0 and not a.no_registration:                                              # PBR.cpp:452-489 (runHybrid)
+        if it > 0 and not a.no_registration and a.superpixel:
+            # runHybrid registers the square CPU patches of generatePatchesCPU (patchBased2D3DRegistration.cpp:227-375) and
+            # updateTransformationMatrices then reads one transformation per GPU patch from that shorter list: undefined in
+            # the reference for superpixel patches, not done here
+            print("superpixel mode: the patch-to-volume registration is skipped", file=sys.stderr)
+        elif it > 0 and not a.no_registration:                                            # PBR.cpp:452-489 (runHybrid)
             T, evals = drv.PatchToVolumeRegistration(prob, T, tattr, backend=_ncc_backend)
             print(f"patch-to-volume registration: {evals} similarity evaluations", file=sys.stderr)
         drv.reconstruct_iteration(a.sr_iterations)

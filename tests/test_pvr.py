@@ -319,7 +319,7 @@ def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
     means = [P.slices[P.stack_index == k][P.slices[P.stack_index == k] > 0].mean() for k in range(2)]
     assert abs(means[0] / means[1] - 1) < 0.05
     with pytest.raises(SystemExit, match="not supported"):
-        pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--superpixel"], _engine_factory=factory)
+        pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--hierarchical"], _engine_factory=factory)
 
 
 def test_pvr_intensity_matching_rules():
@@ -402,7 +402,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path):
     assert np.array_equal(patches, P.slices)                      # same float arithmetic, same rounding
     assert np.allclose(i2w, P.slice_i2w, atol=1e-5)
     assert vmin == np.float32(pmin) and vmax == np.float32(pmax)
-    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--superpixel"], capture_output=True, text=True)
+    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--superpixel"], capture_output=True, text=True)   # C++: square patches only
     assert bad.returncode != 0 and "not supported" in bad.stderr
 
 
