@@ -293,11 +293,13 @@ def test_ragged_and_empty_inputs(oracle_mod):
     assert rel_err(rec.syncCPU(), orc.recon) < 1e-4
 
 
-def test_adjointness_at_full_size():
-    """Size-independent property on the P4 workload (too big for the oracle): the forward
+@pytest.mark.parametrize("workload", ["P4", "S8"])
+def test_adjointness_at_full_size(workload):
+    """Size-independent property on the full-size workloads (too big for the oracle) -- P4 = BASELINE.json configs[1]
+    (4 stacks, 1.0 mm), S8 = configs[3] (8 stacks of 64 x 256^2 slices, 0.75 mm, 33.5 M pixels, 40 M voxels): the forward
     projection and the scatter are adjoint, <A V, e> = <V, A^T e> with unit voxel/slice weights."""
     from fetalreconstruction_amd import engine as E
-    P = phantom.problem_p4()
+    P = phantom.problem_p4() if workload == "P4" else phantom.problem_s8()
     rec = _engine(P)
     rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
     rec.InitializeEMValues()
