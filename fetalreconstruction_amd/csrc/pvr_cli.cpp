@@ -13,9 +13,10 @@
 //
 // The stack-to-stack registration (irtkStack3D3DRegistration, :280-285) runs through csrc/irtk_reg.cpp with every similarity
 // on the GPU; between the outer passes every patch is registered to the volume with the same schedule
-// (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly: superpixels /
-// hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask, --useFullSlices.
+// (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.
+// -s / --superpixel cuts SLICO superpixel patches (csrc/svr_slic.h).  Not built, refused loudly: hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask, --useFullSlices.
 #include "svr_prep.h"
+#include "svr_slic.h"
 
 namespace {
 
@@ -137,7 +138,8 @@ int main(int argc, char **argv) {
   std::vector<int> devices, psize, pstride;
   int iterations = 7, sr_iterations = 7;
   double resolution = 0.75;
-  bool no_matching = false, dry_run = false, no_registration = false;
+  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false;
+  int spx_size = 16, spx_extend = 50;                    // pvrmain:104-106
   std::string dump_name;                                 // test hooks: --dumpProblem <file> [--dryRun]
   // ---- options (pvrmain:108-131) ---------------------------------------------------------------------
   auto is_opt = [](const char *s) { return s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.'; };
@@ -161,10 +163,13 @@ int main(int argc, char **argv) {
     else if (o == "--dumpProblem") dump_name = one();
     else if (o == "--dryRun") dry_run = true;
     else if (o == "--no_registration") no_registration = true;
+    else if (o == "-s" || o == "--superpixel") superpixel = true;
+    else if (o == "--spxSize") spx_size = atoi(one().c_str());
+    else if (o == "--spxExtend") spx_extend = atoi(one().c_str());
     else if (o == "-h" || o == "--help") {
       printf("usage: PVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> -m <mask> [-t id|<dof>|<4x4.txt> ..]\n"
              "       [--thickness th_1 ..] [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7]\n"
-             "       [--sr_iterations 7] [--noMatchIntensities] [--no_registration] [-d device]\n");
+             "       [--sr_iterations 7] [--noMatchIntensities] [--no_registration] [-s [--spxSize 16] [--spxExtend 50]] [-d device]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/pvr_cli.cpp)");
@@ -220,14 +225,29 @@ int main(int argc, char **argv) {
   const Image recon_mask = transform_nn(iso_mask, tattr, ts[tmpl], 0.0);                         // :303-304
 
   // ---- patches (PBR.cpp:385-399) -----------------------------------------------------------------------
-  const int px = psize[0], py = psize[1];
+  int px = psize[0], py = psize[1];
   Patches P;
+  std::vector<char> spx_masks;
   std::vector<int> counts;
   std::vector<float> st, sti, dims;
   std::vector<double> Td;                                // the registrators' m_transformations, one per patch
   for (size_t k = 0; k < n; ++k) {
     const int before = P.n;
-    generate_2d_patches(stacks[k], half_thickness[k], iso_mask, px, py, pstride[0], pstride[1], P);
+    if (superpixel) {                                    // pvrmain:291-296: patch size = spxSize, stride = spxExtend
+      SpxPatches sp;
+      slic_superpixel_patches(stacks[k], half_thickness[k], iso_mask, spx_size, spx_size, spx_extend, sp);
+      if (P.n > 0 && (sp.px != px || sp.py != py)) die("superpixel patches of different sizes (slices narrower than 64 pixels differ between the stacks)");
+      px = sp.px; py = sp.py;
+      P.data.insert(P.data.end(), sp.data.begin(), sp.data.end());
+      P.i2w.insert(P.i2w.end(), sp.i2w.begin(), sp.i2w.end()); P.w2i.insert(P.w2i.end(), sp.w2i.begin(), sp.w2i.end());
+      P.ri2w.insert(P.ri2w.end(), sp.ri2w.begin(), sp.ri2w.end()); P.mo.insert(P.mo.end(), sp.mo.begin(), sp.mo.end());
+      P.invmo.insert(P.invmo.end(), sp.invmo.begin(), sp.invmo.end());
+      P.attr.insert(P.attr.end(), sp.attr.begin(), sp.attr.end());
+      spx_masks.insert(spx_masks.end(), sp.masks.begin(), sp.masks.end());
+      P.n += sp.n;
+    } else {
+      generate_2d_patches(stacks[k], half_thickness[k], iso_mask, px, py, pstride[0], pstride[1], P);
+    }
     counts.push_back(P.n - before);
     float t[16], ti[16];
     to_f16(ts[k], t); to_f16(inverse_rigid_or_affine(ts[k]), ti);
@@ -250,6 +270,7 @@ int main(int argc, char **argv) {
     fwrite(hdr, sizeof(int), 8, f); fwrite(counts.data(), sizeof(int), n, f); fwrite(mm, sizeof(float), 2, f);
     fwrite(P.data.data(), sizeof(float), P.data.size(), f); fwrite(P.i2w.data(), sizeof(float), P.i2w.size(), f);
     fwrite(mf.data(), sizeof(float), mf.size(), f);
+    if (superpixel) fwrite(spx_masks.data(), 1, spx_masks.size(), f);
     fclose(f);
   }
   if (dry_run) return 0;
@@ -269,6 +290,7 @@ int main(int argc, char **argv) {
   std::vector<int> sizes_x(ns, px), sizes_y(ns, py);
   ENG(svr_init_storage_volumes(ctx, ssize, &dims[0]));
   ENG(svr_fill_slices(ctx, P.data.data(), sizes_x.data(), sizes_y.data()));
+  if (superpixel) ENG(svr_set_spx_masks(ctx, spx_masks.data()));
   ENG(svr_set_slice_dims(ctx, dims.data(), 1.0f));
   {
     svr_image_attr pa;
@@ -286,7 +308,11 @@ int main(int argc, char **argv) {
   pvrh_recon *host = pvrh_create(ctx, counts.data(), (int)counts.size(), vmin, vmax);
   if (!host) die("pvrh_create failed");
   for (int it = 0; it < iterations + 1; ++it) {
-    if (it > 0 && !no_registration) {                    // PBR.cpp:452-489: runHybrid, the IRTK schedule on every patch
+    if (it > 0 && !no_registration && superpixel) {
+      // runHybrid registers the square CPU patches of generatePatchesCPU and updateTransformationMatrices then reads one
+      // transformation per GPU patch from that shorter list: undefined in the reference for superpixel patches, not done
+      fprintf(stderr, "superpixel mode: the patch-to-volume registration is skipped\n");
+    } else if (it > 0 && !no_registration) {             // PBR.cpp:452-489: runHybrid, the IRTK schedule on every patch
       std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
       ENG(svr_sync_cpu(ctx, vol.data()));                // m_GPURecon.copyToHost
       long evals = 0;

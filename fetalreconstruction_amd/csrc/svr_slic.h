@@ -1,0 +1,273 @@
+// svr_slic.h -- SLICO superpixels and the superpixel patches of the patch-based path in C++, included by
+// csrc/pvr_cli.cpp after svr_prep.h.  The Python twin is fetalreconstruction_amd/slic.py; tests compare the two.
+//   runStackSLIC<T>::segmentSLIC, rgbtolab, getLABXYSeeds, PerformSuperpixelSLICO, EnforceSuperpixelConnectivity
+//       source/reconstructionGPU2/runStackSLIC.cpp:55-151, 291-537, 665-840 (SLICO itself is Achanta et al.'s published code)
+//   PatchBasedObject<T>::generate2DSuperpixelPatches, dilatePatch
+//       source/reconstructionGPU2/include/patchBasedObject.cuh:347-367, 433-802
+// Kept quirks: the slice goes into SLIC's buffer column by column and is segmented as a ny-wide, nx-high image (the
+// transposed slice); klabels of pixels no seed window reaches are undefined in the reference (-1 here); the connectivity
+// pass writes past its 10 * SUPSZ work arrays for larger segments there (dynamic here); the superpixel loop stops before the
+// largest label; patches are 64x64 clamped to the slice; a patch pixel that keeps the dilated mask value but falls outside
+// the mask image keeps the value 1.
+#ifndef SVR_SLIC_H
+#define SVR_SLIC_H
+
+#include <float.h>
+#include <limits.h>
+
+namespace {
+
+void slic_rgbtolab(const std::vector<int> &grey, std::vector<double> &l, std::vector<double> &a, std::vector<double> &b) {
+  const double epsilon = 0.008856, kappa = 903.3, Xr = 0.950456, Yr = 1.0, Zr = 1.088754;
+  const size_t n = grey.size();
+  l.resize(n); a.resize(n); b.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    const double R = grey[i] / 255.0;
+    const double r = R <= 0.04045 ? R / 12.92 : pow((R + 0.055) / 1.055, 2.4);
+    const double X = r * 0.4124564 + r * 0.3575761 + r * 0.1804375;
+    const double Y = r * 0.2126729 + r * 0.7151522 + r * 0.0721750;
+    const double Z = r * 0.0193339 + r * 0.1191920 + r * 0.9503041;
+    const double xr = X / Xr, yr = Y / Yr, zr = Z / Zr;
+    const double fx = xr > epsilon ? pow(xr, 1.0 / 3.0) : (kappa * xr + 16.0) / 116.0;
+    const double fy = yr > epsilon ? pow(yr, 1.0 / 3.0) : (kappa * yr + 16.0) / 116.0;
+    const double fz = zr > epsilon ? pow(zr, 1.0 / 3.0) : (kappa * zr + 16.0) / 116.0;
+    l[i] = 116.0 * fy - 16.0; a[i] = 500.0 * (fx - fy); b[i] = 200.0 * (fy - fz);
+  }
+}
+
+std::vector<int> slic_seeds(int STEP, int width, int height) {
+  int xstrips = (int)(0.5 + (double)width / (double)STEP), ystrips = (int)(0.5 + (double)height / (double)STEP);
+  int xerr = width - STEP * xstrips;
+  if (xerr < 0) { xstrips--; xerr = width - STEP * xstrips; }
+  int yerr = height - STEP * ystrips;
+  if (yerr < 0) { ystrips--; yerr = height - STEP * ystrips; }
+  const double xeps = (double)xerr / (double)xstrips, yeps = (double)yerr / (double)ystrips;
+  const int off = STEP / 2;
+  std::vector<int> seeds;
+  for (int y = 0; y < ystrips; ++y) {
+    const int ye = (int)(y * yeps);
+    for (int x = 0; x < xstrips; ++x) {
+      const int xe = (int)(x * xeps);
+      seeds.push_back((y * STEP + off + ye) * width + (x * STEP + off + xe));
+    }
+  }
+  return seeds;
+}
+
+void slic_slico(const std::vector<double> &lv, const std::vector<double> &av, const std::vector<double> &bv, const std::vector<int> &seeds, int width,
+                int height, int STEP, std::vector<int> &klabels) {
+  const int sz = width * height, numk = (int)seeds.size();
+  std::vector<double> kx(numk), ky(numk), kl(numk), ka(numk), kb(numk), maxlab(numk, 100.0), distlab(sz, DBL_MAX), distvec(sz);
+  for (int k = 0; k < numk; ++k) { kx[k] = seeds[k] % width; ky[k] = seeds[k] / width; kl[k] = lv[seeds[k]]; ka[k] = av[seeds[k]]; kb[k] = bv[seeds[k]]; }
+  klabels.assign(sz, -1);
+  const double invxywt = 1.0 / (STEP * STEP);
+  std::vector<double> sl(numk), sa(numk), sb(numk), sx(numk), sy(numk), cs(numk);
+  for (int itr = 0; itr < 10; ++itr) {
+    std::fill(distvec.begin(), distvec.end(), DBL_MAX);
+    for (int n = 0; n < numk; ++n) {
+      int x1 = (int)(kx[n] - STEP); if (x1 < 0) x1 = 0;
+      int y1 = (int)(ky[n] - STEP); if (y1 < 0) y1 = 0;
+      int x2 = (int)(kx[n] + STEP); if (x2 > width) x2 = width;
+      int y2 = (int)(ky[n] + STEP); if (y2 > height) y2 = height;
+      for (int y = y1; y < y2; ++y)
+        for (int x = x1; x < x2; ++x) {
+          const int i = y * width + x;
+          const double l = lv[i], a = av[i], b = bv[i];
+          distlab[i] = (l - kl[n]) * (l - kl[n]) + (a - ka[n]) * (a - ka[n]) + (b - kb[n]) * (b - kb[n]);
+          const double distxy = (x - kx[n]) * (x - kx[n]) + (y - ky[n]) * (y - ky[n]);
+          const double dist = distlab[i] / maxlab[n] + distxy * invxywt;
+          if (dist < distvec[i]) { distvec[i] = dist; klabels[i] = n; }
+        }
+    }
+    if (itr == 0) std::fill(maxlab.begin(), maxlab.end(), 1.0);
+    for (int i = 0; i < sz; ++i)
+      if (klabels[i] >= 0 && maxlab[klabels[i]] < distlab[i]) maxlab[klabels[i]] = distlab[i];
+    for (int k = 0; k < numk; ++k) sl[k] = sa[k] = sb[k] = sx[k] = sy[k] = cs[k] = 0;
+    int ind = 0;
+    for (int r = 0; r < height; ++r)
+      for (int c = 0; c < width; ++c, ++ind)
+        if (klabels[ind] >= 0) {
+          const int k = klabels[ind];
+          sl[k] += lv[ind]; sa[k] += av[ind]; sb[k] += bv[ind]; sx[k] += c; sy[k] += r; cs[k] += 1.0;
+        }
+    for (int k = 0; k < numk; ++k) {
+      const double inv = 1.0 / (cs[k] <= 0 ? 1.0 : cs[k]);
+      kl[k] = sl[k] * inv; ka[k] = sa[k] * inv; kb[k] = sb[k] * inv; kx[k] = sx[k] * inv; ky[k] = sy[k] * inv;
+    }
+  }
+}
+
+void slic_connectivity(const std::vector<int> &labels, int width, int height, int num_superpixels, std::vector<int> &nl) {
+  static const int dx4[4] = {-1, 0, 1, 0}, dy4[4] = {0, -1, 0, 1};
+  const int sz = width * height, supsz = sz / std::max(num_superpixels, 1);
+  nl.assign(sz, -1);
+  int label = 0, adjlabel = 0;
+  std::vector<int> xs, ys;
+  for (int o = 0; o < sz; ++o) {
+    if (nl[o] >= 0) continue;
+    const int j = o / width, k = o % width;
+    nl[o] = label;
+    for (int n = 0; n < 4; ++n) {
+      const int x = k + dx4[n], y = j + dy4[n];
+      if (x >= 0 && x < width && y >= 0 && y < height && nl[y * width + x] >= 0) adjlabel = nl[y * width + x];
+    }
+    xs.assign(1, k); ys.assign(1, j);
+    for (size_t c = 0; c < xs.size(); ++c)
+      for (int n = 0; n < 4; ++n) {
+        const int x = xs[c] + dx4[n], y = ys[c] + dy4[n];
+        if (x >= 0 && x < width && y >= 0 && y < height) {
+          const int ni = y * width + x;
+          if (nl[ni] < 0 && labels[o] == labels[ni]) { xs.push_back(x); ys.push_back(y); nl[ni] = label; }
+        }
+      }
+    if ((int)xs.size() <= (supsz >> 2)) {
+      for (size_t c = 0; c < xs.size(); ++c) nl[ys[c] * width + xs[c]] = adjlabel;
+      label--;
+    }
+    label++;
+  }
+}
+
+// segmentSLIC: labels of every slice, float like the reference's stack_spx, [z][y][x]
+std::vector<float> slic_segment(const Image &stack, int spx, int spy) {
+  const int nx = stack.a.nx, ny = stack.a.ny, nz = stack.a.nz, width = ny, height = nx, sz = width * height;
+  float vmin = FLT_MAX, vmax = -FLT_MAX;
+  for (double v : stack.d) { vmin = std::min(vmin, (float)v); vmax = std::max(vmax, (float)v); }
+  const int nsp = (int)(sz / (spx * spy));
+  std::vector<float> out(stack.d.size(), 0.0f);
+  std::vector<int> grey(sz), kl, cl;
+  std::vector<double> l, a, b;
+  for (int z = 0; z < nz; ++z) {
+    int p = 0;
+    for (int x = 0; x < nx; ++x)
+      for (int y = 0; y < ny; ++y, ++p)
+        grey[p] = vmax > vmin ? (int)((255.0f * ((float)stack.at(x, y, z) - vmin)) / (vmax - vmin)) : 0;   // (int) 255 * (v - min) / (max - min), float
+    slic_rgbtolab(grey, l, a, b);
+    const int step = (int)(sqrt((double)sz / (double)nsp) + 0.5);
+    const std::vector<int> seeds = slic_seeds(step, width, height);
+    slic_slico(l, a, b, seeds, width, height, step, kl);
+    slic_connectivity(kl, width, height, nsp, cl);
+    p = 0;
+    for (int x = 0; x < nx; ++x)
+      for (int y = 0; y < ny; ++y, ++p) out[((size_t)z * ny + y) * nx + x] = (float)cl[p];
+  }
+  return out;
+}
+
+struct SpxPatches {
+  std::vector<float> data, i2w, w2i, ri2w, mo, invmo;
+  std::vector<char> masks;                                 // [n][4096], '1' / 0, 64 wide (ImagePatch2D.cuh:51)
+  std::vector<svr_image_attr> attr;
+  int n = 0, px = 0, py = 0;
+};
+
+// generate2DSuperpixelPatches for one stack; `half_thickness` = m_thickness, mask = the iso mask
+void slic_superpixel_patches(const Image &stack, double half_thickness, const Image &mask, int spx, int spy, int extend_percent, SpxPatches &out) {
+  const svr_image_attr &a = stack.a;
+  if (spx > a.nx) spx = a.nx / 2;
+  if (spy > a.ny) spy = a.ny / 2;
+  const std::vector<float> labels = slic_segment(stack, spx, spy);
+  const float ratio = (float)extend_percent / 100.0f;
+  const int px = std::min(64, a.nx), py = std::min(64, a.ny);
+  out.px = px; out.py = py;
+  const M4 s_i2w = image_to_world(a), m_w2i = world_to_image(mask.a);
+  std::vector<float> pm((size_t)px * py), tmp((size_t)px * py), val((size_t)px * py);
+  for (int z = 0; z < a.nz; ++z) {
+    const float *lab = &labels[(size_t)z * a.nx * a.ny];
+    svr_image_attr sl = a;
+    sl.nz = 1;
+    sl.dz = half_thickness * 2;
+    const double c[3] = {(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, (double)z};
+    for (int k = 0; k < 3; ++k) sl.origin[k] = s_i2w.m[4 * k] * c[0] + s_i2w.m[4 * k + 1] * c[1] + s_i2w.m[4 * k + 2] * c[2] + s_i2w.m[4 * k + 3];
+    const M4 sl_i2w = image_to_world(sl), sl_w2i = world_to_image(sl);
+    float lmin = FLT_MAX, lmax = -FLT_MAX;
+    for (int i = 0; i < a.nx * a.ny; ++i) { lmin = std::min(lmin, lab[i]); lmax = std::max(lmax, lab[i]); }
+    for (int idx = (int)lmin; idx < (int)lmax; ++idx) {      // the largest label is never cut out
+      int x_min = INT_MAX, y_min = INT_MAX, x_max = INT_MIN, y_max = INT_MIN;
+      for (int yi = 0; yi < a.ny; ++yi)
+        for (int xi = 0; xi < a.nx; ++xi)
+          if ((int)lab[yi * a.nx + xi] == idx) { x_min = std::min(x_min, xi); x_max = std::max(x_max, xi); y_min = std::min(y_min, yi); y_max = std::max(y_max, yi); }
+      if (x_max == INT_MIN) continue;
+      const int wx = x_max - x_min, wy = y_max - y_min;
+      const int diter = (int)(ratio * (float)(wx > wy ? wx : wy));
+      const int ex = (int)irtk_round(((float)px - (float)wx) / 2.), ey = (int)irtk_round(((float)py - (float)wy) / 2.);
+      if (x_min - ex < 0) { x_max = px; x_min = 0; }
+      else if (x_max + ex > a.nx) { x_max = a.nx; x_min = x_max - px; }
+      else { x_min -= ex; x_max = x_min + px; }
+      if (y_min - ey < 0) { y_max = py; y_min = 0; }
+      else if (y_max + ey > a.ny) { y_max = a.ny; y_min = y_max - py; }
+      else { y_min -= ey; y_max = y_min + py; }
+      svr_image_attr pa = sl;
+      pa.nx = px; pa.ny = py;
+      const double pc[2] = {x_min + (px - 1) / 2.0, y_min + (py - 1) / 2.0};
+      for (int k = 0; k < 3; ++k) pa.origin[k] = sl_i2w.m[4 * k] * pc[0] + sl_i2w.m[4 * k + 1] * pc[1] + sl_i2w.m[4 * k + 3];
+      const M4 p_i2w = image_to_world(pa);
+      const M4 to_slice = mul(sl_w2i, p_i2w), to_mask = mul(m_w2i, p_i2w);
+      // the two-matrix form (ImageToWorld then WorldToImage) of the reference is kept for the rounded coordinates below
+      int count = 0;
+      std::vector<int> qx((size_t)px * py), qy((size_t)px * py);
+      std::vector<char> in_maskimg((size_t)px * py), mpos((size_t)px * py);
+      for (int j = 0; j < py; ++j)
+        for (int i = 0; i < px; ++i) {
+          const size_t q = (size_t)j * px + i;
+          const double wxx = p_i2w.m[0] * i + p_i2w.m[1] * j + p_i2w.m[3], wyy = p_i2w.m[4] * i + p_i2w.m[5] * j + p_i2w.m[7],
+                       wzz = p_i2w.m[8] * i + p_i2w.m[9] * j + p_i2w.m[11];
+          const double sx = irtk_round(sl_w2i.m[0] * wxx + sl_w2i.m[1] * wyy + sl_w2i.m[2] * wzz + sl_w2i.m[3]);
+          const double sy = irtk_round(sl_w2i.m[4] * wxx + sl_w2i.m[5] * wyy + sl_w2i.m[6] * wzz + sl_w2i.m[7]);
+          const double m1 = irtk_round(m_w2i.m[0] * wxx + m_w2i.m[1] * wyy + m_w2i.m[2] * wzz + m_w2i.m[3]);
+          const double m2 = irtk_round(m_w2i.m[4] * wxx + m_w2i.m[5] * wyy + m_w2i.m[6] * wzz + m_w2i.m[7]);
+          const double m3 = irtk_round(m_w2i.m[8] * wxx + m_w2i.m[9] * wyy + m_w2i.m[10] * wzz + m_w2i.m[11]);
+          const bool ins = sx >= 0 && sy >= 0 && sx < a.nx && sy < a.ny;
+          const bool inm = m1 >= 0 && m2 >= 0 && m3 >= 0 && m1 < mask.a.nx && m2 < mask.a.ny && m3 < mask.a.nz;
+          qx[q] = ins ? (int)sx : -1; qy[q] = ins ? (int)sy : -1;
+          in_maskimg[q] = inm;
+          mpos[q] = inm && mask.at((int)m1, (int)m2, (int)m3) > 0;
+          pm[q] = (ins && inm && mpos[q] && (int)lab[(int)sy * a.nx + (int)sx] == idx) ? 1.0f : 0.0f;
+          if (pm[q] > 0) count++;
+        }
+      (void)to_slice; (void)to_mask;
+      if (count < 2 || count < 1.0f / 4.0f * spy * spx) continue;
+      for (int it = 0; it < diter; ++it) {                   // dilatePatch
+        tmp = pm;
+        for (int j = 0; j < py; ++j)
+          for (int i = 0; i < px; ++i)
+            if (pm[(size_t)j * px + i] == 1) {
+              if (i > 0 && pm[(size_t)j * px + i - 1] == 0) tmp[(size_t)j * px + i - 1] = 1;
+              if (j > 0 && pm[(size_t)(j - 1) * px + i] == 0) tmp[(size_t)(j - 1) * px + i] = 1;
+              if (i + 1 < px && pm[(size_t)j * px + i + 1] == 0) tmp[(size_t)j * px + i + 1] = 1;
+              if (j + 1 < py && pm[(size_t)(j + 1) * px + i] == 0) tmp[(size_t)(j + 1) * px + i] = 1;
+            }
+        pm = tmp;
+      }
+      std::vector<char> msk(4096, 0);
+      for (int j = 0; j < py; ++j)
+        for (int i = 0; i < px; ++i) {
+          const size_t q = (size_t)j * px + i;
+          float v;
+          if (pm[q] == 0) v = -1.0f;
+          else if (qx[q] >= 0 && in_maskimg[q]) v = mpos[q] ? (float)stack.at(qx[q], qy[q], z) : -1.0f;
+          else v = pm[q];
+          val[q] = v;
+          if (v != -1.0f) msk[i + 64 * j] = '1';
+        }
+      out.data.insert(out.data.end(), val.begin(), val.end());
+      out.masks.insert(out.masks.end(), msk.begin(), msk.end());
+      float f[16];
+      to_f16(p_i2w, f); out.i2w.insert(out.i2w.end(), f, f + 16);
+      to_f16(world_to_image(pa), f); out.w2i.insert(out.w2i.end(), f, f + 16);
+      svr_image_attr p0 = pa;
+      p0.origin[0] = p0.origin[1] = p0.origin[2] = 0;
+      to_f16(image_to_world(p0), f); out.ri2w.insert(out.ri2w.end(), f, f + 16);
+      M4 mo = ident();
+      for (int k = 0; k < 3; ++k) mo.m[4 * k + 3] = pa.origin[k];
+      to_f16(mo, f); out.mo.insert(out.mo.end(), f, f + 16);
+      to_f16(inverse_rigid_or_affine(mo), f); out.invmo.insert(out.invmo.end(), f, f + 16);
+      out.attr.push_back(pa);
+      out.n++;
+    }
+  }
+}
+
+}  // namespace
+
+#endif  // SVR_SLIC_H

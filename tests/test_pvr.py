@@ -402,7 +402,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path):
     assert np.array_equal(patches, P.slices)                      # same float arithmetic, same rounding
     assert np.allclose(i2w, P.slice_i2w, atol=1e-5)
     assert vmin == np.float32(pmin) and vmax == np.float32(pmax)
-    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--superpixel"], capture_output=True, text=True)   # C++: square patches only
+    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--hierarchical"], capture_output=True, text=True)
     assert bad.returncode != 0 and "not supported" in bad.stderr
 
 

@@ -109,3 +109,48 @@ def test_pvr_command_line_with_superpixels_end_to_end(tmp_path):
     w = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(float) @ geo.image_to_world(va).T
     inside = (np.sum(w[..., :3] ** 2, -1) < 12.0 ** 2) & (vol > 0)
     assert inside.sum() > 3000 and np.corrcoef(vol[inside], phantom.phantom_intensity(w[..., :3], 16.0)[inside])[0, 1] > 0.5   # 6-slice stacks of 4.4 mm patches: coarse
+    # the C++ command line (csrc/svr_slic.h) gives the same volume
+    import subprocess
+    from fetalreconstruction_amd import build
+    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "cc.nii.gz"), "-i", *paths, "-m", str(tmp_path / "mask.nii.gz"), "-s", "--spxSize", "12",
+                        "--spxExtend", "30", "--resolution", "1.0", "--iterations", "1", "--sr_iterations", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vc, _ = nifti.read(tmp_path / "cc.nii.gz")
+    ok = (vol > 0) & (vc > 0)
+    assert vc.shape == vol.shape and np.corrcoef(vol[ok], vc[ok])[0, 1] > 0.97
+
+
+def test_cpp_superpixel_patches_match_the_python_ones(tmp_path):
+    """bin/PVRreconstructionGPU -s --dumpProblem --dryRun (csrc/svr_slic.h) against slic.py through the same pre-processing."""
+    import subprocess
+    from fetalreconstruction_amd import build, nifti, pvr_cli
+    from fetalreconstruction_amd import preprocess as pp
+    build.build()
+    stacks, mask, mattr, rattr, rmask = _stacks()
+    paths = []
+    for k, st in enumerate(stacks):
+        nifti.write(tmp_path / f"s{k}.nii.gz", st.data, st.attr)
+        paths.append(str(tmp_path / f"s{k}.nii.gz"))
+    nifti.write(tmp_path / "mask.nii.gz", rmask, rattr)
+    dump = tmp_path / "problem.bin"
+    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", str(tmp_path / "mask.nii.gz"), "-s", "--spxSize", "12",
+                        "--spxExtend", "30", "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = dump.read_bytes()
+    ns, px, py, nst, vx, vy, vz = [int(v) for v in np.frombuffer(raw, np.int32, 8)[:7]]
+    o = 32
+    counts = np.frombuffer(raw, np.int32, nst, o); o += 4 * nst + 8
+    patches = np.frombuffer(raw, np.float32, ns * py * px, o).reshape(ns, py, px); o += 4 * ns * py * px + 64 * ns + 4 * vx * vy * vz
+    masks = np.frombuffer(raw, np.uint8, ns * 4096, o).reshape(ns, 4096)
+    # the Python twin on the same files
+    ims = []
+    for p in paths:
+        d, at = nifti.read(p)
+        ims.append(pp.Image(d.astype(np.float64), at))
+    md, mat = nifti.read(tmp_path / "mask.nii.gz")
+    ims, ts, iso, tattr, rm = pvr_cli.prepare(ims, [np.eye(4)] * 2, pp.Image(md.astype(np.float64), mat), 1.0, 0, False)
+    pst = [pvr.Stack(s.data.astype(np.float32), s.attr, t, s.attr.dz) for s, t in zip(ims, ts)]
+    P = pvr.make_pvr_problem(pst, iso.data, iso.attr, tattr, rm.data, (12, 12), (30, 30), superpixel=True)
+    assert list(counts) == list(P.patches_per_stack) and (py, px) == P.slices.shape[1:]
+    assert np.array_equal(masks, P.spx_masks) and np.array_equal(patches, P.slices)     # same labels, same dilation, same values
