@@ -11,7 +11,7 @@ Stack transformations (`id`, IRTK rigid `dof` files or 4x4 text matrices) start 
 (StackRegistrations, before and after the other stacks are cropped, main.cc:661,711); slice-to-volume registration is
 the reference's default IRTK schedule with every similarity evaluated on the GPU (csrc/irtk_reg.cpp) or, with
 --useGPUReg, the reference's GPU registration.  --no_registration (not a reference option) skips both.  --packages runs PackageToVolume
-with the schedule of main.cc:832-864.  Superpixels and the CPU reconstruction path are refused, loudly.
+with the schedule of main.cc:832-864; --tfolder reads `transformation<i>.dof` per slice (--debug writes them next to the output).  Superpixels and the CPU reconstruction path are refused, loudly.
 """
 from __future__ import annotations
 
@@ -52,7 +52,8 @@ def _parser():
     p.add_argument("-d", "--devices", nargs="+", type=int, default=[0])
     p.add_argument("--debug", action="store_true")
     p.add_argument("--packages", nargs="+", type=int)
-    for refused in ("--useCPU", "--patchBased", "--superpixelBased", "--tfolder", "--sfolder"):
+    p.add_argument("--tfolder")
+    for refused in ("--useCPU", "--patchBased", "--superpixelBased", "--sfolder"):
         p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
     return p
 
@@ -72,7 +73,7 @@ def _load_transformation(spec):
 
 def main(argv=None):
     a = _parser().parse_args(argv)
-    for refused in ("useCPU", "patchBased", "superpixelBased", "tfolder", "sfolder"):
+    for refused in ("useCPU", "patchBased", "superpixelBased", "sfolder"):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/cli.py)")
     n = len(a.input)
@@ -132,6 +133,12 @@ def main(argv=None):
     drv.SetForceExcludedSlices(a.force_exclude)
     rs = reg.PrepareRegistrationSlices(rec, prob.slices, prob.slice_attr, resolution) if a.useGPUReg else None
     T = np.stack(slice_t)
+    if a.tfolder:                                                                                # ReadTransformation, RG.cc:4733-4765
+        import os
+        T = np.stack([nifti.read_dof(os.path.join(a.tfolder, f"transformation{i}.dof"))[1] for i in range(prob.ns)])
+        ti = np.stack([np.linalg.inv(t) for t in T])
+        rec.SetSliceMatrices(np.stack([t.astype(np.float32).reshape(16) for t in T]), np.stack([t.astype(np.float32).reshape(16) for t in ti]),
+                             prob.slice_i2w, prob.slice_w2i, prob.slice_i2w, prob.slice_w2i, prob.recon_i2w, prob.recon_w2i)
     for it in range(a.iterations):                                                               # main.cc:816-1237
         slice_reg = it > 0 and not a.no_registration
         if slice_reg and a.packages and it <= a.iterations * (a.multires - 1) // a.multires and it < a.iterations - 1:
@@ -174,8 +181,11 @@ def main(argv=None):
     drv.ScaleVolumeGPU()
     out = rec.syncCPU().reshape(tattr.nz, tattr.ny, tattr.nx)
     nifti.write(a.output, out, tattr)
-    if a.debug:
-        np.save(a.output + ".transformations.npy", T)
+    if a.debug:                                                                                  # SaveTransformations, RG.cc:4903-4915
+        import os
+        folder = os.path.dirname(os.path.abspath(a.output))
+        for i, t in enumerate(T):
+            nifti.write_dof(os.path.join(folder, f"transformation{i}.dof"), host.irtk_rigid_parameters(t)[0])
     return 0
 
 

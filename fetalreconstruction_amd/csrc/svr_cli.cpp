@@ -16,13 +16,15 @@
 // stack-to-stack registration (StackRegistrations, before and after the other stacks are cropped, main.cc:661,711).
 // Slice-to-volume registration is the reference's default IRTK schedule (csrc/irtk_reg.cpp, every similarity evaluation
 // on the GPU) or, with --useGPUReg, the reference's GPU registration.  --no_registration (not a reference option) skips
-// both.  --packages runs PackageToVolume with the schedule of main.cc:832-864.  Not built, refused loudly: patch/superpixel
+// both.  --packages runs PackageToVolume with the schedule of main.cc:832-864; --tfolder reads transformation<i>.dof per
+// slice and --debug writes them next to the output.  Not built, refused loudly: patch/superpixel
 // modes, the CPU reconstruction path.
 #include "svr_prep.h"
 
 
 int main(int argc, char **argv) {
-  std::string output, mask_name;
+  std::string output, mask_name, tfolder;
+  bool debug = false;
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
   std::vector<int> force_excluded, devices, packages;
@@ -56,6 +58,8 @@ int main(int argc, char **argv) {
     else if (o == "--useGPUReg") use_gpu_reg = true;
     else if (o == "-p" || o == "--packages") { std::vector<std::string> v; multi(v); for (auto &x : v) packages.push_back(atoi(x.c_str())); }
     else if (o == "--no_registration") no_registration = true;
+    else if (o == "--tfolder") tfolder = one();
+    else if (o == "--debug") debug = true;
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
     else if (o == "-d" || o == "--devices") { std::vector<std::string> v; multi(v); for (auto &s : v) devices.push_back(atoi(s.c_str())); }
     else if (o == "-h" || o == "--help") {
@@ -184,6 +188,19 @@ int main(int argc, char **argv) {
   if (!force_excluded.empty()) svrh_set_force_excluded(host, force_excluded.data(), (int)force_excluded.size());
   if (use_gpu_reg) HOST(svrh_prepare_registration_slices(host, grid.data(), mx, my, sattr.data(), resolution));
 
+  if (!tfolder.empty()) {                                                // ReadTransformation, RG.cc:4733-4765
+    for (int s = 0; s < ns; ++s) {
+      double p6[6];
+      char e[256] = {0};
+      const std::string path = tfolder + "/transformation" + std::to_string(s) + ".dof";
+      if (svr_dof_read(path.c_str(), p6, &T[16 * (size_t)s], e)) die(path + ": " + e);
+      M4 t;
+      for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];
+      to_f16(t, &st[16 * (size_t)s]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)s]);
+    }
+    ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), i2w.data(), w2i.data(), i2w.data(), w2i.data(), ri2w, rw2i));
+  }
+
   // ---- registration-reconstruction loop (main.cc:816-1237) ---------------------------------------------
   for (int it = 0; it < iterations; ++it) {
     bool slice_reg = it > 0 && !no_registration;
@@ -249,6 +266,17 @@ int main(int argc, char **argv) {
   ENG(svr_sync_cpu(ctx, vol.data()));
   char err[256] = {0};
   if (svr_nifti_write(output.c_str(), &tattr, vol.data(), err)) die(output + ": " + err);
+  if (debug) {                                                           // SaveTransformations, RG.cc:4903-4915
+    const size_t cut = output.find_last_of('/');
+    const std::string folder = cut == std::string::npos ? "." : output.substr(0, cut);
+    for (int s = 0; s < ns; ++s) {
+      double p6[6];
+      svrh_irtk_rigid_parameters(&T[16 * (size_t)s], p6, nullptr);
+      char e[256] = {0};
+      const std::string path = folder + "/transformation" + std::to_string(s) + ".dof";
+      if (svr_dof_write(path.c_str(), p6, e)) die(path + ": " + e);
+    }
+  }
   svrh_destroy(host);
   svr_destroy(ctx);
   return 0;

@@ -185,3 +185,32 @@ def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
         assert np.abs(vp - vc).max() <= 2e-4 * np.abs(vp).max()
     bad = subprocess.run([build.CLI, "-o", "x.nii", "-i", paths[0], "--useCPU"], capture_output=True, text=True)
     assert bad.returncode != 0 and "not supported" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_transformations_round_trip_through_tfolder(tmp_path):
+    """--debug writes transformation<i>.dof per slice (SaveTransformations), --tfolder reads them back (ReadTransformation): a
+    second run that starts from the first run's registered slices and does not register reproduces its last iteration's input."""
+    import subprocess
+    from fetalreconstruction_amd import build, cli, nifti
+    paths, mpath, rattr, rmask = _write_case(tmp_path)
+    first = tmp_path / "a"
+    first.mkdir()
+    common = ["-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--rec_iterations_first", "2",
+              "--rec_iterations_last", "3", "--smooth_mask", "0"]
+    r = subprocess.run([build.CLI, "-o", str(first / "r.nii.gz"), *common, "--iterations", "2", "--debug"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    dofs = sorted(first.glob("transformation*.dof"))
+    assert len(dofs) == 36
+    p6, m = nifti.read_dof(first / "transformation7.dof")
+    assert np.allclose(m[:3, :3] @ m[:3, :3].T, np.eye(3), atol=1e-9) and np.abs(p6).max() < 20
+    assert cli.main(["-o", str(tmp_path / "b.nii.gz"), *common, "--iterations", "1", "--no_registration", "--tfolder", str(first)]) == 0
+    r2 = subprocess.run([build.CLI, "-o", str(tmp_path / "c.nii.gz"), *common, "--iterations", "1", "--no_registration", "--tfolder", str(first)],
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    vb, _ = nifti.read(tmp_path / "b.nii.gz")
+    vc, _ = nifti.read(tmp_path / "c.nii.gz")
+    assert np.abs(vb - vc).max() <= 2e-4 * np.abs(vb).max()              # both command lines read the same transformations
+    va, _ = nifti.read(first / "r.nii.gz")
+    ok = (va > 0) & (vb > 0)
+    assert np.corrcoef(va[ok], vb[ok])[0, 1] > 0.95                       # same registered slices, same last-iteration settings
