@@ -1,4 +1,5 @@
-"""P4-scale PVR run: patch extraction (32x32 stride 16), one outer iteration with 3 SR iterations; kernel times."""
+"""P4-scale PVR run: patch extraction (32x32 stride 16; `spx` = SLICO superpixel patches, --spxSize 32 --spxExtend 2 as in
+BASELINE.json configs[4]), one outer iteration with 3 SR iterations; kernel times.  usage: run_pvr.py [spx]"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
@@ -7,12 +8,15 @@ from fetalreconstruction_amd import phantom, engine, pvr
 t0 = time.time()
 stacks, mask, mattr, rattr, rmask = phantom.make_stacks(4, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, seed=1,
                                                         orientations=("ax", "cor", "sag", "ax"))
-P = pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (32, 32), (16, 16))
+SPX = len(sys.argv) > 1 and sys.argv[1] == 'spx'
+P = pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (32, 32), (2, 2) if SPX else (16, 16), superpixel=SPX)
 print("patch extraction s:", round(time.time() - t0, 1), "patches", P.slices.shape, P.patches_per_stack,
       "non-zero px", int((P.slices > 0).sum()))
 rec = engine.Reconstruction(0)
 rec.set_option("pvr", 1)
 engine.sync_gpu(rec, P, quality_factor=1.0)
+if SPX:
+    rec.set_spx_masks(P.spx_masks)
 d = pvr.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity)
 rec.timer_enable(True)
 t0 = time.time()
