@@ -26,6 +26,15 @@ from . import registration as reg
 from .reconstruction import irtkReconstruction
 
 
+def _bool(v):
+    v = str(v).lower()
+    if v in ("1", "true", "yes", "on"):
+        return True
+    if v in ("0", "false", "no", "off"):
+        return False
+    raise argparse.ArgumentTypeError(f"boolean expected, got {v}")
+
+
 def _parser():
     p = argparse.ArgumentParser(prog="SVRreconstructionGPU (MI355X)", description=__doc__.split("\n\n")[0])
     p.add_argument("-o", "--output", required=True)
@@ -42,7 +51,16 @@ def _parser():
     p.add_argument("--lambda", dest="lam", type=float, default=0.02)
     p.add_argument("--lastIterLambda", type=float, default=0.01)
     p.add_argument("--smooth_mask", type=float, default=4.0)
-    p.add_argument("--no_intensity_matching", action="store_true")
+    # po::value<bool> options of the reference take a value (--debug 1); a bare flag is accepted too.  The value of
+    # --no_intensity_matching lands in `intensity_matching` (main.cc:186): 0 switches the matching off, a bare flag does as well
+    p.add_argument("--no_intensity_matching", nargs="?", const="0", default=None, type=_bool)
+    p.add_argument("--num_stacks_tuner", type=int, default=0)
+    for ignored in ("--log_prefix", "--low_intensity_cutoff", "--patchSize", "--patchStride"):     # no log files; bias / patch modes are off
+        p.add_argument(ignored, help=argparse.SUPPRESS)
+    for ignored in ("--no_log", "--global_bias_correction"):
+        p.add_argument(ignored, nargs="?", const="1", type=_bool, help=argparse.SUPPRESS)
+    p.add_argument("--useCPUReg", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--debug_gpu", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--force_exclude", nargs="+", type=int, default=[])
     p.add_argument("--rec_iterations_first", type=int, default=4)
     p.add_argument("--rec_iterations_last", type=int, default=13)
@@ -50,7 +68,7 @@ def _parser():
     p.add_argument("--no_registration", action="store_true")
     p.add_argument("--disableBiasCorrection", action="store_true", default=True)
     p.add_argument("-d", "--devices", nargs="+", type=int, default=[0])
-    p.add_argument("--debug", action="store_true")
+    p.add_argument("--debug", nargs="?", const="1", default=False, type=_bool)
     p.add_argument("--packages", nargs="+", type=int)
     p.add_argument("--tfolder")
     for refused in ("--useCPU", "--patchBased", "--superpixelBased", "--sfolder"):
@@ -76,6 +94,12 @@ def main(argv=None):
     for refused in ("useCPU", "patchBased", "superpixelBased", "sfolder"):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/cli.py)")
+    if a.num_stacks_tuner > 0:                                              # main.cc:406-419: only the first stacks are used
+        k = a.num_stacks_tuner
+        a.input = a.input[:k]
+        for name in ("transformation", "thickness", "packages"):
+            if getattr(a, name):
+                setattr(a, name, getattr(a, name)[:k])
     n = len(a.input)
     stacks = []
     for path in a.input:                                                    # main.cc:386-430
@@ -121,7 +145,7 @@ def main(argv=None):
         stacks[k] = pp.CropImage(stacks[k], m)
     transformations = stack_registrations(transformations)                                       # main.cc:707-713
     factors = pp.MatchStackIntensitiesWithMasking(stacks, transformations, vol_mask, a.average,
-                                                  together=a.no_intensity_matching)              # main.cc:676-679
+                                                  together=a.no_intensity_matching is not None and not a.no_intensity_matching)              # main.cc:676-679
     slices, attrs, slice_t, stack_index = pp.CreateSlicesAndTransformations(stacks, transformations, thickness)
     slices = pp.MaskSlices(slices, attrs, slice_t, vol_mask)                                     # main.cc:700
     prob = pp.build_problem(tattr, vol_mask, slices, attrs, slice_t, stack_index)

@@ -28,7 +28,7 @@ int main(int argc, char **argv) {
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
   std::vector<int> force_excluded, devices, packages;
-  int iterations = 4, levels = 3, rec_first = 4, rec_last = 13;
+  int iterations = 4, levels = 3, rec_first = 4, rec_last = 13, num_stacks_tuner = 0;
   double resolution = 0.75, average = 700, delta = 150, lambda = 0.02, last_lambda = 0.01, smooth_mask = 4;
   bool no_matching = false, use_gpu_reg = false, no_registration = false;
   // ---- options (main.cc:164-211) ---------------------------------------------------------------------
@@ -37,6 +37,15 @@ int main(int argc, char **argv) {
     const std::string o = argv[i];
     auto multi = [&](std::vector<std::string> &dst) { while (i + 1 < argc && !is_opt(argv[i + 1])) dst.push_back(argv[++i]); };
     auto one = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + o); return argv[++i]; };
+    // po::value<bool> options of the reference take a value (--debug 1); a bare flag is accepted as `true`
+    auto opt_bool = [&](bool bare) -> bool {
+      if (i + 1 < argc) {
+        const std::string v = argv[i + 1];
+        if (v == "1" || v == "true" || v == "yes" || v == "on") { ++i; return true; }
+        if (v == "0" || v == "false" || v == "no" || v == "off") { ++i; return false; }
+      }
+      return bare;
+    };
     if (o == "-o" || o == "--output") output = one();
     else if (o == "-m" || o == "--mask") mask_name = one();
     else if (o == "-i" || o == "--input") multi(inputs);
@@ -51,7 +60,10 @@ int main(int argc, char **argv) {
     else if (o == "--lambda") lambda = atof(one().c_str());
     else if (o == "--lastIterLambda") last_lambda = atof(one().c_str());
     else if (o == "--smooth_mask") smooth_mask = atof(one().c_str());
-    else if (o == "--no_intensity_matching") no_matching = true;
+    else if (o == "--no_intensity_matching") no_matching = !opt_bool(false);   // the value lands in `intensity_matching` (main.cc:186): 0 switches it off
+    else if (o == "--num_stacks_tuner") num_stacks_tuner = atoi(one().c_str());
+    else if (o == "--log_prefix" || o == "--low_intensity_cutoff" || o == "--patchSize" || o == "--patchStride") (void)one();   // no log files; bias / patch modes are off
+    else if (o == "--no_log" || o == "--global_bias_correction") (void)opt_bool(true);
     else if (o == "--force_exclude") { std::vector<std::string> v; multi(v); for (auto &s : v) force_excluded.push_back(atoi(s.c_str())); }
     else if (o == "--rec_iterations_first") rec_first = atoi(one().c_str());
     else if (o == "--rec_iterations_last") rec_last = atoi(one().c_str());
@@ -59,7 +71,7 @@ int main(int argc, char **argv) {
     else if (o == "-p" || o == "--packages") { std::vector<std::string> v; multi(v); for (auto &x : v) packages.push_back(atoi(x.c_str())); }
     else if (o == "--no_registration") no_registration = true;
     else if (o == "--tfolder") tfolder = one();
-    else if (o == "--debug") debug = true;
+    else if (o == "--debug") debug = opt_bool(true);
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
     else if (o == "-d" || o == "--devices") { std::vector<std::string> v; multi(v); for (auto &s : v) devices.push_back(atoi(s.c_str())); }
     else if (o == "-h" || o == "--help") {
@@ -73,6 +85,12 @@ int main(int argc, char **argv) {
     }
   }
   if (output.empty() || inputs.empty()) die("-o and -i are required (try --help)");
+  if (num_stacks_tuner > 0 && (size_t)num_stacks_tuner < inputs.size()) {      // main.cc:406-419: only the first stacks are used
+    inputs.resize(num_stacks_tuner);
+    if (tspecs.size() > (size_t)num_stacks_tuner) tspecs.resize(num_stacks_tuner);
+    if (thickness.size() > (size_t)num_stacks_tuner) thickness.resize(num_stacks_tuner);
+    if (packages.size() > (size_t)num_stacks_tuner) packages.resize(num_stacks_tuner);
+  }
   const size_t n = inputs.size();
   if (tspecs.empty()) tspecs.assign(n, "id");
   if (tspecs.size() != n) die("one transformation per stack expected");

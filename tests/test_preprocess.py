@@ -159,7 +159,9 @@ def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
     from fetalreconstruction_amd import build, cli, nifti
     paths, mpath, rattr, rmask = _write_case(tmp_path)
     common = ["-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "2",
-              "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2"] + {"none": ["--no_registration"], "irtk": [],
+              "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2"] + {"none": ["--no_registration", "--no_log", "1", "--log_prefix", "x", "--global_bias_correction", "0",
+                                                                                                           "--low_intensity_cutoff", "0.01", "--no_intensity_matching", "1", "--debug", "0"],
+                                                                                                  "irtk": ["--num_stacks_tuner", "3"],
                                                                                                   "gpu": ["--useGPUReg"],
                                                                                                   "packages": ["--packages", "2", "2", "2"]}[registration]
     if registration == "packages":
@@ -214,3 +216,18 @@ def test_transformations_round_trip_through_tfolder(tmp_path):
     va, _ = nifti.read(first / "r.nii.gz")
     ok = (va > 0) & (vb > 0)
     assert np.corrcoef(va[ok], vb[ok])[0, 1] > 0.95                       # same registered slices, same last-iteration settings
+
+
+def test_command_line_boolean_options_follow_the_reference():
+    """`--debug`, `--no_intensity_matching`, `--no_log` are po::value<bool> in the reference (reconstruction.cc:186-205): they take
+    a value, and the value of --no_intensity_matching lands in `intensity_matching` itself (0 switches the matching off)."""
+    from fetalreconstruction_amd import cli
+    p = cli._parser()
+    a = p.parse_args("-o x -i a b --no_intensity_matching 1 --debug 0 --no_log 1 --log_prefix q --num_stacks_tuner 1".split())
+    assert a.no_intensity_matching is True and a.debug is False and a.num_stacks_tuner == 1
+    a = p.parse_args("-o x -i a b --no_intensity_matching --debug".split())
+    assert a.no_intensity_matching is False and a.debug is True
+    a = p.parse_args("-o x --no_intensity_matching 0 -i a b".split())
+    assert a.no_intensity_matching is False and a.input == ["a", "b"]
+    a = p.parse_args("-o x -i a b".split())
+    assert a.no_intensity_matching is None and a.debug is False
