@@ -14,7 +14,8 @@
 // The stack-to-stack registration (irtkStack3D3DRegistration, :280-285) runs through csrc/irtk_reg.cpp with every similarity
 // on the GPU; between the outer passes every patch is registered to the volume with the same schedule
 // (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.
-// -s / --superpixel cuts SLICO superpixel patches (csrc/svr_slic.h).  Not built, refused loudly: hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask, --useFullSlices.
+// -s / --superpixel cuts SLICO superpixel patches (csrc/svr_slic.h).  --useFullSlices makes every slice one patch (patchBasedObject.cuh:183-189).
+// Not built, refused loudly: hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.
 #include "svr_prep.h"
 #include "svr_slic.h"
 
@@ -138,7 +139,7 @@ int main(int argc, char **argv) {
   std::vector<int> devices, psize, pstride;
   int iterations = 7, sr_iterations = 7;
   double resolution = 0.75;
-  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false;
+  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false;
   int spx_size = 16, spx_extend = 50;                    // pvrmain:104-106
   std::string dump_name;                                 // test hooks: --dumpProblem <file> [--dryRun]
   // ---- options (pvrmain:108-131) ---------------------------------------------------------------------
@@ -153,6 +154,7 @@ int main(int argc, char **argv) {
     else if (o == "-i" || o == "--input") multi(inputs);
     else if (o == "-t" || o == "--transformation") multi(tspecs);
     else if (o == "--thickness") { std::vector<std::string> v; multi(v); for (auto &s : v) thickness.push_back(atof(s.c_str())); }
+    else if (o == "--useFullSlices") full_slices = true;
     else if (o == "--patchSize") ints(psize);
     else if (o == "--patchStride") ints(pstride);
     else if (o == "--resolution") resolution = atof(one().c_str());
@@ -169,7 +171,7 @@ int main(int argc, char **argv) {
     else if (o == "-h" || o == "--help") {
       printf("usage: PVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> -m <mask> [-t id|<dof>|<4x4.txt> ..]\n"
              "       [--thickness th_1 ..] [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7]\n"
-             "       [--sr_iterations 7] [--noMatchIntensities] [--no_registration] [-s [--spxSize 16] [--spxExtend 50]] [-d device]\n");
+             "       [--sr_iterations 7] [--noMatchIntensities] [--no_registration] [-s [--spxSize 16] [--spxExtend 50]] [--useFullSlices] [-d device]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/pvr_cli.cpp)");
@@ -226,6 +228,11 @@ int main(int argc, char **argv) {
 
   // ---- patches (PBR.cpp:385-399) -----------------------------------------------------------------------
   int px = psize[0], py = psize[1];
+  if (full_slices) {                                     // the patch is the slice; stacks of different sizes share a grid padded with -1
+    if (superpixel) die("--superpixel with --useFullSlices is not supported by this build");
+    px = py = 0;
+    for (size_t k = 0; k < n; ++k) { px = std::max(px, stacks[k].a.nx); py = std::max(py, stacks[k].a.ny); }
+  }
   Patches P;
   std::vector<char> spx_masks;
   std::vector<int> counts;
@@ -245,6 +252,20 @@ int main(int argc, char **argv) {
       P.attr.insert(P.attr.end(), sp.attr.begin(), sp.attr.end());
       spx_masks.insert(spx_masks.end(), sp.masks.begin(), sp.masks.end());
       P.n += sp.n;
+    } else if (full_slices) {                            // patchBasedObject.cuh:183-189: size = the slice, stride = size + 1
+      const int nx = stacks[k].a.nx, ny = stacks[k].a.ny;
+      Patches one;
+      generate_2d_patches(stacks[k], half_thickness[k], iso_mask, nx, ny, nx + 1, ny + 1, one);
+      for (int q = 0; q < one.n; ++q) {
+        std::vector<float> padded((size_t)px * py, -1.0f);
+        for (int j = 0; j < ny; ++j) memcpy(&padded[(size_t)j * px], &one.data[((size_t)q * ny + j) * nx], nx * sizeof(float));
+        P.data.insert(P.data.end(), padded.begin(), padded.end());
+      }
+      P.i2w.insert(P.i2w.end(), one.i2w.begin(), one.i2w.end()); P.w2i.insert(P.w2i.end(), one.w2i.begin(), one.w2i.end());
+      P.ri2w.insert(P.ri2w.end(), one.ri2w.begin(), one.ri2w.end()); P.mo.insert(P.mo.end(), one.mo.begin(), one.mo.end());
+      P.invmo.insert(P.invmo.end(), one.invmo.begin(), one.invmo.end());
+      P.attr.insert(P.attr.end(), one.attr.begin(), one.attr.end());
+      P.n += one.n;
     } else {
       generate_2d_patches(stacks[k], half_thickness[k], iso_mask, px, py, pstride[0], pstride[1], P);
     }

@@ -86,13 +86,23 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
     return res + (np.stack(origins) if n else np.zeros((0, 3)),) if with_origins else res
 
 
-def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(32, 32), stride=(16, 16), name="pvr", superpixel=False):
+def make_pvr_problem(stacks, mask, mask_attr, recon_attr, recon_mask, pbbsize=(32, 32), stride=(16, 16), name="pvr", superpixel=False,
+                     full_slices=False):
     """PatchBasedVolume<T>::init for every stack (irtkPatchBasedReconstruction.cpp:385-399) packed into
     one Problem: slices = patches, slice dims = the stack's voxel size `getDim()` (z = stack spacing,
-    R2/patchBasedPSFReconstruction_gpu.cu:67), T = the stack transformation."""
+    R2/patchBasedPSFReconstruction_gpu.cu:67), T = the stack transformation.  full_slices = --useFullSlices: the patch is the
+    whole slice and the stride steps past it (patchBasedObject.cuh:183-189), one patch per slice that covers the mask by a third;
+    stacks of different in-plane sizes share one grid padded with -1."""
     P, I, W, T, TI, D, SI, counts, RI, MO, MI, AT, SM = [], [], [], [], [], [], [], [], [], [], [], [], []
+    gx = max(st.attr.nx for st in stacks) if full_slices else 0
+    gy = max(st.attr.ny for st in stacks) if full_slices else 0
     for k, st in enumerate(stacks):
-        if superpixel:      # pbbsize = --spxSize, stride = --spxExtend (pvrmain:291-296); patches of 64x64 with a mask each
+        if full_slices and not superpixel:
+            pbb = (st.attr.nx, st.attr.ny)
+            p0, i2w, w2i, _, org = generate2DPatches(st, mask, mask_attr, pbb, (pbb[0] + 1, pbb[1] + 1), with_origins=True)
+            p = np.full((len(p0), gy, gx), -1.0, np.float32)
+            p[:, :pbb[1], :pbb[0]] = p0
+        elif superpixel:      # pbbsize = --spxSize, stride = --spxExtend (pvrmain:291-296); patches of 64x64 with a mask each
             from . import slic
             p, i2w, w2i, sm, org, _ = slic.generate2DSuperpixelPatches(st, mask, mask_attr, pbbsize, stride[0])
             SM.append(sm)

@@ -12,7 +12,8 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
 similarity on the GPU; between the outer passes every patch is registered to the volume with the same schedule
 (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly:
-hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.  -s/--superpixel cuts SLICO superpixel patches
+hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.  --useFullSlices makes every slice one patch
+(patchBasedObject.cuh:183-189).  -s/--superpixel cuts SLICO superpixel patches
 (slic.py) instead of square ones; the patch-to-volume registration is skipped in that mode (undefined in the reference).
 """
 from __future__ import annotations
@@ -47,7 +48,8 @@ def _parser():
     p.add_argument("-s", "--superpixel", action="store_true")
     p.add_argument("--spxSize", type=int, default=16)
     p.add_argument("--spxExtend", type=int, default=50)
-    for refused in ("--hierarchical", "--packages", "--existingReconTarget", "--resample", "--dilateMask", "--useFullSlices"):
+    p.add_argument("--useFullSlices", action="store_true")
+    for refused in ("--hierarchical", "--packages", "--existingReconTarget", "--resample", "--dilateMask"):
         p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
     return p
 
@@ -124,7 +126,7 @@ def _hip_engine(prob, device):
 def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     """`_engine_factory` / `_ncc_backend` exist for the CPU tests, which drive the same pipeline over the test oracle."""
     a = _parser().parse_args(argv)
-    for refused in ("hierarchical", "packages", "existingReconTarget", "resample", "dilateMask", "useFullSlices"):
+    for refused in ("hierarchical", "packages", "existingReconTarget", "resample", "dilateMask"):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/pvr_cli.py)")
     n = len(a.input)
@@ -148,10 +150,12 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     stacks, ts, iso_mask, tattr, recon_mask = prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), a.resolution, template,
                                                       a.noMatchIntensities, None if a.no_registration else register)
     pstacks = [pvr.Stack(s.data.astype(np.float32), s.attr, t, th / 2.0) for s, t, th in zip(stacks, ts, thickness)]
+    if a.superpixel and a.useFullSlices:
+        raise SystemExit("--superpixel with --useFullSlices is not supported by this build")
     if a.superpixel:                                                                      # pvrmain:291-296
         a.patchSize, a.patchStride = [a.spxSize, a.spxSize], [a.spxExtend, a.spxExtend]
     prob = pvr.make_pvr_problem(pstacks, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, a.patchSize, a.patchStride,
-                                superpixel=a.superpixel)
+                                superpixel=a.superpixel, full_slices=a.useFullSlices)
     print(f"{n} stacks, {prob.ns} patches of {prob.slices.shape[2]}x{prob.slices.shape[1]} {prob.patches_per_stack}, volume {prob.vsize} at "
           f"{a.resolution} mm", file=sys.stderr)
     rec = _engine_factory(prob, a.devices[0])

@@ -322,6 +322,29 @@ def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
         pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--hierarchical"], _engine_factory=factory)
 
 
+def test_full_slice_patches_of_stacks_of_different_sizes_share_a_padded_grid():
+    """--useFullSlices (patchBasedObject.cuh:183-189): patch = slice, stride = size + 1; the engine's slice grid is padded with -1."""
+    from fetalreconstruction_amd import pvr
+    a, mask, mattr, rattr, rmask = phantom.make_stacks(2, (30, 30, 7), 1.1, 2.2, None, 1.0, 14.0, seed=4, orientations=("ax", "sag"),
+                                                       stack_motion_mm=0.0, stack_motion_deg=0.0)
+    b = phantom.make_stacks(2, (36, 26, 7), 1.1, 2.2, None, 1.0, 14.0, seed=4, orientations=("ax", "sag"), stack_motion_mm=0.0,
+                            stack_motion_deg=0.0)[0]
+    stacks = [a[0], b[1]]
+    P = pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, full_slices=True)
+    assert P.slices.shape[1:] == (30, 36) and sum(P.patches_per_stack) == P.ns and all(0 < c <= 7 for c in P.patches_per_stack)
+    q = 0
+    for c, st in zip(P.patches_per_stack, stacks):
+        nx, ny = st.attr.nx, st.attr.ny
+        for k in range(q, q + c):
+            assert (P.slices[k, :ny, :nx] >= 0).all() and (P.slices[k, ny:, :] == -1).all() and (P.slices[k, :, nx:] == -1).all()
+            assert (P.slice_attr[k].nx, P.slice_attr[k].ny) == (nx, ny)
+            # pixel (0,0) of the patch sits on pixel (0,0) of its slice
+            w = P.slice_i2w[k].reshape(4, 4).astype(np.float64) @ np.array([0, 0, 0, 1.0])
+            v = geo.world_to_image(st.attr) @ w
+            assert abs(v[0]) < 1e-3 and abs(v[1]) < 1e-3 and abs(v[2] - round(v[2])) < 1e-3
+        q += c
+
+
 def test_pvr_intensity_matching_rules():
     from fetalreconstruction_amd import pvr_cli
     from fetalreconstruction_amd import preprocess as pp
@@ -358,7 +381,7 @@ def test_pvr_command_line_end_to_end(tmp_path):
     _check_pvr_volume(out, stacks)
 
 
-def _python_pvr_problem(paths, mpath, psize, pstride, resolution):
+def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=False):
     """What pvr_cli.main builds before it touches the engine."""
     from fetalreconstruction_amd import nifti, pvr, pvr_cli
     from fetalreconstruction_amd import preprocess as pp
@@ -370,21 +393,24 @@ def _python_pvr_problem(paths, mpath, psize, pstride, resolution):
     ts = [np.eye(4)] * len(stacks)
     stacks, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False)
     pst = [pvr.Stack(s.data.astype(np.float32), s.attr, t, s.attr.dz) for s, t in zip(stacks, ts)]
-    prob = pvr.make_pvr_problem(pst, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, psize, pstride)
+    prob = pvr.make_pvr_problem(pst, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, psize, pstride, full_slices=full_slices)
+    prob.cropped_stacks = stacks
     pos = np.concatenate([s.data[s.data > 0].astype(np.float32) for s in stacks])
     return prob, float(pos.min()), float(pos.max())
 
 
-def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path):
+@pytest.mark.parametrize("full_slices", [False, True])
+def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices):
     """bin/PVRreconstructionGPU --dumpProblem --dryRun (csrc/pvr_cli.cpp: mask, cropping, intensity matching,
-    template, patch extraction in C++) against the Python twin; no GPU involved."""
+    template, patch extraction in C++) against the Python twin; no GPU involved.  --useFullSlices: one patch per slice."""
     import subprocess
     from fetalreconstruction_amd import build
     build.build()
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     dump = tmp_path / "problem.bin"
-    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", mpath, "--patchSize", "16", "16",
-                        "--patchStride", "8", "8", "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
+    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", mpath,
+                        *(["--useFullSlices"] if full_slices else ["--patchSize", "16", "16", "--patchStride", "8", "8"]),
+                        "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     raw = dump.read_bytes()
@@ -396,7 +422,22 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path):
     patches = np.frombuffer(raw, np.float32, ns * py * px, o).reshape(ns, py, px); o += 4 * ns * py * px
     i2w = np.frombuffer(raw, np.float32, ns * 16, o).reshape(ns, 16); o += 64 * ns
     mask = np.frombuffer(raw, np.float32, vx * vy * vz, o)
-    P, pmin, pmax = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0)
+    P, pmin, pmax = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0, full_slices)
+    if full_slices:
+        # patchBasedObject.cuh:183-189, 318: the slices that the mask covers by more than a third, whole, zero outside the mask;
+        # the cropped stacks differ in size and share a grid padded with -1
+        cs = P.cropped_stacks
+        assert (px, py) == (max(c.attr.nx for c in cs), max(c.attr.ny for c in cs))
+        assert all(0 < c <= s.attr.nz for c, s in zip(counts, cs))
+        q = 0
+        for c, s in zip(counts, cs):
+            for k in range(c):
+                blk = patches[q + k, :s.attr.ny, :s.attr.nx]
+                assert (blk >= 0).all() and (blk > 0).sum() > s.attr.nx * s.attr.ny / 3.0
+                assert (patches[q + k, s.attr.ny:, :] == -1).all() and (patches[q + k, :, s.attr.nx:] == -1).all()
+                z = [z for z in range(s.attr.nz) if np.array_equal(blk[blk > 0], s.data[z].astype(np.float32)[blk > 0])]
+                assert z, "a full-slice patch is a masked slice of its stack"
+            q += c
     assert (vx, vy, vz) == P.vsize and list(counts) == list(P.patches_per_stack) and ns == P.ns
     assert np.array_equal(mask, P.mask.reshape(-1))
     assert np.array_equal(patches, P.slices)                      # same float arithmetic, same rounding
@@ -433,13 +474,13 @@ def test_cpp_pvr_loop_matches_the_python_loop():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("registration", [False, True])
-def test_cpp_pvr_command_line_matches_the_python_one(tmp_path, registration):
+@pytest.mark.parametrize("registration,full_slices", [(False, False), (True, False), (False, True), (True, True)])
+def test_cpp_pvr_command_line_matches_the_python_one(tmp_path, registration, full_slices):
     import subprocess
     from fetalreconstruction_amd import build, nifti, pvr_cli
     paths, mpath, stacks = _write_pvr_case(tmp_path)
-    common = ["-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8", "--resolution", "1.0",
-              "--iterations", "1", "--sr_iterations", "3"] + ([] if registration else ["--no_registration"])
+    common = ["-i", *paths, "-m", mpath, *(["--useFullSlices"] if full_slices else ["--patchSize", "16", "16", "--patchStride", "8", "8"]),
+              "--resolution", "1.0", "--iterations", "1", "--sr_iterations", "3"] + ([] if registration else ["--no_registration"])
     assert pvr_cli.main(["-o", str(tmp_path / "py.nii.gz"), *common]) == 0
     r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "cc.nii.gz"), *common], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
