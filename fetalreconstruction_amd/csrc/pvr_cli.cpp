@@ -15,7 +15,8 @@
 // on the GPU; between the outer passes every patch is registered to the volume with the same schedule
 // (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.
 // -s / --superpixel cuts SLICO superpixel patches (csrc/svr_slic.h).  --useFullSlices makes every slice one patch (patchBasedObject.cuh:183-189).
-// Not built, refused loudly: hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.
+// --existingReconTarget starts from a given volume (and its grid); --hierarchical runs iterations + 1 levels of shrinking patches (pvrmain:359-432).
+// Not built, refused loudly: packages, --resample, --dilateMask.
 #include "svr_prep.h"
 #include "svr_slic.h"
 
@@ -139,8 +140,9 @@ int main(int argc, char **argv) {
   std::vector<int> devices, psize, pstride;
   int iterations = 7, sr_iterations = 7;
   double resolution = 0.75;
-  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false;
+  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false, hierarchical = false;
   int spx_size = 16, spx_extend = 50;                    // pvrmain:104-106
+  std::string existing_name;                             // --existingReconTarget (pvrmain:118)
   std::string dump_name;                                 // test hooks: --dumpProblem <file> [--dryRun]
   // ---- options (pvrmain:108-131) ---------------------------------------------------------------------
   auto is_opt = [](const char *s) { return s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.'; };
@@ -155,6 +157,8 @@ int main(int argc, char **argv) {
     else if (o == "-t" || o == "--transformation") multi(tspecs);
     else if (o == "--thickness") { std::vector<std::string> v; multi(v); for (auto &s : v) thickness.push_back(atof(s.c_str())); }
     else if (o == "--useFullSlices") full_slices = true;
+    else if (o == "--hierarchical") hierarchical = true;
+    else if (o == "--existingReconTarget") existing_name = one();
     else if (o == "--patchSize") ints(psize);
     else if (o == "--patchStride") ints(pstride);
     else if (o == "--resolution") resolution = atof(one().c_str());
@@ -223,13 +227,24 @@ int main(int argc, char **argv) {
   for (const Image &s : stacks)
     for (double v : s.d)
       if (v > 0) { vmax = std::max(vmax, (float)v); vmin = std::min(vmin, (float)v); }
-  const svr_image_attr tattr = resample_attr(stacks[tmpl].a, resolution);                        // CreateTemplate :941-965
+  svr_image_attr tattr = resample_attr(stacks[tmpl].a, resolution);                              // CreateTemplate :941-965
+  std::vector<float> existing;                           // setExistingReconstructionTarget :185-191: the volume and its grid
+  if (!existing_name.empty()) {
+    const Image ex = read_image(existing_name);
+    tattr = ex.a;
+    existing.assign(ex.d.begin(), ex.d.end());
+  }
   const Image recon_mask = transform_nn(iso_mask, tattr, ts[tmpl], 0.0);                         // :303-304
+  if (superpixel && full_slices) die("--superpixel with --useFullSlices is not supported by this build");
+  if (hierarchical && full_slices) hierarchical = false;                                         // pvrmain:282-285 "SVR ON"
+  bool first_level = true;
 
+  // one irtkPatchBasedReconstruction<T>::run from the patch extraction on (the set-up above gives the same result every time)
+  auto run_level = [&](const std::vector<int> &psize, const std::vector<int> &pstride, int iterations, const std::vector<float> &existing,
+                       std::vector<float> &vol_out) -> bool {
   // ---- patches (PBR.cpp:385-399) -----------------------------------------------------------------------
   int px = psize[0], py = psize[1];
   if (full_slices) {                                     // the patch is the slice; stacks of different sizes share a grid padded with -1
-    if (superpixel) die("--superpixel with --useFullSlices is not supported by this build");
     px = py = 0;
     for (size_t k = 0; k < n; ++k) { px = std::max(px, stacks[k].a.nx); py = std::max(py, stacks[k].a.ny); }
   }
@@ -282,7 +297,7 @@ int main(int argc, char **argv) {
   if (ns == 0) die("no patch overlaps the mask");
   fprintf(stderr, "%zu stacks, %d patches of %dx%d, volume %dx%dx%d at %g mm\n", n, ns, px, py, tattr.nx, tattr.ny, tattr.nz, resolution);
 
-  if (!dump_name.empty()) {                              // what the engine is about to receive, for the CPU tests
+  if (!dump_name.empty() && first_level) {               // what the engine is about to receive, for the CPU tests
     FILE *f = fopen(dump_name.c_str(), "wb");
     if (!f) die("cannot write " + dump_name);
     const int hdr[8] = {ns, px, py, (int)n, tattr.nx, tattr.ny, tattr.nz, 0};
@@ -294,7 +309,8 @@ int main(int argc, char **argv) {
     if (superpixel) fwrite(spx_masks.data(), 1, spx_masks.size(), f);
     fclose(f);
   }
-  if (dry_run) return 0;
+  if (dry_run) return false;
+  first_level = false;
 
   // ---- upload (the engine in PVR mode; m_quality_factor = 1, PBR.cpp:415) -----------------------------------
   svr_ctx *ctx = nullptr;
@@ -305,7 +321,8 @@ int main(int argc, char **argv) {
   std::vector<float> maskf(recon_mask.d.begin(), recon_mask.d.end());
   float ri2w[16], rw2i[16];
   to_f16(image_to_world(tattr), ri2w); to_f16(world_to_image(tattr), rw2i);
-  ENG(svr_init_reconstruction_volume(ctx, vsize, vdim, nullptr, 12.0f));
+  if (!existing.empty() && existing.size() != (size_t)tattr.nx * tattr.ny * tattr.nz) die("existing reconstruction target of the wrong size");
+  ENG(svr_init_reconstruction_volume(ctx, vsize, vdim, existing.empty() ? nullptr : existing.data(), 12.0f));   // copyFromHost :310-314
   ENG(svr_set_mask(ctx, vsize, vdim, maskf.data(), 12.0f));
   const uint32_t ssize[3] = {(uint32_t)px, (uint32_t)py, (uint32_t)ns};
   std::vector<int> sizes_x(ns, px), sizes_y(ns, py);
@@ -329,11 +346,12 @@ int main(int argc, char **argv) {
   pvrh_recon *host = pvrh_create(ctx, counts.data(), (int)counts.size(), vmin, vmax);
   if (!host) die("pvrh_create failed");
   for (int it = 0; it < iterations + 1; ++it) {
-    if (it > 0 && !no_registration && superpixel) {
+    const bool have_volume = it > 0 || !existing.empty();                                      // PBR.cpp:456
+    if (have_volume && !no_registration && superpixel) {
       // runHybrid registers the square CPU patches of generatePatchesCPU and updateTransformationMatrices then reads one
       // transformation per GPU patch from that shorter list: undefined in the reference for superpixel patches, not done
       fprintf(stderr, "superpixel mode: the patch-to-volume registration is skipped\n");
-    } else if (it > 0 && !no_registration) {             // PBR.cpp:452-489: runHybrid, the IRTK schedule on every patch
+    } else if (have_volume && !no_registration) {        // PBR.cpp:452-489: runHybrid, the IRTK schedule on every patch
       std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
       ENG(svr_sync_cpu(ctx, vol.data()));                // m_GPURecon.copyToHost
       long evals = 0;
@@ -354,11 +372,33 @@ int main(int argc, char **argv) {
     pvrh_get_state(host, nullptr, nullptr, nullptr, sc);
     fprintf(stderr, "iteration %d: sigma %.4g mix %.3f\n", it, sc[0], sc[1]);
   }
-  std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
-  ENG(svr_sync_cpu(ctx, vol.data()));
-  char err[256] = {0};
-  if (svr_nifti_write(output.c_str(), &tattr, vol.data(), err)) die(output + ": " + err);
+  vol_out.resize((size_t)tattr.nx * tattr.ny * tattr.nz);
+  ENG(svr_sync_cpu(ctx, vol_out.data()));
   pvrh_destroy(host);
   svr_destroy(ctx);
+  return true;
+  };
+
+  std::vector<float> vol;
+  if (!hierarchical) {
+    if (!run_level(psize, pstride, iterations, existing, vol)) return 0;
+  } else {
+    // pvrmain:359-432: iterations + 1 levels of one registration-reconstruction iteration each; a level starts from the volume of
+    // the level before (its "reconimage1_<size>_<stride>.nii.gz") and cuts patches 4 pixels smaller (stride 2 smaller, not for superpixels)
+    std::vector<int> ps = psize, pt = pstride;
+    for (int level = 0; level <= iterations; ++level) {
+      if (superpixel ? spx_size < 1 : (ps[0] < 1 || ps[1] < 1 || pt[0] < 1 || pt[1] < 1))
+        die("hierarchical mode: the patch size reached zero at level " + std::to_string(level) + " (--patchSize - 4 * --iterations must stay positive)");
+      fprintf(stderr, "hierarchical level %d: patch size %d stride %d\n", level, superpixel ? spx_size : ps[0], superpixel ? spx_extend : pt[0]);
+      std::vector<float> next;
+      if (!run_level(ps, pt, 1, existing, next)) return 0;
+      existing = next;
+      vol.swap(next);
+      if (superpixel) spx_size -= 4;
+      else { ps[0] -= 4; ps[1] -= 4; pt[0] -= 2; pt[1] -= 2; }
+    }
+  }
+  char err[256] = {0};
+  if (svr_nifti_write(output.c_str(), &tattr, vol.data(), err)) die(output + ": " + err);
   return 0;
 }

@@ -293,14 +293,15 @@ class irtkPatchBasedReconstruction:
         self.e.SetSliceMatrices(t, ti, prob.slice_i2w, prob.slice_w2i, prob.slice_i2w, prob.slice_w2i, prob.recon_i2w, prob.recon_w2i)
         return counters
 
-    def PatchToVolumeRegistration(self, prob, T, recon_attr, backend=None):
+    def PatchToVolumeRegistration(self, prob, T, recon_attr, backend=None, volume=None):
         """patchBased2D3DRegistration<T>::runHybrid (patchBased2D3DRegistration.cpp:184-225), what PBR.cpp:452-489 runs between the
         outer iterations: the IRTK slice-to-volume schedule on every patch (csrc/irtk_reg.cpp, similarities on the GPU) against
         the host copy of the reconstruction.  T: float64 [n][4][4], the registrator's own transformations; returns the new ones
-        and the number of similarity evaluations, and hands them to the engine."""
+        and the number of similarity evaluations, and hands them to the engine.  `volume`: an existing reconstruction target that
+        stands in for the device copy before the first iteration (PBR.cpp:310-314, 456-459 upload it and read it back)."""
         from . import host
         vx, vy, vz = prob.vsize
-        vol = np.asarray(self.e.syncCPU(), np.float32).reshape(vz, vy, vx)                 # m_GPURecon.copyToHost
+        vol = np.asarray(self.e.syncCPU() if volume is None else volume, np.float32).reshape(vz, vy, vx)   # m_GPURecon.copyToHost
         hip = self.e if hasattr(self.e, "_h") else None
         T, evals = host.SliceToVolumeRegistration(hip, prob.slices, prob.slice_attr, T, recon_attr, vol, backend=backend, no_resample=True)
         t = np.stack([geo.to_matrix4(m) for m in T])

@@ -12,7 +12,8 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
 similarity on the GPU; between the outer passes every patch is registered to the volume with the same schedule
 (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly:
-hierarchical mode, packages, --existingReconTarget, --resample, --dilateMask.  --useFullSlices makes every slice one patch
+packages, --resample, --dilateMask.  --existingReconTarget starts from a given volume and its grid, --hierarchical runs
+iterations + 1 levels of shrinking patches (pvrmain:359-432).  --useFullSlices makes every slice one patch
 (patchBasedObject.cuh:183-189).  -s/--superpixel cuts SLICO superpixel patches
 (slic.py) instead of square ones; the patch-to-volume registration is skipped in that mode (undefined in the reference).
 """
@@ -49,7 +50,9 @@ def _parser():
     p.add_argument("--spxSize", type=int, default=16)
     p.add_argument("--spxExtend", type=int, default=50)
     p.add_argument("--useFullSlices", action="store_true")
-    for refused in ("--hierarchical", "--packages", "--existingReconTarget", "--resample", "--dilateMask"):
+    p.add_argument("--hierarchical", action="store_true")
+    p.add_argument("--existingReconTarget")
+    for refused in ("--packages", "--resample", "--dilateMask"):
         p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
     return p
 
@@ -126,7 +129,7 @@ def _hip_engine(prob, device):
 def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     """`_engine_factory` / `_ncc_backend` exist for the CPU tests, which drive the same pipeline over the test oracle."""
     a = _parser().parse_args(argv)
-    for refused in ("hierarchical", "packages", "existingReconTarget", "resample", "dilateMask"):
+    for refused in ("packages", "resample", "dilateMask"):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/pvr_cli.py)")
     n = len(a.input)
@@ -152,29 +155,56 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     pstacks = [pvr.Stack(s.data.astype(np.float32), s.attr, t, th / 2.0) for s, t, th in zip(stacks, ts, thickness)]
     if a.superpixel and a.useFullSlices:
         raise SystemExit("--superpixel with --useFullSlices is not supported by this build")
-    if a.superpixel:                                                                      # pvrmain:291-296
-        a.patchSize, a.patchStride = [a.spxSize, a.spxSize], [a.spxExtend, a.spxExtend]
-    prob = pvr.make_pvr_problem(pstacks, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, a.patchSize, a.patchStride,
-                                superpixel=a.superpixel, full_slices=a.useFullSlices)
-    print(f"{n} stacks, {prob.ns} patches of {prob.slices.shape[2]}x{prob.slices.shape[1]} {prob.patches_per_stack}, volume {prob.vsize} at "
-          f"{a.resolution} mm", file=sys.stderr)
-    rec = _engine_factory(prob, a.devices[0])
+    existing = None
+    if a.existingReconTarget:                                                             # setExistingReconstructionTarget :185-191
+        ed, tattr = nifti.read(a.existingReconTarget)                                     # the volume and its grid (no CreateTemplate)
+        existing = ed.astype(np.float32)
+        recon_mask = pp.TransformMask(tattr, iso_mask, ts[template])
     pos = np.concatenate([s.data[s.data > 0].astype(np.float32) for s in stacks])          # computeMinMaxIntensities :792-814:
     vmin, vmax = float(pos.min()), float(pos.max())                                       # over the whole (cropped) stacks
-    drv = pvr.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, vmin, vmax)
-    T = np.stack([np.asarray(ts[int(k)], np.float64) for k in prob.stack_index])          # the registrators' m_transformations
-    for it in range(a.iterations + 1):                                                    # PBR.cpp:445
-        if it > 0 and not a.no_registration and a.superpixel:
-            # runHybrid registers the square CPU patches of generatePatchesCPU (patchBased2D3DRegistration.cpp:227-375) and
-            # updateTransformationMatrices then reads one transformation per GPU patch from that shorter list: undefined in
-            # the reference for superpixel patches, not done here
-            print("superpixel mode: the patch-to-volume registration is skipped", file=sys.stderr)
-        elif it > 0 and not a.no_registration:                                            # PBR.cpp:452-489 (runHybrid)
-            T, evals = drv.PatchToVolumeRegistration(prob, T, tattr, backend=_ncc_backend)
-            print(f"patch-to-volume registration: {evals} similarity evaluations", file=sys.stderr)
-        drv.reconstruct_iteration(a.sr_iterations)
-        print(f"iteration {it}: sigma {float(drv.m_sigma_gpu):.4g} mix {float(drv.m_mix_gpu):.3f}", file=sys.stderr)
-    out = rec.syncCPU().reshape(tattr.nz, tattr.ny, tattr.nx)
+
+    def run_level(psize, pstride, iterations, existing):
+        """irtkPatchBasedReconstruction<T>::run from the patch extraction on (the set-up above gives the same result every time)."""
+        prob = pvr.make_pvr_problem(pstacks, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, psize, pstride,
+                                    superpixel=a.superpixel, full_slices=a.useFullSlices)
+        print(f"{n} stacks, {prob.ns} patches of {prob.slices.shape[2]}x{prob.slices.shape[1]} {prob.patches_per_stack}, volume {prob.vsize} at "
+              f"{a.resolution} mm", file=sys.stderr)
+        rec = _engine_factory(prob, a.devices[0])
+        drv = pvr.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, vmin, vmax)
+        T = np.stack([np.asarray(ts[int(k)], np.float64) for k in prob.stack_index])      # the registrators' m_transformations
+        for it in range(iterations + 1):                                                  # PBR.cpp:445
+            have_volume = it > 0 or existing is not None                                  # :456
+            if have_volume and not a.no_registration and a.superpixel:
+                # runHybrid registers the square CPU patches of generatePatchesCPU (patchBased2D3DRegistration.cpp:227-375) and
+                # updateTransformationMatrices then reads one transformation per GPU patch from that shorter list: undefined in
+                # the reference for superpixel patches, not done here
+                print("superpixel mode: the patch-to-volume registration is skipped", file=sys.stderr)
+            elif have_volume and not a.no_registration:                                   # PBR.cpp:452-489 (runHybrid)
+                T, evals = drv.PatchToVolumeRegistration(prob, T, tattr, backend=_ncc_backend, volume=existing if it == 0 else None)
+                print(f"patch-to-volume registration: {evals} similarity evaluations", file=sys.stderr)
+            drv.reconstruct_iteration(a.sr_iterations)
+            print(f"iteration {it}: sigma {float(drv.m_sigma_gpu):.4g} mix {float(drv.m_mix_gpu):.3f}", file=sys.stderr)
+        return np.asarray(rec.syncCPU(), np.float32).reshape(tattr.nz, tattr.ny, tattr.nx).copy()
+
+    psize, pstride = list(a.patchSize), list(a.patchStride)
+    if a.superpixel:                                                                      # pvrmain:291-296
+        psize, pstride = [a.spxSize, a.spxSize], [a.spxExtend, a.spxExtend]
+    if a.hierarchical and a.useFullSlices:                                                # pvrmain:282-285 "SVR ON"
+        a.hierarchical = False
+    if not a.hierarchical:
+        out = run_level(psize, pstride, a.iterations, existing)
+    else:
+        # pvrmain:359-432: iterations + 1 levels of one registration-reconstruction iteration each; a level starts from the volume
+        # of the level before (its "reconimage1_<size>_<stride>.nii.gz") and cuts patches 4 pixels smaller (stride 2 smaller, not
+        # for superpixels)
+        for level in range(a.iterations + 1):
+            if min(psize + pstride) < 1:
+                raise SystemExit(f"hierarchical mode: the patch size reached zero at level {level} (--patchSize - 4 * --iterations must stay positive)")
+            print(f"hierarchical level {level}: patch size {psize[0]} stride {pstride[0]}", file=sys.stderr)
+            existing = out = run_level(psize, pstride, 1, existing)
+            psize = [psize[0] - 4, psize[1] - 4]
+            if not a.superpixel:
+                pstride = [pstride[0] - 2, pstride[1] - 2]
     nifti.write(a.output, out, tattr)
     return 0
 

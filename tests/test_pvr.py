@@ -276,7 +276,7 @@ def _write_pvr_case(tmp_path):
     return paths, str(tmp_path / "mask.nii.gz"), stacks
 
 
-def _check_pvr_volume(path, stacks):
+def _check_pvr_volume(path, stacks, min_cc=0.6):
     from fetalreconstruction_amd import nifti
     vol, va = nifti.read(path)
     assert abs(va.dx - 1.0) < 1e-6 and abs(va.dz - 1.0) < 1e-6
@@ -288,7 +288,7 @@ def _check_pvr_volume(path, stacks):
     assert inside.sum() > 1500
     cc = np.corrcoef(vol[inside], truth[inside])[0, 1]
     print('correlation with the phantom', cc)
-    assert cc > 0.6             # coarse case (4.4 mm thick patches of two 7-slice stacks): the same stacks fed straight
+    assert cc > min_cc          # coarse case (4.4 mm thick patches of two 7-slice stacks): the same stacks fed straight
                                 # to make_pvr_problem on the phantom's own grid reach 0.74
     return vol, va
 
@@ -319,7 +319,52 @@ def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
     means = [P.slices[P.stack_index == k][P.slices[P.stack_index == k] > 0].mean() for k in range(2)]
     assert abs(means[0] / means[1] - 1) < 0.05
     with pytest.raises(SystemExit, match="not supported"):
-        pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--hierarchical"], _engine_factory=factory)
+        pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--resample"], _engine_factory=factory)
+
+
+def test_pvr_hierarchical_levels_on_the_oracle(tmp_path, oracle_mod, capsys):
+    """--hierarchical (pvrmain:359-432): iterations + 1 levels of one reconstruction iteration each with patches 4 pixels
+    (stride 2) smaller per level; the registration side of it runs in the GPU suite."""
+    from fetalreconstruction_amd import pvr_cli
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    sizes = []
+
+    def factory(prob, device):
+        sizes.append(prob.slices.shape[1:])
+        return oracle_mod.OracleReconstruction(prob, oracle_mod.CANON, pvr=True)
+
+    common = ["-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8", "--resolution", "1.0", "--sr_iterations", "1",
+              "--no_registration", "--hierarchical"]
+    out = tmp_path / "h.nii.gz"
+    assert pvr_cli.main(["-o", str(out), *common, "--iterations", "1"], _engine_factory=factory) == 0
+    err = capsys.readouterr().err
+    assert sizes == [(16, 16), (12, 12)] and "hierarchical level 1: patch size 12 stride 6" in err
+    _check_pvr_volume(out, stacks, min_cc=0.5)
+    with pytest.raises(SystemExit, match="patch size reached zero"):
+        pvr_cli.main(["-o", str(out), "-i", *paths, "-m", mpath, "--patchSize", "4", "4", "--patchStride", "8", "8", "--resolution", "1.0",
+                      "--sr_iterations", "1", "--no_registration", "--hierarchical", "--iterations", "1"], _engine_factory=factory)
+
+
+@pytest.mark.gpu
+def test_pvr_hierarchical_and_existing_target(tmp_path, capsys):
+    """--hierarchical with registration: level 0 reconstructs, registers, reconstructs; level 1 registers to the level-0 volume
+    first.  --existingReconTarget (PBR.cpp:185-191, 296-314, 456): the given volume is the grid and the target of iteration 0."""
+    from fetalreconstruction_amd import nifti, pvr_cli
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    common = ["-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8", "--resolution", "1.0", "--sr_iterations", "3"]
+    out = tmp_path / "h.nii.gz"
+    assert pvr_cli.main(["-o", str(out), *common, "--iterations", "1", "--hierarchical"]) == 0
+    err = capsys.readouterr().err
+    assert "hierarchical level 1: patch size 12 stride 6" in err and err.count("patch-to-volume registration") == 3
+    vol, va = _check_pvr_volume(out, stacks, min_cc=0.5)
+    out2 = tmp_path / "e.nii.gz"
+    assert pvr_cli.main(["-o", str(out2), *common, "--iterations", "0", "--existingReconTarget", str(out)]) == 0
+    err = capsys.readouterr().err
+    assert err.count("patch-to-volume registration") == 1
+    v2, a2 = nifti.read(out2)
+    assert v2.shape == vol.shape and np.allclose(geo.image_to_world(a2), geo.image_to_world(va))
+    ok = (v2 > 0) & (vol > 0)
+    assert np.corrcoef(v2[ok], vol[ok])[0, 1] > 0.9
 
 
 def test_full_slice_patches_of_stacks_of_different_sizes_share_a_padded_grid():
@@ -443,7 +488,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices):
     assert np.array_equal(patches, P.slices)                      # same float arithmetic, same rounding
     assert np.allclose(i2w, P.slice_i2w, atol=1e-5)
     assert vmin == np.float32(pmin) and vmax == np.float32(pmax)
-    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--hierarchical"], capture_output=True, text=True)
+    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--resample"], capture_output=True, text=True)
     assert bad.returncode != 0 and "not supported" in bad.stderr
 
 
@@ -474,19 +519,24 @@ def test_cpp_pvr_loop_matches_the_python_loop():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("registration,full_slices", [(False, False), (True, False), (False, True), (True, True)])
-def test_cpp_pvr_command_line_matches_the_python_one(tmp_path, registration, full_slices):
+@pytest.mark.parametrize("registration,full_slices,hierarchical", [(False, False, False), (True, False, False), (False, True, False),
+                                                                  (True, True, False), (False, False, True), (True, False, True)])
+def test_cpp_pvr_command_line_matches_the_python_one(tmp_path, registration, full_slices, hierarchical):
     import subprocess
     from fetalreconstruction_amd import build, nifti, pvr_cli
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     common = ["-i", *paths, "-m", mpath, *(["--useFullSlices"] if full_slices else ["--patchSize", "16", "16", "--patchStride", "8", "8"]),
-              "--resolution", "1.0", "--iterations", "1", "--sr_iterations", "3"] + ([] if registration else ["--no_registration"])
+              "--resolution", "1.0", "--iterations", "1", "--sr_iterations", "3"] + ([] if registration else ["--no_registration"]) \
+        + (["--hierarchical"] if hierarchical else [])
     assert pvr_cli.main(["-o", str(tmp_path / "py.nii.gz"), *common]) == 0
     r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "cc.nii.gz"), *common], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     vp, ap = nifti.read(tmp_path / "py.nii.gz")
     vc, ac = nifti.read(tmp_path / "cc.nii.gz")
     assert vp.shape == vc.shape and np.allclose(geo.image_to_world(ap), geo.image_to_world(ac), atol=1e-6)
+    if hierarchical:
+        assert "hierarchical level 1: patch size 12 stride 6" in r.stderr
+        assert r.stderr.count("patch-to-volume registration") == (3 if registration else 0)
     if registration:
         assert "stack-to-stack registration" in r.stderr and "patch-to-volume registration" in r.stderr
         # the optimisers amplify last-bit differences of their inputs into different accept / reject decisions: compare as images
