@@ -16,7 +16,7 @@
 // (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.
 // -s / --superpixel cuts SLICO superpixel patches (csrc/svr_slic.h).  --useFullSlices makes every slice one patch (patchBasedObject.cuh:183-189).
 // --existingReconTarget starts from a given volume (and its grid); --hierarchical runs iterations + 1 levels of shrinking patches (pvrmain:359-432).
-// Not built, refused loudly: packages, --resample, --dilateMask.
+// --dilateMask n dilates the mask n times.  Not built, refused loudly: packages, --resample.
 #include "svr_prep.h"
 #include "svr_slic.h"
 
@@ -65,6 +65,24 @@ void match_stack_intensities_pvr(std::vector<Image> &stacks, const std::vector<M
   for (size_t s = 0; s < stacks.size(); ++s) {
     const double f = average / avg[s];
     for (double &v : stacks[s].d) if (v > 0) v = (double)(float)(v * f);      // float voxels times a double factor
+  }
+}
+
+// irtkDilation<T> with CONNECTIVITY_26 (irtkDilation.cc:50-78): an interior voxel becomes the maximum of its 26 neighbours and
+// itself, the voxels on the faces of the image keep their value
+void dilate_mask(Image &m, int iterations) {
+  const int nx = m.a.nx, ny = m.a.ny, nz = m.a.nz;
+  for (int it = 0; it < iterations; ++it) {
+    const std::vector<double> in = m.d;
+    for (int z = 1; z + 1 < nz; ++z)
+      for (int y = 1; y + 1 < ny; ++y)
+        for (int x = 1; x + 1 < nx; ++x) {
+          double v = in[((size_t)z * ny + y) * nx + x];
+          for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+              for (int dx = -1; dx <= 1; ++dx) v = std::max(v, in[((size_t)(z + dz) * ny + (y + dy)) * nx + (x + dx)]);
+          m.d[((size_t)z * ny + y) * nx + x] = v;
+        }
   }
 }
 
@@ -138,7 +156,7 @@ int main(int argc, char **argv) {
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
   std::vector<int> devices, psize, pstride;
-  int iterations = 7, sr_iterations = 7;
+  int iterations = 7, sr_iterations = 7, dilate = 0;
   double resolution = 0.75;
   bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false, hierarchical = false;
   int spx_size = 16, spx_extend = 50;                    // pvrmain:104-106
@@ -158,6 +176,7 @@ int main(int argc, char **argv) {
     else if (o == "--thickness") { std::vector<std::string> v; multi(v); for (auto &s : v) thickness.push_back(atof(s.c_str())); }
     else if (o == "--useFullSlices") full_slices = true;
     else if (o == "--hierarchical") hierarchical = true;
+    else if (o == "--dilateMask") dilate = atoi(one().c_str());
     else if (o == "--existingReconTarget") existing_name = one();
     else if (o == "--patchSize") ints(psize);
     else if (o == "--patchStride") ints(pstride);
@@ -201,6 +220,7 @@ int main(int argc, char **argv) {
   for (size_t k = 0; k < n; ++k) if (tspecs[k] == "id") { tmpl = k; break; }
   Image mask = read_image(mask_name);
   for (double &v : mask.d) v = ((long long)v == 0) ? 0.0 : 1.0;                               // PBR.cpp:201-209
+  if (dilate > 0) dilate_mask(mask, dilate);                                                     // :212-223
   for (size_t k = 0; k < n; ++k) {                                                               // :229-236
     const Image m = transform_nn(mask, stacks[k].a, ts[k], 0.0);
     stacks[k] = crop_image(stacks[k], m);

@@ -12,7 +12,7 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
 similarity on the GPU; between the outer passes every patch is registered to the volume with the same schedule
 (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly:
-packages, --resample, --dilateMask.  --existingReconTarget starts from a given volume and its grid, --hierarchical runs
+packages, --resample.  --dilateMask n dilates the mask n times (26-connectivity); --existingReconTarget starts from a given volume and its grid, --hierarchical runs
 iterations + 1 levels of shrinking patches (pvrmain:359-432).  --useFullSlices makes every slice one patch
 (patchBasedObject.cuh:183-189).  -s/--superpixel cuts SLICO superpixel patches
 (slic.py) instead of square ones; the patch-to-volume registration is skipped in that mode (undefined in the reference).
@@ -52,7 +52,8 @@ def _parser():
     p.add_argument("--useFullSlices", action="store_true")
     p.add_argument("--hierarchical", action="store_true")
     p.add_argument("--existingReconTarget")
-    for refused in ("--packages", "--resample", "--dilateMask"):
+    p.add_argument("--dilateMask", type=int, default=0)
+    for refused in ("--packages", "--resample"):
         p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
     return p
 
@@ -100,10 +101,30 @@ def match_stack_intensities_pvr(stacks, transformations, mask, together=False):
     return average_value
 
 
-def prepare(stacks, transformations, mask, resolution, template, no_match, register=None):
+def dilate_mask(m, iterations):
+    """irtkDilation<T> with CONNECTIVITY_26 (irtkDilation.cc:50-78), `iterations` runs: an interior voxel becomes the maximum of
+    its 26 neighbours and itself, the voxels on the faces of the image keep their value."""
+    m = np.asarray(m, np.float64)
+    for _ in range(int(iterations)):
+        out = m.copy()
+        if min(m.shape) > 2:
+            core = m[1:-1, 1:-1, 1:-1].copy()
+            nz, ny, nx = m.shape
+            for dz in (0, 1, 2):
+                for dy in (0, 1, 2):
+                    for dx in (0, 1, 2):
+                        np.maximum(core, m[dz:nz - 2 + dz, dy:ny - 2 + dy, dx:nx - 2 + dx], out=core)
+            out[1:-1, 1:-1, 1:-1] = core
+        m = out
+    return m
+
+
+def prepare(stacks, transformations, mask, resolution, template, no_match, register=None, dilate=0):
     """PBR.cpp:197-310.  `register(stacks, transformations, iso_mask) -> transformations` is the stack-to-stack registration
     (irtkStack3D3DRegistration, :280-285) or None.  Returns (stacks, transformations, iso mask, template attributes, recon mask)."""
     mask = pp.Image((np.trunc(mask.data) != 0).astype(np.float64), mask.attr)            # :201-209, (unsigned int) cast
+    if dilate:
+        mask = pp.Image(dilate_mask(mask.data, dilate), mask.attr)                        # :212-223
     for k in range(len(stacks)):                                                          # :229-236
         m = pp.TransformMask(stacks[k].attr, mask, transformations[k])
         stacks[k] = pp.CropImage(stacks[k], m)
@@ -129,7 +150,7 @@ def _hip_engine(prob, device):
 def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     """`_engine_factory` / `_ncc_backend` exist for the CPU tests, which drive the same pipeline over the test oracle."""
     a = _parser().parse_args(argv)
-    for refused in ("packages", "resample", "dilateMask"):
+    for refused in ("packages", "resample"):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/pvr_cli.py)")
     n = len(a.input)
@@ -151,7 +172,7 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
         return list(out)
 
     stacks, ts, iso_mask, tattr, recon_mask = prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), a.resolution, template,
-                                                      a.noMatchIntensities, None if a.no_registration else register)
+                                                      a.noMatchIntensities, None if a.no_registration else register, a.dilateMask)
     pstacks = [pvr.Stack(s.data.astype(np.float32), s.attr, t, th / 2.0) for s, t, th in zip(stacks, ts, thickness)]
     if a.superpixel and a.useFullSlices:
         raise SystemExit("--superpixel with --useFullSlices is not supported by this build")

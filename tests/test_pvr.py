@@ -426,7 +426,7 @@ def test_pvr_command_line_end_to_end(tmp_path):
     _check_pvr_volume(out, stacks)
 
 
-def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=False):
+def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=False, dilate=0):
     """What pvr_cli.main builds before it touches the engine."""
     from fetalreconstruction_amd import nifti, pvr, pvr_cli
     from fetalreconstruction_amd import preprocess as pp
@@ -436,7 +436,7 @@ def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=Fa
         stacks.append(pp.Image(d.astype(np.float64), at))
     md, mat = nifti.read(mpath)
     ts = [np.eye(4)] * len(stacks)
-    stacks, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False)
+    stacks, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False, dilate=dilate)
     pst = [pvr.Stack(s.data.astype(np.float32), s.attr, t, s.attr.dz) for s, t in zip(stacks, ts)]
     prob = pvr.make_pvr_problem(pst, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, psize, pstride, full_slices=full_slices)
     prob.cropped_stacks = stacks
@@ -444,8 +444,23 @@ def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=Fa
     return prob, float(pos.min()), float(pos.max())
 
 
-@pytest.mark.parametrize("full_slices", [False, True])
-def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices):
+def test_dilate_mask_rule():
+    """irtkDilation, 26-connectivity (irtkDilation.cc:50-78): binary dilation by a 3x3x3 box, the faces of the image untouched."""
+    from scipy import ndimage
+    from fetalreconstruction_amd import pvr_cli
+    rng = np.random.default_rng(3)
+    m = (rng.random((9, 10, 11)) > 0.97).astype(np.float64)
+    d = pvr_cli.dilate_mask(m, 2)
+    ref = m.copy()
+    for _ in range(2):
+        nxt = ndimage.binary_dilation(ref > 0, structure=np.ones((3, 3, 3))).astype(np.float64)
+        nxt[0], nxt[-1], nxt[:, 0], nxt[:, -1], nxt[:, :, 0], nxt[:, :, -1] = ref[0], ref[-1], ref[:, 0], ref[:, -1], ref[:, :, 0], ref[:, :, -1]
+        ref = nxt
+    assert np.array_equal(d, ref) and d.sum() > m.sum()
+
+
+@pytest.mark.parametrize("full_slices,dilate", [(False, 0), (True, 0), (False, 2)])
+def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices, dilate):
     """bin/PVRreconstructionGPU --dumpProblem --dryRun (csrc/pvr_cli.cpp: mask, cropping, intensity matching,
     template, patch extraction in C++) against the Python twin; no GPU involved.  --useFullSlices: one patch per slice."""
     import subprocess
@@ -455,6 +470,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices):
     dump = tmp_path / "problem.bin"
     r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", mpath,
                         *(["--useFullSlices"] if full_slices else ["--patchSize", "16", "16", "--patchStride", "8", "8"]),
+                        *(["--dilateMask", str(dilate)] if dilate else []),
                         "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
@@ -467,7 +483,9 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices):
     patches = np.frombuffer(raw, np.float32, ns * py * px, o).reshape(ns, py, px); o += 4 * ns * py * px
     i2w = np.frombuffer(raw, np.float32, ns * 16, o).reshape(ns, 16); o += 64 * ns
     mask = np.frombuffer(raw, np.float32, vx * vy * vz, o)
-    P, pmin, pmax = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0, full_slices)
+    P, pmin, pmax = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0, full_slices, dilate)
+    if dilate:
+        assert P.mask.sum() > _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0)[0].mask.sum()
     if full_slices:
         # patchBasedObject.cuh:183-189, 318: the slices that the mask covers by more than a third, whole, zero outside the mask;
         # the cropped stacks differ in size and share a grid padded with -1
