@@ -16,7 +16,8 @@
 // (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.
 // -s / --superpixel cuts SLICO superpixel patches (csrc/svr_slic.h).  --useFullSlices makes every slice one patch (patchBasedObject.cuh:183-189).
 // --existingReconTarget starts from a given volume (and its grid); --hierarchical runs iterations + 1 levels of shrinking patches (pvrmain:359-432).
-// --dilateMask n dilates the mask n times.  Not built, refused loudly: packages, --resample.
+// --dilateMask n dilates the mask n times, --packages p_1 .. p_N splits every stack into its interleaved packages (PBR.cpp:134-146).
+// Not built, refused loudly: --resample.
 #include "svr_prep.h"
 #include "svr_slic.h"
 
@@ -84,6 +85,28 @@ void dilate_mask(Image &m, int iterations) {
           m.d[((size_t)z * ny + y) * nx + x] = v;
         }
   }
+}
+
+// patchBasedPackageSplitter<T>::makePackageVolumes (patchBasedPackageSplitter.cpp:76-146): package l holds slices l, l + packages, ...
+// of the stack at `packages` times the slice spacing, with its first voxel where slice l's first voxel was
+std::vector<Image> split_packages(const Image &stack, int packages) {
+  std::vector<Image> out;
+  const svr_image_attr &a = stack.a;
+  const int pkg_z = a.nz / packages;
+  const M4 i2w = image_to_world(a);
+  for (int l = 0; l < packages; ++l) {
+    Image p;
+    p.a = a;
+    p.a.nz = (pkg_z * packages + l < a.nz) ? pkg_z + 1 : pkg_z;
+    p.a.dz = a.dz * packages;
+    const M4 first = image_to_world(p.a);
+    for (int k = 0; k < 3; ++k) p.a.origin[k] += (i2w.m[4 * k + 2] * l + i2w.m[4 * k + 3]) - first.m[4 * k + 3];
+    p.d.resize((size_t)p.a.nx * p.a.ny * p.a.nz);
+    const size_t plane = (size_t)a.nx * a.ny;
+    for (int k = 0; k < p.a.nz; ++k) memcpy(&p.d[(size_t)k * plane], &stack.d[(size_t)(k * packages + l) * plane], plane * sizeof(double));
+    out.push_back(std::move(p));
+  }
+  return out;
 }
 
 struct Patches {
@@ -155,7 +178,7 @@ int main(int argc, char **argv) {
   std::string output, mask_name;
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
-  std::vector<int> devices, psize, pstride;
+  std::vector<int> devices, psize, pstride, packages;
   int iterations = 7, sr_iterations = 7, dilate = 0;
   double resolution = 0.75;
   bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false, hierarchical = false;
@@ -176,6 +199,7 @@ int main(int argc, char **argv) {
     else if (o == "--thickness") { std::vector<std::string> v; multi(v); for (auto &s : v) thickness.push_back(atof(s.c_str())); }
     else if (o == "--useFullSlices") full_slices = true;
     else if (o == "--hierarchical") hierarchical = true;
+    else if (o == "--packages") ints(packages);
     else if (o == "--dilateMask") dilate = atoi(one().c_str());
     else if (o == "--existingReconTarget") existing_name = one();
     else if (o == "--patchSize") ints(psize);
@@ -205,7 +229,7 @@ int main(int argc, char **argv) {
   if (pstride.empty()) pstride = {16, 16};
   if (psize.size() != 2 || pstride.size() != 2 || psize[0] < 1 || psize[1] < 1 || pstride[0] < 1 || pstride[1] < 1)
     die("--patchSize and --patchStride take two positive integers");
-  const size_t n = inputs.size();
+  size_t n = inputs.size();
   if (tspecs.empty()) tspecs.assign(n, "id");
   if (tspecs.size() != n) die("one transformation per stack expected");
 
@@ -218,6 +242,17 @@ int main(int argc, char **argv) {
   else { if (thickness.size() != n) die("one thickness per stack expected"); for (double t : thickness) half_thickness.push_back(t / 2.0); }
   size_t tmpl = 0;
   for (size_t k = 0; k < n; ++k) if (tspecs[k] == "id") { tmpl = k; break; }
+  if (packages.size() == n) {                            // setImageStacks, PBR.cpp:134-146: every package becomes a stack of its own;
+    std::vector<Image> ps;                               // m_template_num keeps indexing the new list
+    std::vector<M4> pt;
+    std::vector<double> ph;
+    for (size_t k = 0; k < n; ++k) {
+      if (packages[k] < 1) die("--packages takes positive integers");
+      for (Image &p : split_packages(stacks[k], packages[k])) { ps.push_back(std::move(p)); pt.push_back(ts[k]); ph.push_back(half_thickness[k]); }
+    }
+    stacks.swap(ps); ts.swap(pt); half_thickness.swap(ph);
+    n = stacks.size();
+  }
   Image mask = read_image(mask_name);
   for (double &v : mask.d) v = ((long long)v == 0) ? 0.0 : 1.0;                               // PBR.cpp:201-209
   if (dilate > 0) dilate_mask(mask, dilate);                                                     // :212-223

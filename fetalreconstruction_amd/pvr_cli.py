@@ -12,7 +12,7 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
 similarity on the GPU; between the outer passes every patch is registered to the volume with the same schedule
 (patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly:
-packages, --resample.  --dilateMask n dilates the mask n times (26-connectivity); --existingReconTarget starts from a given volume and its grid, --hierarchical runs
+--resample.  --packages p_1 .. p_N splits every stack into its interleaved packages (PBR.cpp:134-146); --dilateMask n dilates the mask n times (26-connectivity); --existingReconTarget starts from a given volume and its grid, --hierarchical runs
 iterations + 1 levels of shrinking patches (pvrmain:359-432).  --useFullSlices makes every slice one patch
 (patchBasedObject.cuh:183-189).  -s/--superpixel cuts SLICO superpixel patches
 (slic.py) instead of square ones; the patch-to-volume registration is skipped in that mode (undefined in the reference).
@@ -53,7 +53,8 @@ def _parser():
     p.add_argument("--hierarchical", action="store_true")
     p.add_argument("--existingReconTarget")
     p.add_argument("--dilateMask", type=int, default=0)
-    for refused in ("--packages", "--resample"):
+    p.add_argument("--packages", nargs="+", type=int)
+    for refused in ("--resample",):
         p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
     return p
 
@@ -99,6 +100,25 @@ def match_stack_intensities_pvr(stacks, transformations, mask, together=False):
         f = average_value / (glob if together else av)
         st.data = np.where(st.data > 0, st.data * f, st.data)
     return average_value
+
+
+def split_packages(stack, packages):
+    """patchBasedPackageSplitter<T>::makePackageVolumes (patchBasedPackageSplitter.cpp:76-146): package l holds slices l, l + packages,
+    ... of the stack at `packages` times the slice spacing, with its first voxel where slice l's first voxel was."""
+    out = []
+    a = stack.attr
+    pkg_z = a.nz // packages
+    i2w = geo.image_to_world(a)
+    for l in range(packages):
+        pa = copy.copy(a)
+        pa.nz = pkg_z + 1 if pkg_z * packages + l < a.nz else pkg_z
+        pa.dz = a.dz * packages
+        pa.origin = np.asarray(a.origin, np.float64).copy()
+        target = i2w @ np.array([0.0, 0.0, float(l), 1.0])
+        first = geo.image_to_world(pa) @ np.array([0.0, 0.0, 0.0, 1.0])
+        pa.origin = pa.origin + (target - first)[:3]
+        out.append(pp.Image(stack.data[l::packages][:pa.nz].copy(), pa))
+    return out
 
 
 def dilate_mask(m, iterations):
@@ -150,7 +170,7 @@ def _hip_engine(prob, device):
 def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     """`_engine_factory` / `_ncc_backend` exist for the CPU tests, which drive the same pipeline over the test oracle."""
     a = _parser().parse_args(argv)
-    for refused in ("packages", "resample"):
+    for refused in ("resample",):
         if getattr(a, refused) is not None:
             raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/pvr_cli.py)")
     n = len(a.input)
@@ -162,6 +182,12 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     ts = [_load_transformation(s) for s in specs]
     thickness = a.thickness or [2.0 * s.attr.dz for s in stacks]                          # pvrmain: twice the z spacing
     template = next((k for k, s in enumerate(specs) if s == "id"), 0)
+    if a.packages and len(a.packages) == n:                                               # setImageStacks, PBR.cpp:134-146: every package
+        if min(a.packages) < 1:                                                           # becomes a stack of its own; m_template_num
+            raise SystemExit("--packages takes positive integers")                        # keeps indexing the new list
+        split = [(pk, t, th) for s, t, th, k in zip(stacks, ts, thickness, a.packages) for pk in split_packages(s, k)]
+        stacks, ts, thickness = [list(v) for v in zip(*split)]
+        n = len(stacks)
     md, mat = nifti.read(a.mask)
     def register(st, tr, iso):                                                            # irtkStack3D3DRegistration<T>::run
         from . import host
