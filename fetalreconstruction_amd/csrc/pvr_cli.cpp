@@ -17,7 +17,8 @@
 // -s / --superpixel cuts SLICO superpixel patches (csrc/svr_slic.h).  --useFullSlices makes every slice one patch (patchBasedObject.cuh:183-189).
 // --existingReconTarget starts from a given volume (and its grid); --hierarchical runs iterations + 1 levels of shrinking patches (pvrmain:359-432).
 // --dilateMask n dilates the mask n times, --packages p_1 .. p_N splits every stack into its interleaved packages (PBR.cpp:134-146).
-// Not built, refused loudly: --resample.
+// --resample resamples the cropped stacks to the output voxel size with IRTK's cubic B-spline interpolator.
+#include <float.h>
 #include "svr_prep.h"
 #include "svr_slic.h"
 
@@ -85,6 +86,90 @@ void dilate_mask(Image &m, int iterations) {
           m.d[((size_t)z * ny + y) * nx + x] = v;
         }
   }
+}
+
+// ConvertToInterpolationCoefficients, cubic spline, mirror boundaries (irtkBSplineInterpolateImageFunction.cc:68-144)
+void bspline_coefficients(double *c, int n) {
+  if (n == 1) return;
+  const double z = sqrt(3.0) - 2.0;
+  const double lambda = (1.0 - z) * (1.0 - 1.0 / z);
+  for (int k = 0; k < n; ++k) c[k] *= lambda;
+  const int horizon = (int)ceil(log(DBL_EPSILON) / log(fabs(z)));
+  double zn = z, sum;
+  if (horizon < n) {
+    sum = c[0];
+    for (int k = 1; k < horizon; ++k) { sum += zn * c[k]; zn *= z; }
+    c[0] = sum;
+  } else {
+    const double iz = 1.0 / z;
+    double z2n = pow(z, (double)(n - 1));
+    sum = c[0] + z2n * c[n - 1];
+    z2n *= z2n * iz;
+    for (int k = 1; k <= n - 2; ++k) { sum += (zn + z2n) * c[k]; zn *= z; z2n *= iz; }
+    c[0] = sum / (1.0 - zn * zn);
+  }
+  for (int k = 1; k < n; ++k) c[k] += z * c[k - 1];
+  c[n - 1] = (z / (z * z - 1.0)) * (z * c[n - 2] + c[n - 1]);
+  for (int k = n - 2; k >= 0; --k) c[k] = z * (c[k + 1] - c[k]);
+}
+
+// irtkResampling<T> with irtkBSplineInterpolateImageFunction (cubic, clamped to the input's range): what --resample does to every
+// cropped stack (PBR.cpp:225-246; irtkResampling.cc:74-175, irtkBSplineInterpolateImageFunction.cc:146-433); float voxels
+Image resample_bspline(const Image &img, double d) {
+  const svr_image_attr &a = img.a;
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  std::vector<double> coeff = img.d, line((size_t)std::max(nx, std::max(ny, nz)));
+  auto C = [&](int x, int y, int z) -> double & { return coeff[((size_t)z * ny + y) * nx + x]; };
+  for (int z = 0; z < nz; ++z)
+    for (int y = 0; y < ny; ++y) bspline_coefficients(&C(0, y, z), nx);
+  for (int z = 0; z < nz; ++z)
+    for (int x = 0; x < nx; ++x) {
+      for (int y = 0; y < ny; ++y) line[y] = C(x, y, z);
+      bspline_coefficients(line.data(), ny);
+      for (int y = 0; y < ny; ++y) C(x, y, z) = line[y];
+    }
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      for (int z = 0; z < nz; ++z) line[z] = C(x, y, z);
+      bspline_coefficients(line.data(), nz);
+      for (int z = 0; z < nz; ++z) C(x, y, z) = line[z];
+    }
+  double vmin = img.d[0], vmax = img.d[0];
+  for (double v : img.d) { vmin = std::min(vmin, v); vmax = std::max(vmax, v); }
+  Image out;
+  out.a = resample_attr(a, d);
+  out.d.resize((size_t)out.a.nx * out.a.ny * out.a.nz);
+  const M4 m = mul(world_to_image(a), image_to_world(out.a));
+  const int dims[3] = {nx, ny, nz};
+  for (int k = 0; k < out.a.nz; ++k)
+    for (int j = 0; j < out.a.ny; ++j)
+      for (int i = 0; i < out.a.nx; ++i) {
+        int idx[3][4];
+        double wgt[3][4];
+        for (int r = 0; r < 3; ++r) {
+          const double x = m.m[4 * r] * i + m.m[4 * r + 1] * j + m.m[4 * r + 2] * k + m.m[4 * r + 3];
+          const int i0 = (int)floor(x) - 1;
+          const double w = x - (double)(i0 + 1);
+          wgt[r][3] = (1.0 / 6.0) * w * w * w;
+          wgt[r][0] = (1.0 / 6.0) + (1.0 / 2.0) * w * (w - 1.0) - wgt[r][3];
+          wgt[r][2] = w + wgt[r][0] - 2.0 * wgt[r][3];
+          wgt[r][1] = 1.0 - wgt[r][0] - wgt[r][2] - wgt[r][3];
+          const int n = dims[r], half = 2 * n - 2;
+          for (int q = 0; q < 4; ++q) {
+            int v = i0 + q;
+            v = (n == 1) ? 0 : (v < 0 ? -v - half * ((-v) / half) : v - half * (v / half));
+            if (n <= v) v = half - v;
+            idx[r][q] = v;
+          }
+        }
+        double value = 0.0;
+        for (int c = 0; c < 4; ++c)
+          for (int b = 0; b < 4; ++b)
+            for (int e = 0; e < 4; ++e) value += wgt[0][e] * wgt[1][b] * wgt[2][c] * C(idx[0][e], idx[1][b], idx[2][c]);
+        value = std::min(std::max(value, vmin), vmax);
+        out.d[((size_t)k * out.a.ny + j) * out.a.nx + i] = (double)(float)value;
+      }
+  return out;
 }
 
 // patchBasedPackageSplitter<T>::makePackageVolumes (patchBasedPackageSplitter.cpp:76-146): package l holds slices l, l + packages, ...
@@ -181,7 +266,7 @@ int main(int argc, char **argv) {
   std::vector<int> devices, psize, pstride, packages;
   int iterations = 7, sr_iterations = 7, dilate = 0;
   double resolution = 0.75;
-  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false, hierarchical = false;
+  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false, hierarchical = false, resample = false;
   int spx_size = 16, spx_extend = 50;                    // pvrmain:104-106
   std::string existing_name;                             // --existingReconTarget (pvrmain:118)
   std::string dump_name;                                 // test hooks: --dumpProblem <file> [--dryRun]
@@ -199,6 +284,7 @@ int main(int argc, char **argv) {
     else if (o == "--thickness") { std::vector<std::string> v; multi(v); for (auto &s : v) thickness.push_back(atof(s.c_str())); }
     else if (o == "--useFullSlices") full_slices = true;
     else if (o == "--hierarchical") hierarchical = true;
+    else if (o == "--resample") resample = true;
     else if (o == "--packages") ints(packages);
     else if (o == "--dilateMask") dilate = atoi(one().c_str());
     else if (o == "--existingReconTarget") existing_name = one();
@@ -259,6 +345,7 @@ int main(int argc, char **argv) {
   for (size_t k = 0; k < n; ++k) {                                                               // :229-236
     const Image m = transform_nn(mask, stacks[k].a, ts[k], 0.0);
     stacks[k] = crop_image(stacks[k], m);
+    if (resample) stacks[k] = resample_bspline(stacks[k], resolution);                          // :237-246
   }
   const Image iso_mask = transform_nn(mask, resample_attr(mask.a, resolution), ident(), 0.0);    // :258-266
   if (!no_registration && n > 1) {                       // irtkStack3D3DRegistration<T>::run, :280-285

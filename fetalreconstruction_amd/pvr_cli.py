@@ -11,8 +11,9 @@ Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
 
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
 similarity on the GPU; between the outer passes every patch is registered to the volume with the same schedule
-(patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built, refused loudly:
---resample.  --packages p_1 .. p_N splits every stack into its interleaved packages (PBR.cpp:134-146); --dilateMask n dilates the mask n times (26-connectivity); --existingReconTarget starts from a given volume and its grid, --hierarchical runs
+(patchBased2D3DRegistration<T>::runHybrid, what PBR.cpp:472-476 calls); --no_registration (not a reference option) skips both.  Not built: the CPU
+path (--useCPU) and the evaluation options.  --resample resamples the cropped stacks to the output voxel size with IRTK's cubic
+B-spline interpolator; --packages p_1 .. p_N splits every stack into its interleaved packages (PBR.cpp:134-146); --dilateMask n dilates the mask n times (26-connectivity); --existingReconTarget starts from a given volume and its grid, --hierarchical runs
 iterations + 1 levels of shrinking patches (pvrmain:359-432).  --useFullSlices makes every slice one patch
 (patchBasedObject.cuh:183-189).  -s/--superpixel cuts SLICO superpixel patches
 (slic.py) instead of square ones; the patch-to-volume registration is skipped in that mode (undefined in the reference).
@@ -54,8 +55,8 @@ def _parser():
     p.add_argument("--existingReconTarget")
     p.add_argument("--dilateMask", type=int, default=0)
     p.add_argument("--packages", nargs="+", type=int)
-    for refused in ("--resample",):
-        p.add_argument(refused, nargs="*", help=argparse.SUPPRESS)
+    p.add_argument("--resample", action="store_true")
+    p.add_argument("--useCPU", action="store_true", help=argparse.SUPPRESS)
     return p
 
 
@@ -121,6 +122,82 @@ def split_packages(stack, packages):
     return out
 
 
+def _bspline_coefficients(c):
+    """ConvertToInterpolationCoefficients along the last axis, cubic spline, mirror boundaries
+    (irtkBSplineInterpolateImageFunction.cc:68-144), in place."""
+    import math
+    n = c.shape[-1]
+    if n == 1:
+        return
+    z = math.sqrt(3.0) - 2.0
+    c *= (1.0 - z) * (1.0 - 1.0 / z)
+    horizon = int(math.ceil(math.log(np.finfo(np.float64).eps) / math.log(abs(z))))
+    zn = z
+    if horizon < n:
+        s = c[..., 0].copy()
+        for k in range(1, horizon):
+            s += zn * c[..., k]
+            zn *= z
+        c[..., 0] = s
+    else:
+        iz = 1.0 / z
+        z2n = math.pow(z, float(n - 1))
+        s = c[..., 0] + z2n * c[..., n - 1]
+        z2n *= z2n * iz
+        for k in range(1, n - 1):
+            s += (zn + z2n) * c[..., k]
+            zn *= z
+            z2n *= iz
+        c[..., 0] = s / (1.0 - zn * zn)
+    for k in range(1, n):
+        c[..., k] += z * c[..., k - 1]
+    c[..., n - 1] = (z / (z * z - 1.0)) * (z * c[..., n - 2] + c[..., n - 1])
+    for k in range(n - 2, -1, -1):
+        c[..., k] = z * (c[..., k + 1] - c[..., k])
+
+
+def resample_bspline(img, d):
+    """irtkResampling<T> with irtkBSplineInterpolateImageFunction (cubic, clamped to the input's range), what --resample does to
+    every cropped stack (PBR.cpp:225-246; irtkResampling.cc:74-175, irtkBSplineInterpolateImageFunction.cc:146-433).  The
+    voxels are float, as in irtkGenericImage<float>."""
+    a = img.attr
+    coeff = np.array(img.data, np.float64)
+    for axis in (2, 1, 0):                                                   # x, then y, then z
+        v = np.moveaxis(coeff, axis, -1)
+        _bspline_coefficients(v)
+    out_attr = resample_attr(a, d)
+    m = geo.world_to_image(a) @ geo.image_to_world(out_attr)
+    kk, jj, ii = np.meshgrid(np.arange(out_attr.nz), np.arange(out_attr.ny), np.arange(out_attr.nx), indexing="ij")
+    p = [m[r, 0] * ii + m[r, 1] * jj + m[r, 2] * kk + m[r, 3] for r in range(3)]
+    idx, wgt = [], []
+    for x, n in zip(p, (a.nx, a.ny, a.nz)):
+        i0 = np.floor(x).astype(np.int64) - 1
+        w = x - (i0 + 1)
+        w3 = (1.0 / 6.0) * w * w * w
+        w0 = (1.0 / 6.0) + (1.0 / 2.0) * w * (w - 1.0) - w3
+        w2 = w + w0 - 2.0 * w3
+        w1 = 1.0 - w0 - w2 - w3
+        wgt.append((w0, w1, w2, w3))
+        half = 2 * n - 2
+        ids = []
+        for mm in range(4):
+            q = i0 + mm
+            if n == 1:
+                q = np.zeros_like(q)
+            else:
+                q = np.where(q < 0, -q - half * ((-q) // half), q - half * (q // half))   # C division of non-negative operands
+                q = np.where(q >= n, half - q, q)
+            ids.append(q)
+        idx.append(ids)
+    value = np.zeros(p[0].shape, np.float64)
+    for k in range(4):
+        for j in range(4):
+            for i in range(4):
+                value += wgt[0][i] * wgt[1][j] * wgt[2][k] * coeff[idx[2][k], idx[1][j], idx[0][i]]
+    value = np.clip(value, img.data.min(), img.data.max())
+    return pp.Image(value.astype(np.float32).astype(np.float64), out_attr)
+
+
 def dilate_mask(m, iterations):
     """irtkDilation<T> with CONNECTIVITY_26 (irtkDilation.cc:50-78), `iterations` runs: an interior voxel becomes the maximum of
     its 26 neighbours and itself, the voxels on the faces of the image keep their value."""
@@ -139,7 +216,7 @@ def dilate_mask(m, iterations):
     return m
 
 
-def prepare(stacks, transformations, mask, resolution, template, no_match, register=None, dilate=0):
+def prepare(stacks, transformations, mask, resolution, template, no_match, register=None, dilate=0, resample=False):
     """PBR.cpp:197-310.  `register(stacks, transformations, iso_mask) -> transformations` is the stack-to-stack registration
     (irtkStack3D3DRegistration, :280-285) or None.  Returns (stacks, transformations, iso mask, template attributes, recon mask)."""
     mask = pp.Image((np.trunc(mask.data) != 0).astype(np.float64), mask.attr)            # :201-209, (unsigned int) cast
@@ -148,6 +225,8 @@ def prepare(stacks, transformations, mask, resolution, template, no_match, regis
     for k in range(len(stacks)):                                                          # :229-236
         m = pp.TransformMask(stacks[k].attr, mask, transformations[k])
         stacks[k] = pp.CropImage(stacks[k], m)
+        if resample:
+            stacks[k] = resample_bspline(stacks[k], resolution)                           # :237-246
     iso_mask = pp.transform_nn(mask, resample_attr(mask.attr, resolution))               # :258-266
     if register is not None and len(stacks) > 1:
         transformations = register(stacks, transformations, iso_mask)                    # :280-285
@@ -170,9 +249,8 @@ def _hip_engine(prob, device):
 def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
     """`_engine_factory` / `_ncc_backend` exist for the CPU tests, which drive the same pipeline over the test oracle."""
     a = _parser().parse_args(argv)
-    for refused in ("resample",):
-        if getattr(a, refused) is not None:
-            raise SystemExit(f"--{refused} is not supported by this build (see fetalreconstruction_amd/pvr_cli.py)")
+    if a.useCPU:
+        raise SystemExit("--useCPU is not supported by this build: there is no CPU reconstruction path (see fetalreconstruction_amd/pvr_cli.py)")
     n = len(a.input)
     stacks = []
     for path in a.input:
@@ -198,7 +276,7 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
         return list(out)
 
     stacks, ts, iso_mask, tattr, recon_mask = prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), a.resolution, template,
-                                                      a.noMatchIntensities, None if a.no_registration else register, a.dilateMask)
+                                                      a.noMatchIntensities, None if a.no_registration else register, a.dilateMask, a.resample)
     pstacks = [pvr.Stack(s.data.astype(np.float32), s.attr, t, th / 2.0) for s, t, th in zip(stacks, ts, thickness)]
     if a.superpixel and a.useFullSlices:
         raise SystemExit("--superpixel with --useFullSlices is not supported by this build")

@@ -319,7 +319,7 @@ def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
     means = [P.slices[P.stack_index == k][P.slices[P.stack_index == k] > 0].mean() for k in range(2)]
     assert abs(means[0] / means[1] - 1) < 0.05
     with pytest.raises(SystemExit, match="not supported"):
-        pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--resample"], _engine_factory=factory)
+        pvr_cli.main(["-o", "x.nii", "-i", paths[0], "-m", mpath, "--useCPU"], _engine_factory=factory)
 
 
 def test_pvr_hierarchical_levels_on_the_oracle(tmp_path, oracle_mod, capsys):
@@ -426,7 +426,7 @@ def test_pvr_command_line_end_to_end(tmp_path):
     _check_pvr_volume(out, stacks)
 
 
-def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=False, dilate=0, packages=None):
+def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=False, dilate=0, packages=None, resample=False):
     """What pvr_cli.main builds before it touches the engine."""
     from fetalreconstruction_amd import nifti, pvr, pvr_cli
     from fetalreconstruction_amd import preprocess as pp
@@ -441,7 +441,7 @@ def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=Fa
         half = [h for h, k in zip(half, packages) for _ in range(k)]
         stacks = [p for s, k in zip(stacks, packages) for p in pvr_cli.split_packages(s, k)]
         ts = [np.eye(4)] * len(stacks)
-    stacks, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False, dilate=dilate)
+    stacks, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(stacks, ts, pp.Image(md.astype(np.float64), mat), resolution, 0, False, dilate=dilate, resample=resample)
     pst = [pvr.Stack(s.data.astype(np.float32), s.attr, t, h) for s, t, h in zip(stacks, ts, half)]
     prob = pvr.make_pvr_problem(pst, iso_mask.data, iso_mask.attr, tattr, recon_mask.data, psize, pstride, full_slices=full_slices)
     prob.cropped_stacks = stacks
@@ -478,8 +478,33 @@ def test_split_packages_rule():
             assert np.allclose(geo.image_to_world(p.attr) @ [2, 3, k, 1], geo.image_to_world(st.attr) @ [2, 3, k * 3 + l, 1], atol=1e-9)
 
 
-@pytest.mark.parametrize("full_slices,dilate,packages", [(False, 0, None), (True, 0, None), (False, 2, None), (False, 0, (2, 1))])
-def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices, dilate, packages):
+def test_bspline_resampling_rule():
+    """--resample: irtkResampling with the cubic B-spline interpolator (irtkBSplineInterpolateImageFunction.cc): Unser's
+    recursive prefilter with mirror boundaries, 4x4x4 taps, mirrored indices, clamped to the input range -- which is what
+    scipy's spline_filter / map_coordinates(order=3, mode="mirror") compute."""
+    from scipy import ndimage
+    from fetalreconstruction_amd import pvr_cli
+    from fetalreconstruction_amd import preprocess as pp
+    st = phantom.make_stacks(2, (30, 26, 7), 1.1, 2.2, None, 1.0, 11.0, seed=4, orientations=("ax", "sag"))[0][0]
+    img = pp.Image(st.data.astype(np.float64), st.attr)
+    out = pvr_cli.resample_bspline(img, 1.0)
+    a, oa = st.attr, out.attr
+    assert (oa.nx, oa.ny, oa.nz) == (int(a.nx * a.dx), int(a.ny * a.dy), int(a.nz * a.dz)) and oa.dx == oa.dy == oa.dz == 1.0
+    m = geo.world_to_image(a) @ geo.image_to_world(oa)
+    kk, jj, ii = np.meshgrid(np.arange(oa.nz), np.arange(oa.ny), np.arange(oa.nx), indexing="ij")
+    p = [m[r, 0] * ii + m[r, 1] * jj + m[r, 2] * kk + m[r, 3] for r in range(3)]
+    ref = np.clip(ndimage.map_coordinates(img.data, [p[2], p[1], p[0]], order=3, mode="mirror"), img.data.min(), img.data.max())
+    assert np.abs(ref - out.data).max() < 2e-7 * np.abs(ref).max() + 1e-9
+    # a linear ramp is reproduced away from the mirrored borders
+    ramp = pp.Image(np.broadcast_to(np.arange(30, dtype=np.float64), (7, 26, 30)).copy(), st.attr)
+    r = pvr_cli.resample_bspline(ramp, 1.0)
+    x = (geo.world_to_image(a) @ geo.image_to_world(r.attr) @ np.array([10, 5, 5, 1.0]))[0]
+    assert abs(r.data[5, 5, 10] - x) < 1e-4
+
+
+@pytest.mark.parametrize("full_slices,dilate,packages,resample", [(False, 0, None, False), (True, 0, None, False), (False, 2, None, False),
+                                                                  (False, 0, (2, 1), False), (False, 0, None, True)])
+def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices, dilate, packages, resample):
     """bin/PVRreconstructionGPU --dumpProblem --dryRun (csrc/pvr_cli.cpp: mask, cropping, intensity matching,
     template, patch extraction in C++) against the Python twin; no GPU involved.  --useFullSlices: one patch per slice."""
     import subprocess
@@ -490,6 +515,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices, d
     r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", mpath,
                         *(["--useFullSlices"] if full_slices else ["--patchSize", "16", "16", "--patchStride", "8", "8"]),
                         *(["--dilateMask", str(dilate)] if dilate else []), *(["--packages", *map(str, packages)] if packages else []),
+                        *(["--resample"] if resample else []),
                         "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
@@ -502,7 +528,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices, d
     patches = np.frombuffer(raw, np.float32, ns * py * px, o).reshape(ns, py, px); o += 4 * ns * py * px
     i2w = np.frombuffer(raw, np.float32, ns * 16, o).reshape(ns, 16); o += 64 * ns
     mask = np.frombuffer(raw, np.float32, vx * vy * vz, o)
-    P, pmin, pmax = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0, full_slices, dilate, packages)
+    P, pmin, pmax = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0, full_slices, dilate, packages, resample)
     if packages:
         assert nst == sum(packages)
     if dilate:
@@ -527,7 +553,7 @@ def test_cpp_pvr_command_line_prepares_the_same_problem(tmp_path, full_slices, d
     assert np.array_equal(patches, P.slices)                      # same float arithmetic, same rounding
     assert np.allclose(i2w, P.slice_i2w, atol=1e-5)
     assert vmin == np.float32(pmin) and vmax == np.float32(pmax)
-    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--resample"], capture_output=True, text=True)
+    bad = subprocess.run([build.PVR_CLI, "-o", "x.nii", "-i", paths[0], "-m", mpath, "--useCPU"], capture_output=True, text=True)
     assert bad.returncode != 0 and "not supported" in bad.stderr
 
 
@@ -560,7 +586,7 @@ def test_cpp_pvr_loop_matches_the_python_loop():
 @pytest.mark.gpu
 @pytest.mark.parametrize("registration,full_slices,hierarchical,extra", [
     (False, False, False, []), (True, False, False, []), (False, True, False, []), (True, True, False, []), (False, False, True, []),
-    (True, False, True, []), (False, False, False, ["--packages", "2", "1", "--dilateMask", "1"])])
+    (True, False, True, []), (False, False, False, ["--packages", "2", "1", "--dilateMask", "1"]), (False, False, False, ["--resample"])])
 def test_cpp_pvr_command_line_matches_the_python_one(tmp_path, registration, full_slices, hierarchical, extra):
     import subprocess
     from fetalreconstruction_amd import build, nifti, pvr_cli
