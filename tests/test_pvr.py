@@ -116,6 +116,59 @@ def test_pvr_psf_kernels_parity(tiny, oracle_mod, use_spx, pvr_mode):
     assert rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("superpixel", [False, True])
+def test_pvr_kernel_variants_agree_at_full_size(superpixel):
+    """BASELINE.json configs[2] (PVR, 32x32 patches stride 16 on the 4-stack 1.0 mm case; too big for the oracle) and the
+    superpixel variant of configs[4] (--spxSize 32 --spxExtend 2) on the same stacks: the LDS-tiled gather / plane-owned
+    scatter (pvr_mode 1) against the wave-per-pixel kernels (pvr_mode 0) on the device.  Hit sets exact, sums to round-off."""
+    from fetalreconstruction_amd import engine as E, pvr
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(4, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, seed=1,
+                                                            orientations=("ax", "cor", "sag", "ax"))
+    if superpixel:
+        stacks = [pvr.Stack(st.data[20:50:3].copy(), _sub_attr(st.attr, 20, 50, 3), st.transformation, st.thickness) for st in stacks]
+    P = pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (32, 32), (2, 2) if superpixel else (16, 16), superpixel=superpixel)
+    assert P.ns > (100 if superpixel else 3000)
+    out = {}
+    for mode in (1, 0):
+        rec = E.Reconstruction(0)
+        rec.set_option("pvr", 1)
+        rec.set_option("pvr_mode", mode)
+        E.sync_gpu(rec, P, quality_factor=1.0)
+        if superpixel:
+            rec.set_spx_masks(P.spx_masks)
+        ones = np.ones(P.ns, np.float32)
+        rec.UpdateScaleVector(ones, ones)
+        rec.InitializeEMValues()
+        n = rec.GaussianReconstruction()
+        ps = rec.debug_get(E.BUF_PSF_SUMS).copy()
+        vol, vw = rec.syncCPU().copy(), rec.getVolWeights().copy()
+        rec.SimulateSlices()
+        sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
+        rec.SuperresolutionBackproject(ones)
+        out[mode] = (n, ps, vol, vw, sim, sw, si, rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
+        del rec
+    a, b = out[1], out[0]
+    assert a[0] == b[0] and np.array_equal(a[1] != 0, b[1] != 0) and np.array_equal(a[6], b[6])
+    assert np.allclose(a[1], b[1], rtol=2e-6, atol=0)
+    for k in (2, 3, 7, 8):        # float atomics in run-dependent order; overlapping patches: 4x the addends per voxel of the SVR case
+        assert rel_err(a[k], b[k]) < 5e-5, k
+    assert np.array_equal(a[8] > 0, b[8] > 0)
+    assert np.abs(a[5] - b[5]).max() < 3e-6 and rel_err(a[4], b[4]) < 5e-6
+
+
+def _sub_attr(a, z0, z1, step):
+    """attributes of stack[z0:z1:step]: fewer, thicker-spaced slices around the same geometry"""
+    import copy
+    r = copy.copy(a)
+    n = len(range(z0, z1, step))
+    first = geo.image_to_world(a) @ np.array([0, 0, z0, 1.0])
+    r.nz, r.dz = n, a.dz * step
+    r.origin = np.asarray(a.origin, np.float64).copy()
+    r.origin = r.origin + (first - geo.image_to_world(r) @ np.array([0, 0, 0, 1.0]))[:3]
+    return r
+
+
 # ---- patch extraction + the PVR loop (host side: fetalreconstruction_amd/pvr.py) ----------------
 def _small_pvr():
     from fetalreconstruction_amd import pvr
