@@ -201,6 +201,12 @@ struct Patches {
   int n = 0;
 };
 
+// A patch pixel sits exactly on a slice pixel (and, for a mask drawn on the stack's grid, on a mask voxel): its coordinate is an
+// integer in exact arithmetic, and the reference truncates what the double arithmetic makes of it (patchBasedObject.cuh:262-277),
+// so on an oblique grid 19.999999999999996 reads pixel 19 or 20 depending on the last bit.  Here a coordinate within 1e-6 of an
+// integer IS that integer; everything else is untouched.
+inline double snap(double v) { const double r = nearbyint(v); return fabs(v - r) < 1e-6 ? r : v; }
+
 // PatchBasedVolume<T>::generate2DPatches, patchBasedObject.cuh:176-342
 void generate_2d_patches(const Image &stack, double thickness, const Image &mask, int px, int py, int sx, int sy, Patches &out) {
   const svr_image_attr &a = stack.a;
@@ -226,9 +232,9 @@ void generate_2d_patches(const Image &stack, double thickness, const Image &mask
         int set_count = 0;
         for (int j = 0; j < py; ++j)
           for (int i = 0; i < px; ++i) {
-            const double xx = to_slice.m[0] * i + to_slice.m[1] * j + to_slice.m[3], yy = to_slice.m[4] * i + to_slice.m[5] * j + to_slice.m[7];
-            const double x1 = to_mask.m[0] * i + to_mask.m[1] * j + to_mask.m[3], y1 = to_mask.m[4] * i + to_mask.m[5] * j + to_mask.m[7],
-                         z1 = to_mask.m[8] * i + to_mask.m[9] * j + to_mask.m[11];
+            const double xx = snap(to_slice.m[0] * i + to_slice.m[1] * j + to_slice.m[3]), yy = snap(to_slice.m[4] * i + to_slice.m[5] * j + to_slice.m[7]);
+            const double x1 = snap(to_mask.m[0] * i + to_mask.m[1] * j + to_mask.m[3]), y1 = snap(to_mask.m[4] * i + to_mask.m[5] * j + to_mask.m[7]),
+                         z1 = snap(to_mask.m[8] * i + to_mask.m[9] * j + to_mask.m[11]);
             float v = 0;                                 // a patch starts as an all-zero image
             if (xx >= 0 && yy >= 0 && xx < a.nx && yy < a.ny && x1 >= 0 && y1 >= 0 && z1 >= 0 && x1 < mask.a.nx && y1 < mask.a.ny &&
                 z1 < mask.a.nz && mask.at((int)x1, (int)y1, (int)z1) > 0) {

@@ -32,6 +32,15 @@ class Stack:
     thickness: float
 
 
+def _snap(v):
+    """A patch pixel sits exactly on a slice pixel (and, for a mask drawn on the stack's grid, on a mask voxel): its
+    coordinate is an integer in exact arithmetic, and the reference truncates what the double arithmetic makes of it
+    (patchBasedObject.cuh:262-277), so on an oblique grid 19.999999999999996 reads pixel 19 or 20 depending on the last
+    bit.  Here a coordinate within 1e-6 of an integer IS that integer; everything else is untouched."""
+    r = np.rint(v)
+    return np.where(np.abs(v - r) < 1e-6, r, v)
+
+
 def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttributes, pbbsize, stride, with_origins=False):
     """patchBasedObject.cuh:176-342.  Returns (patches float32 [n][pY][pX], I2W [n][16], W2I [n][16],
     total_pixels).  A patch starts as an all-zero image (irtkGenericImage(sattr)); pixels whose position
@@ -62,9 +71,9 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
                 p_i2w = geo.image_to_world(pa)
                 w = pix @ p_i2w.T
                 q = w @ sl_w2i.T
-                xx, yy = q[..., 0], q[..., 1]
+                xx, yy = _snap(q[..., 0]), _snap(q[..., 1])
                 qm = w @ m_w2i.T
-                x1, y1, z1 = qm[..., 0], qm[..., 1], qm[..., 2]
+                x1, y1, z1 = _snap(qm[..., 0]), _snap(qm[..., 1]), _snap(qm[..., 2])
                 ok = (xx >= 0) & (yy >= 0) & (xx < a.nx) & (yy < a.ny)
                 ok &= (x1 >= 0) & (y1 >= 0) & (z1 >= 0) & (x1 < mx) & (y1 < my) & (z1 < mz)
                 xi, yi = np.clip(xx.astype(int), 0, a.nx - 1), np.clip(yy.astype(int), 0, a.ny - 1)   # int truncation
