@@ -139,3 +139,41 @@ def test_pvr_command_line_on_the_oblique_grid(tmp_path):
     vol, va, inside, cc = _correlation(tmp_path / "pvr.nii.gz", c, m, a)
     print("PVR: voxels in the mask", int(inside.sum()), "correlation with the phantom", cc)
     assert inside.sum() > 0.8 * m.sum() * a.dx * a.dy * a.dz and cc > 0.85
+
+
+def _moved_problem(prob):
+    """The same problem seen from the bundled mask's frame: every matrix composed with the rigid map G that takes the
+    problem's world axes to the mask's oblique axes and its origin to the mask's centre (~475 mm from the world origin)."""
+    import copy
+    m, a, _ = rm.load()
+    G = np.eye(4)
+    G[:3, 0], G[:3, 1], G[:3, 2] = a.xaxis, a.yaxis, a.zaxis
+    G[:3, 3] = rm.centre(m, a)
+    Gi = np.linalg.inv(G)
+    q = copy.copy(prob)
+    f = lambda M: np.stack([geo.to_matrix4(x) for x in M])
+    M4 = lambda A: A.reshape(-1, 4, 4).astype(np.float64)
+    q.slice_i2w = f(G @ M4(prob.slice_i2w))
+    q.slice_w2i = f(M4(prob.slice_w2i) @ Gi)
+    q.slice_t = f(G @ M4(prob.slice_t) @ Gi)
+    q.slice_tinv = f(G @ M4(prob.slice_tinv) @ Gi)
+    q.recon_i2w = geo.to_matrix4(G @ prob.recon_i2w.reshape(4, 4).astype(np.float64))
+    q.recon_w2i = geo.to_matrix4(prob.recon_w2i.reshape(4, 4).astype(np.float64) @ Gi)
+    q.name = prob.name + "@mask"
+    return q
+
+
+@pytest.mark.gpu
+def test_kernel_parity_in_the_bundled_mask_frame(tiny, oracle_mod):
+    """Index work stays bit-exact and the sums within tolerance when the float32 transform chain (W2I . T^-1 . reconI2W, RC.cu:223)
+    carries the oblique axes and the 300-400 mm offsets of real scanner coordinates: the parity tests of test_parity_gpu.py on the
+    tiny problem moved into the bundled mask's frame."""
+    import tests.test_parity_gpu as TPG
+    P = _moved_problem(tiny)
+    assert np.abs(P.slice_i2w[:, 3]).max() > 250 and np.abs(P.slice_t.reshape(-1, 4, 4)[:, :3, :3]).max() < 1.0 + 1e-6
+    TPG.test_psf_taps_are_bit_identical(P, oracle_mod, golden=False)
+    TPG.test_gaussian_reconstruction_parity(P, oracle_mod, 1, 3)
+    TPG.test_gaussian_reconstruction_parity(P, oracle_mod, 0, 1)
+    TPG.test_forward_projection_parity(P, oracle_mod, 3)
+    TPG.test_backprojection_parity(P, oracle_mod, 2)
+    TPG.test_em_steps_parity(P, oracle_mod)
