@@ -163,15 +163,41 @@ def test_registration_refuses_missing_engine():
         host.StackRegistrations(None, [np.zeros((2, 2, 2))], [geo.ImageAttributes(2, 2, 2, 1, 1, 1)], [np.eye(4)], 0)
 
 
+def _moved_attr(a, G):
+    """the same image seen from the frame G (a rigid map of the world)"""
+    import copy
+    r = copy.copy(a)
+    r.xaxis, r.yaxis, r.zaxis = G[:3, :3] @ np.asarray(a.xaxis, float), G[:3, :3] @ np.asarray(a.yaxis, float), G[:3, :3] @ np.asarray(a.zaxis, float)
+    r.origin = (G @ np.array([*np.asarray(a.origin, float), 1.0]))[:3]
+    return r
+
+
 @pytest.mark.gpu
-def test_engine_and_oracle_evaluators_give_the_same_trajectory(tiny, oracle_mod):
+@pytest.mark.parametrize("frame", ["phantom", "bundled mask"])
+def test_engine_and_oracle_evaluators_give_the_same_trajectory(tiny, oracle_mod, frame):
+    """`bundled mask`: the same case in the oblique frame of the reference's bundled mask, 475 mm from the world origin
+    (tests/real_mask.py): the decisions of the optimiser still coincide between the device and the oracle similarity."""
     from fetalreconstruction_amd import engine as E
     vol, rattr, sel, T, P = _slice_case(tiny, oracle_mod)
     rec = E.Reconstruction(0)
-    args = (tiny.slices[sel], [tiny.slice_attr[k] for k in sel], P, rattr, vol)
+    sattr = [tiny.slice_attr[k] for k in sel]
+    if frame != "phantom":
+        import real_mask as rm
+        m, a, _ = rm.load()
+        G = np.eye(4)
+        G[:3, 0], G[:3, 1], G[:3, 2] = a.xaxis, a.yaxis, a.zaxis
+        G[:3, 3] = rm.centre(m, a)
+        Gi = np.linalg.inv(G)
+        sattr = [_moved_attr(x, G) for x in sattr]
+        rattr = _moved_attr(rattr, G)
+        P = np.stack([G @ p @ Gi for p in P])
+    args = (tiny.slices[sel], sattr, P, rattr, vol)
     dev, nev_d = host.SliceToVolumeRegistration(rec, *args)
     cpu, nev_c = host.SliceToVolumeRegistration(None, *args, backend=_oracle_backend(oracle_mod))
     assert nev_d == nev_c and np.array_equal(dev, cpu)                                # exact integer moments -> identical decisions
+    assert nev_d > 100 and not np.array_equal(dev, P)
+    if frame != "phantom":
+        return
     stacks, _, _ = _stacks()
     sargs = ([s.data.astype(np.float64) for s in stacks], [s.attr for s in stacks], [np.eye(4)] * 2, 0)
     dev, nev_d = host.StackRegistrations(rec, *sargs)
