@@ -159,6 +159,13 @@ def _moved_problem(prob):
     q.slice_tinv = f(G @ M4(prob.slice_tinv) @ Gi)
     q.recon_i2w = geo.to_matrix4(G @ prob.recon_i2w.reshape(4, 4).astype(np.float64))
     q.recon_w2i = geo.to_matrix4(prob.recon_w2i.reshape(4, 4).astype(np.float64) @ Gi)
+    if prob.slice_attr is not None:
+        q.slice_attr = []
+        for sa in prob.slice_attr:
+            r = copy.copy(sa)
+            r.xaxis, r.yaxis, r.zaxis = (G[:3, :3] @ np.asarray(v, np.float64) for v in (sa.xaxis, sa.yaxis, sa.zaxis))
+            r.origin = (G @ np.array([*np.asarray(sa.origin, np.float64), 1.0]))[:3]
+            q.slice_attr.append(r)
     q.name = prob.name + "@mask"
     return q
 
@@ -177,3 +184,8 @@ def test_kernel_parity_in_the_bundled_mask_frame(tiny, oracle_mod):
     TPG.test_forward_projection_parity(P, oracle_mod, 3)
     TPG.test_backprojection_parity(P, oracle_mod, 2)
     TPG.test_em_steps_parity(P, oracle_mod)
+    # the GPU registration of --useGPUReg (a17): sampled and blurred slices bit-exact, the same decisions at every step
+    import tests.test_registration as TR
+    vol = TR._analytic_volume(tiny)
+    TR.test_cost_evaluation_parity(P, oracle_mod, vol=vol)
+    TR.test_registration_parity(P, oracle_mod, vol=vol)

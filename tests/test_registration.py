@@ -174,8 +174,8 @@ def _engine_with_volume(P, vol):
 
 
 @pytest.mark.gpu
-def test_cost_evaluation_parity(tiny, oracle_mod):
-    vol = _analytic_volume(tiny)
+def test_cost_evaluation_parity(tiny, oracle_mod, vol=None):
+    vol = _analytic_volume(tiny) if vol is None else vol
     rec = _engine_with_volume(tiny, vol)
     rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
     o = _oracle_reg(oracle_mod, tiny, rs, vol)
@@ -195,8 +195,8 @@ def test_cost_evaluation_parity(tiny, oracle_mod):
 
 
 @pytest.mark.gpu
-def test_registration_parity(tiny, oracle_mod):
-    vol = _analytic_volume(tiny)
+def test_registration_parity(tiny, oracle_mod, vol=None):
+    vol = _analytic_volume(tiny) if vol is None else vol
     rec = _engine_with_volume(tiny, vol)
     rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
     o = _oracle_reg(oracle_mod, tiny, rs, vol)
