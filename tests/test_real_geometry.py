@@ -189,3 +189,8 @@ def test_kernel_parity_in_the_bundled_mask_frame(tiny, oracle_mod):
     vol = TR._analytic_volume(tiny)
     TR.test_cost_evaluation_parity(P, oracle_mod, vol=vol)
     TR.test_registration_parity(P, oracle_mod, vol=vol)
+    # the patch-to-volume twins (a18): support 12, PVR constants, superpixel masks
+    import tests.test_pvr as TPV
+    TPV.test_pvr_taps_are_bit_identical(P, oracle_mod)
+    TPV.test_pvr_psf_kernels_parity(P, oracle_mod, False, 1)
+    TPV.test_pvr_psf_kernels_parity(P, oracle_mod, True, 1)
