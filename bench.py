@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="P4", choices=["P4", "S8", "tiny"])
+    ap.add_argument("--workload", default="P4", choices=["P4", "S8", "S8h", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="dev/test: all ranks use cuda:0 (gloo only)")
@@ -118,6 +118,9 @@ def main():
     # weak scaling: 4 stacks per rank of the named shape
     if args.workload == "P4":
         prob = phantom.make_problem(4 * world, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, name="P4")
+    elif args.workload == "S8h":      # the grid of BASELINE.json configs[4]: the S8 stacks reconstructed at 0.5 mm (406^3 voxels)
+        prob = phantom.make_problem(8 * world, (256, 256, 64), 1.0, 2.5, 2.5, 0.5, 100.0,
+                                    orientations=("ax", "cor", "sag"), name="S8h")
     elif args.workload == "S8":
         prob = phantom.make_problem(8 * world, (256, 256, 64), 1.0, 2.5, 2.5, 0.75, 100.0,
                                     orientations=("ax", "cor", "sag"), name="S8")

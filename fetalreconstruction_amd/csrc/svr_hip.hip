@@ -2181,6 +2181,12 @@ struct svr_ctx {
   int fwd_mode = 3;         // 3 = per slice: row-list gather where >= 25 % of the rows are epsilon-dead, else the
                             // plain LDS-tiled gather; 2 / 1 = one of the two for every slice; 0 = wave-per-pixel kernel
   int fwd_cap = 9216;       // box voxels: 36 KiB -> 4 workgroups of 8 waves per CU
+  // The forward tile shape that suits a problem depends on how many voxels a pixel spans: 8x4 pixels fill the box at ~1.2
+  // voxels per pixel, at 2 voxels per pixel (0.5 mm reconstructions of 1 mm pixels) their box no longer fits and every tap
+  // falls back to global loads (4x slower).  The first forward pass of a problem times the candidate shapes on the real data
+  // and keeps the fastest; the results do not depend on the shape (per-pixel sums in a fixed order).
+  bool fwd_tune_pending = true, fwd_tile_user = false;
+  int fwd_autotune = 1;
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   int pvr_mode = 1;         // PVR kernels: 1 = the LDS-tiled gather / plane-owned scatter with support 12, 0 = wave-per-pixel
   unsigned char *d_spx = nullptr;
@@ -2573,8 +2579,10 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     int w = !strcmp(name, "fwd_tile_w") ? value : ctx->fwd_tw, h = !strcmp(name, "fwd_tile_h") ? value : ctx->fwd_th;
     if (w < 1 || h < 1 || w * h > 64) return fail(ctx, SVR_E_ARG, "fwd tile must hold 1..64 pixels");
     ctx->fwd_tw = w; ctx->fwd_th = h; ctx->psf_list_valid = false;
+    ctx->fwd_tile_user = true;                           // an explicit shape switches the tuning off
     return SVR_OK;
   }
+  if (!strcmp(name, "fwd_autotune")) { ctx->fwd_autotune = value ? 1 : 0; ctx->fwd_tune_pending = value != 0; return SVR_OK; }
   if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; return SVR_OK; }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
@@ -2742,6 +2750,7 @@ int svr_set_slice_dims(svr_ctx *ctx, const float *slice_dims, float quality_fact
   NEED(ctx->ns > 0, "initStorageVolumes first");
   ctx->slice_dims.assign(slice_dims, slice_dims + 3 * (size_t)ctx->ns);
   ctx->quality_factor = quality_factor;   // only sizes the (unused) finite-support dim, RC.cu:772-784
+  ctx->fwd_tune_pending = ctx->fwd_autotune != 0;        // new slice geometry: time the forward tile shapes again
   ctx->have_dims = true;
   ctx->sc_dirty = true;
   return SVR_OK;
@@ -2964,42 +2973,79 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
-  ScopedTimer t(ctx, SVR_T_FORWARD);
-  if (a.n && ctx->pvr && ctx->pvr_mode == 1) {
-    TileArgs ta;                                         // all forward tiles (h_rows_sel is all 0 for PVR)
-    ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
-    ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
-    ta.gauss = 0;
-    hipLaunchKernelGGL((fwd_tile_kernel<false, false, PVR_N, true>), dim3(ta.ntiles), dim3(FWD_WAVES * 64),
-                       (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
-    KCHK("fwd_tile_kernel<PVR>");
-  } else if (a.n && ctx->pvr) {
-    hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                       ctx->stream, a);
-    KCHK("pvr_kernel<FWD>");
-  } else if (a.n && ctx->fwd_mode >= 1) {
-    TileArgs ta;
-    ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
-    ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
-    ta.gauss = 0;
-    const uint32_t n_plain = ctx->fwd_mode == 1 ? ctx->n_tiles_fwd : ctx->fwd_mode == 2 ? 0u : ctx->n_tiles_fwd_plain;
-    const uint32_t n_rows = ctx->n_tiles_fwd - n_plain;
-    if (n_plain) {
-      ta.ntiles = n_plain;
-      hipLaunchKernelGGL((fwd_tile_kernel<false, false>), dim3(n_plain), dim3(FWD_WAVES * 64),
+  auto launch_forward = [&]() -> int {
+    if (a.n && ctx->pvr && ctx->pvr_mode == 1) {
+      TileArgs ta;                                         // all forward tiles (h_rows_sel is all 0 for PVR)
+      ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
+      ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
+      ta.gauss = 0;
+      hipLaunchKernelGGL((fwd_tile_kernel<false, false, PVR_N, true>), dim3(ta.ntiles), dim3(FWD_WAVES * 64),
                          (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
+      KCHK("fwd_tile_kernel<PVR>");
+    } else if (a.n && ctx->pvr) {
+      hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                         ctx->stream, a);
+      KCHK("pvr_kernel<FWD>");
+    } else if (a.n && ctx->fwd_mode >= 1) {
+      TileArgs ta;
+      ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
+      ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
+      ta.gauss = 0;
+      const uint32_t n_plain = ctx->fwd_mode == 1 ? ctx->n_tiles_fwd : ctx->fwd_mode == 2 ? 0u : ctx->n_tiles_fwd_plain;
+      const uint32_t n_rows = ctx->n_tiles_fwd - n_plain;
+      if (n_plain) {
+        ta.ntiles = n_plain;
+        hipLaunchKernelGGL((fwd_tile_kernel<false, false>), dim3(n_plain), dim3(FWD_WAVES * 64),
+                           (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
+      }
+      if (n_rows) {
+        ta.tiles = ctx->d_tiles_fwd + n_plain; ta.ntiles = n_rows;
+        hipLaunchKernelGGL((fwd_tile_kernel<false, true>), dim3(n_rows), dim3(FWD_WAVES * 64),
+                           (size_t)ta.cap * sizeof(float) + (size_t)ta.tw * ta.th * 256, ctx->stream, a, ta);
+      }
+      KCHK("fwd_tile_kernel");
+    } else if (a.n) {
+      hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),
+                         (size_t)ctx->dbg_fwd_lds, ctx->stream, a);
+      KCHK("psf_kernel<FWD>");
     }
-    if (n_rows) {
-      ta.tiles = ctx->d_tiles_fwd + n_plain; ta.ntiles = n_rows;
-      hipLaunchKernelGGL((fwd_tile_kernel<false, true>), dim3(n_rows), dim3(FWD_WAVES * 64),
-                         (size_t)ta.cap * sizeof(float) + (size_t)ta.tw * ta.th * 256, ctx->stream, a, ta);
+    return SVR_OK;
+  };
+  const bool tiled = a.n && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1);
+  if (tiled && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
+    ctx->fwd_tune_pending = false;
+    static const int cand[2][2] = {{8, 4}, {4, 4}};
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float best = 3.0e38f;
+    int pick = 0;
+    for (int c = 0; c < 2; ++c) {
+      ctx->fwd_tw = cand[c][0]; ctx->fwd_th = cand[c][1]; ctx->psf_list_valid = false;
+      r = ensure_psf_list(ctx);
+      if (r) return r;
+      a.list = ctx->d_psf_list; a.n = ctx->n_psf;
+      float ms = 0.0f;
+      for (int rep = 0; rep < 2; ++rep) {                // the second run is the one that counts
+        HIPCHK(hipEventRecord(e0, ctx->stream));
+        r = launch_forward();
+        if (r) return r;
+        HIPCHK(hipEventRecord(e1, ctx->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      if (ms < best) { best = ms; pick = c; }
     }
-    KCHK("fwd_tile_kernel");
-  } else if (a.n) {
-    hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),
-                       (size_t)ctx->dbg_fwd_lds, ctx->stream, a);
-    KCHK("psf_kernel<FWD>");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ctx->fwd_tw = cand[pick][0]; ctx->fwd_th = cand[pick][1]; ctx->psf_list_valid = false;
+    r = ensure_psf_list(ctx);
+    if (r) return r;
+    a.list = ctx->d_psf_list; a.n = ctx->n_psf;
   }
+  ScopedTimer t(ctx, SVR_T_FORWARD);
+  r = launch_forward();
+  if (r) return r;
   t.stop();
   hipLaunchKernelGGL(k_slice_inside, dim3(ctx->ns), dim3(256), 0, ctx->stream, ctx->d_siminside,
                      (int)(ctx->sx * ctx->sy), ctx->d_slice_inside);
