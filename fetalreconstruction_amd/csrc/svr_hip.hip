@@ -2171,6 +2171,7 @@ struct svr_ctx {
   bool psf_list_valid = false;
   unsigned char *d_gauss_flag = nullptr;   // pixels whose sume passed in the current Gaussian pass
   uint32_t *d_tiles_tmp = nullptr;         // tile list of the Gaussian passes
+  size_t tiles_tmp_cap = 0;                // its capacity in tiles (the tile shapes can change between calls)
   int gauss_mode = 1;                      // 1 = tiled pass 1 + plane-owned scatter, 0 = psf_kernel<MODE_GAUSS>
   uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_tile_kernel
   uint32_t n_tiles_fwd = 0;
@@ -2187,6 +2188,9 @@ struct svr_ctx {
   // and keeps the fastest; the results do not depend on the shape (per-pixel sums in a fixed order).
   bool fwd_tune_pending = true, fwd_tile_user = false;
   int fwd_autotune = 1;
+  // the same for the scatter's tile (4x4 pixels; 4x2 and 2x2 once a pixel spans more than ~2.4 voxels), timed on the first
+  // back-projection after new slice geometry.  The scatter's sums are float atomics in run-dependent order with any shape.
+  bool back_tune_pending = true, tile_user = false, in_tune = false;
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   int pvr_mode = 1;         // PVR kernels: 1 = the LDS-tiled gather / plane-owned scatter with support 12, 0 = wave-per-pixel
   unsigned char *d_spx = nullptr;
@@ -2582,7 +2586,11 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     ctx->fwd_tile_user = true;                           // an explicit shape switches the tuning off
     return SVR_OK;
   }
-  if (!strcmp(name, "fwd_autotune")) { ctx->fwd_autotune = value ? 1 : 0; ctx->fwd_tune_pending = value != 0; return SVR_OK; }
+  if (!strcmp(name, "fwd_autotune")) {
+    ctx->fwd_autotune = value ? 1 : 0;
+    ctx->fwd_tune_pending = ctx->back_tune_pending = value != 0;
+    return SVR_OK;
+  }
   if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; return SVR_OK; }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
@@ -2595,6 +2603,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     int w = !strcmp(name, "tile_w") ? value : ctx->tile_w, h = !strcmp(name, "tile_h") ? value : ctx->tile_h;
     if (w < 1 || h < 1 || w * h > 64) return fail(ctx, SVR_E_ARG, "tile_w * tile_h must be in 1..64");
     ctx->tile_w = w; ctx->tile_h = h;
+    if (!ctx->in_tune) ctx->tile_user = true;            // an explicit shape switches the tuning off
     if (ctx->np) {
       free_dev(ctx->d_tiles); free_dev(ctx->d_tiles_fb);
       ctx->tiles_x = (int)((ctx->sx + w - 1) / w);
@@ -2750,7 +2759,7 @@ int svr_set_slice_dims(svr_ctx *ctx, const float *slice_dims, float quality_fact
   NEED(ctx->ns > 0, "initStorageVolumes first");
   ctx->slice_dims.assign(slice_dims, slice_dims + 3 * (size_t)ctx->ns);
   ctx->quality_factor = quality_factor;   // only sizes the (unused) finite-support dim, RC.cu:772-784
-  ctx->fwd_tune_pending = ctx->fwd_autotune != 0;        // new slice geometry: time the forward tile shapes again
+  ctx->fwd_tune_pending = ctx->back_tune_pending = ctx->fwd_autotune != 0;   // new slice geometry: time the tile shapes again
   ctx->have_dims = true;
   ctx->sc_dirty = true;
   return SVR_OK;
@@ -2860,7 +2869,11 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     HIPCHK(hipMemsetAsync(ctx->d_gauss_flag, 0, ctx->np, ctx->stream));
     const int ftx = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw), fty = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
     const size_t max_tiles = std::max((size_t)ftx * fty, (size_t)ctx->tiles_x * ctx->tiles_y) * ctx->ns;
-    if (!ctx->d_tiles_tmp) HIPCHK(hipMalloc(&ctx->d_tiles_tmp, max_tiles * sizeof(uint32_t)));
+    if (max_tiles > ctx->tiles_tmp_cap) {
+      free_dev(ctx->d_tiles_tmp);
+      HIPCHK(hipMalloc(&ctx->d_tiles_tmp, max_tiles * sizeof(uint32_t)));
+      ctx->tiles_tmp_cap = max_tiles;
+    }
     uint32_t n1 = 0, n2 = 0, nfb = 0;
     TileArgs ta;
     ta.tiles_x = ftx; ta.tiles_y = fty;
@@ -3014,13 +3027,13 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   const bool tiled = a.n && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1);
   if (tiled && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
     ctx->fwd_tune_pending = false;
-    static const int cand[2][2] = {{8, 4}, {4, 4}};
+    static const int cand[4][2] = {{8, 4}, {4, 4}, {4, 2}, {2, 2}};   // smaller boxes for finer volumes; stop at the first loss
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     float best = 3.0e38f;
     int pick = 0;
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 4; ++c) {
       ctx->fwd_tw = cand[c][0]; ctx->fwd_th = cand[c][1]; ctx->psf_list_valid = false;
       r = ensure_psf_list(ctx);
       if (r) return r;
@@ -3035,6 +3048,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
       }
       if (ms < best) { best = ms; pick = c; }
+      else break;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -3182,6 +3196,39 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   if (r) return r;
   if (slice_weight) {
     r = svr_update_slice_weights(ctx, slice_weight);   // RC.cu:2123
+    if (r) return r;
+  }
+  if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode == 2)) {
+    ctx->back_tune_pending = false;
+    ctx->in_tune = true;
+    static const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
+    const auto timing = ctx->timers;
+    ctx->timers = false;                                 // the trial runs stay out of the kernel timers
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float best = 3.0e38f;
+    int pick = 0;
+    for (int c = 0; c < 3 && !r; ++c) {
+      r = svr_set_option(ctx, "tile_w", cand[c][0]);
+      if (!r) r = svr_set_option(ctx, "tile_h", cand[c][1]);
+      float ms = 0.0f;
+      for (int rep = 0; rep < 2 && !r; ++rep) {          // the second run is the one that counts
+        HIPCHK(hipEventRecord(e0, ctx->stream));
+        r = svr_superresolution_backproject(ctx, nullptr);
+        HIPCHK(hipEventRecord(e1, ctx->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      if (ms < best) { best = ms; pick = c; }
+      else break;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!r) r = svr_set_option(ctx, "tile_w", cand[pick][0]);
+    if (!r) r = svr_set_option(ctx, "tile_h", cand[pick][1]);
+    ctx->timers = timing;
+    ctx->in_tune = false;
     if (r) return r;
   }
   r = ensure_psf_list(ctx);
