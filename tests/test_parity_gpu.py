@@ -368,3 +368,38 @@ def test_kernel_variants_agree_at_full_size():
         res[bm] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
     assert np.array_equal(res[2][1] > 0, res[0][1] > 0)
     assert rel_err(res[2][1], res[0][1]) < TOL_SUM and rel_err(res[2][0], res[0][0]) < TOL_SUM
+
+
+def test_tile_shapes_do_not_change_results(tiny, oracle_mod):
+    """The gather's and the scatter's tile shapes are timed per problem (svr_set_option "fwd_autotune"): the simulated slices
+    must not depend on the shape at all (fixed per-pixel summation order), the scatter only through the order of its float
+    atomics -- and every shape must still agree with the oracle."""
+    from fetalreconstruction_amd import engine as E
+    orc = oracle_mod.OracleReconstruction(tiny, oracle_mod.CANON)
+    ones = np.ones(tiny.ns, np.float32)
+    orc.UpdateScaleVector(ones, ones)
+    orc.InitializeEMValues()
+    orc.GaussianReconstruction()
+    orc.SimulateSlices()
+    orc.SuperresolutionBackproject(ones)
+    res = {}
+    for name, opts in (("auto", []), ("8x4/4x4", [("fwd_tile_w", 8), ("fwd_tile_h", 4), ("tile_w", 4), ("tile_h", 4)]),
+                       ("4x2/2x2", [("fwd_tile_w", 4), ("fwd_tile_h", 2), ("tile_w", 2), ("tile_h", 2)]),
+                       ("2x2/4x2", [("fwd_tile_w", 2), ("fwd_tile_h", 2), ("tile_w", 4), ("tile_h", 2)])):
+        rec = _engine(tiny)
+        for k, v in opts:
+            rec.set_option(k, v)
+        rec.UpdateScaleVector(ones, ones)
+        rec.InitializeEMValues()
+        rec.GaussianReconstruction()
+        rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon.astype(np.float32))        # the same volume under every shape
+        rec.SimulateSlices()
+        sim, sw = rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy()
+        rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+        rec.SuperresolutionBackproject(ones)
+        res[name] = (sim, sw, rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
+        assert rel_err(sim, orc.simslices) < TOL_SUM and rel_err(res[name][2], orc.addon) < TOL_SUM
+        assert np.array_equal(res[name][3] > 0, orc.cmap > 0)
+    for name in res:
+        assert np.array_equal(res[name][0], res["auto"][0]) and np.array_equal(res[name][1], res["auto"][1]), name
+        assert rel_err(res[name][2], res["auto"][2]) < TOL_SUM and rel_err(res[name][3], res["auto"][3]) < TOL_SUM, name
