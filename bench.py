@@ -142,6 +142,11 @@ def main():
     drv.SimulateSlicesGPU()
     drv.InitializeRobustStatisticsGPU()
     drv.EStepGPU()
+    # the engine times its tile shapes on the first gather / scatter after new geometry ("Tile shapes follow the
+    # problem"); the gather was tuned by SimulateSlicesGPU above, this untimed scatter keeps the other one out of the timed
+    # region whatever --warmup is (it only writes addon/cmap, which every SR iteration rebuilds, and the slice weights, which
+    # every SR iteration uploads)
+    rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
     for i in range(args.warmup):
         drv.sr_iteration(i)
 
