@@ -1,12 +1,13 @@
 """P4-scale PVR run: patch extraction (32x32 stride 16; `spx` = SLICO superpixel patches, --spxSize 32 --spxExtend 2 as in
-BASELINE.json configs[4]), one outer iteration with 3 SR iterations; kernel times.  usage: run_pvr.py [spx]"""
+BASELINE.json configs[4]), one outer iteration with 3 SR iterations; kernel times.  usage: run_pvr.py [spx|sq] [recon mm]"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
 from fetalreconstruction_amd import phantom, engine, pvr
 
 t0 = time.time()
-stacks, mask, mattr, rattr, rmask = phantom.make_stacks(4, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, seed=1,
+RES = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+stacks, mask, mattr, rattr, rmask = phantom.make_stacks(4, (100, 93, 70), 1.17647, 1.25, 2.5, RES, 50.0, seed=1,
                                                         orientations=("ax", "cor", "sag", "ax"))
 SPX = len(sys.argv) > 1 and sys.argv[1] == 'spx'
 P = pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (32, 32), (2, 2) if SPX else (16, 16), superpixel=SPX)
