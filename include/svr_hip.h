@@ -49,7 +49,10 @@ int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
 /* engine tuning knobs (no reference equivalent).  "back_mode": 2 = plane-owned LDS tiles
  * (default; no atomics inside a tile), 1 = LDS tiles with ds_add_f32, 0 = direct device-scope
  * atomics per tap.  "fwd_mode": 1 = LDS-tiled forward gather (default), 0 = wave-per-pixel kernel.
- * "tile_w"/"tile_h", "fwd_tile_w"/"fwd_tile_h", "plane_waves", "plane_cap", "fwd_cap": tile geometry. */
+ * "tile_w"/"tile_h", "fwd_tile_w"/"fwd_tile_h", "plane_waves", "plane_cap", "fwd_cap": tile geometry.
+ * "fwd_autotune" (default 1): the first forward projection / back-projection after new slice geometry times the
+ * candidate tile shapes on the data and keeps the fastest; an explicit tile_w/h or fwd_tile_w/h switches that off.
+ * "pvr": 1 selects the patch-to-volume constants and kernels; "pvr_mode", "gauss_mode": kernel variants for the tests. */
 int svr_set_option(svr_ctx *ctx, const char *name, int value);
 /* "pvr" = 1 switches the PSF kernels to the patch-to-volume constants of
  * PVRreconstructionGPU (patchBasedPSFReconstruction_gpu.cu, patchBasedSimulatePatches_gpu.cu,
