@@ -18,7 +18,7 @@ for k, st in enumerate(stacks):
     nifti.write(f"{tmp}/s{k}.nii.gz", st.data, st.attr); paths.append(f"{tmp}/s{k}.nii.gz")
 nifti.write(f"{tmp}/mask.nii.gz", rmask.astype(np.float32), rattr)
 print("stacks written in", round(time.time() - t0, 1), "s", flush=True)
-opts = ["-s", "--spxSize", "32", "--spxExtend", "2"] if mode == "superpixel" else ["--patchSize", "32", "32", "--patchStride", "16", "16"]
+opts = ["-s", "--spxSize", "32", "--spxExtend", "2"] if mode.startswith("superpixel") else ["--patchSize", "32", "32", "--patchStride", "16", "16"]
 t0 = time.time()
 if mode.startswith("svr"):          # configs[3] on one GPU: bin/SVRreconstructionGPU, `svr` without / `svrreg` with the registrations
     r = subprocess.run([build.CLI, "-o", f"{tmp}/out.nii.gz", "-i", *paths, "-m", f"{tmp}/mask.nii.gz", "--thickness", *["2.5"] * 8,
@@ -26,7 +26,8 @@ if mode.startswith("svr"):          # configs[3] on one GPU: bin/SVRreconstructi
                         *([] if mode == "svrreg" else ["--no_registration"])], capture_output=True, text=True)
 else:
     r = subprocess.run([build.PVR_CLI, "-o", f"{tmp}/out.nii.gz", "-i", *paths, "-m", f"{tmp}/mask.nii.gz", "--thickness", *["2.5"] * 8,
-                        "--resolution", str(res), "--iterations", "1", "--sr_iterations", "3", "--no_registration", *opts], capture_output=True, text=True)
+                        "--resolution", str(res), "--iterations", "1", "--sr_iterations", "3", *([] if mode.endswith("reg") else ["--no_registration"]), *opts],
+                       capture_output=True, text=True)
 print(mode, "command line rc", r.returncode, "wall", round(time.time() - t0, 1), "s")
 print(r.stderr[-1500:])
 if r.returncode == 0:
