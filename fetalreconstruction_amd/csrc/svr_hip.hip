@@ -72,7 +72,9 @@ struct SliceConst {
   float dim[3];    // slice voxel dims (dx, dy, thickness)
   float kx, ky, inv2s2;
   float dd, w;     // Gaussian recurrence along a row: (z' step)^2, and exp(-2 dd inv2s2) or -1 (see gauss_pairs)
-  float pad[11];
+  int own;         // volume axis whose planes the scatter's slots own: 1 = y, 2 = z (the one closer to the slice normal)
+  float invD;      // 1 / determinant of the in-plane map over (x, lane axis), or 0 if degenerate (unit_is_dead)
+  float pad[9];
 };
 static_assert(sizeof(SliceConst) == 256, "SliceConst layout");
 
@@ -84,25 +86,8 @@ struct VolGeom {
 };
 
 // ------------------------------------------------------------------------------------------
-// canonical PSF (bit-identical to oracle/svr_oracle.c psf_canon: IEEE fma/mul/add/div/sqrt)
+// canonical PSF (bit-identical to oracle/svr_oracle.c psf_canon: IEEE fma/mul/add/rint + integer ops)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float canon_abs_sin(float R) {
-  const float INV_PI = 0.318309886183790671538f;
-  const float PI_A = 3.1414794921875f;
-  const float PI_B = 0.00011315941810607910156f;
-  const float PI_C = 1.9841872589410058936e-09f;
-  float k = __builtin_rintf(R * INV_PI);
-  float r = __builtin_fmaf(k, -PI_A, R);
-  r = __builtin_fmaf(k, -PI_B, r);
-  r = __builtin_fmaf(k, -PI_C, r);
-  float s = r * r;
-  float u = 2.6083159809786593541503e-06f;
-  u = __builtin_fmaf(u, s, -0.0001981069071916863322258f);
-  u = __builtin_fmaf(u, s, 0.00833307858556509017944336f);
-  u = __builtin_fmaf(u, s, -0.166666597127914428710938f);
-  u = __builtin_fmaf(s, u * r, r);
-  return __builtin_fabsf(u);
-}
 __host__ __device__ __forceinline__ float canon_exp_neg(float a) {
   const float LOG2E = 1.442695040888963407359924681001892137426645954152985934135449406931f;
   const float L2U = 0.693145751953125f;
@@ -121,17 +106,6 @@ __host__ __device__ __forceinline__ float canon_exp_neg(float a) {
   float r = ldexpf(u, (int)q);
   return (a > 87.0f) ? 0.0f : r;
 }
-// calcPSF (RC.cu:112-130) on the scaled lattice coordinates
-__device__ __forceinline__ float psf_eval(float xs, float ys, float zs, float inv2s2) {
-  float q = __builtin_fmaf(ys, ys, xs * xs);
-  // plain sqrtf and '/' are IEEE correctly rounded under hipcc's default
-  // -fhip-fp32-correctly-rounded-divide-sqrt; HIP's __fsqrt_rn is NOT (it is the native v_sqrt_f32)
-  float R = 3.14159265359f * sqrtf(q);
-  float si = canon_abs_sin(R) / R;
-  float gz = canon_exp_neg((zs * zs) * inv2s2);
-  return (si * si) * gz;
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -214,6 +188,7 @@ struct RowConst {
   float Lp[9];
   float inv2s2;
   float dd, w;
+  float invD;
 };
 __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
   RowConst R;
@@ -222,6 +197,7 @@ __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
   R.inv2s2 = S.inv2s2;
   R.dd = S.dd;
   R.w = S.w;
+  R.invD = S.invD;
   return R;
 }
 
@@ -232,7 +208,7 @@ __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
 // registers): every stage is EVAL_CHUNK independent instructions, which is what lets one wave
 // issue back to back -- evaluated tap after tap the dependent chains (sqrt, division, two
 // polynomials) left the SIMDs latency-bound (forward time scaled 1:1 with occupancy).  The
-// arithmetic per tap is exactly psf_eval's, so the values stay bit-identical to the oracle.
+// arithmetic per tap is exactly the oracle's psf_canon, so the values stay bit-identical.
 // N = PSF support (16 for SVR, 12 for PVR), CENTRE = (N-1)/2; PVR selects the patch-to-volume
 // constants (sinc_pi Taylor branch, strict float epsilon; R2/include/pointSpreadFunction.cuh:45-70,
 // R2/include/reconConfig.cuh:138).
@@ -331,97 +307,85 @@ __device__ __forceinline__ f2 gauss_first_tap2(const RowConst &S, f2 rowz) {
   return g;
 }
 
-// in-plane factor sinc^2 of 2H taps given their scaled in-plane lattice coordinates (x', y'), two per lane-op
+// in-plane factor sinc^2 of 2H taps given their scaled in-plane lattice coordinates (x', y'), two per lane-op.
+// The canonical sequence (oracle: canon_rsqrt / canon_sinc) is built from fma / mul / add / rint and one integer
+// shift-subtract only -- no quarter-rate transcendental, no correctly rounded sqrt or division to emulate:
+//   q = x'^2 + y'^2;  y ~ 1/sqrt(q) (bit-trick start + 3 Newton steps);  r = q y;  f = r - rint(r) (exact);
+//   sin(pi r)/(pi r) = +-(f y) P(f^2), P = degree-4 fit of sinc on [0, 1/4];  the square removes the sign.
+// q == 0 gives NaN like sin(0)/0 in the reference (RC.cu:129); PVR takes sinc_pi's Taylor branch there instead.
+#define RSQRT_MAGIC 0x5f375a86u
 template <int H, bool PVR>
 __device__ __forceinline__ void eval_pairs_xyz(const RowConst &S, const f2 xs[H], const f2 ys[H], f2 val2[H]) {
 #define EACH for (int i = 0; i < H; ++i)
-#define PERC(dst, expr_x, expr_y) dst = (f2){(expr_x), (expr_y)}
-    f2 R[H], r[H], s[H], u[H], k[H];
+    f2 q[H], y[H], h[H], r[H], f[H], p[H];
 #pragma unroll
-    EACH {
-      R[i] = fma2(ys[i], ys[i], xs[i] * xs[i]);        // q
-    }
-    // correctly rounded sqrt: the core of LLVM's IEEE expansion (v_sqrt_f32, then pick among the two
-    // neighbours with exact fma residuals) without its denormal-input scaling and inf handling,
-    // which q = x'^2 + y'^2 in [0, ~1e3] never needs; sqrt(0) = 0 falls out of the residual tests.
-    // Bit-identical to sqrtf (tests/test_parity_gpu.py::test_psf_taps_are_bit_identical, tools/ulp_check.hip).
+    EACH q[i] = fma2(ys[i], ys[i], xs[i] * xs[i]);
 #pragma unroll
-    EACH PERC(s[i], __builtin_amdgcn_sqrtf(R[i].x), __builtin_amdgcn_sqrtf(R[i].y));
+    EACH y[i] = (f2){__uint_as_float(RSQRT_MAGIC - (__float_as_uint(q[i].x) >> 1)),
+                     __uint_as_float(RSQRT_MAGIC - (__float_as_uint(q[i].y) >> 1))};
 #pragma unroll
-    EACH {
-      const f2 sd = (f2){__int_as_float(__float_as_int(s[i].x) - 1), __int_as_float(__float_as_int(s[i].y) - 1)};
-      const f2 su = (f2){__int_as_float(__float_as_int(s[i].x) + 1), __int_as_float(__float_as_int(s[i].y) + 1)};
-      const f2 rd = fma2(-sd, s[i], R[i]), ru = fma2(-su, s[i], R[i]);
-      f2 t;
-      t.x = (0.0f >= rd.x) ? sd.x : s[i].x;
-      t.y = (0.0f >= rd.y) ? sd.y : s[i].y;
-      t.x = (0.0f < ru.x) ? su.x : t.x;
-      t.y = (0.0f < ru.y) ? su.y : t.y;
-      R[i] = bc2(3.14159265359f) * t;
-    }
-    // sin R by canon_abs_sin without the final fabs: the value is only used squared below and every
-    // operation in between is sign-symmetric, so the squares are bit-identical
+    EACH h[i] = bc2(0.5f) * q[i];
 #pragma unroll
-    EACH {
-      const f2 t = R[i] * bc2(0.318309886183790671538f);
-      PERC(k[i], __builtin_rintf(t.x), __builtin_rintf(t.y));
+    for (int it = 0; it < 3; ++it) {
+#pragma unroll
+      EACH r[i] = h[i] * y[i];
+#pragma unroll
+      EACH r[i] = fma2(-r[i], y[i], bc2(1.5f));
+#pragma unroll
+      EACH y[i] = y[i] * r[i];
     }
 #pragma unroll
-    EACH r[i] = fma2(k[i], bc2(-3.1414794921875f), R[i]);
+    EACH r[i] = q[i] * y[i];
 #pragma unroll
-    EACH r[i] = fma2(k[i], bc2(-0.00011315941810607910156f), r[i]);
+    EACH f[i] = r[i] - (f2){__builtin_rintf(r[i].x), __builtin_rintf(r[i].y)};
 #pragma unroll
-    EACH r[i] = fma2(k[i], bc2(-1.9841872589410058936e-09f), r[i]);
+    EACH h[i] = f[i] * f[i];
 #pragma unroll
-    EACH s[i] = r[i] * r[i];
+    EACH p[i] = fma2(bc2(0.024719201028347015f), h[i], bc2(-0.1904420256614685f));
 #pragma unroll
-    EACH u[i] = fma2(bc2(2.6083159809786593541503e-06f), s[i], bc2(-0.0001981069071916863322258f));
+    EACH p[i] = fma2(p[i], h[i], bc2(0.8117148876190186f));
 #pragma unroll
-    EACH u[i] = fma2(u[i], s[i], bc2(0.00833307858556509017944336f));
+    EACH p[i] = fma2(p[i], h[i], bc2(-1.6449332237243652f));
 #pragma unroll
-    EACH u[i] = fma2(u[i], s[i], bc2(-0.166666597127914428710938f));
+    EACH p[i] = fma2(p[i], h[i], bc2(1.0f));
 #pragma unroll
-    EACH u[i] = fma2(s[i], u[i] * r[i], r[i]);
-    // si = sin R / R (NaN at R == 0, RC.cu:129): correctly rounded division = LLVM's IEEE expansion
-    // (rcp, one Newton step on the reciprocal, two residual corrections of the quotient) without the
-    // v_div_scale / v_div_fmas / v_div_fixup range handling, which operands in [1e-10,1] / (0,1e2] never
-    // trigger; 0/0 still yields NaN (rcp(0) = inf, 0 * inf).  Bit-identical to '/' on these ranges.
-#pragma unroll
-    EACH PERC(k[i], __builtin_amdgcn_rcpf(R[i].x), __builtin_amdgcn_rcpf(R[i].y));
-#pragma unroll
-    EACH k[i] = fma2(fma2(-R[i], k[i], bc2(1.0f)), k[i], k[i]);
-#pragma unroll
-    EACH s[i] = u[i] * k[i];
-#pragma unroll
-    EACH s[i] = fma2(fma2(-R[i], s[i], u[i]), k[i], s[i]);
-#pragma unroll
-    EACH u[i] = fma2(fma2(-R[i], s[i], u[i]), k[i], s[i]);
+    EACH p[i] = (f[i] * y[i]) * p[i];
     if (PVR) {
-      // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70);
-      // above it sin(x)/x with x > 0, i.e. |sin x| / x up to the sign that the square removes
+      // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70)
 #pragma unroll
       EACH {
         for (int c = 0; c < 2; ++c) {
-          const float x = c ? R[i].y : R[i].x, x2 = x * x;
+          const float x = 3.14159265359f * (c ? r[i].y : r[i].x), x2 = x * x;
           float t = 1.0f;
           if (x >= 1.1920929e-07f) {
             t -= x2 / 6.0f;
             if (x >= 3.4526698300e-04f) t += (x2 * x2) / 120.0f;
           }
-          if (c) u[i].y = (x >= 1.8581361323e-02f) ? u[i].y : t;
-          else u[i].x = (x >= 1.8581361323e-02f) ? u[i].x : t;
+          if (c) p[i].y = (x >= 1.8581361323e-02f) ? p[i].y : t;
+          else p[i].x = (x >= 1.8581361323e-02f) ? p[i].x : t;
+        }
+      }
+    } else {
+      // the R = 0 tap: only a pixel that sits exactly on a voxel centre of an aligned slice has one
+      float qmin = FLT_MAX;
+#pragma unroll
+      EACH qmin = __builtin_fminf(qmin, __builtin_fminf(q[i].x, q[i].y));
+      if (__any(qmin == 0.0f)) {
+#pragma unroll
+        EACH {
+          p[i].x = (q[i].x == 0.0f) ? __builtin_nanf("") : p[i].x;
+          p[i].y = (q[i].y == 0.0f) ? __builtin_nanf("") : p[i].y;
         }
       }
     }
 #pragma unroll
-    EACH u[i] = u[i] * u[i];
-#pragma unroll
-    EACH val2[i] = u[i];                              // si * si; the caller multiplies by the Gaussian factor
+    EACH val2[i] = p[i] * p[i];                         // si * si; the caller multiplies by the Gaussian factor
 #undef EACH
-#undef PERC
 }
 
-template <int N, bool PVR>
+// ZERO: skipped taps come out as -0.0f instead of -1: adding them changes nothing, and a processed tap whose value is
+// exactly +0 (an underflowed Gaussian factor, sin(pi r) at an integer r) can still be told from a skipped one by its bits
+template <int N, bool PVR, bool ZERO = false>
 __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by, float bz, float fy,
                                            float fz, float out[N]) {
   // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage of eval_pairs_xyz
@@ -429,9 +393,12 @@ __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by
   // sqrt, rcp, rint and the selects stay per component.  Pair j holds the taps at lattice offsets -j and 1 + j
   // (the order of the Gaussian recurrence, gauss_pairs); the in-plane part is evaluated in two chunks of N/4 pairs.
   constexpr int NP = N / 2;
-  constexpr int H = NP / 2;
+#ifndef SVR_EVAL_H16
+#define SVR_EVAL_H16 4
+#endif
+  constexpr int H = N == 16 ? SVR_EVAL_H16 : NP / 2;   // pairs evaluated side by side (instruction-level parallelism against registers)
   constexpr int CENTRE = (N - 1) / 2;
-  static_assert(NP % 2 == 0 && CENTRE == NP - 1, "pairs (-j, 1 + j) around the central taps");
+  static_assert(NP % H == 0 && CENTRE == NP - 1, "pairs (-j, 1 + j) around the central taps");
   const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
   const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
   const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
@@ -461,7 +428,7 @@ __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by
     const float v = val[x];
     // SVR: |d| < 0.00001 (double) == |d| <= 0.00001f; PVR: |d| < 0.00001f.  NaN compares false -> processed
     const bool skip = PVR ? (__builtin_fabsf(old - v) < PSF_EPS_F) : (__builtin_fabsf(old - v) <= PSF_EPS_F);
-    out[x] = skip ? -1.0f : v;
+    out[x] = skip ? (ZERO ? -0.0f : -1.0f) : v;
     old = skip ? old : v;
   }
 }
@@ -1010,6 +977,587 @@ __global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a,
 }
 
 // ------------------------------------------------------------------------------------------
+// Slot-owned back-projection with dead-unit shortcut: the production scatter of round 2
+// ------------------------------------------------------------------------------------------
+// Ownership as in back_plane_kernel -- a 16-lane slot owns one absolute plane of the tile's box, its lanes are the 16
+// rows of the (pixel, plane offset) unit it is working on, so the accumulation is a plain LDS read-add-write -- plus:
+//  * OWNED AXIS PER SLICE.  The planes are y- or z-planes of the volume, whichever axis is closer to the slice normal
+//    (SliceConst::own); the lanes run over the other one.  Rows are along x either way (the epsilon-skip chain runs
+//    along x in the reference, RC.cu:233-239), and every row is evaluated with its true (y, z) offsets, so the values
+//    do not depend on the choice.  Below, "z" / "y" name the owned / lane axis.
+//  * DEAD UNITS.  A row whose 16 taps are provably below the epsilon of the skip test has only its first tap processed
+//    by the reference (oldPSF starts at FLT_MAX).  With the planes across the slice normal, a unit more than ~4.8
+//    sigma_z away from the slice is dead as a whole (unit_is_dead: 5 of 16 for 2.5 mm slices on a 1 mm grid) and costs
+//    one tap per lane instead of 16, two units at a time in the two halves of the packed evaluator.
+//  * PER-PLANE PITCH.  A plane that only receives dead units needs the columns of the first taps only: x pitch
+//    (spread of the centre voxels + 1) instead of (spread + 16).
+//  * TWO PHASES, planes dealt round-robin: live planes to the slots, then dead planes to the slots, so every wavefront
+//    of the workgroup has the same share of both (with planes in z order the outer wavefronts only held dead planes and
+//    one SIMD of four idled) and a box with more planes than slots needs no other kernel.
+//  * {addon, cmap} interleaved as float2: one ds_read_b64 / ds_write_b64 and one v_pk_fma_f32 per tap.
+// Tiles whose box does not fit go to the fallback list (the caller re-runs them with the large-box instance, then with
+// back_tiled_kernel).
+#define SLOT_MAXP 48      // planes of a box the plane tables are sized for
+struct RowWalk {       // i = y * P + x walked in steps of `stride` without a division per element
+  int x, y, tx, ty, P;
+  __device__ __forceinline__ void init(int i0, int stride, int P_) {
+    P = P_;
+    y = i0 / P; x = i0 - y * P;
+    ty = stride / P; tx = stride - ty * P;
+  }
+  __device__ __forceinline__ void step() {
+    x += tx; y += ty;
+    if (x >= P) { x -= P; ++y; }
+  }
+};
+
+// Is every tap of the unit (all x, all offsets of the lane axis, fixed offset `fo` of volume axis F in {1, 2}) provably
+// below the epsilon of the skip test, and free of the R = 0 tap?  |z'| is bounded from below over the unit's lattice
+// square (z' is affine), exp(-a_min) with sinc^2 <= 1 bounds the value; the R = 0 tap (NaN, RC.cu:129 -- it would be
+// processed, and so would every tap after it in its row) is excluded by evaluating q at the lattice points around the
+// real solution of x' = y' = 0.  A degenerate in-plane map (rows along the slice normal) never takes the shortcut.
+__device__ __forceinline__ bool unit_is_dead(const RowConst &S, float bx, float by, float bz, int F, float fo) {
+  const bool f1 = F == 1;                               // (selects, not indexing: an index would put RowConst into scratch)
+  const float LxF = f1 ? S.Lp[1] : S.Lp[2], LxG = f1 ? S.Lp[2] : S.Lp[1];
+  const float LyF = f1 ? S.Lp[4] : S.Lp[5], LyG = f1 ? S.Lp[5] : S.Lp[4];
+  const float LzF = f1 ? S.Lp[7] : S.Lp[8], LzG = f1 ? S.Lp[8] : S.Lp[7];
+  const float lo_ = (float)(-PSF_CENTRE), hi_ = (float)(PSF_SUPPORT - 1 - PSF_CENTRE);
+  const float c = __builtin_fmaf(LzF, fo, bz);
+  const float zlo = c + fminf(S.Lp[6] * lo_, S.Lp[6] * hi_) + fminf(LzG * lo_, LzG * hi_);
+  const float zhi = c + fmaxf(S.Lp[6] * lo_, S.Lp[6] * hi_) + fmaxf(LzG * lo_, LzG * hi_);
+  if (!(zlo > 0.0f || zhi < 0.0f)) return false;
+  const float zmin = fminf(fabsf(zlo), fabsf(zhi)) * 0.999f - 1e-4f;      // covers the roundings of the fma chains of z'
+  if (!(zmin > 0.0f && (zmin * zmin) * S.inv2s2 > SVR_DEAD_THR)) return false;
+  if (S.invD == 0.0f) return false;                     // degenerate in-plane map: no shortcut
+  const float cx = __builtin_fmaf(LxF, fo, bx), cy = __builtin_fmaf(LyF, fo, by);
+  const float ox = (cy * LxG - cx * LyG) * S.invD, og = (cx * S.Lp[3] - cy * S.Lp[0]) * S.invD;
+  if (!(fabsf(ox) < 64.0f && fabsf(og) < 64.0f)) return true;             // the zero of (x', y') is far outside the lattice
+  const float fx0 = floorf(ox), fg0 = floorf(og);
+  bool zero = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float fx = fx0 + (float)(j & 1), fg = fg0 + (float)(j >> 1);
+    const float fy = f1 ? fo : fg, fz = f1 ? fg : fo;
+    const float xs = __builtin_fmaf(S.Lp[0], fx, __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx)));
+    const float ys = __builtin_fmaf(S.Lp[3], fx, __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by)));
+    zero = zero || __builtin_fmaf(ys, ys, xs * xs) == 0.0f;
+  }
+  return !zero;
+}
+
+#ifndef SVR_WPE_SLOT
+#define SVR_WPE_SLOT 4
+#endif
+template <int WAVES, int NS = PSF_SUPPORT, bool PVR = false>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SVR_WPE_SLOT, SVR_WPE_SLOT))) void back_slot_kernel(PsfArgs a, TileArgs ta, uint32_t *fallback_tiles,
+                                                                uint32_t *fallback_count) {
+  constexpr int SLOTS = WAVES * 4;
+  constexpr int T = WAVES * 64;
+  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  f2 *box = reinterpret_cast<f2 *>(tile);               // {addon, cmap} per box voxel, [plane][y][x], pitch per plane
+  __shared__ int sh_lo[3], sh_hi[3];
+  __shared__ PixelRec sh_px[64];                        // cy = centre on the lane axis, cz = centre on the owned axis
+  __shared__ uint32_t sh_dead[64];                      // bit z: unit (pixel, z) is dead
+  __shared__ unsigned char sh_list[SLOT_MAXP][64];      // per plane: live units from the front, dead units from the back
+  __shared__ unsigned char sh_nl[SLOT_MAXP], sh_nd[SLOT_MAXP];
+  __shared__ unsigned char sh_order[SLOT_MAXP];         // planes with live units (ascending), then planes with dead units only
+  __shared__ int sh_off[SLOT_MAXP];
+  __shared__ int sh_npix, sh_nlive, sh_nused, sh_vox;
+  const int TILE_W = ta.tw, TILE_H = ta.th;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const VolGeom &vg = a.vg;
+  const uint32_t t = ta.tiles[blockIdx.x];
+  const int per_slice = ta.tiles_x * ta.tiles_y;
+  const uint32_t sl = t / per_slice;
+  const int r = t - sl * per_slice;
+  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
+  const SliceConst &S = a.sc[sl];
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+  const bool swap = S.own == 1;                         // slots own y-planes, lanes run over z
+  const int F = swap ? 1 : 2;                           // the owned volume axis
+  const int vgy = swap ? vg.vz : vg.vy, vgz = swap ? vg.vy : vg.vz;
+  const uint32_t sty = swap ? (uint32_t)(vg.vx * vg.vy) : (uint32_t)vg.vx;   // volume strides of the lane / owned axis
+  const uint32_t stz = swap ? (uint32_t)vg.vx : (uint32_t)(vg.vx * vg.vy);
+
+  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
+  if (threadIdx.x < 64) sh_dead[threadIdx.x] = 0u;
+  __syncthreads();
+  if (wave == 0) {
+    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+    bool act = false;
+    uint32_t idx = 0;
+    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
+      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
+      act = pixel_active(a.slices, a.psf_sums, a.flag, idx);
+    }
+    unsigned long long b = __ballot(act);
+    if (act) {
+      PixelState P = pixel_setup(S, vg, px, py);
+      const float sume = a.psf_sums[idx];
+      const float ss = a.simslices[idx];
+      float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * a.scales[sl] : a.slices[idx] * a.scales[sl];
+      float f1;
+      if (ta.gauss) {                                          // RC.cu:278-282
+        f1 = 1.0f / sume;
+      } else {
+        e = (ss > 0.0f) ? (e - ss) : 0.0f;                     // RC.cu:439-447
+        f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
+      }
+      PixelRec R;
+      R.cx = P.cxi; R.cy = swap ? P.czi : P.cyi; R.cz = swap ? P.cyi : P.czi;
+      R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
+      sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
+      atomicMin(&sh_lo[0], R.cx); atomicMax(&sh_hi[0], R.cx);
+      atomicMin(&sh_lo[1], R.cy); atomicMax(&sh_hi[1], R.cy);
+      atomicMin(&sh_lo[2], R.cz); atomicMax(&sh_hi[2], R.cz);
+    }
+    if (lane == 0) sh_npix = __popcll(b);
+  }
+  __syncthreads();
+  const int npix = sh_npix;
+  // unsaturated box coordinates as in back_plane_kernel: negative positions alias to 0 at flush time (RC.cu:508),
+  // positions beyond the high end are dropped (RC.cu:509)
+  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
+  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vgy - 1);
+  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vgz - 1);
+  const int Dy = hiy - loy + 1, Dz = hiz - loz + 1;
+  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
+  const int PL = (hix - lox + 1) | 1;                   // pitch of a plane that takes whole rows (odd: 16 y rows -> distinct banks)
+  const int PD = (sh_hi[0] - sh_lo[0] + 1) | 1;         // pitch of a plane that only takes first taps
+  const RowConst RC = load_row_const(S);
+  if (!PVR && ta.dbg != 4) {
+    for (int i = threadIdx.x; i < npix * NS; i += T) {  // which (pixel, z) units are dead
+      const int k = i / NS, z = i % NS;
+      const PixelRec R = sh_px[k];
+      if (unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(z - NC))) atomicOr(&sh_dead[k], 1u << z);
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < min(Dz, SLOT_MAXP)) {
+    // units landing on absolute plane loz + threadIdx.x, in pixel order
+    const int P = loz + (int)threadIdx.x;
+    int nl = 0, nd = 0;
+    for (int k = 0; k < npix; ++k) {
+      const int z = P - sh_px[k].cz + NC;
+      if (z >= 0 && z < NS) {
+        if ((sh_dead[k] >> z) & 1u) sh_list[threadIdx.x][63 - nd++] = (unsigned char)k;
+        else sh_list[threadIdx.x][nl++] = (unsigned char)k;
+      }
+    }
+    sh_nl[threadIdx.x] = (unsigned char)nl;
+    sh_nd[threadIdx.x] = (unsigned char)nd;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int off = 0, n = 0;
+    const int np = min(Dz, SLOT_MAXP);
+    for (int p = 0; p < np; ++p)
+      if (sh_nl[p]) { sh_order[n++] = (unsigned char)p; sh_off[p] = off; off += PL * Dy; }
+    sh_nlive = n;
+    for (int p = 0; p < np; ++p)
+      if (!sh_nl[p] && sh_nd[p]) { sh_order[n++] = (unsigned char)p; sh_off[p] = off; off += PD * Dy; }
+    sh_nused = n;
+    sh_vox = off;
+  }
+  __syncthreads();
+  const int vox = sh_vox, nlive = sh_nlive, nused = sh_nused;
+  if (Dz > SLOT_MAXP || vox > ta.cap) {
+    if (threadIdx.x == 0) fallback_tiles[atomicAdd(fallback_count, 1u)] = t;
+    return;
+  }
+  for (int i = threadIdx.x; i < vox; i += T) box[i] = (f2){0.0f, 0.0f};
+  __syncthreads();
+
+  const int slot = threadIdx.x >> 4;
+  const int y = lane & 15;
+  const float fyl = (float)(y - NC);                    // lane-axis offset of this lane's rows
+  // phase 1: planes with live units, dealt round-robin to the slots
+  for (int j = slot; j < nlive; j += SLOTS) {
+    const int p = sh_order[j];
+    const int P = loz + p;                              // <= hiz: plane in bounds
+    const int nl = sh_nl[p], nd = sh_nd[p];
+    f2 *pb = box + sh_off[p] - lox;
+    for (int i = 0; i < nl; ++i) {
+      const PixelRec R = sh_px[sh_list[p][i]];
+      const float fzu = (float)(P - R.cz);              // owned-axis offset of the unit
+      const int ay = R.cy + y - NC;                     // may be negative: aliases to 0 at flush
+      const bool rowok = y < NS && ay < vgy;
+      const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
+      // all NS x positions are inside the box by construction, so the read-add-write is unconditional (skipped taps add 0)
+#ifdef SVR_SLOT_PREFETCH
+      f2 acc[NS];
+      if (rowok) {
+#pragma unroll
+        for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
+      }
+#endif
+      float out[NS];
+      eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fzu : fyl, swap ? fyl : fzu, out);
+      if (rowok) {
+        const f2 ff = (f2){R.f0, R.f1};
+#ifndef SVR_SLOT_PREFETCH
+        f2 acc[NS];
+#pragma unroll
+        for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
+#endif
+#pragma unroll
+        for (int x = 0; x < NS; ++x) pb[rb + x] = fma2(bc2(out[x]), ff, acc[x]);
+      }
+    }
+    if (!PVR) {
+      // dead units sharing a live plane: the first tap of every row, two units per pass
+      for (int i = 0; i < nd; i += 2) {
+        const bool two = i + 1 < nd;
+        const PixelRec Ra = sh_px[sh_list[p][63 - i]];
+        const PixelRec Rb = sh_px[sh_list[p][two ? 63 - i - 1 : 63 - i]];
+        const float fua = (float)(P - Ra.cz), fub = (float)(P - Rb.cz);
+        const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
+        const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
+                             __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
+        const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
+                             __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
+        const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
+                             __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
+        f2 xs[1], ys[1], t0[1];
+        xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
+        ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
+        eval_pairs_xyz<1, false>(RC, xs, ys, t0);
+        const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);        // always processed: |FLT_MAX - v| is not <= eps
+        const int aya = Ra.cy + y - NC, ayb = Rb.cy + y - NC;
+        if (aya < vgy) {
+          f2 *q = pb + (aya - loy) * PL + Ra.cx - NC;
+          *q = fma2(bc2(v.x), (f2){Ra.f0, Ra.f1}, *q);
+        }
+        if (two && ayb < vgy) {
+          f2 *q = pb + (ayb - loy) * PL + Rb.cx - NC;
+          *q = fma2(bc2(v.y), (f2){Rb.f0, Rb.f1}, *q);
+        }
+      }
+    }
+  }
+  if (!PVR) {
+    // phase 2: planes with dead units only (narrow pitch), dealt round-robin to the slots
+    for (int j = nlive + slot; j < nused; j += SLOTS) {
+      const int p = sh_order[j];
+      const int P = loz + p;
+      const int nd = sh_nd[p];
+      f2 *pb = box + sh_off[p] - lox;
+      for (int i = 0; i < nd; i += 2) {
+        const bool two = i + 1 < nd;
+        const PixelRec Ra = sh_px[sh_list[p][63 - i]];
+        const PixelRec Rb = sh_px[sh_list[p][two ? 63 - i - 1 : 63 - i]];
+        const float fua = (float)(P - Ra.cz), fub = (float)(P - Rb.cz);
+        const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
+        const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
+                             __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
+        const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
+                             __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
+        const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
+                             __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
+        f2 xs[1], ys[1], t0[1];
+        xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
+        ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
+        eval_pairs_xyz<1, false>(RC, xs, ys, t0);
+        const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);
+        const int aya = Ra.cy + y - NC, ayb = Rb.cy + y - NC;
+        if (aya < vgy) {
+          f2 *q = pb + (aya - loy) * PD + Ra.cx - NC;
+          *q = fma2(bc2(v.x), (f2){Ra.f0, Ra.f1}, *q);
+        }
+        if (two && ayb < vgy) {
+          f2 *q = pb + (ayb - loy) * PD + Rb.cx - NC;
+          *q = fma2(bc2(v.y), (f2){Rb.f0, Rb.f1}, *q);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (ta.dbg == 3) return;                              // timing experiments: no flush
+  // flush: one pair of device-scope atomics per touched, in-mask voxel of the box; the float->uint saturation of the
+  // reference (negative -> 0, RC.cu:508) is applied here, which sums exactly the taps that alias
+  RowWalk wl, wd;
+  wl.init(threadIdx.x, T, PL);
+  wd.init(threadIdx.x, T, PD);
+  for (int j = 0; j < nused; ++j) {
+    const int p = sh_order[j];
+    const bool live = j < nlive;
+    RowWalk w;                                           // (field by field: selecting the struct goes through scratch)
+    w.x = live ? wl.x : wd.x; w.y = live ? wl.y : wd.y; w.tx = live ? wl.tx : wd.tx; w.ty = live ? wl.ty : wd.ty; w.P = live ? wl.P : wd.P;
+    const int n = w.P * Dy;
+    const f2 *pl = box + sh_off[p];
+    for (int i = threadIdx.x; i < n; i += T, w.step()) {
+      const f2 v = pl[i];
+      if (v.x != 0.0f || v.y != 0.0f) {
+        const int gx = w.x + lox;
+        if (gx < vg.vx) {                                // beyond the high end: out of bounds
+          const uint32_t vi = sat0(gx) + sat0(w.y + loy) * sty + sat0(p + loz) * stz;
+          if (a.mask[vi] != 0.0f) {
+            unsafeAtomicAdd(a.addon + vi, v.x);
+            unsafeAtomicAdd(a.cmap + vi, v.y);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-owned back-projection: one wavefront = one workgroup = four planes of a tile's box
+// ------------------------------------------------------------------------------------------
+// The slots of back_slot_kernel never talk to each other: a slot owns a plane, a wavefront four of them.  So the
+// workgroup is cut down to ONE wavefront that owns four planes of the tile's box (positions 4 g .. 4 g + 3 of the plane
+// order: planes with live units first, then planes with dead units only), and the grid is tiles x groups.  What that
+// buys: no workgroup barrier, no wavefront waiting for the slowest of its workgroup, ~16 KiB of LDS per wavefront
+// instead of 50-75 KiB per workgroup (9 independent wavefronts per CU, placed on whichever SIMD is free), and the
+// cheap wavefronts (dead planes) leave early instead of holding a workgroup's LDS.  The price is the tile set-up
+// (pixel records, dead-unit test: ~4 % of a wavefront's work) repeated by every group.  `groups` is a launch
+// parameter: planes beyond 4 * groups are dealt round-robin to the same wavefronts.
+template <int NS = PSF_SUPPORT, bool PVR = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SVR_WPE_SLOT, SVR_WPE_SLOT)))
+void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_tiles, uint32_t *fallback_count) {
+  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  f2 *box = reinterpret_cast<f2 *>(tile);               // {addon, cmap} per box voxel of this wavefront's four planes
+  __shared__ PixelRec sh_px[64];                        // cy = centre on the lane axis, cz = centre on the owned axis
+  __shared__ unsigned char sh_list[4][64];              // per slot: live units from the front, dead units from the back
+  const int TILE_W = ta.tw, TILE_H = ta.th;
+  const int lane = threadIdx.x;
+  const VolGeom &vg = a.vg;
+  const uint32_t bt = blockIdx.x / (uint32_t)groups;
+  const int grp = (int)(blockIdx.x - bt * (uint32_t)groups);
+  const uint32_t t = ta.tiles[bt];
+  const int per_slice = ta.tiles_x * ta.tiles_y;
+  const uint32_t sl = t / per_slice;
+  const int r = t - sl * per_slice;
+  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
+  const SliceConst &S = a.sc[sl];
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+  const bool swap = S.own == 1;                         // slots own y-planes, lanes run over z
+  const int F = swap ? 1 : 2;
+  const int vgy = swap ? vg.vz : vg.vy, vgz = swap ? vg.vy : vg.vz;
+  const uint32_t sty = swap ? (uint32_t)(vg.vx * vg.vy) : (uint32_t)vg.vx;
+  const uint32_t stz = swap ? (uint32_t)vg.vx : (uint32_t)(vg.vx * vg.vy);
+
+  // lane = pixel of the tile
+  int cx = 0, cy = 0, cz = 0;
+  bool act = false;
+  {
+    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+    uint32_t idx = 0;
+    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
+      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
+      act = pixel_active(a.slices, a.psf_sums, a.flag, idx);
+    }
+    const unsigned long long b = __ballot(act);
+    if (act) {
+      PixelState P = pixel_setup(S, vg, px, py);
+      const float sume = a.psf_sums[idx];
+      const float ss = a.simslices[idx];
+      float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * a.scales[sl] : a.slices[idx] * a.scales[sl];
+      float f1;
+      if (ta.gauss) {                                          // RC.cu:278-282
+        f1 = 1.0f / sume;
+      } else {
+        e = (ss > 0.0f) ? (e - ss) : 0.0f;                     // RC.cu:439-447
+        f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
+      }
+      PixelRec R;
+      cx = P.cxi; cy = swap ? P.czi : P.cyi; cz = swap ? P.cyi : P.czi;
+      R.cx = cx; R.cy = cy; R.cz = cz;
+      R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
+      sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
+    }
+  }
+  const int npix = __popcll(__ballot(act));
+  if (npix == 0) return;
+  int lo[3], hi[3];
+  {
+    int mn[3] = {act ? cx : INT_MAX, act ? cy : INT_MAX, act ? cz : INT_MAX};
+    int mx[3] = {act ? cx : INT_MIN, act ? cy : INT_MIN, act ? cz : INT_MIN};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        mn[k] = min(mn[k], __shfl_xor(mn[k], o, 64));
+        mx[k] = max(mx[k], __shfl_xor(mx[k], o, 64));
+      }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = __builtin_amdgcn_readfirstlane(mn[k]); hi[k] = __builtin_amdgcn_readfirstlane(mx[k]); }
+  }
+  __syncthreads();
+  // unsaturated box coordinates: negative positions alias to 0 at flush time (RC.cu:508), positions beyond the high
+  // end are dropped (RC.cu:509)
+  const int lox = lo[0] - NC, hix = hi[0] + NH;
+  const int loy = lo[1] - NC, hiy = min(hi[1] + NH, vgy - 1);
+  const int loz = lo[2] - NC, hiz = min(hi[2] + NH, vgz - 1);
+  const int Dy = hiy - loy + 1, Dz = hiz - loz + 1;
+  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
+  const int PL = (hix - lox + 1) | 1;                   // x pitch (odd: 16 y rows -> distinct banks)
+  const int PP = PL * Dy;                               // voxels of one plane
+  if (Dz > 64 || 4 * PP > ta.cap) {                     // more planes than lanes / planes larger than this launch's box:
+    if (lane == 0 && grp == 0) fallback_tiles[atomicAdd(fallback_count, 1u)] = t;   // the workgroup kernels take the tile
+    return;
+  }
+  const RowConst RC = load_row_const(S);
+  // dead (pixel, z) units: lane k < npix ends up with the NS bits of its pixel
+  uint32_t deadbits = 0u;
+  if (!PVR && ta.dbg != 4) {
+    static_assert(PVR || NS == 16, "four pixels of 16 units per pass of the dead-unit test");
+    for (int m = 0; m * 4 < npix; ++m) {
+      const int k = m * 4 + (lane >> 4), z = lane & 15;
+      const PixelRec R = sh_px[min(k, npix - 1)];
+      const bool d = k < npix && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(z - NC));
+      const unsigned long long bd = __ballot(d);
+      if ((lane >> 2) == m) deadbits = (uint32_t)(bd >> (16 * (lane & 3))) & 0xFFFFu;
+    }
+  }
+  // planes: lane p < Dz counts the live and the dead units landing on absolute plane loz + p
+  int nl = 0, nd = 0;
+  for (int k = 0; k < npix; ++k) {
+    const int czk = sh_px[k].cz;
+    const uint32_t dk = (uint32_t)__shfl((int)deadbits, k, 64);
+    const int z = loz + lane - czk + NC;
+    if (lane < Dz && z >= 0 && z < NS) {
+      if ((dk >> z) & 1u) ++nd; else ++nl;
+    }
+  }
+  const unsigned long long mlive = __ballot(nl > 0), mdead = __ballot(nl == 0 && nd > 0);
+  const int nlive = __popcll(mlive), nused = nlive + __popcll(mdead);
+  if (grp * 4 >= nused) return;                         // nothing left for this group
+  // position of plane `lane` in the order [planes with live units, ascending | planes with dead units only, ascending]
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int pos = nl > 0 ? __popcll(mlive & below) : (nd > 0 ? nlive + __popcll(mdead & below) : -1);
+  const int mycz = lane < npix ? sh_px[lane].cz : 0;
+  const int slot = lane >> 4;
+  const int y = lane & 15;
+  const float fyl = (float)(y - NC);
+  for (int j0 = grp * 4; j0 < nused; j0 += groups * 4) {
+    // this pass: order positions j0 .. j0 + 3, one per slot
+    int pl[4];
+    int p = -1, mynl = 0, mynd = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned long long m = __ballot(pos == j0 + q);
+      pl[q] = m ? (int)__builtin_ctzll(m) : -1;
+      const int src = m ? pl[q] : 0;
+      const int a_nl = __shfl(nl, src, 64), a_nd = __shfl(nd, src, 64);
+      if (slot == q) { p = pl[q]; mynl = m ? a_nl : 0; mynd = m ? a_nd : 0; }
+      // unit lists of the plane: lane k < npix files its pixel
+      bool isl = false, isd = false;
+      if (m && lane < npix) {
+        const int z = loz + pl[q] - mycz + NC;
+        if (z >= 0 && z < NS) {
+          isd = (deadbits >> z) & 1u;
+          isl = !isd;
+        }
+      }
+      const unsigned long long bl = __ballot(isl), bdd = __ballot(isd);
+      if (isl) sh_list[q][__popcll(bl & below)] = (unsigned char)lane;
+      if (isd) sh_list[q][63 - __popcll(bdd & below)] = (unsigned char)lane;
+    }
+    for (int i = lane; i < 4 * PP; i += 64) box[i] = (f2){0.0f, 0.0f};
+    __syncthreads();
+
+    if (p >= 0) {
+      const int P = loz + p;                            // <= hiz: plane in bounds
+      f2 *pb = box + slot * PP - lox;
+      for (int i = 0; i < mynl; ++i) {
+        const PixelRec R = sh_px[sh_list[slot][i]];
+        const float fzu = (float)(P - R.cz);            // owned-axis offset of the unit
+        const int ay = R.cy + y - NC;                   // may be negative: aliases to 0 at flush
+        const bool rowok = y < NS && ay < vgy;
+        const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
+        float out[NS];
+        eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fzu : fyl, swap ? fyl : fzu, out);
+        if (rowok) {
+          // all NS x positions are inside the box by construction: unconditional read-add-write (skipped taps add 0)
+          const f2 ff = (f2){R.f0, R.f1};
+          f2 acc[NS];
+#pragma unroll
+          for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
+#pragma unroll
+          for (int x = 0; x < NS; ++x) pb[rb + x] = fma2(bc2(out[x]), ff, acc[x]);
+        }
+      }
+      if (!PVR) {
+        // dead units: the first tap of every row, two units per pass in the two halves of the packed evaluator
+        for (int i = 0; i < mynd; i += 2) {
+          const bool two = i + 1 < mynd;
+          const PixelRec Ra = sh_px[sh_list[slot][63 - i]];
+          const PixelRec Rb = sh_px[sh_list[slot][two ? 63 - i - 1 : 63 - i]];
+          const float fua = (float)(P - Ra.cz), fub = (float)(P - Rb.cz);
+          const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
+          const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
+                               __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
+          const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
+                               __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
+          const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
+                               __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
+          f2 xs[1], ys[1], t0[1];
+          xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
+          ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
+          eval_pairs_xyz<1, false>(RC, xs, ys, t0);
+          const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);      // always processed: |FLT_MAX - v| is not <= eps
+          const int aya = Ra.cy + y - NC, ayb = Rb.cy + y - NC;
+          if (aya < vgy) {
+            f2 *q = pb + (aya - loy) * PL + Ra.cx - NC;
+            *q = fma2(bc2(v.x), (f2){Ra.f0, Ra.f1}, *q);
+          }
+          if (two && ayb < vgy) {
+            f2 *q = pb + (ayb - loy) * PL + Rb.cx - NC;
+            *q = fma2(bc2(v.y), (f2){Rb.f0, Rb.f1}, *q);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (ta.dbg != 3) {
+      // flush: one pair of device-scope atomics per touched, in-mask voxel; the float->uint saturation of the reference
+      // (negative -> 0, RC.cu:508) is applied here, which sums exactly the taps that alias
+      RowWalk w0;
+      w0.init(lane, 64, PL);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (pl[q] < 0) continue;
+        RowWalk w = w0;
+        const f2 *pq = box + q * PP;
+        const uint32_t zoff = sat0(pl[q] + loz) * stz;
+        // FLUSH_U elements per lane at a time: their mask words are in flight together (one dependent global load per
+        // element made the flush latency-bound)
+        constexpr int FLUSH_U = 8;
+        for (int i0 = lane; i0 < PP; i0 += 64 * FLUSH_U) {
+          uint32_t vi[FLUSH_U];
+          float mk[FLUSH_U];
+#pragma unroll
+          for (int u = 0; u < FLUSH_U; ++u) {
+            const int i = i0 + 64 * u;
+            bool ok = i < PP;
+            if (ok) {
+              const f2 v = pq[i];
+              ok = (v.x != 0.0f || v.y != 0.0f) && w.x + lox < vg.vx;   // beyond the high end: out of bounds
+            }
+            vi[u] = sat0(w.x + lox) + sat0(w.y + loy) * sty + zoff;
+            mk[u] = ok ? a.mask[vi[u]] : 0.0f;
+            w.step();
+          }
+#pragma unroll
+          for (int u = 0; u < FLUSH_U; ++u) {
+            if (mk[u] != 0.0f) {
+              const f2 v = pq[i0 + 64 * u];
+              unsafeAtomicAdd(a.addon + vi[u], v.x);
+              unsafeAtomicAdd(a.cmap + vi[u], v.y);
+            }
+          }
+        }
+      }
+    }
+    if (j0 + groups * 4 < nused) __syncthreads();        // another pass reuses the box and the lists
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LDS-tiled forward projection (simulateSlicesKernel3D_tex RC.cu:298-404): the production gather
 // ------------------------------------------------------------------------------------------
 // Same tile box as the scatter (unsaturated coordinates, saturation applied when the box is
@@ -1350,6 +1898,278 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
       const float sim = wave_sum(f0), w = wave_sum(f1);
       if (lane == 0 && w > 0.0f) {                         // RC.cu:398-403
         a.simslices[idx] = sim / w;
+        a.simweights[idx] = w;
+        a.siminside[idx] = inside ? 1 : 0;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Unit-based forward projection: the production gather of round 2 (simulateSlicesKernel3D_tex RC.cu:298-404)
+// ------------------------------------------------------------------------------------------
+// Work item = a (pixel, plane offset) UNIT of 16 rows, as in the scatter: a 16-lane slot evaluates one unit, a wavefront
+// four at a time, the eight wavefronts of the workgroup take the tile's units off one list -- live units first, then the
+// dead ones (unit_is_dead: every row provably below the epsilon of the skip test, only the first tap of each row is
+// processed).  The planes run across the slice normal (SliceConst::own) so that dead rows come as whole units.
+//   * The tile's box of the volume sits in LDS as float2 {V * m, m} (m = 1 inside the mask and the volume, else 0):
+//     a tap is one ds_read_b64 and one v_pk_fma_f32 into {sum psf V, sum psf} -- no sentinel test, no branch per tap;
+//     skipped taps add 0.  siminside (any processed tap on a mask voxel, RC.cu:391-394) is kept exactly with one
+//     compare per tap whose result stays in scalar registers.
+//   * Every unit leaves {sum psf V, sum psf, hit} in LDS; the pixel's 16 partial sums are added in a fixed order, so
+//     the result does not depend on the tile shape, on which wavefront took which unit, or on the run.
+//   * GAUSS1 turns the walk into pass 1 of gaussianReconstructionKernel3D_tex (RC.cu:228-258): the box holds
+//     {in bounds, in mask}, the sums become {sume (double, like the oracle), -}, plus the `sume > 0.5` gate, v_PSF_sums
+//     and the sliceVoxel_count flag.
+// Registers: no accumulator array, the row's 16 values and the packed evaluator: ~90 VGPRs, no scratch.
+#define FWDU_WAVES 8
+#define FWDU_MAXPIX 32     // pixels of a tile (8 x 4 at most)
+template <bool GAUSS1>
+__global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, TileArgs ta) {
+  constexpr int NS = PSF_SUPPORT, NC = PSF_CENTRE, NH = NS - 1 - NC;
+  constexpr int T = FWDU_WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  f2 *box = reinterpret_cast<f2 *>(tile);               // {V m, m} (GAUSS1: {in bounds, in mask}) per box voxel [z][y][x]
+  __shared__ int sh_lo[3], sh_hi[3];
+  __shared__ PixelRec sh_px[FWDU_MAXPIX];
+  __shared__ uint32_t sh_idx[FWDU_MAXPIX];
+  __shared__ uint32_t sh_dead[FWDU_MAXPIX];                      // bit u: unit (pixel, u) is dead
+  __shared__ unsigned short sh_units[FWDU_MAXPIX * NS];          // (pixel << 4 | u): live units from the front, dead units from the back
+  __shared__ f2 sh_part[FWDU_MAXPIX * NS];                       // per unit {sum psf V, sum psf}
+  __shared__ double sh_partd[GAUSS1 ? FWDU_MAXPIX * NS : 1];     // GAUSS1: per unit sume in double
+  __shared__ uint32_t sh_hit[FWDU_MAXPIX];                       // bit u: unit (pixel, u) had a processed tap on a mask voxel
+  __shared__ int sh_npix, sh_nlive, sh_ndead;
+  const int TILE_W = ta.tw, TILE_H = ta.th;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const VolGeom &vg = a.vg;
+  const uint32_t t = ta.tiles[blockIdx.x];
+  const int per_slice = ta.tiles_x * ta.tiles_y;
+  const uint32_t sl = t / per_slice;
+  const int r = t - sl * per_slice;
+  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
+  const SliceConst &S = a.sc[sl];
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+  const bool swap = S.own == 1;                         // units are y-planes, lanes run over z
+  const int F = swap ? 1 : 2;
+
+  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
+  if (threadIdx.x < FWDU_MAXPIX) { sh_dead[threadIdx.x] = 0u; sh_hit[threadIdx.x] = 0u; }
+  if (threadIdx.x == 0) { sh_nlive = 0; sh_ndead = 0; }
+  __syncthreads();
+  if (wave == 0) {
+    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+    bool act = false;
+    uint32_t idx = 0;
+    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
+      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
+      act = pixel_active(a.slices, GAUSS1 ? (const float *)nullptr : a.psf_sums, a.flag, idx);
+    }
+    unsigned long long b = __ballot(act);
+    if (act) {
+      PixelState P = pixel_setup(S, vg, px, py);
+      PixelRec R;
+      R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz;
+      R.f1 = GAUSS1 ? 0.0f : 1.0f / a.psf_sums[idx]; R.f0 = 0.0f;
+      const int k = __popcll(b & ((1ull << lane) - 1ull));
+      sh_px[k] = R;
+      sh_idx[k] = idx;
+      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
+      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
+      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
+    }
+    if (lane == 0) sh_npix = __popcll(b);
+  }
+  __syncthreads();
+  const int npix = sh_npix;
+  // the box in unsaturated coordinates (x, y, z of the volume); the float->uint saturation of the reference (negative ->
+  // 0, RC.cu:382) is applied when the box is filled
+  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
+  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vg.vy - 1);
+  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vg.vz - 1);
+  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
+  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // nothing in bounds: no pixel gets a weight > 0
+  const int Px = Dx | 1;
+  const int Pxy = Px * Dy + ((Px * Dy) & 1 ? 0 : 1);    // odd pitches: the 16 rows of a unit spread over the banks either way
+  const bool in_lds = (long long)Pxy * Dz <= (long long)ta.cap;
+  const uint32_t sxy = (uint32_t)(vg.vx * vg.vy);
+  const RowConst RC = load_row_const(S);
+  if (in_lds) {
+    const int vox = Pxy * Dz;
+    BoxWalk bw;
+    bw.init(threadIdx.x, T, Px, Pxy);
+    for (int i = threadIdx.x; i < vox; i += T, bw.step()) {
+      const int gx = bw.x + lox;
+      f2 v = (f2){0.0f, 0.0f};
+      if (bw.y < Dy && bw.x < Dx && gx < vg.vx) {
+        const uint32_t vi = sat0(gx) + sat0(bw.y + loy) * (uint32_t)vg.vx + sat0(bw.z + loz) * sxy;
+        const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
+        v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
+      }
+      box[i] = v;
+    }
+  }
+  // units: dead test, then the list (live from the front, dead from the back); units whose rows all lie beyond the
+  // volume's high end take no part
+  for (int i = threadIdx.x; i < npix * NS; i += T) {
+    const int k = i / NS, u = i % NS;
+    const PixelRec R = sh_px[k];
+    const int cu = swap ? R.cy : R.cz;
+    const bool inb = cu + u - NC < (swap ? vg.vy : vg.vz);      // negatives alias to 0: "in bounds"
+    if (inb) {
+      const bool dead = ta.dbg != 4 && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(u - NC));
+      if (dead) {
+        atomicOr(&sh_dead[k], 1u << u);
+        sh_units[FWDU_MAXPIX * NS - 1 - atomicAdd(&sh_ndead, 1)] = (unsigned short)(k << 4 | u);
+      } else {
+        sh_units[atomicAdd(&sh_nlive, 1)] = (unsigned short)(k << 4 | u);
+      }
+    } else {
+      sh_part[k * NS + u] = (f2){0.0f, 0.0f};
+      if (GAUSS1) sh_partd[k * NS + u] = 0.0;
+    }
+  }
+  __syncthreads();
+  const int nlive = sh_nlive, ndead = sh_ndead;
+  const int slot = lane >> 4, y = lane & 15;
+  const float fyl = (float)(y - NC);
+  // ---- live units: all 16 taps of every row --------------------------------------------------------------
+  for (int j0 = wave * 4; j0 < nlive; j0 += FWDU_WAVES * 4) {
+    const int j = j0 + slot;
+    const bool valid = j < nlive;
+    const int ku = sh_units[valid ? j : j0];
+    const int k = ku >> 4, u = ku & 15;
+    const PixelRec R = sh_px[k];
+    const float fu = (float)(u - NC);
+    const int ay = R.cy + (swap ? u : y) - NC, az = R.cz + (swap ? y : u) - NC;
+    const bool rowok = valid && ay < vg.vy && az < vg.vz;      // negatives alias to 0: always "in bounds"
+    float out[NS];
+    eval_row_t<NS, false, true>(RC, R.bx, R.by, R.bz, swap ? fu : fyl, swap ? fyl : fu, out);
+    f2 acc = (f2){0.0f, 0.0f};
+    double accd = 0.0;
+    bool hit = false;
+    if (rowok) {
+      if (in_lds) {
+        const f2 *pb = box + (ay - loy) * Px + (az - loz) * Pxy + R.cx - NC - lox;
+#pragma unroll
+        for (int x = 0; x < NS; ++x) {
+          const f2 v = pb[x];
+          if (GAUSS1) accd += (double)(out[x] * v.x);          // RC.cu:241-245 (in bounds, no mask test)
+          else acc = fma2(bc2(out[x]), v, acc);
+          hit = hit || (v.y != 0.0f && __float_as_uint(out[x]) != 0x80000000u);   // processed (not the skip marker) on a mask voxel
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < NS; ++x) {
+          const int gx = R.cx + x - NC;
+          f2 v = (f2){0.0f, 0.0f};
+          if (gx < vg.vx) {
+            const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
+            const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
+            v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
+          }
+          if (GAUSS1) accd += (double)(out[x] * v.x);
+          else acc = fma2(bc2(out[x]), v, acc);
+          hit = hit || (v.y != 0.0f && __float_as_uint(out[x]) != 0x80000000u);   // processed (not the skip marker) on a mask voxel
+        }
+      }
+    }
+    // reduce over the 16 lanes of the slot
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      if (GAUSS1) accd += __shfl_xor(accd, o, 64);
+      else { acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); }
+    }
+    const bool anyhit = ((uint32_t)(__ballot(hit) >> (16 * slot)) & 0xFFFFu) != 0u;
+    if (valid && y == 0) {
+      if (GAUSS1) sh_partd[k * NS + u] = accd; else sh_part[k * NS + u] = acc;
+      if (anyhit) atomicOr(&sh_hit[k], 1u << u);
+    }
+  }
+  // ---- dead units: the first tap of every row, two units per pass ------------------------------------------
+  for (int j0 = wave * 8; j0 < ndead; j0 += FWDU_WAVES * 8) {
+    const int ja = j0 + 2 * slot, jb = ja + 1;
+    const bool va = ja < ndead, vb = jb < ndead;
+    const int kua = sh_units[FWDU_MAXPIX * NS - 1 - (va ? ja : j0)], kub = sh_units[FWDU_MAXPIX * NS - 1 - (vb ? jb : j0)];
+    const PixelRec Ra = sh_px[kua >> 4], Rb = sh_px[kub >> 4];
+    const float fua = (float)((kua & 15) - NC), fub = (float)((kub & 15) - NC);
+    const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
+    const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
+                         __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
+    const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
+                         __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
+    const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
+                         __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
+    f2 xs[1], ys[1], t0[1];
+    xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
+    ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
+    eval_pairs_xyz<1, false>(RC, xs, ys, t0);
+    const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);        // always processed: |FLT_MAX - v| is not <= eps
+    f2 wa = (f2){0.0f, 0.0f}, wb = (f2){0.0f, 0.0f};
+    {
+      const int aya = Ra.cy + (int)fya, aza = Ra.cz + (int)fza, ayb = Rb.cy + (int)fyb, azb = Rb.cz + (int)fzb;
+      if (in_lds) {
+        if (va && aya < vg.vy && aza < vg.vz) wa = box[(aya - loy) * Px + (aza - loz) * Pxy + Ra.cx - NC - lox];
+        if (vb && ayb < vg.vy && azb < vg.vz) wb = box[(ayb - loy) * Px + (azb - loz) * Pxy + Rb.cx - NC - lox];
+      } else {
+        if (va && aya < vg.vy && aza < vg.vz && Ra.cx - NC < vg.vx) {
+          const uint32_t vi = sat0(Ra.cx - NC) + sat0(aya) * (uint32_t)vg.vx + sat0(aza) * sxy;
+          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
+          wa = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
+        }
+        if (vb && ayb < vg.vy && azb < vg.vz && Rb.cx - NC < vg.vx) {
+          const uint32_t vi = sat0(Rb.cx - NC) + sat0(ayb) * (uint32_t)vg.vx + sat0(azb) * sxy;
+          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
+          wb = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
+        }
+      }
+    }
+    f2 acca = bc2(v.x) * wa, accb = bc2(v.y) * wb;
+    double da = (double)acca.x, db = (double)accb.x;
+    const bool hita = wa.y != 0.0f, hitb = wb.y != 0.0f;        // the processed first tap lands on a mask voxel
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      if (GAUSS1) { da += __shfl_xor(da, o, 64); db += __shfl_xor(db, o, 64); }
+      else {
+        acca.x += __shfl_xor(acca.x, o, 64); acca.y += __shfl_xor(acca.y, o, 64);
+        accb.x += __shfl_xor(accb.x, o, 64); accb.y += __shfl_xor(accb.y, o, 64);
+      }
+    }
+    const bool anya = ((uint32_t)(__ballot(hita) >> (16 * slot)) & 0xFFFFu) != 0u;
+    const bool anyb = ((uint32_t)(__ballot(hitb) >> (16 * slot)) & 0xFFFFu) != 0u;
+    if (y == 0) {
+      if (va) {
+        if (GAUSS1) sh_partd[(kua >> 4) * NS + (kua & 15)] = da; else sh_part[(kua >> 4) * NS + (kua & 15)] = acca;
+        if (anya) atomicOr(&sh_hit[kua >> 4], 1u << (kua & 15));
+      }
+      if (vb) {
+        if (GAUSS1) sh_partd[(kub >> 4) * NS + (kub & 15)] = db; else sh_part[(kub >> 4) * NS + (kub & 15)] = accb;
+        if (anyb) atomicOr(&sh_hit[kub >> 4], 1u << (kub & 15));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the pixel's partial sums in unit order ------------------------------------------------------------------
+  if ((int)threadIdx.x < npix) {
+    const int k = threadIdx.x;
+    const uint32_t idx = sh_idx[k];
+    const bool inside = sh_hit[k] != 0u;
+    if (GAUSS1) {
+      double sd = 0.0;
+      for (int u = 0; u < NS; ++u) sd += sh_partd[k * NS + u];
+      const float sume = (float)sd;
+      const bool pass = sume > 0.5f;                          // also drops NaN (RC.cu:251-258)
+      a.flag_out[idx] = pass ? 1 : 0;
+      if (pass) {
+        a.psf_sums[idx] = sume;
+        if (inside) a.voxcount[idx] = 1;                      // RC.cu:291-294
+      }
+    } else {
+      f2 sm = (f2){0.0f, 0.0f};
+      for (int u = 0; u < NS; ++u) sm = sm + sh_part[k * NS + u];
+      const float w = sm.y * sh_px[k].f1;                     // sum psf / sume
+      if (w > 0.0f) {                                         // RC.cu:398-403
+        a.simslices[idx] = sm.x / sm.y;
         a.simweights[idx] = w;
         a.siminside[idx] = inside ? 1 : 0;
       }
@@ -2179,7 +2999,8 @@ struct svr_ctx {
   std::vector<unsigned char> h_rows_sel;   // per slice: 1 = enough provably dead rows for the row-list gather
   unsigned char *d_rows_sel = nullptr;
   int fwd_tw = 8, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
-  int fwd_mode = 3;         // 3 = per slice: row-list gather where >= 25 % of the rows are epsilon-dead, else the
+  int fwd_unit_cap = 9000;  // box voxels (float2) of fwd_unit_kernel: 70 KiB + 8 KiB static -> 2 workgroups of 8 waves per CU
+  int fwd_mode = 4;         // 4 = unit-based gather (fwd_unit_kernel); 3 = per slice: row-list gather where >= 25 % of the rows are epsilon-dead, else the
                             // plain LDS-tiled gather; 2 / 1 = one of the two for every slice; 0 = wave-per-pixel kernel
   int fwd_cap = 9216;       // box voxels: 36 KiB -> 4 workgroups of 8 waves per CU
   // The forward tile shape that suits a problem depends on how many voxels a pixel spans: 8x4 pixels fill the box at ~1.2
@@ -2194,12 +3015,18 @@ struct svr_ctx {
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   int pvr_mode = 1;         // PVR kernels: 1 = the LDS-tiled gather / plane-owned scatter with support 12, 0 = wave-per-pixel
   unsigned char *d_spx = nullptr;
-  int back_mode = 2;        // 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
+  int back_mode = 3;        // 3 = slot-owned LDS tiles with the dead-unit shortcut (back_slot_kernel), 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
                             // 0 = direct device-scope atomics per tap
   int tile_cap = 0;         // voxels of LDS accumulator per workgroup
   int dbg_back = 0;
   int dbg_fwd_lds = 0;      // dev experiment: extra dynamic LDS on the forward launch (limits occupancy)
   uint32_t n_tiles_fb = 0;
+  uint32_t n_tiles_fb8 = 0;   // tiles of the 5-wave scatter instance that were re-run with 8 waves (more planes than 20 slots / box too large)
+  uint32_t n_tiles_plain = 0; // d_tiles = [tiles of slices without epsilon-dead planes | tiles of slices with them]
+  uint32_t *d_tiles_fb2 = nullptr;
+  int slot_waves_a = 4, slot_cap_a = 5900;   // back_slot_kernel on slices with dead planes: 46 KiB + 5.8 KiB static -> 3 workgroups per CU
+  int slot_waves_b = 5, slot_cap_b = 9200;   // ... on the others (whole-box planes): 2 per CU
+  int wave_groups = 3, wave_cap = 2116;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (4 x 23 x 23: 16.5 KiB)
 
   // reductions
   double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
@@ -2299,6 +3126,7 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_gauss_flag);
   free_dev(c->d_tiles_tmp);
   free_dev(c->d_tiles_fb);
+  free_dev(c->d_tiles_fb2);
   free_dev(c->d_partial); free_dev(c->d_per_slice);
 }
 
@@ -2333,6 +3161,12 @@ int prepare_slice_consts(svr_ctx *ctx) {
     S.dd = S.Lp[6] * S.Lp[6];
     const double tmax = 2.0 * sqrt((double)GAUSS_AMAX * (double)S.inv2s2) * fabs((double)S.Lp[6]) + (double)S.dd * (double)S.inv2s2;
     S.w = tmax <= 80.0 ? canon_exp_neg((2.0f * S.dd) * S.inv2s2) : -1.0f;
+    S.own = fabsf(S.Lp[7]) > fabsf(S.Lp[8]) ? 1 : 2;
+    {
+      const int G = S.own == 1 ? 2 : 1;                    // the lane axis
+      const float D = S.Lp[0] * S.Lp[3 + G] - S.Lp[G] * S.Lp[3];
+      S.invD = fabsf(D) > 1e-4f ? 1.0f / D : 0.0f;
+    }
   }
   // which gather suits a slice: share of provably epsilon-dead rows of a pixel that sits on a voxel centre
   ctx->h_rows_sel.assign(ctx->ns, 0);
@@ -2342,6 +3176,7 @@ int prepare_slice_consts(svr_ctx *ctx) {
     R.inv2s2 = h[s].inv2s2;
     R.dd = h[s].dd;
     R.w = h[s].w;
+    R.invD = h[s].invD;
     int dead = 0;
     for (int z = 0; z < PSF_SUPPORT; ++z)
       for (int y = 0; y < PSF_SUPPORT; ++y)
@@ -2370,15 +3205,19 @@ int build_list(svr_ctx *ctx, bool with_psf) {
     ctx->n_psf = n;
     ctx->psf_list_valid = true;
     // tiles of TILE_W x TILE_H pixels that hold at least one pixel of the list
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t total = (uint32_t)ctx->tiles_x * ctx->tiles_y * ctx->ns;
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
-                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
-                       ctx->d_tiles, ctx->d_counter);
-    KCHK("k_build_tiles");
-    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_tiles = n;
+    uint32_t segb[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) {                          // segment 0: slices without epsilon-dead planes, 1: with
+      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
+                         (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
+                         ctx->d_tiles + segb[0], ctx->d_counter, (const unsigned char *)ctx->d_rows_sel, w);
+      KCHK("k_build_tiles");
+      HIPCHK(hipMemcpyAsync(&segb[w], ctx->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->n_tiles_plain = segb[0];
+    ctx->n_tiles = n = segb[0] + segb[1];
     // forward tiles
     free_dev(ctx->d_tiles_fwd);
     ctx->fwd_tiles_x = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw);
@@ -2484,6 +3323,86 @@ int ensure_psf_list(svr_ctx *ctx) {
   return SVR_OK;
 }
 
+// The slot-owned scatter over the tile list [seg0 | seg1] (seg1 = tiles of slices with epsilon-dead planes): seg1 with
+// `slot_waves_a` waves and a box of `slot_cap_a` voxels (4 waves, 3 workgroups per CU), seg0 with `slot_waves_b` /
+// `slot_cap_b`; tiles whose box did not fit are re-run with 8 waves and the largest box the CU can hold, the rest
+// (none on the workloads of BASELINE.json) with back_tiled_kernel's LDS atomics.
+int launch_slot(svr_ctx *ctx, int waves, const PsfArgs &a, const TileArgs &ta, uint32_t *fb, uint32_t *cnt) {
+  const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
+#define LAUNCH_SLOT(NW) \
+  hipLaunchKernelGGL(back_slot_kernel<NW>, dim3(ta.ntiles), dim3(NW * 64), lds, ctx->stream, a, ta, fb, cnt)
+  switch (waves) {
+    case 4: LAUNCH_SLOT(4); break;
+    case 5: LAUNCH_SLOT(5); break;
+    case 6: LAUNCH_SLOT(6); break;
+    default: LAUNCH_SLOT(8); break;
+  }
+#undef LAUNCH_SLOT
+  KCHK("back_slot_kernel");
+  return SVR_OK;
+}
+// back_mode 4: every tile with back_wave_kernel (one wavefront per four planes, `wave_groups` wavefronts per tile); tiles whose
+// planes do not fit `wave_cap` go to the 8-wave workgroup kernel with the largest box, the rest to back_tiled_kernel.
+int launch_wave_scatter(svr_ctx *ctx, const PsfArgs &a, TileArgs ta, const uint32_t *tiles, uint32_t n) {
+  uint32_t *cnt = ctx->d_counter;
+  HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), ctx->stream));
+  if (!n) return SVR_OK;
+  int r;
+  ta.tiles = tiles; ta.ntiles = n; ta.cap = std::min(ctx->wave_cap, ctx->tile_cap);
+  hipLaunchKernelGGL(back_wave_kernel<>, dim3(n * (uint32_t)ctx->wave_groups), dim3(64), (size_t)ta.cap * 2 * sizeof(float),
+                     ctx->stream, a, ta, ctx->wave_groups, ctx->d_tiles_fb, cnt);
+  KCHK("back_wave_kernel");
+  uint32_t nfb[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_tiles_fb8 = nfb[0];
+  if (nfb[0]) {
+    ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb[0]; ta.cap = ctx->tile_cap;
+    if ((r = launch_slot(ctx, 8, a, ta, ctx->d_tiles_fb2, cnt + 1))) return r;
+    HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->n_tiles_fb = nfb[1];
+  if (nfb[1]) {
+    ta.tiles = ctx->d_tiles_fb2; ta.ntiles = nfb[1]; ta.cap = ctx->tile_cap;
+    hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb[1]), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
+                       ctx->stream, a, ta);
+    KCHK("back_tiled_kernel(fallback)");
+  }
+  return SVR_OK;
+}
+int launch_slot_scatter(svr_ctx *ctx, const PsfArgs &a, TileArgs ta, const uint32_t *tiles, uint32_t n0, uint32_t n1) {
+  uint32_t *cnt = ctx->d_counter;                         // [0]: did not fit the first box, [1]: did not fit the largest
+  HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), ctx->stream));
+  int r;
+  if (n1) {
+    ta.tiles = tiles + n0; ta.ntiles = n1; ta.cap = std::min(ctx->slot_cap_a, ctx->tile_cap);
+    if ((r = launch_slot(ctx, ctx->slot_waves_a, a, ta, ctx->d_tiles_fb, cnt))) return r;
+  }
+  if (n0) {
+    ta.tiles = tiles; ta.ntiles = n0; ta.cap = std::min(ctx->slot_cap_b, ctx->tile_cap);
+    if ((r = launch_slot(ctx, ctx->slot_waves_b, a, ta, ctx->d_tiles_fb, cnt))) return r;
+  }
+  uint32_t nfb[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_tiles_fb8 = nfb[0];
+  if (nfb[0]) {
+    ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb[0]; ta.cap = ctx->tile_cap;
+    if ((r = launch_slot(ctx, 8, a, ta, ctx->d_tiles_fb2, cnt + 1))) return r;
+    HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->n_tiles_fb = nfb[1];
+  if (nfb[1]) {
+    ta.tiles = ctx->d_tiles_fb2; ta.ntiles = nfb[1]; ta.cap = ctx->tile_cap;
+    hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb[1]), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
+                       ctx->stream, a, ta);
+    KCHK("back_tiled_kernel(fallback)");
+  }
+  return SVR_OK;
+}
+
 // reduce partial[ns*chunks][K] -> per_slice[ns][K] (+ optionally -> d_out[K])
 int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
   hipLaunchKernelGGL(k_reduce_chunks, dim3(nblk((size_t)ctx->ns * K)), dim3(256), 0, ctx->stream,
@@ -2553,6 +3472,20 @@ int svr_create(int device, svr_ctx **out) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<8, PVR_N, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_unit_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_unit_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_wave_kernel<>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<5>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<6>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<5>),
@@ -2564,7 +3497,7 @@ int svr_create(int device, svr_ctx **out) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) {
       (void)hipGetLastError();
-      dyn = 65536 - 1024;
+      dyn = 65536 - 1024 - 8192;   // the default 64 KiB minus the kernels' static LDS
     }
     ctx->tile_cap = dyn / (2 * (int)sizeof(float));
   }
@@ -2578,6 +3511,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }
   if (!strcmp(name, "pvr_mode")) { ctx->pvr_mode = value; return SVR_OK; }
   if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
+  if (!strcmp(name, "fwd_unit_cap")) { ctx->fwd_unit_cap = std::max(2048, value); return SVR_OK; }
   if (!strcmp(name, "fwd_cap")) { ctx->fwd_cap = std::max(4096, value); return SVR_OK; }
   if (!strcmp(name, "fwd_tile_w") || !strcmp(name, "fwd_tile_h")) {
     int w = !strcmp(name, "fwd_tile_w") ? value : ctx->fwd_tw, h = !strcmp(name, "fwd_tile_h") ? value : ctx->fwd_th;
@@ -2596,6 +3530,12 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
   if (!strcmp(name, "plane_waves")) { ctx->plane_waves = std::max(4, std::min(value, PLANE_MAX_WAVES)); return SVR_OK; }
   if (!strcmp(name, "plane_cap")) { ctx->plane_cap = std::max(4096, value); return SVR_OK; }
+  if (!strcmp(name, "slot_cap_a")) { ctx->slot_cap_a = std::max(2048, value); return SVR_OK; }
+  if (!strcmp(name, "slot_cap_b")) { ctx->slot_cap_b = std::max(2048, value); return SVR_OK; }
+  if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
+  if (!strcmp(name, "wave_cap")) { ctx->wave_cap = std::max(1024, value); return SVR_OK; }
+  if (!strcmp(name, "slot_waves_a")) { ctx->slot_waves_a = value; return SVR_OK; }
+  if (!strcmp(name, "slot_waves_b")) { ctx->slot_waves_b = value; return SVR_OK; }
   if (!strcmp(name, "pvr_reg_levels")) { ctx->pvr_reg_levels = std::min(3, std::max(1, value)); return SVR_OK; }
   if (!strcmp(name, "pvr_reg_steps")) { ctx->pvr_reg_steps = std::max(1, value); return SVR_OK; }
   if (!strcmp(name, "pvr_reg_iterations")) { ctx->pvr_reg_iterations = std::max(1, value); return SVR_OK; }
@@ -2605,12 +3545,13 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     ctx->tile_w = w; ctx->tile_h = h;
     if (!ctx->in_tune) ctx->tile_user = true;            // an explicit shape switches the tuning off
     if (ctx->np) {
-      free_dev(ctx->d_tiles); free_dev(ctx->d_tiles_fb);
+      free_dev(ctx->d_tiles); free_dev(ctx->d_tiles_fb); free_dev(ctx->d_tiles_fb2);
       ctx->tiles_x = (int)((ctx->sx + w - 1) / w);
       ctx->tiles_y = (int)((ctx->sy + h - 1) / h);
       const size_t nb = (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t);
       HIPCHK(hipMalloc(&ctx->d_tiles, nb));
       HIPCHK(hipMalloc(&ctx->d_tiles_fb, nb));
+      HIPCHK(hipMalloc(&ctx->d_tiles_fb2, nb));
       ctx->psf_list_valid = false;
     }
     return SVR_OK;
@@ -2723,6 +3664,7 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   ctx->tiles_y = (int)((ctx->sy + ctx->tile_h - 1) / ctx->tile_h);
   HIPCHK(hipMalloc(&ctx->d_tiles, (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&ctx->d_tiles_fb, (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&ctx->d_tiles_fb2, (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&ctx->d_scales, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_slice_weights, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_scales_host_copy, ctx->ns * sizeof(float)));
@@ -2880,6 +3822,19 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th; ta.gauss = 1;
     a.flag = nullptr; a.flag_out = ctx->d_gauss_flag;
     // pass 1 per slice group: plain gather walk / row-list walk (fwd_mode 3 splits by h_rows_sel)
+    if (!pvr_tiled && ctx->fwd_mode == 4) {                // the unit-based walk over every tile
+      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
+                         (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
+                         fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter);
+      KCHK("k_build_tiles(gauss1)");
+      HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1; ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
+      if (n1) hipLaunchKernelGGL(fwd_unit_kernel<true>, dim3(n1), dim3(FWDU_WAVES * 64), (size_t)ta.cap * 2 * sizeof(float),
+                                 ctx->stream, a, ta);
+      KCHK("fwd_unit_kernel<GAUSS1>");
+    } else
     for (int w = 0; w < 2; ++w) {
       const bool rows = w == 1;
       const int fm = pvr_tiled ? 1 : ctx->fwd_mode;       // row lists exist for the SVR support only
@@ -2905,18 +3860,28 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
                            ctx->stream, a, ta);
       KCHK("fwd_tile_kernel<GAUSS1>");
     }
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns, 4)), dim3(256), 0, ctx->stream,
-                       ctx->d_slices, (const float *)nullptr, ctx->d_gauss_flag, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns,
-                       ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter);
-    KCHK("k_build_tiles(gauss2)");
-    HIPCHK(hipMemcpyAsync(&n2, ctx->d_counter, sizeof(n2), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t seg2[2] = {0, 0};
+    const bool slots = !pvr_tiled && ctx->back_mode >= 3;
+    for (int w = 0; w < (slots ? 2 : 1); ++w) {             // slot-owned scatter: [slices without dead planes | with]
+      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns, 4)), dim3(256), 0, ctx->stream,
+                         ctx->d_slices, (const float *)nullptr, ctx->d_gauss_flag, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns,
+                         ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp + seg2[0], ctx->d_counter,
+                         slots ? (const unsigned char *)ctx->d_rows_sel : (const unsigned char *)nullptr, w);
+      KCHK("k_build_tiles(gauss2)");
+      HIPCHK(hipMemcpyAsync(&seg2[w], ctx->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    n2 = seg2[0] + seg2[1];
     a.flag = ctx->d_gauss_flag;
     a.addon = ctx->recon(); a.cmap = ctx->volw();       // scatter targets of pass 2 (RC.cu:279-282)
     ta.ntiles = n2; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.tw = ctx->tile_w; ta.th = ctx->tile_h;
     ta.cap = std::min(ctx->plane_cap, ctx->tile_cap);
-    if (n2) {
+    if (n2 && slots) {
+      r = ctx->back_mode == 4 ? launch_wave_scatter(ctx, a, ta, ctx->d_tiles_tmp, n2)
+                              : launch_slot_scatter(ctx, a, ta, ctx->d_tiles_tmp, seg2[0], seg2[1]);
+      if (r) return r;
+    } else if (n2) {
       HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
       if (pvr_tiled)
         hipLaunchKernelGGL((back_plane_kernel<8, PVR_N, true>), dim3(n2), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float),
@@ -2999,6 +3964,14 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                          ctx->stream, a);
       KCHK("pvr_kernel<FWD>");
+    } else if (a.n && ctx->fwd_mode == 4) {
+      TileArgs ta;
+      ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
+      ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
+      ta.gauss = 0;
+      hipLaunchKernelGGL(fwd_unit_kernel<false>, dim3(ta.ntiles), dim3(FWDU_WAVES * 64), (size_t)ta.cap * 2 * sizeof(float),
+                         ctx->stream, a, ta);
+      KCHK("fwd_unit_kernel");
     } else if (a.n && ctx->fwd_mode >= 1) {
       TileArgs ta;
       ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
@@ -3198,7 +4171,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     r = svr_update_slice_weights(ctx, slice_weight);   // RC.cu:2123
     if (r) return r;
   }
-  if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode == 2)) {
+  if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 2)) {
     ctx->back_tune_pending = false;
     ctx->in_tune = true;
     static const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
@@ -3260,6 +4233,18 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     hipLaunchKernelGGL(pvr_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("pvr_kernel<BACK>");
+  } else if (a.n && ctx->back_mode == 4) {
+    TileArgs ta;
+    ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.dbg = ctx->dbg_back;
+    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
+    r = launch_wave_scatter(ctx, a, ta, ctx->d_tiles, ctx->n_tiles);
+    if (r) return r;
+  } else if (a.n && ctx->back_mode == 3) {
+    TileArgs ta;
+    ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.dbg = ctx->dbg_back;
+    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
+    r = launch_slot_scatter(ctx, a, ta, ctx->d_tiles, ctx->n_tiles_plain, ctx->n_tiles - ctx->n_tiles_plain);
+    if (r) return r;
   } else if (a.n && ctx->back_mode == 2) {
     TileArgs ta;
     ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
@@ -3689,7 +4674,7 @@ int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
     if (r) return r;
   }
   out5[0] = ctx->np; out5[1] = ctx->n_active; out5[2] = ctx->n_psf; out5[3] = ctx->nv; out5[4] = ctx->ns;
-  out5[5] = ctx->n_tiles; out5[6] = ctx->n_tiles_fb;
+  out5[5] = ctx->n_tiles; out5[6] = ctx->n_tiles_fb; out5[7] = ctx->n_tiles_fb8;
   return SVR_OK;
 }
 

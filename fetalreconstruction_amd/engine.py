@@ -418,7 +418,7 @@ class Reconstruction:
         o = (C.c_uint64 * 8)()
         self._ck(self._lib.svr_counters(self._h, o))
         return dict(Vs=int(o[0]), active=int(o[1]), Va=int(o[2]), Nv=int(o[3]), slices=int(o[4]),
-                    tiles=int(o[5]), fallback_tiles=int(o[6]))
+                    tiles=int(o[5]), fallback_tiles=int(o[6]), rerun8_tiles=int(o[7]))
 
 
 def sync_gpu(rec: Reconstruction, prob, quality_factor: float = 2.0):

@@ -250,7 +250,8 @@ int svr_timer_reset(svr_ctx *ctx);
 int svr_timer_enable(svr_ctx *ctx, int enable);
 /* workload counters: [0] pixels in slice grid (Vs), [1] active pixels s!=-1,
  * [2] pixels with v_PSF_sums!=0 (Va), [3] volume voxels (Nv), [4] slices,
- * [5] pixel tiles of the scatter, [6] tiles that took the atomic fallback in the last scatter, [7] 0 */
+ * [5] pixel tiles of the scatter, [6] tiles that took the atomic fallback in the last scatter, [7] tiles the 5-wave scatter
+ * instance handed to the 8-wave one */
 int svr_counters(svr_ctx *ctx, uint64_t out8[8]);
 
 #ifdef __cplusplus

@@ -124,26 +124,45 @@ static uint32_t f2u_sat(float f) {
   return (uint32_t)f;
 }
 
-/* ---- canonical sin / exp: IEEE-only building blocks ----------------------- */
-/* |sin(R)| for R>=0; polynomial on [-pi/2,pi/2] after Cody-Waite reduction.  The
- * sign is irrelevant because the PSF squares it (RC.cu:129-130). */
+/* ---- canonical sinc / exp: IEEE-only building blocks ----------------------- */
 #define GAUSS_AMAX 60.0f
-static float canon_abs_sin(float R) {
-  const float INV_PI = 0.318309886183790671538f;
-  const float PI_A = 3.1414794921875f;            /* 3-term split of pi, exact for k < 2^11 */
-  const float PI_B = 0.00011315941810607910156f;
-  const float PI_C = 1.9841872589410058936e-09f;
-  float k = rintf(R * INV_PI);
-  float r = fmaf(k, -PI_A, R);
-  r = fmaf(k, -PI_B, r);
-  r = fmaf(k, -PI_C, r);
-  float s = r * r;
-  float u = 2.6083159809786593541503e-06f;
-  u = fmaf(u, s, -0.0001981069071916863322258f);
-  u = fmaf(u, s, 0.00833307858556509017944336f);
-  u = fmaf(u, s, -0.166666597127914428710938f);
-  u = fmaf(s, u * r, r);
-  return fabsf(u);
+/* The in-plane factor sin(R)/R, R = pi sqrt(q), q = x'^2 + y'^2 (RC.cu:125-129), from q alone and with
+ * nothing but fma / mul / add / rint and one integer shift-subtract -- operations that are correctly rounded
+ * (or exact) on x86 and on gfx950 alike, so host and device agree bit for bit, and none of which is a
+ * quarter-rate transcendental on the device (round 1 used a correctly rounded sqrt and division here: 22 of its
+ * 47 issue slots per tap):
+ *   y ~ 1/sqrt(q): bit-trick start + 3 Newton steps;  r = q y ~ sqrt(q);  k = rint(r), f = r - k (exact);
+ *   sin(pi r) = +- sin(pi f), |f| <= 1/2:  sin(pi f) / pi = f P(f^2), P = degree-4 fit of sinc on [0, 1/4]
+ *   (4.3e-9);  sin(R)/R = +- (f y) P(f^2).  The sign is irrelevant because the PSF squares it (RC.cu:130).
+ * Against sin(pi sqrt q)^2 / (pi^2 q) in double: |error| <= 6.6e-7 over q in [1e-30, 1e3] (values <= 1).
+ * q == 0 is NaN like sin(0)/0 in the reference (RC.cu:129). */
+static float canon_rsqrt(float q) {
+  uint32_t b;
+  memcpy(&b, &q, 4);
+  b = 0x5f375a86u - (b >> 1);
+  float y;
+  memcpy(&y, &b, 4);
+  const float h = 0.5f * q;
+  for (int i = 0; i < 3; ++i) {
+    const float t = h * y;
+    const float u = fmaf(-t, y, 1.5f);
+    y = y * u;
+  }
+  return y;
+}
+static float canon_sinc(float q, float *r_out) {
+  const float y = canon_rsqrt(q);
+  const float r = q * y;
+  const float k = rintf(r);
+  const float f = r - k;
+  const float s = f * f;
+  float p = 0.024719201028347015f;
+  p = fmaf(p, s, -0.1904420256614685f);
+  p = fmaf(p, s, 0.8117148876190186f);
+  p = fmaf(p, s, -1.6449332237243652f);
+  p = fmaf(p, s, 1.0f);
+  if (r_out) *r_out = r;
+  return (f * y) * p;
 }
 /* exp(-a) for a>=0 (NaN propagates); flushes to 0 for a > 87 (no denormals). */
 static float canon_exp_neg(float a) {
@@ -254,9 +273,9 @@ static void pixel_setup(const orc_geom *g, int sl, const slice_psf *sp, int px, 
 }
 
 /* PointSpreadFunction::sinc_pi (pointSpreadFunction.cuh:45-70), float instantiation */
-static float sinc_pi_f(float x, int canon) {
+static float sinc_pi_f(float x, int canon, float canon_si) {
   const float t0 = FLT_EPSILON, t2 = 3.4526698300e-04f /* sqrtf(eps) */, tn = 1.8581361323e-02f /* sqrtf(t2) */;
-  if (fabsf(x) >= tn) return canon ? canon_abs_sin(x) / x : sinf(x) / x;
+  if (fabsf(x) >= tn) return canon ? canon_si : sinf(x) / x;
   float result = 1.0f;
   if (fabsf(x) >= t0) {
     float x2 = x * x;
@@ -284,7 +303,7 @@ static float psf_literal(const orc_geom *g, const slice_psf *sp, const pixel_psf
   float y_ = q[1] * sp->dim[1] / 2.3548f;
   float x = sqrtf(x_ * x_ + y_ * y_);
   float R = 3.14159265359f * x;
-  float si = g->pvr ? sinc_pi_f(R, 0) : sinf(R) / (R);
+  float si = g->pvr ? sinc_pi_f(R, 0, 0.0f) : sinf(R) / (R);
   return si * si * expf((-q[2] * q[2]) / (2.0f * sigmaz * sigmaz));
 }
 static float psf_canon(const orc_geom *g, const slice_psf *sp, const pixel_psf *pp, int ox, int oy, int oz,
@@ -296,8 +315,10 @@ static float psf_canon(const orc_geom *g, const slice_psf *sp, const pixel_psf *
   float xs = fmaf(sp->Lp[0], fx, fmaf(sp->Lp[1], fy, fmaf(sp->Lp[2], fz, pp->b[0])));
   float ys = fmaf(sp->Lp[3], fx, fmaf(sp->Lp[4], fy, fmaf(sp->Lp[5], fz, pp->b[1])));
   float q = fmaf(ys, ys, xs * xs);
-  float R = 3.14159265359f * sqrtf(q);
-  float si = g->pvr ? sinc_pi_f(R, 1) : canon_abs_sin(R) / R;
+  float r;
+  float si = canon_sinc(q, &r);
+  if (g->pvr) si = sinc_pi_f(3.14159265359f * r, 1, si);   /* the Taylor branch below eps^(1/4) instead of the NaN */
+  else if (q == 0.0f) si = NAN;                            /* sin(0)/0, RC.cu:129 */
   return (si * si) * gz;                               /* gz: the row's canon_gauss_row factor of this tap */
 }
 
