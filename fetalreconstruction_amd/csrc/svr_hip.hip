@@ -1314,14 +1314,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SVR_
 // cheap wavefronts (dead planes) leave early instead of holding a workgroup's LDS.  The price is the tile set-up
 // (pixel records, dead-unit test: ~4 % of a wavefront's work) repeated by every group.  `groups` is a launch
 // parameter: planes beyond 4 * groups are dealt round-robin to the same wavefronts.
+#define WAVE_MAXPIX 32    // pixels of a tile (larger tiles go to the workgroup kernels)
 template <int NS = PSF_SUPPORT, bool PVR = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SVR_WPE_SLOT, SVR_WPE_SLOT)))
 void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_tiles, uint32_t *fallback_count) {
   constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
   extern __shared__ __attribute__((aligned(16))) float tile[];
   f2 *box = reinterpret_cast<f2 *>(tile);               // {addon, cmap} per box voxel of this wavefront's four planes
-  __shared__ PixelRec sh_px[64];                        // cy = centre on the lane axis, cz = centre on the owned axis
-  __shared__ unsigned char sh_list[4][64];              // per slot: live units from the front, dead units from the back
+  __shared__ PixelRec sh_px[WAVE_MAXPIX];               // cy = centre on the lane axis, cz = centre on the owned axis
+  __shared__ unsigned char sh_list[4][WAVE_MAXPIX];     // per slot: live units from the front, dead units from the back
   const int TILE_W = ta.tw, TILE_H = ta.th;
   const int lane = threadIdx.x;
   const VolGeom &vg = a.vg;
@@ -1396,7 +1397,7 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
   if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
   const int PL = (hix - lox + 1) | 1;                   // x pitch (odd: 16 y rows -> distinct banks)
   const int PP = PL * Dy;                               // voxels of one plane
-  if (Dz > 64 || 4 * PP > ta.cap) {                     // more planes than lanes / planes larger than this launch's box:
+  if (Dz > 64 || 4 * PP > ta.cap || TILE_W * TILE_H > WAVE_MAXPIX) {                     // more planes than lanes / planes larger than this launch's box:
     if (lane == 0 && grp == 0) fallback_tiles[atomicAdd(fallback_count, 1u)] = t;   // the workgroup kernels take the tile
     return;
   }
@@ -1455,7 +1456,7 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
       }
       const unsigned long long bl = __ballot(isl), bdd = __ballot(isd);
       if (isl) sh_list[q][__popcll(bl & below)] = (unsigned char)lane;
-      if (isd) sh_list[q][63 - __popcll(bdd & below)] = (unsigned char)lane;
+      if (isd) sh_list[q][WAVE_MAXPIX - 1 - __popcll(bdd & below)] = (unsigned char)lane;
     }
     for (int i = lane; i < 4 * PP; i += 64) box[i] = (f2){0.0f, 0.0f};
     __syncthreads();
@@ -1485,8 +1486,8 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
         // dead units: the first tap of every row, two units per pass in the two halves of the packed evaluator
         for (int i = 0; i < mynd; i += 2) {
           const bool two = i + 1 < mynd;
-          const PixelRec Ra = sh_px[sh_list[slot][63 - i]];
-          const PixelRec Rb = sh_px[sh_list[slot][two ? 63 - i - 1 : 63 - i]];
+          const PixelRec Ra = sh_px[sh_list[slot][WAVE_MAXPIX - 1 - i]];
+          const PixelRec Rb = sh_px[sh_list[slot][two ? WAVE_MAXPIX - 2 - i : WAVE_MAXPIX - 1 - i]];
           const float fua = (float)(P - Ra.cz), fub = (float)(P - Rb.cz);
           const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
           const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
@@ -1516,38 +1517,58 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
     if (ta.dbg != 3) {
       // flush: one pair of device-scope atomics per touched, in-mask voxel; the float->uint saturation of the reference
       // (negative -> 0, RC.cu:508) is applied here, which sums exactly the taps that alias
+      // the lane's elements i = lane + 64 u of a plane sit at the same in-plane voxel offset on all four planes: work
+      // the offsets out once (saturation of negative coordinates and the bound in x included; -1 = nothing to flush)
+      constexpr int FLUSH_U = 8;
       RowWalk w0;
       w0.init(lane, 64, PL);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (pl[q] < 0) continue;
-        RowWalk w = w0;
-        const f2 *pq = box + q * PP;
-        const uint32_t zoff = sat0(pl[q] + loz) * stz;
-        // FLUSH_U elements per lane at a time: their mask words are in flight together (one dependent global load per
-        // element made the flush latency-bound)
-        constexpr int FLUSH_U = 8;
-        for (int i0 = lane; i0 < PP; i0 += 64 * FLUSH_U) {
-          uint32_t vi[FLUSH_U];
-          float mk[FLUSH_U];
+      if (PP <= 64 * FLUSH_U) {
+        int eoff[FLUSH_U];
+        {
+          RowWalk w = w0;
 #pragma unroll
           for (int u = 0; u < FLUSH_U; ++u) {
-            const int i = i0 + 64 * u;
-            bool ok = i < PP;
-            if (ok) {
-              const f2 v = pq[i];
-              ok = (v.x != 0.0f || v.y != 0.0f) && w.x + lox < vg.vx;   // beyond the high end: out of bounds
-            }
-            vi[u] = sat0(w.x + lox) + sat0(w.y + loy) * sty + zoff;
-            mk[u] = ok ? a.mask[vi[u]] : 0.0f;
+            const bool ok = lane + 64 * u < PP && w.x + lox < vg.vx;    // beyond the high end: out of bounds
+            eoff[u] = ok ? (int)(sat0(w.x + lox) + sat0(w.y + loy) * sty) : -1;
             w.step();
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (pl[q] < 0) continue;
+          const f2 *pq = box + q * PP + lane;
+          const float *mz = a.mask + sat0(pl[q] + loz) * stz;
+          float *az_ = a.addon + sat0(pl[q] + loz) * stz, *cz_ = a.cmap + sat0(pl[q] + loz) * stz;
+          f2 v[FLUSH_U];
+          float mk[FLUSH_U];
+#pragma unroll
+          for (int u = 0; u < FLUSH_U; ++u) {                 // all mask words of the plane in flight together
+            v[u] = lane + 64 * u < PP ? pq[64 * u] : (f2){0.0f, 0.0f};
+            const bool ok = eoff[u] >= 0 && (v[u].x != 0.0f || v[u].y != 0.0f);
+            mk[u] = ok ? mz[eoff[u]] : 0.0f;
           }
 #pragma unroll
           for (int u = 0; u < FLUSH_U; ++u) {
             if (mk[u] != 0.0f) {
-              const f2 v = pq[i0 + 64 * u];
-              unsafeAtomicAdd(a.addon + vi[u], v.x);
-              unsafeAtomicAdd(a.cmap + vi[u], v.y);
+              unsafeAtomicAdd(az_ + eoff[u], v[u].x);
+              unsafeAtomicAdd(cz_ + eoff[u], v[u].y);
+            }
+          }
+        }
+      } else {
+        for (int q = 0; q < 4; ++q) {
+          if (pl[q] < 0) continue;
+          RowWalk w = w0;
+          const f2 *pq = box + q * PP;
+          const uint32_t zoff = sat0(pl[q] + loz) * stz;
+          for (int i = lane; i < PP; i += 64, w.step()) {
+            const f2 v = pq[i];
+            if ((v.x != 0.0f || v.y != 0.0f) && w.x + lox < vg.vx) {
+              const uint32_t vi = sat0(w.x + lox) + sat0(w.y + loy) * sty + zoff;
+              if (a.mask[vi] != 0.0f) {
+                unsafeAtomicAdd(a.addon + vi, v.x);
+                unsafeAtomicAdd(a.cmap + vi, v.y);
+              }
             }
           }
         }
@@ -2034,6 +2055,10 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
   const int slot = lane >> 4, y = lane & 15;
   const float fyl = (float)(y - NC);
   // ---- live units: all 16 taps of every row --------------------------------------------------------------
+  // siminside needs no bookkeeping in the gather proper: it is only written where the pixel's weight is > 0
+  // (RC.cu:398-403), and a positive weight is a processed tap on a mask voxel.  Pass 1 of the Gaussian reconstruction
+  // needs "any processed tap on a mask voxel" next to a sum that ignores the mask: one compare pair per tap, combined
+  // in scalar registers (bitwise, no branch).
   for (int j0 = wave * 4; j0 < nlive; j0 += FWDU_WAVES * 4) {
     const int j = j0 + slot;
     const bool valid = j < nlive;
@@ -2048,42 +2073,53 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     f2 acc = (f2){0.0f, 0.0f};
     double accd = 0.0;
     bool hit = false;
-    if (rowok) {
-      if (in_lds) {
-        const f2 *pb = box + (ay - loy) * Px + (az - loz) * Pxy + R.cx - NC - lox;
+    if (in_lds) {                                              // (wave-uniform)
+      const f2 *pb = box + (rowok ? (ay - loy) * Px + (az - loz) * Pxy + R.cx - NC - lox : 0);
+      f2 v[NS];
 #pragma unroll
-        for (int x = 0; x < NS; ++x) {
-          const f2 v = pb[x];
-          if (GAUSS1) accd += (double)(out[x] * v.x);          // RC.cu:241-245 (in bounds, no mask test)
-          else acc = fma2(bc2(out[x]), v, acc);
-          hit = hit || (v.y != 0.0f && __float_as_uint(out[x]) != 0x80000000u);   // processed (not the skip marker) on a mask voxel
+      for (int x = 0; x < NS; ++x) v[x] = pb[x];
+#pragma unroll
+      for (int x = 0; x < NS; ++x) {
+        if (GAUSS1) {
+          accd += (double)(out[x] * v[x].x);                   // RC.cu:241-245 (in bounds, no mask test)
+          hit = hit | ((v[x].y != 0.0f) & (__float_as_uint(out[x]) != 0x80000000u));   // processed, on a mask voxel
+        } else {
+          acc = fma2(bc2(out[x]), v[x], acc);
         }
-      } else {
-#pragma unroll
-        for (int x = 0; x < NS; ++x) {
-          const int gx = R.cx + x - NC;
-          f2 v = (f2){0.0f, 0.0f};
-          if (gx < vg.vx) {
-            const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
-            const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-            v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
-          }
-          if (GAUSS1) accd += (double)(out[x] * v.x);
-          else acc = fma2(bc2(out[x]), v, acc);
-          hit = hit || (v.y != 0.0f && __float_as_uint(out[x]) != 0x80000000u);   // processed (not the skip marker) on a mask voxel
+      }
+    } else {
+      // the tile's box does not fit the LDS: every tap from global memory (strongly oblique tiles of fine volumes)
+      for (int x = 0; x < NS; ++x) {
+        const int gx = R.cx + x - NC;
+        f2 v = (f2){0.0f, 0.0f};
+        if (rowok && gx < vg.vx) {
+          const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
+          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
+          v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
+        }
+        if (GAUSS1) {
+          accd += (double)(out[x] * v.x);
+          hit = hit | ((v.y != 0.0f) & (__float_as_uint(out[x]) != 0x80000000u));
+        } else {
+          acc = fma2(bc2(out[x]), v, acc);
         }
       }
     }
+    if (!rowok) { acc = (f2){0.0f, 0.0f}; accd = 0.0; hit = false; }
     // reduce over the 16 lanes of the slot
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
       if (GAUSS1) accd += __shfl_xor(accd, o, 64);
       else { acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); }
     }
-    const bool anyhit = ((uint32_t)(__ballot(hit) >> (16 * slot)) & 0xFFFFu) != 0u;
-    if (valid && y == 0) {
-      if (GAUSS1) sh_partd[k * NS + u] = accd; else sh_part[k * NS + u] = acc;
-      if (anyhit) atomicOr(&sh_hit[k], 1u << u);
+    if (GAUSS1) {
+      const bool anyhit = ((uint32_t)(__ballot(hit) >> (16 * slot)) & 0xFFFFu) != 0u;
+      if (valid && y == 0) {
+        sh_partd[k * NS + u] = accd;
+        if (anyhit) atomicOr(&sh_hit[k], 1u << u);
+      }
+    } else if (valid && y == 0) {
+      sh_part[k * NS + u] = acc;
     }
   }
   // ---- dead units: the first tap of every row, two units per pass ------------------------------------------
@@ -2135,8 +2171,8 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
         accb.x += __shfl_xor(accb.x, o, 64); accb.y += __shfl_xor(accb.y, o, 64);
       }
     }
-    const bool anya = ((uint32_t)(__ballot(hita) >> (16 * slot)) & 0xFFFFu) != 0u;
-    const bool anyb = ((uint32_t)(__ballot(hitb) >> (16 * slot)) & 0xFFFFu) != 0u;
+    const bool anya = GAUSS1 && ((uint32_t)(__ballot(hita) >> (16 * slot)) & 0xFFFFu) != 0u;
+    const bool anyb = GAUSS1 && ((uint32_t)(__ballot(hitb) >> (16 * slot)) & 0xFFFFu) != 0u;
     if (y == 0) {
       if (va) {
         if (GAUSS1) sh_partd[(kua >> 4) * NS + (kua & 15)] = da; else sh_part[(kua >> 4) * NS + (kua & 15)] = acca;
@@ -2171,7 +2207,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       if (w > 0.0f) {                                         // RC.cu:398-403
         a.simslices[idx] = sm.x / sm.y;
         a.simweights[idx] = w;
-        a.siminside[idx] = inside ? 1 : 0;
+        a.siminside[idx] = 1;                                 // w > 0: a processed tap landed on a mask voxel
       }
     }
   }
@@ -3015,7 +3051,7 @@ struct svr_ctx {
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   int pvr_mode = 1;         // PVR kernels: 1 = the LDS-tiled gather / plane-owned scatter with support 12, 0 = wave-per-pixel
   unsigned char *d_spx = nullptr;
-  int back_mode = 3;        // 3 = slot-owned LDS tiles with the dead-unit shortcut (back_slot_kernel), 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
+  int back_mode = 4;        // 4 = wave-owned LDS planes (back_wave_kernel), 3 = slot-owned LDS tiles with the dead-unit shortcut (back_slot_kernel), 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
                             // 0 = direct device-scope atomics per tap
   int tile_cap = 0;         // voxels of LDS accumulator per workgroup
   int dbg_back = 0;
@@ -3026,7 +3062,8 @@ struct svr_ctx {
   uint32_t *d_tiles_fb2 = nullptr;
   int slot_waves_a = 4, slot_cap_a = 5900;   // back_slot_kernel on slices with dead planes: 46 KiB + 5.8 KiB static -> 3 workgroups per CU
   int slot_waves_b = 5, slot_cap_b = 9200;   // ... on the others (whole-box planes): 2 per CU
-  int wave_groups = 3, wave_cap = 2116;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (4 x 23 x 23: 16.5 KiB)
+  bool wave_cap_user = false;
+  int wave_groups = 1, wave_cap = 2116;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (4 x 23 x 23: 16.5 KiB)
 
   // reductions
   double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
@@ -3533,7 +3570,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "slot_cap_a")) { ctx->slot_cap_a = std::max(2048, value); return SVR_OK; }
   if (!strcmp(name, "slot_cap_b")) { ctx->slot_cap_b = std::max(2048, value); return SVR_OK; }
   if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
-  if (!strcmp(name, "wave_cap")) { ctx->wave_cap = std::max(1024, value); return SVR_OK; }
+  if (!strcmp(name, "wave_cap")) { ctx->wave_cap = std::max(1024, value); ctx->wave_cap_user = true; return SVR_OK; }
   if (!strcmp(name, "slot_waves_a")) { ctx->slot_waves_a = value; return SVR_OK; }
   if (!strcmp(name, "slot_waves_b")) { ctx->slot_waves_b = value; return SVR_OK; }
   if (!strcmp(name, "pvr_reg_levels")) { ctx->pvr_reg_levels = std::min(3, std::max(1, value)); return SVR_OK; }
@@ -4196,10 +4233,30 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
       if (ms < best) { best = ms; pick = c; }
       else break;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (!r) r = svr_set_option(ctx, "tile_w", cand[pick][0]);
     if (!r) r = svr_set_option(ctx, "tile_h", cand[pick][1]);
+    if (!r && !ctx->pvr && ctx->back_mode == 4 && !ctx->wave_cap_user) {
+      // the wave-owned scatter's LDS request decides how many wavefronts a CU holds; the smallest box that still takes
+      // (nearly) every tile wins -- tiles that do not fit are re-run by the workgroup kernel, so any value is correct
+      static const int caps[4] = {2116, 1936, 1764, 1600};       // 4 planes of 23^2, 22^2, 21^2, 20^2 voxels
+      float bestc = 3.0e38f;
+      int pickc = ctx->wave_cap;
+      for (int c = 0; c < 4 && !r; ++c) {
+        ctx->wave_cap = caps[c];
+        float ms = 0.0f;
+        for (int rep = 0; rep < 2 && !r; ++rep) {
+          HIPCHK(hipEventRecord(e0, ctx->stream));
+          r = svr_superresolution_backproject(ctx, nullptr);
+          HIPCHK(hipEventRecord(e1, ctx->stream));
+          HIPCHK(hipEventSynchronize(e1));
+          HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        if (ms < bestc) { bestc = ms; pickc = caps[c]; }
+      }
+      ctx->wave_cap = pickc;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     ctx->timers = timing;
     ctx->in_tune = false;
     if (r) return r;
