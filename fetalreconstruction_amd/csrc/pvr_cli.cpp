@@ -448,13 +448,23 @@ int main(int argc, char **argv) {
   if (!dump_name.empty() && first_level) {               // what the engine is about to receive, for the CPU tests
     FILE *f = fopen(dump_name.c_str(), "wb");
     if (!f) die("cannot write " + dump_name);
-    const int hdr[8] = {ns, px, py, (int)n, tattr.nx, tattr.ny, tattr.nz, 0};
+    const int hdr[8] = {ns, px, py, (int)n, tattr.nx, tattr.ny, tattr.nz, 1};   // [7] = 1: the geometry block at the end
     const float mm[2] = {vmin, vmax};
     std::vector<float> mf(recon_mask.d.begin(), recon_mask.d.end());
     fwrite(hdr, sizeof(int), 8, f); fwrite(counts.data(), sizeof(int), n, f); fwrite(mm, sizeof(float), 2, f);
     fwrite(P.data.data(), sizeof(float), P.data.size(), f); fwrite(P.i2w.data(), sizeof(float), P.i2w.size(), f);
     fwrite(mf.data(), sizeof(float), mf.size(), f);
     if (superpixel) fwrite(spx_masks.data(), 1, spx_masks.size(), f);
+    {
+      // everything else svr_set_slice_matrices / svr_set_slice_dims / svr_init_reconstruction_volume receive: per patch
+      // w2i, T, Tinv, dims; the volume's image-to-world / world-to-image matrices and voxel size
+      float gi2w[16], gw2i[16];
+      to_f16(image_to_world(tattr), gi2w); to_f16(world_to_image(tattr), gw2i);
+      const float gdim[3] = {(float)tattr.dx, (float)tattr.dy, (float)tattr.dz};
+      fwrite(P.w2i.data(), sizeof(float), P.w2i.size(), f); fwrite(st.data(), sizeof(float), st.size(), f);
+      fwrite(sti.data(), sizeof(float), sti.size(), f); fwrite(dims.data(), sizeof(float), dims.size(), f);
+      fwrite(gi2w, sizeof(float), 16, f); fwrite(gw2i, sizeof(float), 16, f); fwrite(gdim, sizeof(float), 3, f);
+    }
     fclose(f);
   }
   if (dry_run) return false;
