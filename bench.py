@@ -1,20 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark: MVoxels/s per SR iteration (PSF forward + back-projection), SVR.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one super-resolution iteration of the reference's hot loop
-(reconstruction.cc:1013-1108, bias correction off): Scale -> Superresolution (back-projection,
-all-reduce, Prep + regulariser) -> SimulateSlices (forward) -> MStep -> EStep, on seeded synthetic
-stacks that are resident in HBM before the timed region.  value = Va / t_step / 1e6 where Va is
-the number of slice pixels with s != -1 and v_PSF_sums != 0 summed over all ranks.
-Workload at N=1: P4 (4 stacks 100x93x70 of 1.176x1.176x1.25 mm voxels, thickness 2.5 mm,
-1.0 mm reconstruction) = BASELINE.json configs[1].  Weak scaling for N>1: every rank gets its own
-4 stacks of that shape (n_stacks = 4N), slices sharded by active-pixel count.
-"""
+A "step" is one super-resolution iteration of the reference's hot loop (reconstruction.cc:1013-1108, bias correction
+off): Scale -> Superresolution (back-projection, all-reduce, Prep + regulariser) -> SimulateSlices (forward) -> MStep ->
+EStep, driven by the C++ host object (csrc/svr_host.cpp) on seeded synthetic stacks that are resident in HBM before the
+timed region.  value = Va / t_step / 1e6, Va = slice pixels with s != -1 and v_PSF_sums != 0 over all ranks.
+
+Workloads are FIXED (strong scaling, as BASELINE.json's metric and configs name them):
+  P4  (default) BASELINE configs[1]: 4 stacks 100x93x70 on the reference's bundled mask geometry, 1.0 mm (workloads.py)
+  S8            BASELINE configs[3]: 8 stacks of 64 x 256^2 slices, 0.75 mm
+  P4s / S8h / tiny: the round-1 axis-aligned P4, the S8 stacks at 0.5 mm, the oracle-sized case.
+N > 1: one process per GPU, slices sharded by active-pixel count, the exchanges on RCCL bound directly by the C library
+(csrc/svr_rccl.cpp; `--comm torch` routes them through torch.distributed instead).  Launched by torch.distributed.run --
+or by this script itself: `python bench.py --gpus N` without WORLD_SIZE in the environment re-executes under
+`python -m torch.distributed.run --nproc-per-node N`.  torch.distributed (gloo) only carries the rendezvous (the 128-byte
+ncclUniqueId) and the timing barrier."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,29 +30,34 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC_BACK_P4 = (110879.0 + 3789632.0) * 1024.0   # bytes per back_plane_kernel launch, see roofline.traffic
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-F32_PEAK_TFLOPS = 157.3      # f32 MFMA dense peak == f32 vector peak on gfx950 (same guide)
-# algorithmic flops of one PSF tap of the canonical float32 sequence:
-# 3 fma (lattice) + q (mul,fma) + sqrt + mul + sin (13) + div + exp (18) + 3 mul = 49 counted as
-# fma=2, everything else 1
-FLOPS_PER_TAP = 49
+F32_PEAK_TFLOPS = 157.3      # f32 vector peak with packed FMA on gfx950 (= the f32 MFMA dense peak, same guide)
+# flops of one PSF tap (fma = 2).  FORMULA: the reference's per-tap formula, RC.cu:112-130 + 164-174 -- 3 fma (lattice),
+# mul + fma (q), sqrt, mul, sin (13), div, exp (18), 3 mul = 49.  EXECUTED: the canonical sequence of round 2 -- 2 fma
+# (x', y'), mul + fma (q), mul (h), 3 x (mul, fma, mul), mul (r), rint, sub, mul (s), 4 fma, 2 mul, mul (square), 2 mul
+# (Gaussian recurrence), mul = 38, on the taps that are evaluated (dead units cost one tap per row).
+FLOPS_PER_TAP_FORMULA = 49
+FLOPS_PER_TAP_EXECUTED = 38
 TAPS = 4096
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")     # written by tools/prof_final.py in the same round
+METRIC = "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR, 1/2/4/8 GPU"
 
 
-def cpu_baseline(prob, target_seconds=10.0):
-    """The CPU port (oracle, literal float32 mode) timed on a bounded sample of the same workload on all host
-    cores: forward + back-projection of every k-th slice (the rest of an SR iteration is <1 % of the CPU time).
-    The sample's slices are dealt to one oracle instance per core (its own partial volume, like the slice-sharded
-    GPU ranks); the C calls release the GIL, so the instances run concurrently.  Reported baseline only."""
+def cpu_baseline(prob, target_seconds=12.0):
+    """The CPU port (oracle, literal float32 mode = the reference's own arithmetic) timed on a bounded sample of the same
+    workload on the host cores: ONE WHOLE SR ITERATION (Scale, back-projection, Prep + regulariser, forward projection,
+    M-step, E-step -- the Python mirror of the host driver on the oracle engine) of every k-th slice.  The sample's
+    slices are dealt to one oracle instance per core (its own volume, like the slice-sharded ranks); the C calls
+    release the GIL.  A reported baseline, not a target."""
     from concurrent.futures import ThreadPoolExecutor
 
     from fetalreconstruction_amd.phantom import sub_problem
+    from fetalreconstruction_amd.reconstruction import irtkReconstruction
     from oracle import pyoracle as po
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
-    per_pixel_s = 2 * 0.14e-3                    # measured ~0.14 ms / pixel / pass / core on this class of host
+    per_pixel_s = 2 * 0.14e-3                    # ~0.14 ms / pixel / PSF pass / core on this class of host
     want = max(2000, int(target_seconds / per_pixel_s)) * cores
     step = max(1, int(np.ceil(act.sum() / want)))
     sel = np.arange(0, prob.ns, step)
@@ -59,25 +71,32 @@ def cpu_baseline(prob, target_seconds=10.0):
     cores = len(parts)
 
     def setup(idx):
-        o = po.OracleReconstruction(sub_problem(prob, 0, 0, select=idx), po.LITERAL)
-        o.InitializeEMValues()
-        o.GaussianReconstruction()
-        o.SimulateSlices()
-        return o
-
-    def step_fn(o):
-        o.SuperresolutionBackproject(np.ones(o.prob.ns, np.float32))
-        o.SimulateSlices()
+        sub = sub_problem(prob, 0, 0, select=idx)
+        o = po.OracleReconstruction(sub, po.LITERAL)
+        d = irtkReconstruction(o, sub.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
+        d.SetSmoothingParameters(150, 0.02)
+        d.InitializeEMValuesGPU(); d.GaussianReconstructionGPU(); d.SimulateSlicesGPU()
+        d.InitializeRobustStatisticsGPU(); d.EStepGPU()
+        return o, d
 
     with ThreadPoolExecutor(cores) as pool:
-        orcs = list(pool.map(setup, parts))
-        va = int(sum(((o.slices != -1) & (o.psf_sums != 0)).sum() for o in orcs))
+        pairs = list(pool.map(setup, parts))
+        va = int(sum(((o.slices != -1) & (o.psf_sums != 0)).sum() for o, _ in pairs))
         t0 = time.perf_counter()
-        list(pool.map(step_fn, orcs))
+        list(pool.map(lambda od: od[1].sr_iteration(0), pairs))
         dt = time.perf_counter() - t0
     return {"value": va / dt / 1e6, "unit": "MVoxels/s per SR iteration", "cores": cores, "kind": "port",
             "sample": f"every {step}th slice of the workload ({len(sel)} slices, {va} active pixels) dealt to {cores} oracle "
-                      f"instances, one thread each: literal-mode back-projection + forward projection in {dt:.1f} s"}
+                      f"instances, one thread each: one whole SR iteration (Scale, back-projection, regulariser, forward "
+                      f"projection, M-step, E-step) in literal mode in {dt:.1f} s"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -85,55 +104,60 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="P4", choices=["P4", "S8", "S8h", "tiny"])
+    ap.add_argument("--workload", default="P4", choices=["P4", "P4s", "S8", "S8h", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
-    ap.add_argument("--share-gpu", action="store_true", help="dev/test: all ranks use cuda:0 (gloo only)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="rccl: the C library's own RCCL collectives; torch: torch.distributed callbacks (--backend)")
+    ap.add_argument("--backend", default="nccl", help="--comm torch: torch.distributed backend (nccl = RCCL, gloo)")
+    ap.add_argument("--share-gpu", action="store_true", help="dev/test: all ranks use cuda:0 (--comm torch --backend gloo only)")
     args = ap.parse_args()
 
-    import torch
-    from fetalreconstruction_amd import engine, phantom
-    from fetalreconstruction_amd.host import irtkReconstruction          # the C++ host object
-    from fetalreconstruction_amd.reconstruction import LocalComm, TorchComm, shard_slices
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly: become the launcher -- N ranks of this script, one per GPU, on this node
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.call(cmd))
+
+    import torch                                                      # before the engine: one RCCL copy per process
+    from fetalreconstruction_amd import engine, phantom, workloads
+    from fetalreconstruction_amd.host import RcclComm, irtkReconstruction      # the C++ host object
+    from fetalreconstruction_amd.reconstruction import TorchComm, shard_slices
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.share_gpu:
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
+        if args.comm == "torch" and args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(args.backend)
-        comm = TorchComm(device=torch.device("cuda", local_rank))
-    else:
-        comm = LocalComm()
-    if args.gpus != world and rank == 0:
-        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+            dist.init_process_group("gloo")                           # rendezvous + barrier only
 
-    # weak scaling: 4 stacks per rank of the named shape
-    if args.workload == "P4":
-        prob = phantom.make_problem(4 * world, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, name="P4")
-    elif args.workload == "S8h":      # the grid of BASELINE.json configs[4]: the S8 stacks reconstructed at 0.5 mm (406^3 voxels)
-        prob = phantom.make_problem(8 * world, (256, 256, 64), 1.0, 2.5, 2.5, 0.5, 100.0,
-                                    orientations=("ax", "cor", "sag"), name="S8h")
-    elif args.workload == "S8":
-        prob = phantom.make_problem(8 * world, (256, 256, 64), 1.0, 2.5, 2.5, 0.75, 100.0,
-                                    orientations=("ax", "cor", "sag"), name="S8")
-    else:
-        prob = phantom.problem_tiny()
+    # ---- the workload: fixed, whatever the world size --------------------------------------------------------------
+    prob = workloads.get(args.workload) if args.workload != "tiny" else phantom.problem_tiny()
     act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
     lo, hi = shard_slices(act, world)[rank]
     local = phantom.sub_problem(prob, lo, hi) if world > 1 else prob
 
     rec = engine.Reconstruction(local_rank)
     engine.sync_gpu(rec, local)
-    drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm if world > 1 else None, prob.max_intensity,
-                             prob.min_intensity)
+    comm, rccl_world = None, None
+    if world > 1:
+        if args.comm == "rccl":
+            box = [RcclComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = RcclComm(rec, rank, world, box[0])
+            rccl_world = comm.rccl_world()
+        else:
+            comm = TorchComm(device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+    drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity)
     drv.SetSmoothingParameters(150, 0.02)      # reconstruction.cc:99-100 defaults (delta, lambda)
 
     # untimed set-up: the part of an outer iteration before the SR loop (reconstruction.cc:930-1001)
@@ -142,10 +166,9 @@ def main():
     drv.SimulateSlicesGPU()
     drv.InitializeRobustStatisticsGPU()
     drv.EStepGPU()
-    # the engine times its tile shapes on the first gather / scatter after new geometry ("Tile shapes follow the
-    # problem"); the gather was tuned by SimulateSlicesGPU above, this untimed scatter keeps the other one out of the timed
-    # region whatever --warmup is (it only writes addon/cmap, which every SR iteration rebuilds, and the slice weights, which
-    # every SR iteration uploads)
+    # the engine times its tile shapes / box sizes on the first gather / scatter after new geometry; the gather was tuned by
+    # SimulateSlicesGPU above, this untimed scatter keeps the other one out of the timed region whatever --warmup is (it
+    # only writes addon|cmap and the slice weights, which every SR iteration rebuilds / uploads)
     rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
     for i in range(args.warmup):
         drv.sr_iteration(i)
@@ -153,10 +176,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
             torch.cuda.synchronize()
 
-    rec.timer_enable(True)
+    rec.timer_enable(True)       # HIP events on the engine's own stream around each hot kernel (svr_timer_*)
     rec.timer_reset()
     barrier()
     t0 = time.perf_counter()
@@ -174,41 +197,60 @@ def main():
         va = cnt["Va"]
 
     if rank == 0:
-        ms_step = dt / max(args.steps, 1) * 1e3
-        value = va / (dt / max(args.steps, 1)) / 1e6
+        steps = max(args.steps, 1)
+        ms_step = dt / steps * 1e3
+        value = va / (dt / steps) / 1e6
         bp_ms, bp_n = timers["backproject"]
         fw_ms, fw_n = timers["forward"]
         bp_avg = bp_ms / max(bp_n, 1) * 1e-3
+        fw_avg = fw_ms / max(fw_n, 1) * 1e-3
         vs, va_l, nv = cnt["Vs"], cnt["Va"], cnt["Nv"]
-        # B_back = 4*Vs + 12*Va + 12*Nv algorithmic bytes per launch
+        # B_back = 4 Vs + 12 Va + 12 Nv, B_fwd = 4 Vs + 13 Va + 8 Nv algorithmic bytes per launch (this rank)
         b_back = 4.0 * vs + 12.0 * va_l + 12.0 * nv
-        flops = float(va_l) * TAPS * FLOPS_PER_TAP
+        b_fwd = 4.0 * vs + 13.0 * va_l + 8.0 * nv
+        flops = float(va_l) * TAPS * FLOPS_PER_TAP_FORMULA
+        traffic = None
+        try:
+            tj = json.load(open(TRAFFIC_JSON))
+            if tj.get("workload") == prob.name and world == 1:
+                traffic = float(tj["back"]["fetch_bytes"] + tj["back"]["write_bytes"])
+        except Exception:
+            traffic = None
+        achieved = flops / bp_avg / 1e12 if bp_n else None
         out = {
-            "metric": "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR, 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": value, "unit": "MVoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{prob.name}: {int(prob.stack_index.max()) + 1} synthetic stacks, volume {prob.vsize}, "
-                                   f"{prob.ns} slices of {prob.slices.shape[2]}x{prob.slices.shape[1]}, "
-                                   f"recon {prob.vdim[0]} mm",
+            "config": {"workload": f"{prob.name}: {int(prob.stack_index.max()) + 1} synthetic stacks, volume {tuple(prob.vsize)}, "
+                                   f"{prob.ns} slices of {prob.slices.shape[2]}x{prob.slices.shape[1]}, recon {prob.vdim[0]} mm"
+                                   + (" on the reference's bundled mask geometry (oblique, 300-400 mm off the origin)" if prob.name == "P4" else ""),
                        "Vs": vs, "Va_rank0": va_l, "Va_total": va, "Nv": nv, "slices": prob.ns,
-                       "parallelism": f"slice-sharded x{world}, 1 volume all-reduce per scatter pass"},
+                       "parallelism": f"slice-sharded x{world}, 1 in-place RCCL all-reduce of addon|cmap (float[2 Nv]) per scatter pass"
+                                      if world > 1 else "1 GPU",
+                       "comm": (args.comm if world > 1 else None), "rccl_world": rccl_world},
             "roofline": {
-                "kernel": "back_plane_kernel<8> (SuperresolutionKernel3D_tex, RC.cu:408-522)",
-                "bound": "mfma", "achieved": flops / bp_avg / 1e12 if bp_n else None, "peak": F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": (flops / bp_avg / 1e12 / F32_PEAK_TFLOPS) if bp_n else None,
-                # bytes per launch through the L2's memory side on P4 (FETCH_SIZE + WRITE_SIZE, separate
-                # rocprofv3 --pmc passes, KB -> B; profiles/r01_f_pmc_back_fwd.txt).  Not measured live.
-                "traffic": PMC_TRAFFIC_BACK_P4 if (prob.name == "P4" and world == 1) else None,
-                "note": "f32 VALU bound: 4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; peak = dense f32 "
-                        "MFMA peak = f32 vector FMA peak on gfx950; `achieved` counts the 49 algorithmic flops per "
-                        "tap, the kernel issues ~47 VALU instructions per tap and keeps the VALU 70 % active "
-                        "(forward gather: 38 per tap; SQ_ACTIVE_INST_VALU, profiles/r01_f_pmc_back_fwd.txt); "
-                        "the HBM view follows",
-                "hbm": {"bound": "hbm", "achieved": b_back / bp_avg / 1e9 if bp_n else None, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": (b_back / bp_avg / 1e9 / HBM_PEAK_GBS) if bp_n else None,
-                        "algorithmic_bytes": b_back},
+                "kernel": "back_wave_kernel (SuperresolutionKernel3D_tex, RC.cu:408-522): the dominant kernel of the step",
+                "bound": "valu_f32",
+                "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (achieved / F32_PEAK_TFLOPS) if achieved else None,
+                "frac_executed": (achieved * FLOPS_PER_TAP_EXECUTED / FLOPS_PER_TAP_FORMULA / F32_PEAK_TFLOPS) if achieved else None,
+                "hbm_achieved_gbs": b_back / bp_avg / 1e9 if bp_n else None, "hbm_peak_gbs": HBM_PEAK_GBS,
+                "hbm_frac": (b_back / bp_avg / 1e9 / HBM_PEAK_GBS) if bp_n else None,
+                "algorithmic_bytes": b_back, "traffic": traffic,
+                "traffic_ratio": (traffic / b_back) if traffic else None,
                 "avg_launch_ms": bp_avg * 1e3, "launches": bp_n,
+                "forward": {"kernel": "fwd_unit_kernel (simulateSlicesKernel3D_tex, RC.cu:298-404)", "avg_launch_ms": fw_avg * 1e3,
+                            "launches": fw_n, "achieved": flops / fw_avg / 1e12 if fw_n else None,
+                            "frac": (flops / fw_avg / 1e12 / F32_PEAK_TFLOPS) if fw_n else None,
+                            "hbm_frac": (b_fwd / fw_avg / 1e9 / HBM_PEAK_GBS) if fw_n else None, "algorithmic_bytes": b_fwd},
+                "note": "f32 VALU bound (4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; no MFMA: a scatter/gather "
+                        "stencil has no contraction).  `achieved` / `frac` credit the reference's 49-flop per-tap formula on "
+                        "all 4096 taps of a pixel against the packed-f32 vector peak; `frac_executed` the 38 flops of the "
+                        "canonical sequence.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch time.  `traffic`: "
+                        "FETCH_SIZE + WRITE_SIZE of the kernel from this round's rocprofv3 --pmc passes "
+                        "(profiles/r02_traffic.json, written by tools/prof_final.py); null when that file is absent or was "
+                        "made on another workload.  Launch time: HIP events on the engine's stream, inside this run.",
             },
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in timers.items()},
         }
@@ -218,8 +260,11 @@ def main():
             except Exception as ex:  # the bench line must still be printed
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))
+    if comm is not None and hasattr(comm, "close"):
+        barrier()
+        comm.close()
     if world > 1:
-        torch.distributed.destroy_process_group()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

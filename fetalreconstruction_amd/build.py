@@ -15,6 +15,7 @@ SRC_REG = os.path.join(HERE, "csrc", "svr_reg.inc")       # GPU registration, #i
 SRC_HOST = os.path.join(HERE, "csrc", "svr_host.cpp")     # plain host C++ (the irtkReconstruction mirror)
 SRC_IO = os.path.join(HERE, "csrc", "svr_io.cpp")         # NIfTI-1 reader / writer (zlib)
 SRC_PVR_HOST = os.path.join(HERE, "csrc", "pvr_host.cpp")  # the irtkPatchBasedReconstruction loop (host C++)
+SRC_RCCL = os.path.join(HERE, "csrc", "svr_rccl.cpp")     # the collectives on RCCL (dlopen: no link-time dependency)
 SRC_IRTK = os.path.join(HERE, "csrc", "irtk_reg.cpp")      # the IRTK registration schedule around the NCC cost (host C++)
 SRC_PREP = os.path.join(HERE, "csrc", "svr_prep.h")       # pre-processing shared by the two command lines
 SRC_SLIC = os.path.join(HERE, "csrc", "svr_slic.h")       # SLICO superpixel patches of the PVR command line
@@ -48,7 +49,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_PREP, SRC_SLIC, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
                                                __file__)) or not (os.path.exists(CLI) and os.path.exists(PVR_CLI))
 
 
@@ -59,7 +60,7 @@ def build(force=False, verbose=False, extra=(), variant=None):
     if not variant and not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra, "-o", out, SRC, SRC_HOST, SRC_PVR_HOST, SRC_IRTK, SRC_IO, "-lz"]
+    cmd = [hipcc(), *FLAGS, *extra, "-o", out, SRC, SRC_HOST, SRC_PVR_HOST, SRC_IRTK, SRC_IO, SRC_RCCL, "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -73,7 +74,7 @@ def build_cli(verbose=False):
     os.makedirs(BIN_DIR, exist_ok=True)
     cxx = shutil.which("g++") or hipcc()
     for exe, src in ((CLI, SRC_CLI), (PVR_CLI, SRC_PVR_CLI)):
-        cmd = [cxx, "-O2", "-std=c++17", "-o", exe, src, "-L" + OUT_DIR, "-lsvr_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+        cmd = [cxx, "-O2", "-std=c++17", "-pthread", "-o", exe, src, "-L" + OUT_DIR, "-lsvr_hip", "-Wl,-rpath,$ORIGIN/../lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -19,6 +19,9 @@
 // both.  --packages runs PackageToVolume with the schedule of main.cc:832-864; --tfolder reads transformation<i>.dof per
 // slice and --debug writes them next to the output.  Not built, refused loudly: patch/superpixel
 // modes, the CPU reconstruction path.
+#include <functional>
+#include <thread>
+
 #include "svr_prep.h"
 
 
@@ -78,7 +81,7 @@ int main(int argc, char **argv) {
       printf("usage: SVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> [-m <mask>] [-t id|<4x4.txt> ..] [--thickness th_1 ..]\n"
              "       [--iterations 4] [--resolution 0.75] [--multires 3] [--average 700] [--delta 150] [--lambda 0.02]\n"
              "       [--lastIterLambda 0.01] [--smooth_mask 4] [--no_intensity_matching] [--force_exclude i ..]\n"
-             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [-d device]\n");
+             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [-d device_1 .. device_N]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/svr_cli.cpp)");
@@ -176,35 +179,95 @@ int main(int argc, char **argv) {
   fprintf(stderr, "%zu stacks, %d slices of up to %dx%d, volume %dx%dx%d at %g mm\n", n, ns, mx, my, tattr.nx, tattr.ny, tattr.nz,
           resolution);
 
-  // ---- SyncGPU + generatePSFVolume + UpdateGPUTranformationMatrices (RG.cc:249-401, 1496-1610) ----------
+  // ---- ranks: one engine context per device of -d (main.cc:191), the slices sharded over them in contiguous ranges
+  // balanced by active pixels (reconstruction_cuda2.cu:1413-1457 shards by slice count and drops the remainder) ----------
+  const int nr = (int)std::max<size_t>(1, devices.size());
+  std::vector<int> rlo(nr, 0), rhi(nr, ns);
+  {
+    std::vector<double> cum(ns + 1, 0.0);
+    for (int s = 0; s < ns; ++s) {
+      long c = 0;
+      for (size_t i = 0; i < (size_t)mx * my; ++i) c += grid[(size_t)s * mx * my + i] != -1.0f;
+      cum[s + 1] = cum[s] + (double)c;
+    }
+    int at = 0;
+    for (int r = 0; r < nr; ++r) {
+      rlo[r] = at;
+      if (r == nr - 1) at = ns;
+      else {
+        const double want = cum[ns] * (r + 1) / nr;
+        while (at < ns - (nr - 1 - r) && cum[at] < want) ++at;
+        at = std::max(at, rlo[r] + 1);
+      }
+      rhi[r] = std::min(at, ns);
+    }
+    if (ns < nr) die("fewer slices than devices");
+  }
+  std::vector<svr_ctx *> ctxs(nr, nullptr);
+  std::vector<svrh_recon *> hosts(nr, nullptr);
+  ctxs[0] = ctx;
+  for (int r = 1; r < nr; ++r)
+    if (svr_create(devices[r], &ctxs[r]) || !ctxs[r]) die("no usable HIP device " + std::to_string(devices[r]) + " (svr_create failed)");
+  svr_group *group = nr > 1 ? svr_group_create(nr, devices.data()) : nullptr;
+  if (nr > 1 && !group) die("cannot set up the rank group (librccl not found?)");
+  // every rank in its own thread (the collectives inside block until all ranks have arrived)
+  auto par = [&](const std::function<void(int)> &fn) {
+    if (nr == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int r = 0; r < nr; ++r) th.emplace_back(fn, r);
+    for (auto &t : th) t.join();
+  };
+#define ENGR(r, call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + svr_last_error(ctxs[r])); } while (0)
+#define HOSTR(r, call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + svrh_last_error(hosts[r])); } while (0)
+  float ri2w[16], rw2i[16];
+  to_f16(image_to_world(tattr), ri2w); to_f16(world_to_image(tattr), rw2i);
+  auto set_matrices = [&](int r) {
+    const size_t o = 16 * (size_t)rlo[r];
+    ENGR(r, svr_set_slice_matrices(ctxs[r], st.data() + o, sti.data() + o, i2w.data() + o, w2i.data() + o, i2w.data() + o, w2i.data() + o, ri2w, rw2i));
+  };
+
+  // ---- SyncGPU + generatePSFVolume + UpdateGPUTranformationMatrices (RG.cc:249-401, 1496-1610), per rank ----------
   const uint32_t vsize[3] = {(uint32_t)tattr.nx, (uint32_t)tattr.ny, (uint32_t)tattr.nz};
   const float vdim[3] = {(float)tattr.dx, (float)tattr.dy, (float)tattr.dz};
   std::vector<float> maskf(vol_mask.d.begin(), vol_mask.d.end());
-  float ri2w[16], rw2i[16];
-  to_f16(image_to_world(tattr), ri2w); to_f16(world_to_image(tattr), rw2i);
-  ENG(svr_init_reconstruction_volume(ctx, vsize, vdim, nullptr, 12.0f));
-  ENG(svr_set_mask(ctx, vsize, vdim, maskf.data(), 12.0f));
-  const uint32_t ssize[3] = {(uint32_t)mx, (uint32_t)my, (uint32_t)ns};
-  ENG(svr_init_storage_volumes(ctx, ssize, &dims[0]));
-  ENG(svr_fill_slices(ctx, grid.data(), sizes_x.data(), sizes_y.data()));
-  ENG(svr_set_slice_dims(ctx, dims.data(), 2.0f));
+  float pi2w[16], pw2i[16];
   {
     svr_image_attr pa;                                                   // PSF_SIZE 128 (RC.cuh:56), RG.cc:1534-1551
     memset(&pa, 0, sizeof(pa));
     pa.nx = pa.ny = pa.nz = 128; pa.dx = tattr.dx; pa.dy = tattr.dy; pa.dz = tattr.dz;
     pa.xaxis[0] = pa.yaxis[1] = pa.zaxis[2] = 1.0;
-    float pi2w[16], pw2i[16];
     to_f16(image_to_world(pa), pi2w); to_f16(world_to_image(pa), pw2i);
-    const uint32_t psize[3] = {128, 128, 128};
-    ENG(svr_generate_psf_volume(ctx, nullptr, psize, &dims[0], vdim, pi2w, pw2i, 2.0f));
   }
-  ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), i2w.data(), w2i.data(), i2w.data(), w2i.data(), ri2w, rw2i));
-
-  svrh_recon *host = svrh_create(ctx, ns, 0, ns, nullptr);
-  if (!host) die("svrh_create failed");
-  svrh_set_intensity_range(host, vmin, vmax);                            // InitializeEMGPU RG.cc:2937-2951
-  if (!force_excluded.empty()) svrh_set_force_excluded(host, force_excluded.data(), (int)force_excluded.size());
-  if (use_gpu_reg) HOST(svrh_prepare_registration_slices(host, grid.data(), mx, my, sattr.data(), resolution));
+  par([&](int r) {
+    const int nl = rhi[r] - rlo[r];
+    const size_t o = (size_t)rlo[r];
+    ENGR(r, svr_init_reconstruction_volume(ctxs[r], vsize, vdim, nullptr, 12.0f));
+    ENGR(r, svr_set_mask(ctxs[r], vsize, vdim, maskf.data(), 12.0f));
+    const uint32_t ssize[3] = {(uint32_t)mx, (uint32_t)my, (uint32_t)nl};
+    ENGR(r, svr_init_storage_volumes(ctxs[r], ssize, &dims[3 * o]));
+    ENGR(r, svr_fill_slices(ctxs[r], grid.data() + o * mx * my, sizes_x.data() + o, sizes_y.data() + o));
+    ENGR(r, svr_set_slice_dims(ctxs[r], dims.data() + 3 * o, 2.0f));
+    const uint32_t psize[3] = {128, 128, 128};
+    ENGR(r, svr_generate_psf_volume(ctxs[r], nullptr, psize, &dims[3 * o], vdim, pi2w, pw2i, 2.0f));
+    set_matrices(r);
+    hosts[r] = svrh_create(ctxs[r], ns, rlo[r], rhi[r], group ? svr_group_join(group, r, ctxs[r]) : nullptr);
+    if (!hosts[r]) die("svrh_create failed");
+    svrh_set_intensity_range(hosts[r], vmin, vmax);                      // InitializeEMGPU RG.cc:2937-2951
+    if (!force_excluded.empty()) svrh_set_force_excluded(hosts[r], force_excluded.data(), (int)force_excluded.size());
+    if (use_gpu_reg) HOSTR(r, svrh_prepare_registration_slices(hosts[r], grid.data() + o * mx * my, mx, my, sattr.data() + o, resolution));
+  });
+  if (nr > 1)
+    fprintf(stderr, "%d ranks on devices%s, collectives: %s\n", nr, [&] { std::string t; for (int d : devices) t += " " + std::to_string(d); return t; }().c_str(),
+            svr_group_uses_rccl(group) ? "RCCL" : "host memory (a device is named more than once: test mode)");
+  svrh_recon *host = hosts[0];
+  auto update_matrices_from_T = [&]() {                                  // UpdateGPUTranformationMatrices RG.cc:372-401
+    for (int s = 0; s < ns; ++s) {
+      M4 t;
+      for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];
+      to_f16(t, &st[16 * (size_t)s]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)s]);
+    }
+    for (int r = 0; r < nr; ++r) set_matrices(r);
+  };
 
   if (!tfolder.empty()) {                                                // ReadTransformation, RG.cc:4733-4765
     for (int s = 0; s < ns; ++s) {
@@ -212,11 +275,8 @@ int main(int argc, char **argv) {
       char e[256] = {0};
       const std::string path = tfolder + "/transformation" + std::to_string(s) + ".dof";
       if (svr_dof_read(path.c_str(), p6, &T[16 * (size_t)s], e)) die(path + ": " + e);
-      M4 t;
-      for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];
-      to_f16(t, &st[16 * (size_t)s]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)s]);
     }
-    ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), i2w.data(), w2i.data(), i2w.data(), w2i.data(), ri2w, rw2i));
+    update_matrices_from_T();
   }
 
   // ---- registration-reconstruction loop (main.cc:816-1237) ---------------------------------------------
@@ -236,18 +296,11 @@ int main(int argc, char **argv) {
         die(std::string("package-to-volume registration: ") + e);
       fprintf(stderr, "package-to-volume registration: %ld similarity evaluations\n", evals);
       slice_reg = it >= 4;
-      if (!slice_reg) {
-        for (int s = 0; s < ns; ++s) {
-          M4 t;
-          for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];
-          to_f16(t, &st[16 * (size_t)s]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)s]);
-        }
-        ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), i2w.data(), w2i.data(), i2w.data(), w2i.data(), ri2w, rw2i));
-      }
+      if (!slice_reg) update_matrices_from_T();
     }
     if (slice_reg) {                                                      // main.cc:829-880
-      if (use_gpu_reg) {
-        HOST(svrh_slice_to_volume_registration_gpu(host, T.data()));
+      if (use_gpu_reg) {                                                  // every rank registers its own slices
+        par([&](int r) { HOSTR(r, svrh_slice_to_volume_registration_gpu(hosts[r], T.data() + 16 * (size_t)rlo[r])); });
       } else {                                                            // SliceToVolumeRegistration, RG.cc:2291-2303
         std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
         ENG(svr_sync_cpu(ctx, vol.data()));                               // _reconstructed after SyncCPU, main.cc:1189
@@ -257,29 +310,28 @@ int main(int argc, char **argv) {
           die(std::string("slice-to-volume registration: ") + e);
         fprintf(stderr, "slice-to-volume registration: %ld similarity evaluations\n", evals);
       }
-      for (int s = 0; s < ns; ++s) {                                      // UpdateGPUTranformationMatrices RG.cc:372-401
-        M4 t;
-        for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];
-        to_f16(t, &st[16 * (size_t)s]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)s]);
-      }
-      ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), i2w.data(), w2i.data(), i2w.data(), w2i.data(), ri2w, rw2i));
+      update_matrices_from_T();
     }
-    if (it == iterations - 1) {                                           // main.cc:884-896
-      svrh_set_smoothing_parameters(host, delta, last_lambda);
-    } else {
-      double l = lambda;
-      for (int i = 0; i < levels; ++i) {
-        if (it == iterations * (levels - i - 1) / levels) svrh_set_smoothing_parameters(host, delta, l);
-        l *= 2;
+    for (int r = 0; r < nr; ++r) {
+      if (it == iterations - 1) {                                         // main.cc:884-896
+        svrh_set_smoothing_parameters(hosts[r], delta, last_lambda);
+      } else {
+        double l = lambda;
+        for (int i = 0; i < levels; ++i) {
+          if (it == iterations * (levels - i - 1) / levels) svrh_set_smoothing_parameters(hosts[r], delta, l);
+          l *= 2;
+        }
       }
     }
-    HOST(svrh_reconstruct_iteration(host, it == iterations - 1 ? rec_last : rec_first));   // main.cc:930-1140
+    par([&](int r) { HOSTR(r, svrh_reconstruct_iteration(hosts[r], it == iterations - 1 ? rec_last : rec_first)); });   // main.cc:930-1140
     double sc[8];
     svrh_get_state(host, nullptr, nullptr, nullptr, nullptr, sc);
     fprintf(stderr, "iteration %d: sigma %.4g mix %.3f\n", it, sc[0], sc[1]);
   }
-  ENG(svr_restore_slice_intensities(ctx, factors.data(), (int)factors.size(), stack_index.data()));   // main.cc:1189-1193
-  HOST(svrh_scale_volume_gpu(host));
+  par([&](int r) {                                                       // main.cc:1189-1193
+    ENGR(r, svr_restore_slice_intensities(ctxs[r], factors.data(), (int)factors.size(), stack_index.data() + rlo[r]));
+    HOSTR(r, svrh_scale_volume_gpu(hosts[r]));
+  });
   std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
   ENG(svr_sync_cpu(ctx, vol.data()));
   char err[256] = {0};
@@ -295,7 +347,8 @@ int main(int argc, char **argv) {
       if (svr_dof_write(path.c_str(), p6, e)) die(path + ": " + e);
     }
   }
-  svrh_destroy(host);
-  svr_destroy(ctx);
+  for (int r = 0; r < nr; ++r) svrh_destroy(hosts[r]);
+  svr_group_destroy(group);
+  for (int r = 0; r < nr; ++r) svr_destroy(ctxs[r]);
   return 0;
 }

@@ -3635,6 +3635,13 @@ int svr_set_stream(svr_ctx *ctx, void *hip_stream) {
   return SVR_OK;
 }
 
+void *svr_get_stream(svr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int svr_device(svr_ctx *ctx) { return ctx ? ctx->device : -1; }
+int svr_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const float dim[3],
                                    const float *data, float sigma_bias) {
   if (!ctx || !size || !dim) return SVR_E_ARG;

@@ -3,6 +3,7 @@
 // Plain host C++: no HIP calls here, everything device-side goes through include/svr_hip.h.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <string>
@@ -36,7 +37,7 @@ class irtkReconstruction {
   std::vector<unsigned char> _slice_inside_gpu;
 
   irtkReconstruction(svr_ctx *engine, int n_global, int lo_, int hi_, const svr_collectives *c)
-      : reconstructionGPU(engine), ns(n_global), lo(lo_), hi(hi_), have_coll(c != nullptr && c->world > 1) {
+      : reconstructionGPU(engine), ns(n_global), lo(lo_), hi(hi_), have_coll(c != nullptr && (c->world > 1 || getenv("SVR_FORCE_COLLECTIVES"))) {   // (the variable: test hook, world 1 through the callbacks)
     if (c) coll = *c;
     else { coll.user = nullptr; coll.rank = 0; coll.world = 1; coll.allreduce_volume_pair = nullptr;
            coll.allreduce_host = nullptr; coll.allgather_slices = nullptr; }

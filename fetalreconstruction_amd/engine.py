@@ -38,7 +38,7 @@ EXPORTS = [
     "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
-    "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_ncc_set_targets", "svr_ncc_set_source",
+    "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_ncc_set_targets", "svr_ncc_set_source",
     "svr_ncc_evaluate", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
@@ -419,6 +419,11 @@ class Reconstruction:
         self._ck(self._lib.svr_counters(self._h, o))
         return dict(Vs=int(o[0]), active=int(o[1]), Va=int(o[2]), Nv=int(o[3]), slices=int(o[4]),
                     tiles=int(o[5]), fallback_tiles=int(o[6]), rerun8_tiles=int(o[7]))
+
+
+def device_count():
+    """HIP devices visible to this process (0 without a GPU)"""
+    return int(load_library().svr_device_count())
 
 
 def sync_gpu(rec: Reconstruction, prob, quality_factor: float = 2.0):

@@ -13,6 +13,8 @@ _AR_PAIR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _AR_HOST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int)
 
+COMM_EXPORTS = ["svr_comm_unique_id", "svr_comm_create", "svr_comm_collectives", "svr_comm_world", "svr_comm_allreduce_host",
+                "svr_comm_last_error", "svr_comm_destroy", "svr_group_create", "svr_group_uses_rccl", "svr_group_join", "svr_group_destroy"]                                                  # csrc/svr_rccl.cpp
 HOST_EXPORTS = [
     "svrh_create", "svrh_destroy", "svrh_last_error", "svrh_set_intensity_range", "svrh_set_smoothing_parameters",
     "svrh_set_force_excluded", "svrh_initialize_em_values_gpu", "svrh_gaussian_reconstruction_gpu",
@@ -48,8 +50,69 @@ class _Coll(C.Structure):
                 ("allreduce_host", _AR_HOST), ("allgather_slices", _AG)]
 
 
+class RcclComm:
+    """One rank's RCCL communicator, made and driven by the C library (include/svr_host.h `svr_comm_*`, csrc/svr_rccl.cpp): the
+    volume pair is all-reduced in place on the engine's stream, the small host vectors through a device scratch buffer.
+    `unique_id` = 128 bytes from `RcclComm.unique_id()` on ONE rank, handed to all (the launcher's job); the constructor
+    blocks until every rank of `world` has called it."""
+
+    @staticmethod
+    def unique_id():
+        lib = _engine.load_library()
+        buf = C.create_string_buffer(128)
+        if lib.svr_comm_unique_id(buf):
+            raise _engine.SvrError("svr_comm_unique_id failed (librccl not found?)")
+        return buf.raw
+
+    def __init__(self, rec, rank, world, unique_id):
+        self._lib = _engine.load_library()
+        self._lib.svr_comm_create.restype = C.c_void_p
+        self._lib.svr_comm_collectives.restype = C.c_void_p
+        self._lib.svr_comm_last_error.restype = C.c_char_p
+        self._lib.svr_comm_destroy.restype = None
+        self.rank, self.world = int(rank), int(world)
+        assert len(unique_id) == 128
+        h = self._lib.svr_comm_create(self.rank, self.world, C.c_char_p(unique_id), rec._h)
+        if not h:
+            raise _engine.SvrError("svr_comm_create failed (see stderr)")
+        self._h = C.c_void_p(h)
+        self.collectives = C.c_void_p(self._lib.svr_comm_collectives(self._h))
+        self._rec = rec                                   # the engine must outlive the communicator's use of its stream
+
+    def rccl_world(self):
+        """the communicator's size as RCCL reports it (ncclCommCount)"""
+        return int(self._lib.svr_comm_world(self._h))
+
+    def _host(self, a, op):
+        v = np.ascontiguousarray(a, np.float64).copy()
+        if self._lib.svr_comm_allreduce_host(self._h, v.ctypes.data_as(C.c_void_p), int(v.size), int(op)):
+            raise _engine.SvrError("svr_comm_allreduce_host: " + self._lib.svr_comm_last_error(self._h).decode())
+        return v
+
+    def allreduce_sum(self, a):
+        return self._host(a, 0)
+
+    def allreduce_min(self, a):
+        return self._host(a, 1)
+
+    def allreduce_max(self, a):
+        return self._host(a, 2)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.svr_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class irtkReconstruction:
-    """C++ host object over one engine; `comm` is a reconstruction.TorchComm (or None)."""
+    """C++ host object over one engine; `comm` is an RcclComm (the C library's RCCL collectives), a reconstruction.TorchComm
+    (torch.distributed callbacks: gloo in the CPU tests) or None."""
 
     def __init__(self, rec: "_engine.Reconstruction", n_slices_global, slice_range=None, comm=None,
                  max_intensity=1.0, min_intensity=0.0):
@@ -64,7 +127,13 @@ class irtkReconstruction:
         self.ns = int(n_slices_global)
         self.lo, self.hi = slice_range if slice_range is not None else (0, self.ns)
         self._coll = None
-        if comm is not None and comm.world > 1:
+        coll_ptr = None
+        if isinstance(comm, RcclComm):
+            import os
+            if comm.world > 1 or os.environ.get("SVR_FORCE_COLLECTIVES"):
+                self._comm = comm                       # the C library's own collectives (csrc/svr_rccl.cpp)
+                coll_ptr = comm.collectives
+        elif comm is not None and comm.world > 1:
             self._comm = comm
             self._views = {}
             counts = [int(round(x)) for x in comm.allreduce_sum(np.eye(comm.world)[comm.rank] * (self.hi - self.lo))]
@@ -103,8 +172,9 @@ class irtkReconstruction:
 
             self._cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag))     # keep the thunks alive
             self._coll = _Coll(None, comm.rank, comm.world, *self._cbs)
-        h = self._lib.svrh_create(rec._h, self.ns, int(self.lo), int(self.hi),
-                                  C.byref(self._coll) if self._coll is not None else None)
+        if self._coll is not None:
+            coll_ptr = C.byref(self._coll)
+        h = self._lib.svrh_create(rec._h, self.ns, int(self.lo), int(self.hi), coll_ptr)
         if not h:
             raise _engine.SvrError("svrh_create failed")
         self._h = C.c_void_p(h)

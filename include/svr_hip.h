@@ -164,6 +164,12 @@ void *svr_device_ptr(svr_ctx *ctx, int which);
 size_t svr_volume_voxels(const svr_ctx *ctx);
 /* run all kernels on this hipStream_t (e.g. the caller's torch stream); NULL = default */
 int svr_set_stream(svr_ctx *ctx, void *hip_stream);
+/* the hipStream_t every kernel of the context is enqueued on, and the context's device (for collectives that must be ordered
+ * with the kernels: csrc/svr_rccl.cpp) */
+void *svr_get_stream(svr_ctx *ctx);
+int svr_device(svr_ctx *ctx);
+/* number of HIP devices visible to this process (hipGetDeviceCount; 0 on error): what `-d` / --gpus can name */
+int svr_device_count(void);
 int svr_gaussian_reconstruction_local(svr_ctx *ctx);            /* scatter into recon|volw */
 int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num_local); /* equalize */
 int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight); /* addon|cmap */

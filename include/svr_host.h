@@ -39,6 +39,29 @@ typedef struct svr_collectives {
   int (*allgather_slices)(void *user, const float *local, int n_local, float *global_out, int n_global);
 } svr_collectives;
 
+/* ---- the collectives on RCCL, bound directly (csrc/svr_rccl.cpp) ---------------------------------------------------
+ * One communicator per rank = per GPU: a process of its own (bench.py) or a thread of the command line (`-d 0 1 ..`).
+ * Replaces the reference's per-device worker threads with their reduce on GPU 0 (reconstruction_cuda2.cu:1413-1457,
+ * 2225-2239).  The volume pair is all-reduced in place on the engine's stream.  id128 = ncclUniqueId made by ONE rank
+ * (svr_comm_unique_id) and handed to all; svr_comm_create blocks until all `world` ranks have called it. */
+typedef struct svr_comm svr_comm;
+int svr_comm_unique_id(char id128[128]);
+svr_comm *svr_comm_create(int rank, int world, const char id128[128], svr_ctx *engine);
+const svr_collectives *svr_comm_collectives(svr_comm *c);
+int svr_comm_world(svr_comm *c);                                     /* ncclCommCount */
+int svr_comm_allreduce_host(svr_comm *c, double *data, int n, int op); /* op: 0 sum, 1 min, 2 max */
+const char *svr_comm_last_error(const svr_comm *c);
+void svr_comm_destroy(svr_comm *c);
+/* the ranks of ONE process (the command line's `-d 0 1 2 ..`, one thread and one engine context per rank): RCCL
+ * communicators when the devices are distinct, an exchange through host memory under a thread barrier when a device is
+ * named more than once (RCCL refuses that; a test mode for one-GPU boxes).  svr_group_join is called by every rank from its
+ * own thread and blocks until all have joined; NULL for world 1. */
+typedef struct svr_group svr_group;
+svr_group *svr_group_create(int world, const int *devices);
+int svr_group_uses_rccl(const svr_group *g);
+const svr_collectives *svr_group_join(svr_group *g, int rank, svr_ctx *engine);
+void svr_group_destroy(svr_group *g);
+
 typedef struct svrh_recon svrh_recon;
 
 /* irtkReconstruction(std::vector<int> dev, bool useCPUReg)  RG.cc:159-221; the engine context is

@@ -41,7 +41,9 @@ def test_host_object_exports_all_declared_symbols():
     assert lib.pvrh_create(None, None, 0, ctypes.c_float(0), ctypes.c_float(1)) is None
     assert not [n for n in host.IRTK_EXPORTS if not hasattr(lib, n)]
     io = [n for n in _declared("svr_host.h", "svr_") if not n.startswith("svrh_") and n != "svr_collectives"]
-    assert sorted(host.IO_EXPORTS) == sorted(n for n in io if hasattr(lib, n)) == sorted(io)
+    assert sorted(host.IO_EXPORTS + host.COMM_EXPORTS) == sorted(n for n in io if hasattr(lib, n)) == sorted(io)
+    lib.svr_comm_create.restype = ctypes.c_void_p
+    assert lib.svr_comm_create(0, 2, None, None) is None       # no id / engine -> refused, librccl is not even opened
     lib.svrh_create.restype = ctypes.c_void_p
     assert lib.svrh_create(None, 4, 0, 4, None) is None        # no engine -> refused
 

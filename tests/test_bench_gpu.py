@@ -1,5 +1,6 @@
-"""bench.py on a GPU box: the one-line contract at N = 1, and two ranks sharing the GPU through the slice-sharded C++ host
-(gloo carries the collectives here; the driver's multi-GPU runs use RCCL through the same callbacks)."""
+"""bench.py on a GPU box: the one-line contract at N = 1; two ranks sharing the GPU through the slice-sharded C++ host (gloo
+carries the collectives there: RCCL refuses two ranks on one device); the C library's RCCL communicator at world size 1 on
+the one GPU of the box; and, where two devices are visible, `python bench.py --gpus 2` launching its own ranks over RCCL."""
 import json
 import os
 import subprocess
@@ -27,13 +28,63 @@ def test_bench_line_and_two_ranks_on_one_gpu():
                 "data", "config", "roofline"):
         assert key in a, key
     assert a["n_gpus"] == 1 and a["steps"] == 3 and a["value"] > 0 and a["dtype"] == "f32" and a["roofline"]["frac"] > 0
+    assert a["scaling"] == "strong" and a["roofline"]["bound"] == "valu_f32" and a["roofline"]["hbm_frac"] > 0
+    assert a["roofline"]["algorithmic_bytes"] > 0 and "traffic" in a["roofline"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29517", "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",
-                          "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+                          "--comm", "torch", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-3000:]
     b = _last_json(two.stdout)
     assert b["n_gpus"] == 2 and b["value"] > 0
-    # weak scaling: the tiny workload is not multiplied (only P4 / S8 are); both ranks together cover the same active pixels
+    # strong scaling: the workload is fixed, both ranks together cover the same active pixels
     assert b["config"]["Va_total"] == a["config"]["Va_total"] and b["config"]["slices"] == a["config"]["slices"]
     assert 0 < b["config"]["Va_rank0"] < b["config"]["Va_total"]
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
+    """csrc/svr_rccl.cpp on the one GPU of the box: librccl is opened, a communicator of world size 1 is made on the engine's
+    stream, and the sharded C++ host runs a whole iteration through its three collectives (identity at world 1) -- the same
+    result as without a communicator."""
+    import numpy as np
+    from fetalreconstruction_amd import engine as E, host
+    recs, vols = [], []
+    os.environ["SVR_FORCE_COLLECTIVES"] = "1"          # world 1 through the callbacks (csrc/svr_host.cpp)
+    for use_comm in (False, True):
+        rec = E.Reconstruction(0)
+        E.sync_gpu(rec, tiny)
+        comm = None
+        if use_comm:
+            comm = host.RcclComm(rec, 0, 1, host.RcclComm.unique_id())
+            assert comm.rccl_world() == 1
+            assert np.array_equal(comm.allreduce_sum(np.array([1.5, 2.0])), [1.5, 2.0])
+            assert np.array_equal(comm.allreduce_max(np.array([3.0])), [3.0]) and np.array_equal(comm.allreduce_min(np.array([-1.0])), [-1.0])
+        d = host.irtkReconstruction(rec, tiny.ns, (0, tiny.ns), comm, tiny.max_intensity, tiny.min_intensity)
+        d.SetSmoothingParameters(150, 0.02)
+        d.reconstruct_iteration(2)
+        vols.append(rec.syncCPU().copy())
+        recs.append((rec, comm, d))
+    assert np.array_equal(vols[0] == -1, vols[1] == -1)
+    assert np.abs(vols[0] - vols[1]).max() <= 2e-5 * np.abs(vols[0]).max()      # float atomics in run-dependent order
+    recs[1][1].close()
+    del os.environ["SVR_FORCE_COLLECTIVES"]
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_rccl_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment spawns two ranks (one GPU each) whose collectives run
+    on RCCL, and says which world size RCCL saw.  Needs two visible devices (the gpurun box has one: skipped there)."""
+    from fetalreconstruction_amd import engine         # (not torch: a second RCCL copy in this process, after the C library opened its own)
+    if engine.device_count() < 2:
+        pytest.skip("one visible device")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    one = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600, env=env)
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0 and two.returncode == 0, two.stderr[-3000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["rccl_world"] == 2 and b["config"]["comm"] == "rccl"
+    assert b["config"]["Va_total"] == a["config"]["Va_total"] and 0 < b["config"]["Va_rank0"] < b["config"]["Va_total"]
