@@ -115,11 +115,16 @@ def main(argv=None):
         raise SystemExit("one thickness per stack expected")
     if a.packages and len(a.packages) != n:
         raise SystemExit("one package count per stack expected")
-    template = next((k for k, s in enumerate(a.transformation or ["id"] * n) if s == "id"), 0)   # first 'id' stack
-    mask = None
+    template = next((k for k, s in enumerate(a.transformation or ["id"] * n) if s == "id"), None)   # first 'id' stack
+    if template is None:
+        raise SystemExit("Please identify the template by assigning id transformation.")           # main.cc:452-457
     if a.mask:
         md, mat = nifti.read(a.mask)
         mask = pp.Image(md.astype(np.float64), mat)
+    else:
+        # no mask given: CreateMask(stacks[templateNumber]) binarises the template stack (> 0), in case it was padded; the
+        # normal mask path follows (main.cc:458-480, RG.cc:736-748)
+        mask = pp.Image((stacks[template].data > 0).astype(np.float64), stacks[template].attr)
 
     # template stack: mask onto its grid, crop (main.cc:583-584)
     if mask is not None:
@@ -154,6 +159,8 @@ def main(argv=None):
 
     engine.sync_gpu(rec, prob)                                                                   # SyncGPU, main.cc:722
     drv = irtkReconstruction(rec, prob.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
+    # `--no_intensity_matching v` stores v in intensity_matching (main.cc:183): 0 (and the bare flag here) switches Bias / Scale off
+    drv._intensity_matching = a.no_intensity_matching is None or bool(a.no_intensity_matching)     # main.cc:1018, 1062
     drv.SetForceExcludedSlices(a.force_exclude)
     rs = reg.PrepareRegistrationSlices(rec, prob.slices, prob.slice_attr, resolution) if a.useGPUReg else None
     T = np.stack(slice_t)

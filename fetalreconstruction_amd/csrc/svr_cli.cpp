@@ -99,6 +99,10 @@ int main(int argc, char **argv) {
   if (tspecs.size() != n) die("one transformation per stack expected");
   if (!packages.empty() && packages.size() != n) die("one package count per stack expected");
 
+  size_t tmpl = n;
+  for (size_t k = 0; k < n; ++k) if (tspecs[k] == "id") { tmpl = k; break; }
+  if (tmpl == n) die("Please identify the template by assigning id transformation.");          // main.cc:452-457
+
   svr_ctx *ctx = nullptr;
   if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
 
@@ -108,12 +112,17 @@ int main(int argc, char **argv) {
   for (size_t k = 0; k < n; ++k) { stacks.push_back(read_image(inputs[k])); ts.push_back(load_transformation(tspecs[k])); }
   if (thickness.empty()) for (auto &s : stacks) thickness.push_back(2.0 * s.a.dz);            // main.cc:422-431
   if (thickness.size() != n) die("one thickness per stack expected");
-  size_t tmpl = 0;
-  for (size_t k = 0; k < n; ++k) if (tspecs[k] == "id") { tmpl = k; break; }
   Image mask_img;
-  const bool have_mask = !mask_name.empty();
-  if (have_mask) {
+  const bool have_mask = true;
+  if (!mask_name.empty()) {
     mask_img = read_image(mask_name);
+  } else {
+    // no mask given: CreateMask(stacks[templateNumber]) binarises the template stack (> 0), in case it was padded; the
+    // normal mask path follows (main.cc:458-480, RG.cc:736-748)
+    mask_img = stacks[tmpl];
+    for (auto &v : mask_img.d) v = v > 0.0 ? 1.0 : 0.0;
+  }
+  {
     const Image m = transform_nn(mask_img, stacks[tmpl].a, ts[tmpl], 0.0);                     // TransformMask RG.cc:805-821
     stacks[tmpl] = crop_image(stacks[tmpl], m);
   }
@@ -253,6 +262,7 @@ int main(int argc, char **argv) {
     hosts[r] = svrh_create(ctxs[r], ns, rlo[r], rhi[r], group ? svr_group_join(group, r, ctxs[r]) : nullptr);
     if (!hosts[r]) die("svrh_create failed");
     svrh_set_intensity_range(hosts[r], vmin, vmax);                      // InitializeEMGPU RG.cc:2937-2951
+    svrh_set_intensity_matching(hosts[r], no_matching ? 0 : 1);         // main.cc:1018, 1062
     if (!force_excluded.empty()) svrh_set_force_excluded(hosts[r], force_excluded.data(), (int)force_excluded.size());
     if (use_gpu_reg) HOSTR(r, svrh_prepare_registration_slices(hosts[r], grid.data() + o * mx * my, mx, my, sattr.data() + o, resolution));
   });

@@ -3008,6 +3008,7 @@ struct svr_ctx {
 
   // geometry
   std::vector<float> slice_dims;   // ns*3
+  std::vector<uint32_t> stack_sizes;   // updateStackSizes (RC.cuh:210)
   std::vector<float> mI2W, mW2I, mT, mTinv;
   float reconI2W[16], reconW2I[16];
   float psf_c0[3] = {0, 0, 0};
@@ -3077,6 +3078,10 @@ struct svr_ctx {
 
   // registration cost (NCC)
   short *d_reg_targets = nullptr, *d_reg_source = nullptr;
+  int *d_ncc_idx = nullptr;              // grow-only scratch of svr_ncc_evaluate
+  double *d_ncc_m = nullptr;
+  long long *d_ncc_s = nullptr;
+  size_t ncc_cap = 0;
   int reg_tx = 0, reg_ty = 0, reg_n = 0;
   uint32_t reg_vx = 0, reg_vy = 0, reg_vz = 0;
 
@@ -3607,6 +3612,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_bias_vol); free_dev(ctx->d_volume_weights); free_dev(ctx->d_maskC); free_dev(ctx->d_mbuf);
   free_dev(ctx->d_reg_targets);
   free_dev(ctx->d_reg_source);
+  free_dev(ctx->d_ncc_idx); free_dev(ctx->d_ncc_m); free_dev(ctx->d_ncc_s);
   reg_free(ctx->reg);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
@@ -3815,6 +3821,24 @@ int svr_sync_cpu(svr_ctx *ctx, float *out) {
   if (!ctx || !out) return SVR_E_ARG;
   NEED(ctx->nv > 0, "InitReconstructionVolume first");
   HIPCHK(hipMemcpyAsync(out, ctx->recon(), ctx->nv * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+// Reconstruction::updateStackSizes (RC.cuh:210): the sizes are stored; nothing in the reference reads them back
+int svr_update_stack_sizes(svr_ctx *ctx, const uint32_t *sizes3, int n_stacks) {
+  if (!ctx || n_stacks < 0 || (n_stacks > 0 && !sizes3)) return SVR_E_ARG;
+  ctx->stack_sizes.assign(sizes3, sizes3 + 3 * (size_t)n_stacks);
+  return SVR_OK;
+}
+
+// Reconstruction::combineWeights (RC.cu:5091-5097): the bias path's accumulated volume weights (dev_volume_weights_) of device 0;
+// zeros while no NormaliseBias has run (the reference's buffer is cleared at allocation, RC.cu:1214)
+int svr_combine_weights(svr_ctx *ctx, float *out) {
+  if (!ctx || !out) return SVR_E_ARG;
+  NEED(ctx->nv > 0, "InitReconstructionVolume first");
+  if (!ctx->d_volume_weights) { memset(out, 0, ctx->nv * sizeof(float)); return SVR_OK; }
+  HIPCHK(hipMemcpyAsync(out, ctx->d_volume_weights, ctx->nv * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
 }
@@ -4683,12 +4707,19 @@ int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const do
   NEED(ctx->d_reg_targets && ctx->d_reg_source, "svr_ncc_set_targets / svr_ncc_set_source first");
   for (int i = 0; i < n_eval; ++i)
     if (target_index[i] < 0 || target_index[i] >= ctx->reg_n) return fail(ctx, SVR_E_ARG, "target index out of range");
-  int *d_idx = nullptr;
-  double *d_m = nullptr;
-  long long *d_s = nullptr;
-  HIPCHK(hipMalloc(&d_idx, n_eval * sizeof(int)));
-  HIPCHK(hipMalloc(&d_m, (size_t)n_eval * 16 * sizeof(double)));
-  HIPCHK(hipMalloc(&d_s, (size_t)n_eval * 6 * sizeof(long long)));
+  // grow-only scratch of the context (the optimiser calls this ~60 k times per registration pass)
+  if ((size_t)n_eval > ctx->ncc_cap) {
+    free_dev(ctx->d_ncc_idx); free_dev(ctx->d_ncc_m); free_dev(ctx->d_ncc_s);
+    ctx->ncc_cap = 0;
+    const size_t cap = std::max<size_t>(256, (size_t)n_eval * 3 / 2);
+    HIPCHK(hipMalloc(&ctx->d_ncc_idx, cap * sizeof(int)));
+    HIPCHK(hipMalloc(&ctx->d_ncc_m, cap * 16 * sizeof(double)));
+    HIPCHK(hipMalloc(&ctx->d_ncc_s, cap * 6 * sizeof(long long)));
+    ctx->ncc_cap = cap;
+  }
+  int *d_idx = ctx->d_ncc_idx;
+  double *d_m = ctx->d_ncc_m;
+  long long *d_s = ctx->d_ncc_s;
   std::vector<long long> h((size_t)n_eval * 6);
   hipError_t e = hipMemcpyAsync(d_idx, target_index, n_eval * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_m, matrices, (size_t)n_eval * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -4699,7 +4730,6 @@ int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const do
   }
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_s, h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_idx); (void)hipFree(d_m); (void)hipFree(d_s);
   if (e != hipSuccess) return fail(ctx, (int)e, "svr_ncc_evaluate");
   for (int i = 0; i < n_eval; ++i) {
     const long long *s = &h[6 * (size_t)i];

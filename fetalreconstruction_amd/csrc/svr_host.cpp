@@ -31,6 +31,7 @@ class irtkReconstruction {
   double _delta, _lambda, _alpha;
   float _low_intensity_cutoff;
   bool _global_bias_correction, _adaptive, _disableBiasC;
+  bool _intensity_matching;            // reconstruction.cc:114,183: false skips Bias / Scale / NormaliseBias in every SR iteration
   double _max_intensity, _min_intensity;
   std::vector<int> _force_excluded, _small_slices;
   std::vector<float> _scale_gpu, _slice_weight_gpu, _slice_potential_gpu;
@@ -55,6 +56,7 @@ class irtkReconstruction {
     _global_bias_correction = false;
     _adaptive = false;
     _disableBiasC = true;   // reconstruction.cc:121,202
+    _intensity_matching = true;
     _max_intensity = 1; _min_intensity = 0;
     _sigma_gpu = 0; _m_gpu = 0; _mean_s_gpu = 0; _mean_s2_gpu = 0;
     _scale_gpu.assign(ns, 1.0f);
@@ -295,11 +297,13 @@ class irtkReconstruction {
   // reconstruction.cc:1013-1108 with bias correction off
   int sr_iteration(int i) {
     int rc;
-    if (!_disableBiasC && _sigma_bias > 0)                                   // reconstruction.cc:1032-1037
-      if ((rc = BiasGPU())) return rc;
-    if ((rc = ScaleGPU())) return rc;
+    if (_intensity_matching) {                                               // reconstruction.cc:1018-1045
+      if (!_disableBiasC && _sigma_bias > 0)                                 // reconstruction.cc:1032-1037
+        if ((rc = BiasGPU())) return rc;
+      if ((rc = ScaleGPU())) return rc;
+    }
     if ((rc = SuperresolutionGPU(i + 1))) return rc;
-    if (!_disableBiasC && _sigma_bias > 0 && !_global_bias_correction)       // reconstruction.cc:1066-1076
+    if (_intensity_matching && !_disableBiasC && _sigma_bias > 0 && !_global_bias_correction)   // reconstruction.cc:1062-1076
       if ((rc = NormaliseBiasGPU(i))) return rc;
     if ((rc = SimulateSlicesGPU())) return rc;
     if ((rc = MStepGPU(i + 1))) return rc;
@@ -487,6 +491,7 @@ int svrh_initialize_robust_statistics_gpu(svrh_recon *r) { return r->impl.Initia
 int svrh_estep_gpu(svrh_recon *r) { return r->impl.EStepGPU(); }
 int svrh_scale_gpu(svrh_recon *r) { return r->impl.ScaleGPU(); }
 int svrh_superresolution_gpu(svrh_recon *r, int iter) { return r->impl.SuperresolutionGPU(iter); }
+void svrh_set_intensity_matching(svrh_recon *r, int on) { if (r) r->impl._intensity_matching = on != 0; }
 int svrh_mstep_gpu(svrh_recon *r, int iter) { return r->impl.MStepGPU(iter); }
 int svrh_mask_volume_gpu(svrh_recon *r) { return r->impl.MaskVolumeGPU(); }
 int svrh_scale_volume_gpu(svrh_recon *r) { return r->impl.ScaleVolumeGPU(); }

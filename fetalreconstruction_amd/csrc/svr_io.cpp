@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <string>
+#include <exception>
 #include <vector>
 
 #include "../../include/svr_host.h"
@@ -179,10 +180,20 @@ int svr_nifti_read(const char *path, svr_image_attr *attr, int *nt, float **data
     case 64: bytes = 8; break;                   // float64
     default: gzclose(f); return set_err(err, "unsupported NIfTI datatype " + std::to_string(h.datatype));
   }
+  // a header is 16-bit counts times each other: bound the product before anything is allocated (no exception may cross
+  // the C boundary, and a corrupt header must not ask for terabytes)
+  const double n_d = (double)a.nx * a.ny * a.nz * t;
+  if (!(n_d * bytes <= 64.0 * 1024 * 1024 * 1024)) { gzclose(f); return set_err(err, "image larger than 64 GiB: corrupt header?"); }
   const size_t n = (size_t)a.nx * a.ny * a.nz * t;
   const long off = (long)h.vox_offset >= 348 ? (long)h.vox_offset : 352;
   if (gzseek(f, off, SEEK_SET) < 0) { gzclose(f); return set_err(err, "seek to vox_offset failed"); }
-  std::vector<unsigned char> raw(n * bytes);
+  std::vector<unsigned char> raw;
+  try {
+    raw.resize(n * bytes);
+  } catch (const std::exception &) {
+    gzclose(f);
+    return set_err(err, "out of memory");
+  }
   size_t got = 0;
   while (got < raw.size()) {
     const int r = gzread(f, raw.data() + got, (unsigned)std::min<size_t>(raw.size() - got, 1u << 30));
@@ -220,6 +231,8 @@ int svr_nifti_read(const char *path, svr_image_attr *attr, int *nt, float **data
 int svr_nifti_write(const char *path, const svr_image_attr *attr, const float *data, char err[256]) {
   if (!path || !attr || !data) return SVR_E_ARG;
   const svr_image_attr &a = *attr;
+  if (a.nx < 1 || a.ny < 1 || a.nz < 1 || a.nx > 32767 || a.ny > 32767 || a.nz > 32767)
+    return set_err(err, "NIfTI-1 dimensions are 16-bit: 1..32767 per axis");
   Nifti1Header h;
   memset(&h, 0, sizeof(h));
   h.sizeof_hdr = 348;

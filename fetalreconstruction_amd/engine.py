@@ -38,7 +38,7 @@ EXPORTS = [
     "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
-    "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_ncc_set_targets", "svr_ncc_set_source",
+    "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
     "svr_ncc_evaluate", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
@@ -164,6 +164,15 @@ class Reconstruction:
         out = np.empty(int(np.prod(self.vsize)), np.float32)
         self._ck(self._lib.svr_sync_cpu(self._h, _p(out)))
         return out
+
+    def combineWeights(self):
+        out = np.zeros(int(np.prod(self.vsize)), np.float32)
+        self._ck(self._lib.svr_combine_weights(self._h, _p(out)))
+        return out
+
+    def updateStackSizes(self, stack_sizes):
+        a = np.ascontiguousarray(stack_sizes, np.uint32).reshape(-1, 3)
+        self._ck(self._lib.svr_update_stack_sizes(self._h, _p(a), len(a)))
 
     def getVolWeights(self):
         out = np.empty(int(np.prod(self.vsize)), np.float32)

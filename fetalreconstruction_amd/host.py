@@ -16,7 +16,7 @@ _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(
 COMM_EXPORTS = ["svr_comm_unique_id", "svr_comm_create", "svr_comm_collectives", "svr_comm_world", "svr_comm_allreduce_host",
                 "svr_comm_last_error", "svr_comm_destroy", "svr_group_create", "svr_group_uses_rccl", "svr_group_join", "svr_group_destroy"]                                                  # csrc/svr_rccl.cpp
 HOST_EXPORTS = [
-    "svrh_create", "svrh_destroy", "svrh_last_error", "svrh_set_intensity_range", "svrh_set_smoothing_parameters",
+    "svrh_create", "svrh_destroy", "svrh_last_error", "svrh_set_intensity_range", "svrh_set_intensity_matching", "svrh_set_smoothing_parameters",
     "svrh_set_force_excluded", "svrh_initialize_em_values_gpu", "svrh_gaussian_reconstruction_gpu",
     "svrh_simulate_slices_gpu", "svrh_initialize_robust_statistics_gpu", "svrh_estep_gpu", "svrh_scale_gpu",
     "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
@@ -194,6 +194,10 @@ class irtkReconstruction:
 
     def SetSmoothingParameters(self, delta, lam):
         self._lib.svrh_set_smoothing_parameters(self._h, C.c_double(delta), C.c_double(lam))
+
+    def SetIntensityMatching(self, on):
+        self._lib.svrh_set_intensity_matching.restype = None
+        self._lib.svrh_set_intensity_matching(self._h, int(bool(on)))
 
     def SetForceExcludedSlices(self, idx):
         a = np.ascontiguousarray(idx, np.int32)

@@ -158,6 +158,7 @@ class irtkReconstruction:
         self._force_excluded = []
         self._small_slices = []
         self._disableBiasC = True      # reconstruction.cc:121,202: the CLI can never switch it on
+        self._intensity_matching = True  # reconstruction.cc:114,183: --no_intensity_matching 0 switches Bias / Scale / NormaliseBias off
         self._scale_gpu = np.ones(self.ns, np.float32)
         self._slice_weight_gpu = np.ones(self.ns, np.float32)
         self._slice_inside_gpu = np.ones(self.ns, bool)
@@ -391,11 +392,12 @@ class irtkReconstruction:
 
     def sr_iteration(self, i):
         """The hot loop body, reconstruction.cc:1013-1108 with bias correction off."""
-        if not self._disableBiasC and self._sigma_bias > 0:      # reconstruction.cc:1032-1037
-            self.BiasGPU()
-        self.ScaleGPU()
+        if self._intensity_matching:                              # reconstruction.cc:1018-1045
+            if not self._disableBiasC and self._sigma_bias > 0:  # reconstruction.cc:1032-1037
+                self.BiasGPU()
+            self.ScaleGPU()
         self.SuperresolutionGPU(i + 1)
-        if not self._disableBiasC and self._sigma_bias > 0 and not self._global_bias_correction:
+        if self._intensity_matching and not self._disableBiasC and self._sigma_bias > 0 and not self._global_bias_correction:
             self.NormaliseBiasGPU(i)                              # reconstruction.cc:1066-1076
         self.SimulateSlicesGPU()
         self.MStepGPU(i + 1)

@@ -95,6 +95,10 @@ int svr_update_reconstructed(svr_ctx *ctx, const uint32_t size[3], const float *
 int svr_sync_cpu(svr_ctx *ctx, float *reconstructed);
 /* getVolWeights(float*)  RC.cuh:206 */
 int svr_get_vol_weights(svr_ctx *ctx, float *weights);
+/* Reconstruction::combineWeights(float*) RC.cuh:190, RC.cu:5091-5097: the bias path's volume weights of device 0 */
+int svr_combine_weights(svr_ctx *ctx, float *out);
+/* Reconstruction::updateStackSizes(std::vector<uint3>) RC.cuh:210: stored (the reference never reads them back); sizes3 = n_stacks x {x, y, z} */
+int svr_update_stack_sizes(svr_ctx *ctx, const uint32_t *sizes3, int n_stacks);
 
 /* ---- compute ------------------------------------------------------------------------ */
 /* GaussianReconstruction(std::vector<int>& voxel_num): voxel_num[0] = #pixels that hit the ROI

@@ -75,6 +75,9 @@ const char *svrh_last_error(const svrh_recon *r);
 void svrh_set_intensity_range(svrh_recon *r, double min_intensity, double max_intensity); /* RG.cc:2937-2951 */
 void svrh_set_smoothing_parameters(svrh_recon *r, double delta, double lambda);             /* RG.h:605-612 */
 void svrh_set_force_excluded(svrh_recon *r, const int *idx, int n);                         /* RG.h:614-617 */
+/* `intensity_matching` of reconstruction.cc:114,183 (--no_intensity_matching 0): off = no Bias / Scale / NormaliseBias in the SR
+ * iterations (reconstruction.cc:1018-1045, 1062-1076); the scales stay 1 */
+void svrh_set_intensity_matching(svrh_recon *r, int on);
 
 /* disableBiasCorrection() RG.cc:234-238 / SetSigma RG.h:376; BiasGPU RG.cc:3904-3913, NormaliseBiasGPU RG.cc:4653 */
 int svrh_set_bias_correction(svrh_recon *r, int enable, double sigma_bias);

@@ -257,3 +257,74 @@ def test_command_line_shards_the_slices_over_the_devices_of_d(tmp_path, registra
     else:
         ok = (v1 > 0) & (v3 > 0)
         assert np.corrcoef(v1[ok], v3[ok])[0, 1] > 0.98
+
+
+def test_template_must_be_identified(tmp_path):
+    """reconstruction.cc:452-457: with transformations given and none of them `id`, the reference stops with 'Please identify
+    the template by assigning id transformation' -- both command lines do (before any GPU work)."""
+    import subprocess
+    from fetalreconstruction_amd import build, cli, nifti
+    build.build()
+    img = _stack()
+    paths = []
+    for k in range(2):
+        nifti.write(tmp_path / f"s{k}.nii", img.data.astype(np.float32), img.attr)
+        paths.append(str(tmp_path / f"s{k}.nii"))
+    np.savetxt(tmp_path / "t.txt", np.eye(4))
+    args = ["-o", str(tmp_path / "o.nii"), "-i", *paths, "-t", str(tmp_path / "t.txt"), str(tmp_path / "t.txt")]
+    r = subprocess.run([build.CLI, *args], capture_output=True, text=True)
+    assert r.returncode != 0 and "identify the template" in r.stderr
+    with pytest.raises(SystemExit, match="identify the template"):
+        cli.main(args)
+
+
+@pytest.mark.gpu
+def test_no_mask_option_builds_the_mask_from_the_template(tmp_path):
+    """Without -m the reference binarises the template stack (CreateMask: > 0, reconstruction.cc:458-480, RG.cc:736-748) and
+    runs the normal mask path (TransformMask, CropImage, SetMask); both command lines, same volume, and nothing is reconstructed
+    where the template stack was padding."""
+    import subprocess
+    from fetalreconstruction_amd import build, cli, nifti
+    paths, mpath, rattr, rmask = _write_case(tmp_path)
+    common = ["-i", *paths, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "1", "--rec_iterations_last", "2",
+              "--no_registration", "--smooth_mask", "0"]
+    assert cli.main(["-o", str(tmp_path / "py.nii.gz"), *common]) == 0
+    r = subprocess.run([build.CLI, "-o", str(tmp_path / "cc.nii.gz"), *common], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vp, ap = nifti.read(tmp_path / "py.nii.gz")
+    vc, ac = nifti.read(tmp_path / "cc.nii.gz")
+    assert vp.shape == vc.shape and np.array_equal(vp == -1, vc == -1)
+    assert np.abs(vp - vc).max() <= 2e-4 * np.abs(vp).max()
+    masked = subprocess.run([build.CLI, "-o", str(tmp_path / "m.nii.gz"), *common, "-m", mpath], capture_output=True, text=True, timeout=300)
+    assert masked.returncode == 0
+    vm, _ = nifti.read(tmp_path / "m.nii.gz")
+    d0, _ = nifti.read(paths[0])
+    assert (vc == -1).any() and (vc > 0).sum() != (vm > 0).sum()            # a mask of its own, not all ones, not the given one
+    assert 0.2 < (vc > 0).mean() < 0.98 * (d0 > 0).mean() + 0.5
+
+
+@pytest.mark.gpu
+def test_no_intensity_matching_keeps_the_scales_at_one(tiny):
+    """`--no_intensity_matching 0` (intensity_matching = false, reconstruction.cc:183, 1018-1045): no Scale (and no Bias /
+    NormaliseBias) in the SR iterations -- the per-slice scales stay 1 in both hosts."""
+    from fetalreconstruction_amd import engine as E, host
+    from fetalreconstruction_amd.reconstruction import irtkReconstruction
+    out = {}
+    for on in (True, False):
+        rec = E.Reconstruction(0)
+        E.sync_gpu(rec, tiny)
+        hc = host.irtkReconstruction(rec, tiny.ns, max_intensity=tiny.max_intensity, min_intensity=tiny.min_intensity)
+        hc.SetSmoothingParameters(150, 0.02)
+        hc.SetIntensityMatching(on)
+        hc.reconstruct_iteration(2)
+        rec2 = E.Reconstruction(0)
+        E.sync_gpu(rec2, tiny)
+        py = irtkReconstruction(rec2, tiny.ns, max_intensity=tiny.max_intensity, min_intensity=tiny.min_intensity)
+        py.SetSmoothingParameters(150, 0.02)
+        py._intensity_matching = on
+        py.reconstruct_iteration(2)
+        out[on] = (hc.state()["scale"].copy(), py._scale_gpu.copy(), rec.syncCPU().copy(), rec2.syncCPU().copy())
+    assert np.all(out[False][0] == 1) and np.all(out[False][1] == 1)
+    assert np.abs(out[True][0] - 1).max() > 1e-4 and np.allclose(out[True][0], out[True][1], rtol=2e-5)
+    assert np.abs(out[False][2] - out[False][3]).max() <= 2e-5 * np.abs(out[False][2]).max()
+    assert np.abs(out[False][2] - out[True][2]).max() > 1e-3 * np.abs(out[True][2]).max()
