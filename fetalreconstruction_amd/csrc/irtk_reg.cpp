@@ -23,6 +23,7 @@
 #include <float.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <thread>
 
 #include "svr_prep.h"
@@ -32,7 +33,7 @@ namespace {
 // rows of an image are independent in every filter below: split them over the host cores (results do not depend on it)
 template <class F> void parallel_rows(int n, size_t work_per_row, F fn) {
   unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 32u), (size_t)n * work_per_row / 200000 + 1);
+  int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 64u), (size_t)n * work_per_row / 100000 + 1);
   if (nt <= 1 || n < 2) { fn(0, n); return; }
   nt = std::min(nt, n);
   std::vector<std::thread> th;
@@ -285,11 +286,17 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
                       long *n_eval, std::string &err) {
   if (targets.empty()) return 0;
   const short source_padding = guess_padding(source);
+  const bool timing = getenv("SVR_REG_TIMING") != nullptr;        // dev: where a registration pass spends its wall time
+  double t_src = 0, t_tgt = 0, t_pack = 0, t_opt = 0, t_eval = 0;
+  long rounds = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int level = 2; level >= 0; --level) {
+    double t0 = now();
     // ---- Initialize(level): every target and the source -------------------------------------------------------------
     Vol<short> src;
     const Schedule ps = guess_parameters(targets[0].full->a, source.a, slice_to_volume);
     if (prepare_level(source, ps.s_blur[level], ps.s_res[level], ps.s_res[0], level, source_padding, src, err)) return 1;
+    t_src += now() - t0; t0 = now();
     int tx = 0, ty = 0, planes = 0;
     std::vector<int> bad(targets.size(), 0);
     std::vector<std::string> errs(targets.size());
@@ -305,6 +312,7 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
         t.step = p.length[level]; t.delta = p.delta[level];
       }
     });
+    t_tgt += now() - t0; t0 = now();
     for (size_t r = 0; r < targets.size(); ++r) {
       if (bad[r]) { err = errs[r]; return 1; }
       Target &t = targets[r];
@@ -323,6 +331,7 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
     if (be.set_source(ssz, src.d.data())) { err = "svr_ncc_set_source failed"; return 2; }
     const M4 s_w2i = world_to_image(src.a);
     const Schedule p0 = ps;
+    t_pack += now() - t0; t0 = now();
     // ---- the optimiser, one round = one batched evaluation --------------------------------------------------------------
     for (;;) {
       std::vector<int> idx, owner, count;                   // per request: its owner and its number of planes
@@ -346,7 +355,9 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
       }
       if (owner.empty()) break;
       std::vector<int64_t> sums(6 * idx.size());
+      const double te = now();
       if (be.evaluate((int)idx.size(), idx.data(), mats.data(), sums.data())) { err = "svr_ncc_evaluate failed"; return 2; }
+      t_eval += now() - te; ++rounds;
       if (n_eval) *n_eval += (long)owner.size();
       std::vector<double> value(owner.size());
       size_t at = 0;
@@ -402,7 +413,11 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
         }
       }
     }
+    t_opt += now() - t0;
   }
+  if (timing)
+    fprintf(stderr, "[svr reg timing] source pyramid %.1f ms, target pyramids %.1f ms, pack + upload %.1f ms, optimiser %.1f ms (%ld rounds, %.1f ms in the batched evaluations)\n",
+            1e3 * t_src, 1e3 * t_tgt, 1e3 * t_pack, 1e3 * t_opt, rounds, 1e3 * t_eval);
   return 0;
 }
 
