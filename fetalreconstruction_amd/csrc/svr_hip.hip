@@ -812,174 +812,16 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void back_tiled_kernel(PsfArgs a, 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Plane-owned back-projection: the production scatter (no atomics inside the tile)
-// ------------------------------------------------------------------------------------------
-// LDS float atomics (ds_add_f32) turned out to run at ~1 lane / 2.6 clk / CU on gfx950 -- barely
-// faster than device-scope atomics -- so the tile box is instead partitioned by ABSOLUTE z-plane:
-// each 16-lane "slot" owns one plane of the box, walks the (pixel, z) units of the tile that land
-// on its plane, and its 16 lanes are the 16 y-rows of that unit.  No two lanes ever touch the
-// same LDS word, so the accumulation is a plain read-add-write in a fixed order (deterministic
-// inside a tile); only the final flush uses device-scope atomics.  Tiles that touch the low
-// volume boundary (saturated, aliasing coordinates) or whose box does not fit go through
-// back_tiled_kernel's atomic path instead.
-#define PLANE_MAX_WAVES 8
-
 struct PixelRec {      // per tile pixel, in LDS
   int cx, cy, cz;
   float bx, by, bz;
   float f0, f1;
 };
 
-// NS = PSF support (16 SVR, 12 PVR), PVR = patch-to-volume constants of the evaluator and of the residual
-// (R2/patchBasedSuperresolution_gpu.cu:34-111, R2/patchBasedPSFReconstruction_gpu.cu:112-139)
-template <int PLANE_WAVES, int NS = PSF_SUPPORT, bool PVR = false>
-__global__ __launch_bounds__(PLANE_WAVES * 64) void back_plane_kernel(PsfArgs a, TileArgs ta,
-                                                                       uint32_t *fallback_tiles,
-                                                                       uint32_t *fallback_count) {
-  constexpr int PLANE_SLOTS = PLANE_WAVES * 4;
-  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
-  constexpr bool GAUSS1_ACT = false;
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // addon[cap] | cmap[cap]
-  __shared__ int sh_lo[3], sh_hi[3];
-  __shared__ PixelRec sh_px[64];
-  __shared__ unsigned char sh_list[PLANE_SLOTS][64];
-  __shared__ int sh_cnt[PLANE_SLOTS];
-  __shared__ int sh_npix;
-  const int TILE_W = ta.tw, TILE_H = ta.th;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const VolGeom &vg = a.vg;
-  const uint32_t t = ta.tiles[blockIdx.x];
-  const int per_slice = ta.tiles_x * ta.tiles_y;
-  const uint32_t sl = t / per_slice;
-  const int r = t - sl * per_slice;
-  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
-  const SliceConst &S = a.sc[sl];
-  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
-
-  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
-  __syncthreads();
-  if (wave == 0) {
-    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
-    bool act = false;
-    uint32_t idx = 0;
-    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
-      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = pixel_active(a.slices, GAUSS1_ACT ? (const float *)nullptr : a.psf_sums, a.flag, idx);
-    }
-    unsigned long long b = __ballot(act);
-    if (act) {
-      PixelState P = pixel_setup(S, vg, px, py);
-      const float sume = a.psf_sums[idx];
-      const float ss = a.simslices[idx];
-      float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * a.scales[sl] : a.slices[idx] * a.scales[sl];
-      float f1;
-      if (ta.gauss) {                                          // RC.cu:278-282
-        f1 = 1.0f / sume;
-      } else {
-        e = (ss > 0.0f) ? (e - ss) : 0.0f;                     // RC.cu:439-447
-        f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
-      }
-      PixelRec R;
-      R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
-      sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
-      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
-      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
-      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
-    }
-    if (lane == 0) sh_npix = __popcll(b);
-  }
-  __syncthreads();
-  const int npix = sh_npix;
-  // The box is kept in UNSATURATED coordinates: x spans every tap position (also negative ones and
-  // ones beyond the volume), y/z are clipped at the high end only.  The float->uint saturation of
-  // the reference (negative -> 0, RC.cu:508) is applied once per box voxel at flush time, which
-  // sums exactly the taps that alias; taps beyond the high end are dropped (RC.cu:509).
-  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
-  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vg.vy - 1);
-  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vg.vz - 1);
-  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
-  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
-  const int Px = Dx | 1;                                // odd x pitch: 16 y rows -> 16 distinct banks
-  const int Pxy = Px * Dy;
-  const bool fast = Dz <= PLANE_SLOTS && (long long)Pxy * Dz <= (long long)ta.cap;
-  if (!fast) {
-    if (threadIdx.x == 0) fallback_tiles[atomicAdd(fallback_count, 1u)] = t;
-    return;
-  }
-  const int vox = Pxy * Dz;
-  float *t_addon = tile, *t_cmap = tile + ta.cap;
-  for (int i = threadIdx.x; i < vox; i += PLANE_WAVES * 64) { t_addon[i] = 0.0f; t_cmap[i] = 0.0f; }
-  if ((int)threadIdx.x < Dz) {
-    // (pixel, z) units landing on absolute plane loz + threadIdx.x, in pixel order
-    const int P = loz + (int)threadIdx.x;
-    int c = 0;
-    for (int k = 0; k < npix; ++k) {
-      const int z = P - sh_px[k].cz + NC;
-      if (z >= 0 && z < NS) sh_list[threadIdx.x][c++] = (unsigned char)k;
-    }
-    sh_cnt[threadIdx.x] = c;
-  }
-  __syncthreads();
-
-  const RowConst RC = load_row_const(S);
-  const int slot = threadIdx.x >> 4;
-  const int y = lane & 15;
-  if (slot < Dz) {
-    const int P = loz + slot;                           // <= hiz < vz: plane in bounds
-    const int cnt = sh_cnt[slot];
-    float *pa = t_addon + slot * Pxy - lox, *pc = t_cmap + slot * Pxy - lox;
-    for (int i = 0; i < cnt; ++i) {
-      const PixelRec R = sh_px[sh_list[slot][i]];
-      const int z = P - R.cz + NC;
-      const int ay = R.cy + y - NC;                     // may be negative: aliases to 0 at flush
-      const bool rowok = y < NS && ay < vg.vy;
-      const int rb = rowok ? (ay - loy) * Px + R.cx - NC : 0;
-      // the row's 16 accumulators are fetched before the PSF evaluation (their LDS latency hides
-      // behind ~1200 ALU instructions) and written back after it; all 16 x positions are inside the
-      // box by construction, so the read-add-write is unconditional (skipped taps add 0)
-      float va[NS], vc[NS];
-      if (rowok) {
-#pragma unroll
-        for (int x = 0; x < NS; ++x) { va[x] = pa[rb + x]; vc[x] = pc[rb + x]; }
-      }
-      float out[NS];
-      eval_row_t<NS, PVR>(RC, R.bx, R.by, R.bz, (float)(y - NC), (float)(z - NC), out);
-      if (rowok) {
-#pragma unroll
-        for (int x = 0; x < NS; ++x) {
-          const float v = (out[x] < 0.0f) ? 0.0f : out[x];
-          pa[rb + x] = va[x] + v * R.f0;
-          pc[rb + x] = vc[x] + v * R.f1;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  BoxWalk bw;
-  bw.init(threadIdx.x, PLANE_WAVES * 64, Px, Pxy);
-  for (int i = threadIdx.x; i < vox; i += PLANE_WAVES * 64, bw.step()) {
-    const float c = t_cmap[i], ad = t_addon[i];
-    if (c != 0.0f || ad != 0.0f) {
-      const int z = bw.z, yy = bw.y, xx = bw.x;
-      const int gx = xx + lox;
-      if (gx < vg.vx) {                                  // beyond the high end: out of bounds
-        const uint32_t vi = sat0(gx) + sat0(yy + loy) * (uint32_t)vg.vx +
-                            sat0(z + loz) * (uint32_t)(vg.vx * vg.vy);
-        if (a.mask[vi] != 0.0f) {
-          unsafeAtomicAdd(a.addon + vi, ad);
-          unsafeAtomicAdd(a.cmap + vi, c);
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // Slot-owned back-projection with dead-unit shortcut: the production scatter of round 2
 // ------------------------------------------------------------------------------------------
-// Ownership as in back_plane_kernel -- a 16-lane slot owns one absolute plane of the tile's box, its lanes are the 16
+// Ownership: a 16-lane slot owns one absolute plane of the tile's box, its lanes are the 16
 // rows of the (pixel, plane offset) unit it is working on, so the accumulation is a plain LDS read-add-write -- plus:
 //  * OWNED AXIS PER SLICE.  The planes are y- or z-planes of the volume, whichever axis is closer to the slice normal
 //    (SliceConst::own); the lanes run over the other one.  Rows are along x either way (the epsilon-skip chain runs
@@ -1117,7 +959,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SVR_
   }
   __syncthreads();
   const int npix = sh_npix;
-  // unsaturated box coordinates as in back_plane_kernel: negative positions alias to 0 at flush time (RC.cu:508),
+  // unsaturated box coordinates: negative positions alias to 0 at flush time (RC.cu:508),
   // positions beyond the high end are dropped (RC.cu:509)
   const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
   const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vgy - 1);
@@ -1578,22 +1420,6 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// LDS-tiled forward projection (simulateSlicesKernel3D_tex RC.cu:298-404): the production gather
-// ------------------------------------------------------------------------------------------
-// Same tile box as the scatter (unsaturated coordinates, saturation applied when the box is
-// filled), holding the masked volume: V where the voxel is in bounds and mask != 0, a sentinel bit
-// pattern otherwise.  A gather has no write conflicts, so every wave takes whole pixels
-// (lane = (y,z) row, as in Phase 1) and reads its row's 16 box words straight from the
-// row-per-lane layout -- no LDS transposition, no per-tap global loads, no Phase 2.
-#define FWD_WAVES 8
-#define FWD_SENTINEL 0xFFFFFFFFu      // never produced by arithmetic (canonical NaNs are 0x7fc00000 / 0xffc00000)
-
-#define FWD_MASKED 0xFFFFFFFEu        // Gaussian pass 1: voxel in bounds but outside the mask
-// GAUSS1 = true turns the same walk into pass 1 of gaussianReconstructionKernel3D_tex (RC.cu:228-258):
-// sume over processed in-bounds taps (no mask), the `sume > 0.5` gate, v_PSF_sums, and the
-// sliceVoxel_count flag (any processed tap on an in-mask voxel, RC.cu:283-294); the box then only
-// encodes {out of bounds, masked, in mask}.
 // getReconValueFromTexture (R2/reconVolume.cu:170-187): linear filter at the un-offset coordinate =
 // 0.125 * sum over {p-1,p}^3 with zero border
 __device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, int X, int Y, int Z) {
@@ -1609,321 +1435,6 @@ __device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, in
         v += 0.125f * t;
       }
   return v;
-}
-
-// ROWS = true: per pixel the 256 (y,z) rows are first classified (row_is_dead); rows outside the volume
-// are dropped, dead rows get only their first tap evaluated, live rows all 16.  A wavefront then works
-// on FOUR pixels at once, 16 lanes each, every lane group walking its pixel's compacted row lists --
-// so the work per pixel is (live rows) x 16 + (dead rows) x 2 taps instead of 256 x 16.
-// register budget: 8 waves per SIMD for the plain gather (64 VGPRs, what it needs anyway), 6 for the
-// row-list variant, whose per-lane pixel state does not fit 64 (measured: 8 -> 9.7 ms, 6 -> 5.4, 5 -> 5.5, 4 -> 6.0)
-// NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: evaluator, texture-averaged volume read
-// (R2/reconVolume.cu:170-187), pass-1 gate sume > 1e-5 or NaN and superpixel test (R2/patchBasedPSFReconstruction_gpu.cu:95-110)
-template <bool GAUSS1, bool ROWS, int NS = PSF_SUPPORT, bool PVR = false>
-__global__ __launch_bounds__(FWD_WAVES * 64) __attribute__((amdgpu_waves_per_eu(ROWS ? SVR_WPE_ROWS : SVR_WPE_PLAIN, ROWS ? SVR_WPE_ROWS : SVR_WPE_PLAIN)))
-void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
-  constexpr bool GAUSS1_ACT = GAUSS1;
-  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
-  static_assert(!ROWS || (NS == PSF_SUPPORT && !PVR), "row lists are built for the SVR support");
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // masked volume box [cap] (+ row lists)
-  __shared__ int sh_lo[3], sh_hi[3];
-  __shared__ PixelRec sh_px[64];
-  __shared__ uint32_t sh_idx[64];
-  __shared__ int sh_npix;
-  const int TILE_W = ta.tw, TILE_H = ta.th;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const VolGeom &vg = a.vg;
-  const uint32_t t = ta.tiles[blockIdx.x];
-  const int per_slice = ta.tiles_x * ta.tiles_y;
-  const uint32_t sl = t / per_slice;
-  const int r = t - sl * per_slice;
-  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
-  const SliceConst &S = a.sc[sl];
-  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
-
-  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
-  __syncthreads();
-  if (wave == 0) {
-    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
-    bool act = false;
-    uint32_t idx = 0;
-    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
-      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = pixel_active(a.slices, GAUSS1_ACT ? (const float *)nullptr : a.psf_sums, a.flag, idx);
-    }
-    unsigned long long b = __ballot(act);
-    if (act) {
-      PixelState P = pixel_setup(S, vg, px, py);
-      PixelRec R;
-      R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz;
-      R.f1 = GAUSS1 ? 0.0f : 1.0f / a.psf_sums[idx]; R.f0 = 0.0f;
-      const int k = __popcll(b & ((1ull << lane) - 1ull));
-      sh_px[k] = R;
-      sh_idx[k] = idx;
-      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
-      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
-      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
-    }
-    if (lane == 0) sh_npix = __popcll(b);
-  }
-  __syncthreads();
-  const int npix = sh_npix;
-  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
-  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vg.vy - 1);
-  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vg.vz - 1);
-  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
-  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // nothing in bounds: no pixel gets a weight > 0
-  const int Px = Dx | 1;
-  const int Pxy = Px * Dy + ((Px * Dy) & 1 ? 0 : 1);    // odd plane pitch as well: rows of 4 planes spread over banks
-  const bool in_lds = (long long)Pxy * Dz <= (long long)ta.cap;
-  const uint32_t sxy = (uint32_t)(vg.vx * vg.vy);
-  if (in_lds) {
-    const int vox = Pxy * Dz;
-    BoxWalk bw;
-    bw.init(threadIdx.x, FWD_WAVES * 64, Px, Pxy);
-    for (int i = threadIdx.x; i < vox; i += FWD_WAVES * 64, bw.step()) {
-      const int z = bw.z, yy = bw.y, xx = bw.x;
-      const int gx = xx + lox;
-      uint32_t bits = FWD_SENTINEL;
-      if (yy < Dy && xx < Dx && gx < vg.vx) {
-        const uint32_t vi = sat0(gx) + sat0(yy + loy) * (uint32_t)vg.vx + sat0(z + loz) * sxy;
-        if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
-        else if (a.mask[vi] != 0.0f)
-          bits = __float_as_uint(PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(yy + loy), (int)sat0(z + loz)) : a.vol[vi]);
-      }
-      reinterpret_cast<uint32_t *>(tile)[i] = bits;
-    }
-  }
-  __syncthreads();
-
-  const RowConst RC = load_row_const(S);
-  if (ROWS) {
-    unsigned char *rowlist = reinterpret_cast<unsigned char *>(tile + ta.cap);   // [tw*th][256]: live from the front, dead from the back
-    const int g = lane >> 4, i = lane & 15;
-    for (int base = 4 * wave; base < npix; base += 4 * FWD_WAVES) {
-      const int k = base + g;
-      const bool pix = k < npix;
-      const PixelRec R = sh_px[pix ? k : base];
-      unsigned char *mine = rowlist + 256 * (pix ? k : base);
-      int nl = 0, nd = 0;
-      for (int z = 0; z < 16; ++z) {                      // lane i classifies row (y = i, z)
-        const int ay = R.cy + i - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
-        const bool inb = pix && ay < vg.vy && az < vg.vz;  // negatives alias to 0: always "in bounds"
-        const bool dead = inb && row_is_dead(RC, R.bx, R.by, R.bz, (float)(i - PSF_CENTRE), (float)(z - PSF_CENTRE));
-        const bool live = inb && !dead;
-        const uint32_t ml = (uint32_t)(__ballot(live) >> (16 * g)) & 0xFFFFu;
-        const uint32_t md = (uint32_t)(__ballot(dead) >> (16 * g)) & 0xFFFFu;
-        const uint32_t below = (1u << i) - 1u;
-        if (live) mine[nl + __popc(ml & below)] = (unsigned char)(16 * z + i);
-        if (dead) mine[255 - (nd + __popc(md & below))] = (unsigned char)(16 * z + i);
-        nl += __popc(ml);
-        nd += __popc(md);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int nlmax = max(max(__shfl(nl, 0), __shfl(nl, 16)), max(__shfl(nl, 32), __shfl(nl, 48)));
-      const int ndmax = max(max(__shfl(nd, 0), __shfl(nd, 16)), max(__shfl(nd, 32), __shfl(nd, 48)));
-      float f0 = 0.0f, f1 = 0.0f;
-      double acc = 0.0;
-      bool hit = false;
-      const int cb = R.cx - PSF_CENTRE - lox;
-      for (int r0 = 0; r0 < nlmax; r0 += 16) {            // live rows: all 16 taps
-        const bool valid = r0 + i < nl;
-        const int row = valid ? mine[r0 + i] : 0;
-        const int y = row & 15, z = row >> 4;
-        const int ay = R.cy + y - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
-        uint32_t vb[16];
-        if (in_lds) {
-          const int rb = valid ? (ay - loy) * Px + (az - loz) * Pxy + cb : 0;
-#pragma unroll
-          for (int x = 0; x < 16; ++x) vb[x] = reinterpret_cast<const uint32_t *>(tile)[rb + x];
-        } else {
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            const int gx = R.cx + x - PSF_CENTRE;
-            uint32_t bits = FWD_SENTINEL;
-            if (valid && gx < vg.vx) {
-              const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
-              if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
-              else if (a.mask[vi] != 0.0f) bits = __float_as_uint(a.vol[vi]);
-            }
-            vb[x] = bits;
-          }
-        }
-        float out[16];
-        eval_row_at(RC, R.bx, R.by, R.bz, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE), out);
-        if (valid) {
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            if (GAUSS1) {
-              if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
-                acc += (double)out[x];
-                hit = hit || vb[x] == 1u;
-              }
-            } else if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
-              const float p = out[x] * R.f1;
-              f0 += p * __uint_as_float(vb[x]);
-              f1 += p;
-              hit = true;
-            }
-          }
-        }
-      }
-      for (int r0 = 0; r0 < ndmax; r0 += 128) {           // dead rows: only the first tap is processed, 8 rows per lane
-        f2 xs[4], ys[4], zs[4], t0[4];
-        uint32_t v0[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int p = r0 + 16 * j + i;
-          const bool valid = p < nd;
-          const int row = valid ? mine[255 - p] : 0;
-          const int y = row & 15, z = row >> 4;
-          const int ay = R.cy + y - PSF_CENTRE, az = R.cz + z - PSF_CENTRE;
-          uint32_t v = FWD_SENTINEL;
-          if (valid) {
-            if (in_lds) {
-              v = reinterpret_cast<const uint32_t *>(tile)[(ay - loy) * Px + (az - loz) * Pxy + cb];
-            } else if (R.cx - PSF_CENTRE < vg.vx) {
-              const uint32_t vi = sat0(R.cx - PSF_CENTRE) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
-              if (GAUSS1) v = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
-              else if (a.mask[vi] != 0.0f) v = __float_as_uint(a.vol[vi]);
-            }
-          }
-          v0[j] = v;
-          const float fy = (float)(y - PSF_CENTRE), fz = (float)(z - PSF_CENTRE);
-          const float rowx = __builtin_fmaf(RC.Lp[1], fy, __builtin_fmaf(RC.Lp[2], fz, R.bx));
-          const float rowy = __builtin_fmaf(RC.Lp[4], fy, __builtin_fmaf(RC.Lp[5], fz, R.by));
-          const float rowz = __builtin_fmaf(RC.Lp[7], fy, __builtin_fmaf(RC.Lp[8], fz, R.bz));
-          const float x1 = __builtin_fmaf(RC.Lp[0], (float)(-PSF_CENTRE), rowx);
-          const float y1 = __builtin_fmaf(RC.Lp[3], (float)(-PSF_CENTRE), rowy);
-          if (j & 1) { xs[j >> 1].y = x1; ys[j >> 1].y = y1; zs[j >> 1].y = rowz; }
-          else { xs[j >> 1].x = x1; ys[j >> 1].x = y1; zs[j >> 1].x = rowz; }
-        }
-        eval_pairs_xyz<4, false>(RC, xs, ys, t0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t0[q] = t0[q] * gauss_first_tap2<PSF_CENTRE>(RC, zs[q]);   // zs holds the rows' z'_0
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float o0 = (j & 1) ? t0[j >> 1].y : t0[j >> 1].x;   // always processed: |FLT_MAX - v| is not <= eps
-          if (v0[j] != FWD_SENTINEL) {
-            if (GAUSS1) {
-              acc += (double)o0;
-              hit = hit || v0[j] == 1u;
-            } else {
-              const float p = o0 * R.f1;
-              f0 += p * __uint_as_float(v0[j]);
-              f1 += p;
-              hit = true;
-            }
-          }
-        }
-      }
-      // reduce over the 16 lanes of the pixel's group
-      const bool inside = ((uint32_t)(__ballot(hit) >> (16 * g)) & 0xFFFFu) != 0u;
-      if (GAUSS1) {
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        const float sume = (float)acc;
-        if (pix && i == 0) {
-          const uint32_t idx = sh_idx[k];
-          const bool pass = sume > 0.5f;
-          a.flag_out[idx] = pass ? 1 : 0;
-          if (pass) {
-            a.psf_sums[idx] = sume;
-            if (inside) a.voxcount[idx] = 1;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { f0 += __shfl_xor(f0, off); f1 += __shfl_xor(f1, off); }
-        if (pix && i == 0 && f1 > 0.0f) {
-          const uint32_t idx = sh_idx[k];
-          a.simslices[idx] = f0 / f1;
-          a.simweights[idx] = f1;
-          a.siminside[idx] = inside ? 1 : 0;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    return;
-  }
-  for (int k = wave; k < npix; k += FWD_WAVES) {
-    const PixelRec R = sh_px[k];
-    float f0 = 0.0f, f1 = 0.0f;
-    double acc = 0.0;
-    bool hit = false;
-    for (int q = 0; q < (NS + 3) / 4; ++q) {
-      const int z = 4 * q + (lane >> 4), y = lane & 15;
-      const int ay = R.cy + y - NC, az = R.cz + z - NC;
-      const bool rowok = y < NS && z < NS && ay < vg.vy && az < vg.vz;   // negatives alias to 0: always "in bounds"
-      uint32_t vb[NS];
-      if (in_lds) {
-        const int rb = rowok ? (ay - loy) * Px + (az - loz) * Pxy + R.cx - NC - lox : 0;
-#pragma unroll
-        for (int x = 0; x < NS; ++x) vb[x] = reinterpret_cast<const uint32_t *>(tile)[rb + x];
-      } else {
-#pragma unroll
-        for (int x = 0; x < NS; ++x) {
-          const int gx = R.cx + x - NC;
-          uint32_t bits = FWD_SENTINEL;
-          if (rowok && gx < vg.vx) {
-            const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
-            if (GAUSS1) bits = (a.mask[vi] != 0.0f) ? 1u : FWD_MASKED;
-            else if (a.mask[vi] != 0.0f)
-              bits = __float_as_uint(PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(ay), (int)sat0(az)) : a.vol[vi]);
-          }
-          vb[x] = bits;
-        }
-      }
-      float out[NS];
-      eval_row_t<NS, PVR>(RC, R.bx, R.by, R.bz, (float)(y - NC), (float)(z - NC), out);
-      // the per-tap branch pays: most taps are epsilon-skipped and the whole wave jumps over the body
-      // (a branch-free version measured 6.7 vs 5.9 ms on P4)
-      if (rowok) {
-#pragma unroll
-        for (int x = 0; x < NS; ++x) {
-          if (GAUSS1) {
-            if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
-              acc += (double)out[x];                       // RC.cu:241-245 (no mask test)
-              hit = hit || vb[x] == 1u;
-            }
-          } else if (!(out[x] < 0.0f) && vb[x] != FWD_SENTINEL) {
-            const float p = out[x] * R.f1;               // psf / sume
-            f0 += p * __uint_as_float(vb[x]);
-            f1 += p;
-            hit = true;
-          }
-        }
-      }
-    }
-    const bool inside = __ballot(hit) != 0ull;
-    const uint32_t idx = sh_idx[k];
-    if (GAUSS1) {
-      float sume = (float)wave_sum(acc);
-      bool pass = sume > 0.5f;                             // also drops NaN (RC.cu:251-258)
-      if (PVR) {
-        const uint32_t rem = idx % (uint32_t)(a.sx * a.sy);
-        const uint32_t ppx = rem % (uint32_t)a.sx, ppy = rem / (uint32_t)a.sx;
-        if (a.spx && a.spx[(size_t)sl * 4096 + ppx + 64 * ppy] != '1') sume = 0.0f;   // superpixel test of pass 1
-        pass = (sume > 0.00001f) || (sume != sume);
-      }
-      if (lane == 0) {
-        a.flag_out[idx] = pass ? 1 : 0;
-        if (pass) {
-          a.psf_sums[idx] = sume;
-          if (inside) a.voxcount[idx] = 1;                 // RC.cu:291-294
-        }
-      }
-    } else {
-      const float sim = wave_sum(f0), w = wave_sum(f1);
-      if (lane == 0 && w > 0.0f) {                         // RC.cu:398-403
-        a.simslices[idx] = sim / w;
-        a.simweights[idx] = w;
-        a.siminside[idx] = inside ? 1 : 0;
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1945,9 +1456,13 @@ void fwd_tile_kernel(PsfArgs a, TileArgs ta) {
 // Registers: no accumulator array, the row's 16 values and the packed evaluator: ~90 VGPRs, no scratch.
 #define FWDU_WAVES 8
 #define FWDU_MAXPIX 32     // pixels of a tile (8 x 4 at most)
-template <bool GAUSS1>
+// NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: the evaluator's sinc_pi branch, the volume read through the
+// 8-voxel texture average of getReconValueFromTexture (R2/reconVolume.cu:170-187), pass-1 gate `sume > 1e-5 or NaN` with the superpixel
+// test (R2/patchBasedPSFReconstruction_gpu.cu:95-110); no dead-unit shortcut (the bound is derived for the SVR constants).
+template <bool GAUSS1, int NS = PSF_SUPPORT, bool PVR = false>
 __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, TileArgs ta) {
-  constexpr int NS = PSF_SUPPORT, NC = PSF_CENTRE, NH = NS - 1 - NC;
+  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;
+  constexpr int US = 16;                                // stride of the per-pixel unit tables (k << 4 | u)
   constexpr int T = FWDU_WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float tile[];
   f2 *box = reinterpret_cast<f2 *>(tile);               // {V m, m} (GAUSS1: {in bounds, in mask}) per box voxel [z][y][x]
@@ -1955,9 +1470,9 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
   __shared__ PixelRec sh_px[FWDU_MAXPIX];
   __shared__ uint32_t sh_idx[FWDU_MAXPIX];
   __shared__ uint32_t sh_dead[FWDU_MAXPIX];                      // bit u: unit (pixel, u) is dead
-  __shared__ unsigned short sh_units[FWDU_MAXPIX * NS];          // (pixel << 4 | u): live units from the front, dead units from the back
-  __shared__ f2 sh_part[FWDU_MAXPIX * NS];                       // per unit {sum psf V, sum psf}
-  __shared__ double sh_partd[GAUSS1 ? FWDU_MAXPIX * NS : 1];     // GAUSS1: per unit sume in double
+  __shared__ unsigned short sh_units[FWDU_MAXPIX * US];          // (pixel << 4 | u): live units from the front, dead units from the back
+  __shared__ f2 sh_part[FWDU_MAXPIX * US];                       // per unit {sum psf V, sum psf}
+  __shared__ double sh_partd[GAUSS1 ? FWDU_MAXPIX * US : 1];     // GAUSS1: per unit sume in double
   __shared__ uint32_t sh_hit[FWDU_MAXPIX];                       // bit u: unit (pixel, u) had a processed tap on a mask voxel
   __shared__ int sh_npix, sh_nlive, sh_ndead;
   const int TILE_W = ta.tw, TILE_H = ta.th;
@@ -2025,7 +1540,8 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       if (bw.y < Dy && bw.x < Dx && gx < vg.vx) {
         const uint32_t vi = sat0(gx) + sat0(bw.y + loy) * (uint32_t)vg.vx + sat0(bw.z + loz) * sxy;
         const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-        v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
+        v = GAUSS1 ? (f2){1.0f, m}
+                   : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(bw.y + loy), (int)sat0(bw.z + loz)) : a.vol[vi]) : 0.0f, m};
       }
       box[i] = v;
     }
@@ -2038,16 +1554,16 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     const int cu = swap ? R.cy : R.cz;
     const bool inb = cu + u - NC < (swap ? vg.vy : vg.vz);      // negatives alias to 0: "in bounds"
     if (inb) {
-      const bool dead = ta.dbg != 4 && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(u - NC));
+      const bool dead = !PVR && ta.dbg != 4 && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(u - NC));
       if (dead) {
         atomicOr(&sh_dead[k], 1u << u);
-        sh_units[FWDU_MAXPIX * NS - 1 - atomicAdd(&sh_ndead, 1)] = (unsigned short)(k << 4 | u);
+        sh_units[FWDU_MAXPIX * US - 1 - atomicAdd(&sh_ndead, 1)] = (unsigned short)(k << 4 | u);
       } else {
         sh_units[atomicAdd(&sh_nlive, 1)] = (unsigned short)(k << 4 | u);
       }
     } else {
-      sh_part[k * NS + u] = (f2){0.0f, 0.0f};
-      if (GAUSS1) sh_partd[k * NS + u] = 0.0;
+      sh_part[k * US + u] = (f2){0.0f, 0.0f};
+      if (GAUSS1) sh_partd[k * US + u] = 0.0;
     }
   }
   __syncthreads();
@@ -2067,9 +1583,9 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     const PixelRec R = sh_px[k];
     const float fu = (float)(u - NC);
     const int ay = R.cy + (swap ? u : y) - NC, az = R.cz + (swap ? y : u) - NC;
-    const bool rowok = valid && ay < vg.vy && az < vg.vz;      // negatives alias to 0: always "in bounds"
+    const bool rowok = valid && y < NS && ay < vg.vy && az < vg.vz;      // negatives alias to 0: always "in bounds"
     float out[NS];
-    eval_row_t<NS, false, true>(RC, R.bx, R.by, R.bz, swap ? fu : fyl, swap ? fyl : fu, out);
+    eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fu : fyl, swap ? fyl : fu, out);
     f2 acc = (f2){0.0f, 0.0f};
     double accd = 0.0;
     bool hit = false;
@@ -2095,7 +1611,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
         if (rowok && gx < vg.vx) {
           const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
           const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-          v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
+          v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(ay), (int)sat0(az)) : a.vol[vi]) : 0.0f, m};
         }
         if (GAUSS1) {
           accd += (double)(out[x] * v.x);
@@ -2115,18 +1631,18 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     if (GAUSS1) {
       const bool anyhit = ((uint32_t)(__ballot(hit) >> (16 * slot)) & 0xFFFFu) != 0u;
       if (valid && y == 0) {
-        sh_partd[k * NS + u] = accd;
+        sh_partd[k * US + u] = accd;
         if (anyhit) atomicOr(&sh_hit[k], 1u << u);
       }
     } else if (valid && y == 0) {
-      sh_part[k * NS + u] = acc;
+      sh_part[k * US + u] = acc;
     }
   }
   // ---- dead units: the first tap of every row, two units per pass ------------------------------------------
-  for (int j0 = wave * 8; j0 < ndead; j0 += FWDU_WAVES * 8) {
+  for (int j0 = wave * 8; !PVR && j0 < ndead; j0 += FWDU_WAVES * 8) {
     const int ja = j0 + 2 * slot, jb = ja + 1;
     const bool va = ja < ndead, vb = jb < ndead;
-    const int kua = sh_units[FWDU_MAXPIX * NS - 1 - (va ? ja : j0)], kub = sh_units[FWDU_MAXPIX * NS - 1 - (vb ? jb : j0)];
+    const int kua = sh_units[FWDU_MAXPIX * US - 1 - (va ? ja : j0)], kub = sh_units[FWDU_MAXPIX * US - 1 - (vb ? jb : j0)];
     const PixelRec Ra = sh_px[kua >> 4], Rb = sh_px[kub >> 4];
     const float fua = (float)((kua & 15) - NC), fub = (float)((kub & 15) - NC);
     const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
@@ -2140,7 +1656,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
     ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
     eval_pairs_xyz<1, false>(RC, xs, ys, t0);
-    const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);        // always processed: |FLT_MAX - v| is not <= eps
+    const f2 v = t0[0] * gauss_first_tap2<PSF_CENTRE>(RC, rowz);   // always processed: |FLT_MAX - v| is not <= eps (SVR only)
     f2 wa = (f2){0.0f, 0.0f}, wb = (f2){0.0f, 0.0f};
     {
       const int aya = Ra.cy + (int)fya, aza = Ra.cz + (int)fza, ayb = Rb.cy + (int)fyb, azb = Rb.cz + (int)fzb;
@@ -2175,11 +1691,11 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     const bool anyb = GAUSS1 && ((uint32_t)(__ballot(hitb) >> (16 * slot)) & 0xFFFFu) != 0u;
     if (y == 0) {
       if (va) {
-        if (GAUSS1) sh_partd[(kua >> 4) * NS + (kua & 15)] = da; else sh_part[(kua >> 4) * NS + (kua & 15)] = acca;
+        if (GAUSS1) sh_partd[(kua >> 4) * US + (kua & 15)] = da; else sh_part[(kua >> 4) * US + (kua & 15)] = acca;
         if (anya) atomicOr(&sh_hit[kua >> 4], 1u << (kua & 15));
       }
       if (vb) {
-        if (GAUSS1) sh_partd[(kub >> 4) * NS + (kub & 15)] = db; else sh_part[(kub >> 4) * NS + (kub & 15)] = accb;
+        if (GAUSS1) sh_partd[(kub >> 4) * US + (kub & 15)] = db; else sh_part[(kub >> 4) * US + (kub & 15)] = accb;
         if (anyb) atomicOr(&sh_hit[kub >> 4], 1u << (kub & 15));
       }
     }
@@ -2192,9 +1708,15 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     const bool inside = sh_hit[k] != 0u;
     if (GAUSS1) {
       double sd = 0.0;
-      for (int u = 0; u < NS; ++u) sd += sh_partd[k * NS + u];
-      const float sume = (float)sd;
-      const bool pass = sume > 0.5f;                          // also drops NaN (RC.cu:251-258)
+      for (int u = 0; u < NS; ++u) sd += sh_partd[k * US + u];
+      float sume = (float)sd;
+      bool pass = sume > 0.5f;                                // also drops NaN (RC.cu:251-258)
+      if (PVR) {
+        const uint32_t rem = idx % (uint32_t)(a.sx * a.sy);
+        const uint32_t ppx = rem % (uint32_t)a.sx, ppy = rem / (uint32_t)a.sx;
+        if (a.spx && a.spx[(size_t)sl * 4096 + ppx + 64 * ppy] != '1') sume = 0.0f;   // superpixel test of pass 1
+        pass = (sume > 0.00001f) || (sume != sume);
+      }
       a.flag_out[idx] = pass ? 1 : 0;
       if (pass) {
         a.psf_sums[idx] = sume;
@@ -2202,7 +1724,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       }
     } else {
       f2 sm = (f2){0.0f, 0.0f};
-      for (int u = 0; u < NS; ++u) sm = sm + sh_part[k * NS + u];
+      for (int u = 0; u < NS; ++u) sm = sm + sh_part[k * US + u];
       const float w = sm.y * sh_px[k].f1;                     // sum psf / sume
       if (w > 0.0f) {                                         // RC.cu:398-403
         a.simslices[idx] = sm.x / sm.y;
@@ -3021,28 +2543,19 @@ struct svr_ctx {
            *d_tiles_fb = nullptr;
   uint32_t n_active = 0, n_psf = 0, n_tiles = 0;
   int tiles_x = 0, tiles_y = 0, tile_w = 4, tile_h = 4;
-  int plane_waves = 8;      // waves per workgroup of back_plane_kernel (4 planes each)
-  int plane_cap = 9600;     // LDS accumulator voxels of back_plane_kernel: 75 KiB + 4.3 KiB static
   int pvr_reg_levels = 3, pvr_reg_steps = 4, pvr_reg_iterations = 20;   // PatchBased2D3DRegistration_gpu2 schedule (tests shorten it)
-                            // -> exactly 2 workgroups per CU (measured: 1 per CU is 1.6x slower)
   bool psf_list_valid = false;
   unsigned char *d_gauss_flag = nullptr;   // pixels whose sume passed in the current Gaussian pass
   uint32_t *d_tiles_tmp = nullptr;         // tile list of the Gaussian passes
   size_t tiles_tmp_cap = 0;                // its capacity in tiles (the tile shapes can change between calls)
-  int gauss_mode = 1;                      // 1 = tiled pass 1 + plane-owned scatter, 0 = psf_kernel<MODE_GAUSS>
-  uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_tile_kernel
+  int gauss_mode = 1;                      // 1 = unit-based pass 1 (fwd_unit_kernel<GAUSS1>) + the LDS scatter, 0 = psf_kernel<MODE_GAUSS>
+  uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_unit_kernel
   uint32_t n_tiles_fwd = 0;
-  uint32_t n_tiles_fwd_plain = 0;    // fwd_mode 3: d_tiles_fwd = [plain-gather tiles | row-list tiles]
-  std::vector<unsigned char> h_rows_sel;   // per slice: 1 = enough provably dead rows for the row-list gather
-  unsigned char *d_rows_sel = nullptr;
-  int fwd_tw = 8, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
+  int fwd_tw = 4, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
   int fwd_unit_cap = 9000;  // box voxels (float2) of fwd_unit_kernel: 70 KiB + 8 KiB static -> 2 workgroups of 8 waves per CU
-  int fwd_mode = 4;         // 4 = unit-based gather (fwd_unit_kernel); 3 = per slice: row-list gather where >= 25 % of the rows are epsilon-dead, else the
-                            // plain LDS-tiled gather; 2 / 1 = one of the two for every slice; 0 = wave-per-pixel kernel
-  int fwd_cap = 9216;       // box voxels: 36 KiB -> 4 workgroups of 8 waves per CU
-  // The forward tile shape that suits a problem depends on how many voxels a pixel spans: 8x4 pixels fill the box at ~1.2
-  // voxels per pixel, at 2 voxels per pixel (0.5 mm reconstructions of 1 mm pixels) their box no longer fits and every tap
-  // falls back to global loads (4x slower).  The first forward pass of a problem times the candidate shapes on the real data
+  int fwd_mode = 1;         // >= 1 = unit-based gather (fwd_unit_kernel), 0 = wave-per-pixel kernel (psf_kernel<MODE_FWD>)
+  // The forward tile shape that suits a problem depends on how many voxels a pixel spans: at 2 voxels per pixel (0.5 mm
+  // reconstructions of 1 mm pixels) the box of a 4x4 tile no longer fits the LDS and every tap falls back to global loads.  The first forward pass of a problem times the candidate shapes on the real data
   // and keeps the fastest; the results do not depend on the shape (per-pixel sums in a fixed order).
   bool fwd_tune_pending = true, fwd_tile_user = false;
   int fwd_autotune = 1;
@@ -3050,19 +2563,16 @@ struct svr_ctx {
   // back-projection after new slice geometry.  The scatter's sums are float atomics in run-dependent order with any shape.
   bool back_tune_pending = true, tile_user = false, in_tune = false;
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
-  int pvr_mode = 1;         // PVR kernels: 1 = the LDS-tiled gather / plane-owned scatter with support 12, 0 = wave-per-pixel
+  int pvr_mode = 1;         // PVR kernels: 1 = the unit-based gather / wave-owned scatter with support 12, 0 = wave-per-pixel (pvr_kernel)
   unsigned char *d_spx = nullptr;
-  int back_mode = 4;        // 4 = wave-owned LDS planes (back_wave_kernel), 3 = slot-owned LDS tiles with the dead-unit shortcut (back_slot_kernel), 2 = plane-owned LDS tiles (+ atomic fallback), 1 = LDS tiles with ds_add_f32,
-                            // 0 = direct device-scope atomics per tap
+  int back_mode = 4;        // 4 = wave-owned LDS planes (back_wave_kernel), 3 = the workgroup kernel for every tile (back_slot_kernel<8>),
+                            // 1 = LDS tiles with ds_add_f32 (back_tiled_kernel), 0 = direct device-scope atomics per tap (psf_kernel<MODE_BACK>)
   int tile_cap = 0;         // voxels of LDS accumulator per workgroup
   int dbg_back = 0;
   int dbg_fwd_lds = 0;      // dev experiment: extra dynamic LDS on the forward launch (limits occupancy)
   uint32_t n_tiles_fb = 0;
-  uint32_t n_tiles_fb8 = 0;   // tiles of the 5-wave scatter instance that were re-run with 8 waves (more planes than 20 slots / box too large)
-  uint32_t n_tiles_plain = 0; // d_tiles = [tiles of slices without epsilon-dead planes | tiles of slices with them]
+  uint32_t n_tiles_fb8 = 0;   // tiles of the last scatter that the wave-owned kernel handed to the workgroup kernel (box larger than wave_cap)
   uint32_t *d_tiles_fb2 = nullptr;
-  int slot_waves_a = 4, slot_cap_a = 5900;   // back_slot_kernel on slices with dead planes: 46 KiB + 5.8 KiB static -> 3 workgroups per CU
-  int slot_waves_b = 5, slot_cap_b = 9200;   // ... on the others (whole-box planes): 2 per CU
   bool wave_cap_user = false;
   int wave_groups = 1, wave_cap = 2116;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (4 x 23 x 23: 16.5 KiB)
 
@@ -3164,7 +2674,6 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_slice_inside); free_dev(c->d_sc); free_dev(c->d_active); free_dev(c->d_psf_list);
   free_dev(c->d_tiles);
   free_dev(c->d_tiles_fwd);
-  free_dev(c->d_rows_sel);
   free_dev(c->d_gauss_flag);
   free_dev(c->d_tiles_tmp);
   free_dev(c->d_tiles_fb);
@@ -3210,26 +2719,8 @@ int prepare_slice_consts(svr_ctx *ctx) {
       S.invD = fabsf(D) > 1e-4f ? 1.0f / D : 0.0f;
     }
   }
-  // which gather suits a slice: share of provably epsilon-dead rows of a pixel that sits on a voxel centre
-  ctx->h_rows_sel.assign(ctx->ns, 0);
-  for (uint32_t s = 0; s < ctx->ns && !ctx->pvr; ++s) {
-    RowConst R;
-    for (int i = 0; i < 9; ++i) R.Lp[i] = h[s].Lp[i];
-    R.inv2s2 = h[s].inv2s2;
-    R.dd = h[s].dd;
-    R.w = h[s].w;
-    R.invD = h[s].invD;
-    int dead = 0;
-    for (int z = 0; z < PSF_SUPPORT; ++z)
-      for (int y = 0; y < PSF_SUPPORT; ++y)
-        dead += row_is_dead(R, 0.0f, 0.0f, 0.0f, (float)(y - PSF_CENTRE), (float)(z - PSF_CENTRE)) ? 1 : 0;
-    ctx->h_rows_sel[s] = dead * 4 >= PSF_SUPPORT * PSF_SUPPORT ? 1 : 0;
-  }
-  if (!ctx->d_rows_sel) HIPCHK(hipMalloc(&ctx->d_rows_sel, ctx->ns));
-  HIPCHK(hipMemcpyAsync(ctx->d_rows_sel, ctx->h_rows_sel.data(), ctx->ns, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_sc, h.data(), h.size() * sizeof(SliceConst), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->psf_list_valid = false;          // the forward tile lists are split by h_rows_sel
   ctx->sc_dirty = false;
   return SVR_OK;
 }
@@ -3248,38 +2739,28 @@ int build_list(svr_ctx *ctx, bool with_psf) {
     ctx->psf_list_valid = true;
     // tiles of TILE_W x TILE_H pixels that hold at least one pixel of the list
     const uint32_t total = (uint32_t)ctx->tiles_x * ctx->tiles_y * ctx->ns;
-    uint32_t segb[2] = {0, 0};
-    for (int w = 0; w < 2; ++w) {                          // segment 0: slices without epsilon-dead planes, 1: with
-      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
-                         (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
-                         ctx->d_tiles + segb[0], ctx->d_counter, (const unsigned char *)ctx->d_rows_sel, w);
-      KCHK("k_build_tiles");
-      HIPCHK(hipMemcpyAsync(&segb[w], ctx->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    ctx->n_tiles_plain = segb[0];
-    ctx->n_tiles = n = segb[0] + segb[1];
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
+                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
+                       ctx->d_tiles, ctx->d_counter);
+    KCHK("k_build_tiles");
+    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_tiles = n;
     // forward tiles
     free_dev(ctx->d_tiles_fwd);
     ctx->fwd_tiles_x = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw);
     ctx->fwd_tiles_y = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
     const uint32_t total_f = (uint32_t)ctx->fwd_tiles_x * ctx->fwd_tiles_y * ctx->ns;
     HIPCHK(hipMalloc(&ctx->d_tiles_fwd, (size_t)total_f * sizeof(uint32_t)));
-    // segment 0: slices for the plain gather, segment 1: slices for the row-list gather
-    uint32_t seg[2] = {0, 0};
-    for (int w = 0; w < 2; ++w) {
-      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total_f, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
-                         (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->fwd_tiles_x,
-                         ctx->fwd_tiles_y, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_fwd + seg[0], ctx->d_counter,
-                         (const unsigned char *)ctx->d_rows_sel, w);
-      KCHK("k_build_tiles(fwd)");
-      HIPCHK(hipMemcpyAsync(&seg[w], ctx->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    ctx->n_tiles_fwd_plain = seg[0];
-    ctx->n_tiles_fwd = seg[0] + seg[1];
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total_f, 4)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
+                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->fwd_tiles_x,
+                       ctx->fwd_tiles_y, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_fwd, ctx->d_counter);
+    KCHK("k_build_tiles(fwd)");
+    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_tiles_fwd = n;
   } else {
     ctx->n_active = n;
   }
@@ -3365,82 +2846,60 @@ int ensure_psf_list(svr_ctx *ctx) {
   return SVR_OK;
 }
 
-// The slot-owned scatter over the tile list [seg0 | seg1] (seg1 = tiles of slices with epsilon-dead planes): seg1 with
-// `slot_waves_a` waves and a box of `slot_cap_a` voxels (4 waves, 3 workgroups per CU), seg0 with `slot_waves_b` /
-// `slot_cap_b`; tiles whose box did not fit are re-run with 8 waves and the largest box the CU can hold, the rest
-// (none on the workloads of BASELINE.json) with back_tiled_kernel's LDS atomics.
-int launch_slot(svr_ctx *ctx, int waves, const PsfArgs &a, const TileArgs &ta, uint32_t *fb, uint32_t *cnt) {
+// The scatter over a tile list (back-projection into addon|cmap, or pass 2 of the Gaussian reconstruction into
+// recon|volw): the wave-owned kernel with a box of `wave_cap` voxels; tiles whose planes do not fit it are re-run by the
+// workgroup kernel (8 wavefronts, the largest box the CU can hold); what fits neither -- strongly oblique tiles of very fine
+// volumes -- takes LDS atomics (SVR: back_tiled_kernel) or device atomics per tap (PVR: pvr_tiles_kernel).
+// level: 4 = start with the wave-owned kernel, 3 = with the workgroup kernel, 1 = the last resort for every tile.
+int launch_slot(svr_ctx *ctx, bool pvr, const PsfArgs &a, const TileArgs &ta, uint32_t *fb, uint32_t *cnt) {
   const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-#define LAUNCH_SLOT(NW) \
-  hipLaunchKernelGGL(back_slot_kernel<NW>, dim3(ta.ntiles), dim3(NW * 64), lds, ctx->stream, a, ta, fb, cnt)
-  switch (waves) {
-    case 4: LAUNCH_SLOT(4); break;
-    case 5: LAUNCH_SLOT(5); break;
-    case 6: LAUNCH_SLOT(6); break;
-    default: LAUNCH_SLOT(8); break;
-  }
-#undef LAUNCH_SLOT
+  if (pvr) hipLaunchKernelGGL((back_slot_kernel<8, PVR_N, true>), dim3(ta.ntiles), dim3(8 * 64), lds, ctx->stream, a, ta, fb, cnt);
+  else hipLaunchKernelGGL(back_slot_kernel<8>, dim3(ta.ntiles), dim3(8 * 64), lds, ctx->stream, a, ta, fb, cnt);
   KCHK("back_slot_kernel");
   return SVR_OK;
 }
-// back_mode 4: every tile with back_wave_kernel (one wavefront per four planes, `wave_groups` wavefronts per tile); tiles whose
-// planes do not fit `wave_cap` go to the 8-wave workgroup kernel with the largest box, the rest to back_tiled_kernel.
-int launch_wave_scatter(svr_ctx *ctx, const PsfArgs &a, TileArgs ta, const uint32_t *tiles, uint32_t n) {
-  uint32_t *cnt = ctx->d_counter;
+int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, const uint32_t *tiles, uint32_t n, int mode_last) {
+  PsfArgs a = a_;
+  const bool pvr = ctx->pvr != 0;
+  uint32_t *cnt = ctx->d_counter;                         // [0]: did not fit the wavefront's box, [1]: did not fit the workgroup's
   HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), ctx->stream));
+  ctx->n_tiles_fb8 = ctx->n_tiles_fb = 0;
   if (!n) return SVR_OK;
   int r;
-  ta.tiles = tiles; ta.ntiles = n; ta.cap = std::min(ctx->wave_cap, ctx->tile_cap);
-  hipLaunchKernelGGL(back_wave_kernel<>, dim3(n * (uint32_t)ctx->wave_groups), dim3(64), (size_t)ta.cap * 2 * sizeof(float),
-                     ctx->stream, a, ta, ctx->wave_groups, ctx->d_tiles_fb, cnt);
-  KCHK("back_wave_kernel");
   uint32_t nfb[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->n_tiles_fb8 = nfb[0];
-  if (nfb[0]) {
-    ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb[0]; ta.cap = ctx->tile_cap;
-    if ((r = launch_slot(ctx, 8, a, ta, ctx->d_tiles_fb2, cnt + 1))) return r;
+  const uint32_t *cur = tiles;
+  uint32_t ncur = n;
+  if (level >= 4) {
+    ta.tiles = cur; ta.ntiles = ncur; ta.cap = std::min(ctx->wave_cap, ctx->tile_cap);
+    const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
+    if (pvr) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
+                                ctx->wave_groups, ctx->d_tiles_fb, cnt);
+    else hipLaunchKernelGGL(back_wave_kernel<>, dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
+                            ctx->wave_groups, ctx->d_tiles_fb, cnt);
+    KCHK("back_wave_kernel");
     HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n_tiles_fb8 = nfb[0];
+    cur = ctx->d_tiles_fb; ncur = nfb[0];
   }
-  ctx->n_tiles_fb = nfb[1];
-  if (nfb[1]) {
-    ta.tiles = ctx->d_tiles_fb2; ta.ntiles = nfb[1]; ta.cap = ctx->tile_cap;
-    hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb[1]), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
-                       ctx->stream, a, ta);
-    KCHK("back_tiled_kernel(fallback)");
-  }
-  return SVR_OK;
-}
-int launch_slot_scatter(svr_ctx *ctx, const PsfArgs &a, TileArgs ta, const uint32_t *tiles, uint32_t n0, uint32_t n1) {
-  uint32_t *cnt = ctx->d_counter;                         // [0]: did not fit the first box, [1]: did not fit the largest
-  HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), ctx->stream));
-  int r;
-  if (n1) {
-    ta.tiles = tiles + n0; ta.ntiles = n1; ta.cap = std::min(ctx->slot_cap_a, ctx->tile_cap);
-    if ((r = launch_slot(ctx, ctx->slot_waves_a, a, ta, ctx->d_tiles_fb, cnt))) return r;
-  }
-  if (n0) {
-    ta.tiles = tiles; ta.ntiles = n0; ta.cap = std::min(ctx->slot_cap_b, ctx->tile_cap);
-    if ((r = launch_slot(ctx, ctx->slot_waves_b, a, ta, ctx->d_tiles_fb, cnt))) return r;
-  }
-  uint32_t nfb[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->n_tiles_fb8 = nfb[0];
-  if (nfb[0]) {
-    ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb[0]; ta.cap = ctx->tile_cap;
-    if ((r = launch_slot(ctx, 8, a, ta, ctx->d_tiles_fb2, cnt + 1))) return r;
+  if (ncur && level >= 3) {
+    ta.tiles = cur; ta.ntiles = ncur; ta.cap = ctx->tile_cap;
+    if ((r = launch_slot(ctx, pvr, a, ta, ctx->d_tiles_fb2, cnt + 1))) return r;
     HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    cur = ctx->d_tiles_fb2; ncur = nfb[1];
   }
-  ctx->n_tiles_fb = nfb[1];
-  if (nfb[1]) {
-    ta.tiles = ctx->d_tiles_fb2; ta.ntiles = nfb[1]; ta.cap = ctx->tile_cap;
-    hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb[1]), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
-                       ctx->stream, a, ta);
-    KCHK("back_tiled_kernel(fallback)");
+  if (level >= 3) ctx->n_tiles_fb = ncur;
+  if (ncur) {
+    ta.tiles = cur; ta.ntiles = ncur; ta.cap = ctx->tile_cap;
+    if (pvr) {
+      if (mode_last == MODE_GAUSS2) { a.recon = a.addon; a.volw = a.cmap; }
+      if (mode_last == MODE_GAUSS2) hipLaunchKernelGGL(pvr_tiles_kernel<MODE_GAUSS2>, dim3(ncur), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
+      else hipLaunchKernelGGL(pvr_tiles_kernel<MODE_BACK>, dim3(ncur), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
+    } else {
+      hipLaunchKernelGGL(back_tiled_kernel, dim3(ncur), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
+    }
+    KCHK("scatter (last resort)");
   }
   return SVR_OK;
 }
@@ -3497,49 +2956,17 @@ int svr_create(int device, svr_ctx **out) {
     (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     if (lds_max <= 0) lds_max = 65536;
     int dyn = lds_max - 1024;
-    dyn -= 8192;   // static LDS of back_plane_kernel (pixel table + plane lists)
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(back_tiled_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<false, false, PVR_N, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_tile_kernel<true, false, PVR_N, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<8, PVR_N, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_unit_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_unit_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_wave_kernel<>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<5>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<6>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_slot_kernel<8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<5>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<6>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<7>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(back_plane_kernel<8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) {
+    dyn -= 16384;  // static LDS of the kernels (pixel table, unit lists, partial sums: fwd_unit_kernel<GAUSS1> 14.6 KiB)
+    const void *big_lds[] = {reinterpret_cast<const void *>(back_tiled_kernel),
+                             reinterpret_cast<const void *>(fwd_unit_kernel<false>), reinterpret_cast<const void *>(fwd_unit_kernel<true>),
+                             reinterpret_cast<const void *>(fwd_unit_kernel<false, PVR_N, true>), reinterpret_cast<const void *>(fwd_unit_kernel<true, PVR_N, true>),
+                             reinterpret_cast<const void *>(back_wave_kernel<>), reinterpret_cast<const void *>(back_wave_kernel<PVR_N, true>),
+                             reinterpret_cast<const void *>(back_slot_kernel<8>), reinterpret_cast<const void *>(back_slot_kernel<8, PVR_N, true>)};
+    bool ok = true;
+    for (const void *f : big_lds) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
+    if (!ok) {
       (void)hipGetLastError();
-      dyn = 65536 - 1024 - 8192;   // the default 64 KiB minus the kernels' static LDS
+      dyn = 65536 - 1024 - 16384;  // the default 64 KiB minus the kernels' static LDS
     }
     ctx->tile_cap = dyn / (2 * (int)sizeof(float));
   }
@@ -3550,11 +2977,10 @@ int svr_create(int device, svr_ctx **out) {
 int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; return SVR_OK; }
-  if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }
+  if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
   if (!strcmp(name, "pvr_mode")) { ctx->pvr_mode = value; return SVR_OK; }
   if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_unit_cap")) { ctx->fwd_unit_cap = std::max(2048, value); return SVR_OK; }
-  if (!strcmp(name, "fwd_cap")) { ctx->fwd_cap = std::max(4096, value); return SVR_OK; }
   if (!strcmp(name, "fwd_tile_w") || !strcmp(name, "fwd_tile_h")) {
     int w = !strcmp(name, "fwd_tile_w") ? value : ctx->fwd_tw, h = !strcmp(name, "fwd_tile_h") ? value : ctx->fwd_th;
     if (w < 1 || h < 1 || w * h > 64) return fail(ctx, SVR_E_ARG, "fwd tile must hold 1..64 pixels");
@@ -3570,14 +2996,8 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; return SVR_OK; }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
-  if (!strcmp(name, "plane_waves")) { ctx->plane_waves = std::max(4, std::min(value, PLANE_MAX_WAVES)); return SVR_OK; }
-  if (!strcmp(name, "plane_cap")) { ctx->plane_cap = std::max(4096, value); return SVR_OK; }
-  if (!strcmp(name, "slot_cap_a")) { ctx->slot_cap_a = std::max(2048, value); return SVR_OK; }
-  if (!strcmp(name, "slot_cap_b")) { ctx->slot_cap_b = std::max(2048, value); return SVR_OK; }
   if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
   if (!strcmp(name, "wave_cap")) { ctx->wave_cap = std::max(1024, value); ctx->wave_cap_user = true; return SVR_OK; }
-  if (!strcmp(name, "slot_waves_a")) { ctx->slot_waves_a = value; return SVR_OK; }
-  if (!strcmp(name, "slot_waves_b")) { ctx->slot_waves_b = value; return SVR_OK; }
   if (!strcmp(name, "pvr_reg_levels")) { ctx->pvr_reg_levels = std::min(3, std::max(1, value)); return SVR_OK; }
   if (!strcmp(name, "pvr_reg_steps")) { ctx->pvr_reg_steps = std::max(1, value); return SVR_OK; }
   if (!strcmp(name, "pvr_reg_iterations")) { ctx->pvr_reg_iterations = std::max(1, value); return SVR_OK; }
@@ -3871,10 +3291,10 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   a.list = ctx->d_active;
   a.n = ctx->n_active;
   ScopedTimer t(ctx, SVR_T_GAUSS);
-  const bool pvr_tiled = ctx->pvr && ctx->pvr_mode == 1;
-  if (a.n && ctx->gauss_mode == 1 && (!ctx->pvr || pvr_tiled)) {
-    // pass 1 (tiled walk: sume, gate, v_PSF_sums, voxel-count flag), pass 2 = the plane-owned scatter
-    // of the back-projection with {recon|volw} as targets and unit voxel/slice weights
+  const bool tiled = ctx->gauss_mode == 1 && (!ctx->pvr || ctx->pvr_mode == 1);
+  if (a.n && tiled) {
+    // pass 1 = the unit-based walk of the gather (sume, gate, v_PSF_sums, voxel-count flag), pass 2 = the scatter of the
+    // back-projection with {recon|volw} as targets and unit voxel / slice weights
     if (!ctx->d_gauss_flag) HIPCHK(hipMalloc(&ctx->d_gauss_flag, ctx->np));
     HIPCHK(hipMemsetAsync(ctx->d_gauss_flag, 0, ctx->np, ctx->stream));
     const int ftx = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw), fty = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
@@ -3884,94 +3304,37 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       HIPCHK(hipMalloc(&ctx->d_tiles_tmp, max_tiles * sizeof(uint32_t)));
       ctx->tiles_tmp_cap = max_tiles;
     }
-    uint32_t n1 = 0, n2 = 0, nfb = 0;
+    uint32_t n1 = 0, n2 = 0;
     TileArgs ta;
-    ta.tiles_x = ftx; ta.tiles_y = fty;
-    ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th; ta.gauss = 1;
+    ta.tiles_x = ftx; ta.tiles_y = fty; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th; ta.gauss = 1;
+    ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
     a.flag = nullptr; a.flag_out = ctx->d_gauss_flag;
-    // pass 1 per slice group: plain gather walk / row-list walk (fwd_mode 3 splits by h_rows_sel)
-    if (!pvr_tiled && ctx->fwd_mode == 4) {                // the unit-based walk over every tile
-      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
-                         (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
-                         fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter);
-      KCHK("k_build_tiles(gauss1)");
-      HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1; ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
-      if (n1) hipLaunchKernelGGL(fwd_unit_kernel<true>, dim3(n1), dim3(FWDU_WAVES * 64), (size_t)ta.cap * 2 * sizeof(float),
-                                 ctx->stream, a, ta);
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
+                       (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
+                       fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter);
+    KCHK("k_build_tiles(gauss1)");
+    HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1;
+    if (n1) {
+      const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
+      if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<true, PVR_N, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      else hipLaunchKernelGGL(fwd_unit_kernel<true>, dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       KCHK("fwd_unit_kernel<GAUSS1>");
-    } else
-    for (int w = 0; w < 2; ++w) {
-      const bool rows = w == 1;
-      const int fm = pvr_tiled ? 1 : ctx->fwd_mode;       // row lists exist for the SVR support only
-      if ((fm == 2 && !rows) || (fm != 2 && fm != 3 && rows)) continue;
-      const unsigned char *sel = fm == 3 ? ctx->d_rows_sel : nullptr;
-      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 4)), dim3(256), 0, ctx->stream, ctx->d_slices,
-                         (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
-                         fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter, sel, w);
-      KCHK("k_build_tiles(gauss1)");
-      HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1;
-      if (!n1) continue;
-      if (pvr_tiled)
-        hipLaunchKernelGGL((fwd_tile_kernel<true, false, PVR_N, true>), dim3(n1), dim3(FWD_WAVES * 64),
-                           (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
-      else if (rows)
-        hipLaunchKernelGGL((fwd_tile_kernel<true, true>), dim3(n1), dim3(FWD_WAVES * 64),
-                           (size_t)ta.cap * sizeof(float) + (size_t)ta.tw * ta.th * 256, ctx->stream, a, ta);
-      else
-        hipLaunchKernelGGL((fwd_tile_kernel<true, false>), dim3(n1), dim3(FWD_WAVES * 64), (size_t)ta.cap * sizeof(float),
-                           ctx->stream, a, ta);
-      KCHK("fwd_tile_kernel<GAUSS1>");
     }
-    uint32_t seg2[2] = {0, 0};
-    const bool slots = !pvr_tiled && ctx->back_mode >= 3;
-    for (int w = 0; w < (slots ? 2 : 1); ++w) {             // slot-owned scatter: [slices without dead planes | with]
-      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns, 4)), dim3(256), 0, ctx->stream,
-                         ctx->d_slices, (const float *)nullptr, ctx->d_gauss_flag, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns,
-                         ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp + seg2[0], ctx->d_counter,
-                         slots ? (const unsigned char *)ctx->d_rows_sel : (const unsigned char *)nullptr, w);
-      KCHK("k_build_tiles(gauss2)");
-      HIPCHK(hipMemcpyAsync(&seg2[w], ctx->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    n2 = seg2[0] + seg2[1];
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns, 4)), dim3(256), 0, ctx->stream,
+                       ctx->d_slices, (const float *)nullptr, ctx->d_gauss_flag, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns,
+                       ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter);
+    KCHK("k_build_tiles(gauss2)");
+    HIPCHK(hipMemcpyAsync(&n2, ctx->d_counter, sizeof(n2), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     a.flag = ctx->d_gauss_flag;
     a.addon = ctx->recon(); a.cmap = ctx->volw();       // scatter targets of pass 2 (RC.cu:279-282)
-    ta.ntiles = n2; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.tw = ctx->tile_w; ta.th = ctx->tile_h;
-    ta.cap = std::min(ctx->plane_cap, ctx->tile_cap);
-    if (n2 && slots) {
-      r = ctx->back_mode == 4 ? launch_wave_scatter(ctx, a, ta, ctx->d_tiles_tmp, n2)
-                              : launch_slot_scatter(ctx, a, ta, ctx->d_tiles_tmp, seg2[0], seg2[1]);
-      if (r) return r;
-    } else if (n2) {
-      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-      if (pvr_tiled)
-        hipLaunchKernelGGL((back_plane_kernel<8, PVR_N, true>), dim3(n2), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float),
-                           ctx->stream, a, ta, ctx->d_tiles_fb, ctx->d_counter);
-      else
-        hipLaunchKernelGGL(back_plane_kernel<8>, dim3(n2), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float), ctx->stream, a, ta,
-                           ctx->d_tiles_fb, ctx->d_counter);
-      KCHK("back_plane_kernel(gauss)");
-      HIPCHK(hipMemcpyAsync(&nfb, ctx->d_counter, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      if (nfb) {
-        ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb; ta.cap = ctx->tile_cap;
-        if (pvr_tiled) {
-          a.recon = ctx->recon(); a.volw = ctx->volw();
-          hipLaunchKernelGGL(pvr_tiles_kernel<MODE_GAUSS2>, dim3(nfb), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
-        } else {
-          hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float),
-                             ctx->stream, a, ta);
-        }
-        KCHK("back_tiled_kernel(gauss fallback)");
-      }
-    }
+    ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.dbg = 0;
+    r = launch_scatter(ctx, ctx->pvr ? 4 : std::max(1, ctx->back_mode), a, ta, ctx->d_tiles_tmp, n2, MODE_GAUSS2);
+    if (r) return r;
   } else if (a.n && ctx->pvr) {
     hipLaunchKernelGGL(pvr_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
@@ -4020,44 +3383,20 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   auto launch_forward = [&]() -> int {
-    if (a.n && ctx->pvr && ctx->pvr_mode == 1) {
-      TileArgs ta;                                         // all forward tiles (h_rows_sel is all 0 for PVR)
-      ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
-      ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
-      ta.gauss = 0;
-      hipLaunchKernelGGL((fwd_tile_kernel<false, false, PVR_N, true>), dim3(ta.ntiles), dim3(FWD_WAVES * 64),
-                         (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
-      KCHK("fwd_tile_kernel<PVR>");
-    } else if (a.n && ctx->pvr) {
-      hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                         ctx->stream, a);
-      KCHK("pvr_kernel<FWD>");
-    } else if (a.n && ctx->fwd_mode == 4) {
+    const bool tiled_ = ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1;
+    if (a.n && tiled_) {
       TileArgs ta;
       ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
       ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
       ta.gauss = 0;
-      hipLaunchKernelGGL(fwd_unit_kernel<false>, dim3(ta.ntiles), dim3(FWDU_WAVES * 64), (size_t)ta.cap * 2 * sizeof(float),
-                         ctx->stream, a, ta);
+      const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
+      if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<false, PVR_N, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      else hipLaunchKernelGGL(fwd_unit_kernel<false>, dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       KCHK("fwd_unit_kernel");
-    } else if (a.n && ctx->fwd_mode >= 1) {
-      TileArgs ta;
-      ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
-      ta.cap = std::min(ctx->fwd_cap, ctx->tile_cap * 2); ta.dbg = 0; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
-      ta.gauss = 0;
-      const uint32_t n_plain = ctx->fwd_mode == 1 ? ctx->n_tiles_fwd : ctx->fwd_mode == 2 ? 0u : ctx->n_tiles_fwd_plain;
-      const uint32_t n_rows = ctx->n_tiles_fwd - n_plain;
-      if (n_plain) {
-        ta.ntiles = n_plain;
-        hipLaunchKernelGGL((fwd_tile_kernel<false, false>), dim3(n_plain), dim3(FWD_WAVES * 64),
-                           (size_t)ta.cap * sizeof(float), ctx->stream, a, ta);
-      }
-      if (n_rows) {
-        ta.tiles = ctx->d_tiles_fwd + n_plain; ta.ntiles = n_rows;
-        hipLaunchKernelGGL((fwd_tile_kernel<false, true>), dim3(n_rows), dim3(FWD_WAVES * 64),
-                           (size_t)ta.cap * sizeof(float) + (size_t)ta.tw * ta.th * 256, ctx->stream, a, ta);
-      }
-      KCHK("fwd_tile_kernel");
+    } else if (a.n && ctx->pvr) {
+      hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
+                         ctx->stream, a);
+      KCHK("pvr_kernel<FWD>");
     } else if (a.n) {
       hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),
                          (size_t)ctx->dbg_fwd_lds, ctx->stream, a);
@@ -4068,7 +3407,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   const bool tiled = a.n && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1);
   if (tiled && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
     ctx->fwd_tune_pending = false;
-    static const int cand[4][2] = {{8, 4}, {4, 4}, {4, 2}, {2, 2}};   // smaller boxes for finer volumes; stop at the first loss
+    static const int cand[4][2] = {{4, 4}, {8, 4}, {4, 2}, {2, 2}};   // the first is the default; smaller boxes for finer volumes
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -4089,7 +3428,6 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
       }
       if (ms < best) { best = ms; pick = c; }
-      else break;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -4239,7 +3577,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     r = svr_update_slice_weights(ctx, slice_weight);   // RC.cu:2123
     if (r) return r;
   }
-  if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 2)) {
+  if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 3)) {
     ctx->back_tune_pending = false;
     ctx->in_tune = true;
     static const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
@@ -4266,7 +3604,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     }
     if (!r) r = svr_set_option(ctx, "tile_w", cand[pick][0]);
     if (!r) r = svr_set_option(ctx, "tile_h", cand[pick][1]);
-    if (!r && !ctx->pvr && ctx->back_mode == 4 && !ctx->wave_cap_user) {
+    if (!r && (ctx->pvr || ctx->back_mode == 4) && !ctx->wave_cap_user) {
       // the wave-owned scatter's LDS request decides how many wavefronts a CU holds; the smallest box that still takes
       // (nearly) every tile wins -- tiles that do not fit are re-run by the workgroup kernel, so any value is correct
       static const int caps[4] = {2116, 1936, 1764, 1600};       // 4 planes of 23^2, 22^2, 21^2, 20^2 voxels
@@ -4299,79 +3637,17 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
-  if (a.n && ctx->pvr && ctx->pvr_mode == 1) {
+  const bool tiled = ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 1;
+  if (a.n && tiled) {
     TileArgs ta;
-    ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
-    ta.cap = std::min(ctx->plane_cap, ctx->tile_cap); ta.dbg = 0;
+    ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.dbg = ctx->dbg_back;
     ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL((back_plane_kernel<8, PVR_N, true>), dim3(ctx->n_tiles), dim3(8 * 64), (size_t)ta.cap * 2 * sizeof(float),
-                       ctx->stream, a, ta, ctx->d_tiles_fb, ctx->d_counter);
-    KCHK("back_plane_kernel<PVR>");
-    uint32_t nfb = 0;
-    HIPCHK(hipMemcpyAsync(&nfb, ctx->d_counter, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_tiles_fb = nfb;
-    if (nfb) {
-      ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb;
-      hipLaunchKernelGGL(pvr_tiles_kernel<MODE_BACK>, dim3(nfb), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
-      KCHK("pvr_tiles_kernel<BACK>");
-    }
+    r = launch_scatter(ctx, ctx->pvr ? 4 : ctx->back_mode, a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
+    if (r) return r;
   } else if (a.n && ctx->pvr) {
     hipLaunchKernelGGL(pvr_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);
     KCHK("pvr_kernel<BACK>");
-  } else if (a.n && ctx->back_mode == 4) {
-    TileArgs ta;
-    ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.dbg = ctx->dbg_back;
-    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
-    r = launch_wave_scatter(ctx, a, ta, ctx->d_tiles, ctx->n_tiles);
-    if (r) return r;
-  } else if (a.n && ctx->back_mode == 3) {
-    TileArgs ta;
-    ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.dbg = ctx->dbg_back;
-    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
-    r = launch_slot_scatter(ctx, a, ta, ctx->d_tiles, ctx->n_tiles_plain, ctx->n_tiles - ctx->n_tiles_plain);
-    if (r) return r;
-  } else if (a.n && ctx->back_mode == 2) {
-    TileArgs ta;
-    ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
-    ta.cap = std::min(ctx->plane_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
-    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-#define LAUNCH_PLANE(NW)                                                                                   \
-  hipLaunchKernelGGL(back_plane_kernel<NW>, dim3(ctx->n_tiles), dim3(NW * 64), lds, ctx->stream, a, ta,   \
-                     ctx->d_tiles_fb, ctx->d_counter)
-    switch (ctx->plane_waves) {
-      case 4: LAUNCH_PLANE(4); break;
-      case 5: LAUNCH_PLANE(5); break;
-      case 6: LAUNCH_PLANE(6); break;
-      case 7: LAUNCH_PLANE(7); break;
-      default: LAUNCH_PLANE(8); break;
-    }
-#undef LAUNCH_PLANE
-    KCHK("back_plane_kernel");
-    ta.cap = ctx->tile_cap;
-    uint32_t nfb = 0;
-    HIPCHK(hipMemcpyAsync(&nfb, ctx->d_counter, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_tiles_fb = nfb;
-    if (nfb) {
-      ta.tiles = ctx->d_tiles_fb; ta.ntiles = nfb;
-      hipLaunchKernelGGL(back_tiled_kernel, dim3(nfb), dim3(TILE_WAVES * 64),
-                         (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
-      KCHK("back_tiled_kernel(fallback)");
-    }
-  } else if (a.n && ctx->back_mode == 1) {
-    TileArgs ta;
-    ta.tiles = ctx->d_tiles; ta.ntiles = ctx->n_tiles; ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y;
-    ta.cap = ctx->tile_cap;
-    ta.dbg = ctx->dbg_back;
-    ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
-    hipLaunchKernelGGL(back_tiled_kernel, dim3(ctx->n_tiles), dim3(TILE_WAVES * 64),
-                       (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
-    KCHK("back_tiled_kernel");
   } else if (a.n) {
     hipLaunchKernelGGL(psf_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
                        ctx->stream, a);

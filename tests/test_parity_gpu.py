@@ -103,10 +103,9 @@ def test_thin_slices_take_the_exponential_per_tap(oracle_mod, thickness):
     assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
 
 
-@pytest.mark.parametrize("gauss_mode,fwd_mode", [(1, 4), (1, 3), (1, 2), (1, 1), (0, 1)])
+@pytest.mark.parametrize("gauss_mode,fwd_mode", [(1, 1), (0, 1), (0, 0)])
 def test_gaussian_reconstruction_parity(tiny, oracle_mod, gauss_mode, fwd_mode):
-    """gauss_mode 1 = tiled pass 1 (fwd_mode 4: unit-based walk with the dead-unit shortcut, 2: row lists) + the LDS-tiled
-    scatter, 0 = wave-per-pixel kernel with atomics."""
+    """gauss_mode 1 = unit-based pass 1 (dead-unit shortcut) + the LDS scatter, 0 = wave-per-pixel kernel with atomics."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("gauss_mode", gauss_mode)
     rec.set_option("fwd_mode", fwd_mode)
@@ -135,10 +134,9 @@ def test_against_committed_golden(tiny, oracle_mod):
     assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), gold["siminside0"])
 
 
-@pytest.mark.parametrize("fwd_mode", [4, 3, 2, 1, 0])
+@pytest.mark.parametrize("fwd_mode", [1, 0])
 def test_forward_projection_parity(tiny, oracle_mod, fwd_mode):
-    """fwd_mode 4 = unit-based gather (default: float2 {V m, m} box, dead-unit shortcut), 2 = LDS-tiled gather over row lists (provably epsilon-dead rows get only their first tap),
-    1 = plain LDS-tiled gather, 3 = per slice whichever suits (default), 0 = wave-per-pixel kernel."""
+    """fwd_mode 1 = unit-based gather (default: float2 {V m, m} box, dead-unit shortcut), 0 = wave-per-pixel kernel."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("fwd_mode", fwd_mode)
     run_to_state(dg, "sim")
@@ -149,10 +147,10 @@ def test_forward_projection_parity(tiny, oracle_mod, fwd_mode):
     assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
 
 
-@pytest.mark.parametrize("back_mode", [4, 3, 2, 1, 0])
+@pytest.mark.parametrize("back_mode", [4, 3, 1, 0])
 def test_backprojection_parity(tiny, oracle_mod, back_mode):
-    """back_mode 3 = slot-owned LDS tiles with the dead-unit shortcut (default), 2 = plane-owned LDS tiles, 1 = LDS tiles with
-    ds_add_f32, 0 = direct atomics."""
+    """back_mode 4 = wave-owned LDS planes with the dead-unit shortcut (default), 3 = the workgroup kernel for every tile,
+    1 = LDS tiles with ds_add_f32, 0 = direct atomics."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("back_mode", back_mode)
     run_to_state(dg, "scale")
@@ -221,7 +219,7 @@ def test_full_iteration_tracks_the_oracle(tiny, oracle_mod):
 
 
 @pytest.mark.parametrize("shift", [(-14.2, -14.4, -14.6), (14.3, 14.1, 13.9), (-14.2, 14.1, 0.3)])
-@pytest.mark.parametrize("back_mode", [4, 3, 2, 1])
+@pytest.mark.parametrize("back_mode", [4, 3, 1])
 def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
     """Slices hanging off the volume: negative coordinates alias to index 0 (float->uint
     saturation), taps beyond the high end are dropped -- in the Gaussian scatter, the forward
@@ -238,8 +236,8 @@ def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
     P.slices[:, ::3, ::2] = 140.0
     E, rec, orc, dg, do = _drivers(P, oracle_mod)
     rec.set_option("back_mode", back_mode)
-    rec.set_option("fwd_mode", 4 if back_mode >= 3 else (3 if back_mode == 2 else 0))
-    rec.set_option("gauss_mode", 1 if back_mode >= 2 else 0)
+    rec.set_option("fwd_mode", 1 if back_mode >= 3 else 0)
+    rec.set_option("gauss_mode", 1 if back_mode >= 3 else 0)
     run_to_state(dg, "sim")
     run_to_state(do, "sim")
     assert (orc.psf_sums != 0).any()
@@ -333,18 +331,17 @@ def test_adjointness_at_full_size(workload):
 
 
 def test_kernel_variants_agree_at_full_size():
-    """P4 (too big for the oracle): the production kernels against their simpler variants on the device --
-    row-list gather vs plain gather (any row wrongly declared epsilon-dead would lose >= 1e-5 of a pixel's
-    weight), tiled two-pass Gaussian reconstruction vs the wave-per-pixel kernel, plane-owned scatter vs
-    direct atomics.  Hit sets exact, sums to float round-off."""
+    """P4 (too big for the oracle): the production kernels against their simplest variants on the device -- unit-based gather
+    with the dead-unit shortcut vs the wave-per-pixel kernel (a unit wrongly declared dead would lose >= 1e-5 of a pixel's
+    weight), two-pass Gaussian reconstruction vs the wave-per-pixel kernel, wave-owned / workgroup scatter vs direct atomics.
+    Hit sets exact, sums to float round-off."""
     from fetalreconstruction_amd import engine as E
     P = phantom.problem_p4()
     rec = _engine(P)
     rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
     rec.InitializeEMValues()
     out = {}
-    for name, opts in (("units", dict(gauss_mode=1, fwd_mode=4)), ("tiled_rows", dict(gauss_mode=1, fwd_mode=3)), ("tiled_plain", dict(gauss_mode=1, fwd_mode=1)),
-                       ("simple", dict(gauss_mode=0, fwd_mode=0))):
+    for name, opts in (("units", dict(gauss_mode=1, fwd_mode=1)), ("simple", dict(gauss_mode=0, fwd_mode=0))):
         for k, v in opts.items():
             rec.set_option(k, v)
         rec.GaussianReconstruction()
@@ -354,20 +351,20 @@ def test_kernel_variants_agree_at_full_size():
         out[name] = (ps, vol, vw, rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy(),
                      rec.debug_get(E.BUF_SIMINSIDE).copy(), rec.debug_get(E.BUF_VOXEL_COUNT).copy())
     ref = out["simple"]
-    for name in ("units", "tiled_rows", "tiled_plain"):
+    for name in ("units",):
         ps, vol, vw, sim, sw, si, vc = out[name]
         assert np.array_equal(ps != 0, ref[0] != 0) and np.array_equal(vc, ref[6]) and np.array_equal(si, ref[5])
         assert np.allclose(ps, ref[0], rtol=2e-6, atol=0)
         assert rel_err(vol, ref[1]) < TOL_SUM and rel_err(vw, ref[2]) < TOL_SUM     # float atomics in run-dependent order
         assert np.abs(sw - ref[4]).max() < 3e-6 and rel_err(sim, ref[3]) < 5e-6
-    rec.set_option("fwd_mode", 4)
+    rec.set_option("fwd_mode", 1)
     rec.set_option("gauss_mode", 1)
     res = {}
-    for bm in (4, 3, 2, 0):
+    for bm in (4, 3, 0):
         rec.set_option("back_mode", bm)
         rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
         res[bm] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
-    for bm in (4, 3, 2):
+    for bm in (4, 3):
         assert np.array_equal(res[bm][1] > 0, res[0][1] > 0)
         assert rel_err(res[bm][1], res[0][1]) < TOL_SUM and rel_err(res[bm][0], res[0][0]) < TOL_SUM
 
