@@ -47,14 +47,14 @@ void match_stack_intensities_pvr(std::vector<Image> &stacks, const std::vector<M
   std::vector<double> avg;
   for (size_t s = 0; s < stacks.size(); ++s) {
     const Image &st = stacks[s];
-    const M4 m = mul(mw2i, mul(ts[s], image_to_world(st.a)));
+    const M4 s_i2w = image_to_world(st.a);
     double sum = 0, num = 0;
     for (int z = 0; z < st.a.nz; ++z)
       for (int y = 0; y < st.a.ny; ++y)
         for (int x = 0; x < st.a.nx; ++x) {
-          const long i = (long)irtk_round(m.m[0] * x + m.m[1] * y + m.m[2] * z + m.m[3]);
-          const long j = (long)irtk_round(m.m[4] * x + m.m[5] * y + m.m[6] * z + m.m[7]);
-          const long k = (long)irtk_round(m.m[8] * x + m.m[9] * y + m.m[10] * z + m.m[11]);
+          double qx = x, qy = y, qz = z;
+          apply_point(s_i2w, qx, qy, qz); apply_point(ts[s], qx, qy, qz); apply_point(mw2i, qx, qy, qz);
+          const long i = (long)irtk_round(qx), j = (long)irtk_round(qy), k = (long)irtk_round(qz);
           if (i >= 0 && i < mask.a.nx && j >= 0 && j < mask.a.ny && k >= 0 && k < mask.a.nz &&
               mask.at((int)i, (int)j, (int)k) == 1 && st.at(x, y, z) > 0) {
             sum += st.at(x, y, z);
@@ -228,13 +228,15 @@ void generate_2d_patches(const Image &stack, double thickness, const Image &mask
         svr_image_attr pa = p0;                          // shift the origin so that pixel (0,0) sits on slice pixel (x,y) :232-246
         for (int k = 0; k < 3; ++k) pa.origin[k] = (sl_i2w.m[4 * k] * x + sl_i2w.m[4 * k + 1] * y + sl_i2w.m[4 * k + 3]) - p0_i2w.m[4 * k + 3];
         const M4 p_i2w = image_to_world(pa);
-        const M4 to_slice = mul(sl_w2i, p_i2w), to_mask = mul(m_w2i, p_i2w);
         int set_count = 0;
         for (int j = 0; j < py; ++j)
           for (int i = 0; i < px; ++i) {
-            const double xx = snap(to_slice.m[0] * i + to_slice.m[1] * j + to_slice.m[3]), yy = snap(to_slice.m[4] * i + to_slice.m[5] * j + to_slice.m[7]);
-            const double x1 = snap(to_mask.m[0] * i + to_mask.m[1] * j + to_mask.m[3]), y1 = snap(to_mask.m[4] * i + to_mask.m[5] * j + to_mask.m[7]),
-                         z1 = snap(to_mask.m[8] * i + to_mask.m[9] * j + to_mask.m[11]);
+            double wx = i, wy = j, wz = 0;                 // patch.ImageToWorld, then slice / mask WorldToImage (:262-277)
+            apply_point(p_i2w, wx, wy, wz);
+            double xx = wx, yy = wy, zz = wz, x1 = wx, y1 = wy, z1 = wz;
+            apply_point(sl_w2i, xx, yy, zz);
+            apply_point(m_w2i, x1, y1, z1);
+            xx = snap(xx); yy = snap(yy); x1 = snap(x1); y1 = snap(y1); z1 = snap(z1);
             float v = 0;                                 // a patch starts as an all-zero image
             if (xx >= 0 && yy >= 0 && xx < a.nx && yy < a.ny && x1 >= 0 && y1 >= 0 && z1 >= 0 && x1 < mask.a.nx && y1 < mask.a.ny &&
                 z1 < mask.a.nz && mask.at((int)x1, (int)y1, (int)z1) > 0) {

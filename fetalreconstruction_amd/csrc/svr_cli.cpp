@@ -165,13 +165,14 @@ int main(int argc, char **argv) {
     for (int j = 0; j < stacks[k].a.nz; ++j, ++sl) {
       Image r = get_region(stacks[k], 0, 0, j, stacks[k].a.nx, stacks[k].a.ny, j + 1);
       r.a.dz = thickness[k];
-      const M4 si2w = image_to_world(r.a), m = mul(mw2i, mul(ts[k], si2w));
+      const M4 si2w = image_to_world(r.a);
       for (int y = 0; y < r.a.ny; ++y)
         for (int x = 0; x < r.a.nx; ++x) {
           double v = r.at(x, y, 0);
           if (v < 0.01) v = -1;
-          const long i = (long)irtk_round(m.m[0] * x + m.m[1] * y + m.m[3]), jj = (long)irtk_round(m.m[4] * x + m.m[5] * y + m.m[7]),
-                     kk = (long)irtk_round(m.m[8] * x + m.m[9] * y + m.m[11]);
+          double qx = x, qy = y, qz = 0;                   // ImageToWorld, Transform, WorldToImage: three applications (RG.cc:1961-1972)
+          apply_point(si2w, qx, qy, qz); apply_point(ts[k], qx, qy, qz); apply_point(mw2i, qx, qy, qz);
+          const long i = (long)irtk_round(qx), jj = (long)irtk_round(qy), kk = (long)irtk_round(qz);
           if (!(i >= 0 && i < vol_mask.a.nx && jj >= 0 && jj < vol_mask.a.ny && kk >= 0 && kk < vol_mask.a.nz) ||
               vol_mask.at((int)i, (int)jj, (int)kk) == 0)
             v = -1;

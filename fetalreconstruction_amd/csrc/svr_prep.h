@@ -135,17 +135,26 @@ void gaussian_blur(Image &im, double sigma) {
   }
 }
 
+// One point through a chain of matrices, ONE APPLICATION AT A TIME like the reference (ImageToWorld, Transform, WorldToImage are
+// three calls there): composing the matrices first changes the last bits, and a coordinate that is x.5 in exact arithmetic
+// then rounds to the other voxel (found by oracle/prep_oracle.c on the bundled mask's grid).
+inline void apply_point(const M4 &m, double &x, double &y, double &z) {
+  const double a = m.m[0] * x + m.m[1] * y + m.m[2] * z + m.m[3], b = m.m[4] * x + m.m[5] * y + m.m[6] * z + m.m[7],
+               c = m.m[8] * x + m.m[9] * y + m.m[10] * z + m.m[11];
+  x = a; y = b; z = c;
+}
+
 // irtkImageTransformation + nearest neighbour, target padding -1 on an all-zero target (RG.cc:782-793, 808-819)
 Image transform_nn(const Image &src, const svr_image_attr &target, const M4 &t, double source_padding) {
   Image out;
   out.a = target;
   out.d.assign((size_t)target.nx * target.ny * target.nz, source_padding);
-  const M4 m = mul(world_to_image(src.a), mul(t, image_to_world(target)));
+  const M4 t_i2w = image_to_world(target), s_w2i = world_to_image(src.a);
   for (int z = 0; z < target.nz; ++z)
     for (int y = 0; y < target.ny; ++y)
       for (int x = 0; x < target.nx; ++x) {
-        const double q[3] = {m.m[0] * x + m.m[1] * y + m.m[2] * z + m.m[3], m.m[4] * x + m.m[5] * y + m.m[6] * z + m.m[7],
-                             m.m[8] * x + m.m[9] * y + m.m[10] * z + m.m[11]};
+        double q[3] = {(double)x, (double)y, (double)z};
+        apply_point(t_i2w, q[0], q[1], q[2]); apply_point(t, q[0], q[1], q[2]); apply_point(s_w2i, q[0], q[1], q[2]);
         const long i = (long)irtk_round(q[0]), j = (long)irtk_round(q[1]), k = (long)irtk_round(q[2]);
         if (i >= 0 && i < src.a.nx && j >= 0 && j < src.a.ny && k >= 0 && k < src.a.nz)
           out.at(x, y, z) = src.at((int)i, (int)j, (int)k);
@@ -205,14 +214,14 @@ std::vector<float> match_stack_intensities(std::vector<Image> &stacks, const std
   std::vector<double> avg;
   for (size_t s = 0; s < stacks.size(); ++s) {
     const Image &st = stacks[s];
-    const M4 m = mul(mw2i, mul(ts[s], image_to_world(st.a)));
+    const M4 s_i2w = image_to_world(st.a);
     double sum = 0, num = 0;
     for (int z = 0; z < st.a.nz; ++z)
       for (int y = 0; y < st.a.ny; ++y)
         for (int x = 0; x < st.a.nx; ++x) {
-          const long i = (long)irtk_round(m.m[0] * x + m.m[1] * y + m.m[2] * z + m.m[3]);
-          const long j = (long)irtk_round(m.m[4] * x + m.m[5] * y + m.m[6] * z + m.m[7]);
-          const long k = (long)irtk_round(m.m[8] * x + m.m[9] * y + m.m[10] * z + m.m[11]);
+          double qx = x, qy = y, qz = z;
+          apply_point(s_i2w, qx, qy, qz); apply_point(ts[s], qx, qy, qz); apply_point(mw2i, qx, qy, qz);
+          const long i = (long)irtk_round(qx), j = (long)irtk_round(qy), k = (long)irtk_round(qz);
           if (i >= 0 && i < mask.a.nx && j >= 0 && j < mask.a.ny && k >= 0 && k < mask.a.nz && mask.at((int)i, (int)j, (int)k) == 1) {
             sum += st.at(x, y, z);
             num += 1;

@@ -29,6 +29,29 @@ class ImageAttributes:
     origin: np.ndarray = field(default_factory=lambda: np.zeros(3))
 
 
+def mat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """4x4 product with irtkMatrix::operator*'s arithmetic (irtkMatrix.cc:222-242): every element a plain double sum from 0 over
+    k = 0..3, no fused multiply-add, no BLAS reordering -- so the image <-> world matrices have the reference's last bits (a
+    coordinate that is x.5 in exact arithmetic rounds to the same voxel as there; oracle/prep_oracle.c checks it)."""
+    c = np.zeros((4, 4))
+    for i in range(4):
+        for j in range(4):
+            t = 0.0
+            for k in range(4):
+                t += float(a[i, k]) * float(b[k, j])
+            c[i, j] = t
+    return c
+
+
+def apply_points(m: np.ndarray, p: np.ndarray) -> np.ndarray:
+    """irtkBaseImage::ImageToWorld / WorldToImage / irtkHomogeneousTransformation::Transform on an array of points [..., 3 or 4]:
+    a = M00 x + M01 y + M02 z + M03 evaluated left to right per element (irtkBaseImage.h:425-468); returns [..., 3]."""
+    x, y, z = p[..., 0], p[..., 1], p[..., 2]
+    return np.stack([m[0, 0] * x + m[0, 1] * y + m[0, 2] * z + m[0, 3],
+                     m[1, 0] * x + m[1, 1] * y + m[1, 2] * z + m[1, 3],
+                     m[2, 0] * x + m[2, 1] * y + m[2, 2] * z + m[2, 3]], -1)
+
+
 def image_to_world(a: ImageAttributes) -> np.ndarray:
     """irtkBaseImage::GetImageToWorldMatrix (irtkBaseImage.cc:79-111)."""
     t1 = np.eye(4)
@@ -42,7 +65,7 @@ def image_to_world(a: ImageAttributes) -> np.ndarray:
     rot[:3, 2] = a.zaxis
     t2 = np.eye(4)
     t2[:3, 3] = a.origin
-    return t2 @ (rot @ (sc @ t1))
+    return mat_mul(t2, mat_mul(rot, mat_mul(sc, t1)))
 
 
 def world_to_image(a: ImageAttributes) -> np.ndarray:
@@ -58,7 +81,7 @@ def world_to_image(a: ImageAttributes) -> np.ndarray:
     t2[0, 3] = (a.nx - 1) / 2.0
     t2[1, 3] = (a.ny - 1) / 2.0
     t2[2, 3] = (a.nz - 1) / 2.0
-    return t2 @ (sc @ (rot @ t1))
+    return mat_mul(t2, mat_mul(sc, mat_mul(rot, t1)))
 
 
 def rigid_matrix(tx=0.0, ty=0.0, tz=0.0, rx=0.0, ry=0.0, rz=0.0) -> np.ndarray:

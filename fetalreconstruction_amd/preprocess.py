@@ -96,8 +96,9 @@ def transform_nn(source: Image, target_attr, transformation=None, source_padding
     target: every target voxel takes the source voxel nearest to T(world position), `source_padding`
     where that falls outside the source (RG.cc:782-793, 808-819)."""
     t = np.eye(4) if transformation is None else np.asarray(transformation, np.float64)
-    m = geo.world_to_image(source.attr) @ t @ geo.image_to_world(target_attr)
-    q = _grid(target_attr) @ m.T
+    # one matrix application at a time like the reference (ImageToWorld, Transform, WorldToImage): composing the matrices first
+    # changes the last bits and flips coordinates that are x.5 in exact arithmetic (oracle/prep_oracle.c)
+    q = geo.apply_points(geo.world_to_image(source.attr), geo.apply_points(t, geo.apply_points(geo.image_to_world(target_attr), _grid(target_attr))))
     idx = _round_half_away(q[..., :3]).astype(np.int64)
     sa = source.attr
     ok = ((idx[..., 0] >= 0) & (idx[..., 0] < sa.nx) & (idx[..., 1] >= 0) & (idx[..., 1] < sa.ny) &
@@ -151,7 +152,7 @@ def MatchStackIntensitiesWithMasking(stacks, stack_transformations, mask: Image,
     ma = mask.attr
     averages = []
     for st, t in zip(stacks, stack_transformations):
-        q = _grid(st.attr) @ (m_w2i @ np.asarray(t, np.float64) @ geo.image_to_world(st.attr)).T
+        q = geo.apply_points(m_w2i, geo.apply_points(np.asarray(t, np.float64), geo.apply_points(geo.image_to_world(st.attr), _grid(st.attr))))   # RG.cc:1404-1410
         idx = _round_half_away(q[..., :3]).astype(np.int64)
         ok = ((idx[..., 0] >= 0) & (idx[..., 0] < ma.nx) & (idx[..., 1] >= 0) & (idx[..., 1] < ma.ny) &
               (idx[..., 2] >= 0) & (idx[..., 2] < ma.nz))
@@ -192,7 +193,7 @@ def MaskSlices(slices, attrs, transformations, mask: Image):
     out = []
     for s, a, t in zip(slices, attrs, transformations):
         s = np.where(s < 0.01, -1.0, np.asarray(s, np.float64))
-        q = _grid(a)[0] @ (m_w2i @ np.asarray(t, np.float64) @ geo.image_to_world(a)).T
+        q = geo.apply_points(m_w2i, geo.apply_points(np.asarray(t, np.float64), geo.apply_points(geo.image_to_world(a), _grid(a)[0])))   # RG.cc:1961-1972
         idx = _round_half_away(q[..., :3]).astype(np.int64)
         ok = ((idx[..., 0] >= 0) & (idx[..., 0] < ma.nx) & (idx[..., 1] >= 0) & (idx[..., 1] < ma.ny) &
               (idx[..., 2] >= 0) & (idx[..., 2] < ma.nz))

@@ -69,10 +69,10 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
                 pa = copy.copy(p0)
                 pa.origin = (first - p0_first)[:3]                              # :232-246
                 p_i2w = geo.image_to_world(pa)
-                w = pix @ p_i2w.T
-                q = w @ sl_w2i.T
+                w = geo.apply_points(p_i2w, pix)                                # patch.ImageToWorld, then slice / mask WorldToImage
+                q = geo.apply_points(sl_w2i, w)
                 xx, yy = _snap(q[..., 0]), _snap(q[..., 1])
-                qm = w @ m_w2i.T
+                qm = geo.apply_points(m_w2i, w)
                 x1, y1, z1 = _snap(qm[..., 0]), _snap(qm[..., 1]), _snap(qm[..., 2])
                 ok = (xx >= 0) & (yy >= 0) & (xx < a.nx) & (yy < a.ny)
                 ok &= (x1 >= 0) & (y1 >= 0) & (z1 >= 0) & (x1 < mx) & (y1 < my) & (z1 < mz)

@@ -86,7 +86,7 @@ def match_stack_intensities_pvr(stacks, transformations, mask, together=False):
     m_w2i, ma = geo.world_to_image(mask.attr), mask.attr
     averages = []
     for st, t in zip(stacks, transformations):
-        q = pp._grid(st.attr) @ (m_w2i @ np.asarray(t, np.float64) @ geo.image_to_world(st.attr)).T
+        q = geo.apply_points(m_w2i, geo.apply_points(np.asarray(t, np.float64), geo.apply_points(geo.image_to_world(st.attr), pp._grid(st.attr))))
         idx = pp._round_half_away(q[..., :3]).astype(np.int64)
         ok = ((idx[..., 0] >= 0) & (idx[..., 0] < ma.nx) & (idx[..., 1] >= 0) & (idx[..., 1] < ma.ny) &
               (idx[..., 2] >= 0) & (idx[..., 2] < ma.nz))

@@ -35,7 +35,7 @@ class Geom(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libsvr_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("svr_oracle.c", "reg_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("svr_oracle.c", "reg_oracle.c", "prep_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsvr_oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -483,3 +483,59 @@ def cc_patches(buffers, ri2w, tmats, recon_w2i, volume, level):
         out[i] = lib().orc_cc_patch(_p(b[i]), px, py, _p(r[i]), _p(t[i]), _p(w), _p(v), vx, vy, vz, int(level),
                                     _p(sums[i]))
     return out, sums
+
+
+# ---- host functions around the hot path (oracle/prep_oracle.c) -------------------------------------------------------------
+class Attr(C.Structure):
+    """orc_attr = svr_image_attr, field for field"""
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+                ("xaxis", C.c_double * 3), ("yaxis", C.c_double * 3), ("zaxis", C.c_double * 3), ("origin", C.c_double * 3)]
+
+    @classmethod
+    def of(cls, a):
+        return cls(int(a.nx), int(a.ny), int(a.nz), float(a.dx), float(a.dy), float(a.dz),
+                   (C.c_double * 3)(*[float(v) for v in a.xaxis]), (C.c_double * 3)(*[float(v) for v in a.yaxis]),
+                   (C.c_double * 3)(*[float(v) for v in a.zaxis]), (C.c_double * 3)(*[float(v) for v in a.origin]))
+
+
+def match_stack_intensities(stacks, attrs, transformations, mask, mask_attr, average_value, together=False):
+    """orc_match_stack_intensities (MatchStackIntensitiesWithMasking, RG.cc:1375-1493).  stacks: list of float64 [nz][ny][nx]
+    (copied); returns (rescaled stacks, factors float32, per-stack averages)."""
+    n = len(stacks)
+    data = [np.ascontiguousarray(s, np.float64).copy() for s in stacks]
+    at = (Attr * n)(*[Attr.of(a) for a in attrs])
+    ptrs = (C.c_void_p * n)(*[d.ctypes.data for d in data])
+    T = np.ascontiguousarray(np.stack([np.asarray(t, np.float64).reshape(16) for t in transformations]))
+    m = np.ascontiguousarray(mask, np.float64)
+    fac = np.zeros(n, np.float32)
+    avg = np.zeros(n, np.float64)
+    lib().orc_match_stack_intensities.restype = C.c_int
+    rc = lib().orc_match_stack_intensities(n, at, ptrs, _p(T), C.byref(Attr.of(mask_attr)), _p(m), C.c_double(average_value), int(bool(together)),
+                                           _p(fac), _p(avg))
+    if rc:
+        raise ValueError(f"stack {rc - 1} has no overlap with the ROI")
+    return data, fac, avg
+
+
+def generate_2d_patches(stack, attr, thickness, mask, mask_attr, pbbsize, stride, full_slices=False, snap=True, cap=None):
+    """orc_generate_2d_patches (generate2DPatches, patchBasedObject.cuh:174-342): -> (patches float32 [n][py][px], i2w [n][16],
+    w2i [n][16], total_pixels, origins [n][3])"""
+    st = np.ascontiguousarray(stack, np.float32)
+    mk = np.ascontiguousarray(mask, np.float32)
+    px, py = (int(attr.nx), int(attr.ny)) if full_slices else (int(pbbsize[0]), int(pbbsize[1]))
+    sx, sy = (px + 1, py + 1) if full_slices else (int(stride[0]), int(stride[1]))
+    if cap is None:
+        cap = attr.nz * len(range(0, attr.ny + py, sy)) * len(range(0, attr.nx + px, sx))
+    data = np.zeros((cap, py, px), np.float32)
+    i2w = np.zeros((cap, 16), np.float32)
+    w2i = np.zeros((cap, 16), np.float32)
+    org = np.zeros((cap, 3), np.float64)
+    n = C.c_int(0)
+    total = C.c_long(0)
+    lib().orc_generate_2d_patches.restype = C.c_int
+    rc = lib().orc_generate_2d_patches(C.byref(Attr.of(attr)), _p(st), C.c_double(thickness), C.byref(Attr.of(mask_attr)), _p(mk), px, py, sx, sy,
+                                       int(bool(full_slices)), int(bool(snap)), int(cap), _p(data), _p(i2w), _p(w2i), _p(org), C.byref(n), C.byref(total))
+    if rc:
+        raise ValueError("more patches than the capacity")
+    k = n.value
+    return data[:k].copy(), i2w[:k].copy(), w2i[:k].copy(), int(total.value), org[:k].copy()

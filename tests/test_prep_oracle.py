@@ -1,0 +1,127 @@
+"""The host functions either side of the hot path against an independent restatement of the reference's loops
+(oracle/prep_oracle.c) -- not only against their twin:
+
+  MatchStackIntensitiesWithMasking (RG.cc:1375-1493): preprocess.py (what cli.py runs) and, through the command line's problem
+      dump, csrc/svr_prep.h,
+  generate2DPatches (patchBasedObject.cuh:174-342): pvr.py and csrc/pvr_cli.cpp,
+
+on axis-aligned stacks and on the reference's bundled mask geometry (oblique, 300-400 mm off the origin)."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import real_mask as rm
+from fetalreconstruction_amd import geometry as geo
+from fetalreconstruction_amd import phantom, pvr
+from fetalreconstruction_amd import preprocess as pp
+
+
+def _oblique_case(n=3):
+    m, a, _ = rm.load()
+    stacks, c = rm.stacks_on_mask_grid(m, a, n)
+    rng = np.random.default_rng(3)
+    ts = [geo.rigid_matrix(*np.concatenate([rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3)])) if k else np.eye(4) for k in range(n)]
+    return m, a, stacks, ts
+
+
+def _aligned_case():
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(3, (32, 32, 8), 1.1, 2.2, None, 1.0, 14.0, seed=3)
+    return stacks, mask, mattr
+
+
+@pytest.mark.parametrize("together", [False, True])
+def test_match_stack_intensities_against_the_oracle(oracle_mod, together):
+    m, a, stacks, ts = _oblique_case()
+    imgs = [pp.Image(d.astype(np.float64), sa) for d, sa in stacks]
+    factors = pp.MatchStackIntensitiesWithMasking(imgs, ts, pp.Image(m.astype(np.float64), a), 700.0, together=together)
+    data, fac, avg = oracle_mod.match_stack_intensities([d for d, _ in stacks], [sa for _, sa in stacks], ts, m, a, 700.0, together)
+    # the averages are double sums in different orders (numpy pairwise, the reference x-outermost): 1e-12; the factors are
+    # stored as float like _stack_factor
+    assert np.allclose(factors.astype(np.float64), fac.astype(np.float64), rtol=2e-7, atol=0)
+    for img, d in zip(imgs, data):
+        assert np.array_equal(img.data > 0, d > 0)
+        assert np.allclose(img.data, d, rtol=1e-12, atol=0)
+    if together:
+        assert len(set(np.round(fac.astype(np.float64) / fac[0], 6))) == 1
+    else:
+        inside = [float(d[(d > 0)].mean()) for d in data]
+        assert np.all(np.array(inside) > 0)
+    # the rule itself: after matching, the mean over the ROI is the requested value
+    data1, fac1, avg1 = oracle_mod.match_stack_intensities(data, [sa for _, sa in stacks], ts, m, a, 700.0, together)
+    assert np.allclose(avg1 if not together else np.mean(avg1), 700.0, rtol=1e-9)
+
+
+def test_stack_without_overlap_is_an_error(oracle_mod):
+    m, a, stacks, ts = _oblique_case(2)
+    far = geo.rigid_matrix(tx=1000.0)
+    with pytest.raises(ValueError):
+        oracle_mod.match_stack_intensities([d for d, _ in stacks], [sa for _, sa in stacks], [np.eye(4), far], m, a, 700.0)
+    with pytest.raises(ValueError):
+        pp.MatchStackIntensitiesWithMasking([pp.Image(d.astype(np.float64), sa) for d, sa in stacks], [np.eye(4), far],
+                                            pp.Image(m.astype(np.float64), a), 700.0)
+
+
+@pytest.mark.parametrize("case", ["aligned", "oblique", "full_slices"])
+def test_generate_2d_patches_against_the_oracle(oracle_mod, case):
+    if case == "oblique":
+        m, a, st, _ = _oblique_case(2)
+        stacks = [pvr.Stack(d.astype(np.float32), sa, np.eye(4), sa.dz) for d, sa in st]
+        mask, mattr = (m > 0).astype(np.uint8), a
+        size, stride, full = (16, 16), (8, 8), False
+    else:
+        stacks, mask, mattr = _aligned_case()
+        size, stride, full = ((16, 16), (8, 8), False) if case == "aligned" else ((0, 0), (0, 0), True)
+    checked = 0
+    for st in stacks:
+        if full:
+            pbb = (st.attr.nx, st.attr.ny)
+            p, i2w, w2i, total, org = pvr.generate2DPatches(st, mask, mattr, pbb, (pbb[0] + 1, pbb[1] + 1), with_origins=True)
+        else:
+            p, i2w, w2i, total, org = pvr.generate2DPatches(st, mask, mattr, size, stride, with_origins=True)
+        op, oi, ow, ototal, oorg = oracle_mod.generate_2d_patches(st.data, st.attr, st.thickness, mask, mattr, size, stride, full_slices=full, snap=True)
+        assert len(op) == len(p) > 0 and ototal == total
+        assert np.array_equal(op, p)                                   # which pixel every patch pixel reads: exact
+        assert np.allclose(oi, i2w, rtol=0, atol=2e-4) and np.allclose(ow, w2i, rtol=0, atol=2e-4)    # float32 of doubles built in two orders, 300 mm off
+        assert np.allclose(oorg, org, rtol=0, atol=1e-9)
+        checked += len(p)
+        if case == "aligned":
+            # on a grid whose arithmetic is exact the literal truncation and the 1e-6 snap agree
+            lp, *_ = oracle_mod.generate_2d_patches(st.data, st.attr, st.thickness, mask, mattr, size, stride, snap=False)
+            assert len(lp) == len(op)
+    assert checked > 10
+
+
+def test_cpp_patches_against_the_oracle(tmp_path, oracle_mod):
+    """bin/PVRreconstructionGPU --dumpProblem --dryRun: the patches the C++ command line cuts (csrc/pvr_cli.cpp) are the oracle's
+    cut of the same pre-processed stacks."""
+    from fetalreconstruction_amd import build, nifti
+    from tests.test_pvr import _python_pvr_problem, _write_pvr_case
+    build.build()
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    dump = tmp_path / "problem.bin"
+    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8",
+                        "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = dump.read_bytes()
+    hdr = np.frombuffer(raw, np.int32, 8)
+    ns, px, py, nst = [int(v) for v in hdr[:4]]
+    o = 32
+    counts = np.frombuffer(raw, np.int32, nst, o); o += 4 * nst + 8
+    patches = np.frombuffer(raw, np.float32, ns * py * px, o).reshape(ns, py, px); o += 4 * ns * py * px
+    i2w = np.frombuffer(raw, np.float32, ns * 16, o).reshape(ns, 16)
+    # the same pre-processed stacks (mask binarisation, cropping, iso mask, intensity matching: the Python chain, which the
+    # dump test of test_pvr.py ties to the C++ one), cut by the oracle
+    P, _, _ = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0)
+    from fetalreconstruction_amd import pvr_cli
+    md, mat = nifti.read(mpath)
+    ims = [pp.Image(nifti.read(p)[0].astype(np.float64), nifti.read(p)[1]) for p in paths]
+    st2, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(ims, [np.eye(4)] * len(ims), pp.Image(md.astype(np.float64), mat), 1.0, 0, False)
+    at = 0
+    for k, s in enumerate(st2):
+        op, oi, ow, _, _ = oracle_mod.generate_2d_patches(s.data.astype(np.float32), s.attr, s.attr.dz, iso_mask.data, iso_mask.attr, (16, 16), (8, 8))
+        assert len(op) == counts[k]
+        assert np.array_equal(op, patches[at:at + len(op)])
+        assert np.allclose(oi, i2w[at:at + len(op)], atol=1e-5)
+        at += len(op)
+    assert at == ns
