@@ -57,15 +57,15 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
     out, i2ws, w2is, origins = [], [], [], []
     total = 0
     for z in range(a.nz):
-        centre = s_i2w @ np.array([(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, float(z), 1.0])
+        centre = geo.apply_points(s_i2w, np.array([(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, float(z), 1.0]))
         sl_attr = geo.ImageAttributes(a.nx, a.ny, 1, a.dx, a.dy, stack.thickness * 2, a.xaxis, a.yaxis, a.zaxis,
                                       origin=centre[:3])                       # GetRegion + PutPixelSize :204-205
         sl_i2w, sl_w2i = geo.image_to_world(sl_attr), geo.world_to_image(sl_attr)
         p0 = geo.ImageAttributes(px, py, 1, a.dx, a.dy, stack.thickness * 2, a.xaxis, a.yaxis, a.zaxis)
-        p0_first = geo.image_to_world(p0) @ np.array([0.0, 0.0, 0.0, 1.0])
+        p0_first = geo.apply_points(geo.image_to_world(p0), np.array([0.0, 0.0, 0.0, 1.0]))
         for y in range(0, a.ny + py, sy):
             for x in range(0, a.nx + px, sx):
-                first = sl_i2w @ np.array([float(x), float(y), 0.0, 1.0])
+                first = geo.apply_points(sl_i2w, np.array([float(x), float(y), 0.0, 1.0]))
                 pa = copy.copy(p0)
                 pa.origin = (first - p0_first)[:3]                              # :232-246
                 p_i2w = geo.image_to_world(pa)

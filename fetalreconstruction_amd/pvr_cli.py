@@ -115,8 +115,8 @@ def split_packages(stack, packages):
         pa.nz = pkg_z + 1 if pkg_z * packages + l < a.nz else pkg_z
         pa.dz = a.dz * packages
         pa.origin = np.asarray(a.origin, np.float64).copy()
-        target = i2w @ np.array([0.0, 0.0, float(l), 1.0])
-        first = geo.image_to_world(pa) @ np.array([0.0, 0.0, 0.0, 1.0])
+        target = geo.apply_points(i2w, np.array([0.0, 0.0, float(l), 1.0]))
+        first = geo.apply_points(geo.image_to_world(pa), np.array([0.0, 0.0, 0.0, 1.0]))
         pa.origin = pa.origin + (target - first)[:3]
         out.append(pp.Image(stack.data[l::packages][:pa.nz].copy(), pa))
     return out
@@ -166,7 +166,7 @@ def resample_bspline(img, d):
         v = np.moveaxis(coeff, axis, -1)
         _bspline_coefficients(v)
     out_attr = resample_attr(a, d)
-    m = geo.world_to_image(a) @ geo.image_to_world(out_attr)
+    m = geo.mat_mul(geo.world_to_image(a), geo.image_to_world(out_attr))
     kk, jj, ii = np.meshgrid(np.arange(out_attr.nz), np.arange(out_attr.ny), np.arange(out_attr.nx), indexing="ij")
     p = [m[r, 0] * ii + m[r, 1] * jj + m[r, 2] * kk + m[r, 3] for r in range(3)]
     idx, wgt = [], []
