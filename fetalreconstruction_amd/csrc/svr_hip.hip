@@ -190,14 +190,19 @@ struct RowConst {
   float dd, w;
   float invD;
 };
+__device__ __forceinline__ float uniform_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 __device__ __forceinline__ RowConst load_row_const(const SliceConst &S) {
   RowConst R;
 #pragma unroll
   for (int i = 0; i < 9; ++i) R.Lp[i] = S.Lp[i];
-  R.inv2s2 = S.inv2s2;
-  R.dd = S.dd;
-  R.w = S.w;
-  R.invD = S.invD;
+  // (through readfirstlane: the four values stay in scalar registers; read as plain struct fields the vectoriser fuses
+  // them into one 16-byte load of a stack copy of the struct -- 32 bytes of scratch per lane for nothing)
+  R.inv2s2 = uniform_f(S.inv2s2);
+  R.dd = uniform_f(S.dd);
+  R.w = uniform_f(S.w);
+  R.invD = uniform_f(S.invD);
   return R;
 }
 
@@ -255,7 +260,7 @@ struct GaussStep {        // state of the recurrence between two chunks of pairs
   f2 g, r;
   bool ok;
 };
-__device__ __forceinline__ GaussStep gauss_start(const RowConst &S, float rowz) {
+__device__ __forceinline__ GaussStep gauss_start(const RowConst S, float rowz) {
   const f2 zc = fma2(bc2(S.Lp[6]), (f2){0.0f, 1.0f}, bc2(rowz));
   const f2 ac = (zc * zc) * bc2(S.inv2s2);
   const f2 t = fma2(((f2){-2.0f, 2.0f}) * zc, bc2(S.Lp[6]), bc2(S.dd)) * bc2(S.inv2s2);
@@ -267,7 +272,7 @@ __device__ __forceinline__ GaussStep gauss_start(const RowConst &S, float rowz) 
 }
 // factors of pairs j0 .. j0 + H - 1
 template <int H>
-__device__ __forceinline__ void gauss_pairs(const RowConst &S, float rowz, GaussStep &st, int j0, f2 g[H]) {
+__device__ __forceinline__ void gauss_pairs(const RowConst S, float rowz, GaussStep &st, int j0, f2 g[H]) {
 #pragma unroll
   for (int i = 0; i < H; ++i) {
     if (j0 + i > 0) {
@@ -286,7 +291,7 @@ __device__ __forceinline__ void gauss_pairs(const RowConst &S, float rowz, Gauss
 }
 // the same for the first tap (lattice offset -CENTRE) of two rows at once: x = row A, y = row B
 template <int CENTRE>
-__device__ __forceinline__ f2 gauss_first_tap2(const RowConst &S, f2 rowz) {
+__device__ __forceinline__ f2 gauss_first_tap2(const RowConst S, f2 rowz) {
   const f2 zl = fma2(bc2(S.Lp[6]), bc2(0.0f), rowz), zr = fma2(bc2(S.Lp[6]), bc2(1.0f), rowz);
   const f2 al = (zl * zl) * bc2(S.inv2s2), ar = (zr * zr) * bc2(S.inv2s2);
   const f2 t = fma2(bc2(-2.0f) * zl, bc2(S.Lp[6]), bc2(S.dd)) * bc2(S.inv2s2);
@@ -315,7 +320,7 @@ __device__ __forceinline__ f2 gauss_first_tap2(const RowConst &S, f2 rowz) {
 // q == 0 gives NaN like sin(0)/0 in the reference (RC.cu:129); PVR takes sinc_pi's Taylor branch there instead.
 #define RSQRT_MAGIC 0x5f375a86u
 template <int H, bool PVR>
-__device__ __forceinline__ void eval_pairs_xyz(const RowConst &S, const f2 xs[H], const f2 ys[H], f2 val2[H]) {
+__device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H], const f2 ys[H], f2 val2[H]) {
 #define EACH for (int i = 0; i < H; ++i)
     f2 q[H], y[H], h[H], r[H], f[H], p[H];
 #pragma unroll
@@ -386,7 +391,7 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst &S, const f2 xs[H]
 // ZERO: skipped taps come out as -0.0f instead of -1: adding them changes nothing, and a processed tap whose value is
 // exactly +0 (an underflowed Gaussian factor, sin(pi r) at an integer r) can still be told from a skipped one by its bits
 template <int N, bool PVR, bool ZERO = false>
-__device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by, float bz, float fy,
+__device__ __forceinline__ void eval_row_t(const RowConst S, float bx, float by, float bz, float fy,
                                            float fz, float out[N]) {
   // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage of eval_pairs_xyz
   // compiles to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (half the issue slots for the same cycles);
@@ -440,7 +445,7 @@ __device__ __forceinline__ void eval_row_t(const RowConst &S, float bx, float by
 // quadratic x'^2 + y'^2 shrunk by 1 % (covers the roundings of x', y', q), both with the polynomial errors
 // of the canonical sin / exp (< 1e-6) far inside the 2 % margin of the threshold.  A row that may contain
 // the R = 0 tap (NaN, RC.cu:129) is never declared dead.
-__host__ __device__ __forceinline__ bool row_is_dead(const RowConst &S, float bx, float by, float bz, float fy, float fz) {
+__host__ __device__ __forceinline__ bool row_is_dead(const RowConst S, float bx, float by, float bz, float fy, float fz) {
   const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
   const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
   const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
@@ -466,12 +471,12 @@ __host__ __device__ __forceinline__ bool row_is_dead(const RowConst &S, float bx
   return amin + logf(fmaxf(1.0f, 9.8696044f * qmin)) > SVR_DEAD_THR;
 }
 
-__device__ __forceinline__ void eval_row_at(const RowConst &S, float bx, float by, float bz, float fy,
+__device__ __forceinline__ void eval_row_at(const RowConst S, float bx, float by, float bz, float fy,
                                             float fz, float out[16]) {
   eval_row_t<16, false>(S, bx, by, bz, fy, fz, out);
 }
 // Phase 1 of the wave-per-pixel kernels: lane = one (y,z) row of quarter q (4 z-planes x 16 y)
-__device__ __forceinline__ void eval_row(const RowConst &S, const PixelState &P, int lane, int q,
+__device__ __forceinline__ void eval_row(const RowConst S, const PixelState &P, int lane, int q,
                                          float out[16]) {
   eval_row_at(S, P.bx, P.by, P.bz, (float)((lane & 15) - PSF_CENTRE), (float)(4 * q + (lane >> 4) - PSF_CENTRE), out);
 }
@@ -858,7 +863,7 @@ struct RowWalk {       // i = y * P + x walked in steps of `stride` without a di
 // square (z' is affine), exp(-a_min) with sinc^2 <= 1 bounds the value; the R = 0 tap (NaN, RC.cu:129 -- it would be
 // processed, and so would every tap after it in its row) is excluded by evaluating q at the lattice points around the
 // real solution of x' = y' = 0.  A degenerate in-plane map (rows along the slice normal) never takes the shortcut.
-__device__ __forceinline__ bool unit_is_dead(const RowConst &S, float bx, float by, float bz, int F, float fo) {
+__device__ __forceinline__ bool unit_is_dead(const RowConst S, float bx, float by, float bz, int F, float fo) {
   const bool f1 = F == 1;                               // (selects, not indexing: an index would put RowConst into scratch)
   const float LxF = f1 ? S.Lp[1] : S.Lp[2], LxG = f1 ? S.Lp[2] : S.Lp[1];
   const float LyF = f1 ? S.Lp[4] : S.Lp[5], LyG = f1 ? S.Lp[5] : S.Lp[4];
@@ -1158,7 +1163,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SVR_
 // parameter: planes beyond 4 * groups are dealt round-robin to the same wavefronts.
 #define WAVE_MAXPIX 32    // pixels of a tile (larger tiles go to the workgroup kernels)
 template <int NS = PSF_SUPPORT, bool PVR = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SVR_WPE_SLOT, SVR_WPE_SLOT)))
+#ifndef SVR_WPE_WAVE
+#define SVR_WPE_WAVE 3    // 170 VGPRs: the LDS box allows 8-10 wavefronts per CU anyway
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SVR_WPE_WAVE, SVR_WPE_WAVE)))
 void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_tiles, uint32_t *fallback_count) {
   constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
   extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -1312,14 +1320,17 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
         const int ay = R.cy + y - NC;                   // may be negative: aliases to 0 at flush
         const bool rowok = y < NS && ay < vgy;
         const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
+        // the row's accumulators are fetched before the evaluation (their LDS latency hides behind ~500 instructions; the
+        // registers are free: the box, not the register file, sets the occupancy).  A lane without a row reads the
+        // plane's first words and writes nothing.
+        f2 acc[NS];
+#pragma unroll
+        for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
         float out[NS];
         eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fzu : fyl, swap ? fyl : fzu, out);
         if (rowok) {
           // all NS x positions are inside the box by construction: unconditional read-add-write (skipped taps add 0)
           const f2 ff = (f2){R.f0, R.f1};
-          f2 acc[NS];
-#pragma unroll
-          for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
 #pragma unroll
           for (int x = 0; x < NS; ++x) pb[rb + x] = fma2(bc2(out[x]), ff, acc[x]);
         }
