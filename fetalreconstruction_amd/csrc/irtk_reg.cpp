@@ -23,22 +23,90 @@
 #include <float.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "svr_prep.h"
 
 namespace {
 
-// rows of an image are independent in every filter below: split them over the host cores (results do not depend on it)
+// Rows of an image, and the targets of a registration pass, are independent in every filter below: they are split over a
+// pool of host threads that lives as long as the library (starting threads per call cost more than the 280 small pyramids
+// of a slice-to-volume pass).  Results do not depend on the split.  A call from inside a pool task, or while another
+// host thread (an in-process rank) owns the pool, runs inline.
+class WorkPool {
+ public:
+  static WorkPool &get() { static WorkPool p; return p; }
+  template <class F> void run(int n, int max_threads, F &fn) {
+    if (n < 2 || max_threads < 2 || inside() || workers_.empty() || !owner_.try_lock()) { fn(0, n); return; }
+    const int nt = std::min<int>({max_threads, (int)workers_.size() + 1, n});
+    {
+      std::lock_guard<std::mutex> g(m_);
+      call_ = [](void *f, int a, int b) { (*static_cast<F *>(f))(a, b); };
+      fn_ = &fn; n_ = n; chunk_ = std::max(1, n / (nt * 4)); next_ = 0; wanted_ = nt - 1; running_ = nt - 1; ++gen_;
+    }
+    cv_.notify_all();
+    inside() = true;
+    work();
+    inside() = false;
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return running_ == 0; });
+    g.unlock();
+    owner_.unlock();
+  }
+  int size() const { return (int)workers_.size() + 1; }
+
+ private:
+  WorkPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = (int)std::min<unsigned>(hw ? hw : 1, 128u);
+    if (const char *e = getenv("SVR_HOST_THREADS")) n = std::max(1, atoi(e));
+    for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~WorkPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  static bool &inside() { static thread_local bool in = false; return in; }
+  void work() {
+    for (;;) {
+      const int a = next_.fetch_add(chunk_);
+      if (a >= n_) break;
+      call_(fn_, a, std::min(n_, a + chunk_));
+    }
+  }
+  void loop() {
+    inside() = true;
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> g(m_);
+    for (;;) {
+      cv_.wait(g, [&] { return stop_ || (gen_ != seen && wanted_ > 0); });
+      if (stop_) return;
+      seen = gen_;
+      --wanted_;
+      g.unlock();
+      work();
+      g.lock();
+      if (--running_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_, owner_;
+  std::condition_variable cv_, done_;
+  void (*call_)(void *, int, int) = nullptr;
+  void *fn_ = nullptr;
+  int n_ = 0, chunk_ = 1, wanted_ = 0, running_ = 0;
+  std::atomic<int> next_{0};
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
 template <class F> void parallel_rows(int n, size_t work_per_row, F fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 64u), (size_t)n * work_per_row / 100000 + 1);
-  if (nt <= 1 || n < 2) { fn(0, n); return; }
-  nt = std::min(nt, n);
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t) th.emplace_back(fn, (int)((long)n * t / nt), (int)((long)n * (t + 1) / nt));
-  for (auto &x : th) x.join();
+  const int nt = (int)std::min<size_t>(128, (size_t)n * work_per_row / 50000 + 1);
+  WorkPool::get().run(n, nt, fn);
 }
 
 template <class T> struct Vol {
@@ -520,27 +588,35 @@ int svrh_slice_to_volume_registration(svr_ctx *ctx, const svr_ncc_backend *backe
   std::vector<Target> targets;
   std::vector<int> which;
   targets.reserve(n_slices);
-  for (int s = 0; s < n_slices; ++s) {                                    // ParallelSliceToVolumeRegistration, RG.cc:2002-2050
-    Vol<double> sl;
-    sl.a = attrs[s];
-    sl.d.resize(sl.n());
-    for (int y = 0; y < sl.a.ny; ++y)
-      for (int x = 0; x < sl.a.nx; ++x) sl.at(x, y, 0) = slices[((size_t)s * sy + y) * sx + x];
-    // the patch-based caller (ParallelPatchToVolumeRegistration, patchBased2D3DRegistration.cpp:113-122) resamples into a variable
-    // that shadows the patch and goes out of scope: its targets are registered as they are
-    const Vol<double> t = (flags & SVRH_S2V_NO_RESAMPLE) ? sl : resample_with_padding<double>(sl, recon_attr->dx, recon_attr->dx, recon_attr->dx, -1.0);
-    grey[s].a = t.a;
-    grey[s].d.resize(t.d.size());
-    short smax = -32768;
-    for (size_t i = 0; i < t.d.size(); ++i) { grey[s].d[i] = (short)t.d[i]; smax = std::max(smax, grey[s].d[i]); }
-    if (!(smax > -1)) continue;                                           // nothing to register
-    M4 mo, m;
-    reset_origin(grey[s].a, mo);
+  std::vector<char> live(n_slices, 0);
+  std::vector<M4> mo_all(n_slices);
+  parallel_rows(n_slices, (size_t)sx * sy * 60, [&](int s0, int s1) {       // ParallelSliceToVolumeRegistration, RG.cc:2002-2050
+    for (int s = s0; s < s1; ++s) {
+      Vol<double> sl;
+      sl.a = attrs[s];
+      sl.d.resize(sl.n());
+      for (int y = 0; y < sl.a.ny; ++y)
+        for (int x = 0; x < sl.a.nx; ++x) sl.at(x, y, 0) = slices[((size_t)s * sy + y) * sx + x];
+      // the patch-based caller (ParallelPatchToVolumeRegistration, patchBased2D3DRegistration.cpp:113-122) resamples into a variable
+      // that shadows the patch and goes out of scope: its targets are registered as they are
+      const Vol<double> t = (flags & SVRH_S2V_NO_RESAMPLE) ? sl : resample_with_padding<double>(sl, recon_attr->dx, recon_attr->dx, recon_attr->dx, -1.0);
+      grey[s].a = t.a;
+      grey[s].d.resize(t.d.size());
+      short smax = -32768;
+      for (size_t i = 0; i < t.d.size(); ++i) { grey[s].d[i] = (short)t.d[i]; smax = std::max(smax, grey[s].d[i]); }
+      if (!(smax > -1)) continue;                                           // nothing to register
+      reset_origin(grey[s].a, mo_all[s]);
+      live[s] = 1;
+    }
+  });
+  for (int s = 0; s < n_slices; ++s) {
+    if (!live[s]) continue;
+    M4 m;
     for (int q = 0; q < 16; ++q) m.m[q] = transformations[16 * s + q];
-    mo_inv[s] = inverse_rigid_or_affine(mo);
+    mo_inv[s] = inverse_rigid_or_affine(mo_all[s]);
     Target tg;
     tg.full = &grey[s];
-    tg.matrix = mul(m, mo);
+    tg.matrix = mul(m, mo_all[s]);
     matrix_to_params(tg.matrix, tg.p);
     targets.push_back(tg);
     which.push_back(s);

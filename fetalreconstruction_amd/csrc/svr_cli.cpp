@@ -26,7 +26,7 @@
 
 
 int main(int argc, char **argv) {
-  std::string output, mask_name, tfolder;
+  std::string output, mask_name, tfolder, sfolder;
   bool debug = false;
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
@@ -74,6 +74,7 @@ int main(int argc, char **argv) {
     else if (o == "-p" || o == "--packages") { std::vector<std::string> v; multi(v); for (auto &x : v) packages.push_back(atoi(x.c_str())); }
     else if (o == "--no_registration") no_registration = true;
     else if (o == "--tfolder") tfolder = one();
+    else if (o == "--sfolder") sfolder = one();
     else if (o == "--debug") debug = opt_bool(true);
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
     else if (o == "-d" || o == "--devices") { std::vector<std::string> v; multi(v); for (auto &s : v) devices.push_back(atoi(s.c_str())); }
@@ -81,7 +82,7 @@ int main(int argc, char **argv) {
       printf("usage: SVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> [-m <mask>] [-t id|<4x4.txt> ..] [--thickness th_1 ..]\n"
              "       [--iterations 4] [--resolution 0.75] [--multires 3] [--average 700] [--delta 150] [--lambda 0.02]\n"
              "       [--lastIterLambda 0.01] [--smooth_mask 4] [--no_intensity_matching] [--force_exclude i ..]\n"
-             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [-d device_1 .. device_N]\n");
+             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [--tfolder dir] [--sfolder dir] [-d device_1 .. device_N]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/svr_cli.cpp)");
@@ -113,23 +114,23 @@ int main(int argc, char **argv) {
   if (thickness.empty()) for (auto &s : stacks) thickness.push_back(2.0 * s.a.dz);            // main.cc:422-431
   if (thickness.size() != n) die("one thickness per stack expected");
   Image mask_img;
-  const bool have_mask = true;
+  const bool have_mask = !mask_name.empty() || sfolder.empty();          // main.cc:461: no mask is made up when --sfolder is given
   if (!mask_name.empty()) {
     mask_img = read_image(mask_name);
-  } else {
+  } else if (have_mask) {
     // no mask given: CreateMask(stacks[templateNumber]) binarises the template stack (> 0), in case it was padded; the
     // normal mask path follows (main.cc:458-480, RG.cc:736-748)
     mask_img = stacks[tmpl];
     for (auto &v : mask_img.d) v = v > 0.0 ? 1.0 : 0.0;
   }
-  {
+  if (have_mask) {
     const Image m = transform_nn(mask_img, stacks[tmpl].a, ts[tmpl], 0.0);                     // TransformMask RG.cc:805-821
     stacks[tmpl] = crop_image(stacks[tmpl], m);
   }
   const svr_image_attr tattr = create_template(stacks[tmpl].a, resolution);
   const Image vol_mask = set_mask(tattr, have_mask ? &mask_img : nullptr, smooth_mask);
   auto stack_registrations = [&]() {                                                             // StackRegistrations, RG.cc:849-1001
-    if (no_registration || n < 2) return;
+    if (no_registration || n < 2 || !sfolder.empty()) return;                                    // main.cc:658, 708
     std::vector<svr_image_attr> at(n);
     std::vector<const double *> ptr(n);
     std::vector<double> tm(16 * n);
@@ -151,8 +152,30 @@ int main(int argc, char **argv) {
   stack_registrations();                                                                         // main.cc:707-713
   const std::vector<float> factors = match_stack_intensities(stacks, ts, vol_mask, average, no_matching);
   // CreateSlicesAndTransformations RG.cc:1835-1880 + MaskSlices RG.cc:1940-1988 + the packing of SyncGPU RG.cc:249-328
-  int ns = 0, mx = 0, my = 0;
-  for (auto &s : stacks) { ns += s.a.nz; mx = std::max(mx, s.a.nx); my = std::max(my, s.a.ny); }
+  struct SliceSrc { Image r; M4 t; int stack; };
+  std::vector<SliceSrc> srcs;
+  for (size_t k = 0; k < n; ++k)
+    for (int j = 0; j < stacks[k].a.nz; ++j) {
+      SliceSrc q{get_region(stacks[k], 0, 0, j, stacks[k].a.nx, stacks[k].a.ny, j + 1), ts[k], (int)k};
+      q.r.a.dz = thickness[k];
+      srcs.push_back(q);
+    }
+  if (!sfolder.empty()) {
+    // replaceSlices, RG.cc:4767-4822: every file of the folder is one slice that is already in place -- identity
+    // transformation, stack 0, 4 mm thickness, "equally many as loaded from stacks".  The reference takes the files in
+    // directory_iterator order (unspecified); here they are taken in the order of their names.
+    std::vector<std::string> files = list_directory(sfolder);
+    if (files.size() != srcs.size())
+      die("--sfolder: " + std::to_string(files.size()) + " files, but the stacks hold " + std::to_string(srcs.size()) + " slices");
+    for (size_t i = 0; i < files.size(); ++i) {
+      SliceSrc q{read_image(sfolder + "/" + files[i]), ident(), 0};
+      if (q.r.a.nz != 1) die("--sfolder: " + files[i] + " is not a single slice");
+      q.r.a.dz = 4.0;
+      srcs[i] = q;
+    }
+  }
+  int ns = (int)srcs.size(), mx = 0, my = 0;
+  for (auto &q : srcs) { mx = std::max(mx, q.r.a.nx); my = std::max(my, q.r.a.ny); }
   std::vector<float> grid((size_t)ns * mx * my, -1.0f), i2w(16 * (size_t)ns), w2i(16 * (size_t)ns), st(16 * (size_t)ns),
       sti(16 * (size_t)ns), dims(3 * (size_t)ns);
   std::vector<int> sizes_x(ns), sizes_y(ns), stack_index(ns);
@@ -160,18 +183,16 @@ int main(int argc, char **argv) {
   std::vector<double> T(16 * (size_t)ns);
   const M4 mw2i = world_to_image(vol_mask.a);
   double vmin = 1e300, vmax = -1e300;
-  int sl = 0;
-  for (size_t k = 0; k < n; ++k)
-    for (int j = 0; j < stacks[k].a.nz; ++j, ++sl) {
-      Image r = get_region(stacks[k], 0, 0, j, stacks[k].a.nx, stacks[k].a.ny, j + 1);
-      r.a.dz = thickness[k];
+  for (int sl = 0; sl < ns; ++sl) {
+      const Image &r = srcs[sl].r;
+      const M4 &tk = srcs[sl].t;
       const M4 si2w = image_to_world(r.a);
       for (int y = 0; y < r.a.ny; ++y)
         for (int x = 0; x < r.a.nx; ++x) {
           double v = r.at(x, y, 0);
           if (v < 0.01) v = -1;
           double qx = x, qy = y, qz = 0;                   // ImageToWorld, Transform, WorldToImage: three applications (RG.cc:1961-1972)
-          apply_point(si2w, qx, qy, qz); apply_point(ts[k], qx, qy, qz); apply_point(mw2i, qx, qy, qz);
+          apply_point(si2w, qx, qy, qz); apply_point(tk, qx, qy, qz); apply_point(mw2i, qx, qy, qz);
           const long i = (long)irtk_round(qx), jj = (long)irtk_round(qy), kk = (long)irtk_round(qz);
           if (!(i >= 0 && i < vol_mask.a.nx && jj >= 0 && jj < vol_mask.a.ny && kk >= 0 && kk < vol_mask.a.nz) ||
               vol_mask.at((int)i, (int)jj, (int)kk) == 0)
@@ -180,14 +201,16 @@ int main(int argc, char **argv) {
           if (v > 0) { vmin = std::min(vmin, (double)(float)v); vmax = std::max(vmax, (double)(float)v); }
         }
       to_f16(si2w, &i2w[16 * (size_t)sl]); to_f16(world_to_image(r.a), &w2i[16 * (size_t)sl]);
-      to_f16(ts[k], &st[16 * (size_t)sl]); to_f16(inverse_rigid_or_affine(ts[k]), &sti[16 * (size_t)sl]);
-      for (int q = 0; q < 16; ++q) T[16 * (size_t)sl + q] = ts[k].m[q];
+      to_f16(tk, &st[16 * (size_t)sl]); to_f16(inverse_rigid_or_affine(tk), &sti[16 * (size_t)sl]);
+      for (int q = 0; q < 16; ++q) T[16 * (size_t)sl + q] = tk.m[q];
       dims[3 * (size_t)sl] = (float)r.a.dx; dims[3 * (size_t)sl + 1] = (float)r.a.dy; dims[3 * (size_t)sl + 2] = (float)r.a.dz;
-      sizes_x[sl] = r.a.nx; sizes_y[sl] = r.a.ny; stack_index[sl] = (int)k; sattr[sl] = r.a;
-    }
+      sizes_x[sl] = r.a.nx; sizes_y[sl] = r.a.ny; stack_index[sl] = srcs[sl].stack; sattr[sl] = r.a;
+  }
   if (!(vmax > 0)) die("no slice pixel lies inside the mask");
-  fprintf(stderr, "%zu stacks, %d slices of up to %dx%d, volume %dx%dx%d at %g mm\n", n, ns, mx, my, tattr.nx, tattr.ny, tattr.nz,
+  fprintf(stderr, "%zu stacks, %d slices of up to %dx%d, volume %dx%dx%d at %g mm, stack factors", n, ns, mx, my, tattr.nx, tattr.ny, tattr.nz,
           resolution);
+  for (float f : factors) fprintf(stderr, " %.9g", f);
+  fprintf(stderr, "\n");
 
   // ---- ranks: one engine context per device of -d (main.cc:191), the slices sharded over them in contiguous ranges
   // balanced by active pixels (reconstruction_cuda2.cu:1413-1457 shards by slice count and drops the remainder) ----------

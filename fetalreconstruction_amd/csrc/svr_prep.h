@@ -5,6 +5,7 @@
 // per program, hence the unnamed namespace.
 #ifndef SVR_PREP_H
 #define SVR_PREP_H
+#include <dirent.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -176,6 +177,20 @@ Image set_mask(const svr_image_attr &tmpl, const Image *mask, double sigma, doub
     for (double &v : m.d) v = v > threshold ? 1.0 : 0.0;
   }
   return transform_nn(m, tmpl, ident(), 0.0);
+}
+
+// the regular entries of a directory, by name
+std::vector<std::string> list_directory(const std::string &dir) {
+  std::vector<std::string> out;
+  DIR *d = opendir(dir.c_str());
+  if (!d) die(dir + " does not exist");
+  while (const dirent *e = readdir(d)) {
+    const std::string name = e->d_name;
+    if (name != "." && name != "..") out.push_back(name);
+  }
+  closedir(d);
+  std::sort(out.begin(), out.end());
+  return out;
 }
 
 // irtkGenericImage::GetRegion(i1, j1, k1, i2, j2, k2)

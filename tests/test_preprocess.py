@@ -218,6 +218,52 @@ def test_transformations_round_trip_through_tfolder(tmp_path):
     assert np.corrcoef(va[ok], vb[ok])[0, 1] > 0.95                       # same registered slices, same last-iteration settings
 
 
+@pytest.mark.gpu
+def test_sfolder_replaces_the_slices_by_the_files_of_a_folder(tmp_path):
+    """--sfolder (reconstruction.cc:193, replaceSlices RG.cc:4767-4822): every file of the folder is one slice that is already
+    in place (identity transformation, stack 0, 4 mm thickness), as many as the stacks hold; no stack registration, no mask
+    made up.  The folder here holds the stacks' own planes cut out with GetRegion and scaled by the factor the intensity
+    matching gave the stacks (it is applied to the stacks, not to the replaced slices), so the run must reproduce the plain run."""
+    import subprocess
+    from fetalreconstruction_amd import build, nifti
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(2, (40, 40, 12), 1.1, 2.0, None, 1.0, 16.0, seed=2,
+                                                            stack_motion_mm=0.0, stack_motion_deg=0.0)
+    paths = []
+    for k, st in enumerate(stacks):
+        nifti.write(tmp_path / f"stack{k}.nii.gz", st.data, st.attr)
+        paths.append(str(tmp_path / f"stack{k}.nii.gz"))
+    # a mask that covers every stack completely: the crop boxes are the whole stacks, so the planes below are the planes the
+    # plain run cuts (cropping to the mask's box in stack space and MaskSlices' voxel test differ by a rim of pixels)
+    big = copy.deepcopy(rattr)
+    big.nx = big.ny = big.nz = 64
+    nifti.write(tmp_path / "mask.nii.gz", np.ones((64, 64, 64), np.float32), big)
+    common = ["-i", *paths, "-m", str(tmp_path / "mask.nii.gz"), "--thickness", "4", "4", "--resolution", "1.0", "--iterations", "1",
+              "--rec_iterations_last", "4", "--smooth_mask", "0", "--no_intensity_matching", "0", "--no_registration"]
+    a = subprocess.run([build.CLI, "-o", str(tmp_path / "a.nii.gz"), *common], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stderr[-2000:]
+    f = [float(x) for x in a.stderr.split("stack factors")[1].split("\n")[0].split()]
+    assert len(f) == 2 and f[0] == f[1] and f[0] > 0                      # matched together: one factor (reconstruction.cc:716-719)
+    folder = tmp_path / "slices"
+    folder.mkdir()
+    n = 0
+    for k, st in enumerate(stacks):
+        img = pp.Image(np.asarray(st.data, np.float64) * f[0], st.attr)
+        for j in range(st.attr.nz):
+            r = pp.get_region(img, 0, 0, j, st.attr.nx, st.attr.ny, j + 1)
+            nifti.write(folder / f"slice{n:04d}.nii.gz", r.data, r.attr)
+            n += 1
+    b = subprocess.run([build.CLI, "-o", str(tmp_path / "b.nii.gz"), *common, "--sfolder", str(folder)], capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-2000:]
+    va, _ = nifti.read(tmp_path / "a.nii.gz")
+    vb, _ = nifti.read(tmp_path / "b.nii.gz")
+    assert (va > 0).sum() > 20000 and np.array_equal(va > 0, vb > 0)
+    d = np.abs(va - vb) / np.abs(va).max()
+    assert d.max() <= 2e-4, (float(d.max()), int((d > 2e-4).sum()))      # the same slices (float32 files of the scaled planes), found another way
+    (folder / "slice0003.nii.gz").unlink()
+    c = subprocess.run([build.CLI, "-o", str(tmp_path / "c.nii.gz"), *common, "--sfolder", str(folder)], capture_output=True, text=True, timeout=300)
+    assert c.returncode != 0 and "23 files, but the stacks hold 24 slices" in c.stderr
+
+
 def test_command_line_boolean_options_follow_the_reference():
     """`--debug`, `--no_intensity_matching`, `--no_log` are po::value<bool> in the reference (reconstruction.cc:186-205): they take
     a value, and the value of --no_intensity_matching lands in `intensity_matching` itself (0 switches the matching off)."""
