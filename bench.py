@@ -151,10 +151,24 @@ def main():
     comm, rccl_world = None, None
     if world > 1:
         if args.comm == "rccl":
-            box = [RcclComm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            comm = RcclComm(rec, rank, world, box[0])
-            rccl_world = comm.rccl_world()
+            # every rank first proves it can open librccl (a rank that cannot would leave the others waiting inside
+            # ncclCommInitRank); if one cannot, all ranks fall back to host-staged exchanges over gloo and say so
+            try:
+                uid, why = RcclComm.unique_id(), None
+            except Exception as ex:
+                uid, why = None, repr(ex)
+            oks = [None] * world
+            dist.all_gather_object(oks, why)
+            if any(w is not None for w in oks):
+                if rank == 0:
+                    print(f"note: RCCL unavailable on some rank ({[w for w in oks if w][0]}); exchanging through gloo", file=sys.stderr)
+                args.comm = "gloo-fallback"
+                comm = TorchComm(device=None)
+            else:
+                box = [uid if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = RcclComm(rec, rank, world, box[0])
+                rccl_world = comm.rccl_world()
         else:
             comm = TorchComm(device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity)

@@ -2585,7 +2585,7 @@ struct svr_ctx {
   uint32_t n_tiles_fb8 = 0;   // tiles of the last scatter that the wave-owned kernel handed to the workgroup kernel (box larger than wave_cap)
   uint32_t *d_tiles_fb2 = nullptr;
   bool wave_cap_user = false;
-  int wave_groups = 1, wave_cap = 2116;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (4 x 23 x 23: 16.5 KiB)
+  int wave_groups = 1, wave_cap = 2096;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (14 LDS granules of 1280 B with the static part: 9 wavefronts per CU)
 
   // reductions
   double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
@@ -3618,10 +3618,13 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     if (!r && (ctx->pvr || ctx->back_mode == 4) && !ctx->wave_cap_user) {
       // the wave-owned scatter's LDS request decides how many wavefronts a CU holds; the smallest box that still takes
       // (nearly) every tile wins -- tiles that do not fit are re-run by the workgroup kernel, so any value is correct
-      static const int caps[4] = {2116, 1936, 1764, 1600};       // 4 planes of 23^2, 22^2, 21^2, 20^2 voxels
+      // LDS is handed out in 1280-byte granules (measured: the time steps between 1764 and 1850 box voxels, not where
+      // 160 KiB / request changes), so a CU holds floor(128 / granules) wavefronts: the candidates are the largest boxes
+      // (with the kernel's 1152 static bytes) that still give 8, 9, 10, 11 and 12 of them
+      static const int caps[5] = {2416, 2096, 1776, 1616, 1456};
       float bestc = 3.0e38f;
       int pickc = ctx->wave_cap;
-      for (int c = 0; c < 4 && !r; ++c) {
+      for (int c = 0; c < 5 && !r; ++c) {
         ctx->wave_cap = caps[c];
         float ms = 0.0f;
         for (int rep = 0; rep < 2 && !r; ++rep) {
