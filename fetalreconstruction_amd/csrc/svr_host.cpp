@@ -79,6 +79,36 @@ class irtkReconstruction {
     if (!have_coll) { std::copy(loc.begin(), loc.end(), glob.begin()); return 0; }
     return coll.allgather_slices(coll.user, loc.data(), hi - lo, glob.data(), ns);
   }
+  // ONE host collective per exchange.  Every host-side collective is a stream synchronisation plus a small RCCL launch
+  // (~60-100 us), and a sharded SR iteration used to make six of them (scale vector, slice_inside, three for the M-step,
+  // slice potentials) against ~1.3 ms of kernels per rank on P4 at 8 GPUs.  So the ns-sized vectors a rank has only its
+  // own part of (`_scale_stale`, `_inside_stale`) ride along with the next exchange that every rank makes anyway: the
+  // M-step's sums, the E-step's potentials, the robust-statistics sums.  All of it is one SUM all-reduce of a vector in
+  // which a rank fills only its own entries (x + 0 is exact, so this is an all-gather), and sums over ranks are then
+  // taken on the host in rank order -- the same bits on every rank and every run.
+  //   mine[n_mine] -> all[world][n_mine];  pot_local (or NULL): this rank's slice potentials -> pot_global[ns]
+  bool _scale_stale = false, _inside_stale = false;
+  int exchange(const double *mine, int n_mine, std::vector<double> &all, const float *pot_local, std::vector<float> *pot_global) {
+    const int W = coll.world, R = coll.rank, nl = hi - lo;
+    const int o_sc = n_mine * W, o_in = o_sc + (_scale_stale ? ns : 0), o_pot = o_in + (_inside_stale ? ns : 0);
+    const int n = o_pot + (pot_local ? ns : 0);
+    std::vector<double> v((size_t)n, 0.0);
+    for (int k = 0; k < n_mine; ++k) v[(size_t)R * n_mine + k] = mine[k];
+    for (int i = 0; i < nl; ++i) {
+      if (_scale_stale) v[o_sc + lo + i] = _scale_gpu[lo + i];
+      if (_inside_stale) v[o_in + lo + i] = _slice_inside_gpu[lo + i];
+      if (pot_local) v[o_pot + lo + i] = pot_local[i];
+    }
+    if (n) { int rc_ = coll.allreduce_host(coll.user, v.data(), n, 0); if (rc_) return rc_; }
+    all.assign(v.begin(), v.begin() + o_sc);
+    for (int i = 0; i < ns; ++i) {
+      if (_scale_stale) _scale_gpu[i] = (float)v[o_sc + i];
+      if (_inside_stale) _slice_inside_gpu[i] = v[o_in + i] > 0.5;
+      if (pot_local) (*pot_global)[i] = (float)v[o_pot + i];
+    }
+    _scale_stale = _inside_stale = false;
+    return 0;
+  }
 
   // RG.h:605-612
   void SetSmoothingParameters(double delta, double lambda) {
@@ -118,9 +148,8 @@ class irtkReconstruction {
   int SimulateSlicesGPU() {
     std::vector<unsigned char> inside(hi - lo);
     ENG(svr_simulate_slices(reconstructionGPU, inside.data()));
-    std::vector<float> loc(inside.begin(), inside.end()), glob;
-    ENG(gather(loc, glob));
-    for (int i = 0; i < ns; ++i) _slice_inside_gpu[i] = glob[i] > 0.5f;
+    for (int i = 0; i < hi - lo; ++i) _slice_inside_gpu[lo + i] = inside[i] != 0;
+    _inside_stale = have_coll;                             // the other ranks' flags arrive with the next exchange
     return 0;
   }
 
@@ -129,10 +158,12 @@ class irtkReconstruction {
     if (!have_coll) {
       ENG(svr_initialize_robust_statistics(reconstructionGPU, &_sigma_gpu));
     } else {
-      double s2[2];
+      double s2[2], t[2] = {0, 0};
       ENG(svr_robust_statistics_sums(reconstructionGPU, s2));
-      ENG(coll.allreduce_host(coll.user, s2, 2, 0));
-      _sigma_gpu = (float)s2[0] / (float)s2[1];
+      std::vector<double> all;
+      ENG(exchange(s2, 2, all, nullptr, nullptr));         // (brings the other ranks' slice_inside along)
+      for (int r = 0; r < coll.world; ++r) { t[0] += all[2 * r]; t[1] += all[2 * r + 1]; }
+      _sigma_gpu = (float)t[0] / (float)t[1];
     }
     for (int i = 0; i < ns; ++i)
       if (!_slice_inside_gpu[i]) _slice_weight_gpu[i] = 0;
@@ -152,7 +183,9 @@ class irtkReconstruction {
     std::vector<float> loc(hi - lo);
     ENG(svr_estep(reconstructionGPU, _m_gpu, _sigma_gpu, _mix_gpu, loc.data()));
     std::vector<float> &slice_potential_gpu = _slice_potential_gpu;
-    ENG(gather(loc, slice_potential_gpu));
+    slice_potential_gpu.resize(ns);
+    if (have_coll) { std::vector<double> none; ENG(exchange(nullptr, 0, none, loc.data(), &slice_potential_gpu)); }   // (and the scale vector)
+    else std::copy(loc.begin(), loc.end(), slice_potential_gpu.begin());
     int inputIndex;
     for (size_t i = 0; i < _force_excluded.size(); i++) slice_potential_gpu[_force_excluded[i]] = -1;
     for (size_t i = 0; i < _small_slices.size(); i++) slice_potential_gpu[_small_slices[i]] = -1;
@@ -229,7 +262,8 @@ class irtkReconstruction {
   int ScaleGPU() {
     std::vector<float> loc(hi - lo);
     ENG(svr_calculate_scale_vector(reconstructionGPU, loc.data()));
-    ENG(gather(loc, _scale_gpu));
+    std::copy(loc.begin(), loc.end(), _scale_gpu.begin() + lo);
+    _scale_stale = have_coll;                              // read next in the E-step, whose exchange completes it
     return 0;
   }
 
@@ -257,9 +291,14 @@ class irtkReconstruction {
     }
     double s5[5];
     ENG(svr_mstep_sums(reconstructionGPU, s5));
-    ENG(coll.allreduce_host(coll.user, s5, 3, 0));
-    ENG(coll.allreduce_host(coll.user, s5 + 3, 1, 1));
-    ENG(coll.allreduce_host(coll.user, s5 + 4, 1, 2));
+    std::vector<double> all;
+    ENG(exchange(s5, 5, all, nullptr, nullptr));           // three sums, a minimum, a maximum: one collective
+    s5[0] = s5[1] = s5[2] = 0;
+    for (int r = 0; r < coll.world; ++r) {
+      for (int k = 0; k < 3; ++k) s5[k] += all[5 * r + k];
+      s5[3] = r ? std::min(s5[3], all[5 * r + 3]) : all[3];
+      s5[4] = r ? std::max(s5[4], all[5 * r + 4]) : all[4];
+    }
     float sigma = (float)s5[0], mix = (float)s5[1], num = (float)s5[2];
     float min_ = std::min(3.402823466e+38f, (float)s5[3]);
     float max_ = std::max(1.175494351e-38f, (float)s5[4]);

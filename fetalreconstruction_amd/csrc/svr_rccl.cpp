@@ -279,6 +279,10 @@ int g_pair(void *user, void *device_ptr, size_t n) {
   g->bar.wait();                                           // fsum is free again
   return 0;
 }
+int g_pair_rccl(void *user, void *device_ptr, size_t n) {
+  auto *m = static_cast<svr_group::Member *>(user);
+  return cb_allreduce_volume_pair(m->g->comms[m->rank], device_ptr, n);
+}
 int g_host(void *user, double *data, int n, int op) {
   auto *m = static_cast<svr_group::Member *>(user);
   svr_group *g = m->g;
@@ -335,13 +339,19 @@ int svr_group_uses_rccl(const svr_group *g) { return g && g->rccl && g->world > 
 /* called by every rank from its own thread; returns the rank's collectives (NULL on failure; NULL also for world 1) */
 const svr_collectives *svr_group_join(svr_group *g, int rank, svr_ctx *engine) {
   if (!g || rank < 0 || rank >= g->world || !engine || g->world == 1) return nullptr;
-  if (g->rccl) {
-    g->comms[rank] = svr_comm_create(rank, g->world, g->id, engine);
-    return g->comms[rank] ? svr_comm_collectives(g->comms[rank]) : nullptr;
-  }
   svr_group::Member &m = g->members[rank];
   m.g = g; m.rank = rank; m.engine = engine;
   m.coll.user = &m; m.coll.rank = rank; m.coll.world = g->world;
+  if (g->rccl) {
+    // the volume pairs over RCCL on the engine's stream; the small host vectors through the memory the rank threads share
+    // (a thread barrier instead of a stream synchronisation plus a collective launch per exchange)
+    g->comms[rank] = svr_comm_create(rank, g->world, g->id, engine);
+    if (!g->comms[rank]) return nullptr;
+    m.coll.allreduce_volume_pair = g_pair_rccl;
+    m.coll.allreduce_host = g_host;
+    m.coll.allgather_slices = g_gather;
+    return &m.coll;
+  }
   m.coll.allreduce_volume_pair = g_pair;
   m.coll.allreduce_host = g_host;
   m.coll.allgather_slices = g_gather;
