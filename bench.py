@@ -121,7 +121,7 @@ def main():
     import torch                                                      # before the engine: one RCCL copy per process
     from fetalreconstruction_amd import engine, phantom, workloads
     from fetalreconstruction_amd.host import RcclComm, irtkReconstruction      # the C++ host object
-    from fetalreconstruction_amd.reconstruction import TorchComm, shard_slices
+    from fetalreconstruction_amd.reconstruction import TorchComm, shard_slices, slice_cost_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -143,7 +143,8 @@ def main():
     # ---- the workload: fixed, whatever the world size --------------------------------------------------------------
     prob = workloads.get(args.workload) if args.workload != "tiny" else phantom.problem_tiny()
     act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
-    lo, hi = shard_slices(act, world)[rank]
+    # contiguous slice ranges balanced by estimated PSF work (active pixels x live planes), not by pixel count alone
+    lo, hi = shard_slices(slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0]), world)[rank]
     local = phantom.sub_problem(prob, lo, hi) if world > 1 else prob
 
     rec = engine.Reconstruction(local_rank)

@@ -213,7 +213,8 @@ int main(int argc, char **argv) {
   fprintf(stderr, "\n");
 
   // ---- ranks: one engine context per device of -d (main.cc:191), the slices sharded over them in contiguous ranges
-  // balanced by active pixels (reconstruction_cuda2.cu:1413-1457 shards by slice count and drops the remainder) ----------
+  // balanced by estimated PSF work = active pixels x (9.4 + live planes of the 16, see reconstruction.py slice_cost_weights;
+  // reconstruction_cuda2.cu:1413-1457 shards by slice count and drops the remainder) -----------------------------------
   const int nr = (int)std::max<size_t>(1, devices.size());
   std::vector<int> rlo(nr, 0), rhi(nr, ns);
   {
@@ -221,7 +222,17 @@ int main(int argc, char **argv) {
     for (int s = 0; s < ns; ++s) {
       long c = 0;
       for (size_t i = 0; i < (size_t)mx * my; ++i) c += grid[(size_t)s * mx * my + i] != -1.0f;
-      cum[s + 1] = cum[s] + (double)c;
+      // slice normal in volume axes: reconW2I * T * sliceI2W applied to the slice's z direction
+      const M4 rw = world_to_image(tattr);
+      double nw[3], nt[3], nv[3], len = 0;
+      for (int k = 0; k < 3; ++k) nw[k] = i2w[16 * (size_t)s + 4 * k + 2];
+      for (int k = 0; k < 3; ++k) nt[k] = T[16 * (size_t)s + 4 * k] * nw[0] + T[16 * (size_t)s + 4 * k + 1] * nw[1] + T[16 * (size_t)s + 4 * k + 2] * nw[2];
+      for (int k = 0; k < 3; ++k) { nv[k] = rw.m[4 * k] * nt[0] + rw.m[4 * k + 1] * nt[1] + rw.m[4 * k + 2] * nt[2]; len += nv[k] * nv[k]; }
+      len = std::max(sqrt(len), 1e-12);
+      const double ax = fabs(nv[0]) / len, ay = fabs(nv[1]) / len, az = fabs(nv[2]) / len;
+      const double ne = std::max(ay, az), no = std::min(ay, az), sigma = dims[3 * (size_t)s + 2] / 2.3548 / tattr.dx;
+      const double live = std::min(16.0, 2.0 * (5.1 * sigma + 8.0 * (ax + no)) / std::max(ne, 1e-3) + 1.0);
+      cum[s + 1] = cum[s] + (double)c * (9.4 + live);
     }
     int at = 0;
     for (int r = 0; r < nr; ++r) {

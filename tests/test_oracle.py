@@ -198,6 +198,25 @@ def test_shard_slices_is_a_balanced_partition():
         assert max(loads) <= a.sum() / world + a.max()
 
 
+def test_slice_cost_weights_follow_the_live_planes():
+    """Sharding weights: a slice whose normal is the volume's x axis keeps all 16 planes of its footprints (x is the axis of the
+    sequential skip chain and cannot be owned), an axial one about 12; thicker slices keep more."""
+    from fetalreconstruction_amd.reconstruction import slice_cost_weights
+    def i2w(normal_axis):
+        m = np.eye(4)
+        cols = {2: [0, 1, 2], 0: [1, 2, 0], 1: [2, 0, 1]}[normal_axis]      # slice x, y, z directions in world axes
+        r = np.zeros((3, 3))
+        for j, c in enumerate(cols):
+            r[c, j] = 1.0
+        m[:3, :3] = r
+        return m.reshape(16)
+    eye = np.eye(4).reshape(16)
+    w = slice_cost_weights([100, 100, 100, 100], [i2w(2), i2w(1), i2w(0), i2w(2)], [eye] * 4, eye,
+                           [[1, 1, 2.5], [1, 1, 2.5], [1, 1, 2.5], [1, 1, 5.0]], 1.0)
+    assert np.isclose(w[0], w[1]) and np.isclose(w[2], 100 * (9.4 + 16.0))
+    assert np.isclose(w[0], 100 * (9.4 + 2 * 5.1 * 2.5 / 2.3548 + 1)) and w[3] > w[0]
+
+
 def test_geometry_conventions():
     a = geo.ImageAttributes(10, 12, 5, 1.2, 0.9, 2.5, np.array([0, 1.0, 0]), np.array([0, 0, 1.0]),
                             np.array([1.0, 0, 0]), np.array([3.0, -2.0, 7.5]))
