@@ -1308,10 +1308,10 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
       if (isl) sh_list[q][__popcll(bl & below)] = (unsigned char)lane;
       if (isd) sh_list[q][WAVE_MAXPIX - 1 - __popcll(bdd & below)] = (unsigned char)lane;
     }
-    for (int i = lane; i < 4 * PP; i += 64) box[i] = (f2){0.0f, 0.0f};
+    for (int i = lane; i < 4 * PP; i += 64) box[i] = ta.dbg == 5 ? (f2){1.0f, 1.0f} : (f2){0.0f, 0.0f};
     __syncthreads();
 
-    if (p >= 0) {
+    if (p >= 0 && ta.dbg < 5) {                         // (timing experiments 5 / 6: flush of a full / an empty box only)
       const int P = loz + p;                            // <= hiz: plane in bounds
       f2 *pb = box + slot * PP - lox;
       for (int i = 0; i < mynl; ++i) {
