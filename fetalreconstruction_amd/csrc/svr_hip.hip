@@ -564,7 +564,6 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void psf_kernel(PsfArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // Phase 2: lane = (x, 4 consecutive y rows): coalesced 4 x 64 B volume accesses
-#pragma unroll 4
     for (int j = 0; j < 16; ++j) {
       const int row = 4 * j + r4;
       const float val = my[row * LDS_ROW + x2];
@@ -1468,6 +1467,28 @@ __device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, in
 //     {in bounds, in mask}, the sums become {sume (double, like the oracle), -}, plus the `sume > 0.5` gate, v_PSF_sums
 //     and the sliceVoxel_count flag.
 // Registers: no accumulator array, the row's 16 values and the packed evaluator: ~90 VGPRs, no scratch.
+// Sum over the 16 lanes of a slot, result in the slot's first lane: four DPP row shifts folded into the additions
+// (v_add_f32_dpp) instead of four dependent ds_bpermute round trips through the LDS crossbar.  Lanes shifted in from
+// beyond the row read 0 (bound_ctrl), so the tree is ((v0 + v8) + (v4 + v12)) + ... -- fixed, the same for every unit.
+template <int N> __device__ __forceinline__ int row_shl_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true);
+}
+template <int N> __device__ __forceinline__ float row_shl_f(float v) {
+  return __builtin_bit_cast(float, row_shl_i<N>(__builtin_bit_cast(int, v)));
+}
+template <int N> __device__ __forceinline__ double row_shl_d(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)row_shl_i<N>((int)(unsigned)b), hi = (unsigned)row_shl_i<N>((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += row_shl_f<8>(v); v += row_shl_f<4>(v); v += row_shl_f<2>(v); v += row_shl_f<1>(v);
+  return v;
+}
+__device__ __forceinline__ double row_sum16(double v) {
+  v += row_shl_d<8>(v); v += row_shl_d<4>(v); v += row_shl_d<2>(v); v += row_shl_d<1>(v);
+  return v;
+}
 #define FWDU_WAVES 8
 #define FWDU_MAXPIX 32     // pixels of a tile (8 x 4 at most)
 // NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: the evaluator's sinc_pi branch, the volume read through the
@@ -1553,9 +1574,12 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       f2 v = (f2){0.0f, 0.0f};
       if (bw.y < Dy && bw.x < Dx && gx < vg.vx) {
         const uint32_t vi = sat0(gx) + sat0(bw.y + loy) * (uint32_t)vg.vx + sat0(bw.z + loz) * sxy;
+        // (SVR: the volume word is fetched whether or not the voxel is in the mask -- two independent loads instead of a
+        // dependent pair; the PVR texture average is eight loads and stays behind the mask test)
+        const float vraw = (GAUSS1 || PVR) ? 0.0f : a.vol[vi];
         const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
         v = GAUSS1 ? (f2){1.0f, m}
-                   : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(bw.y + loy), (int)sat0(bw.z + loz)) : a.vol[vi]) : 0.0f, m};
+                   : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(bw.y + loy), (int)sat0(bw.z + loz)) : vraw) : 0.0f, m};
       }
       box[i] = v;
     }
@@ -1636,12 +1660,9 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       }
     }
     if (!rowok) { acc = (f2){0.0f, 0.0f}; accd = 0.0; hit = false; }
-    // reduce over the 16 lanes of the slot
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      if (GAUSS1) accd += __shfl_xor(accd, o, 64);
-      else { acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); }
-    }
+    // reduce over the 16 lanes of the slot (the sum lands in its first lane, y == 0)
+    if (GAUSS1) accd = row_sum16(accd);
+    else { acc.x = row_sum16(acc.x); acc.y = row_sum16(acc.y); }
     if (GAUSS1) {
       const bool anyhit = ((uint32_t)(__ballot(hit) >> (16 * slot)) & 0xFFFFu) != 0u;
       if (valid && y == 0) {
@@ -1693,13 +1714,10 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     f2 acca = bc2(v.x) * wa, accb = bc2(v.y) * wb;
     double da = (double)acca.x, db = (double)accb.x;
     const bool hita = wa.y != 0.0f, hitb = wb.y != 0.0f;        // the processed first tap lands on a mask voxel
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      if (GAUSS1) { da += __shfl_xor(da, o, 64); db += __shfl_xor(db, o, 64); }
-      else {
-        acca.x += __shfl_xor(acca.x, o, 64); acca.y += __shfl_xor(acca.y, o, 64);
-        accb.x += __shfl_xor(accb.x, o, 64); accb.y += __shfl_xor(accb.y, o, 64);
-      }
+    if (GAUSS1) { da = row_sum16(da); db = row_sum16(db); }
+    else {
+      acca.x = row_sum16(acca.x); acca.y = row_sum16(acca.y);
+      accb.x = row_sum16(accb.x); accb.y = row_sum16(accb.y);
     }
     const bool anya = GAUSS1 && ((uint32_t)(__ballot(hita) >> (16 * slot)) & 0xFFFFu) != 0u;
     const bool anyb = GAUSS1 && ((uint32_t)(__ballot(hitb) >> (16 * slot)) & 0xFFFFu) != 0u;
