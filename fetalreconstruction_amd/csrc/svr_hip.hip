@@ -1489,7 +1489,9 @@ __device__ __forceinline__ double row_sum16(double v) {
   v += row_shl_d<8>(v); v += row_shl_d<4>(v); v += row_shl_d<2>(v); v += row_shl_d<1>(v);
   return v;
 }
+#ifndef FWDU_WAVES
 #define FWDU_WAVES 8
+#endif
 #define FWDU_MAXPIX 32     // pixels of a tile (8 x 4 at most)
 // NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: the evaluator's sinc_pi branch, the volume read through the
 // 8-voxel texture average of getReconValueFromTexture (R2/reconVolume.cu:170-187), pass-1 gate `sume > 1e-5 or NaN` with the superpixel
