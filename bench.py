@@ -132,6 +132,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")             # one node: the host name need not resolve
         if args.share_gpu:
             local_rank = 0
         torch.cuda.set_device(local_rank)

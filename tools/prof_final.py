@@ -74,7 +74,7 @@ def main():
     v4 = pmc("P4", "p4")
     v8 = pmc("S8", "s8")
     traffic = {"workload": "P4", "source": "profiles/r02_pmc_p4.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes)"}
-    for key, pat in (("back", "back_wave_kernel"), ("forward", "fwd_unit_kernel<false>")):
+    for key, pat in (("back", "back_wave_kernel"), ("forward", "fwd_unit_kernel<false")):
         k = [n for n in v4 if pat in n]
         if k and "FETCH_SIZE" in v4[k[0]] and "WRITE_SIZE" in v4[k[0]]:
             traffic[key] = {"kernel": k[0], "fetch_bytes": v4[k[0]]["FETCH_SIZE"] * 1024.0, "write_bytes": v4[k[0]]["WRITE_SIZE"] * 1024.0}
@@ -112,7 +112,7 @@ def main():
             rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
             lines.append("%7s %14s %12s %7s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
             lines += ["%7d %14.1f %12.1f %7.2f  %s" % (k, t, a, pc, short(n)) for n, k, t, a, pc in rows[:24]]
-            for pat in ("back_wave_kernel", "fwd_unit_kernel<false>"):
+            for pat in ("back_wave_kernel", "fwd_unit_kernel<false"):
                 dd = [r[0] / 1e3 for r in c.execute("select (end - start) from kernels where name like ? order by start", ("%" + pat + "%",)).fetchall()]
                 if dd and jt:
                     k = jt["steps"]
