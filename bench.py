@@ -110,6 +110,8 @@ def main():
                     help="rccl: the C library's own RCCL collectives; torch: torch.distributed callbacks (--backend)")
     ap.add_argument("--backend", default="nccl", help="--comm torch: torch.distributed backend (nccl = RCCL, gloo)")
     ap.add_argument("--share-gpu", action="store_true", help="dev/test: all ranks use cuda:0 (--comm torch --backend gloo only)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="dev/test: run the multi-rank code path (rendezvous, communicator, every exchange of the host loop) at world size 1")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -129,7 +131,13 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_comm
+    if args.force_comm:
+        os.environ["SVR_FORCE_COLLECTIVES"] = "1"                     # the C++ host goes through its callbacks at world 1 too
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")             # one node: the host name need not resolve
@@ -151,7 +159,7 @@ def main():
     rec = engine.Reconstruction(local_rank)
     engine.sync_gpu(rec, local)
     comm, rccl_world = None, None
-    if world > 1:
+    if multi:
         if args.comm == "rccl":
             # every rank first proves it can open librccl (a rank that cannot would leave the others waiting inside
             # ncclCommInitRank); if one cannot, all ranks fall back to host-staged exchanges over gloo and say so
@@ -191,7 +199,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -206,7 +214,7 @@ def main():
     timers = rec.timers()
     cnt = rec.counters()
 
-    if world > 1:
+    if multi:
         dt = float(comm.allreduce_max(np.array([dt]))[0])
         va = int(round(comm.allreduce_sum(np.array([float(cnt["Va"])]))[0]))
     else:
@@ -244,7 +252,7 @@ def main():
                        "Vs": vs, "Va_rank0": va_l, "Va_total": va, "Nv": nv, "slices": prob.ns,
                        "parallelism": f"slice-sharded x{world}, 1 in-place RCCL all-reduce of addon|cmap (float[2 Nv]) per scatter pass"
                                       if world > 1 else "1 GPU",
-                       "comm": (args.comm if world > 1 else None), "rccl_world": rccl_world},
+                       "comm": (args.comm if multi else None), "rccl_world": rccl_world},
             "roofline": {
                 "kernel": "back_wave_kernel (SuperresolutionKernel3D_tex, RC.cu:408-522): the dominant kernel of the step",
                 "bound": "valu_f32",
@@ -279,7 +287,7 @@ def main():
     if comm is not None and hasattr(comm, "close"):
         barrier()
         comm.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

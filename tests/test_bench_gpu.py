@@ -44,6 +44,21 @@ def test_bench_line_and_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_multi_rank_path_at_world_one():
+    """`--force-comm`: the code path of `bench.py --gpus N` -- gloo rendezvous, the ncclUniqueId broadcast, the C library's RCCL
+    communicator next to torch's own copy of librccl in one process, every exchange of the sharded host loop -- at world size 1
+    on the one GPU of the box.  Same workload, so the same active pixels and (RCCL at world 1 is the identity) a sane rate."""
+    one = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    forced = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--force-comm"],
+                            cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and forced.returncode == 0, forced.stderr[-3000:]
+    a, b = _last_json(one.stdout), _last_json(forced.stdout)
+    assert b["config"]["comm"] == "rccl" and b["config"]["rccl_world"] == 1, b["config"]
+    assert b["config"]["Va_total"] == a["config"]["Va_total"] and b["value"] > 0.3 * a["value"]
+
+
+@pytest.mark.gpu
 def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
     """csrc/svr_rccl.cpp on the one GPU of the box: librccl is opened, a communicator of world size 1 is made on the engine's
     stream, and the sharded C++ host runs a whole iteration through its three collectives (identity at world 1) -- the same
