@@ -181,6 +181,12 @@ def main():
                 rccl_world = comm.rccl_world()
         else:
             comm = TorchComm(device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+    if multi:
+        try:                                          # RCCL's version banner (C stdio, every rank) goes out now, not at exit
+            import ctypes                             # after rank 0's JSON line
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
     drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity)
     drv.SetSmoothingParameters(150, 0.02)      # reconstruction.cc:99-100 defaults (delta, lambda)
 
@@ -283,7 +289,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(prob)
             except Exception as ex:  # the bench line must still be printed
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out))
+        try:                                          # whatever RCCL / HIP left in the C stdio buffers goes out first:
+            import ctypes                             # the JSON line is the last line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if comm is not None and hasattr(comm, "close"):
         barrier()
         comm.close()
