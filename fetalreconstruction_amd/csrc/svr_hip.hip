@@ -150,6 +150,9 @@ struct PsfArgs {
   // back
   const float *weights, *slice_weights;
   float *addon, *cmap;
+  // coefficient table (COEFF instantiations): the evaluated taps of every live unit of every PSF pixel, kept in HBM
+  const float4 *coeff;        // [pixel id][16 units][4 tap quads][16 rows] float4
+  const uint32_t *coeff_id;   // slice-grid index -> pixel id
 };
 
 // per-pixel state shared by all modes
@@ -891,6 +894,42 @@ __device__ __forceinline__ bool unit_is_dead(const RowConst S, float bx, float b
   return !zero;
 }
 
+// The coefficient table (svr_ctx::d_coeff): one wavefront per PSF pixel, four of its 16 units per pass -- slot = unit,
+// lane = row, exactly the decomposition of the scatter and the gather.  A unit's 16 x 16 taps (skipped ones as -0.0f) go
+// out as 64 float4: [tap quad q][row y], so that the 16 lanes of a slot write and later read 256 contiguous bytes per
+// instruction.  Dead units (unit_is_dead) are not stored: the kernels evaluate their first taps themselves.
+__global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, uint32_t *coeff_id) {
+  constexpr int NC = PSF_CENTRE;
+  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (w >= a.n) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t idx = a.list[w];
+  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
+  const uint32_t sl = idx / n2, rem = idx - sl * n2;
+  const int py = (int)(rem / (uint32_t)a.sx), px = (int)(rem - (uint32_t)py * (uint32_t)a.sx);
+  const SliceConst &S = a.sc[sl];
+  const PixelState P = pixel_setup(S, a.vg, px, py);
+  const RowConst RC = load_row_const(S);
+  const bool swap = S.own == 1;
+  const int F = swap ? 1 : 2;
+  if (lane == 0) coeff_id[idx] = w;
+  const int slot = lane >> 4, y = lane & 15;
+  const float fyl = (float)(y - NC);
+  for (int g = 0; g < 4; ++g) {
+    const int u = 4 * g + slot;
+    const float fu = (float)(u - NC);
+    const bool dead = unit_is_dead(RC, P.bx, P.by, P.bz, F, fu);
+    if (__all(dead)) continue;
+    float out[PSF_SUPPORT];
+    eval_row_t<PSF_SUPPORT, false, true>(RC, P.bx, P.by, P.bz, swap ? fu : fyl, swap ? fyl : fu, out);
+    if (!dead) {
+      float4 *dst = coeff + ((size_t)w * 16 + u) * 64 + y;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[q * 16] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    }
+  }
+}
+
 #ifndef SVR_WPE_SLOT
 #define SVR_WPE_SLOT 4
 #endif
@@ -1160,8 +1199,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SVR_
 // cheap wavefronts (dead planes) leave early instead of holding a workgroup's LDS.  The price is the tile set-up
 // (pixel records, dead-unit test: ~4 % of a wavefront's work) repeated by every group.  `groups` is a launch
 // parameter: planes beyond 4 * groups are dealt round-robin to the same wavefronts.
-#define WAVE_MAXPIX 32    // pixels of a tile (larger tiles go to the workgroup kernels)
-template <int NS = PSF_SUPPORT, bool PVR = false>
+// pixels of a tile (larger tiles go to the workgroup kernels): 32 when the taps are evaluated, 64 -- one per lane -- when
+// they come from the coefficient table (the flush, not the evaluation, is what a table pass waits for: larger tiles)
+#define WAVE_MAXPIX (COEFF ? 64 : 32)
+template <int NS = PSF_SUPPORT, bool PVR = false, bool COEFF = false>
 #ifndef SVR_WPE_WAVE
 #define SVR_WPE_WAVE 3    // 170 VGPRs: the LDS box allows 8-10 wavefronts per CU anyway
 #endif
@@ -1172,6 +1213,7 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
   f2 *box = reinterpret_cast<f2 *>(tile);               // {addon, cmap} per box voxel of this wavefront's four planes
   __shared__ PixelRec sh_px[WAVE_MAXPIX];               // cy = centre on the lane axis, cz = centre on the owned axis
   __shared__ unsigned char sh_list[4][WAVE_MAXPIX];     // per slot: live units from the front, dead units from the back
+  __shared__ uint32_t sh_pid[COEFF ? WAVE_MAXPIX : 1];  // COEFF: the pixels' ids in the coefficient table
   const int TILE_W = ta.tw, TILE_H = ta.th;
   const int lane = threadIdx.x;
   const VolGeom &vg = a.vg;
@@ -1218,6 +1260,7 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
       R.cx = cx; R.cy = cy; R.cz = cz;
       R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
       sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
+      if (COEFF) sh_pid[__popcll(b & ((1ull << lane) - 1ull))] = a.coeff_id[idx];
     }
   }
   const int npix = __popcll(__ballot(act));
@@ -1313,25 +1356,62 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
     if (p >= 0 && ta.dbg < 5) {                         // (timing experiments 5 / 6: flush of a full / an empty box only)
       const int P = loz + p;                            // <= hiz: plane in bounds
       f2 *pb = box + slot * PP - lox;
-      for (int i = 0; i < mynl; ++i) {
-        const PixelRec R = sh_px[sh_list[slot][i]];
-        const float fzu = (float)(P - R.cz);            // owned-axis offset of the unit
-        const int ay = R.cy + y - NC;                   // may be negative: aliases to 0 at flush
-        const bool rowok = y < NS && ay < vgy;
-        const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
-        // the row's accumulators are fetched before the evaluation (their LDS latency hides behind ~500 instructions; the
-        // registers are free: the box, not the register file, sets the occupancy).  A lane without a row reads the
-        // plane's first words and writes nothing.
-        f2 acc[NS];
-#pragma unroll
-        for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
-        float out[NS];
-        eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fzu : fyl, swap ? fyl : fzu, out);
+      // One live unit: the row's accumulators are fetched before its taps are there (their LDS latency hides behind the
+      // evaluation; the registers are free: the box, not the register file, sets the occupancy).  A lane without a row
+      // reads the plane's first words and writes nothing.
+      auto add_unit = [&](const PixelRec &R, const float (&out)[NS], const f2 (&acc)[NS], bool rowok, int rb) {
         if (rowok) {
           // all NS x positions are inside the box by construction: unconditional read-add-write (skipped taps add 0)
           const f2 ff = (f2){R.f0, R.f1};
 #pragma unroll
           for (int x = 0; x < NS; ++x) pb[rb + x] = fma2(bc2(out[x]), ff, acc[x]);
+        }
+      };
+      if (COEFF) {
+        // the taps come from the coefficient table (what eval_row_t returns, written by k_coeff_build): a ring of three
+        // units per slot keeps 3 KiB per slot in flight -- the pass waits for HBM, not for the ALUs
+        float4 ring[3][4];
+        auto request = [&](int i, float4 (&dst)[4]) {
+          const int k1 = sh_list[slot][i];
+          const float4 *src = a.coeff + ((size_t)sh_pid[k1] * 16 + (size_t)(P - sh_px[k1].cz + NC)) * 64 + y;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[q] = src[q * 16];
+        };
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3) if (r3 < mynl) request(r3, ring[r3]);
+        for (int i0 = 0; i0 < mynl; i0 += 3) {
+#pragma unroll
+          for (int r3 = 0; r3 < 3; ++r3) {
+            const int i = i0 + r3;
+            if (i < mynl) {
+              const PixelRec R = sh_px[sh_list[slot][i]];
+              const int ay = R.cy + y - NC;               // may be negative: aliases to 0 at flush
+              const bool rowok = y < NS && ay < vgy;
+              const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
+              f2 acc[NS];
+#pragma unroll
+              for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
+              float out[NS];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { out[4 * q] = ring[r3][q].x; out[4 * q + 1] = ring[r3][q].y; out[4 * q + 2] = ring[r3][q].z; out[4 * q + 3] = ring[r3][q].w; }
+              if (i + 3 < mynl) request(i + 3, ring[r3]);
+              add_unit(R, out, acc, rowok, rb);
+            }
+          }
+        }
+      } else {
+        for (int i = 0; i < mynl; ++i) {
+          const PixelRec R = sh_px[sh_list[slot][i]];
+          const float fzu = (float)(P - R.cz);          // owned-axis offset of the unit
+          const int ay = R.cy + y - NC;                 // may be negative: aliases to 0 at flush
+          const bool rowok = y < NS && ay < vgy;
+          const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
+          f2 acc[NS];
+#pragma unroll
+          for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
+          float out[NS];
+          eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fzu : fyl, swap ? fyl : fzu, out);
+          add_unit(R, out, acc, rowok, rb);
         }
       }
       if (!PVR) {
@@ -1496,7 +1576,7 @@ __device__ __forceinline__ double row_sum16(double v) {
 // NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: the evaluator's sinc_pi branch, the volume read through the
 // 8-voxel texture average of getReconValueFromTexture (R2/reconVolume.cu:170-187), pass-1 gate `sume > 1e-5 or NaN` with the superpixel
 // test (R2/patchBasedPSFReconstruction_gpu.cu:95-110); no dead-unit shortcut (the bound is derived for the SVR constants).
-template <bool GAUSS1, int NS = PSF_SUPPORT, bool PVR = false>
+template <bool GAUSS1, int NS = PSF_SUPPORT, bool PVR = false, bool COEFF = false>
 __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, TileArgs ta) {
   constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;
   constexpr int US = 16;                                // stride of the per-pixel unit tables (k << 4 | u)
@@ -1506,6 +1586,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
   __shared__ int sh_lo[3], sh_hi[3];
   __shared__ PixelRec sh_px[FWDU_MAXPIX];
   __shared__ uint32_t sh_idx[FWDU_MAXPIX];
+  __shared__ uint32_t sh_pid[COEFF ? FWDU_MAXPIX : 1];           // COEFF: the pixels' ids in the coefficient table
   __shared__ uint32_t sh_dead[FWDU_MAXPIX];                      // bit u: unit (pixel, u) is dead
   __shared__ unsigned short sh_units[FWDU_MAXPIX * US];          // (pixel << 4 | u): live units from the front, dead units from the back
   __shared__ f2 sh_part[FWDU_MAXPIX * US];                       // per unit {sum psf V, sum psf}
@@ -1547,6 +1628,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       const int k = __popcll(b & ((1ull << lane) - 1ull));
       sh_px[k] = R;
       sh_idx[k] = idx;
+      if (COEFF) sh_pid[k] = a.coeff_id[idx];
       atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
       atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
       atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
@@ -1587,24 +1669,40 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     }
   }
   // units: dead test, then the list (live from the front, dead from the back); units whose rows all lie beyond the
-  // volume's high end take no part
-  for (int i = threadIdx.x; i < npix * NS; i += T) {
+  // volume's high end take no part.  The live list is in (pixel, unit) order -- ballot + per-wavefront offsets, not an
+  // atomic counter -- so that the four slots of a wavefront, and the wavefronts of a round, work on neighbouring units:
+  // with the coefficient table that makes a round's reads 32 consecutive KiB instead of 32 scattered ones.
+  {
+    static_assert(FWDU_MAXPIX * 16 <= T, "one unit per thread");
+    __shared__ int sh_wlive[FWDU_WAVES];
+    const int i = threadIdx.x;
     const int k = i / NS, u = i % NS;
-    const PixelRec R = sh_px[k];
-    const int cu = swap ? R.cy : R.cz;
-    const bool inb = cu + u - NC < (swap ? vg.vy : vg.vz);      // negatives alias to 0: "in bounds"
-    if (inb) {
-      const bool dead = !PVR && ta.dbg != 4 && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(u - NC));
-      if (dead) {
-        atomicOr(&sh_dead[k], 1u << u);
-        sh_units[FWDU_MAXPIX * US - 1 - atomicAdd(&sh_ndead, 1)] = (unsigned short)(k << 4 | u);
+    bool live = false;
+    if (i < npix * NS) {
+      const PixelRec R = sh_px[k];
+      const int cu = swap ? R.cy : R.cz;
+      const bool inb = cu + u - NC < (swap ? vg.vy : vg.vz);      // negatives alias to 0: "in bounds"
+      if (inb) {
+        const bool dead = !PVR && ta.dbg != 4 && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(u - NC));
+        if (dead) {
+          atomicOr(&sh_dead[k], 1u << u);
+          sh_units[FWDU_MAXPIX * US - 1 - atomicAdd(&sh_ndead, 1)] = (unsigned short)(k << 4 | u);
+        } else {
+          live = true;
+        }
       } else {
-        sh_units[atomicAdd(&sh_nlive, 1)] = (unsigned short)(k << 4 | u);
+        sh_part[k * US + u] = (f2){0.0f, 0.0f};
+        if (GAUSS1) sh_partd[k * US + u] = 0.0;
       }
-    } else {
-      sh_part[k * US + u] = (f2){0.0f, 0.0f};
-      if (GAUSS1) sh_partd[k * US + u] = 0.0;
     }
+    const unsigned long long bl = __ballot(live);
+    if (lane == 0) sh_wlive[wave] = __popcll(bl);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FWDU_WAVES; ++w) { const int c = sh_wlive[w]; base += w < wave ? c : 0; tot += c; }
+    if (live) sh_units[base + __popcll(bl & ((1ull << lane) - 1ull))] = (unsigned short)(k << 4 | u);
+    if (threadIdx.x == 0) sh_nlive = tot;
   }
   __syncthreads();
   const int nlive = sh_nlive, ndead = sh_ndead;
@@ -1615,7 +1713,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
   // (RC.cu:398-403), and a positive weight is a processed tap on a mask voxel.  Pass 1 of the Gaussian reconstruction
   // needs "any processed tap on a mask voxel" next to a sum that ignores the mask: one compare pair per tap, combined
   // in scalar registers (bitwise, no branch).
-  for (int j0 = wave * 4; j0 < nlive; j0 += FWDU_WAVES * 4) {
+  auto live_unit = [&](const int j0) {
     const int j = j0 + slot;
     const bool valid = j < nlive;
     const int ku = sh_units[valid ? j : j0];
@@ -1625,7 +1723,19 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     const int ay = R.cy + (swap ? u : y) - NC, az = R.cz + (swap ? y : u) - NC;
     const bool rowok = valid && y < NS && ay < vg.vy && az < vg.vz;      // negatives alias to 0: always "in bounds"
     float out[NS];
-    eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fu : fyl, swap ? fyl : fu, out);
+    if (COEFF) {
+      // the unit's taps from the coefficient table (what eval_row_t returns, written by k_coeff_build).  Sixteen
+      // wavefronts per CU keep enough of these 1 KiB reads in flight; a three-round prefetch ring was measured and lost
+      // (3.55 against 3.43 ms)
+      const float4 *src = a.coeff + ((size_t)sh_pid[k] * 16 + (size_t)u) * 64 + y;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 c = src[q * 16];
+        out[4 * q] = c.x; out[4 * q + 1] = c.y; out[4 * q + 2] = c.z; out[4 * q + 3] = c.w;
+      }
+    } else {
+      eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fu : fyl, swap ? fyl : fu, out);
+    }
     f2 acc = (f2){0.0f, 0.0f};
     double accd = 0.0;
     bool hit = false;
@@ -1674,7 +1784,8 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
     } else if (valid && y == 0) {
       sh_part[k * US + u] = acc;
     }
-  }
+  };
+  for (int j0 = wave * 4; j0 < nlive; j0 += FWDU_WAVES * 4) live_unit(j0);
   // ---- dead units: the first tap of every row, two units per pass ------------------------------------------
   for (int j0 = wave * 8; !PVR && j0 < ndead; j0 += FWDU_WAVES * 8) {
     const int ja = j0 + 2 * slot, jb = ja + 1;
@@ -2608,6 +2719,16 @@ struct svr_ctx {
   uint32_t n_tiles_fb8 = 0;   // tiles of the last scatter that the wave-owned kernel handed to the workgroup kernel (box larger than wave_cap)
   uint32_t *d_tiles_fb2 = nullptr;
   bool wave_cap_user = false;
+  // The coefficient table: what irtkReconstruction::CoeffInit keeps as _volcoeffs on the CPU path (RG.cc:2305-2673) --
+  // every PSF pixel's evaluated taps, 16 KiB per pixel, written once per slice geometry by k_coeff_build and streamed by
+  // the COEFF instantiations of the scatter and the gather instead of being re-evaluated in every SR iteration.  The
+  // reference's GPU path recomputes them (a 2015 GPU had 6-12 GB); 288 GB of HBM hold them for every workload of
+  // BASELINE.json (P4: 19 GB, S8: 174 GB).  Values are bit-identical to the on-the-fly evaluation by construction.
+  float4 *d_coeff = nullptr;
+  uint32_t *d_coeff_id = nullptr;
+  size_t coeff_cap = 0;        // pixels the allocation holds
+  bool coeff_valid = false;
+  int coeff_mode = 0;          // option "coeff_table": 0 = evaluate on the fly, 1 = stream the table (SVR only; falls back to 0 if it does not fit)
   int wave_groups = 1, wave_cap = 2096;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (14 LDS granules of 1280 B with the static part: 9 wavefronts per CU)
 
   // reductions
@@ -2756,6 +2877,7 @@ int prepare_slice_consts(svr_ctx *ctx) {
   HIPCHK(hipMemcpyAsync(ctx->d_sc, h.data(), h.size() * sizeof(SliceConst), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->sc_dirty = false;
+  ctx->coeff_valid = false;                               // new slice geometry: new taps
   return SVR_OK;
 }
 
@@ -2885,6 +3007,36 @@ int ensure_psf_list(svr_ctx *ctx) {
 // workgroup kernel (8 wavefronts, the largest box the CU can hold); what fits neither -- strongly oblique tiles of very fine
 // volumes -- takes LDS atomics (SVR: back_tiled_kernel) or device atomics per tap (PVR: pvr_tiles_kernel).
 // level: 4 = start with the wave-owned kernel, 3 = with the workgroup kernel, 1 = the last resort for every tile.
+// (Re)build the coefficient table if the option is on and the table does not match the current PSF pixels / geometry.
+// Returns with ctx->coeff_valid set, or with the mode switched off when the table does not fit the free memory.
+int ensure_coeff(svr_ctx *ctx) {
+  if (!ctx->coeff_mode || ctx->pvr || ctx->coeff_valid) return SVR_OK;
+  int r = ensure_psf_list(ctx);
+  if (r) return r;
+  if (!ctx->n_psf) return SVR_OK;
+  if (ctx->n_psf > ctx->coeff_cap) {
+    free_dev(ctx->d_coeff);
+    ctx->coeff_cap = 0;
+    size_t fr = 0, tot = 0;
+    const size_t bytes = (size_t)ctx->n_psf * 16 * 64 * sizeof(float4);
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || bytes + (size_t(2) << 30) > fr || hipMalloc(&ctx->d_coeff, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->d_coeff = nullptr;
+      ctx->coeff_mode = 0;                                 // does not fit: evaluate on the fly (svr_get_option tells)
+      return SVR_OK;
+    }
+    ctx->coeff_cap = ctx->n_psf;
+  }
+  if (!ctx->d_coeff_id) HIPCHK(hipMalloc(&ctx->d_coeff_id, ctx->np * sizeof(uint32_t)));
+  PsfArgs a = make_args(ctx);
+  a.list = ctx->d_psf_list;
+  a.n = ctx->n_psf;
+  hipLaunchKernelGGL(k_coeff_build, dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
+  KCHK("k_coeff_build");
+  ctx->coeff_valid = true;
+  return SVR_OK;
+}
+
 int launch_slot(svr_ctx *ctx, bool pvr, const PsfArgs &a, const TileArgs &ta, uint32_t *fb, uint32_t *cnt) {
   const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
   if (pvr) hipLaunchKernelGGL((back_slot_kernel<8, PVR_N, true>), dim3(ta.ntiles), dim3(8 * 64), lds, ctx->stream, a, ta, fb, cnt);
@@ -2908,6 +3060,8 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
     const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
     if (pvr) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
                                 ctx->wave_groups, ctx->d_tiles_fb, cnt);
+    else if (a.coeff) hipLaunchKernelGGL((back_wave_kernel<PSF_SUPPORT, false, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
+                                         ctx->wave_groups, ctx->d_tiles_fb, cnt);
     else hipLaunchKernelGGL(back_wave_kernel<>, dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
                             ctx->wave_groups, ctx->d_tiles_fb, cnt);
     KCHK("back_wave_kernel");
@@ -2993,8 +3147,10 @@ int svr_create(int device, svr_ctx **out) {
     dyn -= 16384;  // static LDS of the kernels (pixel table, unit lists, partial sums: fwd_unit_kernel<GAUSS1> 14.6 KiB)
     const void *big_lds[] = {reinterpret_cast<const void *>(back_tiled_kernel),
                              reinterpret_cast<const void *>(fwd_unit_kernel<false>), reinterpret_cast<const void *>(fwd_unit_kernel<true>),
+                             reinterpret_cast<const void *>(fwd_unit_kernel<false, PSF_SUPPORT, false, true>),
                              reinterpret_cast<const void *>(fwd_unit_kernel<false, PVR_N, true>), reinterpret_cast<const void *>(fwd_unit_kernel<true, PVR_N, true>),
                              reinterpret_cast<const void *>(back_wave_kernel<>), reinterpret_cast<const void *>(back_wave_kernel<PVR_N, true>),
+                             reinterpret_cast<const void *>(back_wave_kernel<PSF_SUPPORT, false, true>),
                              reinterpret_cast<const void *>(back_slot_kernel<8>), reinterpret_cast<const void *>(back_slot_kernel<8, PVR_N, true>)};
     bool ok = true;
     for (const void *f : big_lds) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
@@ -3027,7 +3183,8 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     ctx->fwd_tune_pending = ctx->back_tune_pending = value != 0;
     return SVR_OK;
   }
-  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; return SVR_OK; }
+  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; return SVR_OK; }
+  if (!strcmp(name, "coeff_table")) { ctx->coeff_mode = value ? 1 : 0; if (!value) { free_dev(ctx->d_coeff); ctx->coeff_cap = 0; ctx->coeff_valid = false; } return SVR_OK; }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
   if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
@@ -3055,6 +3212,17 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);
 }
 
+int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
+  if (!ctx || !name || !value) return SVR_E_ARG;
+  const struct { const char *n; int v; } tab[] = {
+      {"back_mode", ctx->back_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
+      {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
+      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"fwd_unit_cap", ctx->fwd_unit_cap}};
+  for (const auto &e : tab)
+    if (!strcmp(name, e.n)) { *value = e.v; return SVR_OK; }
+  return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);
+}
+
 void svr_destroy(svr_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
@@ -3067,6 +3235,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_reg_targets);
   free_dev(ctx->d_reg_source);
   free_dev(ctx->d_ncc_idx); free_dev(ctx->d_ncc_m); free_dev(ctx->d_ncc_s);
+  free_dev(ctx->d_coeff); free_dev(ctx->d_coeff_id);
   reg_free(ctx->reg);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
@@ -3154,6 +3323,7 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   ctx->np = np;
   ctx->have_slices = false; ctx->have_scales = false; ctx->have_dims = false; ctx->have_mats = false;
   ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->n_active = ctx->n_psf = 0;
+  ctx->coeff_valid = false; free_dev(ctx->d_coeff_id); free_dev(ctx->d_coeff); ctx->coeff_cap = 0;
   const size_t fb = np * sizeof(float);
   HIPCHK(hipMalloc(&ctx->d_slices, fb));
   HIPCHK(hipMalloc(&ctx->d_weights, fb));
@@ -3197,6 +3367,7 @@ int svr_fill_slices(svr_ctx *ctx, const float *sdata, const int *sizes_x, const 
   HIPCHK(hipMemcpyAsync(ctx->d_slices, sdata, ctx->np * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   ctx->have_slices = true;
   ctx->psf_list_valid = false;
+  ctx->coeff_valid = false;
   return build_list(ctx, false);
 }
 
@@ -3380,6 +3551,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   }
   t.stop();
   ctx->psf_list_valid = false;
+  ctx->coeff_valid = false;                               // v_PSF_sums decides which pixels are PSF pixels
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
 }
@@ -3413,9 +3585,12 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   if (r) return r;
   r = ensure_psf_list(ctx);
   if (r) return r;
+  r = ensure_coeff(ctx);
+  if (r) return r;
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
+  if (ctx->coeff_mode && ctx->coeff_valid && !ctx->pvr && ctx->fwd_mode >= 1) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
   auto launch_forward = [&]() -> int {
     const bool tiled_ = ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1;
     if (a.n && tiled_) {
@@ -3425,6 +3600,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       ta.gauss = 0;
       const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
       if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<false, PVR_N, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      else if (a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<false, PSF_SUPPORT, false, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       else hipLaunchKernelGGL(fwd_unit_kernel<false>, dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       KCHK("fwd_unit_kernel");
     } else if (a.n && ctx->pvr) {
@@ -3669,10 +3845,13 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   }
   r = ensure_psf_list(ctx);
   if (r) return r;
+  r = ensure_coeff(ctx);
+  if (r) return r;
   HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream));   // RC.cu:2202-2203
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
+  if (ctx->coeff_mode && ctx->coeff_valid && !ctx->pvr && ctx->back_mode == 4) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
   const bool tiled = ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 1;
   if (a.n && tiled) {
@@ -3832,7 +4011,7 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   if (bytes != b) return fail(ctx, SVR_E_ARG, "svr_debug_set: size mismatch");
   HIPCHK(hipMemcpyAsync(p, host_in, b, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
+  if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) { ctx->psf_list_valid = false; ctx->coeff_valid = false; }
   if (which == SVR_BUF_SLICES) return build_list(ctx, false);
   return SVR_OK;
 }

@@ -27,7 +27,7 @@ T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE, T_RE
 TIMER_NAMES = ("backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale", "register")
 
 EXPORTS = [
-    "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_set_spx_masks", "svr_init_reconstruction_volume",
+    "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_get_option", "svr_set_spx_masks", "svr_init_reconstruction_volume",
     "svr_set_mask", "svr_init_storage_volumes", "svr_fill_slices", "svr_set_slice_dims",
     "svr_set_slice_matrices", "svr_generate_psf_volume", "svr_update_scale_vector",
     "svr_update_slice_weights", "svr_update_reconstructed", "svr_sync_cpu", "svr_get_vol_weights",
@@ -401,6 +401,11 @@ class Reconstruction:
 
     def set_option(self, name, value):
         self._ck(self._lib.svr_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        self._ck(self._lib.svr_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def probe_pixel(self, sl, px, py):
         v = np.zeros(4096, np.float32)

@@ -46,14 +46,22 @@ const char *svr_last_error(const svr_ctx *ctx);
  * reference CLI's: bias correction disabled (reconstruction.cc:121,202).  Call with
  * disable_bias_correction = 0 before the first compute call to enable the bias path. */
 int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
-/* engine tuning knobs (no reference equivalent).  "back_mode": 2 = plane-owned LDS tiles
- * (default; no atomics inside a tile), 1 = LDS tiles with ds_add_f32, 0 = direct device-scope
- * atomics per tap.  "fwd_mode": 1 = LDS-tiled forward gather (default), 0 = wave-per-pixel kernel.
- * "tile_w"/"tile_h", "fwd_tile_w"/"fwd_tile_h", "plane_waves", "plane_cap", "fwd_cap": tile geometry.
+/* engine options (no reference equivalent).
+ * "coeff_table" (default 0): 1 = keep the evaluated PSF taps of every live (pixel, plane) unit in HBM, written once per
+ *   slice geometry, and stream them in the scatter and the gather instead of evaluating them in every SR iteration --
+ *   irtkReconstruction::CoeffInit's _volcoeffs (irtkReconstructionGPU.cc:2305-2673) on the GPU path; 16 KiB per PSF
+ *   pixel; switches itself off when that does not fit the free memory; results are those of the on-the-fly kernels.
+ * "back_mode": 4 = wave-owned LDS planes (default), 3 = the workgroup kernel for every tile, 1 = LDS tiles with
+ *   ds_add_f32, 0 = direct device-scope atomics per tap.  "fwd_mode": 1 = unit-based LDS gather (default), 0 = wave-per-pixel
+ *   kernel.  "gauss_mode", "pvr_mode": the same choice for the Gaussian pass / the patch-to-volume kernels (tests).
+ * "tile_w"/"tile_h", "wave_cap", "fwd_tile_w"/"fwd_tile_h", "fwd_unit_cap": tile shapes and LDS box sizes.
  * "fwd_autotune" (default 1): the first forward projection / back-projection after new slice geometry times the
- * candidate tile shapes on the data and keeps the fastest; an explicit tile_w/h or fwd_tile_w/h switches that off.
- * "pvr": 1 selects the patch-to-volume constants and kernels; "pvr_mode", "gauss_mode": kernel variants for the tests. */
+ *   candidate shapes and box sizes on the data and keeps the fastest; an explicit shape switches that off.
+ * "pvr": 1 selects the patch-to-volume constants and kernels. */
 int svr_set_option(svr_ctx *ctx, const char *name, int value);
+/* the current value of an option: what the tile-shape / box-size timing chose, or whether "coeff_table" stayed on (it
+ * switches itself off when the table -- 16 KiB per PSF pixel -- does not fit the free device memory) */
+int svr_get_option(svr_ctx *ctx, const char *name, int *value);
 /* "pvr" = 1 switches the PSF kernels to the patch-to-volume constants of
  * PVRreconstructionGPU (patchBasedPSFReconstruction_gpu.cu, patchBasedSimulatePatches_gpu.cu,
  * patchBasedSuperresolution_gpu.cu): patches are handed over as the "slices" of the padded grid,

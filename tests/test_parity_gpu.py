@@ -369,6 +369,75 @@ def test_kernel_variants_agree_at_full_size():
         assert rel_err(res[bm][1], res[0][1]) < TOL_SUM and rel_err(res[bm][0], res[0][0]) < TOL_SUM
 
 
+def test_coefficient_table_against_the_oracle(tiny, oracle_mod):
+    """Option coeff_table 1: the taps of every live unit are written once (k_coeff_build) and the scatter / gather stream them
+    instead of evaluating them -- irtkReconstruction::CoeffInit's _volcoeffs (RG.cc:2305-2673) on the GPU path.  Against the
+    oracle like the on-the-fly kernels; the gather bit-identical to the on-the-fly gather (same taps, same order of sums)."""
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    run_to_state(dg, "sim")
+    sim0, sw0 = rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy()
+    rec.set_option("coeff_table", 1)
+    rec.SimulateSlices()
+    assert np.array_equal(rec.debug_get(E.BUF_SIMSLICES), sim0) and np.array_equal(rec.debug_get(E.BUF_SIMWEIGHTS), sw0)
+    run_to_state(do, "sim")
+    assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), orc.siminside)
+    assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
+    run_to_state(dg, "scale")
+    run_to_state(do, "scale")
+    rec.debug_set(E.BUF_WEIGHTS, orc.weights)
+    rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+    rec.debug_set(E.BUF_PSF_SUMS, orc.psf_sums)                          # (invalidates the table: it is rebuilt below)
+    rec.UpdateScaleVector(orc.d_scales, orc.slice_weights)
+    rec.SuperresolutionBackproject(orc.slice_weights)
+    orc.SuperresolutionBackproject(orc.slice_weights)
+    cm, ad = rec.debug_get(E.BUF_CONFIDENCE_MAP), rec.debug_get(E.BUF_ADDON)
+    assert np.array_equal(cm > 0, orc.cmap > 0)
+    assert rel_err(cm, orc.cmap) < TOL_SUM and rel_err(ad, orc.addon) < TOL_SUM
+    # a whole outer iteration with the table on, each side on its own state
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    rec.set_option("coeff_table", 1)
+    dg.reconstruct_iteration(2)
+    do.reconstruct_iteration(2)
+    g, o = rec.syncCPU(), orc.recon
+    assert np.array_equal(g == -1, o == -1) and rel_err(g, o) < 1e-4
+
+
+@pytest.mark.parametrize("workload", ["P4", "S8"])
+def test_coefficient_table_at_full_size(workload):
+    """BASELINE configs[1] / configs[3] on one GPU: the streamed taps give the on-the-fly kernels' results -- the gather bit for
+    bit, the scatter up to the order of its float atomics, hit sets exact -- also after new slice matrices (the table follows)."""
+    from fetalreconstruction_amd import engine as E, workloads
+    P = workloads.get(workload)
+    rec = _engine(P)
+    rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+    rec.InitializeEMValues()
+    rec.GaussianReconstruction()
+    def both():
+        rec.SimulateSlices()
+        sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
+        rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+        return sim, sw, si, rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy()
+    ref = both()
+    rec.set_option("coeff_table", 1)
+    tab = both()
+    assert rec.get_option("coeff_table") == 1                            # it fitted (P4: 19 GB, S8: 174 GB)
+    assert np.array_equal(tab[0], ref[0]) and np.array_equal(tab[1], ref[1]) and np.array_equal(tab[2], ref[2])
+    assert np.array_equal(tab[4] > 0, ref[4] > 0)
+    assert rel_err(tab[3], ref[3]) < TOL_SUM and rel_err(tab[4], ref[4]) < TOL_SUM
+    if workload == "P4":
+        t = P.slice_t.copy().reshape(P.ns, 4, 4)
+        t[::3, :3, 3] += 0.37                                            # a third of the slices move
+        ti = np.stack([np.linalg.inv(m.astype(np.float64)) for m in t]).astype(np.float32)
+        rec.SetSliceMatrices(t.reshape(P.ns, 16), ti.reshape(P.ns, 16), P.slice_i2w, P.slice_w2i, P.slice_i2w, P.slice_w2i, P.recon_i2w, P.recon_w2i)
+        rec.GaussianReconstruction()
+        tab2 = both()
+        rec.set_option("coeff_table", 0)
+        ref2 = both()
+        assert not np.array_equal(ref2[0], ref[0])
+        assert np.array_equal(tab2[0], ref2[0]) and np.array_equal(tab2[1], ref2[1])
+        assert np.array_equal(tab2[4] > 0, ref2[4] > 0) and rel_err(tab2[4], ref2[4]) < TOL_SUM
+
+
 def test_tile_shapes_do_not_change_results(tiny, oracle_mod):
     """The gather's and the scatter's tile shapes are timed per problem (svr_set_option "fwd_autotune"): the simulated slices
     must not depend on the shape at all (fixed per-pixel summation order), the scatter only through the order of its float
