@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
   std::vector<int> force_excluded, devices, packages;
   int iterations = 4, levels = 3, rec_first = 4, rec_last = 13, num_stacks_tuner = 0;
   double resolution = 0.75, average = 700, delta = 150, lambda = 0.02, last_lambda = 0.01, smooth_mask = 4;
-  bool no_matching = false, use_gpu_reg = false, no_registration = false;
+  bool no_matching = false, use_gpu_reg = false, no_registration = false, coeff_table = false;
   // ---- options (main.cc:164-211) ---------------------------------------------------------------------
   auto is_opt = [](const char *s) { return s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.'; };
   for (int i = 1; i < argc; ++i) {
@@ -75,6 +75,7 @@ int main(int argc, char **argv) {
     else if (o == "--no_registration") no_registration = true;
     else if (o == "--tfolder") tfolder = one();
     else if (o == "--sfolder") sfolder = one();
+    else if (o == "--coeffTable") coeff_table = true;                     // not a reference option: keep the PSF taps in HBM (CoeffInit on the GPU path)
     else if (o == "--debug") debug = opt_bool(true);
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
     else if (o == "-d" || o == "--devices") { std::vector<std::string> v; multi(v); for (auto &s : v) devices.push_back(atoi(s.c_str())); }
@@ -82,7 +83,7 @@ int main(int argc, char **argv) {
       printf("usage: SVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> [-m <mask>] [-t id|<4x4.txt> ..] [--thickness th_1 ..]\n"
              "       [--iterations 4] [--resolution 0.75] [--multires 3] [--average 700] [--delta 150] [--lambda 0.02]\n"
              "       [--lastIterLambda 0.01] [--smooth_mask 4] [--no_intensity_matching] [--force_exclude i ..]\n"
-             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [--tfolder dir] [--sfolder dir] [-d device_1 .. device_N]\n");
+             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [--tfolder dir] [--sfolder dir] [--coeffTable] [-d device_1 .. device_N]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/svr_cli.cpp)");
@@ -285,6 +286,7 @@ int main(int argc, char **argv) {
   par([&](int r) {
     const int nl = rhi[r] - rlo[r];
     const size_t o = (size_t)rlo[r];
+    if (coeff_table) ENGR(r, svr_set_option(ctxs[r], "coeff_table", 1));
     ENGR(r, svr_init_reconstruction_volume(ctxs[r], vsize, vdim, nullptr, 12.0f));
     ENGR(r, svr_set_mask(ctxs[r], vsize, vdim, maskf.data(), 12.0f));
     const uint32_t ssize[3] = {(uint32_t)mx, (uint32_t)my, (uint32_t)nl};

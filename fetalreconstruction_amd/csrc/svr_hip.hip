@@ -894,6 +894,14 @@ __device__ __forceinline__ bool unit_is_dead(const RowConst S, float bx, float b
   return !zero;
 }
 
+// 16 bytes of the coefficient table: read once per pass and never again before the next one, so the load is marked
+// non-temporal (it should not push the volume, the mask and the slice data out of the L2 / the memory-side cache)
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_stream(const float4 *p) {
+  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // The coefficient table (svr_ctx::d_coeff): one wavefront per PSF pixel, four of its 16 units per pass -- slot = unit,
 // lane = row, exactly the decomposition of the scatter and the gather.  A unit's 16 x 16 taps (skipped ones as -0.0f) go
 // out as 64 float4: [tap quad q][row y], so that the 16 lanes of a slot write and later read 256 contiguous bytes per
@@ -925,7 +933,8 @@ __global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, u
     if (!dead) {
       float4 *dst = coeff + ((size_t)w * 16 + u) * 64 + y;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dst[q * 16] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+      for (int q = 0; q < 4; ++q)
+        __builtin_nontemporal_store((nt_f4){out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]}, reinterpret_cast<nt_f4 *>(dst + q * 16));
     }
   }
 }
@@ -1375,7 +1384,7 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
           const int k1 = sh_list[slot][i];
           const float4 *src = a.coeff + ((size_t)sh_pid[k1] * 16 + (size_t)(P - sh_px[k1].cz + NC)) * 64 + y;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dst[q] = src[q * 16];
+          for (int q = 0; q < 4; ++q) dst[q] = load_stream(src + q * 16);
         };
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3) if (r3 < mynl) request(r3, ring[r3]);
@@ -1730,7 +1739,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       const float4 *src = a.coeff + ((size_t)sh_pid[k] * 16 + (size_t)u) * 64 + y;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 c = src[q * 16];
+        const float4 c = load_stream(src + q * 16);
         out[4 * q] = c.x; out[4 * q + 1] = c.y; out[4 * q + 2] = c.z; out[4 * q + 3] = c.w;
       }
     } else {
@@ -3184,7 +3193,12 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     return SVR_OK;
   }
   if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; return SVR_OK; }
-  if (!strcmp(name, "coeff_table")) { ctx->coeff_mode = value ? 1 : 0; if (!value) { free_dev(ctx->d_coeff); ctx->coeff_cap = 0; ctx->coeff_valid = false; } return SVR_OK; }
+  if (!strcmp(name, "coeff_table")) {
+    if ((value ? 1 : 0) != ctx->coeff_mode) ctx->fwd_tune_pending = ctx->back_tune_pending = ctx->fwd_autotune != 0;   // other shapes win
+    ctx->coeff_mode = value ? 1 : 0;
+    if (!value) { free_dev(ctx->d_coeff); ctx->coeff_cap = 0; ctx->coeff_valid = false; }
+    return SVR_OK;
+  }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
   if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
@@ -3790,7 +3804,15 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 3)) {
     ctx->back_tune_pending = false;
     ctx->in_tune = true;
-    static const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
+    // with the coefficient table the pass waits for memory, not for the ALUs: larger tiles (fewer flushed voxels per
+    // pixel) are tried first, with the largest box, before the box sizes are timed for the shape that won
+    static const int cand_eval[3][2] = {{4, 4}, {4, 2}, {2, 2}};
+    static const int cand_tab[5][2] = {{8, 4}, {6, 4}, {4, 4}, {4, 2}, {2, 2}};
+    const bool tab = ctx->coeff_mode && !ctx->pvr && ctx->back_mode == 4;
+    const int (*cand)[2] = tab ? cand_tab : cand_eval;
+    const int ncand = tab ? 5 : 3;
+    const int cap0 = ctx->wave_cap;
+    if (tab && !ctx->wave_cap_user) ctx->wave_cap = 2416;
     const auto timing = ctx->timers;
     ctx->timers = false;                                 // the trial runs stay out of the kernel timers
     hipEvent_t e0, e1;
@@ -3798,7 +3820,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     HIPCHK(hipEventCreate(&e1));
     float best = 3.0e38f;
     int pick = 0;
-    for (int c = 0; c < 3 && !r; ++c) {
+    for (int c = 0; c < ncand && !r; ++c) {
       r = svr_set_option(ctx, "tile_w", cand[c][0]);
       if (!r) r = svr_set_option(ctx, "tile_h", cand[c][1]);
       float ms = 0.0f;
@@ -3810,8 +3832,9 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
       }
       if (ms < best) { best = ms; pick = c; }
-      else break;
+      else if (!tab) break;
     }
+    if (tab && !ctx->wave_cap_user) ctx->wave_cap = cap0;
     if (!r) r = svr_set_option(ctx, "tile_w", cand[pick][0]);
     if (!r) r = svr_set_option(ctx, "tile_h", cand[pick][1]);
     if (!r && (ctx->pvr || ctx->back_mode == 4) && !ctx->wave_cap_user) {

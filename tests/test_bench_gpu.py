@@ -30,6 +30,9 @@ def test_bench_line_and_two_ranks_on_one_gpu():
     assert a["n_gpus"] == 1 and a["steps"] == 3 and a["value"] > 0 and a["dtype"] == "f32" and a["roofline"]["frac"] > 0
     assert a["scaling"] == "strong" and a["roofline"]["bound"] == "valu_f32" and a["roofline"]["hbm_frac"] > 0
     assert a["roofline"]["algorithmic_bytes"] > 0 and "traffic" in a["roofline"]
+    # the second measurement of the same steps with the coefficient table, next to the headline
+    t = a["coeff_table"]
+    assert t["fits"] and t["value"] > 0 and t["ms_per_step"] > 0 and t["roofline"]["bound"] == "hbm" and t["table_bytes_rank0"] > 0
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29517", "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",

@@ -264,6 +264,23 @@ def test_sfolder_replaces_the_slices_by_the_files_of_a_folder(tmp_path):
     assert c.returncode != 0 and "23 files, but the stacks hold 24 slices" in c.stderr
 
 
+@pytest.mark.gpu
+def test_command_line_with_the_coefficient_table(tmp_path):
+    """--coeffTable (not a reference option): the engine keeps the PSF taps in HBM (CoeffInit on the GPU path); the volume is the
+    plain run's up to the order of the float atomics."""
+    import subprocess
+    from fetalreconstruction_amd import build, nifti
+    paths, mpath, rattr, rmask = _write_case(tmp_path)
+    common = ["-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "2",
+              "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2", "--no_registration"]
+    a = subprocess.run([build.CLI, "-o", str(tmp_path / "a.nii.gz"), *common], capture_output=True, text=True, timeout=300)
+    b = subprocess.run([build.CLI, "-o", str(tmp_path / "b.nii.gz"), *common, "--coeffTable"], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0, b.stderr[-2000:]
+    va, _ = nifti.read(tmp_path / "a.nii.gz")
+    vb, _ = nifti.read(tmp_path / "b.nii.gz")
+    assert np.array_equal(va == -1, vb == -1) and np.abs(va - vb).max() <= 2e-4 * np.abs(va).max()
+
+
 def test_command_line_boolean_options_follow_the_reference():
     """`--debug`, `--no_intensity_matching`, `--no_log` are po::value<bool> in the reference (reconstruction.cc:186-205): they take
     a value, and the value of --no_intensity_matching lands in `intensity_matching` itself (0 switches the matching off)."""
