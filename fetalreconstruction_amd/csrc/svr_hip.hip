@@ -1460,7 +1460,7 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
       // (negative -> 0, RC.cu:508) is applied here, which sums exactly the taps that alias
       // the lane's elements i = lane + 64 u of a plane sit at the same in-plane voxel offset on all four planes: work
       // the offsets out once (saturation of negative coordinates and the bound in x included; -1 = nothing to flush)
-      constexpr int FLUSH_U = 8;
+      constexpr int FLUSH_U = COEFF ? 10 : 8;           // plane voxels per lane of the unrolled flush (table mode: 8 x 4 / 8 x 8 tiles, planes of up to 640)
       RowWalk w0;
       w0.init(lane, 64, PL);
       if (PP <= 64 * FLUSH_U) {
@@ -3076,8 +3076,24 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
     KCHK("back_wave_kernel");
     HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_tiles_fb8 = nfb[0];
     cur = ctx->d_tiles_fb; ncur = nfb[0];
+    if (ncur && a.coeff && ta.cap < 3696) {
+      // table mode: the tiles whose planes did not fit go through the same kernel once more with the largest box worth
+      // having (4 planes of 30 x 30 voxels: 5 wavefronts per CU) before the evaluating workgroup kernel gets them
+      HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t), ctx->stream));
+      ta.tiles = cur; ta.ntiles = ncur; ta.cap = std::min(3696, ctx->tile_cap);
+      hipLaunchKernelGGL((back_wave_kernel<PSF_SUPPORT, false, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), (size_t)ta.cap * 2 * sizeof(float),
+                         ctx->stream, a, ta, ctx->wave_groups, ctx->d_tiles_fb2, cnt);
+      KCHK("back_wave_kernel (large box)");
+      HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      cur = ctx->d_tiles_fb2; ncur = nfb[0];
+      if (ncur) {                                          // the workgroup kernel writes its own rejects to d_tiles_fb2: move the list
+        HIPCHK(hipMemcpyAsync(ctx->d_tiles_fb, ctx->d_tiles_fb2, (size_t)ncur * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        cur = ctx->d_tiles_fb;
+      }
+    }
+    ctx->n_tiles_fb8 = ncur;
   }
   if (ncur && level >= 3) {
     ta.tiles = cur; ta.ntiles = ncur; ta.cap = ctx->tile_cap;

@@ -43,12 +43,12 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
-def pmc(workload, tag):
+def pmc(workload, tag, opts=()):
     d = os.path.join(OUT, "pmc_" + tag)
     p = sh([sys.executable, os.path.join(R, "tools", "pmc.py"), d, "--filter", "_kernel", "--", sys.executable,
-            os.path.join(R, "tools", "run_sr_kernels.py"), workload])
+            os.path.join(R, "tools", "run_sr_kernels.py"), workload, *opts])
     txt = p.stdout
-    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} (1 GPU), round 2.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
+    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} {' '.join(opts)} (1 GPU), round 2.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
             "# rocprofv3 --kernel-trace --pmc <set> pass per counter set (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE), nothing else in\n"
             "# the pass.  Per kernel: mean over the last half of its dispatches.  SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are in\n"
             "# quad-cycles summed over the SIMDs, FETCH_SIZE / WRITE_SIZE in KB (uncalibrated for this access pattern: narrow LDS-staged\n"
@@ -73,6 +73,7 @@ def main():
     # 3. PMC first (the traffic file must exist before the final bench line)
     v4 = pmc("P4", "p4")
     v8 = pmc("S8", "s8")
+    pmc("P4", "p4_table", ("coeff_table=1",))                # the COEFF instantiations streaming the coefficient table
     traffic = {"workload": "P4", "source": "profiles/r02_pmc_p4.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes)"}
     for key, pat in (("back", "back_wave_kernel"), ("forward", "fwd_unit_kernel<false")):
         k = [n for n in v4 if pat in n]
