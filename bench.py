@@ -43,6 +43,23 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")     # written 
 METRIC = "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR, 1/2/4/8 GPU"
 
 
+def table_traffic(workload, world):
+    """FETCH_SIZE / WRITE_SIZE of the table-mode kernels from this round's PMC passes (profiles/r02_traffic.json), per launch.
+    The guide's gfx950 correction applies to these kernels' reads: 16 B per lane, coalesced, streaming -- FETCH_SIZE reports half
+    of such bytes -- so `fetch_corrected` doubles it; WRITE_SIZE (float atomics) is reported as counted."""
+    try:
+        tj = json.load(open(TRAFFIC_JSON))
+        if tj.get("workload") != workload or world != 1:
+            return None
+        out = {}
+        for key, name in (("back_table", "scatter"), ("forward_table", "gather")):
+            e = tj[key]
+            out[name] = {"fetch_counted": e["fetch_bytes"], "fetch_corrected": 2.0 * e["fetch_bytes"], "write_counted": e["write_bytes"]}
+        return out
+    except Exception:
+        return None
+
+
 def cpu_baseline(prob, target_seconds=12.0):
     """The CPU port (oracle, literal float32 mode = the reference's own arithmetic) timed on a bounded sample of the same
     workload on the host cores: ONE WHOLE SR ITERATION (Scale, back-projection, Prep + regulariser, forward projection,
@@ -321,6 +338,7 @@ def main():
                 "kernel_ms": {"backproject": bp2a * 1e3, "forward": fw2a * 1e3},
                 "table_bytes_rank0": tab["bytes"],
                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                             "traffic": table_traffic(prob.name, world),
                              "bytes_per_launch_upper": tab["bytes"] + b_back,
                              "achieved_upper": ((tab["bytes"] + b_back) / bp2a / 1e9) if bp2[1] else None,
                              "frac_upper": ((tab["bytes"] + b_back) / bp2a / 1e9 / HBM_PEAK_GBS) if bp2[1] else None},

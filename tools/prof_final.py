@@ -73,12 +73,17 @@ def main():
     # 3. PMC first (the traffic file must exist before the final bench line)
     v4 = pmc("P4", "p4")
     v8 = pmc("S8", "s8")
-    pmc("P4", "p4_table", ("coeff_table=1",))                # the COEFF instantiations streaming the coefficient table
+    vt = pmc("P4", "p4_table", ("coeff_table=1",))           # the COEFF instantiations streaming the coefficient table
     traffic = {"workload": "P4", "source": "profiles/r02_pmc_p4.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes)"}
     for key, pat in (("back", "back_wave_kernel"), ("forward", "fwd_unit_kernel<false")):
         k = [n for n in v4 if pat in n]
         if k and "FETCH_SIZE" in v4[k[0]] and "WRITE_SIZE" in v4[k[0]]:
             traffic[key] = {"kernel": k[0], "fetch_bytes": v4[k[0]]["FETCH_SIZE"] * 1024.0, "write_bytes": v4[k[0]]["WRITE_SIZE"] * 1024.0}
+    for key, pat in (("back_table", "back_wave_kernel<16, false, true"), ("forward_table", "fwd_unit_kernel<false, 16, false, true")):
+        k = [n for n in vt if pat in n]
+        if k and "FETCH_SIZE" in vt[k[0]] and "WRITE_SIZE" in vt[k[0]]:
+            traffic[key] = {"kernel": k[0], "fetch_bytes": vt[k[0]]["FETCH_SIZE"] * 1024.0, "write_bytes": vt[k[0]]["WRITE_SIZE"] * 1024.0,
+                            "source": "profiles/r02_pmc_p4_table.txt"}
     if "back" in traffic:
         json.dump(traffic, open(os.path.join(PROF, "r02_traffic.json"), "w"), indent=1)
     # 1. bench lines
