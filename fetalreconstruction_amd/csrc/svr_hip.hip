@@ -3313,6 +3313,7 @@ int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const f
   ctx->vx = size[0]; ctx->vy = size[1]; ctx->vz = size[2];
   memcpy(ctx->vdim, dim, 3 * sizeof(float));
   ctx->nv = nv;
+  ctx->coeff_valid = false;
   HIPCHK(hipMalloc(&ctx->d_recon_volw, 2 * nv * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_addon_cmap, 2 * nv * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_snap, nv * sizeof(float)));
@@ -3438,6 +3439,7 @@ int svr_generate_psf_volume(svr_ctx *ctx, const float *cpu_psf, const uint32_t p
   // d_PSFI2W * ((PSFsize - 1) * 0.5f)   RC.cu:172
   float v[3] = {((float)psf_size[0] - 1) * 0.5f, ((float)psf_size[1] - 1) * 0.5f, ((float)psf_size[2] - 1) * 0.5f};
   matvec3_host(psf_i2w, v, ctx->psf_c0);
+  ctx->coeff_valid = false;                               // the taps' residuals carry c0
   ctx->quality_factor = quality_factor;
   ctx->have_psf = true;
   return SVR_OK;
