@@ -1474,28 +1474,54 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
             w.step();
           }
         }
+        if (COEFF) {
+          // table mode: the pass waits for memory, so the mask is only asked about voxels that have something to flush
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (pl[q] < 0) continue;
+            const f2 *pq = box + q * PP + lane;
+            const float *mz = a.mask + sat0(pl[q] + loz) * stz;
+            float *az_ = a.addon + sat0(pl[q] + loz) * stz, *cz_ = a.cmap + sat0(pl[q] + loz) * stz;
+            f2 v[FLUSH_U];
+            float mk[FLUSH_U];
+#pragma unroll
+            for (int u = 0; u < FLUSH_U; ++u) {                 // all mask words of the plane in flight together
+              v[u] = lane + 64 * u < PP ? pq[64 * u] : (f2){0.0f, 0.0f};
+              const bool ok = eoff[u] >= 0 && (v[u].x != 0.0f || v[u].y != 0.0f);
+              mk[u] = ok ? mz[eoff[u]] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < FLUSH_U; ++u) {
+              if (mk[u] != 0.0f) {
+                unsafeAtomicAdd(az_ + eoff[u], v[u].x);
+                unsafeAtomicAdd(cz_ + eoff[u], v[u].y);
+              }
+            }
+          }
+        } else {
         // the mask words of all four planes first (unconditional, mostly L2 hits, all in flight together), then the box:
-        // two dependent phases per pass instead of three per plane
-        float mk[4][FLUSH_U];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float *mz = a.mask + sat0(max(pl[q], 0) + loz) * stz;
-#pragma unroll
-          for (int u = 0; u < FLUSH_U; ++u) mk[q][u] = (pl[q] >= 0 && eoff[u] >= 0) ? mz[eoff[u]] : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (pl[q] < 0) continue;
-          const f2 *pq = box + q * PP + lane;
-          float *az_ = a.addon + sat0(pl[q] + loz) * stz, *cz_ = a.cmap + sat0(pl[q] + loz) * stz;
-          f2 v[FLUSH_U];
-#pragma unroll
-          for (int u = 0; u < FLUSH_U; ++u) v[u] = lane + 64 * u < PP ? pq[64 * u] : (f2){0.0f, 0.0f};
-#pragma unroll
-          for (int u = 0; u < FLUSH_U; ++u) {
-            if (mk[q][u] != 0.0f && (v[u].x != 0.0f || v[u].y != 0.0f)) {
-              unsafeAtomicAdd(az_ + eoff[u], v[u].x);
-              unsafeAtomicAdd(cz_ + eoff[u], v[u].y);
+          // two dependent phases per pass instead of three per plane
+          float mk[4][FLUSH_U];
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float *mz = a.mask + sat0(max(pl[q], 0) + loz) * stz;
+  #pragma unroll
+            for (int u = 0; u < FLUSH_U; ++u) mk[q][u] = (pl[q] >= 0 && eoff[u] >= 0) ? mz[eoff[u]] : 0.0f;
+          }
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (pl[q] < 0) continue;
+            const f2 *pq = box + q * PP + lane;
+            float *az_ = a.addon + sat0(pl[q] + loz) * stz, *cz_ = a.cmap + sat0(pl[q] + loz) * stz;
+            f2 v[FLUSH_U];
+  #pragma unroll
+            for (int u = 0; u < FLUSH_U; ++u) v[u] = lane + 64 * u < PP ? pq[64 * u] : (f2){0.0f, 0.0f};
+  #pragma unroll
+            for (int u = 0; u < FLUSH_U; ++u) {
+              if (mk[q][u] != 0.0f && (v[u].x != 0.0f || v[u].y != 0.0f)) {
+                unsafeAtomicAdd(az_ + eoff[u], v[u].x);
+                unsafeAtomicAdd(cz_ + eoff[u], v[u].y);
+              }
             }
           }
         }
