@@ -145,6 +145,7 @@ struct PsfArgs {
   int *voxcount;
   // forward
   const float *vol;
+  const float2 *volm;       // SVR gather: {V m, m} per voxel, packed by k_pack_volm right before the pass (NULL: vol + mask)
   float *simslices, *simweights;
   unsigned char *siminside;
   // back
@@ -1695,10 +1696,15 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
         const uint32_t vi = sat0(gx) + sat0(bw.y + loy) * (uint32_t)vg.vx + sat0(bw.z + loz) * sxy;
         // (SVR: the volume word is fetched whether or not the voxel is in the mask -- two independent loads instead of a
         // dependent pair; the PVR texture average is eight loads and stays behind the mask test)
-        const float vraw = (GAUSS1 || PVR) ? 0.0f : a.vol[vi];
-        const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-        v = GAUSS1 ? (f2){1.0f, m}
-                   : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(bw.y + loy), (int)sat0(bw.z + loz)) : vraw) : 0.0f, m};
+        if (!GAUSS1 && !PVR && a.volm) {                    // one 8-byte load of the packed pair
+          const float2 t = a.volm[vi];
+          v = (f2){t.x, t.y};
+        } else {
+          const float vraw = (GAUSS1 || PVR) ? 0.0f : a.vol[vi];
+          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
+          v = GAUSS1 ? (f2){1.0f, m}
+                     : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(bw.y + loy), (int)sat0(bw.z + loz)) : vraw) : 0.0f, m};
+        }
       }
       box[i] = v;
     }
@@ -2473,6 +2479,15 @@ __global__ __launch_bounds__(256) void k_regularize(int vx, int vy, int vz, floa
   out[p] = (valW > 0.0f) ? val / valW : 0.0f;
 }
 // maskVolumeKernel RC.cu:3313-3326
+// {V m, m} per voxel (m = 1 inside the mask, else 0): what the gather's LDS boxes hold, packed once per pass so that a
+// box voxel is one 8-byte load instead of two loads and a select
+__global__ void k_pack_volm(const float *vol, const float *mask, float2 *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float m = mask[i] != 0.0f ? 1.0f : 0.0f;
+  out[i] = make_float2(m != 0.0f ? vol[i] : 0.0f, m);
+}
+
 __global__ void k_mask_volume(float *recon, const float *mask, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && mask[i] == 0) recon[i] = -1.0f;
@@ -2692,6 +2707,7 @@ struct svr_ctx {
   float *d_recon_volw = nullptr;   // recon | volw
   float *d_addon_cmap = nullptr;   // addon | cmap
   float *d_mask = nullptr, *d_snap = nullptr, *d_recon_new = nullptr;
+  float2 *d_volm = nullptr;   // {V m, m}, refreshed before every SVR forward projection
   bool have_mask = false;
 
   // slice grid
@@ -2856,6 +2872,7 @@ void free_volume(svr_ctx *c) {
   free_dev(c->d_addon_cmap);
   free_dev(c->d_snap);
   free_dev(c->d_recon_new);
+  free_dev(c->d_volm);
 }
 void free_slices(svr_ctx *c) {
   free_dev(c->d_slices); free_dev(c->d_weights); free_dev(c->d_simslices); free_dev(c->d_simweights);
@@ -3649,6 +3666,12 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   if (ctx->coeff_mode && ctx->coeff_valid && !ctx->pvr && ctx->fwd_mode >= 1) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
+  if (!ctx->pvr && ctx->fwd_mode >= 1 && a.n) {
+    if (!ctx->d_volm) HIPCHK(hipMalloc(&ctx->d_volm, ctx->nv * sizeof(float2)));
+    hipLaunchKernelGGL(k_pack_volm, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_mask, ctx->d_volm, ctx->nv);
+    KCHK("k_pack_volm");
+    a.volm = ctx->d_volm;
+  }
   auto launch_forward = [&]() -> int {
     const bool tiled_ = ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1;
     if (a.n && tiled_) {
