@@ -1,7 +1,8 @@
 // svr_hip.hip -- MI355X (gfx950) slice-to-volume super-resolution engine behind the C-ABI of
-// include/svr_hip.h.  Written for CDNA4 only: 64-wide wavefronts, one wavefront per slice
-// pixel for the PSF kernels, LDS transposition between the "row-per-lane" PSF evaluation and
-// the "x-per-lane" coalesced volume access, hardware float atomics for the scatter.
+// include/svr_hip.h.  Written for CDNA4 only: 64-wide wavefronts; the PSF evaluated row per lane, two taps per lane-op
+// (v_pk_fma_f32); the scatter with one wavefront owning four planes of a tile's LDS box (back_wave_kernel), the gather
+// with a workgroup per tile over (pixel, plane) units (fwd_unit_kernel); optionally the evaluated taps kept in HBM and
+// streamed (the coefficient table, k_coeff_build); hardware float atomics only at the flush.
 //
 // Reference behaviour being replaced (citations: RC.cu = source/reconstructionGPU2/
 // reconstruction_cuda2.cu, RC.cuh = include/reconstruction_cuda2.cuh, RVH =
@@ -33,13 +34,6 @@
 // (RC.cuh:72, RC.cu:238); for a float f that is exactly  f <= 0.00001f  because 0.00001f is
 // the largest float below 1e-5.
 #define PSF_EPS_F 0.00001f
-#ifndef SVR_WPE_PLAIN
-#define SVR_WPE_PLAIN 7
-#endif
-#ifndef SVR_WPE_ROWS
-#define SVR_WPE_ROWS 5
-#endif
-
 #define LDS_ROW 20              // floats per PSF row in LDS (16 + pad: conflict-free b128 stores)
 #define WAVES_PER_BLOCK 4
 #define CHUNK_PIX 2048          // slice-grid pixels per block in the EM kernels
