@@ -274,7 +274,7 @@ int main(int argc, char **argv) {
   std::vector<int> devices, psize, pstride, packages;
   int iterations = 7, sr_iterations = 7, dilate = 0;
   double resolution = 0.75;
-  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false, hierarchical = false, resample = false;
+  bool no_matching = false, dry_run = false, no_registration = false, superpixel = false, full_slices = false, hierarchical = false, resample = false, coeff_table = false;
   int spx_size = 16, spx_extend = 50;                    // pvrmain:104-106
   std::string existing_name;                             // --existingReconTarget (pvrmain:118)
   std::string dump_name;                                 // test hooks: --dumpProblem <file> [--dryRun]
@@ -302,6 +302,7 @@ int main(int argc, char **argv) {
     else if (o == "--iterations") iterations = atoi(one().c_str());
     else if (o == "--sr_iterations") sr_iterations = atoi(one().c_str());
     else if (o == "--noMatchIntensities") no_matching = true;
+    else if (o == "--coeffTable") coeff_table = true;                      // not a reference option: keep the PSF taps in HBM
     else if (o == "-d" || o == "--devices") ints(devices);
     else if (o == "--dumpProblem") dump_name = one();
     else if (o == "--dryRun") dry_run = true;
@@ -476,6 +477,7 @@ int main(int argc, char **argv) {
   svr_ctx *ctx = nullptr;
   if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
   ENG(svr_set_option(ctx, "pvr", 1));
+  if (coeff_table) ENG(svr_set_option(ctx, "coeff_table", 1));
   const uint32_t vsize[3] = {(uint32_t)tattr.nx, (uint32_t)tattr.ny, (uint32_t)tattr.nz};
   const float vdim[3] = {(float)tattr.dx, (float)tattr.dy, (float)tattr.dz};
   std::vector<float> maskf(recon_mask.d.begin(), recon_mask.d.end());

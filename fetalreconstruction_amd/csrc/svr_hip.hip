@@ -906,12 +906,14 @@ __device__ __forceinline__ float4 load_stream(const float4 *p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// The coefficient table (svr_ctx::d_coeff): one wavefront per PSF pixel, four of its 16 units per pass -- slot = unit,
-// lane = row, exactly the decomposition of the scatter and the gather.  A unit's 16 x 16 taps (skipped ones as -0.0f) go
-// out as 64 float4: [tap quad q][row y], so that the 16 lanes of a slot write and later read 256 contiguous bytes per
-// instruction.  Dead units (unit_is_dead) are not stored: the kernels evaluate their first taps themselves.
+// The coefficient table (svr_ctx::d_coeff): one wavefront per PSF pixel, four of its NS units per pass -- slot = unit,
+// lane = row, exactly the decomposition of the scatter and the gather.  A unit's NS x NS taps (skipped ones as -0.0f) go
+// out as NS/4 x 16 float4: [tap quad q][row y], so that the 16 lanes of a slot write and later read 256 contiguous bytes
+// per instruction (SVR: 16 units of 1 KiB per pixel; PVR, support 12: 12 units of 768 bytes).  Dead units (unit_is_dead) are not stored: the kernels evaluate their first taps themselves.
+template <int NS, bool PVR>
 __global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, uint32_t *coeff_id) {
-  constexpr int NC = PSF_CENTRE;
+  constexpr int NC = (NS - 1) / 2, QUADS = NS / 4;
+  static_assert(NS % 4 == 0 && NS <= 16, "tap quads, one row per lane of a 16-lane slot");
   const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (w >= a.n) return;
   const int lane = threadIdx.x & 63;
@@ -927,17 +929,17 @@ __global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, u
   if (lane == 0) coeff_id[idx] = w;
   const int slot = lane >> 4, y = lane & 15;
   const float fyl = (float)(y - NC);
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; 4 * g < NS; ++g) {
     const int u = 4 * g + slot;
     const float fu = (float)(u - NC);
-    const bool dead = unit_is_dead(RC, P.bx, P.by, P.bz, F, fu);
+    const bool dead = !PVR && unit_is_dead(RC, P.bx, P.by, P.bz, F, fu);   // (the bound is derived for the SVR constants)
     if (__all(dead)) continue;
-    float out[PSF_SUPPORT];
-    eval_row_t<PSF_SUPPORT, false, true>(RC, P.bx, P.by, P.bz, swap ? fu : fyl, swap ? fyl : fu, out);
-    if (!dead) {
-      float4 *dst = coeff + ((size_t)w * 16 + u) * 64 + y;
+    float out[NS];
+    eval_row_t<NS, PVR, true>(RC, P.bx, P.by, P.bz, swap ? fu : fyl, swap ? fyl : fu, out);
+    if (!dead && u < NS && y < NS) {
+      float4 *dst = coeff + ((size_t)w * NS + u) * (QUADS * 16) + y;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < QUADS; ++q)
         __builtin_nontemporal_store((nt_f4){out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]}, reinterpret_cast<nt_f4 *>(dst + q * 16));
     }
   }
@@ -1383,12 +1385,12 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
       if (COEFF) {
         // the taps come from the coefficient table (what eval_row_t returns, written by k_coeff_build): a ring of three
         // units per slot keeps 3 KiB per slot in flight -- the pass waits for HBM, not for the ALUs
-        float4 ring[3][4];
-        auto request = [&](int i, float4 (&dst)[4]) {
+        float4 ring[3][NS / 4];
+        auto request = [&](int i, float4 (&dst)[NS / 4]) {
           const int k1 = sh_list[slot][i];
-          const float4 *src = a.coeff + ((size_t)sh_pid[k1] * 16 + (size_t)(P - sh_px[k1].cz + NC)) * 64 + y;
+          const float4 *src = a.coeff + ((size_t)sh_pid[k1] * NS + (size_t)(P - sh_px[k1].cz + NC)) * (NS / 4 * 16) + (y < NS ? y : 0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dst[q] = load_stream(src + q * 16);
+          for (int q = 0; q < NS / 4; ++q) dst[q] = load_stream(src + q * 16);
         };
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3) if (r3 < mynl) request(r3, ring[r3]);
@@ -1406,7 +1408,7 @@ void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_til
               for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
               float out[NS];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) { out[4 * q] = ring[r3][q].x; out[4 * q + 1] = ring[r3][q].y; out[4 * q + 2] = ring[r3][q].z; out[4 * q + 3] = ring[r3][q].w; }
+              for (int q = 0; q < NS / 4; ++q) { out[4 * q] = ring[r3][q].x; out[4 * q + 1] = ring[r3][q].y; out[4 * q + 2] = ring[r3][q].z; out[4 * q + 3] = ring[r3][q].w; }
               if (i + 3 < mynl) request(i + 3, ring[r3]);
               add_unit(R, out, acc, rowok, rb);
             }
@@ -1771,9 +1773,9 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
       // the unit's taps from the coefficient table (what eval_row_t returns, written by k_coeff_build).  Sixteen
       // wavefronts per CU keep enough of these 1 KiB reads in flight; a three-round prefetch ring was measured and lost
       // (3.55 against 3.43 ms)
-      const float4 *src = a.coeff + ((size_t)sh_pid[k] * 16 + (size_t)u) * 64 + y;
+      const float4 *src = a.coeff + ((size_t)sh_pid[k] * NS + (size_t)u) * (NS / 4 * 16) + (y < NS ? y : 0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NS / 4; ++q) {
         const float4 c = load_stream(src + q * 16);
         out[4 * q] = c.x; out[4 * q + 1] = c.y; out[4 * q + 2] = c.z; out[4 * q + 3] = c.w;
       }
@@ -3065,7 +3067,7 @@ int ensure_psf_list(svr_ctx *ctx) {
 // (Re)build the coefficient table if the option is on and the table does not match the current PSF pixels / geometry.
 // Returns with ctx->coeff_valid set, or with the mode switched off when the table does not fit the free memory.
 int ensure_coeff(svr_ctx *ctx) {
-  if (!ctx->coeff_mode || ctx->pvr || ctx->coeff_valid) return SVR_OK;
+  if (!ctx->coeff_mode || ctx->coeff_valid) return SVR_OK;
   int r = ensure_psf_list(ctx);
   if (r) return r;
   if (!ctx->n_psf) return SVR_OK;
@@ -3073,7 +3075,8 @@ int ensure_coeff(svr_ctx *ctx) {
     free_dev(ctx->d_coeff);
     ctx->coeff_cap = 0;
     size_t fr = 0, tot = 0;
-    const size_t bytes = (size_t)ctx->n_psf * 16 * 64 * sizeof(float4);
+    const size_t per_px = ctx->pvr ? (size_t)PVR_N * (PVR_N / 4) * 16 : (size_t)PSF_SUPPORT * (PSF_SUPPORT / 4) * 16;   // float4 per pixel
+    const size_t bytes = (size_t)ctx->n_psf * per_px * sizeof(float4);
     if (hipMemGetInfo(&fr, &tot) != hipSuccess || bytes + (size_t(2) << 30) > fr || hipMalloc(&ctx->d_coeff, bytes) != hipSuccess) {
       (void)hipGetLastError();
       ctx->d_coeff = nullptr;
@@ -3086,7 +3089,8 @@ int ensure_coeff(svr_ctx *ctx) {
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
-  hipLaunchKernelGGL(k_coeff_build, dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
+  if (ctx->pvr) hipLaunchKernelGGL((k_coeff_build<PVR_N, true>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
+  else hipLaunchKernelGGL((k_coeff_build<PSF_SUPPORT, false>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
   KCHK("k_coeff_build");
   ctx->coeff_valid = true;
   return SVR_OK;
@@ -3113,8 +3117,10 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
   if (level >= 4) {
     ta.tiles = cur; ta.ntiles = ncur; ta.cap = std::min(ctx->wave_cap, ctx->tile_cap);
     const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-    if (pvr) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
-                                ctx->wave_groups, ctx->d_tiles_fb, cnt);
+    if (pvr && a.coeff) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
+                                          ctx->wave_groups, ctx->d_tiles_fb, cnt);
+    else if (pvr) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
+                                     ctx->wave_groups, ctx->d_tiles_fb, cnt);
     else if (a.coeff) hipLaunchKernelGGL((back_wave_kernel<PSF_SUPPORT, false, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
                                          ctx->wave_groups, ctx->d_tiles_fb, cnt);
     else hipLaunchKernelGGL(back_wave_kernel<>, dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
@@ -3128,8 +3134,10 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
       // having (4 planes of 30 x 30 voxels: 5 wavefronts per CU) before the evaluating workgroup kernel gets them
       HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t), ctx->stream));
       ta.tiles = cur; ta.ntiles = ncur; ta.cap = std::min(3696, ctx->tile_cap);
-      hipLaunchKernelGGL((back_wave_kernel<PSF_SUPPORT, false, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), (size_t)ta.cap * 2 * sizeof(float),
-                         ctx->stream, a, ta, ctx->wave_groups, ctx->d_tiles_fb2, cnt);
+      if (pvr) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), (size_t)ta.cap * 2 * sizeof(float),
+                                  ctx->stream, a, ta, ctx->wave_groups, ctx->d_tiles_fb2, cnt);
+      else hipLaunchKernelGGL((back_wave_kernel<PSF_SUPPORT, false, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), (size_t)ta.cap * 2 * sizeof(float),
+                              ctx->stream, a, ta, ctx->wave_groups, ctx->d_tiles_fb2, cnt);
       KCHK("back_wave_kernel (large box)");
       HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -3221,7 +3229,8 @@ int svr_create(int device, svr_ctx **out) {
                              reinterpret_cast<const void *>(fwd_unit_kernel<false, PSF_SUPPORT, false, true>),
                              reinterpret_cast<const void *>(fwd_unit_kernel<false, PVR_N, true>), reinterpret_cast<const void *>(fwd_unit_kernel<true, PVR_N, true>),
                              reinterpret_cast<const void *>(back_wave_kernel<>), reinterpret_cast<const void *>(back_wave_kernel<PVR_N, true>),
-                             reinterpret_cast<const void *>(back_wave_kernel<PSF_SUPPORT, false, true>),
+                             reinterpret_cast<const void *>(back_wave_kernel<PSF_SUPPORT, false, true>), reinterpret_cast<const void *>(back_wave_kernel<PVR_N, true, true>),
+                             reinterpret_cast<const void *>(fwd_unit_kernel<false, PVR_N, true, true>),
                              reinterpret_cast<const void *>(back_slot_kernel<8>), reinterpret_cast<const void *>(back_slot_kernel<8, PVR_N, true>)};
     bool ok = true;
     for (const void *f : big_lds) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
@@ -3254,7 +3263,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     ctx->fwd_tune_pending = ctx->back_tune_pending = value != 0;
     return SVR_OK;
   }
-  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; return SVR_OK; }
+  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; free_dev(ctx->d_coeff); ctx->coeff_cap = 0; return SVR_OK; }
   if (!strcmp(name, "coeff_table")) {
     if ((value ? 1 : 0) != ctx->coeff_mode) ctx->fwd_tune_pending = ctx->back_tune_pending = ctx->fwd_autotune != 0;   // other shapes win
     ctx->coeff_mode = value ? 1 : 0;
@@ -3668,7 +3677,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
-  if (ctx->coeff_mode && ctx->coeff_valid && !ctx->pvr && ctx->fwd_mode >= 1) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
+  if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1)) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
   if (!ctx->pvr && ctx->fwd_mode >= 1 && a.n) {
     if (!ctx->d_volm) HIPCHK(hipMalloc(&ctx->d_volm, ctx->nv * sizeof(float2)));
     hipLaunchKernelGGL(k_pack_volm, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_mask, ctx->d_volm, ctx->nv);
@@ -3683,7 +3692,8 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
       ta.gauss = 0;
       const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-      if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<false, PVR_N, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      if (ctx->pvr && a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<false, PVR_N, true, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      else if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<false, PVR_N, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       else if (a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<false, PSF_SUPPORT, false, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       else hipLaunchKernelGGL(fwd_unit_kernel<false>, dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       KCHK("fwd_unit_kernel");
@@ -3878,7 +3888,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     // pixel) are tried first, with the largest box, before the box sizes are timed for the shape that won
     static const int cand_eval[3][2] = {{4, 4}, {4, 2}, {2, 2}};
     static const int cand_tab[5][2] = {{8, 4}, {6, 4}, {4, 4}, {4, 2}, {2, 2}};
-    const bool tab = ctx->coeff_mode && !ctx->pvr && ctx->back_mode == 4;
+    const bool tab = ctx->coeff_mode && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode == 4);
     const int (*cand)[2] = tab ? cand_tab : cand_eval;
     const int ncand = tab ? 5 : 3;
     const int cap0 = ctx->wave_cap;
@@ -3944,7 +3954,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
-  if (ctx->coeff_mode && ctx->coeff_valid && !ctx->pvr && ctx->back_mode == 4) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
+  if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode == 4)) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
   const bool tiled = ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 1;
   if (a.n && tiled) {

@@ -117,6 +117,30 @@ def test_pvr_psf_kernels_parity(tiny, oracle_mod, use_spx, pvr_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("use_spx", [False, True])
+def test_pvr_coefficient_table(tiny, oracle_mod, use_spx):
+    """Option coeff_table with the patch-to-volume constants (support 12: 12 units of 12 x 12 taps per patch pixel, no dead
+    units): the gather bit-identical to the on-the-fly gather, both kernels against the oracle."""
+    spx = _spx(tiny) if use_spx else None
+    E, rec, orc = _pair(tiny, oracle_mod, spx, 1)
+    rec.GaussianReconstruction(); orc.GaussianReconstruction()
+    rec.SimulateSlices(); orc.SimulateSlices()
+    sim0, sw0 = rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy()
+    rec.set_option("coeff_table", 1)
+    rec.SimulateSlices()
+    assert rec.get_option("coeff_table") == 1
+    assert np.array_equal(rec.debug_get(E.BUF_SIMSLICES), sim0) and np.array_equal(rec.debug_get(E.BUF_SIMWEIGHTS), sw0)
+    assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), orc.siminside) and rel_err(sim0, orc.simslices) < 2e-5
+    rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+    w = np.full(tiny.ns, 0.8, np.float32)
+    rec.SuperresolutionBackproject(w)
+    orc.SuperresolutionBackproject(w)
+    cm = rec.debug_get(E.BUF_CONFIDENCE_MAP)
+    assert np.array_equal(cm > 0, orc.cmap > 0)
+    assert rel_err(cm, orc.cmap) < 2e-5 and rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("superpixel", [False, True])
 def test_pvr_kernel_variants_agree_at_full_size(superpixel):
     """BASELINE.json configs[2] (PVR, 32x32 patches stride 16 on the 4-stack 1.0 mm case; too big for the oracle) and the
@@ -147,6 +171,13 @@ def test_pvr_kernel_variants_agree_at_full_size(superpixel):
         sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
         rec.SuperresolutionBackproject(ones)
         out[mode] = (n, ps, vol, vw, sim, sw, si, rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
+        if mode == 1:                                         # the same engine (same volume) streaming the coefficient table
+            rec.set_option("coeff_table", 1)
+            rec.SimulateSlices()
+            sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
+            rec.SuperresolutionBackproject(ones)
+            assert rec.get_option("coeff_table") == 1
+            out[2] = (n, ps, vol, vw, sim, sw, si, rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
         del rec
     a, b = out[1], out[0]
     assert a[0] == b[0] and np.array_equal(a[1] != 0, b[1] != 0) and np.array_equal(a[6], b[6])
@@ -155,6 +186,9 @@ def test_pvr_kernel_variants_agree_at_full_size(superpixel):
         assert rel_err(a[k], b[k]) < 5e-5, k
     assert np.array_equal(a[8] > 0, b[8] > 0)
     assert np.abs(a[5] - b[5]).max() < 3e-6 and rel_err(a[4], b[4]) < 5e-6
+    t = out[2]                                                # the table: the tiled gather bit for bit, the scatter to round-off
+    assert np.array_equal(t[4], a[4]) and np.array_equal(t[5], a[5]) and np.array_equal(t[6], a[6])
+    assert np.array_equal(t[8] > 0, a[8] > 0) and rel_err(t[7], a[7]) < 5e-5 and rel_err(t[8], a[8]) < 5e-5
 
 
 def _sub_attr(a, z0, z1, step):

@@ -1,5 +1,5 @@
 """P4-scale PVR run: patch extraction (32x32 stride 16; `spx` = SLICO superpixel patches, --spxSize 32 --spxExtend 2 as in
-BASELINE.json configs[4]), one outer iteration with 3 SR iterations; kernel times.  usage: run_pvr.py [spx|sq] [recon mm]"""
+BASELINE.json configs[4]), one outer iteration with 3 SR iterations; kernel times.  usage: run_pvr.py [spx|sq] [recon mm] [table]"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
@@ -15,6 +15,8 @@ print("patch extraction s:", round(time.time() - t0, 1), "patches", P.slices.sha
       "non-zero px", int((P.slices > 0).sum()))
 rec = engine.Reconstruction(0)
 rec.set_option("pvr", 1)
+if "table" in sys.argv:
+    rec.set_option("coeff_table", 1)                     # the taps kept in HBM (12 units of 768 bytes per patch pixel)
 engine.sync_gpu(rec, P, quality_factor=1.0)
 if SPX:
     rec.set_spx_masks(P.spx_masks)
