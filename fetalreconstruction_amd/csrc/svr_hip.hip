@@ -3077,7 +3077,9 @@ int ensure_coeff(svr_ctx *ctx) {
     size_t fr = 0, tot = 0;
     const size_t per_px = ctx->pvr ? (size_t)PVR_N * (PVR_N / 4) * 16 : (size_t)PSF_SUPPORT * (PSF_SUPPORT / 4) * 16;   // float4 per pixel
     const size_t bytes = (size_t)ctx->n_psf * per_px * sizeof(float4);
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess || bytes + (size_t(2) << 30) > fr || hipMalloc(&ctx->d_coeff, bytes) != hipSuccess) {
+    const char *cap_gb = getenv("SVR_COEFF_MAX_GB");     // optional ceiling on the table (GiB): a deployment knob, and how the tests reach the fallback
+    const bool over = cap_gb && (double)bytes > atof(cap_gb) * 1073741824.0;
+    if (over || hipMemGetInfo(&fr, &tot) != hipSuccess || bytes + (size_t(2) << 30) > fr || hipMalloc(&ctx->d_coeff, bytes) != hipSuccess) {
       (void)hipGetLastError();
       ctx->d_coeff = nullptr;
       ctx->coeff_mode = 0;                                 // does not fit: evaluate on the fly (svr_get_option tells)

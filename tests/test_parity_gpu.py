@@ -402,6 +402,22 @@ def test_coefficient_table_against_the_oracle(tiny, oracle_mod):
     assert np.array_equal(g == -1, o == -1) and rel_err(g, o) < 1e-4
 
 
+def test_coefficient_table_that_does_not_fit_is_switched_off(tiny, monkeypatch):
+    """16 KiB per PSF pixel may exceed the free memory (or the ceiling SVR_COEFF_MAX_GB): the engine then evaluates on the fly and
+    svr_get_option says so -- same results, no error."""
+    from fetalreconstruction_amd import engine as E
+    monkeypatch.setenv("SVR_COEFF_MAX_GB", "0.000001")
+    rec = _engine(tiny)
+    rec.UpdateScaleVector(np.ones(tiny.ns), np.ones(tiny.ns))
+    rec.InitializeEMValues()
+    rec.GaussianReconstruction()
+    rec.SimulateSlices()
+    ref = rec.debug_get(E.BUF_SIMSLICES).copy()
+    rec.set_option("coeff_table", 1)
+    rec.SimulateSlices()
+    assert rec.get_option("coeff_table") == 0 and np.array_equal(rec.debug_get(E.BUF_SIMSLICES), ref)
+
+
 @pytest.mark.parametrize("workload", ["P4", "S8"])
 def test_coefficient_table_at_full_size(workload):
     """BASELINE configs[1] / configs[3] on one GPU: the streamed taps give the on-the-fly kernels' results -- the gather bit for
