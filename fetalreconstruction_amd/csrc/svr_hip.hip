@@ -3068,15 +3068,15 @@ int ensure_psf_list(svr_ctx *ctx) {
 // Returns with ctx->coeff_valid set, or with the mode switched off when the table does not fit the free memory.
 int ensure_coeff(svr_ctx *ctx) {
   if (!ctx->coeff_mode || ctx->coeff_valid) return SVR_OK;
-  int r = ensure_psf_list(ctx);
-  if (r) return r;
-  if (!ctx->n_psf) return SVR_OK;
-  if (ctx->n_psf > ctx->coeff_cap) {
+  // every pixel with s != -1: the Gaussian pass walks them all, the PSF pixels of the SR iterations are a subset
+  const size_t npx = ctx->n_active;
+  if (!npx) return SVR_OK;
+  if (npx > ctx->coeff_cap) {
     free_dev(ctx->d_coeff);
     ctx->coeff_cap = 0;
     size_t fr = 0, tot = 0;
     const size_t per_px = ctx->pvr ? (size_t)PVR_N * (PVR_N / 4) * 16 : (size_t)PSF_SUPPORT * (PSF_SUPPORT / 4) * 16;   // float4 per pixel
-    const size_t bytes = (size_t)ctx->n_psf * per_px * sizeof(float4);
+    const size_t bytes = npx * per_px * sizeof(float4);
     const char *cap_gb = getenv("SVR_COEFF_MAX_GB");     // optional ceiling on the table (GiB): a deployment knob, and how the tests reach the fallback
     const bool over = cap_gb && (double)bytes > atof(cap_gb) * 1073741824.0;
     if (over || hipMemGetInfo(&fr, &tot) != hipSuccess || bytes + (size_t(2) << 30) > fr || hipMalloc(&ctx->d_coeff, bytes) != hipSuccess) {
@@ -3085,12 +3085,12 @@ int ensure_coeff(svr_ctx *ctx) {
       ctx->coeff_mode = 0;                                 // does not fit: evaluate on the fly (svr_get_option tells)
       return SVR_OK;
     }
-    ctx->coeff_cap = ctx->n_psf;
+    ctx->coeff_cap = npx;
   }
   if (!ctx->d_coeff_id) HIPCHK(hipMalloc(&ctx->d_coeff_id, ctx->np * sizeof(uint32_t)));
   PsfArgs a = make_args(ctx);
-  a.list = ctx->d_psf_list;
-  a.n = ctx->n_psf;
+  a.list = ctx->d_active;
+  a.n = (uint32_t)npx;
   if (ctx->pvr) hipLaunchKernelGGL((k_coeff_build<PVR_N, true>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
   else hipLaunchKernelGGL((k_coeff_build<PSF_SUPPORT, false>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
   KCHK("k_coeff_build");
@@ -3232,7 +3232,8 @@ int svr_create(int device, svr_ctx **out) {
                              reinterpret_cast<const void *>(fwd_unit_kernel<false, PVR_N, true>), reinterpret_cast<const void *>(fwd_unit_kernel<true, PVR_N, true>),
                              reinterpret_cast<const void *>(back_wave_kernel<>), reinterpret_cast<const void *>(back_wave_kernel<PVR_N, true>),
                              reinterpret_cast<const void *>(back_wave_kernel<PSF_SUPPORT, false, true>), reinterpret_cast<const void *>(back_wave_kernel<PVR_N, true, true>),
-                             reinterpret_cast<const void *>(fwd_unit_kernel<false, PVR_N, true, true>),
+                             reinterpret_cast<const void *>(fwd_unit_kernel<false, PVR_N, true, true>), reinterpret_cast<const void *>(fwd_unit_kernel<true, PVR_N, true, true>),
+                             reinterpret_cast<const void *>(fwd_unit_kernel<true, PSF_SUPPORT, false, true>),
                              reinterpret_cast<const void *>(back_slot_kernel<8>), reinterpret_cast<const void *>(back_slot_kernel<8, PVR_N, true>)};
     bool ok = true;
     for (const void *f : big_lds) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
@@ -3581,11 +3582,16 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   }
   HIPCHK(hipMemsetAsync(ctx->d_voxcount, 0, ctx->np * sizeof(int), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * ctx->nv * sizeof(float), ctx->stream));
+  const bool tiled = ctx->gauss_mode == 1 && (!ctx->pvr || ctx->pvr_mode == 1);
+  if (tiled) {
+    r = ensure_coeff(ctx);
+    if (r) return r;
+  }
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_active;
   a.n = ctx->n_active;
+  if (tiled && ctx->coeff_mode && ctx->coeff_valid) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
   ScopedTimer t(ctx, SVR_T_GAUSS);
-  const bool tiled = ctx->gauss_mode == 1 && (!ctx->pvr || ctx->pvr_mode == 1);
   if (a.n && tiled) {
     // pass 1 = the unit-based walk of the gather (sume, gate, v_PSF_sums, voxel-count flag), pass 2 = the scatter of the
     // back-projection with {recon|volw} as targets and unit voxel / slice weights
@@ -3613,7 +3619,9 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1;
     if (n1) {
       const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-      if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<true, PVR_N, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      if (ctx->pvr && a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<true, PVR_N, true, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      else if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<true, PVR_N, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      else if (a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<true, PSF_SUPPORT, false, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       else hipLaunchKernelGGL(fwd_unit_kernel<true>, dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
       KCHK("fwd_unit_kernel<GAUSS1>");
     }
@@ -3640,7 +3648,6 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   }
   t.stop();
   ctx->psf_list_valid = false;
-  ctx->coeff_valid = false;                               // v_PSF_sums decides which pixels are PSF pixels
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
 }
@@ -4116,7 +4123,8 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   if (bytes != b) return fail(ctx, SVR_E_ARG, "svr_debug_set: size mismatch");
   HIPCHK(hipMemcpyAsync(p, host_in, b, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) { ctx->psf_list_valid = false; ctx->coeff_valid = false; }
+  if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
+  if (which == SVR_BUF_SLICES) ctx->coeff_valid = false;   // the table covers the pixels with s != -1
   if (which == SVR_BUF_SLICES) return build_list(ctx, false);
   return SVR_OK;
 }
