@@ -250,25 +250,36 @@ def main():
     # reference's CPU path (irtkReconstructionGPU.cc:2305-2673) -- and the scatter and the gather stream them from HBM.
     tab = None
     if not args.no_coeff_table:
-        rec.set_option("coeff_table", 1)
-        rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
-        rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
-        for i in range(args.warmup):
-            drv.sr_iteration(args.warmup + args.steps + i)
-        on = rec.get_option("coeff_table") == 1               # it switches itself off when it does not fit the free memory
-        rec.timer_reset()
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            drv.sr_iteration(2 * args.warmup + args.steps + i)
-        barrier()
-        dt2 = time.perf_counter() - t1
-        tm2 = rec.timers()
-        if multi:
-            dt2 = float(comm.allreduce_max(np.array([dt2]))[0])
-            on = bool(comm.allreduce_min(np.array([1.0 if on else 0.0]))[0] > 0.5)
-        tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 16 * 1024.0}
-        rec.set_option("coeff_table", 0)
+        try:
+            rec.set_option("coeff_table", 1)
+            rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
+            rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
+            for i in range(args.warmup):
+                drv.sr_iteration(args.warmup + args.steps + i)
+            on = rec.get_option("coeff_table") == 1               # it switches itself off when it does not fit the free memory
+            rec.timer_reset()
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                drv.sr_iteration(2 * args.warmup + args.steps + i)
+            barrier()
+            dt2 = time.perf_counter() - t1
+            tm2 = rec.timers()
+            if multi:
+                dt2 = float(comm.allreduce_max(np.array([dt2]))[0])
+                on = bool(comm.allreduce_min(np.array([1.0 if on else 0.0]))[0] > 0.5)
+            tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 16 * 1024.0}
+            rec.set_option("coeff_table", 0)
+        except Exception as ex:                              # the headline line must still be printed
+            if multi:
+                raise                                         # (a rank that carried on alone would leave the others in a barrier)
+            tab = None
+            if rank == 0:
+                print(f"note: the coefficient-table measurement failed: {ex!r}", file=sys.stderr)
+            try:
+                rec.set_option("coeff_table", 0)
+            except Exception:
+                pass
 
     if rank == 0:
         steps = max(args.steps, 1)
