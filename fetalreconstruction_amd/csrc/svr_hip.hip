@@ -2770,7 +2770,7 @@ struct svr_ctx {
   uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_unit_kernel
   uint32_t n_tiles_fwd = 0;
   int fwd_tw = 4, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
-  int fwd_unit_cap = 9000;  // box voxels (float2) of fwd_unit_kernel: 70 KiB + 8 KiB static -> 2 workgroups of 8 waves per CU
+  int fwd_unit_cap = 9300;  // box voxels (float2) of fwd_unit_kernel: 72.7 KiB + up to 6.6 KiB static = 64 LDS granules of 1280 B -> 2 workgroups of 8 waves per CU (9400 would push the GAUSS1 table instantiation to 65)
   int fwd_mode = 1;         // >= 1 = unit-based gather (fwd_unit_kernel), 0 = wave-per-pixel kernel (psf_kernel<MODE_FWD>)
   // The forward tile shape that suits a problem depends on how many voxels a pixel spans: at 2 voxels per pixel (0.5 mm
   // reconstructions of 1 mm pixels) the box of a 4x4 tile no longer fits the LDS and every tap falls back to global loads.  The first forward pass of a problem times the candidate shapes on the real data
@@ -3614,7 +3614,9 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     // back-projection with {recon|volw} as targets and unit voxel / slice weights
     if (!ctx->d_gauss_flag) HIPCHK(hipMalloc(&ctx->d_gauss_flag, ctx->np));
     HIPCHK(hipMemsetAsync(ctx->d_gauss_flag, 0, ctx->np, ctx->stream));
-    const int ftx = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw), fty = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
+    // pass 1 keeps 4-pixel-wide tiles when the gather of the SR iterations chose 6 x 4 (measured: 6 x 4 costs pass 1 1.6 ms on P4)
+    const int gtw = ctx->fwd_tw == 6 ? 4 : ctx->fwd_tw, gth = ctx->fwd_th;
+    const int ftx = (int)((ctx->sx + gtw - 1) / gtw), fty = (int)((ctx->sy + gth - 1) / gth);
     const size_t max_tiles = std::max((size_t)ftx * fty, (size_t)ctx->tiles_x * ctx->tiles_y) * ctx->ns;
     if (max_tiles > ctx->tiles_tmp_cap) {
       free_dev(ctx->d_tiles_tmp);
@@ -3623,13 +3625,13 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     }
     uint32_t n1 = 0, n2 = 0;
     TileArgs ta;
-    ta.tiles_x = ftx; ta.tiles_y = fty; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th; ta.gauss = 1;
+    ta.tiles_x = ftx; ta.tiles_y = fty; ta.tw = gtw; ta.th = gth; ta.gauss = 1;
     ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
     a.flag = nullptr; a.flag_out = ctx->d_gauss_flag;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 16)), dim3(1024), 0, ctx->stream, ctx->d_slices,
                        (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
-                       fty, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_tmp, ctx->d_counter);
+                       fty, gtw, gth, ctx->d_tiles_tmp, ctx->d_counter);
     KCHK("k_build_tiles(gauss1)");
     HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -3737,13 +3739,13 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   const bool tiled = a.n && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1);
   if (tiled && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
     ctx->fwd_tune_pending = false;
-    static const int cand[4][2] = {{4, 4}, {8, 4}, {4, 2}, {2, 2}};   // the first is the default; smaller boxes for finer volumes
+    static const int cand[5][2] = {{4, 4}, {6, 4}, {8, 4}, {4, 2}, {2, 2}};   // the first is the default; smaller boxes for finer volumes
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     float best = 3.0e38f;
     int pick = 0;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 5; ++c) {
       ctx->fwd_tw = cand[c][0]; ctx->fwd_th = cand[c][1]; ctx->psf_list_valid = false;
       r = ensure_psf_list(ctx);
       if (r) return r;
