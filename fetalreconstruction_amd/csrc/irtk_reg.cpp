@@ -22,6 +22,7 @@
 // repeated addition (irtkHomogeneousTransformationIterator.h:96-199), and the six moments are added up.
 #include <float.h>
 #include <stdint.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -41,7 +42,8 @@ class WorkPool {
  public:
   static WorkPool &get() { static WorkPool p; return p; }
   template <class F> void run(int n, int max_threads, F &fn) {
-    if (n < 2 || max_threads < 2 || inside() || workers_.empty() || !owner_.try_lock()) { fn(0, n); return; }
+    // (a forked child inherits the object but not the threads: it works inline)
+    if (n < 2 || max_threads < 2 || inside() || workers_.empty() || getpid() != pid_ || !owner_.try_lock()) { fn(0, n); return; }
     const int nt = std::min<int>({max_threads, (int)workers_.size() + 1, n});
     {
       std::lock_guard<std::mutex> g(m_);
@@ -64,9 +66,11 @@ class WorkPool {
     unsigned hw = std::thread::hardware_concurrency();
     int n = (int)std::min<unsigned>(hw ? hw : 1, 128u);
     if (const char *e = getenv("SVR_HOST_THREADS")) n = std::max(1, atoi(e));
+    pid_ = getpid();
     for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
   }
   ~WorkPool() {
+    if (getpid() != pid_) { for (auto &t : workers_) t.detach(); return; }   // forked child: nothing to join
     { std::lock_guard<std::mutex> g(m_); stop_ = true; }
     cv_.notify_all();
     for (auto &t : workers_) t.join();
@@ -103,6 +107,7 @@ class WorkPool {
   std::atomic<int> next_{0};
   uint64_t gen_ = 0;
   bool stop_ = false;
+  pid_t pid_ = 0;
 };
 template <class F> void parallel_rows(int n, size_t work_per_row, F fn) {
   const int nt = (int)std::min<size_t>(128, (size_t)n * work_per_row / 50000 + 1);
