@@ -43,8 +43,8 @@ class WorkPool {
   static WorkPool &get() { static WorkPool p; return p; }
   template <class F> void run(int n, int max_threads, F &fn) {
     // (a forked child inherits the object but not the threads: it works inline)
-    if (n < 2 || max_threads < 2 || inside() || workers_.empty() || getpid() != pid_ || !owner_.try_lock()) { fn(0, n); return; }
-    const int nt = std::min<int>({max_threads, (int)workers_.size() + 1, n});
+    if (n < 2 || max_threads < 2 || inside() || workers_->empty() || getpid() != pid_ || !owner_.try_lock()) { fn(0, n); return; }
+    const int nt = std::min<int>({max_threads, (int)workers_->size() + 1, n});
     {
       std::lock_guard<std::mutex> g(m_);
       call_ = [](void *f, int a, int b) { (*static_cast<F *>(f))(a, b); };
@@ -59,7 +59,7 @@ class WorkPool {
     g.unlock();
     owner_.unlock();
   }
-  int size() const { return (int)workers_.size() + 1; }
+  int size() const { return (int)workers_->size() + 1; }
 
  private:
   WorkPool() {
@@ -67,13 +67,14 @@ class WorkPool {
     int n = (int)std::min<unsigned>(hw ? hw : 1, 128u);
     if (const char *e = getenv("SVR_HOST_THREADS")) n = std::max(1, atoi(e));
     pid_ = getpid();
-    for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    for (int i = 1; i < n; ++i) workers_->emplace_back([this] { loop(); });
   }
   ~WorkPool() {
-    if (getpid() != pid_) { for (auto &t : workers_) t.detach(); return; }   // forked child: nothing to join
+    if (getpid() != pid_) return;                          // forked child: the thread objects name threads it never had (leaked on purpose)
     { std::lock_guard<std::mutex> g(m_); stop_ = true; }
     cv_.notify_all();
-    for (auto &t : workers_) t.join();
+    for (auto &t : *workers_) t.join();
+    delete workers_;
   }
   static bool &inside() { static thread_local bool in = false; return in; }
   void work() {
@@ -98,7 +99,7 @@ class WorkPool {
       if (--running_ == 0) done_.notify_one();
     }
   }
-  std::vector<std::thread> workers_;
+  std::vector<std::thread> *workers_ = new std::vector<std::thread>();
   std::mutex m_, owner_;
   std::condition_variable cv_, done_;
   void (*call_)(void *, int, int) = nullptr;
