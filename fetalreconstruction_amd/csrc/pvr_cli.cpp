@@ -210,14 +210,13 @@ inline double snap(double v) { const double r = nearbyint(v); return fabs(v - r)
 // PatchBasedVolume<T>::generate2DPatches, patchBasedObject.cuh:176-342
 void generate_2d_patches(const Image &stack, double thickness, const Image &mask, int px, int py, int sx, int sy, Patches &out) {
   const svr_image_attr &a = stack.a;
-  const M4 s_i2w = image_to_world(a), m_w2i = world_to_image(mask.a);
+  const M4 m_w2i = world_to_image(mask.a);
   std::vector<float> patch((size_t)px * py);
   for (int z = 0; z < a.nz; ++z) {
     svr_image_attr sl = a;                               // GetRegion(0, 0, z, x, y, z + 1) + PutPixelSize :202-203
     sl.nz = 1;
     sl.dz = thickness * 2;
-    const double c[3] = {(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, (double)z};
-    for (int k = 0; k < 3; ++k) sl.origin[k] = s_i2w.m[4 * k] * c[0] + s_i2w.m[4 * k + 1] * c[1] + s_i2w.m[4 * k + 2] * c[2] + s_i2w.m[4 * k + 3];
+    region_origin(a, 0, 0, z, sl);
     const M4 sl_i2w = image_to_world(sl), sl_w2i = world_to_image(sl);
     svr_image_attr p0 = sl;
     p0.nx = px; p0.ny = py;

@@ -193,14 +193,24 @@ std::vector<std::string> list_directory(const std::string &dir) {
   return out;
 }
 
+// The origin irtkGenericImage::GetRegion gives the sub-image starting at voxel (i1, j1, k1) (irtkGenericImage.cc:570-611):
+// the world position of that voxel minus the position of voxel (0, 0, 0) of the region grid with its origin at zero.  Kept
+// literal, so that coordinates landing on x.5 after a later WorldToImage round the way the reference's do.
+inline void region_origin(const svr_image_attr &src, int i1, int j1, int k1, svr_image_attr &region) {
+  svr_image_attr z = region;
+  z.origin[0] = z.origin[1] = z.origin[2] = 0;
+  const M4 a = image_to_world(src), b = image_to_world(z);
+  for (int k = 0; k < 3; ++k)
+    region.origin[k] = (a.m[4 * k] * (double)i1 + a.m[4 * k + 1] * (double)j1 + a.m[4 * k + 2] * (double)k1 + a.m[4 * k + 3]) -
+                       (b.m[4 * k] * 0.0 + b.m[4 * k + 1] * 0.0 + b.m[4 * k + 2] * 0.0 + b.m[4 * k + 3]);
+}
+
 // irtkGenericImage::GetRegion(i1, j1, k1, i2, j2, k2)
 Image get_region(const Image &im, int x1, int y1, int z1, int x2, int y2, int z2) {
   Image o;
   o.a = im.a;
   o.a.nx = x2 - x1; o.a.ny = y2 - y1; o.a.nz = z2 - z1;
-  const M4 i2w = image_to_world(im.a);
-  const double c[3] = {x1 + (o.a.nx - 1) / 2.0, y1 + (o.a.ny - 1) / 2.0, z1 + (o.a.nz - 1) / 2.0};
-  for (int k = 0; k < 3; ++k) o.a.origin[k] = i2w.m[4 * k] * c[0] + i2w.m[4 * k + 1] * c[1] + i2w.m[4 * k + 2] * c[2] + i2w.m[4 * k + 3];
+  region_origin(im.a, x1, y1, z1, o.a);
   o.d.resize((size_t)o.a.nx * o.a.ny * o.a.nz);
   for (int z = z1; z < z2; ++z)
     for (int y = y1; y < y2; ++y)

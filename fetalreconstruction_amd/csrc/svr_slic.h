@@ -170,16 +170,15 @@ void slic_superpixel_patches(const Image &stack, double half_thickness, const Im
   const float ratio = (float)extend_percent / 100.0f;
   const int px = std::min(64, a.nx), py = std::min(64, a.ny);
   out.px = px; out.py = py;
-  const M4 s_i2w = image_to_world(a), m_w2i = world_to_image(mask.a);
+  const M4 m_w2i = world_to_image(mask.a);
   std::vector<float> pm((size_t)px * py), tmp((size_t)px * py), val((size_t)px * py);
   for (int z = 0; z < a.nz; ++z) {
     const float *lab = &labels[(size_t)z * a.nx * a.ny];
     svr_image_attr sl = a;
     sl.nz = 1;
     sl.dz = half_thickness * 2;
-    const double c[3] = {(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, (double)z};
-    for (int k = 0; k < 3; ++k) sl.origin[k] = s_i2w.m[4 * k] * c[0] + s_i2w.m[4 * k + 1] * c[1] + s_i2w.m[4 * k + 2] * c[2] + s_i2w.m[4 * k + 3];
-    const M4 sl_i2w = image_to_world(sl), sl_w2i = world_to_image(sl);
+    region_origin(a, 0, 0, z, sl);
+    const M4 sl_w2i = world_to_image(sl);
     float lmin = FLT_MAX, lmax = -FLT_MAX;
     for (int i = 0; i < a.nx * a.ny; ++i) { lmin = std::min(lmin, lab[i]); lmax = std::max(lmax, lab[i]); }
     for (int idx = (int)lmin; idx < (int)lmax; ++idx) {      // the largest label is never cut out
@@ -199,8 +198,7 @@ void slic_superpixel_patches(const Image &stack, double half_thickness, const Im
       else { y_min -= ey; y_max = y_min + py; }
       svr_image_attr pa = sl;
       pa.nx = px; pa.ny = py;
-      const double pc[2] = {x_min + (px - 1) / 2.0, y_min + (py - 1) / 2.0};
-      for (int k = 0; k < 3; ++k) pa.origin[k] = sl_i2w.m[4 * k] * pc[0] + sl_i2w.m[4 * k + 1] * pc[1] + sl_i2w.m[4 * k + 3];
+      region_origin(a, x_min, y_min, z, pa);
       const M4 p_i2w = image_to_world(pa);
       const M4 to_slice = mul(sl_w2i, p_i2w), to_mask = mul(m_w2i, p_i2w);
       // the two-matrix form (ImageToWorld then WorldToImage) of the reference is kept for the rounded coordinates below

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
+import copy
+
 import numpy as np
 
 
@@ -66,6 +68,17 @@ def image_to_world(a: ImageAttributes) -> np.ndarray:
     t2 = np.eye(4)
     t2[:3, 3] = a.origin
     return mat_mul(t2, mat_mul(rot, mat_mul(sc, t1)))
+
+
+def region_origin(a: ImageAttributes, i1, j1, k1, region: ImageAttributes) -> np.ndarray:
+    """Origin irtkGenericImage::GetRegion gives the sub-image starting at voxel (i1, j1, k1) (irtkGenericImage.cc:570-611):
+    the world position of that voxel minus the position of voxel (0, 0, 0) of the region grid with its origin at zero.
+    The arithmetic is kept literal: coordinates that land on x.5 after the later WorldToImage round the way the reference's do."""
+    z = copy.copy(region)
+    z.origin = np.zeros(3)
+    p1 = apply_points(image_to_world(a), np.array([float(i1), float(j1), float(k1), 1.0]))
+    p2 = apply_points(image_to_world(z), np.array([0.0, 0.0, 0.0, 1.0]))
+    return (p1 - p2)[:3]
 
 
 def world_to_image(a: ImageAttributes) -> np.ndarray:

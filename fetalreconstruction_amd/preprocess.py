@@ -128,9 +128,7 @@ def get_region(img: Image, x1, y1, z1, x2, y2, z2):
     """irtkGenericImage::GetRegion(i1, j1, k1, i2, j2, k2): the sub-image keeps voxel positions."""
     a = copy.copy(img.attr)
     a.nx, a.ny, a.nz = x2 - x1, y2 - y1, z2 - z1
-    c_old = geo.apply_points(geo.image_to_world(img.attr), np.array([x1 + (a.nx - 1) / 2.0, y1 + (a.ny - 1) / 2.0,
-                                                     z1 + (a.nz - 1) / 2.0, 1.0]))
-    a.origin = c_old[:3]
+    a.origin = geo.region_origin(img.attr, x1, y1, z1, a)
     return Image(img.data[z1:z2, y1:y2, x1:x2].copy(), a)
 
 

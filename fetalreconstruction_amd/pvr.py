@@ -57,9 +57,8 @@ def generate2DPatches(stack: Stack, mask: np.ndarray, mask_attr: geo.ImageAttrib
     out, i2ws, w2is, origins = [], [], [], []
     total = 0
     for z in range(a.nz):
-        centre = geo.apply_points(s_i2w, np.array([(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, float(z), 1.0]))
-        sl_attr = geo.ImageAttributes(a.nx, a.ny, 1, a.dx, a.dy, stack.thickness * 2, a.xaxis, a.yaxis, a.zaxis,
-                                      origin=centre[:3])                       # GetRegion + PutPixelSize :204-205
+        sl_attr = geo.ImageAttributes(a.nx, a.ny, 1, a.dx, a.dy, stack.thickness * 2, a.xaxis, a.yaxis, a.zaxis)
+        sl_attr.origin = geo.region_origin(a, 0, 0, z, sl_attr)                # GetRegion + PutPixelSize :204-205
         sl_i2w, sl_w2i = geo.image_to_world(sl_attr), geo.world_to_image(sl_attr)
         p0 = geo.ImageAttributes(px, py, 1, a.dx, a.dy, stack.thickness * 2, a.xaxis, a.yaxis, a.zaxis)
         p0_first = geo.apply_points(geo.image_to_world(p0), np.array([0.0, 0.0, 0.0, 1.0]))

@@ -204,7 +204,7 @@ def generate2DSuperpixelPatches(stack, mask, mask_attr, spx_size, extend_percent
         sl_attr = copy.copy(a)
         sl_attr.nz = 1
         sl_attr.dz = stack.thickness * 2
-        sl_attr.origin = geo.apply_points(geo.image_to_world(a), np.array([(a.nx - 1) / 2.0, (a.ny - 1) / 2.0, float(z), 1.0]))[:3]
+        sl_attr.origin = geo.region_origin(a, 0, 0, z, sl_attr)
         sl_i2w, sl_w2i = geo.image_to_world(sl_attr), geo.world_to_image(sl_attr)
         for idx in range(int(lab.min()), int(lab.max())):          # `idxLbl < int(maxLbl)`: the last label is never cut out
             ys, xs = np.nonzero(lab.astype(np.int64) == idx)
@@ -233,7 +233,7 @@ def generate2DSuperpixelPatches(stack, mask, mask_attr, spx_size, extend_percent
             # patch = GetRegion(xMin, yMin, z, xMax, yMax, z + 1) with the slice's pixel size
             pa = copy.copy(sl_attr)
             pa.nx, pa.ny = px, py
-            pa.origin = geo.apply_points(sl_i2w, np.array([x_min + (px - 1) / 2.0, y_min + (py - 1) / 2.0, 0.0, 1.0]))[:3]
+            pa.origin = geo.region_origin(a, x_min, y_min, z, pa)
             p_i2w = geo.image_to_world(pa)
             w = geo.apply_points(p_i2w, pix)
             q = geo.apply_points(sl_w2i, w)

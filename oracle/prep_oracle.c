@@ -1,10 +1,14 @@
 /*
- * prep_oracle.c -- CPU restatement of two host functions that feed the hot path:
+ * prep_oracle.c -- CPU restatement of the host functions that feed the hot path:
  *
  *   orc_match_stack_intensities   irtkReconstruction::MatchStackIntensitiesWithMasking
  *                                 (source/reconstructionGPU2/irtkReconstructionGPU.cc:1375-1493)
  *   orc_generate_2d_patches       PatchBasedObject<T>::generate2DPatches
  *                                 (source/reconstructionGPU2/include/patchBasedObject.cuh:174-342)
+ *   orc_segment_slic              runStackSLIC<T>::segmentSLIC: the SLICO superpixel labels of a stack, slice by slice
+ *                                 (source/reconstructionGPU2/runStackSLIC.cpp:55-151, 291-537, 665-840)
+ *   orc_generate_2d_superpixel_patches   PatchBasedObject<T>::generate2DSuperpixelPatches + dilatePatch
+ *                                 (patchBasedObject.cuh:347-367, 433-802)
  *
  * TEST INFRASTRUCTURE ONLY (like svr_oracle.c): nothing in fetalreconstruction_amd/ or include/ may include, link or call
  * this file.  It exists so that the C++ command lines (csrc/svr_prep.h, csrc/pvr_cli.cpp) and their Python mirrors are checked
@@ -217,6 +221,303 @@ int orc_generate_2d_patches(const orc_attr *attr, const float *stack, double thi
         }
       }
   }
+  *n_out = n;
+  return 0;
+}
+
+/* =======================================================================================================================
+ * Superpixel patches (the second generator):
+ *   orc_segment_slic                      runStackSLIC<T>::segmentSLIC with rgbtolab, getLABXYSeeds, PerformSuperpixelSLICO,
+ *                                         EnforceSuperpixelConnectivity   (source/reconstructionGPU2/runStackSLIC.cpp:55-151,
+ *                                         291-537, 665-840; SLICO is Achanta et al.'s zero-parameter SLIC)
+ *   orc_generate_2d_superpixel_patches    PatchBasedObject<T>::generate2DSuperpixelPatches + dilatePatch
+ *                                         (source/reconstructionGPU2/include/patchBasedObject.cuh:347-367, 433-802)
+ * T = float (the command line instantiates PatchBasedObject<float>).  What the reference leaves undefined is pinned the way
+ * both products pin it: klabels of pixels no seed window reaches are -1 and take no part in the cluster statistics
+ * (uninitialised memory there, :305, :372-373); the connectivity pass keeps its work lists as large as the image (10 * SUPSZ
+ * entries there, written past for larger segments, :461-462); a stack whose minimum equals its maximum gets grey value 0
+ * (0/0 there, :738-740).
+ * ======================================================================================================================= */
+static void slic_lab(const int *grey, int sz, double *lv, double *av, double *bv) {          /* rgbtolab :55-110, r = g = b */
+  const double epsilon = 0.008856, kappa = 903.3, Xr = 0.950456, Yr = 1.0, Zr = 1.088754;
+  for (int i = 0; i < sz; i++) {
+    const double C = grey[i] / 255.0;
+    const double c = C <= 0.04045 ? C / 12.92 : pow((C + 0.055) / 1.055, 2.4);
+    const double X = c * 0.4124564 + c * 0.3575761 + c * 0.1804375;
+    const double Y = c * 0.2126729 + c * 0.7151522 + c * 0.0721750;
+    const double Z = c * 0.0193339 + c * 0.1191920 + c * 0.9503041;
+    const double xr = X / Xr, yr = Y / Yr, zr = Z / Zr;
+    const double fx = xr > epsilon ? pow(xr, 1.0 / 3.0) : (kappa * xr + 16.0) / 116.0;
+    const double fy = yr > epsilon ? pow(yr, 1.0 / 3.0) : (kappa * yr + 16.0) / 116.0;
+    const double fz = zr > epsilon ? pow(zr, 1.0 / 3.0) : (kappa * zr + 16.0) / 116.0;
+    lv[i] = 116.0 * fy - 16.0; av[i] = 500.0 * (fx - fy); bv[i] = 200.0 * (fy - fz);
+  }
+}
+
+static int slic_grid_seeds(int STEP, int width, int height, int *seed) {                       /* getLABXYSeeds :111-151 */
+  int xstrips = (int)(0.5 + (double)width / (double)STEP), ystrips = (int)(0.5 + (double)height / (double)STEP);
+  int xerr = width - STEP * xstrips;
+  if (xerr < 0) { xstrips--; xerr = width - STEP * xstrips; }
+  int yerr = height - STEP * ystrips;
+  if (yerr < 0) { ystrips--; yerr = height - STEP * ystrips; }
+  const double xeps = (double)xerr / (double)xstrips, yeps = (double)yerr / (double)ystrips;
+  const int off = STEP / 2;
+  int n = 0;
+  for (int y = 0; y < ystrips; y++) {
+    const int ye = (int)(y * yeps);
+    for (int x = 0; x < xstrips; x++) {
+      const int xe = (int)(x * xeps);
+      seed[n++] = (y * STEP + off + ye) * width + (x * STEP + off + xe);
+    }
+  }
+  return n;
+}
+
+static void slic_slico(const double *lv, const double *av, const double *bv, const int *seed, int numk, int width, int height,
+                       int STEP, int *klabels) {                                               /* PerformSuperpixelSLICO :291-437 */
+  const int sz = width * height;
+  double *kx = malloc(sizeof(double) * numk), *ky = malloc(sizeof(double) * numk), *kl = malloc(sizeof(double) * numk),
+         *ka = malloc(sizeof(double) * numk), *kb = malloc(sizeof(double) * numk), *maxlab = malloc(sizeof(double) * numk),
+         *sum = calloc((size_t)6 * numk, sizeof(double)), *distvec = malloc(sizeof(double) * sz), *distlab = malloc(sizeof(double) * sz);
+  for (int k = 0; k < numk; k++) {
+    kx[k] = seed[k] % width; ky[k] = seed[k] / width;                                          /* :760-767 */
+    kl[k] = lv[seed[k]]; ka[k] = av[seed[k]]; kb[k] = bv[seed[k]];
+    maxlab[k] = 10.0 * 10.0;
+  }
+  for (int i = 0; i < sz; i++) { distlab[i] = 1.7976931348623157e308; klabels[i] = -1; }
+  const double invxywt = 1.0 / (STEP * STEP);
+  for (int itr = 0; itr < 10; itr++) {
+    for (int i = 0; i < sz; i++) distvec[i] = 1.7976931348623157e308;
+    for (int n = 0; n < numk; n++) {
+      int x1 = kx[n] - STEP, y1 = ky[n] - STEP, x2 = kx[n] + STEP, y2 = ky[n] + STEP;          /* double -> int: truncation */
+      if (x1 < 0) x1 = 0;
+      if (y1 < 0) y1 = 0;
+      if (x2 > width) x2 = width;
+      if (y2 > height) y2 = height;
+      for (int y = y1; y < y2; y++)
+        for (int x = x1; x < x2; x++) {
+          const int i = y * width + x;
+          const double l = lv[i], a = av[i], b = bv[i];
+          distlab[i] = (l - kl[n]) * (l - kl[n]) + (a - ka[n]) * (a - ka[n]) + (b - kb[n]) * (b - kb[n]);
+          const double distxy = (x - kx[n]) * (x - kx[n]) + (y - ky[n]) * (y - ky[n]);
+          const double dist = distlab[i] / maxlab[n] + distxy * invxywt;
+          if (dist < distvec[i]) { distvec[i] = dist; klabels[i] = n; }
+        }
+    }
+    if (itr == 0) for (int n = 0; n < numk; n++) maxlab[n] = 1.0;
+    for (int i = 0; i < sz; i++)
+      if (klabels[i] >= 0 && maxlab[klabels[i]] < distlab[i]) maxlab[klabels[i]] = distlab[i];
+    memset(sum, 0, sizeof(double) * 6 * numk);
+    int ind = 0;
+    for (int r = 0; r < height; r++)
+      for (int c = 0; c < width; c++, ind++)
+        if (klabels[ind] >= 0) {
+          double *s = sum + 6 * klabels[ind];
+          s[0] += lv[ind]; s[1] += av[ind]; s[2] += bv[ind]; s[3] += c; s[4] += r; s[5] += 1.0;
+        }
+    for (int k = 0; k < numk; k++) {
+      double *s = sum + 6 * k;
+      if (s[5] <= 0) s[5] = 1;
+      const double inv = 1.0 / s[5];
+      kl[k] = s[0] * inv; ka[k] = s[1] * inv; kb[k] = s[2] * inv; kx[k] = s[3] * inv; ky[k] = s[4] * inv;
+    }
+  }
+  free(kx); free(ky); free(kl); free(ka); free(kb); free(maxlab); free(sum); free(distvec); free(distlab);
+}
+
+static int slic_connectivity(const int *labels, int width, int height, int numSuperpixels, int *nlabels) {   /* :440-537 */
+  const int dx4[4] = {-1, 0, 1, 0}, dy4[4] = {0, -1, 0, 1};
+  const int sz = width * height, SUPSZ = sz / numSuperpixels;
+  int *xvec = malloc(sizeof(int) * sz), *yvec = malloc(sizeof(int) * sz);
+  for (int i = 0; i < sz; i++) nlabels[i] = -1;
+  int oindex = 0, adjlabel = 0, label = 0;
+  for (int j = 0; j < height; j++)
+    for (int k = 0; k < width; k++, oindex++) {
+      if (nlabels[oindex] >= 0) continue;
+      nlabels[oindex] = label;
+      xvec[0] = k; yvec[0] = j;
+      for (int n = 0; n < 4; n++) {
+        const int x = xvec[0] + dx4[n], y = yvec[0] + dy4[n];
+        if (x >= 0 && x < width && y >= 0 && y < height && nlabels[y * width + x] >= 0) adjlabel = nlabels[y * width + x];
+      }
+      int count = 1;
+      for (int c = 0; c < count; c++)
+        for (int n = 0; n < 4; n++) {
+          const int x = xvec[c] + dx4[n], y = yvec[c] + dy4[n];
+          if (x >= 0 && x < width && y >= 0 && y < height) {
+            const int ni = y * width + x;
+            if (nlabels[ni] < 0 && labels[oindex] == labels[ni]) { xvec[count] = x; yvec[count] = y; nlabels[ni] = label; count++; }
+          }
+        }
+      if (count <= SUPSZ >> 2) {
+        for (int c = 0; c < count; c++) nlabels[yvec[c] * width + xvec[c]] = adjlabel;
+        label--;
+      }
+      label++;
+    }
+  free(xvec); free(yvec);
+  return label;
+}
+
+/* stack [nz][ny][nx] -> labels [nz][ny][nx] (the label image stack_spx as float, :811-819).  The slice goes into SLIC's buffer
+ * with x outermost (:731-749), so SLIC sees a ny-wide, nx-high image: the transposed slice. */
+int orc_segment_slic(const float *stack, int nx, int ny, int nz, int spx0, int spx1, float *labels_out) {
+  const int width = ny, height = nx, sz = width * height;                                      /* :704-706 */
+  float vmin = stack[0], vmax = stack[0];
+  for (size_t i = 0; i < (size_t)sz * nz; i++) { if (stack[i] < vmin) vmin = stack[i]; if (stack[i] > vmax) vmax = stack[i]; }
+  const int numSuperpixels = (int)(sz / (spx0 * spx1));                                        /* :710 */
+  if (numSuperpixels < 1) return 1;
+  int *grey = malloc(sizeof(int) * sz), *kl = malloc(sizeof(int) * sz), *cl = malloc(sizeof(int) * sz), *seed = malloc(sizeof(int) * sz);
+  double *lv = malloc(sizeof(double) * sz), *av = malloc(sizeof(double) * sz), *bv = malloc(sizeof(double) * sz);
+  for (int z = 0; z < nz; z++) {
+    const float *sl = stack + (size_t)z * nx * ny;
+    int p = 0;
+    for (int x = 0; x < nx; ++x)
+      for (int y = 0; y < ny; ++y, ++p)                                                        /* `(int) 255 * (v - min) / (max - min)`: float, truncated */
+        grey[p] = vmax > vmin ? (int)(((float)255 * (sl[(size_t)y * nx + x] - vmin)) / (vmax - vmin)) : 0;
+    slic_lab(grey, sz, lv, av, bv);
+    const int step = (int)(sqrt((double)sz / (double)numSuperpixels) + 0.5);                   /* :755 */
+    const int numseeds = slic_grid_seeds(step, width, height, seed);
+    slic_slico(lv, av, bv, seed, numseeds, width, height, step, kl);
+    slic_connectivity(kl, width, height, numSuperpixels, cl);
+    p = 0;
+    for (int x = 0; x < nx; ++x)
+      for (int y = 0; y < ny; ++y, ++p) labels_out[((size_t)z * ny + y) * nx + x] = (float)cl[p];
+  }
+  free(grey); free(kl); free(cl); free(seed); free(lv); free(av); free(bv);
+  return 0;
+}
+
+/* attributes of GetRegion(i1, j1, k1, i2, j2, k2) of an image (irtkGenericImage.cc:570-611) */
+static void region_attr(const orc_attr *src, int i1, int j1, int k1, int i2, int j2, int k2, orc_attr *out) {
+  double s_i2w[16], t[16];
+  *out = *src;
+  out->nx = i2 - i1; out->ny = j2 - j1; out->nz = k2 - k1;
+  out->origin[0] = out->origin[1] = out->origin[2] = 0;
+  double x1 = i1, y1 = j1, z1 = k1, x2 = 0, y2 = 0, z2 = 0;
+  image_to_world(src, s_i2w);
+  apply(s_i2w, &x1, &y1, &z1);
+  image_to_world(out, t);
+  apply(t, &x2, &y2, &z2);
+  out->origin[0] = x1 - x2; out->origin[1] = y1 - y2; out->origin[2] = z1 - z2;
+}
+
+static void dilate_once(float *p, int nx, int ny) {                                            /* dilatePatch :347-367 */
+  for (int j = 0; j < ny; j++)
+    for (int i = 0; i < nx; i++)
+      if (p[j * nx + i] == 1) {
+        if (i > 0 && p[j * nx + i - 1] == 0) p[j * nx + i - 1] = 2;
+        if (j > 0 && p[(j - 1) * nx + i] == 0) p[(j - 1) * nx + i] = 2;
+        if (i + 1 < nx && p[j * nx + i + 1] == 0) p[j * nx + i + 1] = 2;
+        if (j + 1 < ny && p[(j + 1) * nx + i] == 0) p[(j + 1) * nx + i] = 2;
+      }
+  for (int k = 0; k < nx * ny; k++) if (p[k] == 2) p[k] = 1;
+}
+
+/* stack / labels [nz][ny][nx] of `attr` (labels from orc_segment_slic); outputs for up to `cap` patches: data [n][py][px]
+ * (-1 outside the dilated superpixel), spxmask [n][4096] ('1' / 0, 64 wide), i2w / w2i [n][16], origins [n][3].
+ * pxy_out = {px, py} (64 x 64 clamped to the slice, :455-482).  Returns 0, or 1 when more than `cap` patches are kept. */
+int orc_generate_2d_superpixel_patches(const orc_attr *attr, const float *stack, const float *labels, double thickness,
+                                       const orc_attr *mask_attr, const float *mask, int spx_x, int spx_y, int extend_percent, int cap,
+                                       float *data, unsigned char *spxmask, float *i2w, float *w2i, double *origins, int *n_out,
+                                       long *total_pixels, int *pxy_out) {
+  const float dilateRatio = (float)extend_percent / 100.f;                                     /* :449 */
+  int pbx = 64, pby = 64;
+  if (pbx > attr->nx) pbx = attr->nx;
+  if (pby > attr->ny) pby = attr->ny;
+  pxy_out[0] = pbx; pxy_out[1] = pby;
+  double m_w2i[16];
+  world_to_image(mask_attr, m_w2i);
+  float *patch = malloc(sizeof(float) * (size_t)pbx * pby);
+  int n = 0;
+  for (int z = 0; z < attr->nz; z++) {
+    orc_attr sa;
+    region_attr(attr, 0, 0, z, attr->nx, attr->ny, z + 1, &sa);                                /* slice / spx_slice :495-499 */
+    sa.dz = thickness * 2;
+    double sl_w2i[16];
+    world_to_image(&sa, sl_w2i);
+    const float *slice = stack + (size_t)z * attr->nx * attr->ny, *lab = labels + (size_t)z * attr->nx * attr->ny;
+    float minL = lab[0], maxL = lab[0];
+    for (int k = 0; k < attr->nx * attr->ny; k++) { if (lab[k] < minL) minL = lab[k]; if (lab[k] > maxL) maxL = lab[k]; }
+    for (int idx = (int)minL; idx < (int)maxL; idx++) {                                        /* :509: the largest label is never cut out */
+      int xMin = 2147483647, yMin = 2147483647, xMax = -2147483647 - 1, yMax = -2147483647 - 1, exists = 0;
+      for (int yi = 0; yi < attr->ny; yi++)
+        for (int xi = 0; xi < attr->nx; xi++)
+          if ((int)lab[yi * attr->nx + xi] == idx) {
+            if (xi < xMin) xMin = xi;
+            if (xi > xMax) xMax = xi;
+            if (yi < yMin) yMin = yi;
+            if (yi > yMax) yMax = yi;
+            exists = 1;
+          }
+      if (!exists) continue;
+      const unsigned sizex = (unsigned)(xMax - xMin), sizey = (unsigned)(yMax - yMin);
+      const int diter = (int)(sizex > sizey ? dilateRatio * sizex : dilateRatio * sizey);      /* :541-546, float product */
+      const unsigned ex = (unsigned)round(((float)pbx - (float)sizex) / 2.), ey = (unsigned)round(((float)pby - (float)sizey) / 2.);
+      if ((int)(xMin - ex) < 0) { xMax = pbx; xMin = 0; }                                      /* :552-579 */
+      else if ((int)(xMax + ex) > attr->nx) { xMax = attr->nx; xMin = xMax - pbx; }
+      else { xMin -= ex; xMax = xMin + pbx; }
+      if ((int)(yMin - ey) < 0) { yMax = pby; yMin = 0; }
+      else if ((int)(yMax + ey) > attr->ny) { yMax = attr->ny; yMin = yMax - pby; }
+      else { yMin -= ey; yMax = yMin + pby; }
+      orc_attr pa;
+      region_attr(attr, xMin, yMin, z, xMax, yMax, z + 1, &pa);                                /* :602-603 */
+      pa.dz = thickness * 2;
+      double p_i2w[16], p_w2i[16];
+      image_to_world(&pa, p_i2w);
+      world_to_image(&pa, p_w2i);
+      int setCount = 0;
+      for (int j = 0; j < pby; j++)
+        for (int i = 0; i < pbx; i++) {                                                        /* :621-664 */
+          double xx = i, yy = j, zz = 0;
+          apply(p_i2w, &xx, &yy, &zz);
+          double xx1 = xx, yy1 = yy, zz1 = zz;
+          apply(sl_w2i, &xx, &yy, &zz);
+          apply(m_w2i, &xx1, &yy1, &zz1);
+          xx = irtk_round(xx); yy = irtk_round(yy);
+          xx1 = irtk_round(xx1); yy1 = irtk_round(yy1); zz1 = irtk_round(zz1);
+          float v = 0;
+          if (xx >= 0 && yy >= 0 && xx < sa.nx && yy < sa.ny)
+            if (xx1 >= 0 && yy1 >= 0 && zz1 >= 0 && xx1 < mask_attr->nx && yy1 < mask_attr->ny && zz1 < mask_attr->nz)
+              if (mask[((size_t)(int)zz1 * mask_attr->ny + (size_t)(int)yy1) * mask_attr->nx + (size_t)(int)xx1] > 0)
+                v = lab[(int)yy * attr->nx + (int)xx] == idx ? 1 : 0;
+          patch[j * pbx + i] = v;
+          if (v > 0) setCount++;
+        }
+      if (setCount < 2) continue;                                                              /* :667-668 */
+      if (setCount < 1.0f / 4.0f * spx_y * spx_x) continue;
+      for (int it = 0; it < diter; it++) dilate_once(patch, pbx, pby);
+      for (int j = 0; j < pby; j++)
+        for (int i = 0; i < pbx; i++) {                                                        /* :684-726 */
+          if (patch[j * pbx + i] == 0) { patch[j * pbx + i] = -1; continue; }
+          double xx = i, yy = j, zz = 0;
+          apply(p_i2w, &xx, &yy, &zz);
+          double xx1 = xx, yy1 = yy, zz1 = zz;
+          apply(sl_w2i, &xx, &yy, &zz);
+          apply(m_w2i, &xx1, &yy1, &zz1);
+          xx = irtk_round(xx); yy = irtk_round(yy);
+          xx1 = irtk_round(xx1); yy1 = irtk_round(yy1); zz1 = irtk_round(zz1);
+          if (xx >= 0 && yy >= 0 && xx < sa.nx && yy < sa.ny)
+            if (xx1 >= 0 && yy1 >= 0 && zz1 >= 0 && xx1 < mask_attr->nx && yy1 < mask_attr->ny && zz1 < mask_attr->nz) {
+              if (mask[((size_t)(int)zz1 * mask_attr->ny + (size_t)(int)yy1) * mask_attr->nx + (size_t)(int)xx1] > 0)
+                patch[j * pbx + i] = patch[j * pbx + i] == 1 ? slice[(int)yy * attr->nx + (int)xx] : -1;
+              else
+                patch[j * pbx + i] = -1;
+            }
+        }
+      if (n >= cap) { free(patch); return 1; }
+      unsigned char *mk = spxmask + (size_t)n * 4096;
+      memset(mk, 0, 4096);
+      for (int j = 0; j < pby; j++)
+        for (int i = 0; i < pbx; i++)
+          if (patch[j * pbx + i] != -1) { mk[i + 64 * j] = '1'; *total_pixels += 1; }          /* :728-737 */
+      memcpy(data + (size_t)n * pbx * pby, patch, sizeof(float) * (size_t)pbx * pby);
+      for (int q = 0; q < 16; ++q) { i2w[16 * (size_t)n + q] = (float)p_i2w[q]; w2i[16 * (size_t)n + q] = (float)p_w2i[q]; }
+      origins[3 * (size_t)n] = pa.origin[0]; origins[3 * (size_t)n + 1] = pa.origin[1]; origins[3 * (size_t)n + 2] = pa.origin[2];
+      ++n;
+    }
+  }
+  free(patch);
   *n_out = n;
   return 0;
 }

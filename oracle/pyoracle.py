@@ -539,3 +539,40 @@ def generate_2d_patches(stack, attr, thickness, mask, mask_attr, pbbsize, stride
         raise ValueError("more patches than the capacity")
     k = n.value
     return data[:k].copy(), i2w[:k].copy(), w2i[:k].copy(), int(total.value), org[:k].copy()
+
+
+def segment_slic(stack, spx_size):
+    """orc_segment_slic (runStackSLIC<T>::segmentSLIC, runStackSLIC.cpp:665-840): stack [nz][ny][nx] -> labels float32 [nz][ny][nx]"""
+    st = np.ascontiguousarray(stack, np.float32)
+    nz, ny, nx = st.shape
+    out = np.zeros(st.shape, np.float32)
+    lib().orc_segment_slic.restype = C.c_int
+    if lib().orc_segment_slic(_p(st), nx, ny, nz, int(spx_size[0]), int(spx_size[1]), _p(out)):
+        raise ValueError("superpixels larger than the slice")
+    return out
+
+
+def generate_2d_superpixel_patches(stack, attr, labels, thickness, mask, mask_attr, spx_size, extend_percent, cap=None):
+    """orc_generate_2d_superpixel_patches (generate2DSuperpixelPatches, patchBasedObject.cuh:433-802) -> (patches float32 [n][py][px],
+    spxMask uint8 [n][4096], i2w [n][16], w2i [n][16], origins [n][3], total_pixels)"""
+    st = np.ascontiguousarray(stack, np.float32)
+    lb = np.ascontiguousarray(labels, np.float32)
+    mk = np.ascontiguousarray(mask, np.float32)
+    px, py = min(64, int(attr.nx)), min(64, int(attr.ny))
+    if cap is None:
+        cap = int(attr.nz) * (int(lb.max()) + 2)
+    data = np.zeros((cap, py, px), np.float32)
+    sm = np.zeros((cap, 4096), np.uint8)
+    i2w, w2i = np.zeros((cap, 16), np.float32), np.zeros((cap, 16), np.float32)
+    org = np.zeros((cap, 3), np.float64)
+    n, total = C.c_int(0), C.c_long(0)
+    pxy = (C.c_int * 2)()
+    lib().orc_generate_2d_superpixel_patches.restype = C.c_int
+    rc = lib().orc_generate_2d_superpixel_patches(C.byref(Attr.of(attr)), _p(st), _p(lb), C.c_double(thickness), C.byref(Attr.of(mask_attr)), _p(mk),
+                                                  int(spx_size[0]), int(spx_size[1]), int(extend_percent), int(cap), _p(data), _p(sm), _p(i2w),
+                                                  _p(w2i), _p(org), C.byref(n), C.byref(total), pxy)
+    if rc:
+        raise ValueError("more patches than the capacity")
+    assert (pxy[0], pxy[1]) == (px, py)
+    k = n.value
+    return data[:k].copy(), sm[:k].copy(), i2w[:k].copy(), w2i[:k].copy(), org[:k].copy(), int(total.value)

@@ -4,6 +4,8 @@
   MatchStackIntensitiesWithMasking (RG.cc:1375-1493): preprocess.py (what cli.py runs) and, through the command line's problem
       dump, csrc/svr_prep.h,
   generate2DPatches (patchBasedObject.cuh:174-342): pvr.py and csrc/pvr_cli.cpp,
+  segmentSLIC (runStackSLIC.cpp:55-840) + generate2DSuperpixelPatches (patchBasedObject.cuh:347-367, 433-802): slic.py and
+      csrc/svr_slic.h,
 
 on axis-aligned stacks and on the reference's bundled mask geometry (oblique, 300-400 mm off the origin)."""
 import subprocess
@@ -125,3 +127,72 @@ def test_cpp_patches_against_the_oracle(tmp_path, oracle_mod):
         assert np.allclose(oi, i2w[at:at + len(op)], atol=1e-5)
         at += len(op)
     assert at == ns
+
+
+@pytest.mark.parametrize("case", ["aligned", "oblique"])
+def test_slico_labels_and_superpixel_patches_against_the_oracle(oracle_mod, case):
+    """SLICO labels (seeds, ten zero-parameter iterations on the transposed slice, connectivity pass) and the 64 x 64 patches cut
+    around the superpixels with their dilated spxMask: slic.py against the oracle's literal loops."""
+    from fetalreconstruction_amd import slic
+    if case == "oblique":
+        m, a, st, _ = _oblique_case(2)
+        stacks = [pvr.Stack(d.astype(np.float32), sa, np.eye(4), sa.dz) for d, sa in st]
+        mask, mattr = (m > 0).astype(np.uint8), a
+        spx, ext = (16, 16), 20
+    else:
+        stacks, mask, mattr, _, _ = phantom.make_stacks(2, (48, 40, 6), 1.1, 2.2, None, 1.0, 16.0, seed=4, orientations=("ax", "sag"),
+                                                        stack_motion_mm=0.0, stack_motion_deg=0.0)
+        spx, ext = (12, 12), 30
+    checked = 0
+    for st in stacks:
+        data = np.asarray(st.data, np.float32)
+        lab = slic.segment_slic(data, spx)
+        olab = oracle_mod.segment_slic(data, spx)
+        assert np.array_equal(lab, olab)                                 # every pixel's superpixel: exact
+        p, i2w, w2i, msk, org, _ = slic.generate2DSuperpixelPatches(st, mask, mattr, spx, ext)
+        op, om, oi, ow, oorg, total = oracle_mod.generate_2d_superpixel_patches(data, st.attr, olab, st.thickness, mask, mattr, spx, ext)
+        assert len(op) == len(p) > 0
+        assert np.array_equal(op, p) and np.array_equal(om, msk)         # which pixels a patch carries, their values, the 64-wide mask
+        assert total == int((msk == ord("1")).sum())
+        assert np.allclose(oi, i2w, rtol=0, atol=2e-4) and np.allclose(ow, w2i, rtol=0, atol=2e-4)
+        assert np.allclose(oorg, org, rtol=0, atol=1e-9)
+        checked += len(p)
+    assert checked > 20
+
+
+def test_cpp_superpixel_patches_against_the_oracle(tmp_path, oracle_mod):
+    """bin/PVRreconstructionGPU -s --dumpProblem --dryRun: the superpixel patches and masks the C++ command line cuts
+    (csrc/svr_slic.h) are the oracle's cut of the same pre-processed stacks."""
+    from fetalreconstruction_amd import build, nifti, pvr_cli
+    build.build()
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(2, (48, 40, 6), 1.1, 2.2, None, 1.0, 16.0, seed=4, orientations=("ax", "sag"),
+                                                            stack_motion_mm=0.0, stack_motion_deg=0.0)
+    paths = []
+    for k, st in enumerate(stacks):
+        nifti.write(tmp_path / f"s{k}.nii.gz", st.data, st.attr)
+        paths.append(str(tmp_path / f"s{k}.nii.gz"))
+    nifti.write(tmp_path / "mask.nii.gz", rmask, rattr)
+    dump = tmp_path / "problem.bin"
+    r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "x.nii.gz"), "-i", *paths, "-m", str(tmp_path / "mask.nii.gz"), "-s", "--spxSize", "12",
+                        "--spxExtend", "30", "--resolution", "1.0", "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = dump.read_bytes()
+    ns, px, py, nst, vx, vy, vz = [int(v) for v in np.frombuffer(raw, np.int32, 8)[:7]]
+    o = 32
+    counts = np.frombuffer(raw, np.int32, nst, o); o += 4 * nst + 8
+    patches = np.frombuffer(raw, np.float32, ns * py * px, o).reshape(ns, py, px); o += 4 * ns * py * px + 64 * ns + 4 * vx * vy * vz
+    masks = np.frombuffer(raw, np.uint8, ns * 4096, o).reshape(ns, 4096)
+    # the same pre-processed stacks (the Python chain, tied to the C++ one by the dump tests), cut by the oracle
+    ims = [pp.Image(nifti.read(p)[0].astype(np.float64), nifti.read(p)[1]) for p in paths]
+    md, mat = nifti.read(tmp_path / "mask.nii.gz")
+    ims, ts, iso, tattr, rmk = pvr_cli.prepare(ims, [np.eye(4)] * 2, pp.Image(md.astype(np.float64), mat), 1.0, 0, False)
+    at = 0
+    for k, s in enumerate(ims):
+        data = s.data.astype(np.float32)
+        olab = oracle_mod.segment_slic(data, (12, 12))
+        op, om, *_ = oracle_mod.generate_2d_superpixel_patches(data, s.attr, olab, s.attr.dz, iso.data, iso.attr, (12, 12), 30)
+        assert len(op) == counts[k]
+        assert np.array_equal(op, patches[at:at + len(op)]) and np.array_equal(om, masks[at:at + len(op)])
+        at += len(op)
+    assert at == ns > 20
