@@ -208,11 +208,23 @@ struct Patches {
 inline double snap(double v) { const double r = nearbyint(v); return fabs(v - r) < 1e-6 ? r : v; }
 
 // PatchBasedVolume<T>::generate2DPatches, patchBasedObject.cuh:176-342
-void generate_2d_patches(const Image &stack, double thickness, const Image &mask, int px, int py, int sx, int sy, Patches &out) {
+void append(Patches &to, const Patches &from) {
+  to.data.insert(to.data.end(), from.data.begin(), from.data.end());
+  to.i2w.insert(to.i2w.end(), from.i2w.begin(), from.i2w.end()); to.w2i.insert(to.w2i.end(), from.w2i.begin(), from.w2i.end());
+  to.ri2w.insert(to.ri2w.end(), from.ri2w.begin(), from.ri2w.end()); to.mo.insert(to.mo.end(), from.mo.begin(), from.mo.end());
+  to.invmo.insert(to.invmo.end(), from.invmo.begin(), from.invmo.end());
+  to.attr.insert(to.attr.end(), from.attr.begin(), from.attr.end());
+  to.n += from.n;
+}
+
+void generate_2d_patches(const Image &stack, double thickness, const Image &mask, int px, int py, int sx, int sy, Patches &result) {
   const svr_image_attr &a = stack.a;
   const M4 m_w2i = world_to_image(mask.a);
-  std::vector<float> patch((size_t)px * py);
-  for (int z = 0; z < a.nz; ++z) {
+  std::vector<Patches> per_slice(a.nz);                  // the slices are cut on the host threads and appended in slice order
+  parallel_for(a.nz, [&](int z) {
+    Patches &out = per_slice[z];
+    std::vector<float> patch((size_t)px * py);
+    {
     svr_image_attr sl = a;                               // GetRegion(0, 0, z, x, y, z + 1) + PutPixelSize :202-203
     sl.nz = 1;
     sl.dz = thickness * 2;
@@ -258,7 +270,9 @@ void generate_2d_patches(const Image &stack, double thickness, const Image &mask
           out.n++;
         }
       }
-  }
+    }
+  });
+  for (const Patches &p : per_slice) append(result, p);
 }
 
 #define PVRH(call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + pvrh_last_error(host)); } while (0)
@@ -327,10 +341,14 @@ int main(int argc, char **argv) {
   if (tspecs.empty()) tspecs.assign(n, "id");
   if (tspecs.size() != n) die("one transformation per stack expected");
 
+  StageClock clk;
   // ---- set-up (pvrmain:184-257, PBR.cpp:193-310) --------------------------------------------------------
   std::vector<Image> stacks;
   std::vector<M4> ts;
-  for (size_t k = 0; k < n; ++k) { stacks.push_back(read_image(inputs[k])); ts.push_back(load_transformation(tspecs[k])); }
+  stacks.resize(n);
+  parallel_for((int)n, [&](int k) { stacks[k] = read_image(inputs[k]); });                        // gunzip is serial per file
+  for (size_t k = 0; k < n; ++k) ts.push_back(load_transformation(tspecs[k]));
+  clk.mark("read stacks");
   std::vector<double> half_thickness;                    // m_thickness: dz, or the given thickness / 2 (pvrmain:209-217)
   if (thickness.empty()) for (auto &s : stacks) half_thickness.push_back(s.a.dz);
   else { if (thickness.size() != n) die("one thickness per stack expected"); for (double t : thickness) half_thickness.push_back(t / 2.0); }
@@ -355,7 +373,9 @@ int main(int argc, char **argv) {
     stacks[k] = crop_image(stacks[k], m);
     if (resample) stacks[k] = resample_bspline(stacks[k], resolution);                          // :237-246
   }
+  clk.mark("mask, crop (resample)");
   const Image iso_mask = transform_nn(mask, resample_attr(mask.a, resolution), ident(), 0.0);    // :258-266
+  clk.mark("isotropic mask");
   if (!no_registration && n > 1) {                       // irtkStack3D3DRegistration<T>::run, :280-285
     svr_ctx *rctx = nullptr;
     if (svr_create(devices.empty() ? 0 : devices[0], &rctx) || !rctx) die("no usable HIP device (svr_create failed)");
@@ -372,7 +392,9 @@ int main(int argc, char **argv) {
     fprintf(stderr, "stack-to-stack registration: %ld similarity evaluations\n", evals);
     svr_destroy(rctx);
   }
+  clk.mark("stack-to-stack registration");
   if (!no_matching) match_stack_intensities_pvr(stacks, ts, iso_mask);                           // :288-294
+  clk.mark("match stack intensities");
   float vmin = 3.402823466e38f, vmax = 1.175494351e-38f;                                         // computeMinMaxIntensities :792-814
   for (const Image &s : stacks)
     for (double v : s.d)
@@ -385,6 +407,7 @@ int main(int argc, char **argv) {
     existing.assign(ex.d.begin(), ex.d.end());
   }
   const Image recon_mask = transform_nn(iso_mask, tattr, ts[tmpl], 0.0);                         // :303-304
+  clk.mark("template, reconstruction mask");
   if (superpixel && full_slices) die("--superpixel with --useFullSlices is not supported by this build");
   if (hierarchical && full_slices) hierarchical = false;                                         // pvrmain:282-285 "SVR ON"
   bool first_level = true;
@@ -443,6 +466,7 @@ int main(int argc, char **argv) {
       dims.push_back((float)stacks[k].a.dx); dims.push_back((float)stacks[k].a.dy); dims.push_back((float)stacks[k].a.dz);   // getDim()
     }
   }
+  clk.mark("patch generation");
   const int ns = P.n;
   if (ns == 0) die("no patch overlaps the mask");
   fprintf(stderr, "%zu stacks, %d patches of %dx%d, volume %dx%dx%d at %g mm\n", n, ns, px, py, tattr.nx, tattr.ny, tattr.nz, resolution);
@@ -503,6 +527,7 @@ int main(int argc, char **argv) {
   }
   ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), P.i2w.data(), P.w2i.data(), P.i2w.data(), P.w2i.data(), ri2w, rw2i));
 
+  clk.mark("engine set-up and upload");
   // ---- the loop (PBR.cpp:445-593) ----------------------------------------------------------------------------
   pvrh_recon *host = pvrh_create(ctx, counts.data(), (int)counts.size(), vmin, vmax);
   if (!host) die("pvrh_create failed");
@@ -528,13 +553,22 @@ int main(int argc, char **argv) {
       ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), P.i2w.data(), P.w2i.data(), P.i2w.data(), P.w2i.data(), ri2w, rw2i));
       fprintf(stderr, "patch-to-volume registration: %ld similarity evaluations\n", evals);
     }
+    if (have_volume && !no_registration) clk.mark("patch-to-volume registration");
     PVRH(pvrh_reconstruct_iteration(host, sr_iterations));
+    clk.mark("reconstruction iteration");
     double sc[8];
     pvrh_get_state(host, nullptr, nullptr, nullptr, sc);
     fprintf(stderr, "iteration %d: sigma %.4g mix %.3f\n", it, sc[0], sc[1]);
   }
   vol_out.resize((size_t)tattr.nx * tattr.ny * tattr.nz);
   ENG(svr_sync_cpu(ctx, vol_out.data()));
+  if (clk.on) {
+    int o[6] = {0, 0, 0, 0, 0, 0};
+    const char *names[6] = {"tile_w", "tile_h", "wave_cap", "fwd_tile_w", "fwd_tile_h", "fwd_unit_cap"};
+    for (int k = 0; k < 6; ++k) (void)svr_get_option(ctx, names[k], &o[k]);
+    fprintf(stderr, "[timing] tuned: scatter tiles %dx%d box %d, gather tiles %dx%d box %d\n", o[0], o[1], o[2], o[3], o[4], o[5]);
+  }
+  clk.mark("volume download");
   pvrh_destroy(host);
   svr_destroy(ctx);
   return true;
@@ -559,7 +593,9 @@ int main(int argc, char **argv) {
       else { ps[0] -= 4; ps[1] -= 4; pt[0] -= 2; pt[1] -= 2; }
     }
   }
+  clk.mark("engine teardown");
   char err[256] = {0};
   if (svr_nifti_write(output.c_str(), &tattr, vol.data(), err)) die(output + ": " + err);
+  clk.mark("write the volume");
   return 0;
 }

@@ -105,13 +105,18 @@ int main(int argc, char **argv) {
   for (size_t k = 0; k < n; ++k) if (tspecs[k] == "id") { tmpl = k; break; }
   if (tmpl == n) die("Please identify the template by assigning id transformation.");          // main.cc:452-457
 
+  StageClock clk;
   svr_ctx *ctx = nullptr;
   if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
 
+  clk.mark("context");
   // ---- set-up (main.cc:386-815) ----------------------------------------------------------------------
   std::vector<Image> stacks;
   std::vector<M4> ts;
-  for (size_t k = 0; k < n; ++k) { stacks.push_back(read_image(inputs[k])); ts.push_back(load_transformation(tspecs[k])); }
+  stacks.resize(n);
+  parallel_for((int)n, [&](int k) { stacks[k] = read_image(inputs[k]); });                        // gunzip is serial per file
+  for (size_t k = 0; k < n; ++k) ts.push_back(load_transformation(tspecs[k]));
+  clk.mark("read stacks");
   if (thickness.empty()) for (auto &s : stacks) thickness.push_back(2.0 * s.a.dz);            // main.cc:422-431
   if (thickness.size() != n) die("one thickness per stack expected");
   Image mask_img;
@@ -130,6 +135,7 @@ int main(int argc, char **argv) {
   }
   const svr_image_attr tattr = create_template(stacks[tmpl].a, resolution);
   const Image vol_mask = set_mask(tattr, have_mask ? &mask_img : nullptr, smooth_mask);
+  clk.mark("mask, crop, template");
   auto stack_registrations = [&]() {                                                             // StackRegistrations, RG.cc:849-1001
     if (no_registration || n < 2 || !sfolder.empty()) return;                                    // main.cc:658, 708
     std::vector<svr_image_attr> at(n);
@@ -151,7 +157,9 @@ int main(int argc, char **argv) {
     stacks[k] = crop_image(stacks[k], m);
   }
   stack_registrations();                                                                         // main.cc:707-713
+  clk.mark("stack registrations, crops");
   const std::vector<float> factors = match_stack_intensities(stacks, ts, vol_mask, average, no_matching);
+  clk.mark("match stack intensities");
   // CreateSlicesAndTransformations RG.cc:1835-1880 + MaskSlices RG.cc:1940-1988 + the packing of SyncGPU RG.cc:249-328
   struct SliceSrc { Image r; M4 t; int stack; };
   std::vector<SliceSrc> srcs;
@@ -326,6 +334,7 @@ int main(int argc, char **argv) {
     update_matrices_from_T();
   }
 
+  clk.mark("slices, engine set-up, upload");
   // ---- registration-reconstruction loop (main.cc:816-1237) ---------------------------------------------
   for (int it = 0; it < iterations; ++it) {
     bool slice_reg = it > 0 && !no_registration;
@@ -370,10 +379,12 @@ int main(int argc, char **argv) {
         }
       }
     }
+    if (slice_reg) clk.mark("registration");
     par([&](int r) { HOSTR(r, svrh_reconstruct_iteration(hosts[r], it == iterations - 1 ? rec_last : rec_first)); });   // main.cc:930-1140
     double sc[8];
     svrh_get_state(host, nullptr, nullptr, nullptr, nullptr, sc);
     fprintf(stderr, "iteration %d: sigma %.4g mix %.3f\n", it, sc[0], sc[1]);
+    clk.mark("reconstruction iteration");
   }
   par([&](int r) {                                                       // main.cc:1189-1193
     ENGR(r, svr_restore_slice_intensities(ctxs[r], factors.data(), (int)factors.size(), stack_index.data() + rlo[r]));
@@ -382,7 +393,9 @@ int main(int argc, char **argv) {
   std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
   ENG(svr_sync_cpu(ctx, vol.data()));
   char err[256] = {0};
+  clk.mark("restore, scale, download");
   if (svr_nifti_write(output.c_str(), &tattr, vol.data(), err)) die(output + ": " + err);
+  clk.mark("write the volume");
   if (debug) {                                                           // SaveTransformations, RG.cc:4903-4915
     const size_t cut = output.find_last_of('/');
     const std::string folder = cut == std::string::npos ? "." : output.substr(0, cut);
@@ -397,5 +410,6 @@ int main(int argc, char **argv) {
   for (int r = 0; r < nr; ++r) svrh_destroy(hosts[r]);
   svr_group_destroy(group);
   for (int r = 0; r < nr; ++r) svr_destroy(ctxs[r]);
+  clk.mark("teardown");
   return 0;
 }

@@ -2765,6 +2765,8 @@ struct svr_ctx {
   bool psf_list_valid = false;
   unsigned char *d_gauss_flag = nullptr;   // pixels whose sume passed in the current Gaussian pass
   uint32_t *d_tiles_tmp = nullptr;         // tile list of the Gaussian passes
+  uint32_t *d_tiles_sample = nullptr;      // every stride-th tile, for the trial launches of the tuners
+  size_t tiles_sample_cap = 0;
   size_t tiles_tmp_cap = 0;                // its capacity in tiles (the tile shapes can change between calls)
   int gauss_mode = 1;                      // 1 = unit-based pass 1 (fwd_unit_kernel<GAUSS1>) + the LDS scatter, 0 = psf_kernel<MODE_GAUSS>
   uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_unit_kernel
@@ -2905,6 +2907,7 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_tiles_fwd);
   free_dev(c->d_gauss_flag);
   free_dev(c->d_tiles_tmp);
+  free_dev(c->d_tiles_sample); c->tiles_sample_cap = 0;
   free_dev(c->d_tiles_fb);
   free_dev(c->d_tiles_fb2);
   free_dev(c->d_partial); free_dev(c->d_per_slice);
@@ -3071,10 +3074,72 @@ int ready(svr_ctx *ctx) {
   return prepare_slice_consts(ctx);
 }
 
+// The gather takes one workgroup of FWDU_WAVES wavefronts per tile, and a dispatch holds at most 2^32 - 1 work-items per
+// dimension: beyond 8.4 M tiles (2 x 2-pixel tiles of a 0.5 mm patch-based case: 12.2 M) a single launch silently ran the
+// tile count modulo 2^23 -- it looked 3.3 x faster in the tuner and left two thirds of the simulated slices stale.  Long
+// lists go out in pieces of 2^22 tiles (a multiple of the XCD group of xcd_run_index).
+template <bool GAUSS1>
+void launch_fwd_unit(svr_ctx *ctx, const PsfArgs &a, TileArgs ta, size_t lds) {
+  constexpr uint32_t PIECE_MAX = 1u << 22;
+  static_assert((uint64_t)PIECE_MAX * FWDU_WAVES * 64 < (1ull << 32), "a piece must fit one dispatch");
+  const char *env = getenv("SVR_FWD_PIECE");             // test hook: short pieces on a small problem
+  const uint32_t PIECE = env && atol(env) > 0 ? (uint32_t)std::min<long>(atol(env), PIECE_MAX) : PIECE_MAX;
+  const uint32_t *tiles = ta.tiles;
+  const uint32_t total = ta.ntiles;
+  for (uint32_t off = 0; off < total; off += PIECE) {
+    ta.tiles = tiles + off;
+    ta.ntiles = std::min(PIECE, total - off);
+    const dim3 grid(ta.ntiles), block(FWDU_WAVES * 64);
+    if (ctx->pvr && a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<GAUSS1, PVR_N, true, true>), grid, block, lds, ctx->stream, a, ta);
+    else if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<GAUSS1, PVR_N, true>), grid, block, lds, ctx->stream, a, ta);
+    else if (a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<GAUSS1, PSF_SUPPORT, false, true>), grid, block, lds, ctx->stream, a, ta);
+    else hipLaunchKernelGGL((fwd_unit_kernel<GAUSS1>), grid, block, lds, ctx->stream, a, ta);
+  }
+}
+
 int ensure_psf_list(svr_ctx *ctx) {
   if (!ctx->psf_list_valid) return build_list(ctx, true);
   return SVR_OK;
 }
+
+// The tuners time their candidates on real launches whose results are thrown away.  On a long tile list (S8, the
+// patch-based cases: millions of tiles, 0.05-0.2 s per launch, two dozen trials) a trial runs on one run of 4096 consecutive tiles out of every `stride` runs
+// instead, so that tuning costs what it costs on P4 (a list of up to 2 x TUNE_TILES tiles is timed whole).
+constexpr uint32_t TUNE_TILES = 131072;
+__global__ void k_sample_list(const uint32_t *src, uint32_t n_out, uint32_t stride, uint32_t run, uint32_t *dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_out) dst[i] = src[(size_t)(i / run) * run * stride + i % run];
+}
+struct TileSample {
+  uint32_t **list = nullptr, *saved = nullptr;
+  uint32_t *n = nullptr, saved_n = 0;
+  float scale = 1.0f;                    // full list / timed part: the candidates are compared on the time of a whole launch
+  int begin(svr_ctx *ctx, uint32_t *&l, uint32_t &count) {
+    static const long env_tiles = getenv("SVR_TUNE_TILES") ? atol(getenv("SVR_TUNE_TILES")) : -1;   // 0: always the whole list
+    if (env_tiles == 0) return SVR_OK;
+    static const long env_run = getenv("SVR_TUNE_RUN") ? atol(getenv("SVR_TUNE_RUN")) : -1;
+    const uint32_t target = env_tiles > 0 ? (uint32_t)env_tiles : TUNE_TILES;
+    const uint32_t TUNE_RUN = env_run > 0 ? (uint32_t)env_run : 65536u;
+    const uint32_t stride = count / target;
+    if (stride < 2 || (uint64_t)TUNE_RUN * stride > count) return SVR_OK;
+    const uint32_t n_out = count / (TUNE_RUN * stride) * TUNE_RUN;     // whole runs only: the last index stays inside the list
+    if (ctx->tiles_sample_cap < n_out) {
+      free_dev(ctx->d_tiles_sample);
+      ctx->tiles_sample_cap = 0;
+      HIPCHK(hipMalloc(&ctx->d_tiles_sample, (size_t)n_out * sizeof(uint32_t)));
+      ctx->tiles_sample_cap = n_out;
+    }
+    hipLaunchKernelGGL(k_sample_list, dim3(nblk(n_out)), dim3(256), 0, ctx->stream, l, n_out, stride, TUNE_RUN, ctx->d_tiles_sample);
+    KCHK("k_sample_list");
+    list = &l; n = &count; saved = l; saved_n = count;
+    scale = (float)count / (float)n_out;
+    l = ctx->d_tiles_sample; count = n_out;
+    return SVR_OK;
+  }
+  void end() {
+    if (list) { *list = saved; *n = saved_n; list = nullptr; }
+  }
+};
 
 // The scatter over a tile list (back-projection into addon|cmap, or pass 2 of the Gaussian reconstruction into
 // recon|volw): the wave-owned kernel with a box of `wave_cap` voxels; tiles whose planes do not fit it are re-run by the
@@ -3422,7 +3487,8 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   (void)dim;
   HIPCHK(hipSetDevice(ctx->device));
   size_t np = (size_t)size[0] * size[1] * size[2];
-  if (np == 0 || np >= 0xFFFFFFFFull) return fail(ctx, SVR_E_ARG, "slice grid size out of range");
+  // a wavefront per pixel / per tile and 2^32 - 1 work-items per dispatch: 2^26 pixels per context (S8: 2^25; more slices go to more ranks)
+  if (np == 0 || np >= (1ull << 26)) return fail(ctx, SVR_E_ARG, "slice grid out of range: 1 .. 2^26 - 1 pixels per context (shard the slices over more ranks)");
   free_slices(ctx);
   free_dev(ctx->d_bias); free_dev(ctx->d_wb); free_dev(ctx->d_wr); free_dev(ctx->d_buffer);
   ctx->sx = size[0]; ctx->sy = size[1]; ctx->ns = size[2];
@@ -3638,10 +3704,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1;
     if (n1) {
       const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-      if (ctx->pvr && a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<true, PVR_N, true, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
-      else if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<true, PVR_N, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
-      else if (a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<true, PSF_SUPPORT, false, true>), dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
-      else hipLaunchKernelGGL(fwd_unit_kernel<true>, dim3(n1), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      launch_fwd_unit<true>(ctx, a, ta, lds);
       KCHK("fwd_unit_kernel<GAUSS1>");
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
@@ -3720,10 +3783,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
       ta.gauss = 0;
       const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-      if (ctx->pvr && a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<false, PVR_N, true, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
-      else if (ctx->pvr) hipLaunchKernelGGL((fwd_unit_kernel<false, PVR_N, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
-      else if (a.coeff) hipLaunchKernelGGL((fwd_unit_kernel<false, PSF_SUPPORT, false, true>), dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
-      else hipLaunchKernelGGL(fwd_unit_kernel<false>, dim3(ta.ntiles), dim3(FWDU_WAVES * 64), lds, ctx->stream, a, ta);
+      launch_fwd_unit<false>(ctx, a, ta, lds);
       KCHK("fwd_unit_kernel");
     } else if (a.n && ctx->pvr) {
       hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
@@ -3750,15 +3810,21 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       r = ensure_psf_list(ctx);
       if (r) return r;
       a.list = ctx->d_psf_list; a.n = ctx->n_psf;
+      TileSample sample;
+      r = sample.begin(ctx, ctx->d_tiles_fwd, ctx->n_tiles_fwd);
       float ms = 0.0f;
-      for (int rep = 0; rep < 2; ++rep) {                // the second run is the one that counts
-        HIPCHK(hipEventRecord(e0, ctx->stream));
+      for (int rep = 0; rep < 2 && !r; ++rep) {          // the second run is the one that counts
+        hipError_t he = hipEventRecord(e0, ctx->stream);
         r = launch_forward();
-        if (r) return r;
-        HIPCHK(hipEventRecord(e1, ctx->stream));
-        HIPCHK(hipEventSynchronize(e1));
-        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
+        if (he == hipSuccess) he = hipEventSynchronize(e1);
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+        if (!r && he != hipSuccess) r = fail(ctx, (int)he, std::string("tile tuning: ") + hipGetErrorString(he));
       }
+      sample.end();                                      // before anything can rebuild or free the list
+      if (r) return r;
+      ms *= sample.scale;
+      if (getenv("SVR_TUNE_DEBUG")) fprintf(stderr, "[tune] gather %dx%d: %.3f ms (whole launch; timed 1/%.1f of the tiles)\n", cand[c][0], cand[c][1], ms, sample.scale);
       if (ms < best) { best = ms; pick = c; }
     }
     (void)hipEventDestroy(e0);
@@ -3931,14 +3997,22 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     for (int c = 0; c < ncand && !r; ++c) {
       r = svr_set_option(ctx, "tile_w", cand[c][0]);
       if (!r) r = svr_set_option(ctx, "tile_h", cand[c][1]);
+      if (!r) r = ensure_psf_list(ctx);                  // the list of this shape, so that the trial below finds it valid
+      TileSample sample;
+      if (!r) r = sample.begin(ctx, ctx->d_tiles, ctx->n_tiles);
       float ms = 0.0f;
       for (int rep = 0; rep < 2 && !r; ++rep) {          // the second run is the one that counts
-        HIPCHK(hipEventRecord(e0, ctx->stream));
+        hipError_t he = hipEventRecord(e0, ctx->stream);
         r = svr_superresolution_backproject(ctx, nullptr);
-        HIPCHK(hipEventRecord(e1, ctx->stream));
-        HIPCHK(hipEventSynchronize(e1));
-        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
+        if (he == hipSuccess) he = hipEventSynchronize(e1);
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+        if (!r && he != hipSuccess) r = fail(ctx, (int)he, std::string("tile tuning: ") + hipGetErrorString(he));
       }
+      sample.end();
+      if (r) break;
+      ms *= sample.scale;
+      if (getenv("SVR_TUNE_DEBUG")) fprintf(stderr, "[tune] scatter %dx%d: %.3f ms (whole launch; timed 1/%.1f of the tiles)\n", cand[c][0], cand[c][1], ms, sample.scale);
       if (ms < best) { best = ms; pick = c; }
       else if (!tab) break;
     }
@@ -3954,18 +4028,24 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
       static const int caps[5] = {2416, 2096, 1776, 1616, 1456};
       float bestc = 3.0e38f;
       int pickc = ctx->wave_cap;
+      r = ensure_psf_list(ctx);
+      TileSample sample;
+      if (!r) r = sample.begin(ctx, ctx->d_tiles, ctx->n_tiles);
       for (int c = 0; c < 5 && !r; ++c) {
         ctx->wave_cap = caps[c];
         float ms = 0.0f;
         for (int rep = 0; rep < 2 && !r; ++rep) {
-          HIPCHK(hipEventRecord(e0, ctx->stream));
+          hipError_t he = hipEventRecord(e0, ctx->stream);
           r = svr_superresolution_backproject(ctx, nullptr);
-          HIPCHK(hipEventRecord(e1, ctx->stream));
-          HIPCHK(hipEventSynchronize(e1));
-          HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+          if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
+          if (he == hipSuccess) he = hipEventSynchronize(e1);
+          if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+          if (!r && he != hipSuccess) r = fail(ctx, (int)he, std::string("tile tuning: ") + hipGetErrorString(he));
         }
+        if (getenv("SVR_TUNE_DEBUG")) fprintf(stderr, "[tune] scatter box %d: %.3f ms (timed 1/%.1f of the tiles)\n", caps[c], ms, sample.scale);
         if (ms < bestc) { bestc = ms; pickc = caps[c]; }
       }
+      sample.end();
       ctx->wave_cap = pickc;
     }
     (void)hipEventDestroy(e0);

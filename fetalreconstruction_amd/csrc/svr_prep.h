@@ -13,7 +13,11 @@
 
 #include <algorithm>
 #include <fstream>
+#include <chrono>
+#include <atomic>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/svr_host.h"
@@ -76,6 +80,19 @@ struct Image {
 
 const char *prog_name = "SVRreconstructionGPU";
 void die(const std::string &m) { fprintf(stderr, "%s: %s\n", prog_name, m.c_str()); exit(1); }
+
+// SVR_CLI_TIMING=1: wall time of every stage of a command line on stderr (tools/run_cli_*.py read it)
+struct StageClock {
+  bool on = getenv("SVR_CLI_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  void mark(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[timing] %-34s %8.3f s  (at %7.3f s)\n", what, std::chrono::duration<double>(now - last).count(),
+            std::chrono::duration<double>(now - t0).count());
+    last = now;
+  }
+};
 
 Image read_image(const std::string &path) {
   Image im;
@@ -146,12 +163,25 @@ inline void apply_point(const M4 &m, double &x, double &y, double &z) {
 }
 
 // irtkImageTransformation + nearest neighbour, target padding -1 on an all-zero target (RG.cc:782-793, 808-819)
+// fn(i) for i in [0, n) on the host threads (at most 32), items handed out one at a time; every item writes its own output,
+// so the results do not depend on the thread count.  The grids of the fine cases have 10^7..10^8 voxels.
+inline void parallel_for(int n, const std::function<void(int)> &fn) {
+  const unsigned nt = std::max(1u, std::min<unsigned>({std::thread::hardware_concurrency(), 32u, (unsigned)std::max(n, 1)}));
+  if (nt < 2 || n < 2) { for (int i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<int> next{0};
+  auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+}
+
 Image transform_nn(const Image &src, const svr_image_attr &target, const M4 &t, double source_padding) {
   Image out;
   out.a = target;
   out.d.assign((size_t)target.nx * target.ny * target.nz, source_padding);
   const M4 t_i2w = image_to_world(target), s_w2i = world_to_image(src.a);
-  for (int z = 0; z < target.nz; ++z)
+  parallel_for(target.nz, [&](int z) {
     for (int y = 0; y < target.ny; ++y)
       for (int x = 0; x < target.nx; ++x) {
         double q[3] = {(double)x, (double)y, (double)z};
@@ -160,6 +190,7 @@ Image transform_nn(const Image &src, const svr_image_attr &target, const M4 &t, 
         if (i >= 0 && i < src.a.nx && j >= 0 && j < src.a.ny && k >= 0 && k < src.a.nz)
           out.at(x, y, z) = src.at((int)i, (int)j, (int)k);
       }
+  });
   return out;
 }
 

@@ -135,9 +135,9 @@ std::vector<float> slic_segment(const Image &stack, int spx, int spy) {
   for (double v : stack.d) { vmin = std::min(vmin, (float)v); vmax = std::max(vmax, (float)v); }
   const int nsp = (int)(sz / (spx * spy));
   std::vector<float> out(stack.d.size(), 0.0f);
-  std::vector<int> grey(sz), kl, cl;
-  std::vector<double> l, a, b;
-  for (int z = 0; z < nz; ++z) {
+  parallel_for(nz, [&](int z) {                            // the slices are independent: one per host thread
+    std::vector<int> grey(sz), kl, cl;
+    std::vector<double> l, a, b;
     int p = 0;
     for (int x = 0; x < nx; ++x)
       for (int y = 0; y < ny; ++y, ++p)
@@ -150,7 +150,7 @@ std::vector<float> slic_segment(const Image &stack, int spx, int spy) {
     p = 0;
     for (int x = 0; x < nx; ++x)
       for (int y = 0; y < ny; ++y, ++p) out[((size_t)z * ny + y) * nx + x] = (float)cl[p];
-  }
+  });
   return out;
 }
 
@@ -162,17 +162,19 @@ struct SpxPatches {
 };
 
 // generate2DSuperpixelPatches for one stack; `half_thickness` = m_thickness, mask = the iso mask
-void slic_superpixel_patches(const Image &stack, double half_thickness, const Image &mask, int spx, int spy, int extend_percent, SpxPatches &out) {
+void slic_superpixel_patches(const Image &stack, double half_thickness, const Image &mask, int spx, int spy, int extend_percent, SpxPatches &result) {
   const svr_image_attr &a = stack.a;
   if (spx > a.nx) spx = a.nx / 2;
   if (spy > a.ny) spy = a.ny / 2;
   const std::vector<float> labels = slic_segment(stack, spx, spy);
   const float ratio = (float)extend_percent / 100.0f;
   const int px = std::min(64, a.nx), py = std::min(64, a.ny);
-  out.px = px; out.py = py;
+  result.px = px; result.py = py;
   const M4 m_w2i = world_to_image(mask.a);
-  std::vector<float> pm((size_t)px * py), tmp((size_t)px * py), val((size_t)px * py);
-  for (int z = 0; z < a.nz; ++z) {
+  std::vector<SpxPatches> per_slice(a.nz);                 // cut on the host threads, appended in slice order below
+  parallel_for(a.nz, [&](int z) {
+    SpxPatches &out = per_slice[z];
+    std::vector<float> pm((size_t)px * py), tmp((size_t)px * py), val((size_t)px * py);
     const float *lab = &labels[(size_t)z * a.nx * a.ny];
     svr_image_attr sl = a;
     sl.nz = 1;
@@ -263,6 +265,15 @@ void slic_superpixel_patches(const Image &stack, double half_thickness, const Im
       out.attr.push_back(pa);
       out.n++;
     }
+  });
+  for (const SpxPatches &p : per_slice) {
+    result.data.insert(result.data.end(), p.data.begin(), p.data.end());
+    result.masks.insert(result.masks.end(), p.masks.begin(), p.masks.end());
+    result.i2w.insert(result.i2w.end(), p.i2w.begin(), p.i2w.end()); result.w2i.insert(result.w2i.end(), p.w2i.begin(), p.w2i.end());
+    result.ri2w.insert(result.ri2w.end(), p.ri2w.begin(), p.ri2w.end()); result.mo.insert(result.mo.end(), p.mo.begin(), p.mo.end());
+    result.invmo.insert(result.invmo.end(), p.invmo.begin(), p.invmo.end());
+    result.attr.insert(result.attr.end(), p.attr.begin(), p.attr.end());
+    result.n += p.n;
   }
 }
 

@@ -52,6 +52,24 @@ def test_write_read_round_trip(tmp_path, ext):
     assert struct.unpack_from("<h", raw, 70)[0] == 16                                    # float32
 
 
+def test_large_volumes_are_deflated_in_parallel_as_gzip_members(tmp_path):
+    """A volume of 16 MiB or more is written as a sequence of gzip members (csrc/svr_io.cpp): zlib's gzread (the C++ reader)
+    and Python's gzip module read it as one stream, voxels and header unchanged."""
+    a = geo.ImageAttributes(260, 200, 90, 0.5, 0.5, 0.5, origin=np.array([3.0, -2.0, 7.0]))
+    rng = np.random.default_rng(5)
+    v = (rng.random((90, 200, 260)) * 100).astype(np.float32)
+    v[:30] = 0
+    path = tmp_path / "big.nii.gz"
+    nifti.write(path, v, a)
+    w, b = nifti.read(path)
+    assert np.array_equal(w, v)
+    assert (b.nx, b.ny, b.nz) == (a.nx, a.ny, a.nz) and np.allclose(b.origin, a.origin, atol=1e-5)
+    raw = gzip.open(path).read()
+    assert len(raw) == 352 + v.size * 4
+    assert np.array_equal(np.frombuffer(raw[352:], np.float32).reshape(v.shape), v)
+    assert open(path, "rb").read().count(b"\x1f\x8b\x08\x00") >= 4              # 18.7 MB of payload in 4 MiB members
+
+
 def test_left_handed_axes_use_qfac(tmp_path):
     a = _attr()
     a.zaxis = -a.zaxis                                                                   # det < 0

@@ -147,6 +147,28 @@ def test_forward_projection_parity(tiny, oracle_mod, fwd_mode):
     assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
 
 
+def test_gather_in_pieces(tiny, oracle_mod, monkeypatch):
+    """A dispatch holds 2^32 - 1 work-items, i.e. 8.4 M tiles of the gather's 512-lane workgroups; longer tile lists (2 x 2 tiles
+    of a 0.5 mm patch-based case: 12.2 M) go out in pieces.  SVR_FWD_PIECE shortens the pieces so that the tiny problem takes
+    the same path: Gaussian pass 1 and the simulated slices must not change."""
+    outs = []
+    for piece in (None, "48"):
+        if piece:
+            monkeypatch.setenv("SVR_FWD_PIECE", piece)
+        E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+        run_to_state(dg, "sim")
+        outs.append((rec.debug_get(E.BUF_PSF_SUMS), rec.syncCPU(), rec.debug_get(E.BUF_SIMSLICES), rec.debug_get(E.BUF_SIMWEIGHTS),
+                     rec.debug_get(E.BUF_SIMINSIDE)))
+    assert rec.counters()["Va"] // 32 > 3 * 48                               # several pieces even with the largest tiles (8 x 4)
+    for k, (a, b) in enumerate(zip(*outs)):
+        if k in (1, 2):                                                       # the volume comes out of float atomics (pass 2), the simulation reads it
+            assert rel_err(a, b) < 1e-6
+        else:
+            assert np.array_equal(a, b)
+    run_to_state(do, "sim")
+    assert rel_err(outs[1][2], orc.simslices) < TOL_SUM
+
+
 @pytest.mark.parametrize("back_mode", [4, 3, 1, 0])
 def test_backprojection_parity(tiny, oracle_mod, back_mode):
     """back_mode 4 = wave-owned LDS planes with the dead-unit shortcut (default), 3 = the workgroup kernel for every tile,

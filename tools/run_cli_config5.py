@@ -20,6 +20,7 @@ nifti.write(f"{tmp}/mask.nii.gz", rmask.astype(np.float32), rattr)
 print("stacks written in", round(time.time() - t0, 1), "s", flush=True)
 opts = ["-s", "--spxSize", "32", "--spxExtend", "2"] if mode.startswith("superpixel") else ["--patchSize", "32", "32", "--patchStride", "16", "16"]
 t0 = time.time()
+os.environ["SVR_CLI_TIMING"] = "1"
 if mode.startswith("svr"):          # configs[3] on one GPU: bin/SVRreconstructionGPU, `svr` without / `svrreg` with the registrations
     r = subprocess.run([build.CLI, "-o", f"{tmp}/out.nii.gz", "-i", *paths, "-m", f"{tmp}/mask.nii.gz", "--thickness", *["2.5"] * 8,
                         "--resolution", str(res), "--iterations", "2", "--rec_iterations_first", "3", "--rec_iterations_last", "5",
@@ -29,7 +30,7 @@ else:
                         "--resolution", str(res), "--iterations", "1", "--sr_iterations", "3", *([] if mode.endswith("reg") else ["--no_registration"]), *opts],
                        capture_output=True, text=True)
 print(mode, "command line rc", r.returncode, "wall", round(time.time() - t0, 1), "s")
-print(r.stderr[-1500:])
+print(r.stderr[-4000:])
 if r.returncode == 0:
     vol, va = nifti.read(f"{tmp}/out.nii.gz")
     sub = (slice(None, None, 4),) * 3

@@ -24,7 +24,7 @@ t = time.time()
 r = subprocess.run([build.CLI, "-o", str(tmp / "o.nii.gz"), "-i", *paths, "-m", str(tmp / "mask.nii.gz"), "--resolution", "1.0", *sys.argv[1:]],
                    capture_output=True, text=True)
 dt = time.time() - t
-print(r.stderr[-1500:])
+print(r.stderr[-4000:])
 print("exit", r.returncode, f"wall {dt:.2f} s")
 vol, va = nifti.read(tmp / "o.nii.gz")
 kk, jj, ii = np.meshgrid(np.arange(va.nz), np.arange(va.ny), np.arange(va.nx), indexing="ij")
