@@ -342,19 +342,6 @@ double ncc_from_sums(const int64_t s[6]) {                 // irtkCrossCorrelati
   return 0;
 }
 
-// the per-plane matrices of one evaluation: sourceW2I * T * targetI2W with the iterator's accumulated plane starts
-void push_request(const Target &t, const M4 &tm, const M4 &s_w2i, std::vector<int> &idx, std::vector<double> &mats) {
-  const M4 m = mul(mul(s_w2i, tm), image_to_world(t.lvl.a));
-  double zx = m.m[3], zy = m.m[7], zz = m.m[11];
-  for (int k = 0; k < t.lvl.a.nz; ++k) {
-    idx.push_back(t.first_plane + k);
-    M4 q = m;
-    q.m[3] = zx; q.m[7] = zy; q.m[11] = zz;
-    mats.insert(mats.end(), q.m, q.m + 16);
-    zx += m.m[2]; zy += m.m[6]; zz += m.m[10];           // NextZ()
-  }
-}
-
 // irtkImageRegistration::Run for every target against one source, in lock step
 int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol<short> &source, int slice_to_volume, short target_padding,
                       long *n_eval, std::string &err) {
@@ -407,85 +394,113 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
     const Schedule p0 = ps;
     t_pack += now() - t0; t0 = now();
     // ---- the optimiser, one round = one batched evaluation --------------------------------------------------------------
+    // A round costs the host a few double trigonometric calls per target; with tens of thousands of targets (the patches
+    // of the patch-based path) that was 1.6 s of a 2.8 s pass, so the requests are laid out by a prefix sum and written,
+    // and the answers consumed, by the host threads -- every target touches only its own state and its own slots.
+    std::vector<int> live, req_off, plane_off, idx;
+    std::vector<double> mats, value;
+    std::vector<int64_t> sums;
+    auto over_live = [&](size_t work, const std::function<void(int, int)> &fn) {
+      if (live.size() >= 2048) parallel_rows((int)live.size(), work, fn);
+      else fn(0, (int)live.size());
+    };
     for (;;) {
-      std::vector<int> idx, owner, count;                   // per request: its owner and its number of planes
-      std::vector<double> mats;
+      live.clear(); req_off.clear(); plane_off.clear();
+      int n_req = 0, n_planes = 0;
       for (size_t ti = 0; ti < targets.size(); ++ti) {
-        Target &t = targets[ti];
+        const Target &t = targets[ti];
         if (t.done) continue;
-        auto request = [&](const M4 &tm) { const size_t b = idx.size(); push_request(t, tm, s_w2i, idx, mats); owner.push_back((int)ti); count.push_back((int)(idx.size() - b)); };
-        if (t.phase == PH_START) {
-          request(t.matrix);                                // old_similarity = Evaluate(), GDO.cc:31
-        } else if (t.phase == PH_GRAD) {                    // EvaluateGradient, IR.cc:530-568
-          for (int i = 0; i < 6; ++i) {
-            double q[6];
-            for (int k = 0; k < 6; ++k) q[k] = t.p[k];
-            q[i] = t.p[i] + t.step; request(params_to_matrix(q));
-            q[i] = t.p[i] - t.step; request(params_to_matrix(q));
-          }
-        } else {
-          request(t.matrix);                                // a line-search probe
-        }
+        const int nr = t.phase == PH_GRAD ? 12 : 1;         // START: old_similarity = Evaluate(), GDO.cc:31; GRAD: IR.cc:530-568; LINE: one probe
+        live.push_back((int)ti); req_off.push_back(n_req); plane_off.push_back(n_planes);
+        n_req += nr; n_planes += nr * t.lvl.a.nz;
       }
-      if (owner.empty()) break;
-      std::vector<int64_t> sums(6 * idx.size());
-      const double te = now();
-      if (be.evaluate((int)idx.size(), idx.data(), mats.data(), sums.data())) { err = "svr_ncc_evaluate failed"; return 2; }
-      t_eval += now() - te; ++rounds;
-      if (n_eval) *n_eval += (long)owner.size();
-      std::vector<double> value(owner.size());
-      size_t at = 0;
-      for (size_t r = 0; r < owner.size(); ++r) {
-        int64_t s[6] = {0, 0, 0, 0, 0, 0};
-        for (int c = 0; c < count[r]; ++c, ++at) for (int k = 0; k < 6; ++k) s[k] += sums[6 * at + k];
-        value[r] = ncc_from_sums(s);
-      }
-      size_t r = 0;
-      for (size_t ti = 0; ti < targets.size(); ++ti) {
-        Target &t = targets[ti];
-        if (t.done) continue;
-        auto take_step = [&](double sign) {                // Put(i, Get(i) +- StepSize * dx[i]) for every i
-          for (int i = 0; i < 6; ++i) t.p[i] = t.p[i] + sign * (t.step * t.dx[i]);
-          t.matrix = params_to_matrix(t.p);
-        };
-        if (t.phase == PH_START) {
-          t.old_sim = t.new_sim = t.sim = value[r++];
-          for (int i = 0; i < 6; ++i) t.start[i] = t.p[i];   // irtkOptimizer::Run stores the parameters, O.cc:113-116
-          t.phase = PH_GRAD;
-        } else if (t.phase == PH_GRAD) {
-          double norm = 0;
-          for (int i = 0; i < 6; ++i) { const double s1 = value[r++], s2 = value[r++]; t.dx[i] = (float)(s1 - s2); }
-          t.matrix = params_to_matrix(t.p);                  // Put(i, parameterValue) rebuilt the matrix from the parameters
-          for (int i = 0; i < 6; ++i) norm += t.dx[i] * t.dx[i];
-          norm = sqrt(norm);
-          for (int i = 0; i < 6; ++i) t.dx[i] = norm > 0 ? (float)(t.dx[i] / norm) : 0.0f;
-          t.new_sim = t.sim;                                 // first pass of the do-while, GDO.cc:47-54
-          take_step(+1);
-          t.phase = PH_LINE;
-        } else {
-          t.sim = value[r++];
-          if (t.sim > t.new_sim + p0.epsilon) {              // keep stepping
-            t.new_sim = t.sim;
-            take_step(+1);
+      if (live.empty()) break;
+      idx.resize(n_planes); mats.resize(16 * (size_t)n_planes); sums.resize(6 * (size_t)n_planes); value.resize(n_req);
+      over_live(3000, [&](int l0, int l1) {
+        for (int l = l0; l < l1; ++l) {
+          const Target &t = targets[live[l]];
+          int at = plane_off[l];
+          auto request = [&](const M4 &tm) {                 // the per-plane matrices of one evaluation (push_request)
+            const M4 m = mul(mul(s_w2i, tm), image_to_world(t.lvl.a));
+            double zx = m.m[3], zy = m.m[7], zz = m.m[11];
+            for (int k = 0; k < t.lvl.a.nz; ++k, ++at) {
+              idx[at] = t.first_plane + k;
+              M4 q = m;
+              q.m[3] = zx; q.m[7] = zy; q.m[11] = zz;
+              memcpy(&mats[16 * (size_t)at], q.m, sizeof(q.m));
+              zx += m.m[2]; zy += m.m[6]; zz += m.m[10];     // NextZ()
+            }
+          };
+          if (t.phase == PH_GRAD) {
+            for (int i = 0; i < 6; ++i) {
+              double q[6];
+              for (int k = 0; k < 6; ++k) q[k] = t.p[k];
+              q[i] = t.p[i] + t.step; request(params_to_matrix(q));
+              q[i] = t.p[i] - t.step; request(params_to_matrix(q));
+            }
           } else {
-            take_step(-1);                                   // last step was no improvement: back track, GDO.cc:58-61
-            const double eps = t.new_sim > t.old_sim ? t.new_sim - t.old_sim : 0;
-            double max_change = 0;
-            for (int i = 0; i < 6; ++i) max_change = std::max(max_change, fabs(t.p[i] - t.start[i]));
-            bool next_step = true;                           // IR.cc:482-506
-            if (eps > p0.epsilon && max_change > t.delta) {
-              if (++t.iter_j < p0.iterations[level]) next_step = false;
-            }
-            if (next_step) {
-              t.iter_j = 0;
-              t.step = t.step / 2;
-              t.delta = t.delta / 2.0;
-              if (++t.step_i >= p0.steps[level]) t.done = true;
-            }
-            t.phase = PH_START;
+            request(t.matrix);
           }
         }
-      }
+      });
+      const double te = now();
+      if (be.evaluate(n_planes, idx.data(), mats.data(), sums.data())) { err = "svr_ncc_evaluate failed"; return 2; }
+      t_eval += now() - te; ++rounds;
+      if (n_eval) *n_eval += (long)n_req;
+      over_live(600, [&](int l0, int l1) {
+        for (int l = l0; l < l1; ++l) {
+          Target &t = targets[live[l]];
+          const int nz = t.lvl.a.nz, nr = t.phase == PH_GRAD ? 12 : 1;
+          for (int q = 0; q < nr; ++q) {
+            int64_t sacc[6] = {0, 0, 0, 0, 0, 0};
+            const size_t at = (size_t)plane_off[l] + (size_t)q * nz;
+            for (int c = 0; c < nz; ++c) for (int k = 0; k < 6; ++k) sacc[k] += sums[6 * (at + c) + k];
+            value[req_off[l] + q] = ncc_from_sums(sacc);
+          }
+          size_t r = req_off[l];
+          auto take_step = [&](double sign) {                // Put(i, Get(i) +- StepSize * dx[i]) for every i
+            for (int i = 0; i < 6; ++i) t.p[i] = t.p[i] + sign * (t.step * t.dx[i]);
+            t.matrix = params_to_matrix(t.p);
+          };
+          if (t.phase == PH_START) {
+            t.old_sim = t.new_sim = t.sim = value[r++];
+            for (int i = 0; i < 6; ++i) t.start[i] = t.p[i];   // irtkOptimizer::Run stores the parameters, O.cc:113-116
+            t.phase = PH_GRAD;
+          } else if (t.phase == PH_GRAD) {
+            double norm = 0;
+            for (int i = 0; i < 6; ++i) { const double s1 = value[r++], s2 = value[r++]; t.dx[i] = (float)(s1 - s2); }
+            t.matrix = params_to_matrix(t.p);                  // Put(i, parameterValue) rebuilt the matrix from the parameters
+            for (int i = 0; i < 6; ++i) norm += t.dx[i] * t.dx[i];
+            norm = sqrt(norm);
+            for (int i = 0; i < 6; ++i) t.dx[i] = norm > 0 ? (float)(t.dx[i] / norm) : 0.0f;
+            t.new_sim = t.sim;                                 // first pass of the do-while, GDO.cc:47-54
+            take_step(+1);
+            t.phase = PH_LINE;
+          } else {
+            t.sim = value[r++];
+            if (t.sim > t.new_sim + p0.epsilon) {              // keep stepping
+              t.new_sim = t.sim;
+              take_step(+1);
+            } else {
+              take_step(-1);                                   // last step was no improvement: back track, GDO.cc:58-61
+              const double eps = t.new_sim > t.old_sim ? t.new_sim - t.old_sim : 0;
+              double max_change = 0;
+              for (int i = 0; i < 6; ++i) max_change = std::max(max_change, fabs(t.p[i] - t.start[i]));
+              bool next_step = true;                           // IR.cc:482-506
+              if (eps > p0.epsilon && max_change > t.delta) {
+                if (++t.iter_j < p0.iterations[level]) next_step = false;
+              }
+              if (next_step) {
+                t.iter_j = 0;
+                t.step = t.step / 2;
+                t.delta = t.delta / 2.0;
+                if (++t.step_i >= p0.steps[level]) t.done = true;
+              }
+              t.phase = PH_START;
+            }
+          }
+        }
+      });
     }
     t_opt += now() - t0;
   }

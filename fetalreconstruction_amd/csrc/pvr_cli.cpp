@@ -44,8 +44,8 @@ void match_stack_intensities_pvr(std::vector<Image> &stacks, const std::vector<M
       if (v > 0) { average += (float)v; count++; }
   if (count) average /= count;
   const M4 mw2i = world_to_image(mask.a);
-  std::vector<double> avg;
-  for (size_t s = 0; s < stacks.size(); ++s) {
+  std::vector<double> avg(stacks.size());
+  parallel_for((int)stacks.size(), [&](int s) {             // a stack per host thread; the sums of a stack keep the reference's order
     const Image &st = stacks[s];
     const M4 s_i2w = image_to_world(st.a);
     double sum = 0, num = 0;
@@ -62,8 +62,8 @@ void match_stack_intensities_pvr(std::vector<Image> &stacks, const std::vector<M
           }
         }
     if (!(num > 0)) die("a stack has no overlap with the ROI");
-    avg.push_back(sum / num);
-  }
+    avg[s] = sum / num;
+  });
   for (size_t s = 0; s < stacks.size(); ++s) {
     const double f = average / avg[s];
     for (double &v : stacks[s].d) if (v > 0) v = (double)(float)(v * f);      // float voxels times a double factor

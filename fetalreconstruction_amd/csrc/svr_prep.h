@@ -123,6 +123,19 @@ svr_image_attr create_template(const svr_image_attr &stack, double &resolution) 
 }
 
 // irtkGaussianBlurring<irtkRealPixel>(sigma).Run() (irtkGaussianBlurring.cc:40-125, irtkConvolution_1D.cc:42-90)
+// fn(i) for i in [0, n) on the host threads (at most 32), items handed out one at a time; every item writes its own output,
+// so the results do not depend on the thread count.  The grids of the fine cases have 10^7..10^8 voxels.
+inline void parallel_for(int n, const std::function<void(int)> &fn) {
+  const unsigned nt = std::max(1u, std::min<unsigned>({std::thread::hardware_concurrency(), 32u, (unsigned)std::max(n, 1)}));
+  if (nt < 2 || n < 2) { for (int i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<int> next{0};
+  auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+}
+
 void gaussian_blur(Image &im, double sigma) {
   const svr_image_attr &a = im.a;
   const int n[3] = {a.nx, a.ny, a.nz};
@@ -135,7 +148,7 @@ void gaussian_blur(Image &im, double sigma) {
     std::vector<double> k(2 * half + 1);
     for (int t = -half; t <= half; ++t) k[t + half] = exp(-(double)(t * t) / (2.0 * s * s));
     std::vector<double> out(im.d.size());
-    for (int z = 0; z < a.nz; ++z)
+    parallel_for(a.nz, [&](int z) {
       for (int y = 0; y < a.ny; ++y)
         for (int x = 0; x < a.nx; ++x) {
           const int p[3] = {x, y, z};
@@ -149,6 +162,7 @@ void gaussian_blur(Image &im, double sigma) {
           }
           out[base] = sum > 0 ? val / sum : 0.0;
         }
+    });
     im.d.swap(out);
   }
 }
@@ -163,19 +177,6 @@ inline void apply_point(const M4 &m, double &x, double &y, double &z) {
 }
 
 // irtkImageTransformation + nearest neighbour, target padding -1 on an all-zero target (RG.cc:782-793, 808-819)
-// fn(i) for i in [0, n) on the host threads (at most 32), items handed out one at a time; every item writes its own output,
-// so the results do not depend on the thread count.  The grids of the fine cases have 10^7..10^8 voxels.
-inline void parallel_for(int n, const std::function<void(int)> &fn) {
-  const unsigned nt = std::max(1u, std::min<unsigned>({std::thread::hardware_concurrency(), 32u, (unsigned)std::max(n, 1)}));
-  if (nt < 2 || n < 2) { for (int i = 0; i < n; ++i) fn(i); return; }
-  std::atomic<int> next{0};
-  auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-  work();
-  for (auto &t : th) t.join();
-}
-
 Image transform_nn(const Image &src, const svr_image_attr &target, const M4 &t, double source_padding) {
   Image out;
   out.a = target;
@@ -267,8 +268,8 @@ Image crop_image(const Image &im, const Image &mask) {
 std::vector<float> match_stack_intensities(std::vector<Image> &stacks, const std::vector<M4> &ts, const Image &mask,
                                            double average_value, bool together) {
   const M4 mw2i = world_to_image(mask.a);
-  std::vector<double> avg;
-  for (size_t s = 0; s < stacks.size(); ++s) {
+  std::vector<double> avg(stacks.size());
+  parallel_for((int)stacks.size(), [&](int s) {             // a stack per host thread; the sums of a stack keep the reference's order
     const Image &st = stacks[s];
     const M4 s_i2w = image_to_world(st.a);
     double sum = 0, num = 0;
@@ -284,8 +285,8 @@ std::vector<float> match_stack_intensities(std::vector<Image> &stacks, const std
           }
         }
     if (!(num > 0)) die("a stack has no overlap with the ROI");
-    avg.push_back(sum / num);
-  }
+    avg[s] = sum / num;
+  });
   double glob = 0;
   for (double v : avg) glob += v;
   glob /= (double)avg.size();
