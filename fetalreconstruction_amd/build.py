@@ -12,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "svr_hip.hip")
 SRC_REG = os.path.join(HERE, "csrc", "svr_reg.inc")       # GPU registration, #included by svr_hip.hip
+SRC_PYR = os.path.join(HERE, "csrc", "svr_pyr.inc")       # device pyramid of the IRTK registration, #included by svr_hip.hip
 SRC_HOST = os.path.join(HERE, "csrc", "svr_host.cpp")     # plain host C++ (the irtkReconstruction mirror)
 SRC_IO = os.path.join(HERE, "csrc", "svr_io.cpp")         # NIfTI-1 reader / writer (zlib)
 SRC_PVR_HOST = os.path.join(HERE, "csrc", "pvr_host.cpp")  # the irtkPatchBasedReconstruction loop (host C++)
@@ -49,7 +50,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_PYR, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
                                                __file__)) or not (os.path.exists(CLI) and os.path.exists(PVR_CLI))
 
 

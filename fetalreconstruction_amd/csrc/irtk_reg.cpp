@@ -26,6 +26,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <map>
+#include <tuple>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -63,9 +65,7 @@ class WorkPool {
 
  private:
   WorkPool() {
-    unsigned hw = std::thread::hardware_concurrency();
-    int n = (int)std::min<unsigned>(hw ? hw : 1, 128u);
-    if (const char *e = getenv("SVR_HOST_THREADS")) n = std::max(1, atoi(e));
+    const int n = std::min(svr_host_threads(), 128);          // the CPUs this process may actually use (affinity, cgroup quota)
     pid_ = getpid();
     for (int i = 1; i < n; ++i) workers_->emplace_back([this] { loop(); });
   }
@@ -132,11 +132,11 @@ template <> short put_as_double<short>(double v) {
 template <> double put_as_double<double>(double v) { return v; }
 
 // irtkResamplingWithPadding<T>(rx, ry, rz, pad).Run(), RWP.cc:202-443
-template <class T> Vol<T> resample_with_padding(const Vol<T> &in, double rx, double ry, double rz, T pad) {
-  Vol<T> out;
-  out.a = in.a;
-  const double want[3] = {rx, ry, rz}, old[3] = {in.a.dx, in.a.dy, in.a.dz};
-  const int n_old[3] = {in.a.nx, in.a.ny, in.a.nz};
+// the grid irtkResamplingWithPadding gives an image (RWP.cc:202-240)
+svr_image_attr resampled_attr(const svr_image_attr &in, double rx, double ry, double rz) {
+  svr_image_attr out = in;
+  const double want[3] = {rx, ry, rz}, old[3] = {in.dx, in.dy, in.dz};
+  const int n_old[3] = {in.nx, in.ny, in.nz};
   int n_new[3];
   double d_new[3];
   for (int k = 0; k < 3; ++k) {
@@ -144,8 +144,14 @@ template <class T> Vol<T> resample_with_padding(const Vol<T> &in, double rx, dou
     d_new[k] = want[k];
     if (n_new[k] < 1) { n_new[k] = 1; d_new[k] = old[k]; }
   }
-  out.a.nx = n_new[0]; out.a.ny = n_new[1]; out.a.nz = n_new[2];
-  out.a.dx = d_new[0]; out.a.dy = d_new[1]; out.a.dz = d_new[2];
+  out.nx = n_new[0]; out.ny = n_new[1]; out.nz = n_new[2];
+  out.dx = d_new[0]; out.dy = d_new[1]; out.dz = d_new[2];
+  return out;
+}
+
+template <class T> Vol<T> resample_with_padding(const Vol<T> &in, double rx, double ry, double rz, T pad) {
+  Vol<T> out;
+  out.a = resampled_attr(in.a, rx, ry, rz);
   out.d.assign(out.n(), pad);
   const M4 o_i2w = image_to_world(out.a), i_w2i = world_to_image(in.a);
   const int X = in.a.nx, Y = in.a.ny, Z = in.a.nz;
@@ -183,6 +189,20 @@ template <class T> Vol<T> resample_with_padding(const Vol<T> &in, double rx, dou
   return out;
 }
 
+// the sampled Gaussian of one pass of irtkGaussianBlurringWithPadding (GBWP.cc:60-120): sigma in mm, vs = the voxel size along the axis
+std::vector<double> blur_kernel(double sigma, double vs) {
+  const double s = sigma / vs;
+  const int size = 2 * (int)irtk_round(4 * sigma / vs) + 1;
+  std::vector<double> ker(size);                          // irtkScalarGaussian(s, 1, 1, 0, 0, 0) sampled at i - (size-1)/2
+  const double norm = 1.0 / (sqrt(2.0 * M_PI) * s * sqrt(2.0 * M_PI) * 1 * sqrt(2.0 * M_PI) * 1);
+  for (int i = 0; i < size; ++i) {
+    const double x = i - (size - 1) / 2.0;
+    ker[i] = norm * exp(-(x * x) / (2.0 * s * s) - 0.0 - 0.0);
+    if (fabs(ker[i]) < FLT_MIN) ker[i] = 0;               // irtkScalarFunctionToImage.cc:89-92
+  }
+  return ker;
+}
+
 // irtkGaussianBlurringWithPadding<short>(sigma, pad).Run(): three 1-D passes, each rounded (truncated) back to short
 void blur_with_padding(Vol<short> &im, double sigma, short pad) {
   const int n[3] = {im.a.nx, im.a.ny, im.a.nz};
@@ -190,15 +210,8 @@ void blur_with_padding(Vol<short> &im, double sigma, short pad) {
   const ptrdiff_t stride[3] = {1, (ptrdiff_t)im.a.nx, (ptrdiff_t)im.a.nx * im.a.ny};
   for (int axis = 0; axis < 3; ++axis) {
     if (axis == 2 && im.a.nz == 1) continue;             // GBWP.cc:90
-    const double s = sigma / vs[axis];
-    const int size = 2 * (int)irtk_round(4 * sigma / vs[axis]) + 1, half = size / 2;
-    std::vector<double> ker(size);                        // irtkScalarGaussian(s, 1, 1, 0, 0, 0) sampled at i - (size-1)/2
-    const double norm = 1.0 / (sqrt(2.0 * M_PI) * s * sqrt(2.0 * M_PI) * 1 * sqrt(2.0 * M_PI) * 1);
-    for (int i = 0; i < size; ++i) {
-      const double x = i - (size - 1) / 2.0;
-      ker[i] = norm * exp(-(x * x) / (2.0 * s * s) - 0.0 - 0.0);
-      if (fabs(ker[i]) < FLT_MIN) ker[i] = 0;             // irtkScalarFunctionToImage.cc:89-92
-    }
+    const std::vector<double> ker = blur_kernel(sigma, vs[axis]);
+    const int size = (int)ker.size(), half = size / 2;
     std::vector<short> out(im.d.size());
     parallel_rows(n[2] * n[1], (size_t)n[0] * size, [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r) {
@@ -342,6 +355,46 @@ double ncc_from_sums(const int64_t s[6]) {                 // irtkCrossCorrelati
   return 0;
 }
 
+// One level of prepare_level on the device (csrc/svr_pyr.inc) for `n` images of one grid whose unprocessed voxels sit at
+// `offset` of the upload slot: the attributes of the level come back in out[i], the voxels stay on the device as the NCC
+// source (slot 0) or as the target planes first_plane, first_plane + nz, ...
+int device_level(svr_ctx *ctx, int slot, size_t offset, int n, const svr_image_attr *const *in, const short *pads, double blur, const double res[3],
+                 const double res0[3], int level, int first_plane, svr_image_attr *out, std::string &err) {
+  const svr_image_attr &a0 = *in[0];
+  std::vector<double> ker[3];
+  if (blur > 0) {
+    ker[0] = blur_kernel(blur, a0.dx); ker[1] = blur_kernel(blur, a0.dy);
+    if (a0.nz != 1) ker[2] = blur_kernel(blur, a0.dz);     // GBWP.cc:90
+  }
+  const double temp = fabs(res0[0] - a0.dx) + fabs(res0[1] - a0.dy) + fabs(res0[2] - a0.dz);
+  const int resample = level > 0 || temp > 0.000001;
+  std::vector<svr_pyr_image> imgs(n);
+  for (int i = 0; i < n; ++i) {
+    out[i] = resample ? resampled_attr(*in[i], res[0], res[1], res[2]) : *in[i];
+    const M4 o_i2w = image_to_world(out[i]), i_w2i = world_to_image(*in[i]);
+    memcpy(imgs[i].i2w_out, o_i2w.m, sizeof(imgs[i].i2w_out));
+    memcpy(imgs[i].w2i_in, i_w2i.m, sizeof(imgs[i].w2i_in));
+    imgs[i].pad = pads[i];
+  }
+  const int in_dims[3] = {a0.nx, a0.ny, a0.nz}, out_dims[3] = {out[0].nx, out[0].ny, out[0].nz};
+  std::vector<int> mn(n), mx(n);
+  if (svr_pyr_level(ctx, slot, offset, n, in_dims, ker[0].data(), (int)ker[0].size(), ker[1].data(), (int)ker[1].size(), ker[2].data(),
+                    (int)ker[2].size(), resample, out_dims, imgs.data(), first_plane, mn.data(), mx.data())) {
+    err = std::string("svr_pyr_level: ") + svr_last_error(ctx);
+    return 2;
+  }
+  for (int i = 0; i < n; ++i)
+    if ((double)mx[i] - (double)mn[i] > 32767.0) { err = "Initialize: dynamic range of an image is too large"; return 1; }
+  return 0;
+}
+
+struct GridKey {
+  int nx, ny, nz;
+  double dx, dy, dz;
+  bool operator<(const GridKey &o) const { return std::tie(nx, ny, nz, dx, dy, dz) < std::tie(o.nx, o.ny, o.nz, o.dx, o.dy, o.dz); }
+};
+struct GridGroup { std::vector<int> members; size_t offset = 0; };
+
 // irtkImageRegistration::Run for every target against one source, in lock step
 int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol<short> &source, int slice_to_volume, short target_padding,
                       long *n_eval, std::string &err) {
@@ -351,18 +404,77 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
   double t_src = 0, t_tgt = 0, t_pack = 0, t_opt = 0, t_eval = 0;
   long rounds = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  // The engine makes the pyramids itself (csrc/svr_pyr.inc: the same arithmetic, no host pass over the voxels, no upload
+  // per level); another backend (the oracle evaluator of the tests), or SVR_HOST_PYRAMID=1, takes the host code below.
+  const bool dev = !be.be && be.ctx && !getenv("SVR_HOST_PYRAMID");
+  std::map<GridKey, GridGroup> groups;                    // targets of one grid go through the kernels together
+  if (dev) {
+    if (svr_pyr_upload(be.ctx, 0, source.d.data(), source.n())) { err = std::string("svr_pyr_upload: ") + svr_last_error(be.ctx); return 2; }
+    size_t total = 0;
+    for (size_t r = 0; r < targets.size(); ++r) {
+      const svr_image_attr &a = targets[r].full->a;
+      groups[GridKey{a.nx, a.ny, a.nz, a.dx, a.dy, a.dz}].members.push_back((int)r);
+      total += targets[r].full->n();
+    }
+    std::vector<int16_t> all(total);
+    size_t at = 0;
+    for (auto &g : groups) {
+      g.second.offset = at;
+      for (int r : g.second.members) { memcpy(&all[at], targets[r].full->d.data(), sizeof(int16_t) * targets[r].full->n()); at += targets[r].full->n(); }
+    }
+    if (svr_pyr_upload(be.ctx, 1, all.data(), total)) { err = std::string("svr_pyr_upload: ") + svr_last_error(be.ctx); return 2; }
+  }
   for (int level = 2; level >= 0; --level) {
     double t0 = now();
     // ---- Initialize(level): every target and the source -------------------------------------------------------------
     Vol<short> src;
     const Schedule ps = guess_parameters(targets[0].full->a, source.a, slice_to_volume);
-    if (prepare_level(source, ps.s_blur[level], ps.s_res[level], ps.s_res[0], level, source_padding, src, err)) return 1;
+    if (dev) {
+      const svr_image_attr *in = &source.a;
+      if (int rc = device_level(be.ctx, 0, 0, 1, &in, &source_padding, ps.s_blur[level], ps.s_res[level], ps.s_res[0], level, 0, &src.a, err)) return rc;
+    } else if (prepare_level(source, ps.s_blur[level], ps.s_res[level], ps.s_res[0], level, source_padding, src, err)) return 1;
     t_src += now() - t0; t0 = now();
     int tx = 0, ty = 0, planes = 0;
     std::vector<int> bad(targets.size(), 0);
     std::vector<std::string> errs(targets.size());
     size_t pixels = 0;
     for (const Target &t : targets) pixels += t.full->n();
+    if (dev) {
+      // the grids of the level first (the planes must be allocated before the kernels write them), group by group
+      for (auto &g : groups)
+        for (int r : g.second.members) {
+          Target &t = targets[r];
+          const Schedule p = guess_parameters(t.full->a, source.a, slice_to_volume);
+          const double temp = fabs(p.t_res[0][0] - t.full->a.dx) + fabs(p.t_res[0][1] - t.full->a.dy) + fabs(p.t_res[0][2] - t.full->a.dz);
+          t.lvl.a = (level > 0 || temp > 0.000001) ? resampled_attr(t.full->a, p.t_res[level][0], p.t_res[level][1], p.t_res[level][2]) : t.full->a;
+          t.lvl.d.clear();
+          t.phase = PH_START; t.step_i = 0; t.iter_j = 0; t.done = false;
+          t.step = p.length[level]; t.delta = p.delta[level];
+          tx = std::max(tx, t.lvl.a.nx); ty = std::max(ty, t.lvl.a.ny);
+          t.first_plane = planes;
+          planes += t.lvl.a.nz;
+        }
+      if (svr_ncc_alloc_targets(be.ctx, planes, tx, ty)) { err = std::string("svr_ncc_alloc_targets: ") + svr_last_error(be.ctx); return 2; }
+      for (auto &g : groups) {
+        const std::vector<int> &mem = g.second.members;
+        const Schedule p = guess_parameters(targets[mem[0]].full->a, source.a, slice_to_volume);
+        const size_t nvox = targets[mem[0]].full->n();
+        for (size_t c0 = 0; c0 < mem.size(); c0 += 32768) {                        // the grid's y dimension holds 65535 images
+          const int n = (int)std::min<size_t>(32768, mem.size() - c0);
+          std::vector<const svr_image_attr *> in(n);
+          std::vector<short> pads(n);
+          std::vector<svr_image_attr> outa(n);
+          for (int i = 0; i < n; ++i) {
+            const Target &t = targets[mem[c0 + i]];
+            in[i] = &t.full->a;
+            pads[i] = t.own_padding ? t.padding : target_padding;
+          }
+          if (int rc = device_level(be.ctx, 1, g.second.offset + c0 * nvox, n, in.data(), pads.data(), p.t_blur[level], p.t_res[level], p.t_res[0], level,
+                                    targets[mem[c0]].first_plane, outa.data(), err))
+            return rc;
+        }
+      }
+    } else
     parallel_rows((int)targets.size(), pixels / targets.size() * 60, [&](int r0, int r1) {
       for (int r = r0; r < r1; ++r) {
         Target &t = targets[r];
@@ -374,22 +486,24 @@ int run_registrations(const Backend &be, std::vector<Target> &targets, const Vol
       }
     });
     t_tgt += now() - t0; t0 = now();
-    for (size_t r = 0; r < targets.size(); ++r) {
-      if (bad[r]) { err = errs[r]; return 1; }
-      Target &t = targets[r];
-      tx = std::max(tx, t.lvl.a.nx); ty = std::max(ty, t.lvl.a.ny);
-      t.first_plane = planes;
-      planes += t.lvl.a.nz;
+    if (!dev) {
+      for (size_t r = 0; r < targets.size(); ++r) {
+        if (bad[r]) { err = errs[r]; return 1; }
+        Target &t = targets[r];
+        tx = std::max(tx, t.lvl.a.nx); ty = std::max(ty, t.lvl.a.ny);
+        t.first_plane = planes;
+        planes += t.lvl.a.nz;
+      }
+      std::vector<int16_t> packed((size_t)planes * tx * ty, (int16_t)-1);
+      for (const Target &t : targets)
+        for (int k = 0; k < t.lvl.a.nz; ++k)
+          for (int y = 0; y < t.lvl.a.ny; ++y)
+            memcpy(&packed[((size_t)(t.first_plane + k) * ty + y) * tx], &t.lvl.d[((size_t)k * t.lvl.a.ny + y) * t.lvl.a.nx],
+                   sizeof(int16_t) * t.lvl.a.nx);
+      if (be.set_targets(planes, tx, ty, packed.data())) { err = "svr_ncc_set_targets failed"; return 2; }
+      const uint32_t ssz[3] = {(uint32_t)src.a.nx, (uint32_t)src.a.ny, (uint32_t)src.a.nz};
+      if (be.set_source(ssz, src.d.data())) { err = "svr_ncc_set_source failed"; return 2; }
     }
-    std::vector<int16_t> packed((size_t)planes * tx * ty, (int16_t)-1);
-    for (const Target &t : targets)
-      for (int k = 0; k < t.lvl.a.nz; ++k)
-        for (int y = 0; y < t.lvl.a.ny; ++y)
-          memcpy(&packed[((size_t)(t.first_plane + k) * ty + y) * tx], &t.lvl.d[((size_t)k * t.lvl.a.ny + y) * t.lvl.a.nx],
-                 sizeof(int16_t) * t.lvl.a.nx);
-    if (be.set_targets(planes, tx, ty, packed.data())) { err = "svr_ncc_set_targets failed"; return 2; }
-    const uint32_t ssz[3] = {(uint32_t)src.a.nx, (uint32_t)src.a.ny, (uint32_t)src.a.nz};
-    if (be.set_source(ssz, src.d.data())) { err = "svr_ncc_set_source failed"; return 2; }
     const M4 s_w2i = world_to_image(src.a);
     const Schedule p0 = ps;
     t_pack += now() - t0; t0 = now();

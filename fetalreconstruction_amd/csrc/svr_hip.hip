@@ -2818,6 +2818,10 @@ struct svr_ctx {
 
   // registration cost (NCC)
   short *d_reg_targets = nullptr, *d_reg_source = nullptr;
+  short *d_pyr_full[2] = {nullptr, nullptr}, *d_pyr_a = nullptr, *d_pyr_b = nullptr;   // device pyramid of the registration (svr_pyr_*)
+  size_t pyr_full_cap[2] = {0, 0}, pyr_work_cap = 0;
+  void *d_pyr_meta = nullptr;
+  size_t pyr_meta_cap = 0;
   int *d_ncc_idx = nullptr;              // grow-only scratch of svr_ncc_evaluate
   double *d_ncc_m = nullptr;
   long long *d_ncc_s = nullptr;
@@ -3404,6 +3408,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_bias_vol); free_dev(ctx->d_volume_weights); free_dev(ctx->d_maskC); free_dev(ctx->d_mbuf);
   free_dev(ctx->d_reg_targets);
   free_dev(ctx->d_reg_source);
+  free_dev(ctx->d_pyr_full[0]); free_dev(ctx->d_pyr_full[1]); free_dev(ctx->d_pyr_a); free_dev(ctx->d_pyr_b); free_dev(ctx->d_pyr_meta);
   free_dev(ctx->d_ncc_idx); free_dev(ctx->d_ncc_m); free_dev(ctx->d_ncc_s);
   free_dev(ctx->d_coeff); free_dev(ctx->d_coeff_id);
   reg_free(ctx->reg);
@@ -4479,3 +4484,4 @@ int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
 }  // extern "C"
 
 #include "svr_reg.inc"
+#include "svr_pyr.inc"

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -297,7 +298,7 @@ int svr_nifti_write(const char *path, const svr_image_attr *attr, const float *d
         if (rc != Z_STREAM_END) { good = false; return; }
       }
     };
-    const unsigned nt = std::max(1u, std::min<unsigned>({std::thread::hardware_concurrency(), 32u, (unsigned)pieces}));
+    const unsigned nt = std::max(1u, std::min<unsigned>({(unsigned)svr_host_threads(), 32u, (unsigned)pieces}));
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
     work();
@@ -328,6 +329,28 @@ int svr_nifti_write(const char *path, const svr_image_attr *attr, const float *d
   bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(pad, 1, 4, f) == 4 && fwrite(data, sizeof(float), n, f) == n;
   ok = (fclose(f) == 0) && ok;
   return ok ? SVR_OK : set_err(err, "write failed");
+}
+
+int svr_host_threads(void) {
+  static const int cached = [] {
+    if (const char *e = getenv("SVR_HOST_THREADS")) return std::max(1, atoi(e));
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n < 1) n = 1;
+    double quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+      char q[64] = {0};
+      if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+      fclose(f);
+    } else {
+      if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lf", &quota) != 1) quota = -1; fclose(fq); }
+      if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lf", &period) != 1) period = -1; fclose(fp); }
+    }
+    if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)(quota / period + 0.5)));
+    return n;
+  }();
+  return cached;
 }
 
 // IRTK rigid `dof` files (irtkRigidTransformation::Read / Write, IRTKSimple2/packages/transformation/src/

@@ -123,10 +123,10 @@ svr_image_attr create_template(const svr_image_attr &stack, double &resolution) 
 }
 
 // irtkGaussianBlurring<irtkRealPixel>(sigma).Run() (irtkGaussianBlurring.cc:40-125, irtkConvolution_1D.cc:42-90)
-// fn(i) for i in [0, n) on the host threads (at most 32), items handed out one at a time; every item writes its own output,
+// fn(i) for i in [0, n) on the host threads (svr_host_threads(), at most 32), items handed out one at a time; every item writes its own output,
 // so the results do not depend on the thread count.  The grids of the fine cases have 10^7..10^8 voxels.
 inline void parallel_for(int n, const std::function<void(int)> &fn) {
-  const unsigned nt = std::max(1u, std::min<unsigned>({std::thread::hardware_concurrency(), 32u, (unsigned)std::max(n, 1)}));
+  const unsigned nt = std::max(1u, std::min<unsigned>({(unsigned)svr_host_threads(), 32u, (unsigned)std::max(n, 1)}));
   if (nt < 2 || n < 2) { for (int i = 0; i < n; ++i) fn(i); return; }
   std::atomic<int> next{0};
   auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };

@@ -39,7 +39,7 @@ EXPORTS = [
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
     "svr_timer_reset", "svr_timer_enable", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
-    "svr_ncc_evaluate", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
+    "svr_ncc_evaluate", "svr_ncc_alloc_targets", "svr_pyr_upload", "svr_pyr_level", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
     "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches", "svr_pvr_register_patches",

@@ -28,7 +28,7 @@ PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_init
                     "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_register_patches", "pvrh_get_state"]      # csrc/pvr_host.cpp
 IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_package_to_volume", "svrh_irtk_resample_with_padding",
                 "svrh_irtk_blur_with_padding", "svrh_irtk_rigid_parameters"]                                  # csrc/irtk_reg.cpp
-IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write"]      # csrc/svr_io.cpp, declared in svr_host.h
+IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write", "svr_host_threads"]      # csrc/svr_io.cpp, declared in svr_host.h
 
 
 class ImageAttr(C.Structure):

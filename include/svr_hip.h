@@ -213,6 +213,26 @@ int svr_scale_volume_apply(svr_ctx *ctx, float scale);
  * matrices: per evaluation a row-major double 4x4 = sourceW2I * T * targetI2W
  * (irtkHomogeneousTransformationIterator.h:96).  sums6 = {n, sum t, sum s, sum t^2, sum s^2, sum t*s}. */
 int svr_ncc_set_targets(svr_ctx *ctx, int n, int tx, int ty, const int16_t *targets);
+/* The image pyramid of the same registration on the device (irtkImageRegistrationWithPadding::Initialize(level),
+ * irtkImageRegistrationWithPadding.cc:28-334, for one image: irtkGaussianBlurringWithPadding<short> -- three 1-D passes, each
+ * truncated back to short --, irtkResamplingWithPadding<short>, the shift of the range to start at 0 and padding -1), in the
+ * reference's double arithmetic operation for operation, so that the levels are the ones the host code of csrc/irtk_reg.cpp
+ * makes.  svr_pyr_upload keeps the unprocessed images of a registration pass on the device (slot 0: the source volume,
+ * slot 1: the targets, images of one grid back to back); svr_pyr_level makes one level of `n_images` images of one grid
+ * starting at element `offset` of the slot and leaves them where svr_ncc_evaluate reads them: slot 0 -> the NCC source
+ * (n_images must be 1), slot 1 -> the target planes from `first_plane` on (svr_ncc_alloc_targets first).
+ * kernel_x/y/z: the sampled Gaussian of each pass (size 0 = no pass on that axis); resample 0 = the level keeps the grid.
+ * min_out / max_out[n_images]: range of the values above the padding before the shift (max < min: none). */
+typedef struct svr_pyr_image {
+  double i2w_out[12];   /* rows 0..2 of the image-to-world matrix of the level's grid */
+  double w2i_in[12];    /* rows 0..2 of the world-to-image matrix of the unprocessed grid */
+  int pad;              /* the image's padding value */
+} svr_pyr_image;
+int svr_ncc_alloc_targets(svr_ctx *ctx, int n, int tx, int ty);
+int svr_pyr_upload(svr_ctx *ctx, int slot, const int16_t *images, size_t count);
+int svr_pyr_level(svr_ctx *ctx, int slot, size_t offset, int n_images, const int in_dims[3], const double *kernel_x, int size_x,
+                  const double *kernel_y, int size_y, const double *kernel_z, int size_z, int resample, const int out_dims[3],
+                  const svr_pyr_image *images, int first_plane, int *min_out, int *max_out);
 int svr_ncc_set_source(svr_ctx *ctx, const uint32_t size[3], const int16_t *source_or_null);
 int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const double *matrices,
                      int64_t *sums6_or_null, double *ncc_or_null);

@@ -134,6 +134,11 @@ void svr_free(void *p);
  * as doubles (irtkRigidTransformation.cc:392-451); matrix16_or_null = UpdateMatrix's 4x4 (:26-53), row-major. */
 int svr_dof_read(const char *path, double params6[6], double *matrix16_or_null, char err[256]);
 int svr_dof_write(const char *path, const double params6[6], char err[256]);
+/* The number of host threads worth starting: the CPUs of the affinity mask, cut to the cgroup's CPU quota (cpu.max, or
+ * cpu.cfs_quota_us / cpu.cfs_period_us) -- a container with 256 visible CPUs and a quota of 16 loses whole scheduler
+ * periods to throttling when a pool starts 128 threads.  SVR_HOST_THREADS overrides.  Used by the registration's work
+ * pool, the pre-processing of the command lines and the NIfTI writer. */
+int svr_host_threads(void);
 
 /* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
  * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s} */

@@ -205,6 +205,26 @@ def test_engine_and_oracle_evaluators_give_the_same_trajectory(tiny, oracle_mod,
     assert nev_d == nev_c and np.array_equal(dev, cpu)
 
 
+@pytest.mark.gpu
+def test_device_pyramid_is_the_host_pyramid(tiny, oracle_mod, monkeypatch):
+    """The engine blurs, resamples and re-ranges the three levels of every target and of the source on the device
+    (csrc/svr_pyr.inc); SVR_HOST_PYRAMID=1 makes them with the host code of csrc/irtk_reg.cpp and uploads them.  Same
+    integer moments, so the same decisions and the same matrices, for 2-D targets (slices) and 3-D targets (stacks)."""
+    from fetalreconstruction_amd import engine as E
+    vol, rattr, sel, T, P = _slice_case(tiny, oracle_mod)
+    rec = E.Reconstruction(0)
+    args = (tiny.slices[sel], [tiny.slice_attr[k] for k in sel], P, rattr, vol)
+    stacks, _, _ = _stacks()
+    sargs = ([s.data.astype(np.float64) for s in stacks], [s.attr for s in stacks], [np.eye(4)] * 2, 0)
+    dev, nev_d = host.SliceToVolumeRegistration(rec, *args)
+    sdev, snev_d = host.StackRegistrations(rec, *sargs)
+    monkeypatch.setenv("SVR_HOST_PYRAMID", "1")
+    cpu, nev_c = host.SliceToVolumeRegistration(rec, *args)
+    scpu, snev_c = host.StackRegistrations(rec, *sargs)
+    assert nev_d == nev_c and nev_d > 100 and np.array_equal(dev, cpu)
+    assert snev_d == snev_c and np.array_equal(sdev, scpu)
+
+
 # ---- packages (interleaved sub-stacks): PackageToVolume ------------------------------------------------------------------------
 def _package_case():
     """one axial stack acquired as 2 interleaved packages that moved differently, and the analytic volume"""
