@@ -54,3 +54,15 @@ def test_create_rejects_bad_arguments_without_gpu():
     assert lib.svr_last_error(None) == b"null context"
     assert lib.svr_volume_voxels(None) == 0
     assert lib.svr_device_ptr(None, 0) is None
+
+
+def test_host_threads_follow_the_override_and_the_cpu_quota():
+    """svr_host_threads(): the affinity mask cut to the cgroup CPU quota; SVR_HOST_THREADS overrides (read once per process)."""
+    import subprocess, sys, os
+    code = ("from fetalreconstruction_amd import engine; print(engine.load_library().svr_host_threads())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    plain = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, check=True).stdout)
+    assert 1 <= plain <= len(os.sched_getaffinity(0))
+    forced = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, check=True,
+                                env={**os.environ, "SVR_HOST_THREADS": "3"}).stdout)
+    assert forced == 3

@@ -316,6 +316,15 @@ def test_ragged_and_empty_inputs(oracle_mod):
     assert rel_err(rec.syncCPU(), orc.recon) < 1e-4
 
 
+def test_too_many_pixels_for_one_context_are_refused():
+    """Every launch of the path is a wavefront per pixel or per tile and a dispatch holds 2^32 - 1 work-items: 2^26 slice
+    pixels per context and beyond are refused loudly instead of being processed modulo 2^32."""
+    from fetalreconstruction_amd import engine as E
+    rec = E.Reconstruction(0)
+    with pytest.raises(E.SvrError, match="2\\^26"):
+        rec._ck(rec._lib.svr_init_storage_volumes(rec._h, E._p(np.array([4096, 4096, 4], np.uint32)), E._p(np.ones(3, np.float32))))
+
+
 @pytest.mark.parametrize("workload", ["P4", "S8"])
 def test_adjointness_at_full_size(workload):
     """Size-independent property on the full-size workloads (too big for the oracle) -- P4 = BASELINE.json configs[1]
