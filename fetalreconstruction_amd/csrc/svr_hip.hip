@@ -3342,7 +3342,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "fwd_unit_cap")) { ctx->fwd_unit_cap = std::max(2048, value); return SVR_OK; }
   if (!strcmp(name, "fwd_tile_w") || !strcmp(name, "fwd_tile_h")) {
     int w = !strcmp(name, "fwd_tile_w") ? value : ctx->fwd_tw, h = !strcmp(name, "fwd_tile_h") ? value : ctx->fwd_th;
-    if (w < 1 || h < 1 || w * h > 64) return fail(ctx, SVR_E_ARG, "fwd tile must hold 1..64 pixels");
+    if (w < 1 || h < 1 || w * h > 32) return fail(ctx, SVR_E_ARG, "fwd tile must hold 1..32 pixels");   // FWDU_MAXPIX: the gather's pixel tables
     ctx->fwd_tw = w; ctx->fwd_th = h; ctx->psf_list_valid = false;
     ctx->fwd_tile_user = true;                           // an explicit shape switches the tuning off
     return SVR_OK;
@@ -3804,13 +3804,13 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   const bool tiled = a.n && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1);
   if (tiled && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
     ctx->fwd_tune_pending = false;
-    static const int cand[5][2] = {{4, 4}, {6, 4}, {8, 4}, {4, 2}, {2, 2}};   // the first is the default; smaller boxes for finer volumes
+    static const int cand[6][2] = {{4, 4}, {6, 4}, {6, 5}, {8, 4}, {4, 2}, {2, 2}};   // the first is the default; smaller boxes for finer volumes (at most FWDU_MAXPIX = 32 pixels)
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     float best = 3.0e38f;
     int pick = 0;
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < 6; ++c) {
       ctx->fwd_tw = cand[c][0]; ctx->fwd_th = cand[c][1]; ctx->psf_list_valid = false;
       r = ensure_psf_list(ctx);
       if (r) return r;
@@ -3985,74 +3985,68 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     ctx->in_tune = true;
     // with the coefficient table the pass waits for memory, not for the ALUs: larger tiles (fewer flushed voxels per
     // pixel) are tried first, with the largest box, before the box sizes are timed for the shape that won
-    static const int cand_eval[3][2] = {{4, 4}, {4, 2}, {2, 2}};
+    static const int cand_eval[6][2] = {{6, 5}, {6, 4}, {5, 4}, {4, 4}, {4, 2}, {2, 2}};   // the first four always, then smaller ones while they win
     static const int cand_tab[5][2] = {{8, 4}, {6, 4}, {4, 4}, {4, 2}, {2, 2}};
     const bool tab = ctx->coeff_mode && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode == 4);
     const int (*cand)[2] = tab ? cand_tab : cand_eval;
-    const int ncand = tab ? 5 : 3;
+    const int ncand = tab ? 5 : 6;
     const int cap0 = ctx->wave_cap;
-    if (tab && !ctx->wave_cap_user) ctx->wave_cap = 2416;
     const auto timing = ctx->timers;
     ctx->timers = false;                                 // the trial runs stay out of the kernel timers
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    float best = 3.0e38f;
-    int pick = 0;
-    for (int c = 0; c < ncand && !r; ++c) {
-      r = svr_set_option(ctx, "tile_w", cand[c][0]);
-      if (!r) r = svr_set_option(ctx, "tile_h", cand[c][1]);
-      if (!r) r = ensure_psf_list(ctx);                  // the list of this shape, so that the trial below finds it valid
-      TileSample sample;
-      if (!r) r = sample.begin(ctx, ctx->d_tiles, ctx->n_tiles);
-      float ms = 0.0f;
-      for (int rep = 0; rep < 2 && !r; ++rep) {          // the second run is the one that counts
+    // one trial: the whole-launch time of the current shape with box `cap` (two runs, the second one counts)
+    auto trial = [&](int cap, TileSample &sample, float &ms) -> int {
+      ctx->wave_cap = cap;
+      int rr = SVR_OK;
+      ms = 0.0f;
+      for (int rep = 0; rep < 2 && !rr; ++rep) {
         hipError_t he = hipEventRecord(e0, ctx->stream);
-        r = svr_superresolution_backproject(ctx, nullptr);
+        rr = svr_superresolution_backproject(ctx, nullptr);
         if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
         if (he == hipSuccess) he = hipEventSynchronize(e1);
         if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
-        if (!r && he != hipSuccess) r = fail(ctx, (int)he, std::string("tile tuning: ") + hipGetErrorString(he));
+        if (!rr && he != hipSuccess) rr = fail(ctx, (int)he, std::string("tile tuning: ") + hipGetErrorString(he));
+      }
+      ms *= sample.scale;
+      return rr;
+    };
+    // the wave-owned scatter's LDS request decides how many wavefronts a CU holds; the smallest box that still takes
+    // (nearly) every tile wins -- tiles that do not fit are re-run by the workgroup kernel, so any value is correct.
+    // LDS is handed out in 1280-byte granules (measured: the time steps between 1764 and 1850 box voxels, not where
+    // 160 KiB / request changes), so a CU holds floor(128 / granules) wavefronts: the candidates are the largest boxes
+    // (with the kernel's 1152 static bytes) that still give 8, 9, 10, 11 and 12 of them.  A larger tile flushes fewer
+    // voxels per pixel but needs the larger box, so shape and box are timed together: per shape the boxes from the
+    // largest down while they get faster (6x4 with 2096 beats 6x5, which wins at 2416 and then cannot shrink).
+    static const int caps[5] = {2416, 2096, 1776, 1616, 1456};
+    const bool wave = (ctx->pvr || ctx->back_mode == 4) && !ctx->wave_cap_user;
+    float best = 3.0e38f;
+    int pick = 0, pick_cap = wave ? caps[0] : cap0;
+    for (int c = 0; c < ncand && !r; ++c) {
+      r = svr_set_option(ctx, "tile_w", cand[c][0]);
+      if (!r) r = svr_set_option(ctx, "tile_h", cand[c][1]);
+      if (!r) r = ensure_psf_list(ctx);                  // the list of this shape, so that the trials below find it valid
+      TileSample sample;
+      if (!r) r = sample.begin(ctx, ctx->d_tiles, ctx->n_tiles);
+      float shape_best = 3.0e38f;
+      for (int k = 0; k < (wave ? 5 : 1) && !r; ++k) {
+        float ms;
+        r = trial(wave ? caps[k] : cap0, sample, ms);
+        if (r) break;
+        if (getenv("SVR_TUNE_DEBUG"))
+          fprintf(stderr, "[tune] scatter %dx%d box %d: %.3f ms (whole launch; timed 1/%.1f of the tiles)\n", cand[c][0], cand[c][1], ctx->wave_cap, ms, sample.scale);
+        if (ms < best) { best = ms; pick = c; pick_cap = ctx->wave_cap; }
+        if (ms < shape_best) shape_best = ms;
+        else break;                                      // a smaller box stopped paying for this shape
       }
       sample.end();
       if (r) break;
-      ms *= sample.scale;
-      if (getenv("SVR_TUNE_DEBUG")) fprintf(stderr, "[tune] scatter %dx%d: %.3f ms (whole launch; timed 1/%.1f of the tiles)\n", cand[c][0], cand[c][1], ms, sample.scale);
-      if (ms < best) { best = ms; pick = c; }
-      else if (!tab) break;
+      if (shape_best > best && c >= (tab ? 4 : 3)) break;  // the small shapes only while they win
     }
-    if (tab && !ctx->wave_cap_user) ctx->wave_cap = cap0;
+    ctx->wave_cap = pick_cap;
     if (!r) r = svr_set_option(ctx, "tile_w", cand[pick][0]);
     if (!r) r = svr_set_option(ctx, "tile_h", cand[pick][1]);
-    if (!r && (ctx->pvr || ctx->back_mode == 4) && !ctx->wave_cap_user) {
-      // the wave-owned scatter's LDS request decides how many wavefronts a CU holds; the smallest box that still takes
-      // (nearly) every tile wins -- tiles that do not fit are re-run by the workgroup kernel, so any value is correct
-      // LDS is handed out in 1280-byte granules (measured: the time steps between 1764 and 1850 box voxels, not where
-      // 160 KiB / request changes), so a CU holds floor(128 / granules) wavefronts: the candidates are the largest boxes
-      // (with the kernel's 1152 static bytes) that still give 8, 9, 10, 11 and 12 of them
-      static const int caps[5] = {2416, 2096, 1776, 1616, 1456};
-      float bestc = 3.0e38f;
-      int pickc = ctx->wave_cap;
-      r = ensure_psf_list(ctx);
-      TileSample sample;
-      if (!r) r = sample.begin(ctx, ctx->d_tiles, ctx->n_tiles);
-      for (int c = 0; c < 5 && !r; ++c) {
-        ctx->wave_cap = caps[c];
-        float ms = 0.0f;
-        for (int rep = 0; rep < 2 && !r; ++rep) {
-          hipError_t he = hipEventRecord(e0, ctx->stream);
-          r = svr_superresolution_backproject(ctx, nullptr);
-          if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
-          if (he == hipSuccess) he = hipEventSynchronize(e1);
-          if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
-          if (!r && he != hipSuccess) r = fail(ctx, (int)he, std::string("tile tuning: ") + hipGetErrorString(he));
-        }
-        if (getenv("SVR_TUNE_DEBUG")) fprintf(stderr, "[tune] scatter box %d: %.3f ms (timed 1/%.1f of the tiles)\n", caps[c], ms, sample.scale);
-        if (ms < bestc) { bestc = ms; pickc = caps[c]; }
-      }
-      sample.end();
-      ctx->wave_cap = pickc;
-    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ctx->timers = timing;

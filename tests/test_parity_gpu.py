@@ -162,7 +162,7 @@ def test_gather_in_pieces(tiny, oracle_mod, monkeypatch):
     assert rec.counters()["Va"] // 32 > 3 * 48                               # several pieces even with the largest tiles (8 x 4)
     for k, (a, b) in enumerate(zip(*outs)):
         if k in (1, 2):                                                       # the volume comes out of float atomics (pass 2), the simulation reads it
-            assert rel_err(a, b) < 1e-6
+            assert rel_err(a, b) < TOL_SUM
         else:
             assert np.array_equal(a, b)
     run_to_state(do, "sim")
