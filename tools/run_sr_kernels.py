@@ -12,7 +12,8 @@ for a in args:
 d = irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity); d.SetSmoothingParameters(150, 0.02)
 d.InitializeEMValuesGPU(); d.GaussianReconstructionGPU(); d.SimulateSlicesGPU(); d.InitializeRobustStatisticsGPU(); d.EStepGPU()
 sw = d._local(d._slice_weight_gpu)
-for _ in range(4):
+for _ in range(40):          # many more than the tuners' trial launches: pmc.py averages the last half of a kernel's dispatches
     rec.SuperresolutionBackproject(sw)
-for _ in range(4):
+for _ in range(40):
     rec.SimulateSlices()
+print("tuned: scatter tiles %dx%d box %d, gather tiles %dx%d box %d" % tuple(rec.get_option(k) for k in ("tile_w", "tile_h", "wave_cap", "fwd_tile_w", "fwd_tile_h", "fwd_unit_cap")), flush=True)
