@@ -3818,7 +3818,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       TileSample sample;
       r = sample.begin(ctx, ctx->d_tiles_fwd, ctx->n_tiles_fwd);
       float ms = 0.0f;
-      for (int rep = 0; rep < 2 && !r; ++rep) {          // the second run is the one that counts
+      for (int rep = 0; rep < 2 && !r; ++rep) {          // the second run is the one that counts (a new tile list costs its first launch)
         hipError_t he = hipEventRecord(e0, ctx->stream);
         r = launch_forward();
         if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
@@ -3996,12 +3996,14 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    // one trial: the whole-launch time of the current shape with box `cap` (two runs, the second one counts)
+    // one trial: the whole-launch time of the current shape with box `cap`
+    bool warm = false;
     auto trial = [&](int cap, TileSample &sample, float &ms) -> int {
       ctx->wave_cap = cap;
       int rr = SVR_OK;
       ms = 0.0f;
-      for (int rep = 0; rep < 2 && !rr; ++rep) {
+      for (int rep = warm ? 1 : 0; rep < 2 && !rr; ++rep) {   // one timed run per box, after one warm-up run per shape (a new tile list
+        warm = true;                                          // costs its first launch 0.1 ms on P4, enough to turn a near-tie)
         hipError_t he = hipEventRecord(e0, ctx->stream);
         rr = svr_superresolution_backproject(ctx, nullptr);
         if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
@@ -4030,6 +4032,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
       TileSample sample;
       if (!r) r = sample.begin(ctx, ctx->d_tiles, ctx->n_tiles);
       float shape_best = 3.0e38f;
+      warm = false;
       for (int k = 0; k < (wave ? 5 : 1) && !r; ++k) {
         float ms;
         r = trial(wave ? caps[k] : cap0, sample, ms);
@@ -4039,10 +4042,11 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
         if (ms < best) { best = ms; pick = c; pick_cap = ctx->wave_cap; }
         if (ms < shape_best) shape_best = ms;
         else break;                                      // a smaller box stopped paying for this shape
+        if (ms > 1.3f * best) break;                     // ... or the shape is out of reach
       }
       sample.end();
       if (r) break;
-      if (shape_best > best && c >= (tab ? 4 : 3)) break;  // the small shapes only while they win
+      if (pick != c && c >= (tab ? 2 : 3)) break;        // the small shapes only while they win
     }
     ctx->wave_cap = pick_cap;
     if (!r) r = svr_set_option(ctx, "tile_w", cand[pick][0]);
