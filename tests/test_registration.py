@@ -211,6 +211,26 @@ def test_registration_parity(tiny, oracle_mod, vol=None):
 
 
 @pytest.mark.gpu
+def test_batched_gradient_is_the_literal_launch_sequence(tiny):
+    """The twelve evaluations of a central-difference gradient go out as one launch sequence (option reg_batch, default on);
+    one by one, as RC.cu:4060-4082 issues them, the decisions and the matrices are the same to the last bit."""
+    vol = _analytic_volume(tiny)
+    rec = _engine_with_volume(tiny, vol)
+    assert rec.get_option("reg_batch") == 1
+    rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    T[3] = T[3] @ geo.rigid_matrix(tx=1.5, rz=2.0)
+    T[10] = T[10] @ geo.rigid_matrix(ty=-1.0, rx=-1.5)
+    out = {}
+    for batch in (1, 0):
+        rec.set_option("reg_batch", batch)
+        out[batch] = (R.SliceToVolumeRegistrationGPU(rec, rs, T), rec.reg_counters())
+    assert np.array_equal(out[1][1], out[0][1]) and out[0][1][1] > 10
+    assert np.array_equal(out[1][0], out[0][0])
+    assert np.abs(out[1][0] - T).max() > 0.1
+
+
+@pytest.mark.gpu
 def test_registration_on_a_reconstructed_volume(tiny, oracle_mod):
     """End to end on the engine's own reconstruction: reconstruct, register, push the new matrices."""
     from fetalreconstruction_amd import engine as E
