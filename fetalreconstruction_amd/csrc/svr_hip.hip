@@ -2761,6 +2761,7 @@ struct svr_ctx {
            *d_tiles_fb = nullptr;
   uint32_t n_active = 0, n_psf = 0, n_tiles = 0;
   int tiles_x = 0, tiles_y = 0, tile_w = 4, tile_h = 4;
+  int reg_blind = 4;        // GPU slice-to-volume registration: line-search steps per host round trip, the active count on the device (0: a round trip per step)
   int reg_batch = 1;        // GPU slice-to-volume registration: the twelve evaluations of a gradient as one launch sequence (0: one by one)
   int pvr_reg_levels = 3, pvr_reg_steps = 4, pvr_reg_iterations = 20;   // PatchBased2D3DRegistration_gpu2 schedule (tests shorten it)
   bool psf_list_valid = false;
@@ -3364,6 +3365,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "dbg_fwd_lds")) { ctx->dbg_fwd_lds = value; return SVR_OK; }
   if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
   if (!strcmp(name, "wave_cap")) { ctx->wave_cap = std::max(1024, value); ctx->wave_cap_user = true; return SVR_OK; }
+  if (!strcmp(name, "reg_blind")) { ctx->reg_blind = std::max(0, value); return SVR_OK; }
   if (!strcmp(name, "reg_batch")) { ctx->reg_batch = value ? 1 : 0; return SVR_OK; }
   if (!strcmp(name, "pvr_reg_levels")) { ctx->pvr_reg_levels = std::min(3, std::max(1, value)); return SVR_OK; }
   if (!strcmp(name, "pvr_reg_steps")) { ctx->pvr_reg_steps = std::max(1, value); return SVR_OK; }
@@ -3393,7 +3395,7 @@ int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
   const struct { const char *n; int v; } tab[] = {
       {"back_mode", ctx->back_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
       {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
-      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}};
+      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
   for (const auto &e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return SVR_OK; }
   return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);

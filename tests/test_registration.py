@@ -212,8 +212,9 @@ def test_registration_parity(tiny, oracle_mod, vol=None):
 
 @pytest.mark.gpu
 def test_batched_gradient_is_the_literal_launch_sequence(tiny):
-    """The twelve evaluations of a central-difference gradient go out as one launch sequence (option reg_batch, default on);
-    one by one, as RC.cu:4060-4082 issues them, the decisions and the matrices are the same to the last bit."""
+    """The twelve evaluations of a central-difference gradient go out as one launch sequence (option reg_batch, default on) and
+    the line search keeps its active count on the device, four steps per host round trip (reg_blind); one by one with a round
+    trip per step, as RC.cu:4060-4141 issues them, the decisions and the matrices are the same to the last bit."""
     vol = _analytic_volume(tiny)
     rec = _engine_with_volume(tiny, vol)
     assert rec.get_option("reg_batch") == 1
@@ -222,12 +223,16 @@ def test_batched_gradient_is_the_literal_launch_sequence(tiny):
     T[3] = T[3] @ geo.rigid_matrix(tx=1.5, rz=2.0)
     T[10] = T[10] @ geo.rigid_matrix(ty=-1.0, rx=-1.5)
     out = {}
-    for batch in (1, 0):
+    assert rec.get_option("reg_blind") == 4
+    for batch, blind in ((1, 4), (0, 0), (1, 0), (0, 1), (1, 7)):      # reg_blind: line-search steps per host round trip (0: the literal loop)
         rec.set_option("reg_batch", batch)
-        out[batch] = (R.SliceToVolumeRegistrationGPU(rec, rs, T), rec.reg_counters())
-    assert np.array_equal(out[1][1], out[0][1]) and out[0][1][1] > 10
-    assert np.array_equal(out[1][0], out[0][0])
-    assert np.abs(out[1][0] - T).max() > 0.1
+        rec.set_option("reg_blind", blind)
+        out[(batch, blind)] = (R.SliceToVolumeRegistrationGPU(rec, rs, T), rec.reg_counters())
+    ref_t, ref_c = out[(0, 0)]
+    assert ref_c[1] > 10 and np.abs(ref_t - T).max() > 0.1
+    for key, (t, c) in out.items():
+        assert np.array_equal(c, ref_c), key
+        assert np.array_equal(t, ref_t), key
 
 
 @pytest.mark.gpu

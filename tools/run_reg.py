@@ -19,18 +19,19 @@ print("prep (numpy resampling) s:", round(time.time() - t0, 2), "grid", rs.combi
 T = P.slice_t.reshape(-1, 4, 4).astype(np.float64)
 rec.timer_enable(True)
 res = {}
-for batch in (1, 0):
+for batch, blind in ((1, 4), (1, 8), (1, 0), (0, 0)):
     rec.set_option("reg_batch", batch)
-    for rep in range(3):
+    rec.set_option("reg_blind", blind)
+    for rep in range(2):
         rec.timer_reset()
         t0 = time.time()
         Tn = R.SliceToVolumeRegistrationGPU(rec, rs, T)
         wall = time.time() - t0
         c = rec.reg_counters()
         ms, n = rec.timers()["register"]
-        print(f"reg_batch {batch} rep {rep}: wall {wall:.3f} s, device-timer {ms:.1f} ms, evaluations {c[0]}, line-search {c[1]}, "
+        print(f"reg_batch {batch} reg_blind {blind} rep {rep}: wall {wall:.3f} s, device-timer {ms:.1f} ms, evaluations {c[0]}, line-search {c[1]}, "
               f"iterations {c[2]}, slice-evaluations {c[3]} -> {c[3] / wall / 1e3:.1f} k slice-evals/s, "
               f"{c[3] * 3 * rs.combined.shape[1] * rs.combined.shape[2] / wall / 1e9:.2f} G samples/s", flush=True)
-    res[batch] = (Tn, c)
-print("max |dT|", np.abs(res[1][0] - T).max(), " batched vs one by one: max |dT|", np.abs(res[1][0] - res[0][0]).max(),
-      "counters equal:", bool(np.array_equal(res[1][1], res[0][1])))
+    res[(batch, blind)] = (Tn, c)
+print("max |dT|", np.abs(res[(1, 4)][0] - T).max(), " default vs literal: max |dT|", np.abs(res[(1, 4)][0] - res[(0, 0)][0]).max(),
+      "counters equal:", bool(np.array_equal(res[(1, 4)][1], res[(0, 0)][1])))
