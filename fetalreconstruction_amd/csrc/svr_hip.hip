@@ -2762,6 +2762,7 @@ struct svr_ctx {
   uint32_t n_active = 0, n_psf = 0, n_tiles = 0;
   int tiles_x = 0, tiles_y = 0, tile_w = 4, tile_h = 4;
   int reg_blind = 4;        // GPU slice-to-volume registration: line-search steps per host round trip, the active count on the device (0: a round trip per step)
+  int reg_red_threads = 0;  // workgroup size of the registration's per-image reductions: 0 = by image size, 256, 1024
   int reg_batch = 1;        // GPU slice-to-volume registration: the twelve evaluations of a gradient as one launch sequence (0: one by one)
   int pvr_reg_levels = 3, pvr_reg_steps = 4, pvr_reg_iterations = 20;   // PatchBased2D3DRegistration_gpu2 schedule (tests shorten it)
   bool psf_list_valid = false;
@@ -3366,6 +3367,11 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
   if (!strcmp(name, "wave_cap")) { ctx->wave_cap = std::max(1024, value); ctx->wave_cap_user = true; return SVR_OK; }
   if (!strcmp(name, "reg_blind")) { ctx->reg_blind = std::max(0, value); return SVR_OK; }
+  if (!strcmp(name, "reg_red_threads")) {
+    if (value != 0 && value != 256 && value != 1024) return fail(ctx, SVR_E_ARG, "reg_red_threads: 0, 256 or 1024");
+    ctx->reg_red_threads = value;
+    return SVR_OK;
+  }
   if (!strcmp(name, "reg_batch")) { ctx->reg_batch = value ? 1 : 0; return SVR_OK; }
   if (!strcmp(name, "pvr_reg_levels")) { ctx->pvr_reg_levels = std::min(3, std::max(1, value)); return SVR_OK; }
   if (!strcmp(name, "pvr_reg_steps")) { ctx->pvr_reg_steps = std::max(1, value); return SVR_OK; }

@@ -236,6 +236,27 @@ def test_batched_gradient_is_the_literal_launch_sequence(tiny):
 
 
 @pytest.mark.gpu
+def test_reduction_width_does_not_change_the_decisions(tiny, oracle_mod):
+    """Images of more than 4096 pixels are summed by workgroups of 1024 lanes (a tree of 16 leaves instead of 4): the double
+    sums move in their last bits, the float similarities within 2e-6, the decisions against the oracle not at all."""
+    vol = _analytic_volume(tiny)
+    rec = _engine_with_volume(tiny, vol)
+    rs = R.PrepareRegistrationSlices(rec, tiny.slices, tiny.slice_attr, tiny.vdim[0])
+    o = _oracle_reg(oracle_mod, tiny, rs, vol)
+    T = tiny.slice_t.reshape(-1, 4, 4).astype(np.float64)
+    T[3] = T[3] @ geo.rigid_matrix(tx=1.5, rz=2.0)
+    T[10] = T[10] @ geo.rigid_matrix(ty=-1.0, rx=-1.5)
+    To = R.SliceToVolumeRegistrationGPU(o, rs, T, vol)
+    for width in (1024, 256):
+        rec.set_option("reg_red_threads", width)
+        Tg = R.SliceToVolumeRegistrationGPU(rec, rs, T)
+        assert np.array_equal(rec.reg_counters(), o.counters), width
+        assert np.allclose(Tg, To, rtol=0, atol=1e-5), width
+    with pytest.raises(Exception):
+        rec.set_option("reg_red_threads", 512)
+
+
+@pytest.mark.gpu
 def test_registration_on_a_reconstructed_volume(tiny, oracle_mod):
     """End to end on the engine's own reconstruction: reconstruct, register, push the new matrices."""
     from fetalreconstruction_amd import engine as E
