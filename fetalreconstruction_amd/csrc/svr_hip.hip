@@ -1233,7 +1233,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SVR_
 // parameter: planes beyond 4 * groups are dealt round-robin to the same wavefronts.
 // pixels of a tile (larger tiles go to the workgroup kernels): 32 when the taps are evaluated, 64 -- one per lane -- when
 // they come from the coefficient table (the flush, not the evaluation, is what a table pass waits for: larger tiles)
-#define WAVE_MAXPIX (COEFF ? 64 : 32)
+#ifndef SVR_WAVE_MAXPIX_EVAL
+#define SVR_WAVE_MAXPIX_EVAL 32
+#endif
+#define WAVE_MAXPIX (COEFF ? 64 : SVR_WAVE_MAXPIX_EVAL)
 template <int NS = PSF_SUPPORT, bool PVR = false, bool COEFF = false>
 #ifndef SVR_WPE_WAVE
 #define SVR_WPE_WAVE 3    // 170 VGPRs: the LDS box allows 8-10 wavefronts per CU anyway

@@ -11,12 +11,12 @@ d.InitializeEMValuesGPU(); d.GaussianReconstructionGPU(); d.SimulateSlicesGPU();
 sw = d._local(d._slice_weight_gpu)
 rec.timer_enable(True)
 for w, h in ((6, 4), (6, 5), (5, 5), (8, 4), (4, 6), (5, 6), (7, 4), (4, 8), (4, 4)):          # at most 32 pixels (FWDU_MAXPIX)
-    rec.set_option("fwd_tile_w", w); rec.set_option("fwd_tile_h", h)
+    rec.set_option("fwd_tile_h", 1); rec.set_option("fwd_tile_w", w); rec.set_option("fwd_tile_h", h)
     for _ in range(3):
         rec.timer_reset(); rec.SimulateSlices()
     print(f"gather {w}x{h}: {rec.timers()['forward'][0]:.3f} ms", flush=True)
-for w, h in ((4, 4), (5, 4), (6, 4), (8, 4), (6, 5), (7, 4), (8, 3)):
-    rec.set_option("tile_w", w); rec.set_option("tile_h", h)
+for w, h in ((4, 4), (5, 4), (6, 4), (6, 5), (8, 4), (7, 4)):          # at most 32 pixels unless built with -DSVR_WAVE_MAXPIX_EVAL=64
+    rec.set_option("tile_h", 1); rec.set_option("tile_w", w); rec.set_option("tile_h", h)
     for cap in (2416, 2096):
         rec.set_option("wave_cap", cap)
         for _ in range(3):
