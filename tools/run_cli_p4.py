@@ -1,7 +1,7 @@
 """P4-scale end-to-end run of bin/SVRreconstructionGPU (defaults of the reference: 4 iterations, 4 / 13 SR iterations, IRTK
 registration): wall time of the whole command line on NIfTI files.  usage: run_cli_p4.py [extra CLI options]"""
 import pathlib
-import subprocess
+import os, subprocess
 import sys
 import tempfile
 import time
@@ -20,6 +20,7 @@ for k, st in enumerate(stacks):
     nifti.write(tmp / f"s{k}.nii.gz", st.data, st.attr)
     paths.append(str(tmp / f"s{k}.nii.gz"))
 nifti.write(tmp / "mask.nii.gz", rmask, rattr)
+os.environ.setdefault("SVR_CLI_TIMING", "1")      # the stages' wall times on stderr
 t = time.time()
 r = subprocess.run([build.CLI, "-o", str(tmp / "o.nii.gz"), "-i", *paths, "-m", str(tmp / "mask.nii.gz"), "--resolution", "1.0", *sys.argv[1:]],
                    capture_output=True, text=True)
