@@ -162,6 +162,9 @@ def main():
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")             # one node: the host name need not resolve
         if args.share_gpu:
             local_rank = 0
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()}: one GPU per rank "
+                             f"(--share-gpu runs every rank on GPU 0 for a functional check)")
         torch.cuda.set_device(local_rank)
         if args.comm == "torch" and args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
