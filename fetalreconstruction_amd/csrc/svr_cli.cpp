@@ -22,6 +22,8 @@
 #include <functional>
 #include <thread>
 
+#include <future>
+
 #include "svr_prep.h"
 
 
@@ -106,10 +108,14 @@ int main(int argc, char **argv) {
   if (tmpl == n) die("Please identify the template by assigning id transformation.");          // main.cc:452-457
 
   StageClock clk;
+  // the HIP runtime and the context come up (75 ms) while the stacks are read and cropped; first use: the stack registrations
   svr_ctx *ctx = nullptr;
-  if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
+  std::future<int> ctx_ready = std::async(std::launch::async, [&] { return svr_create(devices.empty() ? 0 : devices[0], &ctx); });
+  before_exit = [&] { if (ctx_ready.valid()) ctx_ready.wait(); };     // an error while reading must not exit under the runtime's feet
+  auto need_ctx = [&] {
+    if (ctx_ready.valid() && (ctx_ready.get() || !ctx)) die("no usable HIP device (svr_create failed)");
+  };
 
-  clk.mark("context");
   // ---- set-up (main.cc:386-815) ----------------------------------------------------------------------
   std::vector<Image> stacks;
   std::vector<M4> ts;
@@ -138,6 +144,7 @@ int main(int argc, char **argv) {
   clk.mark("mask, crop, template");
   auto stack_registrations = [&]() {                                                             // StackRegistrations, RG.cc:849-1001
     if (no_registration || n < 2 || !sfolder.empty()) return;                                    // main.cc:658, 708
+    need_ctx();
     std::vector<svr_image_attr> at(n);
     std::vector<const double *> ptr(n);
     std::vector<double> tm(16 * n);
@@ -256,6 +263,7 @@ int main(int argc, char **argv) {
     }
     if (ns < nr) die("fewer slices than devices");
   }
+  need_ctx();
   std::vector<svr_ctx *> ctxs(nr, nullptr);
   std::vector<svrh_recon *> hosts(nr, nullptr);
   ctxs[0] = ctx;

@@ -79,7 +79,12 @@ struct Image {
 };
 
 const char *prog_name = "SVRreconstructionGPU";
-void die(const std::string &m) { fprintf(stderr, "%s: %s\n", prog_name, m.c_str()); exit(1); }
+std::function<void()> before_exit;     // e.g. wait for a context that another thread is still creating
+void die(const std::string &m) {
+  fprintf(stderr, "%s: %s\n", prog_name, m.c_str());
+  if (before_exit) { auto f = before_exit; before_exit = nullptr; f(); }
+  exit(1);
+}
 
 // SVR_CLI_TIMING=1: wall time of every stage of a command line on stderr (tools/run_cli_*.py read it)
 struct StageClock {
