@@ -501,6 +501,7 @@ int main(int argc, char **argv) {
   if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
   ENG(svr_set_option(ctx, "pvr", 1));
   if (coeff_table) ENG(svr_set_option(ctx, "coeff_table", 1));
+  ENG(svr_set_option(ctx, "tune_tiles", 32768));                           // a run is a few dozen PSF launches: cheap tuning trials
   const uint32_t vsize[3] = {(uint32_t)tattr.nx, (uint32_t)tattr.ny, (uint32_t)tattr.nz};
   const float vdim[3] = {(float)tattr.dx, (float)tattr.dy, (float)tattr.dz};
   std::vector<float> maskf(recon_mask.d.begin(), recon_mask.d.end());

@@ -303,6 +303,7 @@ int main(int argc, char **argv) {
     const int nl = rhi[r] - rlo[r];
     const size_t o = (size_t)rlo[r];
     if (coeff_table) ENGR(r, svr_set_option(ctxs[r], "coeff_table", 1));
+    ENGR(r, svr_set_option(ctxs[r], "tune_tiles", 32768));                // a run is a few dozen PSF launches: cheap tuning trials
     ENGR(r, svr_init_reconstruction_volume(ctxs[r], vsize, vdim, nullptr, 12.0f));
     ENGR(r, svr_set_mask(ctxs[r], vsize, vdim, maskf.data(), 12.0f));
     const uint32_t ssize[3] = {(uint32_t)mx, (uint32_t)my, (uint32_t)nl};

@@ -2765,6 +2765,7 @@ struct svr_ctx {
   uint32_t n_active = 0, n_psf = 0, n_tiles = 0;
   int tiles_x = 0, tiles_y = 0, tile_w = 4, tile_h = 4;
   int reg_blind = 4;        // GPU slice-to-volume registration: line-search steps per host round trip, the active count on the device (0: a round trip per step)
+  int tune_tiles = 0;       // tiles a tuner's trial launch runs on (0: TUNE_TILES); a short job -- the command lines -- asks for fewer
   int reg_red_threads = 0;  // workgroup size of the registration's per-image reductions: 0 = by image size, 256, 1024
   int reg_batch = 1;        // GPU slice-to-volume registration: the twelve evaluations of a gradient as one launch sequence (0: one by one)
   int pvr_reg_levels = 3, pvr_reg_steps = 4, pvr_reg_iterations = 20;   // PatchBased2D3DRegistration_gpu2 schedule (tests shorten it)
@@ -3128,8 +3129,8 @@ struct TileSample {
     static const long env_tiles = getenv("SVR_TUNE_TILES") ? atol(getenv("SVR_TUNE_TILES")) : -1;   // 0: always the whole list
     if (env_tiles == 0) return SVR_OK;
     static const long env_run = getenv("SVR_TUNE_RUN") ? atol(getenv("SVR_TUNE_RUN")) : -1;
-    const uint32_t target = env_tiles > 0 ? (uint32_t)env_tiles : TUNE_TILES;
-    const uint32_t TUNE_RUN = env_run > 0 ? (uint32_t)env_run : 65536u;
+    const uint32_t target = env_tiles > 0 ? (uint32_t)env_tiles : ctx->tune_tiles > 0 ? (uint32_t)ctx->tune_tiles : TUNE_TILES;
+    const uint32_t TUNE_RUN = env_run > 0 ? (uint32_t)env_run : std::min(65536u, std::max(4096u, target / 2));
     const uint32_t stride = count / target;
     if (stride < 2 || (uint64_t)TUNE_RUN * stride > count) return SVR_OK;
     const uint32_t n_out = count / (TUNE_RUN * stride) * TUNE_RUN;     // whole runs only: the last index stays inside the list
@@ -3370,6 +3371,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "wave_groups")) { ctx->wave_groups = std::max(1, value); return SVR_OK; }
   if (!strcmp(name, "wave_cap")) { ctx->wave_cap = std::max(1024, value); ctx->wave_cap_user = true; return SVR_OK; }
   if (!strcmp(name, "reg_blind")) { ctx->reg_blind = std::max(0, value); return SVR_OK; }
+  if (!strcmp(name, "tune_tiles")) { ctx->tune_tiles = std::max(0, value); return SVR_OK; }
   if (!strcmp(name, "reg_red_threads")) {
     if (value != 0 && value != 256 && value != 1024) return fail(ctx, SVR_E_ARG, "reg_red_threads: 0, 256 or 1024");
     ctx->reg_red_threads = value;

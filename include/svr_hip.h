@@ -57,8 +57,8 @@ int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
  * "tile_w"/"tile_h", "wave_cap", "fwd_tile_w"/"fwd_tile_h", "fwd_unit_cap": tile shapes and LDS box sizes.
  * "fwd_autotune" (default 1): the first forward projection / back-projection after new slice geometry times the
  *   candidate shapes and box sizes on the data and keeps the fastest; an explicit shape switches that off.
- *   Long tile lists are timed on runs of 65536 consecutive tiles (one run out of every stride, about 131072 tiles per
- *   trial); environment: SVR_TUNE_TILES (tiles per trial, 0 = always the whole list), SVR_TUNE_RUN, SVR_TUNE_DEBUG=1 (the
+ *   Long tile lists are timed on runs of consecutive tiles (one run out of every stride, about 131072 tiles per trial;
+ *   "tune_tiles" sets another number -- the command lines, whose whole job is a few dozen launches, ask for 32768); environment: SVR_TUNE_TILES (tiles per trial, 0 = always the whole list), SVR_TUNE_RUN, SVR_TUNE_DEBUG=1 (the
  *   candidates' times on stderr).
  * "pvr": 1 selects the patch-to-volume constants and kernels.
  * Other environment variables: SVR_COEFF_MAX_GB (ceiling of the coefficient table), SVR_FWD_PIECE (test hook: tiles per
