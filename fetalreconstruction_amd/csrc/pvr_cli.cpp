@@ -19,6 +19,9 @@
 // --dilateMask n dilates the mask n times, --packages p_1 .. p_N splits every stack into its interleaved packages (PBR.cpp:134-146).
 // --resample resamples the cropped stacks to the output voxel size with IRTK's cubic B-spline interpolator.
 #include <float.h>
+
+#include <future>
+
 #include "svr_prep.h"
 #include "svr_slic.h"
 
@@ -342,6 +345,13 @@ int main(int argc, char **argv) {
   if (tspecs.size() != n) die("one transformation per stack expected");
 
   StageClock clk;
+  // the HIP runtime comes up on a second thread while the stacks are read: a first context (the stack-to-stack registration
+  // makes one, the reconstruction another) then costs milliseconds instead of 75
+  std::future<void> runtime_up = std::async(std::launch::async, [&] {
+    svr_ctx *warm = nullptr;
+    if (!dry_run && svr_create(devices.empty() ? 0 : devices[0], &warm) == 0 && warm) svr_destroy(warm);
+  });
+  before_exit = [&] { if (runtime_up.valid()) runtime_up.wait(); };
   // ---- set-up (pvrmain:184-257, PBR.cpp:193-310) --------------------------------------------------------
   std::vector<Image> stacks;
   std::vector<M4> ts;
@@ -376,6 +386,7 @@ int main(int argc, char **argv) {
   clk.mark("mask, crop (resample)");
   const Image iso_mask = transform_nn(mask, resample_attr(mask.a, resolution), ident(), 0.0);    // :258-266
   clk.mark("isotropic mask");
+  if (runtime_up.valid()) runtime_up.wait();
   if (!no_registration && n > 1) {                       // irtkStack3D3DRegistration<T>::run, :280-285
     svr_ctx *rctx = nullptr;
     if (svr_create(devices.empty() ? 0 : devices[0], &rctx) || !rctx) die("no usable HIP device (svr_create failed)");
@@ -392,7 +403,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "stack-to-stack registration: %ld similarity evaluations\n", evals);
     svr_destroy(rctx);
   }
-  clk.mark("stack-to-stack registration");
+  clk.mark("registration of the stacks");
   if (!no_matching) match_stack_intensities_pvr(stacks, ts, iso_mask);                           // :288-294
   clk.mark("match stack intensities");
   float vmin = 3.402823466e38f, vmax = 1.175494351e-38f;                                         // computeMinMaxIntensities :792-814
@@ -554,7 +565,7 @@ int main(int argc, char **argv) {
       ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), P.i2w.data(), P.w2i.data(), P.i2w.data(), P.w2i.data(), ri2w, rw2i));
       fprintf(stderr, "patch-to-volume registration: %ld similarity evaluations\n", evals);
     }
-    if (have_volume && !no_registration) clk.mark("patch-to-volume registration");
+    if (have_volume && !no_registration) clk.mark("registration of the patches");
     PVRH(pvrh_reconstruct_iteration(host, sr_iterations));
     clk.mark("reconstruction iteration");
     double sc[8];
