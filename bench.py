@@ -11,8 +11,11 @@ timed region.  value = Va / t_step / 1e6, Va = slice pixels with s != -1 and v_P
 Workloads are FIXED (strong scaling, as BASELINE.json's metric and configs name them):
   P4  (default) BASELINE configs[1]: 4 stacks 100x93x70 on the reference's bundled mask geometry, 1.0 mm (workloads.py)
   S8            BASELINE configs[3]: 8 stacks of 64 x 256^2 slices, 0.75 mm
+  PVR4          BASELINE configs[2]: 32 x 32 patches, stride 16, of the P4 stacks, 1.0 mm -- the patch-to-volume loop
+                (csrc/pvr_host.cpp): Scale -> scatter (+ all-reduce) + regulariser -> simulate -> M-step -> E-step
+  PVR8spx       BASELINE configs[4]: superpixel patches (--spxSize 32 --spxExtend 2) of the 8 S8 stacks, 0.5 mm
   P4s / S8h / tiny: the round-1 axis-aligned P4, the S8 stacks at 0.5 mm, the oracle-sized case.
-N > 1: one process per GPU, slices sharded by active-pixel count, the exchanges on RCCL bound directly by the C library
+N > 1: one process per GPU, slices (patches) sharded by estimated work, the exchanges on RCCL bound directly by the C library
 (csrc/svr_rccl.cpp; `--comm torch` routes them through torch.distributed instead).  Launched by torch.distributed.run --
 or by this script itself: `python bench.py --gpus N` without WORLD_SIZE in the environment re-executes under
 `python -m torch.distributed.run --nproc-per-node N`.  torch.distributed (gloo) only carries the rendezvous (the 128-byte
@@ -74,7 +77,7 @@ def cpu_baseline(prob, target_seconds=12.0):
     from fetalreconstruction_amd import engine as _engine
     cores = int(_engine.load_library().svr_host_threads())      # affinity mask cut to the cgroup CPU quota (16 of 256 on the gpurun boxes)
     cores = max(1, min(cores, 64))
-    act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
+    act = ((prob.slices > 0) if hasattr(prob, "patches_per_stack") else (prob.slices != -1)).reshape(prob.ns, -1).sum(1)
     per_pixel_s = 2 * 0.14e-3                    # ~0.14 ms / pixel / PSF pass / core on this class of host
     want = max(2000, int(target_seconds / per_pixel_s)) * cores
     step = max(1, int(np.ceil(act.sum() / want)))
@@ -88,14 +91,32 @@ def cpu_baseline(prob, target_seconds=12.0):
     parts = [np.array(sorted(q)) for q in parts if q]
     cores = len(parts)
 
+    is_pvr = hasattr(prob, "patches_per_stack")
+
     def setup(idx):
         sub = sub_problem(prob, 0, 0, select=idx)
+        if is_pvr:                                              # the patch-to-volume loop (pvr.py on the oracle engine)
+            from fetalreconstruction_amd import pvr as _pvr
+            spx = getattr(prob, "spx_masks", None)
+            o = po.OracleReconstruction(sub, po.LITERAL, pvr=True, spx_masks=None if spx is None else np.ascontiguousarray(spx[idx]))
+            counts = np.bincount(sub.stack_index, minlength=int(prob.stack_index.max()) + 1)
+            d = _pvr.irtkPatchBasedReconstruction(o, counts, prob.min_intensity, prob.max_intensity)
+            d.reconstruct_iteration(0)
+            d.sr_iteration = lambda i, d=d: _pvr_sr_iteration(d, i)
+            return o, d
         o = po.OracleReconstruction(sub, po.LITERAL)
         d = irtkReconstruction(o, sub.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
         d.SetSmoothingParameters(150, 0.02)
         d.InitializeEMValuesGPU(); d.GaussianReconstructionGPU(); d.SimulateSlicesGPU()
         d.InitializeRobustStatisticsGPU(); d.EStepGPU()
         return o, d
+
+    def _pvr_sr_iteration(d, i):                                # irtkPatchBasedReconstruction.cpp:505-546
+        d.Scale()
+        d.e.Superresolution(i + 1, d.patch_weight, d.m_adaptive, float(d.m_alpha), d.m_min_intensity, d.m_max_intensity, float(d.m_delta), float(d.m_lambda))
+        d.e.SimulateSlices()
+        d.MStep(i + 1)
+        d.EStep()
 
     with ThreadPoolExecutor(cores) as pool:
         pairs = list(pool.map(setup, parts))
@@ -122,7 +143,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="P4", choices=["P4", "P4s", "S8", "S8h", "tiny"])
+    ap.add_argument("--workload", default="P4", choices=["P4", "P4s", "S8", "S8h", "tiny", "PVR4", "PVR8spx"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coeff-table", action="store_true", help="skip the second measurement with the coefficient table")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
@@ -141,7 +162,7 @@ def main():
 
     import torch                                                      # before the engine: one RCCL copy per process
     from fetalreconstruction_amd import engine, phantom, workloads
-    from fetalreconstruction_amd.host import RcclComm, irtkReconstruction      # the C++ host object
+    from fetalreconstruction_amd.host import RcclComm, irtkPatchBasedReconstruction, irtkReconstruction      # the C++ host objects
     from fetalreconstruction_amd.reconstruction import TorchComm, shard_slices, slice_cost_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,8 +172,7 @@ def main():
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
     multi = world > 1 or args.force_comm
-    if args.force_comm:
-        os.environ["SVR_FORCE_COLLECTIVES"] = "1"                     # the C++ host goes through its callbacks at world 1 too
+    if args.force_comm:                                               # (the C++ hosts then go through their callbacks at world 1 too)
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
@@ -173,13 +193,28 @@ def main():
 
     # ---- the workload: fixed, whatever the world size --------------------------------------------------------------
     prob = workloads.get(args.workload) if args.workload != "tiny" else phantom.problem_tiny()
-    act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
-    # contiguous slice ranges balanced by estimated PSF work (active pixels x live planes), not by pixel count alone
-    lo, hi = shard_slices(slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0]), world)[rank]
+    pvr = args.workload.startswith("PVR")
+    if pvr:
+        if args.comm == "torch":
+            raise SystemExit("bench.py: the patch-based host (csrc/pvr_host.cpp) takes the C library's RCCL communicator; --comm torch is SVR only")
+        # contiguous patch ranges balanced by the pixels that carry data (patches of one stack share their geometry)
+        work = (prob.slices > 0).reshape(prob.ns, -1).sum(1).astype(np.float64)
+    else:
+        act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
+        # contiguous slice ranges balanced by estimated PSF work (active pixels x live planes), not by pixel count alone
+        work = slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0])
+    lo, hi = shard_slices(work, world)[rank]
     local = phantom.sub_problem(prob, lo, hi) if world > 1 else prob
+    spx = getattr(prob, "spx_masks", None)
 
     rec = engine.Reconstruction(local_rank)
-    engine.sync_gpu(rec, local)
+    if pvr:
+        rec.set_option("pvr", 1)
+        engine.sync_gpu(rec, local, quality_factor=1.0)                # m_quality_factor = 1 (irtkPatchBasedReconstruction.cpp:415)
+        if spx is not None:
+            rec.set_spx_masks(np.ascontiguousarray(spx[lo:hi]))
+    else:
+        engine.sync_gpu(rec, local)
     comm, rccl_world = None, None
     if multi:
         if args.comm == "rccl":
@@ -209,15 +244,20 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-    drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity)
-    drv.SetSmoothingParameters(150, 0.02)      # reconstruction.cc:99-100 defaults (delta, lambda)
-
-    # untimed set-up: the part of an outer iteration before the SR loop (reconstruction.cc:930-1001)
-    drv.InitializeEMValuesGPU()
-    drv.GaussianReconstructionGPU()
-    drv.SimulateSlicesGPU()
-    drv.InitializeRobustStatisticsGPU()
-    drv.EStepGPU()
+    if pvr:
+        drv = irtkPatchBasedReconstruction(rec, prob.patches_per_stack, prob.min_intensity, prob.max_intensity, patch_range=(lo, hi),
+                                           comm=comm, force_collectives=args.force_comm)
+        # untimed set-up: the part of an outer iteration before the SR loop (irtkPatchBasedReconstruction.cpp:490-504)
+        drv.reconstruct_iteration(0)
+    else:
+        drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity, force_collectives=args.force_comm)
+        drv.SetSmoothingParameters(150, 0.02)      # reconstruction.cc:99-100 defaults (delta, lambda)
+        # untimed set-up: the part of an outer iteration before the SR loop (reconstruction.cc:930-1001)
+        drv.InitializeEMValuesGPU()
+        drv.GaussianReconstructionGPU()
+        drv.SimulateSlicesGPU()
+        drv.InitializeRobustStatisticsGPU()
+        drv.EStepGPU()
     # the engine times its tile shapes / box sizes on the first gather / scatter after new geometry; the gather was tuned by
     # SimulateSlicesGPU above, this untimed scatter keeps the other one out of the timed region whatever --warmup is (it
     # only writes addon|cmap and the slice weights, which every SR iteration rebuilds / uploads)
@@ -242,11 +282,30 @@ def main():
     timers = rec.timers()
     cnt = rec.counters()
 
+    def per_rank(tm):
+        """what every rank measured on its own engine: average milliseconds per launch of the two PSF kernels, of the volume
+        all-reduce (HIP events around the collective on the engine's stream: the wait for the slowest rank + the ring) and of
+        the small host-side exchanges (wall clock), plus the rank's share of the work -- so that a scaling shortfall can be
+        put down to imbalance, RCCL or the host exchanges from the line alone"""
+        keys = ("backproject", "forward", "allreduce", "exchange_host", "regularize")
+        mine = [tm[k][0] / max(tm[k][1], 1) for k in keys] + [float(tm["exchange_host"][1]) / max(args.steps, 1), float(cnt["Va"]), float(hi - lo)]
+        n = len(mine)
+        v = np.zeros(world * n)
+        v[rank * n:(rank + 1) * n] = mine
+        v = comm.allreduce_sum(v).reshape(world, n) if multi else v.reshape(1, n)
+        out = {f"{k}_ms": [round(float(x), 4) for x in v[:, j]] for j, k in enumerate(keys)}
+        out["exchanges_per_step"] = [round(float(x), 2) for x in v[:, len(keys)]]
+        out["Va"] = [int(x) for x in v[:, len(keys) + 1]]
+        out["units"] = [int(x) for x in v[:, len(keys) + 2]]
+        return out
+
+    ranks = per_rank(timers)
     if multi:
         dt = float(comm.allreduce_max(np.array([dt]))[0])
         va = int(round(comm.allreduce_sum(np.array([float(cnt["Va"])]))[0]))
     else:
         va = cnt["Va"]
+    tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode")}
 
     # ---- the same K steps once more with the coefficient table (reported next to the headline, not as it) ------------
     # `value` above is the reference GPU path's way: every tap evaluated in every pass.  With option coeff_table the taps of
@@ -312,12 +371,17 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{prob.name}: {int(prob.stack_index.max()) + 1} synthetic stacks, volume {tuple(prob.vsize)}, "
-                                   f"{prob.ns} slices of {prob.slices.shape[2]}x{prob.slices.shape[1]}, recon {prob.vdim[0]} mm"
-                                   + (" on the reference's bundled mask geometry (oblique, 300-400 mm off the origin)" if prob.name == "P4" else ""),
+                                   f"{prob.ns} {'patches' if pvr else 'slices'} of {prob.slices.shape[2]}x{prob.slices.shape[1]}, recon {prob.vdim[0]:.3g} mm"
+                                   + (" on the reference's bundled mask geometry (oblique, 300-400 mm off the origin)" if prob.name in ("P4", "PVR4") else "")
+                                   + (" -- patch-to-volume loop (BASELINE configs[2]: 32x32 patches, stride 16)" if prob.name == "PVR4" else "")
+                                   + (" -- patch-to-volume loop (BASELINE configs[4]: superpixel patches, --spxSize 32 --spxExtend 2)" if prob.name == "PVR8spx" else ""),
                        "Vs": vs, "Va_rank0": va_l, "Va_total": va, "Nv": nv, "slices": prob.ns,
-                       "parallelism": f"slice-sharded x{world}, 1 in-place RCCL all-reduce of addon|cmap (float[2 Nv]) per scatter pass"
+                       "parallelism": f"{'patch' if pvr else 'slice'}-sharded x{world}, 1 in-place RCCL all-reduce of addon|cmap (float[2 Nv]) per scatter pass"
                                       if world > 1 else "1 GPU",
-                       "comm": (args.comm if multi else None), "rccl_world": rccl_world},
+                       "comm": (args.comm if multi else None), "rccl_world": rccl_world,
+                       "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",
+                                 "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "pin": os.environ.get("SVR_TILE_PIN")}},
+            "ranks": ranks,
             "roofline": {
                 "kernel": "back_wave_kernel (SuperresolutionKernel3D_tex, RC.cu:408-522): the dominant kernel of the step",
                 "bound": "valu_f32",

@@ -19,7 +19,8 @@ SRC_PVR_HOST = os.path.join(HERE, "csrc", "pvr_host.cpp")  # the irtkPatchBasedR
 SRC_RCCL = os.path.join(HERE, "csrc", "svr_rccl.cpp")     # the collectives on RCCL (dlopen: no link-time dependency)
 SRC_IRTK = os.path.join(HERE, "csrc", "irtk_reg.cpp")      # the IRTK registration schedule around the NCC cost (host C++)
 SRC_PREP = os.path.join(HERE, "csrc", "svr_prep.h")       # pre-processing shared by the two command lines
-SRC_SLIC = os.path.join(HERE, "csrc", "svr_slic.h")       # SLICO superpixel patches of the PVR command line
+SRC_SLIC = os.path.join(HERE, "csrc", "svr_slic.h")
+SRC_SHARD = os.path.join(HERE, "csrc", "svr_shard.h")     # unit ranges + the one exchange per step, shared by the two host objects       # SLICO superpixel patches of the PVR command line
 INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
 INC_HOST = os.path.join(os.path.dirname(HERE), "include", "svr_host.h")
 OUT_DIR = os.path.join(HERE, "lib")
@@ -50,7 +51,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_PYR, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_PYR, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_SHARD, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
                                                __file__)) or not (os.path.exists(CLI) and os.path.exists(PVR_CLI))
 
 

@@ -507,42 +507,99 @@ int main(int argc, char **argv) {
   if (dry_run) return false;
   first_level = false;
 
-  // ---- upload (the engine in PVR mode; m_quality_factor = 1, PBR.cpp:415) -----------------------------------
-  svr_ctx *ctx = nullptr;
-  if (svr_create(devices.empty() ? 0 : devices[0], &ctx) || !ctx) die("no usable HIP device (svr_create failed)");
-  ENG(svr_set_option(ctx, "pvr", 1));
-  if (coeff_table) ENG(svr_set_option(ctx, "coeff_table", 1));
-  ENG(svr_set_option(ctx, "tune_tiles", 32768));                           // a run is a few dozen PSF launches: cheap tuning trials
+  // ---- ranks: one engine context per device of -d, the patches sharded over them in contiguous ranges of the global
+  // numbering (stack after stack) balanced by the pixels that carry data.  The reference's patch-based path is single-GPU
+  // (patchBasedReconMain.cpp:78,177-179, irtkPatchBasedReconstruction.cpp:402); SURVEY 8e: "identical with patches as the unit"
+  const int nr = (int)std::max<size_t>(1, devices.size());
+  if (ns < nr) die("fewer patches than devices");
+  std::vector<int> rlo(nr, 0), rhi(nr, ns);
+  {
+    std::vector<double> cum(ns + 1, 0.0);
+    const size_t pp = (size_t)px * py;
+    parallel_for(ns, [&](int q) {
+      long c = 0;
+      for (size_t i = 0; i < pp; ++i) c += P.data[(size_t)q * pp + i] > 0.0f;
+      cum[q + 1] = (double)c;
+    });
+    for (int q = 0; q < ns; ++q) cum[q + 1] += cum[q];
+    int at = 0;
+    for (int r = 0; r < nr; ++r) {
+      rlo[r] = at;
+      if (r == nr - 1) at = ns;
+      else {
+        const double want = cum[ns] * (r + 1) / nr;
+        while (at < ns - (nr - 1 - r) && cum[at] < want) ++at;
+        at = std::max(at, rlo[r] + 1);
+      }
+      rhi[r] = std::min(at, ns);
+    }
+  }
+  std::vector<svr_ctx *> ctxs(nr, nullptr);
+  std::vector<pvrh_recon *> hosts(nr, nullptr);
+  for (int r = 0; r < nr; ++r)
+    if (svr_create(devices.empty() ? 0 : devices[r], &ctxs[r]) || !ctxs[r])
+      die("no usable HIP device " + std::to_string(devices.empty() ? 0 : devices[r]) + " (svr_create failed)");
+  svr_ctx *ctx = ctxs[0];
+  svr_group *group = nr > 1 ? svr_group_create(nr, devices.data()) : nullptr;
+  if (nr > 1 && !group) die("cannot set up the rank group (librccl not found?)");
+  auto par = [&](const std::function<void(int)> &fn) {   // every rank in its own thread (the collectives block until all have arrived)
+    if (nr == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int r = 0; r < nr; ++r) th.emplace_back(fn, r);
+    for (auto &t : th) t.join();
+  };
+#define ENGR(r, call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + svr_last_error(ctxs[r])); } while (0)
+#define PVRHR(r, call) do { int rc_ = (call); if (rc_) die(std::string(#call) + ": " + pvrh_last_error(hosts[r])); } while (0)
+
+  // ---- upload (the engine in PVR mode; m_quality_factor = 1, PBR.cpp:415), per rank --------------------------------
   const uint32_t vsize[3] = {(uint32_t)tattr.nx, (uint32_t)tattr.ny, (uint32_t)tattr.nz};
   const float vdim[3] = {(float)tattr.dx, (float)tattr.dy, (float)tattr.dz};
   std::vector<float> maskf(recon_mask.d.begin(), recon_mask.d.end());
   float ri2w[16], rw2i[16];
   to_f16(image_to_world(tattr), ri2w); to_f16(world_to_image(tattr), rw2i);
   if (!existing.empty() && existing.size() != (size_t)tattr.nx * tattr.ny * tattr.nz) die("existing reconstruction target of the wrong size");
-  ENG(svr_init_reconstruction_volume(ctx, vsize, vdim, existing.empty() ? nullptr : existing.data(), 12.0f));   // copyFromHost :310-314
-  ENG(svr_set_mask(ctx, vsize, vdim, maskf.data(), 12.0f));
-  const uint32_t ssize[3] = {(uint32_t)px, (uint32_t)py, (uint32_t)ns};
-  std::vector<int> sizes_x(ns, px), sizes_y(ns, py);
-  ENG(svr_init_storage_volumes(ctx, ssize, &dims[0]));
-  ENG(svr_fill_slices(ctx, P.data.data(), sizes_x.data(), sizes_y.data()));
-  if (superpixel) ENG(svr_set_spx_masks(ctx, spx_masks.data()));
-  ENG(svr_set_slice_dims(ctx, dims.data(), 1.0f));
+  float pi2w[16], pw2i[16];
   {
     svr_image_attr pa;
     memset(&pa, 0, sizeof(pa));
     pa.nx = pa.ny = pa.nz = 128; pa.dx = tattr.dx; pa.dy = tattr.dy; pa.dz = tattr.dz;
     pa.xaxis[0] = pa.yaxis[1] = pa.zaxis[2] = 1.0;
-    float pi2w[16], pw2i[16];
     to_f16(image_to_world(pa), pi2w); to_f16(world_to_image(pa), pw2i);
-    const uint32_t psz[3] = {128, 128, 128};
-    ENG(svr_generate_psf_volume(ctx, nullptr, psz, &dims[0], vdim, pi2w, pw2i, 1.0f));
   }
-  ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), P.i2w.data(), P.w2i.data(), P.i2w.data(), P.w2i.data(), ri2w, rw2i));
+  auto set_matrices = [&](int r) {
+    const size_t o = 16 * (size_t)rlo[r];
+    ENGR(r, svr_set_slice_matrices(ctxs[r], st.data() + o, sti.data() + o, P.i2w.data() + o, P.w2i.data() + o, P.i2w.data() + o, P.w2i.data() + o, ri2w, rw2i));
+  };
+  par([&](int r) {
+    const int nl = rhi[r] - rlo[r];
+    const size_t o = (size_t)rlo[r];
+    ENGR(r, svr_set_option(ctxs[r], "pvr", 1));
+    if (coeff_table) ENGR(r, svr_set_option(ctxs[r], "coeff_table", 1));
+    ENGR(r, svr_set_option(ctxs[r], "tune_tiles", 32768));                 // a run is a few dozen PSF launches: cheap tuning trials
+    ENGR(r, svr_init_reconstruction_volume(ctxs[r], vsize, vdim, existing.empty() ? nullptr : existing.data(), 12.0f));   // copyFromHost :310-314
+    ENGR(r, svr_set_mask(ctxs[r], vsize, vdim, maskf.data(), 12.0f));
+    const uint32_t ssize[3] = {(uint32_t)px, (uint32_t)py, (uint32_t)nl};
+    std::vector<int> sizes_x(nl, px), sizes_y(nl, py);
+    ENGR(r, svr_init_storage_volumes(ctxs[r], ssize, &dims[3 * o]));
+    ENGR(r, svr_fill_slices(ctxs[r], P.data.data() + o * px * py, sizes_x.data(), sizes_y.data()));
+    if (superpixel) ENGR(r, svr_set_spx_masks(ctxs[r], spx_masks.data() + o * 4096));
+    ENGR(r, svr_set_slice_dims(ctxs[r], dims.data() + 3 * o, 1.0f));
+    const uint32_t psz[3] = {128, 128, 128};
+    ENGR(r, svr_generate_psf_volume(ctxs[r], nullptr, psz, &dims[3 * o], vdim, pi2w, pw2i, 1.0f));
+    set_matrices(r);
+    hosts[r] = pvrh_create_sharded(ctxs[r], counts.data(), (int)counts.size(), vmin, vmax, rlo[r], rhi[r],
+                                   group ? svr_group_join(group, r, ctxs[r]) : nullptr);
+    if (!hosts[r]) die("pvrh_create_sharded failed" + std::string(group ? " (the rank group could not be joined)" : ""));
+  });
+  if (nr > 1)
+    fprintf(stderr, "%d ranks on devices%s, patches per rank%s, collectives: %s\n", nr,
+            [&] { std::string t; for (int d : devices) t += " " + std::to_string(d); return t; }().c_str(),
+            [&] { std::string t; for (int r = 0; r < nr; ++r) t += " " + std::to_string(rhi[r] - rlo[r]); return t; }().c_str(),
+            svr_group_uses_rccl(group) ? "RCCL" : "host memory (a device is named more than once: test mode)");
 
   clk.mark("engine set-up and upload");
   // ---- the loop (PBR.cpp:445-593) ----------------------------------------------------------------------------
-  pvrh_recon *host = pvrh_create(ctx, counts.data(), (int)counts.size(), vmin, vmax);
-  if (!host) die("pvrh_create failed");
+  pvrh_recon *host = hosts[0];
   for (int it = 0; it < iterations + 1; ++it) {
     const bool have_volume = it > 0 || !existing.empty();                                      // PBR.cpp:456
     if (have_volume && !no_registration && superpixel) {
@@ -551,22 +608,27 @@ int main(int argc, char **argv) {
       fprintf(stderr, "superpixel mode: the patch-to-volume registration is skipped\n");
     } else if (have_volume && !no_registration) {        // PBR.cpp:452-489: runHybrid, the IRTK schedule on every patch
       std::vector<float> vol((size_t)tattr.nx * tattr.ny * tattr.nz);
-      ENG(svr_sync_cpu(ctx, vol.data()));                // m_GPURecon.copyToHost
-      long evals = 0;
-      char e[256] = {0};
-      if (svrh_slice_to_volume_registration(ctx, nullptr, ns, P.data.data(), px, py, P.attr.data(), Td.data(), &tattr, vol.data(),
-                                            SVRH_S2V_NO_RESAMPLE, &evals, e))
-        die(std::string("patch-to-volume registration: ") + e);
+      ENG(svr_sync_cpu(ctx, vol.data()));                // m_GPURecon.copyToHost (every rank holds the same volume)
+      std::vector<long> evals(nr, 0);
+      par([&](int r) {                                   // every rank registers its own patches against the shared volume
+        char e[256] = {0};
+        const size_t o = (size_t)rlo[r];
+        if (svrh_slice_to_volume_registration(ctxs[r], nullptr, rhi[r] - rlo[r], P.data.data() + o * px * py, px, py, P.attr.data() + o,
+                                              Td.data() + 16 * o, &tattr, vol.data(), SVRH_S2V_NO_RESAMPLE, &evals[r], e))
+          die(std::string("patch-to-volume registration: ") + e);
+      });
       for (int q = 0; q < ns; ++q) {                     // updateTransformationMatrices (patchBasedObject.cuh:151-169)
         M4 t;
         for (int k = 0; k < 16; ++k) t.m[k] = Td[16 * (size_t)q + k];
         to_f16(t, &st[16 * (size_t)q]); to_f16(inverse_rigid_or_affine(t), &sti[16 * (size_t)q]);
       }
-      ENG(svr_set_slice_matrices(ctx, st.data(), sti.data(), P.i2w.data(), P.w2i.data(), P.i2w.data(), P.w2i.data(), ri2w, rw2i));
-      fprintf(stderr, "patch-to-volume registration: %ld similarity evaluations\n", evals);
+      for (int r = 0; r < nr; ++r) set_matrices(r);
+      long total = 0;
+      for (long v : evals) total += v;
+      fprintf(stderr, "patch-to-volume registration: %ld similarity evaluations\n", total);
     }
     if (have_volume && !no_registration) clk.mark("registration of the patches");
-    PVRH(pvrh_reconstruct_iteration(host, sr_iterations));
+    par([&](int r) { PVRHR(r, pvrh_reconstruct_iteration(hosts[r], sr_iterations)); });
     clk.mark("reconstruction iteration");
     double sc[8];
     pvrh_get_state(host, nullptr, nullptr, nullptr, sc);
@@ -581,8 +643,9 @@ int main(int argc, char **argv) {
     fprintf(stderr, "[timing] tuned: scatter tiles %dx%d box %d, gather tiles %dx%d box %d\n", o[0], o[1], o[2], o[3], o[4], o[5]);
   }
   clk.mark("volume download");
-  pvrh_destroy(host);
-  svr_destroy(ctx);
+  for (int r = 0; r < nr; ++r) pvrh_destroy(hosts[r]);
+  svr_group_destroy(group);
+  for (int r = 0; r < nr; ++r) svr_destroy(ctxs[r]);
   return true;
   };
 

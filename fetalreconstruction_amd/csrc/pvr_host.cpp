@@ -5,15 +5,21 @@
 // EStep :224-556, MStep :570-640, Scale :672-745, InitializeRobustStatistics :793-845, with T = float.
 // Device work goes through the engine's C-ABI (include/svr_hip.h) with the engine option "pvr" set.
 //
+// Sharded over ranks (svr_shard.h): the engine of a rank holds the patches [lo, hi) of the global numbering, `scale`,
+// `patch_weight` and `patch_potential` stay GLOBAL vectors on every rank and the patch-level EM runs replicated on them.
+//
 // Kept quirks: the patch potentials of stack i are written at the patch index inside the stack, without the
 // stack offset (PRS.cu:256-276); __step of G_ is 0.00001f (:97-101) while m_step is 0.0001; delta 1, lambda 0.1
 // (patchBasedSuperresolution_gpu.cu:291-295).
 #include <math.h>
 
+#include <algorithm>
+
 #include <string>
 #include <vector>
 
 #include "../../include/svr_host.h"
+#include "svr_shard.h"
 
 namespace svr {
 
@@ -28,11 +34,17 @@ class irtkPatchBasedReconstruction {
   float m_delta, m_lambda, m_alpha, m_step;
   float m_sigma_gpu, m_mix_gpu, m_m_gpu, m_sigma_s_gpu, m_mix_s_gpu, m_mean_s_gpu, m_mean_s2_gpu, m_sigma_s2_gpu;
   std::vector<float> scale, patch_weight, patch_potential;
+  Shard sh;
+  int lo, hi;
+  bool scale_stale = false;            // the other ranks' scales arrive with the next exchange (the E-step's)
 
-  irtkPatchBasedReconstruction(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_i, float max_i)
+  irtkPatchBasedReconstruction(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_i, float max_i, int lo_ = 0,
+                               int hi_ = -1, const svr_collectives *c = nullptr)
       : e(engine), counts(patches_per_stack, patches_per_stack + n_stacks), n(0), m_min_intensity(min_i),
         m_max_intensity(max_i), m_adaptive(false) {
-    for (int c : counts) n += c;
+    for (int c_ : counts) n += c_;
+    lo = lo_; hi = hi_ < 0 ? n : hi_;
+    sh.init(engine, n, lo, hi, c);
     m_delta = 1.0f;
     m_lambda = 0.1f;
     m_alpha = (0.05f / m_lambda) * m_delta * m_delta;
@@ -54,14 +66,33 @@ class irtkPatchBasedReconstruction {
   int initializeEMValues() {                                                 // PRS.cu:78-95
     scale.assign(n, 1.0f);
     patch_weight.assign(n, 1.0f);
-    PENG(svr_update_scale_vector(e, scale.data(), patch_weight.data()));
+    PENG(svr_update_scale_vector(e, scale.data() + lo, patch_weight.data() + lo));
     PENG(svr_initialize_em_values(e));
     return 0;
+  }
+
+  int exchange(const double *mine, int n_mine, std::vector<double> &all, std::vector<float> *pot) {
+    std::vector<float> *vec[3] = {scale_stale ? &scale : nullptr, nullptr, pot};
+    const int rc = sh.exchange(mine, n_mine, all, vec);
+    if (rc) { err = rc == SVR_E_STATE ? "exchange: the ranks are not in the same step of the reconstruction" : "exchange: the collective failed"; return rc; }
+    scale_stale = false;
+    return 0;
+  }
+  int flush() {
+    if (!sh.on || !scale_stale) return 0;
+    std::vector<double> none;
+    return exchange(nullptr, 0, none, nullptr);
   }
 
   int InitializeRobustStatistics() {                                         // PRS.cu:793-845
     double s2[2];
     PENG(svr_robust_statistics_sums(e, s2));
+    if (sh.on) {
+      std::vector<double> all;
+      if (int rc = exchange(s2, 2, all, nullptr)) return rc;
+      s2[0] = s2[1] = 0;
+      for (int r = 0; r < sh.coll.world; ++r) { s2[0] += all[2 * r]; s2[1] += all[2 * r + 1]; }   // rank order: the same bits everywhere
+    }
     if (s2[1] == 0) { err = "ERROR: sb = 0!! no sigma computed!"; return 10001; }   // the reference exits here
     m_sigma_gpu = (float)s2[0] / (float)s2[1];
     m_sigma_s_gpu = 0.025f;
@@ -72,8 +103,9 @@ class irtkPatchBasedReconstruction {
   }
 
   int EStep() {                                                              // PRS.cu:224-556
-    std::vector<float> pot(n);
-    PENG(svr_estep(e, m_m_gpu, m_sigma_gpu, m_mix_gpu, pot.data()));
+    std::vector<float> pot(n, 0.0f);
+    PENG(svr_estep(e, m_m_gpu, m_sigma_gpu, m_mix_gpu, pot.data() + lo));
+    if (sh.on) { std::vector<double> none; if (int rc = exchange(nullptr, 0, none, &pot)) return rc; }   // (and the scale vector)
     std::vector<float> pp(n, 0.0f);
     int ofs = 0;
     for (int c : counts) {                                                   // :256-276: no stack offset on the left
@@ -137,13 +169,23 @@ class irtkPatchBasedReconstruction {
       if (pp[i] >= 0) { sum += pw[i]; num++; }
     m_mix_s_gpu = num > 0 ? (float)(sum / num) : 0.9f;                       // :455-468
     patch_potential = pp;
-    PENG(svr_update_scale_vector(e, scale.data(), patch_weight.data()));     // copyToWeightsAndScales :486-491
+    PENG(svr_update_scale_vector(e, scale.data() + lo, patch_weight.data() + lo));     // copyToWeightsAndScales :486-491
     return 0;
   }
 
   int MStep(int iter) {                                                      // PRS.cu:570-640
     double s5[5];
     PENG(svr_mstep_sums(e, s5));
+    if (sh.on) {
+      std::vector<double> all;
+      if (int rc = exchange(s5, 5, all, nullptr)) return rc;                 // three sums, a minimum, a maximum: one collective
+      s5[0] = s5[1] = s5[2] = 0;
+      for (int r = 0; r < sh.coll.world; ++r) {
+        for (int k = 0; k < 3; ++k) s5[k] += all[5 * r + k];
+        s5[3] = r ? std::min(s5[3], all[5 * r + 3]) : all[3];
+        s5[4] = r ? std::max(s5[4], all[5 * r + 4]) : all[4];
+      }
+    }
     const float sigma = (float)s5[0], mix = (float)s5[1], num = (float)s5[2], mn = (float)s5[3], mx = (float)s5[4];
     if (mix > 0) m_sigma_gpu = sigma / mix;
     if (m_sigma_gpu < m_step * m_step / 6.28f) m_sigma_gpu = m_step * m_step / 6.28f;
@@ -153,8 +195,9 @@ class irtkPatchBasedReconstruction {
   }
 
   int Scale() {                                                              // PRS.cu:672-745
-    PENG(svr_calculate_scale_vector(e, scale.data()));
-    PENG(svr_update_scale_vector(e, scale.data(), patch_weight.data()));     // copyToScales: no lag
+    PENG(svr_calculate_scale_vector(e, scale.data() + lo));
+    PENG(svr_update_scale_vector(e, scale.data() + lo, patch_weight.data() + lo));     // copyToScales: no lag
+    scale_stale = sh.on;                                                     // read next in the E-step, whose exchange completes it
     return 0;
   }
 
@@ -172,15 +215,37 @@ class irtkPatchBasedReconstruction {
     int rc;
     if ((rc = initializeEMValues())) return rc;
     int nvox = 0;
-    PENG(svr_gaussian_reconstruction(e, &nvox));     // reset + patchBasedPSFReconstruction_gpu + equalize
-    std::vector<unsigned char> inside(n);
+    if (!sh.on) {
+      PENG(svr_gaussian_reconstruction(e, &nvox));     // reset + patchBasedPSFReconstruction_gpu + equalize
+    } else {
+      PENG(svr_gaussian_reconstruction_local(e));
+      PENG(sh.allreduce_pair(SVR_BUF_RECONSTRUCTED, 2 * svr_volume_voxels(e)));
+      PENG(svr_gaussian_reconstruction_finish(e, &nvox));
+    }
+    std::vector<unsigned char> inside(hi - lo);
     PENG(svr_simulate_slices(e, inside.data()));
     if ((rc = InitializeRobustStatistics())) return rc;
     if ((rc = EStep())) return rc;
     for (int i = 0; i < rec_iterations; ++i) {
+      if ((rc = sr_iteration(i))) return rc;
+    }
+    return 0;
+  }
+
+  // one SR iteration (PBR.cpp:505-546): Scale, resetAddonCmap + run + regularize, simulate, M-step, E-step
+  int sr_iteration(int i) {
+    int rc;
+    std::vector<unsigned char> inside(hi - lo);
+    {
       if ((rc = Scale())) return rc;
-      PENG(svr_superresolution(e, i + 1, patch_weight.data(), m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta,
-                               m_lambda, 0, 12.0f, 0.01f));   // resetAddonCmap + run + regularize
+      if (!sh.on) {
+        PENG(svr_superresolution(e, i + 1, patch_weight.data() + lo, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta,
+                                 m_lambda, 0, 12.0f, 0.01f));
+      } else {
+        PENG(svr_superresolution_backproject(e, patch_weight.data() + lo));
+        PENG(sh.allreduce_pair(SVR_BUF_ADDON, 2 * svr_volume_voxels(e)));
+        PENG(svr_superresolution_update(e, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta, m_lambda));
+      }
       PENG(svr_simulate_slices(e, inside.data()));
       if ((rc = MStep(i + 1))) return rc;
       if ((rc = EStep())) return rc;
@@ -194,15 +259,26 @@ class irtkPatchBasedReconstruction {
 
 struct pvrh_recon {
   svr::irtkPatchBasedReconstruction impl;
-  pvrh_recon(svr_ctx *e, const int *c, int ns, float mn, float mx) : impl(e, c, ns, mn, mx) {}
+  pvrh_recon(svr_ctx *e, const int *c, int ns, float mn, float mx, int lo, int hi, const svr_collectives *coll) : impl(e, c, ns, mn, mx, lo, hi, coll) {}
 };
 
 extern "C" {
 
 pvrh_recon *pvrh_create(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_intensity, float max_intensity) {
   if (!engine || !patches_per_stack || n_stacks <= 0) return nullptr;
-  return new pvrh_recon(engine, patches_per_stack, n_stacks, min_intensity, max_intensity);
+  return new pvrh_recon(engine, patches_per_stack, n_stacks, min_intensity, max_intensity, 0, -1, nullptr);
 }
+pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_intensity, float max_intensity,
+                                int patch_lo, int patch_hi, const svr_collectives *coll) {
+  if (!engine || !patches_per_stack || n_stacks <= 0) return nullptr;
+  long total = 0;
+  for (int k = 0; k < n_stacks; ++k) total += patches_per_stack[k];
+  if (patch_lo < 0 || patch_hi < patch_lo || patch_hi > total) return nullptr;
+  if (coll && coll->world > 1 && (!coll->allreduce_volume_pair || !coll->allreduce_host)) return nullptr;
+  return new pvrh_recon(engine, patches_per_stack, n_stacks, min_intensity, max_intensity, patch_lo, patch_hi, coll);
+}
+void pvrh_force_collectives(pvrh_recon *r, int on) { if (r) r->impl.sh.force(on != 0); }
+int pvrh_sr_iteration(pvrh_recon *r, int i) { return r->impl.sr_iteration(i); }
 void pvrh_destroy(pvrh_recon *r) { delete r; }
 const char *pvrh_last_error(const pvrh_recon *r) { return r ? r->impl.err.c_str() : "null"; }
 int pvrh_initialize_em_values(pvrh_recon *r) { return r->impl.initializeEMValues(); }
@@ -217,6 +293,7 @@ int pvrh_register_patches(pvrh_recon *r, const float *ri2w, const float *mo, con
 }
 int pvrh_get_state(pvrh_recon *r, float *scale, float *patch_weight, float *patch_potential, double scalars8[8]) {
   svr::irtkPatchBasedReconstruction &p = r->impl;
+  if (int rc = p.flush()) return rc;       // sharded: collective (the other ranks' scales may still be on their way)
   if (scale) std::copy(p.scale.begin(), p.scale.end(), scale);
   if (patch_weight) std::copy(p.patch_weight.begin(), p.patch_weight.end(), patch_weight);
   if (patch_potential) std::copy(p.patch_potential.begin(), p.patch_potential.end(), patch_potential);

@@ -2857,6 +2857,13 @@ int fail(svr_ctx *c, int code, const std::string &msg) {
   if (c) c->err = msg;
   return code;
 }
+// Every public entry point selects the context's device first: the command lines run one host thread per device and start
+// fresh threads per phase (a new thread's current device is 0), so hipMalloc / hipMemGetInfo / event calls inside an entry
+// point would otherwise land on GPU 0 until the first call that happened to set the device.
+#define SVR_ENTER(c)                                                                        \
+  do {                                                                                      \
+    if (c) (void)hipSetDevice((c)->device);                                                 \
+  } while (0)
 #define HIPCHK(expr)                                                                        \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \
@@ -3191,12 +3198,29 @@ int ensure_coeff(svr_ctx *ctx) {
   return SVR_OK;
 }
 
-int launch_slot(svr_ctx *ctx, bool pvr, const PsfArgs &a, const TileArgs &ta, uint32_t *fb, uint32_t *cnt) {
-  const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-  if (pvr) hipLaunchKernelGGL((back_slot_kernel<8, PVR_N, true>), dim3(ta.ntiles), dim3(8 * 64), lds, ctx->stream, a, ta, fb, cnt);
-  else hipLaunchKernelGGL(back_slot_kernel<8>, dim3(ta.ntiles), dim3(8 * 64), lds, ctx->stream, a, ta, fb, cnt);
-  KCHK("back_slot_kernel");
+// A dispatch holds at most 2^32 - 1 work-items per dimension (launch_fwd_unit above tells how that was found): every kernel
+// that takes one workgroup per entry of a tile list sends long lists out in pieces.  f(offset, count) launches one piece.
+template <class F>
+int in_pieces(uint32_t n, uint32_t threads_per_tile, F &&f) {
+  static const long env = getenv("SVR_LIST_PIECE") ? atol(getenv("SVR_LIST_PIECE")) : 0;     // test hook: short pieces on a small problem
+  uint32_t piece = (uint32_t)((((1ull << 32) - 1) / threads_per_tile) & ~1023ull);
+  if (env > 0) piece = (uint32_t)std::min<long>(env, piece);
+  for (uint32_t off = 0; off < n; off += piece) {
+    const int r = f(off, std::min(piece, n - off));
+    if (r) return r;
+  }
   return SVR_OK;
+}
+int launch_slot(svr_ctx *ctx, bool pvr, const PsfArgs &a, const TileArgs &ta_, uint32_t *fb, uint32_t *cnt) {
+  const size_t lds = (size_t)ta_.cap * 2 * sizeof(float);
+  return in_pieces(ta_.ntiles, 8 * 64, [&](uint32_t off, uint32_t cntp) {
+    TileArgs ta = ta_;
+    ta.tiles = ta_.tiles + off; ta.ntiles = cntp;
+    if (pvr) hipLaunchKernelGGL((back_slot_kernel<8, PVR_N, true>), dim3(ta.ntiles), dim3(8 * 64), lds, ctx->stream, a, ta, fb, cnt);
+    else hipLaunchKernelGGL(back_slot_kernel<8>, dim3(ta.ntiles), dim3(8 * 64), lds, ctx->stream, a, ta, fb, cnt);
+    KCHK("back_slot_kernel");
+    return (int)SVR_OK;
+  });
 }
 int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, const uint32_t *tiles, uint32_t n, int mode_last) {
   PsfArgs a = a_;
@@ -3254,14 +3278,20 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
   if (level >= 3) ctx->n_tiles_fb = ncur;
   if (ncur) {
     ta.tiles = cur; ta.ntiles = ncur; ta.cap = ctx->tile_cap;
-    if (pvr) {
-      if (mode_last == MODE_GAUSS2) { a.recon = a.addon; a.volw = a.cmap; }
-      if (mode_last == MODE_GAUSS2) hipLaunchKernelGGL(pvr_tiles_kernel<MODE_GAUSS2>, dim3(ncur), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
-      else hipLaunchKernelGGL(pvr_tiles_kernel<MODE_BACK>, dim3(ncur), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
-    } else {
-      hipLaunchKernelGGL(back_tiled_kernel, dim3(ncur), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
-    }
-    KCHK("scatter (last resort)");
+    if (pvr && mode_last == MODE_GAUSS2) { a.recon = a.addon; a.volw = a.cmap; }
+    const TileArgs ta0 = ta;
+    r = in_pieces(ncur, pvr ? WAVES_PER_BLOCK * 64 : TILE_WAVES * 64, [&](uint32_t off, uint32_t cntp) {
+      ta.tiles = ta0.tiles + off; ta.ntiles = cntp;
+      if (pvr) {
+        if (mode_last == MODE_GAUSS2) hipLaunchKernelGGL(pvr_tiles_kernel<MODE_GAUSS2>, dim3(cntp), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
+        else hipLaunchKernelGGL(pvr_tiles_kernel<MODE_BACK>, dim3(cntp), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a, ta);
+      } else {
+        hipLaunchKernelGGL(back_tiled_kernel, dim3(cntp), dim3(TILE_WAVES * 64), (size_t)ctx->tile_cap * 2 * sizeof(float), ctx->stream, a, ta);
+      }
+      KCHK("scatter (last resort)");
+      return (int)SVR_OK;
+    });
+    if (r) return r;
   }
   return SVR_OK;
 }
@@ -3341,6 +3371,7 @@ int svr_create(int device, svr_ctx **out) {
 }
 
 int svr_set_option(svr_ctx *ctx, const char *name, int value) {
+  SVR_ENTER(ctx);
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
@@ -3402,6 +3433,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
 }
 
 int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
+  SVR_ENTER(ctx);
   if (!ctx || !name || !value) return SVR_E_ARG;
   const struct { const char *n; int v; } tab[] = {
       {"back_mode", ctx->back_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
@@ -3439,6 +3471,7 @@ void svr_destroy(svr_ctx *ctx) {
 const char *svr_last_error(const svr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   ctx->disable_bias = disable_bias_correction != 0;
   ctx->debug_gpu = debug_gpu != 0;
@@ -3446,6 +3479,7 @@ int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu) {
 }
 
 int svr_set_stream(svr_ctx *ctx, void *hip_stream) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -3463,6 +3497,7 @@ int svr_device_count(void) {
 
 int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const float dim[3],
                                    const float *data, float sigma_bias) {
+  SVR_ENTER(ctx);
   if (!ctx || !size || !dim) return SVR_E_ARG;
   (void)sigma_bias;
   HIPCHK(hipSetDevice(ctx->device));
@@ -3487,6 +3522,7 @@ int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const f
 
 int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const float *data,
                  float sigma_bias) {
+  SVR_ENTER(ctx);
   if (!ctx || !size || !data) return SVR_E_ARG;
   (void)dim;   // the blurred maskC_ (RC.cu:1129-1157) is built lazily: it only feeds NormaliseBias
   NEED(ctx->nv > 0, "InitReconstructionVolume first");
@@ -3503,6 +3539,7 @@ int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const
 }
 
 int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float dim[3]) {
+  SVR_ENTER(ctx);
   if (!ctx || !size) return SVR_E_ARG;
   (void)dim;
   HIPCHK(hipSetDevice(ctx->device));
@@ -3553,6 +3590,7 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
 }
 
 int svr_fill_slices(svr_ctx *ctx, const float *sdata, const int *sizes_x, const int *sizes_y) {
+  SVR_ENTER(ctx);
   if (!ctx || !sdata) return SVR_E_ARG;
   (void)sizes_x; (void)sizes_y;   // only used by the reference's dead code (RC.cu:3252-3253)
   NEED(ctx->np > 0, "initStorageVolumes first");
@@ -3564,6 +3602,7 @@ int svr_fill_slices(svr_ctx *ctx, const float *sdata, const int *sizes_x, const 
 }
 
 int svr_set_slice_dims(svr_ctx *ctx, const float *slice_dims, float quality_factor) {
+  SVR_ENTER(ctx);
   if (!ctx || !slice_dims) return SVR_E_ARG;
   NEED(ctx->ns > 0, "initStorageVolumes first");
   ctx->slice_dims.assign(slice_dims, slice_dims + 3 * (size_t)ctx->ns);
@@ -3577,6 +3616,7 @@ int svr_set_slice_dims(svr_ctx *ctx, const float *slice_dims, float quality_fact
 int svr_set_slice_matrices(svr_ctx *ctx, const float *T, const float *Tinv, const float *i2w_init,
                            const float *w2i_init, const float *i2w, const float *w2i,
                            const float recon_i2w[16], const float recon_w2i[16]) {
+  SVR_ENTER(ctx);
   if (!ctx || !T || !Tinv || !i2w || !w2i || !recon_i2w || !recon_w2i) return SVR_E_ARG;
   (void)i2w_init; (void)w2i_init;   // registration-only in the reference (RC.cu:3486)
   NEED(ctx->ns > 0, "initStorageVolumes first");
@@ -3595,6 +3635,7 @@ int svr_set_slice_matrices(svr_ctx *ctx, const float *T, const float *Tinv, cons
 int svr_generate_psf_volume(svr_ctx *ctx, const float *cpu_psf, const uint32_t psf_size[3],
                             const float slice_voxel_dim[3], const float psf_dim[3],
                             const float psf_i2w[16], const float psf_w2i[16], float quality_factor) {
+  SVR_ENTER(ctx);
   if (!ctx || !psf_size || !psf_i2w) return SVR_E_ARG;
   (void)cpu_psf; (void)slice_voxel_dim; (void)psf_dim; (void)psf_w2i;
   // d_PSFI2W * ((PSFsize - 1) * 0.5f)   RC.cu:172
@@ -3607,6 +3648,7 @@ int svr_generate_psf_volume(svr_ctx *ctx, const float *cpu_psf, const uint32_t p
 }
 
 int svr_update_scale_vector(svr_ctx *ctx, const float *scales, const float *slice_weights) {
+  SVR_ENTER(ctx);
   if (!ctx || !scales || !slice_weights) return SVR_E_ARG;
   NEED(ctx->ns > 0, "initStorageVolumes first");
   ctx->h_scales.assign(scales, scales + ctx->ns);
@@ -3620,6 +3662,7 @@ int svr_update_scale_vector(svr_ctx *ctx, const float *scales, const float *slic
 }
 
 int svr_update_slice_weights(svr_ctx *ctx, const float *slice_weights) {
+  SVR_ENTER(ctx);
   if (!ctx || !slice_weights) return SVR_E_ARG;
   NEED(ctx->have_scales, "UpdateScaleVector first");
   ctx->h_slice_weights.assign(slice_weights, slice_weights + ctx->ns);
@@ -3627,6 +3670,7 @@ int svr_update_slice_weights(svr_ctx *ctx, const float *slice_weights) {
 }
 
 int svr_update_reconstructed(svr_ctx *ctx, const uint32_t size[3], const float *data) {
+  SVR_ENTER(ctx);
   if (!ctx || !size || !data) return SVR_E_ARG;
   NEED(ctx->nv > 0, "InitReconstructionVolume first");
   if ((size_t)size[0] * size[1] * size[2] != ctx->nv) return fail(ctx, SVR_E_ARG, "size mismatch");
@@ -3636,6 +3680,7 @@ int svr_update_reconstructed(svr_ctx *ctx, const uint32_t size[3], const float *
 }
 
 int svr_sync_cpu(svr_ctx *ctx, float *out) {
+  SVR_ENTER(ctx);
   if (!ctx || !out) return SVR_E_ARG;
   NEED(ctx->nv > 0, "InitReconstructionVolume first");
   HIPCHK(hipMemcpyAsync(out, ctx->recon(), ctx->nv * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -3645,6 +3690,7 @@ int svr_sync_cpu(svr_ctx *ctx, float *out) {
 
 // Reconstruction::updateStackSizes (RC.cuh:210): the sizes are stored; nothing in the reference reads them back
 int svr_update_stack_sizes(svr_ctx *ctx, const uint32_t *sizes3, int n_stacks) {
+  SVR_ENTER(ctx);
   if (!ctx || n_stacks < 0 || (n_stacks > 0 && !sizes3)) return SVR_E_ARG;
   ctx->stack_sizes.assign(sizes3, sizes3 + 3 * (size_t)n_stacks);
   return SVR_OK;
@@ -3653,6 +3699,7 @@ int svr_update_stack_sizes(svr_ctx *ctx, const uint32_t *sizes3, int n_stacks) {
 // Reconstruction::combineWeights (RC.cu:5091-5097): the bias path's accumulated volume weights (dev_volume_weights_) of device 0;
 // zeros while no NormaliseBias has run (the reference's buffer is cleared at allocation, RC.cu:1214)
 int svr_combine_weights(svr_ctx *ctx, float *out) {
+  SVR_ENTER(ctx);
   if (!ctx || !out) return SVR_E_ARG;
   NEED(ctx->nv > 0, "InitReconstructionVolume first");
   if (!ctx->d_volume_weights) { memset(out, 0, ctx->nv * sizeof(float)); return SVR_OK; }
@@ -3662,6 +3709,7 @@ int svr_combine_weights(svr_ctx *ctx, float *out) {
 }
 
 int svr_get_vol_weights(svr_ctx *ctx, float *out) {
+  SVR_ENTER(ctx);
   if (!ctx || !out) return SVR_E_ARG;
   NEED(ctx->nv > 0, "InitReconstructionVolume first");
   HIPCHK(hipMemcpyAsync(out, ctx->volw(), ctx->nv * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -3671,6 +3719,7 @@ int svr_get_vol_weights(svr_ctx *ctx, float *out) {
 
 // ---- Gaussian reconstruction -----------------------------------------------------------
 int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   int r = ready(ctx);
   if (r) return r;
@@ -3755,6 +3804,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
 }
 
 int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(ctx->nv > 0 && ctx->have_slices, "volume / slices not set");
   hipLaunchKernelGGL(k_equalize, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->volw(), ctx->nv);
@@ -3771,6 +3821,7 @@ int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num) {
 }
 
 int svr_gaussian_reconstruction(svr_ctx *ctx, int *voxel_num) {
+  SVR_ENTER(ctx);
   int r = svr_gaussian_reconstruction_local(ctx);
   if (r) return r;
   return svr_gaussian_reconstruction_finish(ctx, voxel_num);
@@ -3778,6 +3829,7 @@ int svr_gaussian_reconstruction(svr_ctx *ctx, int *voxel_num) {
 
 // ---- forward projection ----------------------------------------------------------------
 int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   int r = ready(ctx);
   if (r) return r;
@@ -3869,6 +3921,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
 
 // ---- EM --------------------------------------------------------------------------------
 int svr_initialize_em_values(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(ctx->have_slices, "slices not filled");
   hipLaunchKernelGGL(k_init_em, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights, ctx->np, ctx->pvr);
@@ -3883,6 +3936,7 @@ int svr_initialize_em_values(svr_ctx *ctx) {
 }
 
 int svr_robust_statistics_sums(svr_ctx *ctx, double out2[2]) {
+  SVR_ENTER(ctx);
   if (!ctx || !out2) return SVR_E_ARG;
   NEED(ctx->have_slices, "slices not filled");
   hipLaunchKernelGGL(k_robust, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_siminside,
@@ -3896,6 +3950,7 @@ int svr_robust_statistics_sums(svr_ctx *ctx, double out2[2]) {
 }
 
 int svr_initialize_robust_statistics(svr_ctx *ctx, float *sigma) {
+  SVR_ENTER(ctx);
   if (!ctx || !sigma) return SVR_E_ARG;
   double s2[2];
   int r = svr_robust_statistics_sums(ctx, s2);
@@ -3905,6 +3960,7 @@ int svr_initialize_robust_statistics(svr_ctx *ctx, float *sigma) {
 }
 
 int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potential) {
+  SVR_ENTER(ctx);
   if (!ctx || !slice_potential) return SVR_E_ARG;
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   ScopedTimer t(ctx, SVR_T_ESTEP);
@@ -3924,6 +3980,7 @@ int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potent
 }
 
 int svr_mstep_sums(svr_ctx *ctx, double out5[5]) {
+  SVR_ENTER(ctx);
   if (!ctx || !out5) return SVR_E_ARG;
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   // the reference fills its per-pixel scale buffer from the HOST copy h_scales (RC.cu:3091-3094)
@@ -3943,6 +4000,7 @@ int svr_mstep_sums(svr_ctx *ctx, double out5[5]) {
 }
 
 int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma_io, float *mix_io, float *m_out) {
+  SVR_ENTER(ctx);
   if (!ctx || !sigma_io || !mix_io || !m_out) return SVR_E_ARG;
   double s5[5];
   int r = svr_mstep_sums(ctx, s5);
@@ -3961,6 +4019,7 @@ int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma_io, float *mix_io
 }
 
 int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
+  SVR_ENTER(ctx);
   if (!ctx || !scale_vec) return SVR_E_ARG;
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   ScopedTimer t(ctx, SVR_T_SCALE);
@@ -3988,6 +4047,7 @@ int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
 
 // ---- super-resolution ------------------------------------------------------------------
 int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   int r = ready(ctx);
   if (r) return r;
@@ -4105,6 +4165,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
 
 int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity,
                                float max_intensity, float delta, float lambda) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(ctx->nv > 0, "volume not set");
   if (alpha * lambda / (delta * delta) > 0.068)   // RC.cu:2124-2127
@@ -4126,6 +4187,7 @@ int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float mi
 int svr_superresolution(svr_ctx *ctx, int iter, const float *slice_weight, int adaptive, float alpha,
                         float min_intensity, float max_intensity, float delta, float lambda,
                         int global_bias_correction, float sigma_bias, float low_intensity_cutoff) {
+  SVR_ENTER(ctx);
   (void)iter; (void)sigma_bias; (void)low_intensity_cutoff;
   int r = svr_superresolution_backproject(ctx, slice_weight);
   if (r) return r;
@@ -4136,6 +4198,7 @@ int svr_superresolution(svr_ctx *ctx, int iter, const float *slice_weight, int a
 }
 
 int svr_mask_volume(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(ctx->nv > 0 && ctx->have_mask, "volume / mask not set");
   hipLaunchKernelGGL(k_mask_volume, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_mask, ctx->nv);
@@ -4145,6 +4208,7 @@ int svr_mask_volume(svr_ctx *ctx) {
 }
 
 int svr_scale_volume_sums(svr_ctx *ctx, double out2[2]) {
+  SVR_ENTER(ctx);
   if (!ctx || !out2) return SVR_E_ARG;
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   hipLaunchKernelGGL(k_scalevol, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
@@ -4159,6 +4223,7 @@ int svr_scale_volume_sums(svr_ctx *ctx, double out2[2]) {
 }
 
 int svr_scale_volume_apply(svr_ctx *ctx, float scale) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(ctx->nv > 0, "volume not set");
   hipLaunchKernelGGL(k_scale_volume, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), scale, ctx->nv);
@@ -4168,6 +4233,7 @@ int svr_scale_volume_apply(svr_ctx *ctx, float scale) {
 }
 
 int svr_scale_volume(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
   double s2[2];
   int r = svr_scale_volume_sums(ctx, s2);
   if (r) return r;
@@ -4178,6 +4244,7 @@ int svr_scale_volume(svr_ctx *ctx) {
 
 int svr_restore_slice_intensities(svr_ctx *ctx, const float *stack_factors, int n_stacks,
                                   const int *stack_index) {
+  SVR_ENTER(ctx);
   if (!ctx || !stack_factors || !stack_index || n_stacks <= 0) return SVR_E_ARG;
   NEED(ctx->have_slices, "slices not filled");
   for (uint32_t i = 0; i < ctx->ns; ++i)
@@ -4222,6 +4289,7 @@ static int buffer_info(svr_ctx *ctx, int which, void **ptr, size_t *bytes) {
 }
 
 int svr_debug_get(svr_ctx *ctx, int which, void *host_out, size_t bytes) {
+  SVR_ENTER(ctx);
   if (!ctx || !host_out) return SVR_E_ARG;
   void *p; size_t b;
   int r = buffer_info(ctx, which, &p, &b);
@@ -4233,6 +4301,7 @@ int svr_debug_get(svr_ctx *ctx, int which, void *host_out, size_t bytes) {
 }
 
 int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
+  SVR_ENTER(ctx);
   if (!ctx || !host_in) return SVR_E_ARG;
   void *p; size_t b;
   int r = buffer_info(ctx, which, &p, &b);
@@ -4247,6 +4316,7 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
 }
 
 void *svr_device_ptr(svr_ctx *ctx, int which) {
+  SVR_ENTER(ctx);
   if (!ctx) return nullptr;
   void *p; size_t b;
   if (buffer_info(ctx, which, &p, &b)) return nullptr;
@@ -4256,6 +4326,7 @@ void *svr_device_ptr(svr_ctx *ctx, int which) {
 size_t svr_volume_voxels(const svr_ctx *ctx) { return ctx ? ctx->nv : 0; }
 
 int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals4096, int *centre3) {
+  SVR_ENTER(ctx);
   if (!ctx || !vals4096 || !centre3) return SVR_E_ARG;
   int r = ready(ctx);
   if (r) return r;
@@ -4280,6 +4351,7 @@ int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals40
 
 // ---- PVR superpixel masks (ImagePatch2D::spxMask, R2/include/ImagePatch2D.cuh:51) ----------
 int svr_set_spx_masks(svr_ctx *ctx, const char *masks_or_null) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(ctx->ns > 0, "initStorageVolumes first");
   free_dev(ctx->d_spx);
@@ -4293,6 +4365,7 @@ int svr_set_spx_masks(svr_ctx *ctx, const char *masks_or_null) {
 
 // ---- bias correction --------------------------------------------------------------------
 int svr_correct_bias(svr_ctx *ctx, float sigma_bias, int global_bias_correction) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(!ctx->disable_bias, "bias correction is disabled (svr_set_flags)");
   NEED(ctx->have_slices && ctx->have_scales && ctx->have_dims, "slices / scales / slice dims not set");
@@ -4338,6 +4411,7 @@ int svr_correct_bias(svr_ctx *ctx, float sigma_bias, int global_bias_correction)
 }
 
 int svr_normalise_bias_local(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(!ctx->disable_bias, "bias correction is disabled (svr_set_flags)");
   int r = ready(ctx);
@@ -4360,6 +4434,7 @@ int svr_normalise_bias_local(svr_ctx *ctx) {
 }
 
 int svr_normalise_bias_finish(svr_ctx *ctx, float sigma_bias) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   NEED(!ctx->disable_bias && ctx->d_bias_vol && ctx->maskC_valid, "bias buffers not ready");
   const size_t nv = ctx->nv;
@@ -4383,6 +4458,7 @@ int svr_normalise_bias_finish(svr_ctx *ctx, float sigma_bias) {
 }
 
 int svr_normalise_bias(svr_ctx *ctx, int iter, float sigma_bias) {
+  SVR_ENTER(ctx);
   (void)iter;
   int r = svr_normalise_bias_local(ctx);
   if (r) return r;
@@ -4391,6 +4467,7 @@ int svr_normalise_bias(svr_ctx *ctx, int iter, float sigma_bias) {
 
 // ---- slice-to-volume registration cost --------------------------------------------------
 int svr_ncc_set_targets(svr_ctx *ctx, int n, int tx, int ty, const int16_t *targets) {
+  SVR_ENTER(ctx);
   if (!ctx || !targets || n <= 0 || tx <= 0 || ty <= 0) return SVR_E_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   free_dev(ctx->d_reg_targets);
@@ -4403,6 +4480,7 @@ int svr_ncc_set_targets(svr_ctx *ctx, int n, int tx, int ty, const int16_t *targ
 }
 
 int svr_ncc_set_source(svr_ctx *ctx, const uint32_t size[3], const int16_t *source_or_null) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   if (!source_or_null) NEED(ctx->nv > 0, "no source given and no reconstruction volume");
   uint32_t sx = source_or_null ? size[0] : ctx->vx, sy = source_or_null ? size[1] : ctx->vy,
@@ -4425,6 +4503,7 @@ int svr_ncc_set_source(svr_ctx *ctx, const uint32_t size[3], const int16_t *sour
 
 int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const double *matrices,
                      int64_t *sums6, double *ncc) {
+  SVR_ENTER(ctx);
   if (!ctx || n_eval <= 0 || !target_index || !matrices) return SVR_E_ARG;
   NEED(ctx->d_reg_targets && ctx->d_reg_source, "svr_ncc_set_targets / svr_ncc_set_source first");
   for (int i = 0; i < n_eval; ++i)
@@ -4468,22 +4547,50 @@ int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const do
 
 // ---- measurement -----------------------------------------------------------------------
 int svr_timer_enable(svr_ctx *ctx, int enable) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   ctx->timers = enable != 0;
   return SVR_OK;
 }
 int svr_timer_reset(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
   for (int i = 0; i < SVR_T_COUNT; ++i) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
   return SVR_OK;
 }
 int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches) {
+  SVR_ENTER(ctx);
   if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
   if (ms_total) *ms_total = ctx->t_ms[which];
   if (launches) *launches = ctx->t_n[which];
   return SVR_OK;
 }
+int svr_timer_begin(svr_ctx *ctx, int which) {
+  SVR_ENTER(ctx);
+  if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
+  if (ctx->timers) HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  return SVR_OK;
+}
+int svr_timer_end(svr_ctx *ctx, int which) {
+  SVR_ENTER(ctx);
+  if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
+  if (ctx->timers) {
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->t_ms[which] += ms;
+    ctx->t_n[which] += 1;
+  }
+  return SVR_OK;
+}
+int svr_timer_add(svr_ctx *ctx, int which, double ms) {
+  if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
+  if (ctx->timers) { ctx->t_ms[which] += ms; ctx->t_n[which] += 1; }
+  return SVR_OK;
+}
 int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
+  SVR_ENTER(ctx);
   if (!ctx || !out5) return SVR_E_ARG;
   if (ctx->have_slices && !ctx->psf_list_valid) {
     int r = build_list(ctx, true);

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/svr_host.h"
+#include "svr_shard.h"
 
 namespace svr {
 
@@ -18,8 +19,7 @@ class irtkReconstruction {
   // engine + sharding
   svr_ctx *reconstructionGPU;          // RG.h: Reconstruction* reconstructionGPU
   int ns, lo, hi;
-  svr_collectives coll;
-  bool have_coll;
+  Shard sh;                            // this rank's slice range, the collectives, the one exchange per step (svr_shard.h)
   std::string err;
 
   // members named as in RG.h / RG.cc:159-221
@@ -38,10 +38,8 @@ class irtkReconstruction {
   std::vector<unsigned char> _slice_inside_gpu;
 
   irtkReconstruction(svr_ctx *engine, int n_global, int lo_, int hi_, const svr_collectives *c)
-      : reconstructionGPU(engine), ns(n_global), lo(lo_), hi(hi_), have_coll(c != nullptr && (c->world > 1 || getenv("SVR_FORCE_COLLECTIVES"))) {   // (the variable: test hook, world 1 through the callbacks)
-    if (c) coll = *c;
-    else { coll.user = nullptr; coll.rank = 0; coll.world = 1; coll.allreduce_volume_pair = nullptr;
-           coll.allreduce_host = nullptr; coll.allgather_slices = nullptr; }
+      : reconstructionGPU(engine), ns(n_global), lo(lo_), hi(hi_) {
+    sh.init(engine, n_global, lo_, hi_, c);
     _step = 0.0001;
     _quality_factor = 2;
     _sigma_bias = 12;
@@ -74,40 +72,26 @@ class irtkReconstruction {
 
   // -- sharding helpers ------------------------------------------------------------------
   const float *local(const std::vector<float> &v) const { return v.data() + lo; }
-  int gather(const std::vector<float> &loc, std::vector<float> &glob) {
-    glob.resize(ns);
-    if (!have_coll) { std::copy(loc.begin(), loc.end(), glob.begin()); return 0; }
-    return coll.allgather_slices(coll.user, loc.data(), hi - lo, glob.data(), ns);
-  }
-  // ONE host collective per exchange.  Every host-side collective is a stream synchronisation plus a small RCCL launch
-  // (~60-100 us), and a sharded SR iteration used to make six of them (scale vector, slice_inside, three for the M-step,
-  // slice potentials) against ~1.3 ms of kernels per rank on P4 at 8 GPUs.  So the ns-sized vectors a rank has only its
-  // own part of (`_scale_stale`, `_inside_stale`) ride along with the next exchange that every rank makes anyway: the
-  // M-step's sums, the E-step's potentials, the robust-statistics sums.  All of it is one SUM all-reduce of a vector in
-  // which a rank fills only its own entries (x + 0 is exact, so this is an all-gather), and sums over ranks are then
-  // taken on the host in rank order -- the same bits on every rank and every run.
-  //   mine[n_mine] -> all[world][n_mine];  pot_local (or NULL): this rank's slice potentials -> pot_global[ns]
+  // The ns-sized vectors a rank has only its own part of (`_scale_stale`, `_inside_stale`) ride along with the next exchange
+  // that every rank makes anyway (Shard::exchange: one collective): the M-step's sums, the E-step's potentials, the
+  // robust-statistics sums.
+  //   mine[n_mine] -> all[world][n_mine];  pot (or NULL): the slice potentials, this rank's range filled -> complete
   bool _scale_stale = false, _inside_stale = false;
-  int exchange(const double *mine, int n_mine, std::vector<double> &all, const float *pot_local, std::vector<float> *pot_global) {
-    const int W = coll.world, R = coll.rank, nl = hi - lo;
-    const int o_sc = n_mine * W, o_in = o_sc + (_scale_stale ? ns : 0), o_pot = o_in + (_inside_stale ? ns : 0);
-    const int n = o_pot + (pot_local ? ns : 0);
-    std::vector<double> v((size_t)n, 0.0);
-    for (int k = 0; k < n_mine; ++k) v[(size_t)R * n_mine + k] = mine[k];
-    for (int i = 0; i < nl; ++i) {
-      if (_scale_stale) v[o_sc + lo + i] = _scale_gpu[lo + i];
-      if (_inside_stale) v[o_in + lo + i] = _slice_inside_gpu[lo + i];
-      if (pot_local) v[o_pot + lo + i] = pot_local[i];
-    }
-    if (n) { int rc_ = coll.allreduce_host(coll.user, v.data(), n, 0); if (rc_) return rc_; }
-    all.assign(v.begin(), v.begin() + o_sc);
-    for (int i = 0; i < ns; ++i) {
-      if (_scale_stale) _scale_gpu[i] = (float)v[o_sc + i];
-      if (_inside_stale) _slice_inside_gpu[i] = v[o_in + i] > 0.5;
-      if (pot_local) (*pot_global)[i] = (float)v[o_pot + i];
-    }
+  int exchange(const double *mine, int n_mine, std::vector<double> &all, std::vector<float> *pot) {
+    std::vector<float> inside;
+    if (_inside_stale) inside.assign(_slice_inside_gpu.begin(), _slice_inside_gpu.end());
+    std::vector<float> *vec[3] = {_scale_stale ? &_scale_gpu : nullptr, _inside_stale ? &inside : nullptr, pot};
+    const int rc = sh.exchange(mine, n_mine, all, vec);
+    if (rc) { err = rc == SVR_E_STATE ? "exchange: the ranks are not in the same step of the reconstruction" : "exchange: the collective failed"; return rc; }
+    if (_inside_stale) for (int i = 0; i < ns; ++i) _slice_inside_gpu[i] = inside[i] > 0.5f;
     _scale_stale = _inside_stale = false;
     return 0;
+  }
+  // completes the vectors of which a rank only holds its own part (collective: every rank calls it); svrh_get_state does
+  int flush() {
+    if (!sh.on || (!_scale_stale && !_inside_stale)) return 0;
+    std::vector<double> none;
+    return exchange(nullptr, 0, none, nullptr);
   }
 
   // RG.h:605-612
@@ -130,13 +114,12 @@ class irtkReconstruction {
   // RG.cc:2695-2762.  voxel_num has one entry per device and its median indexes out of range for
   // one device (RG.cc:2714-2726), so no slice is ever "small" on the GPU path.
   int GaussianReconstructionGPU() {
-    if (!have_coll) {
+    if (!sh.on) {
       int n = 0;
       ENG(svr_gaussian_reconstruction(reconstructionGPU, &n));
     } else {
       ENG(svr_gaussian_reconstruction_local(reconstructionGPU));
-      ENG(coll.allreduce_volume_pair(coll.user, svr_device_ptr(reconstructionGPU, SVR_BUF_RECONSTRUCTED),
-                                     2 * svr_volume_voxels(reconstructionGPU)));
+      ENG(sh.allreduce_pair(SVR_BUF_RECONSTRUCTED, 2 * svr_volume_voxels(reconstructionGPU)));
       int n = 0;
       ENG(svr_gaussian_reconstruction_finish(reconstructionGPU, &n));
     }
@@ -149,20 +132,20 @@ class irtkReconstruction {
     std::vector<unsigned char> inside(hi - lo);
     ENG(svr_simulate_slices(reconstructionGPU, inside.data()));
     for (int i = 0; i < hi - lo; ++i) _slice_inside_gpu[lo + i] = inside[i] != 0;
-    _inside_stale = have_coll;                             // the other ranks' flags arrive with the next exchange
+    _inside_stale = sh.on;                             // the other ranks' flags arrive with the next exchange
     return 0;
   }
 
   // RG.cc:2988-3019
   int InitializeRobustStatisticsGPU() {
-    if (!have_coll) {
+    if (!sh.on) {
       ENG(svr_initialize_robust_statistics(reconstructionGPU, &_sigma_gpu));
     } else {
       double s2[2], t[2] = {0, 0};
       ENG(svr_robust_statistics_sums(reconstructionGPU, s2));
       std::vector<double> all;
-      ENG(exchange(s2, 2, all, nullptr, nullptr));         // (brings the other ranks' slice_inside along)
-      for (int r = 0; r < coll.world; ++r) { t[0] += all[2 * r]; t[1] += all[2 * r + 1]; }
+      ENG(exchange(s2, 2, all, nullptr));         // (brings the other ranks' slice_inside along)
+      for (int r = 0; r < sh.coll.world; ++r) { t[0] += all[2 * r]; t[1] += all[2 * r + 1]; }
       _sigma_gpu = (float)t[0] / (float)t[1];
     }
     for (int i = 0; i < ns; ++i)
@@ -183,9 +166,9 @@ class irtkReconstruction {
     std::vector<float> loc(hi - lo);
     ENG(svr_estep(reconstructionGPU, _m_gpu, _sigma_gpu, _mix_gpu, loc.data()));
     std::vector<float> &slice_potential_gpu = _slice_potential_gpu;
-    slice_potential_gpu.resize(ns);
-    if (have_coll) { std::vector<double> none; ENG(exchange(nullptr, 0, none, loc.data(), &slice_potential_gpu)); }   // (and the scale vector)
-    else std::copy(loc.begin(), loc.end(), slice_potential_gpu.begin());
+    slice_potential_gpu.assign(ns, 0.0f);
+    std::copy(loc.begin(), loc.end(), slice_potential_gpu.begin() + lo);
+    if (sh.on) { std::vector<double> none; ENG(exchange(nullptr, 0, none, &slice_potential_gpu)); }   // (and the scale vector)
     int inputIndex;
     for (size_t i = 0; i < _force_excluded.size(); i++) slice_potential_gpu[_force_excluded[i]] = -1;
     for (size_t i = 0; i < _small_slices.size(); i++) slice_potential_gpu[_small_slices[i]] = -1;
@@ -263,20 +246,19 @@ class irtkReconstruction {
     std::vector<float> loc(hi - lo);
     ENG(svr_calculate_scale_vector(reconstructionGPU, loc.data()));
     std::copy(loc.begin(), loc.end(), _scale_gpu.begin() + lo);
-    _scale_stale = have_coll;                              // read next in the E-step, whose exchange completes it
+    _scale_stale = sh.on;                              // read next in the E-step, whose exchange completes it
     return 0;
   }
 
   // RG.cc:4024-4036
   int SuperresolutionGPU(int iter) {
-    if (!have_coll) {
+    if (!sh.on) {
       ENG(svr_superresolution(reconstructionGPU, iter, local(_slice_weight_gpu), _adaptive, (float)_alpha,
                               (float)_min_intensity, (float)_max_intensity, (float)_delta, (float)_lambda,
                               _global_bias_correction, _sigma_bias, _low_intensity_cutoff));
     } else {
       ENG(svr_superresolution_backproject(reconstructionGPU, local(_slice_weight_gpu)));
-      ENG(coll.allreduce_volume_pair(coll.user, svr_device_ptr(reconstructionGPU, SVR_BUF_ADDON),
-                                     2 * svr_volume_voxels(reconstructionGPU)));
+      ENG(sh.allreduce_pair(SVR_BUF_ADDON, 2 * svr_volume_voxels(reconstructionGPU)));
       ENG(svr_superresolution_update(reconstructionGPU, _adaptive, (float)_alpha, (float)_min_intensity,
                                      (float)_max_intensity, (float)_delta, (float)_lambda));
     }
@@ -285,16 +267,16 @@ class irtkReconstruction {
 
   // RG.cc:4214-4223 + Reconstruction::MStep host part (reconstruction_cuda2.cu:3016-3071)
   int MStepGPU(int iter) {
-    if (!have_coll) {
+    if (!sh.on) {
       ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
       return 0;
     }
     double s5[5];
     ENG(svr_mstep_sums(reconstructionGPU, s5));
     std::vector<double> all;
-    ENG(exchange(s5, 5, all, nullptr, nullptr));           // three sums, a minimum, a maximum: one collective
+    ENG(exchange(s5, 5, all, nullptr));           // three sums, a minimum, a maximum: one collective
     s5[0] = s5[1] = s5[2] = 0;
-    for (int r = 0; r < coll.world; ++r) {
+    for (int r = 0; r < sh.coll.world; ++r) {
       for (int k = 0; k < 3; ++k) s5[k] += all[5 * r + k];
       s5[3] = r ? std::min(s5[3], all[5 * r + 3]) : all[3];
       s5[4] = r ? std::max(s5[4], all[5 * r + 4]) : all[4];
@@ -313,11 +295,10 @@ class irtkReconstruction {
   // RG.cc:3904-3913, 4653-4655
   int BiasGPU() { ENG(svr_correct_bias(reconstructionGPU, _sigma_bias, _global_bias_correction)); return 0; }
   int NormaliseBiasGPU(int iter) {
-    if (!have_coll) { ENG(svr_normalise_bias(reconstructionGPU, iter, _sigma_bias)); return 0; }
+    if (!sh.on) { ENG(svr_normalise_bias(reconstructionGPU, iter, _sigma_bias)); return 0; }
     ENG(svr_normalise_bias_local(reconstructionGPU));
     // the bias volume is a single float[Nv] message
-    ENG(coll.allreduce_volume_pair(coll.user, svr_device_ptr(reconstructionGPU, SVR_BUF_BIAS_VOLUME),
-                                   svr_volume_voxels(reconstructionGPU)));
+    ENG(sh.allreduce_pair(SVR_BUF_BIAS_VOLUME, svr_volume_voxels(reconstructionGPU)));
     ENG(svr_normalise_bias_finish(reconstructionGPU, _sigma_bias));
     return 0;
   }
@@ -325,10 +306,10 @@ class irtkReconstruction {
   int MaskVolumeGPU() { ENG(svr_mask_volume(reconstructionGPU)); return 0; }   // RG.cc:5319-5323
 
   int ScaleVolumeGPU() {
-    if (!have_coll) { ENG(svr_scale_volume(reconstructionGPU)); return 0; }
+    if (!sh.on) { ENG(svr_scale_volume(reconstructionGPU)); return 0; }
     double s2[2];
     ENG(svr_scale_volume_sums(reconstructionGPU, s2));
-    ENG(coll.allreduce_host(coll.user, s2, 2, 0));
+    ENG(sh.coll.allreduce_host(sh.coll.user, s2, 2, 0));
     ENG(svr_scale_volume_apply(reconstructionGPU, (float)(s2[0] / s2[1])));
     return 0;
   }
@@ -553,10 +534,13 @@ int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_nul
   return 0;
 }
 
+void svrh_force_collectives(svrh_recon *r, int on) { if (r) r->impl.sh.force(on != 0); }
+
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
                    unsigned char *slice_inside, double s[8]) {
   if (!r) return SVR_E_ARG;
   svr::irtkReconstruction &m = r->impl;
+  if (int rc = m.flush()) return rc;      // sharded: the scale vector / slice_inside of the other ranks may still be on their way
   if (scale) std::copy(m._scale_gpu.begin(), m._scale_gpu.end(), scale);
   if (slice_weight) std::copy(m._slice_weight_gpu.begin(), m._slice_weight_gpu.end(), slice_weight);
   if (slice_potential) std::copy(m._slice_potential_gpu.begin(), m._slice_potential_gpu.end(), slice_potential);

@@ -16,6 +16,8 @@
 #include <chrono>
 #include <atomic>
 #include <functional>
+#include <mutex>
+#include <unistd.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -79,11 +81,19 @@ struct Image {
 };
 
 const char *prog_name = "SVRreconstructionGPU";
-std::function<void()> before_exit;     // e.g. wait for a context that another thread is still creating
-void die(const std::string &m) {
+std::function<void()> before_exit;     // main thread only, e.g. wait for a context that another thread is still creating
+// die() is reachable from the main thread, from pool workers (read_image, match_stack_intensities inside parallel_for) and
+// from the per-device rank threads, possibly from several at once.  The first caller wins (the others wait on the mutex
+// until the process is gone) and the process ends without running static destructors: peers of a failing rank sit in an
+// RCCL collective or a barrier that will never complete, and the pool's destructor would join the very worker that called.
+std::mutex die_mutex;
+const std::thread::id main_thread_id = std::this_thread::get_id();
+[[noreturn]] void die(const std::string &m) {
+  std::lock_guard<std::mutex> first(die_mutex);
   fprintf(stderr, "%s: %s\n", prog_name, m.c_str());
-  if (before_exit) { auto f = before_exit; before_exit = nullptr; f(); }
-  exit(1);
+  if (std::this_thread::get_id() == main_thread_id && before_exit) { auto f = before_exit; before_exit = nullptr; f(); }
+  fflush(nullptr);
+  _exit(1);
 }
 
 // SVR_CLI_TIMING=1: wall time of every stage of a command line on stderr (tools/run_cli_*.py read it)

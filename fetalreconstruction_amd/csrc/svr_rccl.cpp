@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -130,19 +131,31 @@ int cb_allgather_slices(void *user, const float *local, int n_local, float *glob
   svr_comm *c = static_cast<svr_comm *>(user);
   HIPCHK_(c, hipSetDevice(c->device));
   if (scratch(c, (size_t)std::max(n_global, c->world) + 8)) return 1;
-  // where this rank's slices start: the counts of all ranks (they do not change between calls; checked by their sum)
-  int total = 0;
-  for (int v : c->counts) total += v;
-  if ((int)c->counts.size() != c->world || total != n_global || c->counts[c->rank] != n_local) {
-    int *d = static_cast<int *>(c->d_scratch);
-    HIPCHK_(c, hipMemcpyAsync(d + c->rank, &n_local, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(c, g_rccl.AllGather(d + c->rank, d, 1, ncclInt32, c->comm, c->stream));
-    c->counts.assign(c->world, 0);
-    HIPCHK_(c, hipMemcpyAsync(c->counts.data(), d, c->world * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK_(c, hipStreamSynchronize(c->stream));
-    total = 0;
+  // where this rank's slices start: the counts of all ranks, gathered at the first call.  Whether they must be gathered again
+  // (a caller that changed its range) is decided COLLECTIVELY -- a rank that entered the count gather alone would wait for
+  // ever: every call starts with a one-word all-reduce of "my counts are stale".
+  {
+    int total = 0;
     for (int v : c->counts) total += v;
-    if (total != n_global) return cfail(c, "allgather_slices: the ranks' slice counts do not add up to n_global");
+    const int stale = ((int)c->counts.size() != c->world || total != n_global || c->counts[c->rank] != n_local) ? 1 : 0;
+    int *d = static_cast<int *>(c->d_scratch);
+    int any = stale;
+    if (!c->counts.empty()) {                                // (the first call gathers on every rank anyway)
+      HIPCHK_(c, hipMemcpyAsync(d, &stale, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      NCCLCHK(c, g_rccl.AllReduce(d, d, 1, ncclInt32, ncclMax, c->comm, c->stream));
+      HIPCHK_(c, hipMemcpyAsync(&any, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK_(c, hipStreamSynchronize(c->stream));
+    }
+    if (any) {
+      HIPCHK_(c, hipMemcpyAsync(d + c->rank, &n_local, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      NCCLCHK(c, g_rccl.AllGather(d + c->rank, d, 1, ncclInt32, c->comm, c->stream));
+      c->counts.assign(c->world, 0);
+      HIPCHK_(c, hipMemcpyAsync(c->counts.data(), d, c->world * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK_(c, hipStreamSynchronize(c->stream));
+      total = 0;
+      for (int v : c->counts) total += v;
+      if (total != n_global) return cfail(c, "allgather_slices: the ranks' slice counts do not add up to n_global");   // (on every rank alike)
+    }
   }
   int lo = 0;
   for (int r = 0; r < c->rank; ++r) lo += c->counts[r];
@@ -253,6 +266,9 @@ struct svr_group {
   std::vector<double> dsum;
   struct Member { svr_group *g; int rank; svr_ctx *engine; svr_collectives coll; };
   std::vector<Member> members;
+  // a rank that fails still reaches every barrier of the exchange and raises this flag; all ranks return it afterwards
+  // (an early return left the peers waiting at the barrier for ever).  Sticky: a group that failed once stays failed.
+  std::atomic<int> failed{0};
   explicit svr_group(int w) : world(w), bar(w) {}
 };
 
@@ -262,22 +278,25 @@ int g_pair(void *user, void *device_ptr, size_t n) {
   auto *m = static_cast<svr_group::Member *>(user);
   svr_group *g = m->g;
   hipStream_t st = static_cast<hipStream_t>(svr_get_stream(m->engine));
-  if (hipSetDevice(svr_device(m->engine)) != hipSuccess) return 1;
   std::vector<float> &mine = g->fstage[m->rank];
   mine.resize(n);
-  if (hipMemcpyAsync(mine.data(), device_ptr, n * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
-  if (hipStreamSynchronize(st) != hipSuccess) return 1;
+  if (hipSetDevice(svr_device(m->engine)) != hipSuccess ||
+      hipMemcpyAsync(mine.data(), device_ptr, n * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    g->failed.store(1);
   g->bar.wait();
-  if (m->rank == 0) {
+  if (m->rank == 0 && !g->failed.load()) {
     g->fsum.assign(n, 0.0f);
     for (int r = 0; r < g->world; ++r)                     // rank order: the same sum on every run
-      for (size_t i = 0; i < n; ++i) g->fsum[i] += g->fstage[r][i];
+      for (size_t i = 0; i < n && i < g->fstage[r].size(); ++i) g->fsum[i] += g->fstage[r][i];
   }
   g->bar.wait();
-  if (hipMemcpyAsync(device_ptr, g->fsum.data(), n * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
-  if (hipStreamSynchronize(st) != hipSuccess) return 1;
-  g->bar.wait();                                           // fsum is free again
-  return 0;
+  if (!g->failed.load() &&
+      (hipMemcpyAsync(device_ptr, g->fsum.data(), n * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+       hipStreamSynchronize(st) != hipSuccess))
+    g->failed.store(1);
+  g->bar.wait();                                           // fsum is free again; the flag is final for this exchange
+  return g->failed.load();
 }
 int g_pair_rccl(void *user, void *device_ptr, size_t n) {
   auto *m = static_cast<svr_group::Member *>(user);
@@ -288,7 +307,10 @@ int g_host(void *user, double *data, int n, int op) {
   svr_group *g = m->g;
   g->dstage[m->rank].assign(data, data + n);
   g->bar.wait();
-  if (m->rank == 0) {
+  if (m->rank == 0)
+    for (int r = 0; r < g->world; ++r)
+      if ((int)g->dstage[r].size() != n) g->failed.store(1);      // the ranks are not in the same exchange
+  if (m->rank == 0 && !g->failed.load()) {
     g->dsum = g->dstage[0];
     for (int r = 1; r < g->world; ++r)
       for (int i = 0; i < n; ++i) {
@@ -297,9 +319,9 @@ int g_host(void *user, double *data, int n, int op) {
       }
   }
   g->bar.wait();
-  std::copy(g->dsum.begin(), g->dsum.begin() + n, data);
+  if (!g->failed.load()) std::copy(g->dsum.begin(), g->dsum.begin() + n, data);
   g->bar.wait();
-  return 0;
+  return g->failed.load();
 }
 int g_gather(void *user, const float *local, int n_local, float *global_out, int n_global) {
   auto *m = static_cast<svr_group::Member *>(user);
@@ -308,12 +330,13 @@ int g_gather(void *user, const float *local, int n_local, float *global_out, int
   g->bar.wait();
   int o = 0;
   for (int r = 0; r < g->world; ++r) {
-    if (o + (int)g->fstage[r].size() > n_global) return 1;
+    if (o + (int)g->fstage[r].size() > n_global) { g->failed.store(1); break; }
     std::copy(g->fstage[r].begin(), g->fstage[r].end(), global_out + o);
     o += (int)g->fstage[r].size();
   }
+  if (o != n_global) g->failed.store(1);
   g->bar.wait();
-  return o == n_global ? 0 : 1;
+  return g->failed.load();
 }
 
 }  // namespace
@@ -344,9 +367,16 @@ const svr_collectives *svr_group_join(svr_group *g, int rank, svr_ctx *engine) {
   m.coll.user = &m; m.coll.rank = rank; m.coll.world = g->world;
   if (g->rccl) {
     // the volume pairs over RCCL on the engine's stream; the small host vectors through the memory the rank threads share
-    // (a thread barrier instead of a stream synchronisation plus a collective launch per exchange)
+    // (a thread barrier instead of a stream synchronisation plus a collective launch per exchange).
+    // What can fail on ONE rank before ncclCommInitRank (the library, the device) is checked first and agreed on under the
+    // barrier: a rank that gave up alone would leave its peers inside ncclCommInitRank for ever.
+    if (!rccl_load() || hipSetDevice(svr_device(engine)) != hipSuccess) g->failed.store(1);
+    g->bar.wait();
+    if (g->failed.load()) return nullptr;
     g->comms[rank] = svr_comm_create(rank, g->world, g->id, engine);
-    if (!g->comms[rank]) return nullptr;
+    if (!g->comms[rank]) g->failed.store(1);
+    g->bar.wait();
+    if (g->failed.load()) return nullptr;
     m.coll.allreduce_volume_pair = g_pair_rccl;
     m.coll.allreduce_host = g_host;
     m.coll.allgather_slices = g_gather;

@@ -1,0 +1,79 @@
+// svr_shard.h -- what the two host objects (svr::irtkReconstruction, svr::irtkPatchBasedReconstruction) share when the
+// slices / patches are sharded over ranks: the unit range [lo, hi) of this rank, the launcher's collectives, the timed
+// all-reduce of a volume pair and the ONE host-side exchange per step.
+//
+// The reference fans every step out over `devicesToUse` inside one process and adds the per-device volumes up on GPU 0
+// (reconstruction_cuda2.cu:1413-1457, 2225-2239); its patch-based path is single-GPU (patchBasedReconMain.cpp:78,177-179,
+// irtkPatchBasedReconstruction.cpp:402).  Here a rank keeps the whole volume and a contiguous range of units.
+#ifndef SVR_SHARD_H
+#define SVR_SHARD_H
+
+#include <chrono>
+#include <vector>
+
+#include "../../include/svr_host.h"
+
+namespace svr {
+
+struct Shard {
+  svr_ctx *e = nullptr;
+  int n = 0, lo = 0, hi = 0;          // units (slices / patches): global count, this rank's range
+  svr_collectives coll;
+  bool given = false, on = false;     // collectives supplied / in use (world > 1, or forced for tests at world 1)
+
+  void init(svr_ctx *engine, int n_global, int lo_, int hi_, const svr_collectives *c) {
+    e = engine; n = n_global; lo = lo_; hi = hi_;
+    given = c != nullptr;
+    if (c) coll = *c;
+    else { coll.user = nullptr; coll.rank = 0; coll.world = 1; coll.allreduce_volume_pair = nullptr;
+           coll.allreduce_host = nullptr; coll.allgather_slices = nullptr; }
+    on = given && coll.world > 1;
+  }
+  void force(bool f) { on = given && (coll.world > 1 || f); }   // test hook: world 1 through the callbacks
+
+  // in-place sum of a device buffer of the engine over the ranks, on the engine's stream; HIP events around it when the
+  // engine's timers are on (SVR_T_ALLREDUCE: what a rank waits for = its own wait for the slowest rank + the ring)
+  int allreduce_pair(int buffer, size_t n_floats) {
+    int rc = svr_timer_begin(e, SVR_T_ALLREDUCE);
+    if (rc) return rc;
+    rc = coll.allreduce_volume_pair(coll.user, svr_device_ptr(e, buffer), n_floats);
+    if (rc) return rc;
+    return svr_timer_end(e, SVR_T_ALLREDUCE);
+  }
+
+  // ONE host collective per exchange.  Every host-side collective is a stream synchronisation plus a small collective
+  // launch (~60-100 us), so everything a step has to share travels as one SUM all-reduce of a vector in which a rank fills
+  // only its own entries (x + 0 is exact: an all-gather); sums over ranks are then taken by the caller in rank order, the
+  // same bits on every rank and every run.  Layout (its length depends on the call site only, never on a rank's state):
+  //   [world][n_mine] the ranks' scalars | [world] which vectors a rank sent | up to three n-sized vectors.
+  // vec[k] = global vector (complete on return) or NULL; a rank sends its own range [lo, hi) of it.  The ranks must agree
+  // on which vectors travel: a rank whose operator sequence differs from the others' is an error, not a silent mix-up.
+  int exchange(const double *mine, int n_mine, std::vector<double> &all, std::vector<float> *vec[3]) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int W = coll.world, R = coll.rank;
+    const int o_flag = n_mine * W, o_vec = o_flag + W;
+    const int total = o_vec + 3 * n;
+    std::vector<double> v((size_t)total, 0.0);
+    for (int k = 0; k < n_mine; ++k) v[(size_t)R * n_mine + k] = mine[k];
+    int flags = 0;
+    for (int k = 0; k < 3; ++k)
+      if (vec[k]) {
+        flags |= 1 << k;
+        for (int i = lo; i < hi; ++i) v[(size_t)o_vec + (size_t)k * n + i] = (*vec[k])[i];
+      }
+    v[o_flag + R] = (double)(flags + 1);
+    const int rc = coll.allreduce_host(coll.user, v.data(), total, 0);
+    if (rc) return rc;
+    for (int r = 0; r < W; ++r)
+      if ((int)v[o_flag + r] != flags + 1) return SVR_E_STATE;            // the ranks are not in the same step
+    all.assign(v.begin(), v.begin() + o_flag);
+    for (int k = 0; k < 3; ++k)
+      if (vec[k])
+        for (int i = 0; i < n; ++i) (*vec[k])[i] = (float)v[(size_t)o_vec + (size_t)k * n + i];
+    (void)svr_timer_add(e, SVR_T_EXCHANGE, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return 0;
+  }
+};
+
+}  // namespace svr
+#endif

@@ -22,10 +22,11 @@ HOST_EXPORTS = [
     "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
     "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state", "svrh_set_bias_correction", "svrh_bias_gpu",
     "svrh_normalise_bias_gpu", "svrh_prepare_registration_slices", "svrh_slice_to_volume_registration_gpu",
-    "svrh_get_registration_slices",
+    "svrh_get_registration_slices", "svrh_force_collectives",
 ]
 PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_initialize_em_values", "pvrh_initialize_robust_statistics",
-                    "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_register_patches", "pvrh_get_state"]      # csrc/pvr_host.cpp
+                    "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_register_patches", "pvrh_get_state",
+                    "pvrh_create_sharded", "pvrh_force_collectives", "pvrh_sr_iteration"]      # csrc/pvr_host.cpp
 IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_package_to_volume", "svrh_irtk_resample_with_padding",
                 "svrh_irtk_blur_with_padding", "svrh_irtk_rigid_parameters"]                                  # csrc/irtk_reg.cpp
 IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write", "svr_host_threads"]      # csrc/svr_io.cpp, declared in svr_host.h
@@ -115,7 +116,8 @@ class irtkReconstruction:
     (torch.distributed callbacks: gloo in the CPU tests) or None."""
 
     def __init__(self, rec: "_engine.Reconstruction", n_slices_global, slice_range=None, comm=None,
-                 max_intensity=1.0, min_intensity=0.0):
+                 max_intensity=1.0, min_intensity=0.0, force_collectives=False):
+        """force_collectives: a world-1 run goes through the communicator's callbacks like a sharded one (tests, bench.py)"""
         self._lib = _engine.load_library()
         self._lib.svrh_create.restype = C.c_void_p
         self._lib.svrh_last_error.restype = C.c_char_p
@@ -129,8 +131,7 @@ class irtkReconstruction:
         self._coll = None
         coll_ptr = None
         if isinstance(comm, RcclComm):
-            import os
-            if comm.world > 1 or os.environ.get("SVR_FORCE_COLLECTIVES"):
+            if comm.world > 1 or force_collectives:
                 self._comm = comm                       # the C library's own collectives (csrc/svr_rccl.cpp)
                 coll_ptr = comm.collectives
         elif comm is not None and comm.world > 1:
@@ -179,6 +180,9 @@ class irtkReconstruction:
             raise _engine.SvrError("svrh_create failed")
         self._h = C.c_void_p(h)
         self._lib.svrh_set_intensity_range(self._h, C.c_double(min_intensity), C.c_double(max_intensity))
+        if force_collectives:
+            self._lib.svrh_force_collectives.restype = None
+            self._lib.svrh_force_collectives(self._h, 1)
 
     def __del__(self):
         try:
@@ -295,18 +299,31 @@ class irtkPatchBasedReconstruction:
     """The C++ patch-to-volume loop (csrc/pvr_host.cpp) over one engine with option pvr=1; same member names as
     the Python mirror pvr.irtkPatchBasedReconstruction."""
 
-    def __init__(self, rec: "_engine.Reconstruction", patches_per_stack, min_intensity, max_intensity):
+    def __init__(self, rec: "_engine.Reconstruction", patches_per_stack, min_intensity, max_intensity, patch_range=None, comm=None,
+                 force_collectives=False):
+        """patch_range = (lo, hi) + comm (an RcclComm): the engine holds the patches [lo, hi) of the global numbering
+        (pvrh_create_sharded); patches_per_stack stays the global count per stack."""
         self._lib = _engine.load_library()
         self._lib.pvrh_create.restype = C.c_void_p
+        self._lib.pvrh_create_sharded.restype = C.c_void_p
         self._lib.pvrh_last_error.restype = C.c_char_p
         self._lib.pvrh_destroy.restype = None
         self.e = rec
         c = np.ascontiguousarray(patches_per_stack, np.int32)
         self.n = int(c.sum())
-        h = self._lib.pvrh_create(rec._h, c.ctypes.data_as(C.c_void_p), len(c), C.c_float(min_intensity), C.c_float(max_intensity))
+        self.lo, self.hi = patch_range if patch_range is not None else (0, self.n)
+        if comm is not None and not isinstance(comm, RcclComm):
+            raise TypeError("the C++ patch-based host takes the C library's communicator (host.RcclComm)")
+        self._comm = comm
+        use = comm is not None and (comm.world > 1 or force_collectives)
+        h = self._lib.pvrh_create_sharded(rec._h, c.ctypes.data_as(C.c_void_p), len(c), C.c_float(min_intensity), C.c_float(max_intensity),
+                                          int(self.lo), int(self.hi), comm.collectives if use else None)
         if not h:
-            raise _engine.SvrError("pvrh_create failed")
+            raise _engine.SvrError("pvrh_create_sharded failed")
         self._h = C.c_void_p(h)
+        if use and force_collectives:
+            self._lib.pvrh_force_collectives.restype = None
+            self._lib.pvrh_force_collectives(self._h, 1)
 
     def __del__(self):
         try:
@@ -337,6 +354,9 @@ class irtkPatchBasedReconstruction:
 
     def reconstruct_iteration(self, rec_iterations):
         self._ck(self._lib.pvrh_reconstruct_iteration(self._h, int(rec_iterations)))
+
+    def sr_iteration(self, i):
+        self._ck(self._lib.pvrh_sr_iteration(self._h, int(i)))
 
     def state(self):
         sc, pw, pot = (np.zeros(self.n, np.float32) for _ in range(3))

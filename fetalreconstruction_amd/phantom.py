@@ -243,12 +243,12 @@ def problem_tiny(seed=1):
 
 
 def problem_p4(seed=20260928):
-    """P4: stands in for 'SVR on the bundled 4x3T stacks at 1.0 mm' (configs[0..1]).
+    """P4s (the round-1 stand-in, axis-aligned; the bench's P4 is workloads.problem_p4): stands in for 'SVR on the bundled 4x3T stacks at 1.0 mm' (configs[0..1]).
 
     4 stacks of 100x93x70 on the bundled mask's native grid (1.17647 x 1.17647 x 1.25 mm voxels,
     thickness 2.5 = twice the z spacing, reconstruction.cc:422-431), ax/cor/sag/ax30, recon 1.0 mm.
     """
-    return make_problem(4, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, seed=seed, name="P4")
+    return make_problem(4, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, seed=seed, name="P4s")
 
 
 def problem_s8(seed=20260928, n_stacks=8, slices_per_stack=64):

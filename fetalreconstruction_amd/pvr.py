@@ -171,10 +171,15 @@ class irtkPatchBasedReconstruction:
     (irtkPatchBasedReconstruction.cpp:445-593) on one engine (`engine.Reconstruction` with option pvr=1,
     or the oracle twin).  Members carry the reference's names (m_sigma_gpu ...)."""
 
-    def __init__(self, engine, patches_per_stack, min_intensity, max_intensity, adaptive=False):
+    def __init__(self, engine, patches_per_stack, min_intensity, max_intensity, adaptive=False, patch_range=None, comm=None):
+        """patch_range = (lo, hi), comm: the engine holds the patches [lo, hi) of the global numbering and the ranks exchange
+        like csrc/pvr_host.cpp does (the gloo tests run this driver on oracle engines); patches_per_stack stays global."""
         self.e = engine
         self.counts = [int(c) for c in patches_per_stack]
         self.n = int(sum(self.counts))
+        self.lo, self.hi = patch_range if patch_range is not None else (0, self.n)
+        self.comm = comm if comm is not None and comm.world > 1 else None
+        self._scale_stale = False
         self.m_min_intensity, self.m_max_intensity = float(min_intensity), float(max_intensity)
         self.m_adaptive = bool(adaptive)
         self.m_delta = np.float32(1.0)                                   # patchBasedSuperresolution_gpu.cu:291-295
@@ -192,11 +197,42 @@ class irtkPatchBasedReconstruction:
     def initializeEMValues(self):                                         # :78-95
         self.scale[:] = 1.0
         self.patch_weight[:] = 1.0
-        self.e.UpdateScaleVector(self.scale, self.patch_weight)
+        self.e.UpdateScaleVector(self._local(self.scale), self._local(self.patch_weight))
         self.e.InitializeEMValues()
+
+    def _local(self, v):
+        return np.ascontiguousarray(v[self.lo:self.hi])
+
+    def _exchange(self, mine, pot_local=None):
+        """svr::Shard::exchange (csrc/svr_shard.h): ONE sum all-reduce in which a rank fills only its own entries ->
+        (all[world][len(mine)], the complete potentials or None); the scale vector rides along when it is stale."""
+        W, R, n = self.comm.world, self.comm.rank, self.n
+        nm = len(mine)
+        v = np.zeros(nm * W + W + 3 * n, np.float64)
+        v[R * nm:(R + 1) * nm] = mine
+        flags = (1 if self._scale_stale else 0) | (4 if pot_local is not None else 0)
+        v[nm * W + R] = flags + 1
+        o = nm * W + W
+        if self._scale_stale:
+            v[o + self.lo:o + self.hi] = self.scale[self.lo:self.hi]
+        if pot_local is not None:
+            v[o + 2 * n + self.lo:o + 2 * n + self.hi] = pot_local
+        v = self.comm.allreduce_sum(v)
+        if not np.all(v[nm * W:nm * W + W] == flags + 1):
+            raise RuntimeError("exchange: the ranks are not in the same step of the reconstruction")
+        if self._scale_stale:
+            self.scale = v[o:o + n].astype(np.float32)
+            self._scale_stale = False
+        return v[:nm * W].reshape(W, nm), (v[o + 2 * n:o + 3 * n].astype(np.float32) if pot_local is not None else None)
 
     def InitializeRobustStatistics(self):                                 # :793-845
         sa, sb = self.e.RobustStatisticsSums()
+        if self.comm:
+            allv, _ = self._exchange([sa, sb])
+            sa, sb = 0.0, 0.0
+            for r in range(self.comm.world):                               # rank order: the same bits on every rank
+                sa += allv[r][0]
+                sb += allv[r][1]
         if sb == 0:
             raise RuntimeError("ERROR: sb = 0!! no sigma computed!")      # the reference exits here
         self.m_sigma_gpu = np.float32(np.float32(sa) / np.float32(sb))
@@ -208,6 +244,8 @@ class irtkPatchBasedReconstruction:
 
     def EStep(self):                                                      # :224-556
         pot_dev = self.e.EStep(float(self.m_m_gpu), float(self.m_sigma_gpu), float(self.m_mix_gpu))
+        if self.comm:
+            _, pot_dev = self._exchange([], np.asarray(pot_dev, np.float32))   # (and the scale vector)
         # the reference writes stack i's potentials to patch_potential[j], j = index within the stack,
         # without the stack offset (:256-276): later stacks overwrite the head, the tail stays 0
         pp = np.zeros(self.n, np.float32)
@@ -273,10 +311,18 @@ class irtkPatchBasedReconstruction:
         self.m_mix_s_gpu = np.float32(pw.astype(np.float64)[valid].sum() / num) if num > 0 else np.float32(0.9)
         self.patch_potential = pp
         self.patch_weight = pw
-        self.e.UpdateScaleVector(self.scale, self.patch_weight)           # copyToWeightsAndScales :486-491
+        self.e.UpdateScaleVector(self._local(self.scale), self._local(self.patch_weight))           # copyToWeightsAndScales :486-491
 
     def MStep(self, it):                                                  # :570-640
-        sigma, mix, num, mn, mx = [np.float32(v) for v in self.e.MStepSums()]
+        s5 = [float(v) for v in self.e.MStepSums()]
+        if self.comm:
+            allv, _ = self._exchange(s5)
+            s5 = [0.0, 0.0, 0.0, float(allv[0][3]), float(allv[0][4])]
+            for r in range(self.comm.world):
+                for k in range(3):
+                    s5[k] += float(allv[r][k])
+                s5[3], s5[4] = min(s5[3], float(allv[r][3])), max(s5[4], float(allv[r][4]))
+        sigma, mix, num, mn, mx = [np.float32(v) for v in s5]
         if mix > 0:
             self.m_sigma_gpu = np.float32(sigma / mix)
         floor = np.float32(self.m_step * self.m_step) / np.float32(6.28)
@@ -287,8 +333,10 @@ class irtkPatchBasedReconstruction:
         self.m_m_gpu = np.float32(np.float32(1.0) / (mx - mn))
 
     def Scale(self):                                                      # :672-745
-        self.scale = np.asarray(self.e.CalculateScaleVector(), np.float32).copy()
-        self.e.UpdateScaleVector(self.scale, self.patch_weight)           # copyToScales: no lag
+        self.scale = self.scale.copy()
+        self.scale[self.lo:self.hi] = np.asarray(self.e.CalculateScaleVector(), np.float32)
+        self.e.UpdateScaleVector(self._local(self.scale), self._local(self.patch_weight))           # copyToScales: no lag
+        self._scale_stale = self.comm is not None                         # read next in the E-step, whose exchange completes it
 
     # ---- patch-to-volume registration (PBR.cpp:452-489) ----------------------------------------
     def registerPatches(self, prob):
@@ -322,15 +370,24 @@ class irtkPatchBasedReconstruction:
     def reconstruct_iteration(self, rec_iterations):
         """One outer iteration without the patch registration (PBR.cpp:490-548)."""
         self.initializeEMValues()
-        self.e.GaussianReconstruction()        # reset + patchBasedPSFReconstruction_gpu + equalize
+        if self.comm:
+            self.e.GaussianReconstructionLocal()
+            self.comm.allreduce_volume_pair(self.e, 0)
+            self.e.GaussianReconstructionFinish()
+        else:
+            self.e.GaussianReconstruction()        # reset + patchBasedPSFReconstruction_gpu + equalize
         self.e.SimulateSlices()
         self.InitializeRobustStatistics()
         self.EStep()
         for i in range(rec_iterations):
             self.Scale()
-            self.e.Superresolution(i + 1, self.patch_weight, self.m_adaptive, float(self.m_alpha),
-                                   self.m_min_intensity, self.m_max_intensity, float(self.m_delta),
-                                   float(self.m_lambda))                  # resetAddonCmap + run + regularize
+            args = (self.m_adaptive, float(self.m_alpha), self.m_min_intensity, self.m_max_intensity, float(self.m_delta), float(self.m_lambda))
+            if self.comm:
+                self.e.SuperresolutionBackproject(self._local(self.patch_weight))
+                self.comm.allreduce_volume_pair(self.e, 2)
+                self.e.SuperresolutionUpdate(*args)
+            else:
+                self.e.Superresolution(i + 1, self._local(self.patch_weight), *args)   # resetAddonCmap + run + regularize
             self.e.SimulateSlices()
             self.MStep(i + 1)
             self.EStep()

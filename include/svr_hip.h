@@ -285,8 +285,18 @@ int svr_pvr_register_patches(svr_ctx *ctx, const float *RI2W, const float *Mo, c
 /* ---- measurement -------------------------------------------------------------------- */
 enum svr_timer {
   SVR_T_BACKPROJECT = 0, SVR_T_FORWARD = 1, SVR_T_GAUSS = 2, SVR_T_REGULARIZE = 3,
-  SVR_T_ESTEP = 4, SVR_T_MSTEP = 5, SVR_T_SCALE = 6, SVR_T_REGISTER = 7, SVR_T_COUNT = 8
+  SVR_T_ESTEP = 4, SVR_T_MSTEP = 5, SVR_T_SCALE = 6, SVR_T_REGISTER = 7,
+  /* sharded runs, filled by the host objects (csrc/svr_host.cpp, csrc/pvr_host.cpp) through svr_timer_begin / _end / _add:
+   * the all-reduce of a volume pair (HIP events on the engine's stream around the collective) and the small host-side
+   * exchanges (wall clock: a stream synchronisation plus the collective) */
+  SVR_T_ALLREDUCE = 8, SVR_T_EXCHANGE = 9, SVR_T_COUNT = 10
 };
+/* HIP events on the engine's stream around work a caller enqueues there itself (the volume all-reduce); no-ops while the
+ * timers are off.  svr_timer_end waits for the stream. */
+int svr_timer_begin(svr_ctx *ctx, int which);
+int svr_timer_end(svr_ctx *ctx, int which);
+/* adds host-measured milliseconds to a timer (counted as one launch) */
+int svr_timer_add(svr_ctx *ctx, int which, double ms);
 /* accumulated HIP-event time (ms) and launch count of a hot kernel since the last reset */
 int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches);
 int svr_timer_reset(svr_ctx *ctx);

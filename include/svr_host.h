@@ -140,8 +140,13 @@ int svr_dof_write(const char *path, const double params6[6], char err[256]);
  * pool, the pre-processing of the command lines and the NIfTI writer. */
 int svr_host_threads(void);
 
+/* test hook: a world-1 run goes through the launcher's collectives like a sharded one (instead of an environment variable) */
+void svrh_force_collectives(svrh_recon *r, int on);
+
 /* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
- * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s} */
+ * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s}.  Sharded runs: COLLECTIVE -- the scale vector and
+ * slice_inside of the other ranks travel with a rank's next exchange, so every rank must call this together (it completes
+ * them with one exchange if any are pending). */
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
                    unsigned char *slice_inside, double scalars8[8]);
 
@@ -196,6 +201,15 @@ void svrh_irtk_rigid_parameters(const double matrix16[16], double params6[6], do
  * as its slices; patches_per_stack is PatchBasedVolume::getXYZPatchGridSize().z per stack. */
 typedef struct pvrh_recon pvrh_recon;
 pvrh_recon *pvrh_create(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_intensity, float max_intensity);
+/* sharded over ranks ("identical with patches as the unit"; the reference's patch-based path is single-GPU,
+ * patchBasedReconMain.cpp:78,177-179): the engine holds the patches [patch_lo, patch_hi) of the global numbering (stack
+ * after stack, patches_per_stack = the GLOBAL counts), every rank the whole volume.  Exchanges per SR iteration: one
+ * all-reduce of addon|cmap, the M-step's five scalars and the E-step's patch potentials (with the scale vector riding along);
+ * the patch-level EM runs replicated on the global vectors -- including the reference's within-stack indexing of the patch
+ * potentials (patchBasedRobustStatistics_gpu.cu:256-276). */
+pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_intensity, float max_intensity,
+                                int patch_lo, int patch_hi, const svr_collectives *coll_or_null);
+void pvrh_force_collectives(pvrh_recon *r, int on);
 void pvrh_destroy(pvrh_recon *r);
 const char *pvrh_last_error(const pvrh_recon *r);
 int pvrh_initialize_em_values(pvrh_recon *r);
@@ -205,6 +219,7 @@ int pvrh_mstep(pvrh_recon *r, int iter);
 int pvrh_scale(pvrh_recon *r);
 /* one outer iteration without the patch registration (irtkPatchBasedReconstruction.cpp:490-548) */
 int pvrh_reconstruct_iteration(pvrh_recon *r, int rec_iterations);
+int pvrh_sr_iteration(pvrh_recon *r, int i);   /* one SR iteration: Scale, scatter (+ all-reduce) + regulariser, simulate, M-step, E-step */
 /* the patch-to-volume registration between the outer iterations (irtkPatchBasedReconstruction.cpp:452-489): svr_pvr_register_patches,
  * then the new transformations go to the engine.  T / Tinv [n][16] in/out; counters3 = {launches, evaluations, patches} */
 int pvrh_register_patches(pvrh_recon *r, const float *ri2w, const float *mo, const float *invmo, float *T, float *Tinv, const float *i2w,

@@ -176,6 +176,16 @@ class OracleReconstruction:
                                   _p(self.simslices), _p(self.simweights), _p(self.siminside), _p(inside))
         return inside.astype(bool)
 
+    def sample_pixels(self, flat_indices, recon):
+        """Pass 1 of the Gaussian reconstruction and the forward projection of `recon` for the listed slice-grid pixels only
+        (orc_sample_pixels) -> sume, keep, sim, weight, inside."""
+        idx = np.ascontiguousarray(flat_indices, np.uint32)
+        n = len(idx)
+        out = (np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8))
+        lib().orc_sample_pixels(C.byref(self.g), _p(self.slices), _p(_f32(recon).reshape(-1)), _p(self.mask), _p(idx), n,
+                                *[_p(o) for o in out])
+        return out
+
     def SuperresolutionBackproject(self, slice_weight=None):
         if slice_weight is not None:
             self.UpdateSliceWeights(slice_weight)

@@ -491,6 +491,41 @@ void orc_simulate_slices(const orc_geom *g, const float *slices, const float *ps
   }
 }
 
+/* Sampled pixels of a large problem (the parity tests at BASELINE.json's sizes, where a whole pass of the oracle would take
+ * minutes): pass 1 of gaussianReconstructionKernel3D_tex (RC.cu:228-258: sume, the keep gate) and
+ * simulateSlicesKernel3D_tex (RC.cu:298-404) for the listed slice-grid indices only, with the pixel's own sume.
+ * out_*[k] belong to list[k]; a pixel that is padding or fails the gate leaves keep = 0 and the rest 0. */
+void orc_sample_pixels(const orc_geom *g, const float *slices, const float *recon, const float *mask,
+                       const uint32_t *list, int n, float *out_sume, unsigned char *out_keep, float *out_sim,
+                       float *out_w, unsigned char *out_inside) {
+  int canon = g->psf_mode == ORC_PSF_CANON;
+  size_t n2 = (size_t)g->sx * g->sy;
+  for (int k = 0; k < n; ++k) {
+    size_t idx = list[k];
+    int sl = (int)(idx / n2), py = (int)((idx % n2) / g->sx), px = (int)(idx % g->sx);
+    out_sume[k] = 0; out_keep[k] = 0; out_sim[k] = 0; out_w[k] = 0; out_inside[k] = 0;
+    if (slices[idx] == -1.0f) continue;
+    slice_psf sp; slice_setup(g, sl, &sp);
+    pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
+    sume_ctx sc = {g, 0.0f, 0.0};
+    if (!(g->pvr && g->spx_mask && g->spx_mask[(size_t)sl * 4096 + px + 64 * py] != '1'))
+      walk_taps(g, &sp, &pp, visit_sume, &sc);
+    float sume = canon ? (float)sc.sume_d : sc.sume_f;
+    int keep = g->pvr ? ((sume > 0.00001f) || isnan(sume)) : (sume > 0.5f);
+    if (!keep) continue;
+    out_sume[k] = sume; out_keep[k] = 1;
+    if (sume == 0.0f) continue;
+    sim_ctx sm = {g, mask, recon, sume, 0.f, 0.f, 0.0, 0.0, 0};
+    walk_taps(g, &sp, &pp, visit_sim, &sm);
+    float weight = canon ? (float)sm.w_d : sm.w_f;
+    if (weight > 0) {
+      out_sim[k] = canon ? (float)(sm.sim_d / sm.w_d) : sm.sim_f / sm.w_f;
+      out_w[k] = weight;
+      out_inside[k] = (unsigned char)sm.inside;
+    }
+  }
+}
+
 /* ============================ back projection ============================== */
 /* SuperresolutionKernel3D_tex RC.cu:408-522 (bias correction disabled) */
 typedef struct {

@@ -44,6 +44,10 @@ def test_bench_line_and_two_ranks_on_one_gpu():
     # strong scaling: the workload is fixed, both ranks together cover the same active pixels
     assert b["config"]["Va_total"] == a["config"]["Va_total"] and b["config"]["slices"] == a["config"]["slices"]
     assert 0 < b["config"]["Va_rank0"] < b["config"]["Va_total"]
+    # every rank's own timers and share of the work travel in the line
+    k = b["ranks"]
+    assert len(k["Va"]) == 2 and sum(k["Va"]) == b["config"]["Va_total"] and sum(k["units"]) == b["config"]["slices"]
+    assert min(k["backproject_ms"]) > 0 and min(k["allreduce_ms"]) > 0 and k["exchanges_per_step"] == [2.0, 2.0]
 
 
 @pytest.mark.gpu
@@ -69,7 +73,6 @@ def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
     import numpy as np
     from fetalreconstruction_amd import engine as E, host
     recs, vols = [], []
-    os.environ["SVR_FORCE_COLLECTIVES"] = "1"          # world 1 through the callbacks (csrc/svr_host.cpp)
     for use_comm in (False, True):
         rec = E.Reconstruction(0)
         E.sync_gpu(rec, tiny)
@@ -79,15 +82,23 @@ def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
             assert comm.rccl_world() == 1
             assert np.array_equal(comm.allreduce_sum(np.array([1.5, 2.0])), [1.5, 2.0])
             assert np.array_equal(comm.allreduce_max(np.array([3.0])), [3.0]) and np.array_equal(comm.allreduce_min(np.array([-1.0])), [-1.0])
-        d = host.irtkReconstruction(rec, tiny.ns, (0, tiny.ns), comm, tiny.max_intensity, tiny.min_intensity)
+        d = host.irtkReconstruction(rec, tiny.ns, (0, tiny.ns), comm, tiny.max_intensity, tiny.min_intensity,
+                                    force_collectives=use_comm)          # world 1 through the callbacks (csrc/svr_host.cpp)
         d.SetSmoothingParameters(150, 0.02)
         d.reconstruct_iteration(2)
         vols.append(rec.syncCPU().copy())
         recs.append((rec, comm, d))
     assert np.array_equal(vols[0] == -1, vols[1] == -1)
     assert np.abs(vols[0] - vols[1]).max() <= 2e-5 * np.abs(vols[0]).max()      # float atomics in run-dependent order
+    if True:
+        # the all-reduce and the host exchanges were really taken and timed (SVR_T_ALLREDUCE / SVR_T_EXCHANGE)
+        rec, comm, d = recs[1]
+        rec.timer_enable(True)
+        rec.timer_reset()
+        d.sr_iteration(2)
+        tm = rec.timers()
+        assert tm["allreduce"][1] == 1 and tm["exchange_host"][1] == 2 and tm["allreduce"][0] > 0
     recs[1][1].close()
-    del os.environ["SVR_FORCE_COLLECTIVES"]
 
 
 @pytest.mark.gpu
@@ -106,3 +117,20 @@ def test_bench_launches_its_own_rccl_ranks():
     a, b = _last_json(one.stdout), _last_json(two.stdout)
     assert b["n_gpus"] == 2 and b["config"]["rccl_world"] == 2 and b["config"]["comm"] == "rccl"
     assert b["config"]["Va_total"] == a["config"]["Va_total"] and 0 < b["config"]["Va_rank0"] < b["config"]["Va_total"]
+
+
+@pytest.mark.gpu
+def test_bench_pvr_workload_through_the_sharded_path():
+    """`bench.py --workload PVR4` (BASELINE configs[2]: 32 x 32 patches, stride 16, of the four P4 stacks, cut by the product's own
+    command line) through the multi-rank code path at world 1: the line carries the per-rank timers of the two PSF kernels, the
+    volume all-reduce and the host exchanges, and the patches' share per rank."""
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "PVR4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-coeff-table",
+                        "--force-comm"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = _last_json(r.stdout)
+    assert a["value"] > 0 and a["config"]["comm"] == "rccl" and a["config"]["rccl_world"] == 1 and "patches" in a["config"]["workload"]
+    k = a["ranks"]
+    assert len(k["Va"]) == 1 and k["Va"][0] == a["config"]["Va_total"] and k["units"][0] == a["config"]["slices"]
+    assert k["backproject_ms"][0] > 0 and k["forward_ms"][0] > 0 and k["allreduce_ms"][0] > 0 and k["exchange_host_ms"][0] > 0
+    assert k["exchanges_per_step"][0] == 2.0                 # M-step, E-step (the scale vector rides along)
+    assert set(a["config"]["tuned"]) >= {"gather_tile", "scatter_tile", "scatter_box"}

@@ -1,0 +1,127 @@
+"""Oracle checks AT BASELINE.json's sizes, on the workloads bench.py times (round-2 review, item 3): P4 = configs[1] on the
+bundled mask's oblique frame, S8 = configs[3], PVR4 = configs[2] (32 x 32 patches, stride 16), PVR8spx = configs[4]
+(superpixel patches of 8 stacks at 0.5 mm).  A whole pass of the CPU oracle over these would take minutes to hours, so
+
+  * gather side: the engine runs the WHOLE workload (Gaussian pass 1, forward projection of a random volume) and >= 300
+    randomly chosen active pixels are compared with the oracle evaluated for those pixels only (orc_sample_pixels):
+    the keep gate and siminside exactly, v_PSF_sums to 1e-6, simulated value and weight to the scatter / gather tolerance;
+  * scatter side: a sub-problem of a few slices / patches of the workload on its full volume through the production scatter
+    against orc_superresolution_backproject (RC.cu:408-522): hit set exact, sums to tolerance.
+
+Unlike the HIP-vs-HIP variant tests, a unit wrongly declared dead in code shared by every device kernel fails here."""
+import numpy as np
+import pytest
+
+from fetalreconstruction_amd import phantom, workloads
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_SUM = 2e-5          # as in tests/test_parity_gpu.py
+N_SAMPLES = 320
+_cache = {}
+
+
+def _workload(name):
+    if name not in _cache:
+        _cache.clear()                                                   # one big problem in memory at a time
+        _cache[name] = workloads.get(name)
+    return _cache[name]
+
+
+def _engine(P, pvr):
+    from fetalreconstruction_amd import engine as E
+    rec = E.Reconstruction(0)
+    if pvr:
+        rec.set_option("pvr", 1)
+        E.sync_gpu(rec, P, quality_factor=1.0)
+        if getattr(P, "spx_masks", None) is not None:
+            rec.set_spx_masks(P.spx_masks)
+    else:
+        E.sync_gpu(rec, P)
+    ones = np.ones(P.ns, np.float32)
+    rec.UpdateScaleVector(ones, ones)
+    rec.InitializeEMValues()
+    return E, rec
+
+
+def _sub(P, sel):
+    Q = phantom.sub_problem(P, 0, 0, select=sel)
+    Q.spx_masks = None if getattr(P, "spx_masks", None) is None else np.ascontiguousarray(P.spx_masks[sel])
+    return Q
+
+
+@pytest.mark.parametrize("name", ["P4", "S8", "PVR4", "PVR8spx"])
+def test_sampled_pixels_of_the_bench_workloads_against_the_oracle(name, oracle_mod, capsys):
+    pvr = name.startswith("PVR")
+    P = _workload(name)
+    E, rec = _engine(P, pvr)
+    rec.GaussianReconstruction()
+    ps = rec.debug_get(E.BUF_PSF_SUMS).copy()
+    rng = np.random.default_rng(11)
+    V = rng.uniform(0.5, 1.5, P.nvox).astype(np.float32)
+    rec.debug_set(E.BUF_RECONSTRUCTED, V)
+    rec.SimulateSlices()
+    sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
+    rec.close()
+    # the sample: 20 slices / patches (from every stack), 16 pixels with s != -1 of each (PVR: patch pixels are 0, not -1,
+    # outside the slice -- those are candidates too, patchBasedObject.cuh:227)
+    ns, sy, sx = P.slices.shape
+    cand = np.flatnonzero((P.slices != -1).reshape(ns, -1).sum(1) >= 16)
+    sel = np.sort(rng.choice(cand, 20, replace=False))
+    Q = _sub(P, sel)
+    orc = oracle_mod.OracleReconstruction(Q, oracle_mod.CANON, pvr=pvr, spx_masks=Q.spx_masks)
+    local = []
+    for k in range(len(sel)):
+        a = np.flatnonzero(Q.slices[k].reshape(-1) != -1)
+        local.extend(k * sy * sx + rng.choice(a, 16, replace=False))
+    local = np.array(local, np.int64)
+    assert len(local) >= N_SAMPLES - 20
+    sume, keep, osim, ow, oin = orc.sample_pixels(local, V)
+    glob = sel[local // (sy * sx)] * (sy * sx) + local % (sy * sx)
+    g_ps, g_sim, g_sw, g_si = (a.reshape(-1)[glob] for a in (ps, sim, sw, si))
+    with capsys.disabled():
+        print(f"\n[{name}] {len(local)} sampled pixels of {ns} slices/patches, volume {P.vsize}: kept {int(keep.sum())}, inside {int(oin.sum())}, "
+              f"v_PSF_sums rel {rel_err(g_ps, sume):.1e}, sim {rel_err(g_sim, osim):.1e}, simweight {np.abs(g_sw - ow).max():.1e}")
+    assert keep.sum() > 0.5 * len(local)
+    assert np.array_equal(g_ps != 0, keep != 0)                            # the `sume > 0.5` / `> 1e-5` gate: exact
+    assert np.allclose(g_ps, sume, rtol=1e-6, atol=0, equal_nan=True)
+    assert np.array_equal(g_si, oin)                                       # any processed tap on a mask voxel
+    assert rel_err(g_sim, osim) < TOL_SUM and np.abs(g_sw - ow).max() < TOL_SUM * max(1.0, float(np.abs(ow).max()))
+
+
+@pytest.mark.parametrize("name,count", [("P4", 3), ("S8", 2), ("PVR4", 12), ("PVR8spx", 6)])
+def test_scatter_of_a_few_slices_of_the_bench_workloads_against_the_oracle(name, count, oracle_mod, capsys):
+    pvr = name.startswith("PVR")
+    P = _workload(name)
+    ns = P.ns
+    rng = np.random.default_rng(13)
+    act = (P.slices > 0).reshape(ns, -1).sum(1)
+    cand = np.flatnonzero(act >= 0.5 * act.max())
+    stacks = np.unique(P.stack_index[cand])
+    sel = np.unique([rng.choice(cand[P.stack_index[cand] == stacks[k % len(stacks)]]) for k in range(count)])   # from different stacks
+    Q = _sub(P, sel)
+    E, rec = _engine(Q, pvr)
+    orc = oracle_mod.OracleReconstruction(Q, oracle_mod.CANON, pvr=pvr, spx_masks=Q.spx_masks)
+    ones = np.ones(Q.ns, np.float32)
+    orc.UpdateScaleVector(ones, ones)
+    orc.InitializeEMValues()
+    rec.GaussianReconstruction()
+    orc.GaussianReconstruction()
+    assert np.array_equal(rec.debug_get(E.BUF_PSF_SUMS) != 0, orc.psf_sums != 0)
+    assert rel_err(rec.getVolWeights(), orc.volw) < TOL_SUM and np.array_equal(rec.getVolWeights() > 0, orc.volw > 0)
+    # identical per-pixel state on both sides, a non-zero residual and non-trivial weights
+    orc.simslices[...] = np.where(orc.slices > 0, orc.slices * rng.uniform(0.8, 1.2, orc.slices.shape), 0).astype(np.float32)
+    orc.weights[...] = np.where(orc.slices != -1, rng.uniform(0.2, 1.0, orc.slices.shape), 0).astype(np.float32)
+    for b, a in ((E.BUF_SIMSLICES, orc.simslices), (E.BUF_WEIGHTS, orc.weights), (E.BUF_PSF_SUMS, orc.psf_sums)):
+        rec.debug_set(b, a)
+    rec.SuperresolutionBackproject(ones)
+    orc.SuperresolutionBackproject(ones)
+    cm, ad = rec.debug_get(E.BUF_CONFIDENCE_MAP), rec.debug_get(E.BUF_ADDON)
+    with capsys.disabled():
+        print(f"\n[{name}] scatter of slices/patches {list(sel)} on the {P.vsize} volume: {int((orc.cmap > 0).sum())} voxels hit, "
+              f"cmap {rel_err(cm, orc.cmap):.1e}, addon {rel_err(ad, orc.addon):.1e}")
+    assert (orc.cmap > 0).sum() > 1000
+    assert np.array_equal(cm > 0, orc.cmap > 0)                            # hit set: exact
+    assert rel_err(cm, orc.cmap) < TOL_SUM and rel_err(ad, orc.addon) < TOL_SUM
+    rec.close()

@@ -65,3 +65,60 @@ def test_world_size_2_matches_single_process(oracle_mod):
     assert np.allclose(r0["scale"], ref._scale_gpu, rtol=1e-5)
     assert np.allclose(r0["sw"], ref._slice_weight_gpu, atol=1e-4)
     assert np.allclose(r0["em"], [ref._sigma_gpu, ref._mix_gpu, ref._m_gpu, ref._mix_s_gpu], rtol=1e-5)
+
+
+# ---- the patch-to-volume loop sharded by patches ("PVR: identical with patches as the unit") ----------------
+def _pvr_problem():
+    from fetalreconstruction_amd import pvr
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(3, (24, 24, 4), 1.1, 2.2, None, 1.0, 11.0, seed=4, orientations=("ax", "sag", "cor"))
+    return pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (16, 16), (8, 8))
+
+
+def shard_patches(P, world):
+    """contiguous patch ranges balanced by the pixels that carry data (what csrc/pvr_cli.cpp does)"""
+    return shard_slices((P.slices > 0).reshape(P.ns, -1).sum(1), world)
+
+
+def _pvr_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    from fetalreconstruction_amd import pvr
+    from fetalreconstruction_amd.reconstruction import TorchComm
+    from oracle import pyoracle as po
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        P = _pvr_problem()
+        lo, hi = shard_patches(P, world)[rank]
+        eng = po.OracleReconstruction(phantom.sub_problem(P, lo, hi), po.CANON, pvr=True)
+        drv = pvr.irtkPatchBasedReconstruction(eng, P.patches_per_stack, P.min_intensity, P.max_intensity, patch_range=(lo, hi), comm=TorchComm())
+        drv.reconstruct_iteration(2)
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), recon=eng.recon, scale=drv.scale, pw=drv.patch_weight, pot=drv.patch_potential,
+                 em=np.array([drv.m_sigma_gpu, drv.m_mix_gpu, drv.m_m_gpu, drv.m_mix_s_gpu]), lohi=np.array([lo, hi]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_pvr_world_size_2_matches_single_process(oracle_mod):
+    """Patches [lo, hi) per rank, balanced by data-carrying pixels, a stack boundary inside one rank's range: one all-reduce of
+    recon|volw, one of addon|cmap per SR iteration, the robust-statistics / M-step scalars and the patch potentials in one
+    exchange each -- and the reference's within-stack indexing of the potentials (patchBasedRobustStatistics_gpu.cu:256-276)
+    applied to the GLOBAL patch numbering on every rank."""
+    import torch.multiprocessing as mp
+    from fetalreconstruction_amd import pvr
+    P = _pvr_problem()
+    eng = oracle_mod.OracleReconstruction(P, oracle_mod.CANON, pvr=True)
+    ref = pvr.irtkPatchBasedReconstruction(eng, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    ref.reconstruct_iteration(2)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_pvr_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0, r1 = np.load(os.path.join(d, "rank0.npz")), np.load(os.path.join(d, "rank1.npz"))
+    assert r0["lohi"][0] == 0 and r0["lohi"][1] == r1["lohi"][0] and r1["lohi"][1] == P.ns
+    assert r0["lohi"][1] not in np.cumsum(P.patches_per_stack)         # the cut is not a stack boundary
+    for k in ("recon", "scale", "pw", "pot", "em"):
+        assert np.array_equal(r0[k], r1[k]), k                         # both ranks: the same volume and host state
+    assert (r0["pot"][max(P.patches_per_stack):] == 0).all()           # the quirk, on global indices
+    scale = np.abs(eng.recon).max()
+    assert np.max(np.abs(r0["recon"] - eng.recon)) < 2e-5 * scale
+    assert np.allclose(r0["scale"], ref.scale, rtol=1e-5) and np.allclose(r0["pw"], ref.patch_weight, atol=1e-4)
+    assert np.allclose(r0["pot"], ref.patch_potential, rtol=1e-5, atol=1e-9)
+    assert np.allclose(r0["em"], [ref.m_sigma_gpu, ref.m_mix_gpu, ref.m_m_gpu, ref.m_mix_s_gpu], rtol=1e-5)

@@ -22,6 +22,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_v1.npz")
 TOL_SUM = 2e-5
 TOL_SCALAR = 1e-5
+# scatter variants: 4 = wave-owned LDS planes per slice tile, flushed with float atomics; 3 = the workgroup kernel for every
+# tile; 1 = LDS tiles with ds_add_f32; 0 = direct atomics
+BACK_MODES = [4, 3, 1, 0]
 
 
 def _engine(prob):
@@ -169,7 +172,7 @@ def test_gather_in_pieces(tiny, oracle_mod, monkeypatch):
     assert rel_err(outs[1][2], orc.simslices) < TOL_SUM
 
 
-@pytest.mark.parametrize("back_mode", [4, 3, 1, 0])
+@pytest.mark.parametrize("back_mode", BACK_MODES)
 def test_backprojection_parity(tiny, oracle_mod, back_mode):
     """back_mode 4 = wave-owned LDS planes with the dead-unit shortcut (default), 3 = the workgroup kernel for every tile,
     1 = LDS tiles with ds_add_f32, 0 = direct atomics."""
@@ -330,8 +333,8 @@ def test_adjointness_at_full_size(workload):
     """Size-independent property on the full-size workloads (too big for the oracle) -- P4 = BASELINE.json configs[1]
     (4 stacks, 1.0 mm), S8 = configs[3] (8 stacks of 64 x 256^2 slices, 0.75 mm, 33.5 M pixels, 40 M voxels): the forward
     projection and the scatter are adjoint, <A V, e> = <V, A^T e> with unit voxel/slice weights."""
-    from fetalreconstruction_amd import engine as E
-    P = phantom.problem_p4() if workload == "P4" else phantom.problem_s8()
+    from fetalreconstruction_amd import engine as E, workloads
+    P = workloads.get(workload)                                   # the bench's own workloads (P4 = the bundled mask's frame)
     rec = _engine(P)
     rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
     rec.InitializeEMValues()
@@ -366,8 +369,8 @@ def test_kernel_variants_agree_at_full_size():
     with the dead-unit shortcut vs the wave-per-pixel kernel (a unit wrongly declared dead would lose >= 1e-5 of a pixel's
     weight), two-pass Gaussian reconstruction vs the wave-per-pixel kernel, wave-owned / workgroup scatter vs direct atomics.
     Hit sets exact, sums to float round-off."""
-    from fetalreconstruction_amd import engine as E
-    P = phantom.problem_p4()
+    from fetalreconstruction_amd import engine as E, workloads
+    P = workloads.get("P4")                                       # the bench's workload: the bundled mask's oblique frame
     rec = _engine(P)
     rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
     rec.InitializeEMValues()

@@ -798,3 +798,59 @@ def test_pvr_patch_registration_parity(oracle_mod):
     c0, _ = rec.cc_patches(P.slice_i2w, T, 0)
     c1, _ = rec.cc_patches(P.slice_i2w, tg, 0)
     assert c1.mean() > c0.mean()
+
+
+# ---- patches sharded over ranks (csrc/pvr_host.cpp pvrh_create_sharded, csrc/pvr_cli.cpp -d) ---------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("registration", ["none", "patches"])
+def test_pvr_command_line_shards_the_patches_over_the_devices_of_d(tmp_path, registration):
+    """`bin/PVRreconstructionGPU -d 0 0 0`: one rank per listed device, one thread and one engine context each, the patches
+    sharded by data-carrying pixels, recon|volw and addon|cmap all-reduced, the scalars and the patch potentials exchanged,
+    every rank registering its own patches.  The box has one GPU, so the device is named three times and the ranks exchange
+    through host memory (the group's test mode) -- same sharding and call sequence as over RCCL.  Against the one-rank run."""
+    import subprocess
+    from fetalreconstruction_amd import build, nifti
+    paths, mpath, stacks = _write_pvr_case(tmp_path)
+    common = ["-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8", "--resolution", "1.0", "--iterations", "1",
+              "--sr_iterations", "3"] + (["--no_registration"] if registration == "none" else [])
+    one = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "one.nii.gz"), *common, "-d", "0"], capture_output=True, text=True, timeout=600)
+    three = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / "three.nii.gz"), *common, "-d", "0", "0", "0"], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and three.returncode == 0, three.stderr[-2000:]
+    assert "3 ranks on devices 0 0 0" in three.stderr and "host memory" in three.stderr
+    v1, a1 = nifti.read(tmp_path / "one.nii.gz")
+    v3, a3 = nifti.read(tmp_path / "three.nii.gz")
+    assert v1.shape == v3.shape and np.array_equal(v1 > 0, v3 > 0)
+    if registration == "none":
+        assert np.abs(v1 - v3).max() <= 2e-4 * np.abs(v1).max()            # float sums in a different order
+    else:
+        ok = (v1 > 0) & (v3 > 0)
+        assert np.corrcoef(v1[ok], v3[ok])[0, 1] > 0.98
+    _check_pvr_volume(tmp_path / "three.nii.gz", stacks)
+
+
+@pytest.mark.gpu
+def test_cpp_pvr_host_through_the_collectives_at_world_one():
+    """pvrh_create_sharded with the C library's RCCL communicator at world 1 (forced through the callbacks): the sharded code
+    path -- local Gaussian pass + all-reduce + finish, scatter + all-reduce + regulariser, the three exchanges per SR
+    iteration -- gives the volume and the host state of the plain one-rank object."""
+    from fetalreconstruction_amd import engine as E, host
+    pvr, stacks, P = _small_pvr()
+    out = []
+    for use in (False, True):
+        rec = E.Reconstruction(0)
+        rec.set_option("pvr", 1)
+        E.sync_gpu(rec, P, quality_factor=1.0)
+        comm = host.RcclComm(rec, 0, 1, host.RcclComm.unique_id()) if use else None
+        d = host.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity, patch_range=(0, P.ns), comm=comm,
+                                              force_collectives=use)
+        rec.timer_enable(True)
+        d.reconstruct_iteration(2)
+        out.append((rec.syncCPU().copy(), d.state(), rec.timers()))
+        if comm:
+            comm.close()
+    (v0, s0, t0), (v1, s1, t1) = out
+    assert t0["allreduce"][1] == 0 and t1["allreduce"][1] == 3 and t1["exchange_host"][1] == 1 + 1 + 2 * 2   # robust stats, E-step, 2 x (M-step, E-step)
+    assert np.array_equal(v0 > 0, v1 > 0) and np.abs(v0 - v1).max() <= 2e-5 * np.abs(v0).max()
+    for k in ("scale", "patch_weight", "patch_potential"):
+        assert np.allclose(s0[k], s1[k], rtol=2e-5, atol=1e-6), k
+    assert np.allclose([s0[k] for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu")], [s1[k] for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu")], rtol=2e-5)

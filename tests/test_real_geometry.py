@@ -179,11 +179,18 @@ def test_kernel_parity_in_the_bundled_mask_frame(tiny, oracle_mod):
     P = _moved_problem(tiny)
     assert np.abs(P.slice_i2w[:, 3]).max() > 250 and np.abs(P.slice_t.reshape(-1, 4, 4)[:, :3, :3]).max() < 1.0 + 1e-6
     TPG.test_psf_taps_are_bit_identical(P, oracle_mod, golden=False)
-    TPG.test_gaussian_reconstruction_parity(P, oracle_mod, 1, 3)
-    TPG.test_gaussian_reconstruction_parity(P, oracle_mod, 0, 1)
-    TPG.test_forward_projection_parity(P, oracle_mod, 3)
-    TPG.test_backprojection_parity(P, oracle_mod, 2)
+    # the production kernels by their mode numbers (gauss_mode 1 / fwd_mode 1 = the unit gather, back_mode 4 = the wave-owned
+    # scatter, back_mode 5 = the cell-owned scatter without atomics), then the first-generation kernels
+    TPG.test_gaussian_reconstruction_parity(P, oracle_mod, 1, 1)
+    TPG.test_gaussian_reconstruction_parity(P, oracle_mod, 0, 0)
+    TPG.test_forward_projection_parity(P, oracle_mod, 1)
+    TPG.test_forward_projection_parity(P, oracle_mod, 0)
+    for bm in TPG.BACK_MODES:
+        TPG.test_backprojection_parity(P, oracle_mod, bm)
     TPG.test_em_steps_parity(P, oracle_mod)
+    # ... and against the reference's own arithmetic (LITERAL) in this frame, where the float32 lattice is coarsest
+    import tests.test_round2_gaps as TR2
+    TR2.test_hip_path_against_the_literal_oracle(P, oracle_mod, None)
     # the GPU registration of --useGPUReg (a17): sampled and blurred slices bit-exact, the same decisions at every step
     import tests.test_registration as TR
     vol = TR._analytic_volume(tiny)

@@ -21,6 +21,11 @@ TOL_LITERAL = 3e-3
 MAX_FLIP_RATE = 5e-5
 MAX_FLIP_PIXELS = 0.08
 MAX_DPSF = 1e-4
+# largest relative change of ONE pixel's processed PSF sum (sume, RC.cu:251-258): a flipped skip decision moves a whole tap --
+# up to ~1e-2 of a pixel's sum where the PSF changes by almost exactly epsilon per voxel -- in or out of it.  Observed: 3.5e-2
+# (P4s), 9.6e-3 (S8 geometry); a pixel's sume only normalises its own taps (psf / sume), so this is a per-pixel gain error of
+# that size on <= 8 % of the pixels, not an error of the volume
+MAX_SUME_REL = 5e-2
 
 
 def _pair(prob, oracle_mod, mode):
@@ -78,8 +83,10 @@ def test_hip_path_against_the_literal_oracle(tiny, oracle_mod, capsys):
                        ("cmap > 0", rec.debug_get(E.BUF_CONFIDENCE_MAP), orc.cmap), ("siminside", rec.debug_get(E.BUF_SIMINSIDE), orc.siminside),
                        ("voxcount", rec.debug_get(E.BUF_VOXEL_COUNT), orc.voxcount)):
         sym[name] = (int(((g != 0) != (o != 0)).sum()), int((o != 0).sum()))
-    with capsys.disabled():
-        print("\n[HIP vs LITERAL oracle, tiny] hit-set symmetric differences (differing / set size):",
+    import contextlib
+    quiet = capsys.disabled if capsys is not None else contextlib.nullcontext
+    with quiet():
+        print(f"\n[HIP vs LITERAL oracle, {tiny.name}] hit-set symmetric differences (differing / set size):",
               ", ".join(f"{k}: {a}/{b}" for k, (a, b) in sym.items()))
     for k, (a, b) in sym.items():
         assert a <= max(2, b // 2000), (k, a, b)                      # a flipped tap may add or drop a voxel at the rim of a footprint
@@ -89,8 +96,8 @@ def test_hip_path_against_the_literal_oracle(tiny, oracle_mod, capsys):
                        ("simweights", rec.debug_get(E.BUF_SIMWEIGHTS), orc.simweights), ("addon", rec.debug_get(E.BUF_ADDON), orc.addon),
                        ("cmap", rec.debug_get(E.BUF_CONFIDENCE_MAP), orc.cmap)):
         errs[name] = rel_err(g, o)
-    with capsys.disabled():
-        print("[HIP vs LITERAL oracle, tiny] max |diff| / max |ref|:", ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    with quiet():
+        print(f"[HIP vs LITERAL oracle, {tiny.name}] max |diff| / max |ref|:", ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
     assert max(errs.values()) < TOL_LITERAL, errs
     assert np.allclose(dg._scale_gpu, do._scale_gpu, rtol=TOL_LITERAL)
     assert np.allclose([dg._sigma_gpu, dg._mix_gpu, dg._m_gpu], [do._sigma_gpu, do._mix_gpu, do._m_gpu], rtol=TOL_LITERAL)
@@ -108,6 +115,7 @@ def test_literal_vs_canonical_skip_census(oracle_mod, capsys):
             total[k] += r[k]
         assert r["flip_rate"] < MAX_FLIP_RATE and r["pixels_with_flips"] < MAX_FLIP_PIXELS * r["pixels"], (name, r)
         assert r["max_abs_dpsf"] < MAX_DPSF, (name, r)
+        assert r["sume_rel_max"] < MAX_SUME_REL, (name, r)
         assert abs(r["kept_lit"] - r["kept_can"]) <= r["flips"]
     with capsys.disabled():
         print()
