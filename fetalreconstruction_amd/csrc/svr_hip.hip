@@ -19,10 +19,15 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
 #include "../../include/svr_hip.h"
+
+// csrc/svr_sort.hip: radix sort / prefix sum of the vendor's primitives library for the work lists of svr_cell.inc
+int svr_sort_keys_u64(void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, size_t n, int end_bit, hipStream_t stream);
+int svr_inclusive_sum_u32(void *tmp, size_t *tmp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // constants of the reference configuration section (RC.cuh:54-75)
@@ -2717,6 +2722,7 @@ __global__ __launch_bounds__(256) void k_ncc(const short *targets, int tx, int t
 // context
 // ==========================================================================================
 struct RegState;   // GPU slice-to-volume registration state (svr_reg.inc)
+namespace { struct CellState; }  // sorted pixels, runs, items and staging of the scatter without atomics (svr_cell.inc)
 
 struct svr_ctx {
   int device = 0;
@@ -2792,7 +2798,9 @@ struct svr_ctx {
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   int pvr_mode = 1;         // PVR kernels: 1 = the unit-based gather / wave-owned scatter with support 12, 0 = wave-per-pixel (pvr_kernel)
   unsigned char *d_spx = nullptr;
-  int back_mode = 4;        // 4 = wave-owned LDS planes (back_wave_kernel), 3 = the workgroup kernel for every tile (back_slot_kernel<8>),
+  int back_mode = 5;        // 5 = cell-owned planes, staged and combined in a fixed order: no atomics (svr_cell.inc; the default for SVR on the fly --
+                            // patch-based runs and the coefficient table take 4 unless the mode was set explicitly),
+                            // 4 = wave-owned LDS planes (back_wave_kernel), 3 = the workgroup kernel for every tile (back_slot_kernel<8>),
                             // 1 = LDS tiles with ds_add_f32 (back_tiled_kernel), 0 = direct device-scope atomics per tap (psf_kernel<MODE_BACK>)
   int tile_cap = 0;         // voxels of LDS accumulator per workgroup
   int dbg_back = 0;
@@ -2801,6 +2809,7 @@ struct svr_ctx {
   uint32_t n_tiles_fb8 = 0;   // tiles of the last scatter that the wave-owned kernel handed to the workgroup kernel (box larger than wave_cap)
   uint32_t *d_tiles_fb2 = nullptr;
   bool wave_cap_user = false;
+  bool back_mode_user = false;   // svr_set_option("back_mode") was called: no automatic choice between 5 and 4
   // The coefficient table: what irtkReconstruction::CoeffInit keeps as _volcoeffs on the CPU path (RG.cc:2305-2673) --
   // every PSF pixel's evaluated taps, 16 KiB per pixel, written once per slice geometry by k_coeff_build and streamed by
   // the COEFF instantiations of the scatter and the gather instead of being re-evaluated in every SR iteration.  The
@@ -2838,6 +2847,10 @@ struct svr_ctx {
 
   // GPU slice-to-volume registration (svr_reg.inc)
   RegState *reg = nullptr;
+
+  // the scatter without atomics (back_mode 5, svr_cell.inc): cell size in voxels (x, lane axis), wavefronts per item
+  CellState *cell = nullptr;
+  int cell_w = 6, cell_h = 4, cell_split = 1, cell_qx = 1, cell_band = 3;   // cell_qx: cells of a quad along x (1, 2 or 4; the other factor along the lane axis)
 
   // timers
   bool timers = false;
@@ -2881,7 +2894,17 @@ int fail(svr_ctx *c, int code, const std::string &msg) {
     if (!(cond)) return fail(ctx, SVR_E_STATE, std::string(__func__) + ": " + what);      \
   } while (0)
 
+// The scatter variant in effect: the cell-owned scatter (5) is the default for SVR with the taps evaluated on the fly; the
+// patch-based path (runs of a dozen pixels per patch and cell: 22.0 against 20.3 ms on PVR4) and the coefficient table (its
+// pass waits for memory and needs the deeper request pipeline of back_wave_kernel) take the wave-owned scatter with the
+// atomic flush (4) unless the caller named a mode.
+inline int back_mode_eff(const svr_ctx *ctx) {
+  if (ctx->back_mode == 5 && !ctx->back_mode_user && (ctx->pvr || ctx->coeff_mode)) return 4;
+  return ctx->back_mode;
+}
 void reg_free(RegState *r);
+void cell_free(CellState *c);
+void cell_invalidate(svr_ctx *ctx);
 
 template <class T>
 void free_dev(T *&p) {
@@ -2972,7 +2995,7 @@ int prepare_slice_consts(svr_ctx *ctx) {
   HIPCHK(hipMemcpyAsync(ctx->d_sc, h.data(), h.size() * sizeof(SliceConst), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->sc_dirty = false;
-  ctx->coeff_valid = false;                               // new slice geometry: new taps
+  ctx->coeff_valid = false; cell_invalidate(ctx);                               // new slice geometry: new taps
   return SVR_OK;
 }
 
@@ -3296,6 +3319,8 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
   return SVR_OK;
 }
 
+#include "svr_cell.inc"
+
 // reduce partial[ns*chunks][K] -> per_slice[ns][K] (+ optionally -> d_out[K])
 int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
   hipLaunchKernelGGL(k_reduce_chunks, dim3(nblk((size_t)ctx->ns * K)), dim3(256), 0, ctx->stream,
@@ -3373,7 +3398,7 @@ int svr_create(int device, svr_ctx **out) {
 int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   SVR_ENTER(ctx);
   if (!ctx || !name) return SVR_E_ARG;
-  if (!strcmp(name, "back_mode")) { ctx->back_mode = value; return SVR_OK; }
+  if (!strcmp(name, "back_mode")) { ctx->back_mode = value; ctx->back_mode_user = true; return SVR_OK; }
   if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
   if (!strcmp(name, "pvr_mode")) { ctx->pvr_mode = value; return SVR_OK; }
   if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
@@ -3390,11 +3415,29 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     ctx->fwd_tune_pending = ctx->back_tune_pending = value != 0;
     return SVR_OK;
   }
-  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; free_dev(ctx->d_coeff); ctx->coeff_cap = 0; return SVR_OK; }
+  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; cell_invalidate(ctx); free_dev(ctx->d_coeff); ctx->coeff_cap = 0; return SVR_OK; }
   if (!strcmp(name, "coeff_table")) {
     if ((value ? 1 : 0) != ctx->coeff_mode) ctx->fwd_tune_pending = ctx->back_tune_pending = ctx->fwd_autotune != 0;   // other shapes win
     ctx->coeff_mode = value ? 1 : 0;
-    if (!value) { free_dev(ctx->d_coeff); ctx->coeff_cap = 0; ctx->coeff_valid = false; }
+    if (!value) { free_dev(ctx->d_coeff); ctx->coeff_cap = 0; ctx->coeff_valid = false; cell_invalidate(ctx); }
+    return SVR_OK;
+  }
+  if (!strcmp(name, "cell_band")) {
+    if (value < 0 || value > 10) return fail(ctx, SVR_E_ARG, "cell_band: 0..10 (a run holds 2^cell_band centre planes)");
+    ctx->cell_band = value;
+    cell_invalidate(ctx);
+    return SVR_OK;
+  }
+  if (!strcmp(name, "cell_qx")) {
+    if (value != 1 && value != 2 && value != 4) return fail(ctx, SVR_E_ARG, "cell_qx: 1, 2 or 4");
+    ctx->cell_qx = value;
+    cell_invalidate(ctx);
+    return SVR_OK;
+  }
+  if (!strcmp(name, "cell_w") || !strcmp(name, "cell_h") || !strcmp(name, "cell_split")) {
+    if (value < 1 || value > 32) return fail(ctx, SVR_E_ARG, "cell_w / cell_h / cell_split: 1..32");
+    (!strcmp(name, "cell_w") ? ctx->cell_w : !strcmp(name, "cell_h") ? ctx->cell_h : ctx->cell_split) = value;
+    cell_invalidate(ctx);
     return SVR_OK;
   }
   if (!strcmp(name, "dbg_back")) { ctx->dbg_back = value; return SVR_OK; }
@@ -3436,9 +3479,9 @@ int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
   SVR_ENTER(ctx);
   if (!ctx || !name || !value) return SVR_E_ARG;
   const struct { const char *n; int v; } tab[] = {
-      {"back_mode", ctx->back_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
+      {"back_mode", back_mode_eff(ctx)}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
       {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
-      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
+      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", ctx->cell_w}, {"cell_h", ctx->cell_h}, {"cell_split", ctx->cell_split}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
   for (const auto &e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return SVR_OK; }
   return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);
@@ -3459,6 +3502,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_ncc_idx); free_dev(ctx->d_ncc_m); free_dev(ctx->d_ncc_s);
   free_dev(ctx->d_coeff); free_dev(ctx->d_coeff_id);
   reg_free(ctx->reg);
+  cell_free(ctx->cell);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
@@ -3508,7 +3552,7 @@ int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const f
   ctx->vx = size[0]; ctx->vy = size[1]; ctx->vz = size[2];
   memcpy(ctx->vdim, dim, 3 * sizeof(float));
   ctx->nv = nv;
-  ctx->coeff_valid = false;
+  ctx->coeff_valid = false; cell_invalidate(ctx);
   HIPCHK(hipMalloc(&ctx->d_recon_volw, 2 * nv * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_addon_cmap, 2 * nv * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_snap, nv * sizeof(float)));
@@ -3552,7 +3596,7 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   ctx->np = np;
   ctx->have_slices = false; ctx->have_scales = false; ctx->have_dims = false; ctx->have_mats = false;
   ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->n_active = ctx->n_psf = 0;
-  ctx->coeff_valid = false; free_dev(ctx->d_coeff_id); free_dev(ctx->d_coeff); ctx->coeff_cap = 0;
+  ctx->coeff_valid = false; cell_invalidate(ctx); free_dev(ctx->d_coeff_id); free_dev(ctx->d_coeff); ctx->coeff_cap = 0;
   const size_t fb = np * sizeof(float);
   HIPCHK(hipMalloc(&ctx->d_slices, fb));
   HIPCHK(hipMalloc(&ctx->d_weights, fb));
@@ -3597,7 +3641,7 @@ int svr_fill_slices(svr_ctx *ctx, const float *sdata, const int *sizes_x, const 
   HIPCHK(hipMemcpyAsync(ctx->d_slices, sdata, ctx->np * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   ctx->have_slices = true;
   ctx->psf_list_valid = false;
-  ctx->coeff_valid = false;
+  ctx->coeff_valid = false; cell_invalidate(ctx);
   return build_list(ctx, false);
 }
 
@@ -3641,7 +3685,7 @@ int svr_generate_psf_volume(svr_ctx *ctx, const float *cpu_psf, const uint32_t p
   // d_PSFI2W * ((PSFsize - 1) * 0.5f)   RC.cu:172
   float v[3] = {((float)psf_size[0] - 1) * 0.5f, ((float)psf_size[1] - 1) * 0.5f, ((float)psf_size[2] - 1) * 0.5f};
   matvec3_host(psf_i2w, v, ctx->psf_c0);
-  ctx->coeff_valid = false;                               // the taps' residuals carry c0
+  ctx->coeff_valid = false; cell_invalidate(ctx);                               // the taps' residuals carry c0
   ctx->quality_factor = quality_factor;
   ctx->have_psf = true;
   return SVR_OK;
@@ -3786,7 +3830,13 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     a.flag = ctx->d_gauss_flag;
     a.addon = ctx->recon(); a.cmap = ctx->volw();       // scatter targets of pass 2 (RC.cu:279-282)
     ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.dbg = 0;
-    r = launch_scatter(ctx, ctx->pvr ? 4 : std::max(1, ctx->back_mode), a, ta, ctx->d_tiles_tmp, n2, MODE_GAUSS2);
+    bool cells = false;
+    if (back_mode_eff(ctx) == 5) {
+      if ((r = cell_prepare(ctx))) return r;
+      cells = ctx->cell->usable;
+    }
+    if (cells) r = launch_cell_scatter(ctx, a, 1, ctx->recon(), ctx->volw());
+    else r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, std::max(1, back_mode_eff(ctx))), a, ta, ctx->d_tiles_tmp, n2, MODE_GAUSS2);
     if (r) return r;
   } else if (a.n && ctx->pvr) {
     hipLaunchKernelGGL(pvr_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
@@ -4055,14 +4105,14 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     r = svr_update_slice_weights(ctx, slice_weight);   // RC.cu:2123
     if (r) return r;
   }
-  if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 3)) {
+  if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && back_mode_eff(ctx) != 5 && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 3)) {   // (mode 5: cells, no tile shape to time)
     ctx->back_tune_pending = false;
     ctx->in_tune = true;
     // with the coefficient table the pass waits for memory, not for the ALUs: larger tiles (fewer flushed voxels per
     // pixel) are tried first, with the largest box, before the box sizes are timed for the shape that won
     static const int cand_eval[6][2] = {{6, 5}, {6, 4}, {5, 4}, {4, 4}, {4, 2}, {2, 2}};   // the first four always, then smaller ones while they win
     static const int cand_tab[5][2] = {{8, 4}, {6, 4}, {4, 4}, {4, 2}, {2, 2}};
-    const bool tab = ctx->coeff_mode && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode == 4);
+    const bool tab = ctx->coeff_mode && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) == 4);
     const int (*cand)[2] = tab ? cand_tab : cand_eval;
     const int ncand = tab ? 5 : 6;
     const int cap0 = ctx->wave_cap;
@@ -4097,7 +4147,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     // voxels per pixel but needs the larger box, so shape and box are timed together: per shape the boxes from the
     // largest down while they get faster (6x4 with 2096 beats 6x5, which wins at 2416 and then cannot shrink).
     static const int caps[5] = {2416, 2096, 1776, 1616, 1456};
-    const bool wave = (ctx->pvr || ctx->back_mode == 4) && !ctx->wave_cap_user;
+    const bool wave = (ctx->pvr || back_mode_eff(ctx) == 4) && !ctx->wave_cap_user;
     float best = 3.0e38f;
     int pick = 0, pick_cap = wave ? caps[0] : cap0;
     for (int c = 0; c < ncand && !r; ++c) {
@@ -4140,14 +4190,20 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
-  if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode == 4)) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
+  if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 4)) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
-  const bool tiled = ctx->pvr ? ctx->pvr_mode == 1 : ctx->back_mode >= 1;
+  const bool tiled = ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 1;
   if (a.n && tiled) {
     TileArgs ta;
     ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.dbg = ctx->dbg_back;
     ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.gauss = 0;
-    r = launch_scatter(ctx, ctx->pvr ? 4 : ctx->back_mode, a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
+    bool cells = false;
+    if (back_mode_eff(ctx) == 5) {
+      if ((r = cell_prepare(ctx))) return r;
+      cells = ctx->cell->usable;
+    }
+    if (cells) r = launch_cell_scatter(ctx, a, 0, ctx->addon(), ctx->cmap());
+    else r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, back_mode_eff(ctx)), a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
     if (r) return r;
   } else if (a.n && ctx->pvr) {
     hipLaunchKernelGGL(pvr_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
@@ -4310,7 +4366,7 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   HIPCHK(hipMemcpyAsync(p, host_in, b, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
-  if (which == SVR_BUF_SLICES) ctx->coeff_valid = false;   // the table covers the pixels with s != -1
+  if (which == SVR_BUF_SLICES) ctx->coeff_valid = false; cell_invalidate(ctx);   // the table covers the pixels with s != -1
   if (which == SVR_BUF_SLICES) return build_list(ctx, false);
   return SVR_OK;
 }

@@ -22,9 +22,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_v1.npz")
 TOL_SUM = 2e-5
 TOL_SCALAR = 1e-5
-# scatter variants: 4 = wave-owned LDS planes per slice tile, flushed with float atomics; 3 = the workgroup kernel for every
-# tile; 1 = LDS tiles with ds_add_f32; 0 = direct atomics
-BACK_MODES = [4, 3, 1, 0]
+# scatter variants: 5 = cell-owned LDS planes, staged and combined in a fixed order, no atomics (csrc/svr_cell.inc); 4 =
+# wave-owned LDS planes per slice tile, flushed with float atomics; 3 = the workgroup kernel for every tile; 1 = LDS tiles
+# with ds_add_f32; 0 = direct atomics
+BACK_MODES = [5, 4, 3, 1, 0]
 
 
 def _engine(prob):
@@ -244,7 +245,7 @@ def test_full_iteration_tracks_the_oracle(tiny, oracle_mod):
 
 
 @pytest.mark.parametrize("shift", [(-14.2, -14.4, -14.6), (14.3, 14.1, 13.9), (-14.2, 14.1, 0.3)])
-@pytest.mark.parametrize("back_mode", [4, 3, 1])
+@pytest.mark.parametrize("back_mode", [5, 4, 3, 1])
 def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
     """Slices hanging off the volume: negative coordinates alias to index 0 (float->uint
     saturation), taps beyond the high end are dropped -- in the Gaussian scatter, the forward
@@ -394,11 +395,11 @@ def test_kernel_variants_agree_at_full_size():
     rec.set_option("fwd_mode", 1)
     rec.set_option("gauss_mode", 1)
     res = {}
-    for bm in (4, 3, 0):
+    for bm in (5, 4, 3, 0):
         rec.set_option("back_mode", bm)
         rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
         res[bm] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
-    for bm in (4, 3):
+    for bm in (5, 4, 3):
         assert np.array_equal(res[bm][1] > 0, res[0][1] > 0)
         assert rel_err(res[bm][1], res[0][1]) < TOL_SUM and rel_err(res[bm][0], res[0][0]) < TOL_SUM
 
@@ -523,3 +524,29 @@ def test_tile_shapes_do_not_change_results(tiny, oracle_mod):
     for name in res:
         assert np.array_equal(res[name][0], res["auto"][0]) and np.array_equal(res[name][1], res["auto"][1]), name
         assert rel_err(res[name][2], res["auto"][2]) < TOL_SUM and rel_err(res[name][3], res["auto"][3]) < TOL_SUM, name
+
+
+def test_cell_scatter_is_bit_identical_from_run_to_run():
+    """back_mode 5 (the default for SVR on the fly; csrc/svr_cell.inc): no float atomics anywhere -- every (cell, plane) box is
+    accumulated by one wavefront in a fixed order, staged, and the slabs are added per voxel in a fixed order.  Two launches
+    on one engine and a launch on a second engine give the same bits, in the Gaussian pass and in the back-projection (the
+    atomic flush of back_mode 4 agrees with itself to ~1e-6 only)."""
+    from fetalreconstruction_amd import engine as E, workloads
+    P = workloads.get("P4")
+    outs = []
+    for k in range(2):
+        rec = _engine(P)
+        assert rec.get_option("back_mode") == 5
+        rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+        rec.InitializeEMValues()
+        rec.GaussianReconstruction()
+        vol, vw = rec.syncCPU().copy(), rec.getVolWeights().copy()
+        rec.SimulateSlices()
+        for rep in range(2 if k == 0 else 1):
+            rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+            outs.append((vol, vw, rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy()))
+        rec.close()
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert np.array_equal(a, b)
+    assert (outs[0][3] > 0).sum() > 100000
