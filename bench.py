@@ -42,25 +42,35 @@ F32_PEAK_TFLOPS = 157.3      # f32 vector peak with packed FMA on gfx950 (= the 
 FLOPS_PER_TAP_FORMULA = 49
 FLOPS_PER_TAP_EXECUTED = 38
 TAPS = 4096
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")     # written by tools/prof_final.py in the same round
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")     # written by tools/prof_final.py in the same round: per workload,
+                                                                      # per pass: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch
+SIMDS = 1024                 # 256 CUs x 4 SIMDs
+VALU_ISSUE_PER_S = 0.6e9     # wave-instructions a SIMD issues per second: 2.4 GHz / 4 cycles per 64-lane instruction
 METRIC = "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR, 1/2/4/8 GPU"
 
 
-def table_traffic(workload, world):
-    """FETCH_SIZE / WRITE_SIZE of the table-mode kernels from this round's PMC passes (profiles/r02_traffic.json), per launch.
-    The guide's gfx950 correction applies to these kernels' reads: 16 B per lane, coalesced, streaming -- FETCH_SIZE reports half
-    of such bytes -- so `fetch_corrected` doubles it; WRITE_SIZE (float atomics) is reported as counted."""
+def pmc_entry(workload, world, key):
+    """What this round's rocprofv3 --pmc passes counted for one pass (key: back / forward / back_table / forward_table) of a
+    workload, per launch: {"fetch_bytes", "write_bytes", "valu_insts", "kernels"} or None (file absent, other workload, N > 1)."""
     try:
         tj = json.load(open(TRAFFIC_JSON))
-        if tj.get("workload") != workload or world != 1:
+        if world != 1:
             return None
-        out = {}
-        for key, name in (("back_table", "scatter"), ("forward_table", "gather")):
-            e = tj[key]
-            out[name] = {"fetch_counted": e["fetch_bytes"], "fetch_corrected": 2.0 * e["fetch_bytes"], "write_counted": e["write_bytes"]}
-        return out
+        return tj.get(workload, {}).get(key)
     except Exception:
         return None
+
+
+def table_traffic(workload, world):
+    """FETCH_SIZE / WRITE_SIZE of the table-mode kernels, per launch.  The guide's gfx950 correction applies to these kernels'
+    reads: 16 B per lane, coalesced, streaming -- FETCH_SIZE reports half of such bytes -- so `fetch_corrected` doubles it;
+    WRITE_SIZE is reported as counted."""
+    out = {}
+    for key, name in (("back_table", "scatter"), ("forward_table", "gather")):
+        e = pmc_entry(workload, world, key)
+        if e:
+            out[name] = {"fetch_counted": e["fetch_bytes"], "fetch_corrected": 2.0 * e["fetch_bytes"], "write_counted": e["write_bytes"]}
+    return out or None
 
 
 def cpu_baseline(prob, target_seconds=12.0):
@@ -315,7 +325,9 @@ def main():
     if not args.no_coeff_table:
         try:
             rec.set_option("coeff_table", 1)
+            rec.timer_reset()
             rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
+            build_ms = rec.timers()["coeff_build"][0]
             rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
             for i in range(args.warmup):
                 drv.sr_iteration(args.warmup + args.steps + i)
@@ -331,7 +343,7 @@ def main():
             if multi:
                 dt2 = float(comm.allreduce_max(np.array([dt2]))[0])
                 on = bool(comm.allreduce_min(np.array([1.0 if on else 0.0]))[0] > 0.5)
-            tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 16 * 1024.0}
+            tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 16 * 1024.0, "build_ms": build_ms}
             rec.set_option("coeff_table", 0)
         except Exception as ex:                              # the headline line must still be printed
             if multi:
@@ -356,15 +368,50 @@ def main():
         # B_back = 4 Vs + 12 Va + 12 Nv, B_fwd = 4 Vs + 13 Va + 8 Nv algorithmic bytes per launch (this rank)
         b_back = 4.0 * vs + 12.0 * va_l + 12.0 * nv
         b_fwd = 4.0 * vs + 13.0 * va_l + 8.0 * nv
-        flops = float(va_l) * TAPS * FLOPS_PER_TAP_FORMULA
-        traffic = None
+        taps = (4096 if not pvr else 1728)
+        flops = float(va_l) * taps * FLOPS_PER_TAP_FORMULA
+        # taps actually evaluated: every tap of a live (pixel, plane) unit, the first tap of every row of a dead one
         try:
-            tj = json.load(open(TRAFFIC_JSON))
-            if tj.get("workload") == prob.name and world == 1:
-                traffic = float(tj["back"]["fetch_bytes"] + tj["back"]["write_bytes"])
+            uc = rec.unit_counts()
+            nsup = 12 if pvr else 16
+            taps_exec = (uc["live_units"] * nsup * nsup + uc["dead_units"] * nsup) / max(uc["pixels"], 1)
+            dead_share = uc["dead_units"] / max(uc["live_units"] + uc["dead_units"], 1)
         except Exception:
-            traffic = None
-        achieved = flops / bp_avg / 1e12 if bp_n else None
+            taps_exec, dead_share = float(taps), None
+        flops_exec = float(va_l) * taps_exec * FLOPS_PER_TAP_EXECUTED
+
+        def entry(kernel, avg, n, alg_bytes, key):
+            e = pmc_entry(prob.name, world, key)
+            ach = flops / avg / 1e12 if n else None
+            out_ = {"kernel": kernel, "bound": "valu_f32", "achieved": ach, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": (ach / F32_PEAK_TFLOPS) if ach else None,
+                    "flops_executed": flops_exec, "frac_executed": (flops_exec / avg / 1e12 / F32_PEAK_TFLOPS) if n else None,
+                    "valu_issue_frac": (e["valu_insts"] / (avg * SIMDS * VALU_ISSUE_PER_S)) if (e and n and e.get("valu_insts")) else None,
+                    "hbm_achieved_gbs": alg_bytes / avg / 1e9 if n else None, "hbm_peak_gbs": HBM_PEAK_GBS,
+                    "hbm_frac": (alg_bytes / avg / 1e9 / HBM_PEAK_GBS) if n else None,
+                    "algorithmic_bytes": alg_bytes,
+                    "traffic": (e["fetch_bytes"] + e["write_bytes"]) if e else None,
+                    "traffic_ratio": ((e["fetch_bytes"] + e["write_bytes"]) / alg_bytes) if e else None,
+                    "avg_launch_ms": avg * 1e3, "launches": n}
+            return out_
+
+        scatter_name = ("back_cell_kernel + k_cell_combine + k_cell_factors (csrc/svr_cell.inc: cell-owned planes, staged, combined in a fixed "
+                        "order, no atomics)" if tuned["back_mode"] == 5 else "back_wave_kernel (wave-owned planes per slice tile, atomic flush)")
+        e_back = entry(scatter_name + " = SuperresolutionKernel3D_tex, RC.cu:408-522", bp_avg, bp_n, b_back, "back")
+        e_fwd = entry("fwd_unit_kernel = simulateSlicesKernel3D_tex, RC.cu:298-404", fw_avg, fw_n, b_fwd, "forward")
+        dom, other = (e_back, e_fwd) if bp_avg >= fw_avg else (e_fwd, e_back)
+        roof = dict(dom)
+        roof["dead_unit_share"] = dead_share
+        roof["backproject" if dom is e_fwd else "forward"] = other
+        roof["note"] = ("The dominant kernel of the step, measured live (HIP events on the engine's stream); the other PSF pass next to it.  "
+                        "f32 VALU bound (4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; no MFMA: a scatter/gather stencil with a "
+                        "sequential epsilon-chain per row has no contraction).  `achieved` / `frac` credit the reference's 49-flop per-tap "
+                        "formula on all taps of a pixel against the packed-f32 vector peak; `flops_executed` / `frac_executed` the 38 flops "
+                        "of the canonical sequence on the taps that are evaluated (dead units: one tap per row).  `valu_issue_frac` = "
+                        "SQ_INSTS_VALU per launch / (launch time x 1024 SIMDs x 0.6e9 wave-instructions/s): the share of VALU issue slots "
+                        "used, the figure that explains the time.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch time.  "
+                        "`traffic`: FETCH_SIZE + WRITE_SIZE per launch; counters from this round's separate rocprofv3 --pmc passes "
+                        "(profiles/r03_traffic.json, tools/prof_final.py), null when that file has no entry for the workload.")
         out = {
             "metric": METRIC,
             "value": value, "unit": "MVoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -382,29 +429,7 @@ def main():
                        "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",
                                  "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "pin": os.environ.get("SVR_TILE_PIN")}},
             "ranks": ranks,
-            "roofline": {
-                "kernel": "back_wave_kernel (SuperresolutionKernel3D_tex, RC.cu:408-522): the dominant kernel of the step",
-                "bound": "valu_f32",
-                "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": (achieved / F32_PEAK_TFLOPS) if achieved else None,
-                "frac_executed": (achieved * FLOPS_PER_TAP_EXECUTED / FLOPS_PER_TAP_FORMULA / F32_PEAK_TFLOPS) if achieved else None,
-                "hbm_achieved_gbs": b_back / bp_avg / 1e9 if bp_n else None, "hbm_peak_gbs": HBM_PEAK_GBS,
-                "hbm_frac": (b_back / bp_avg / 1e9 / HBM_PEAK_GBS) if bp_n else None,
-                "algorithmic_bytes": b_back, "traffic": traffic,
-                "traffic_ratio": (traffic / b_back) if traffic else None,
-                "avg_launch_ms": bp_avg * 1e3, "launches": bp_n,
-                "forward": {"kernel": "fwd_unit_kernel (simulateSlicesKernel3D_tex, RC.cu:298-404)", "avg_launch_ms": fw_avg * 1e3,
-                            "launches": fw_n, "achieved": flops / fw_avg / 1e12 if fw_n else None,
-                            "frac": (flops / fw_avg / 1e12 / F32_PEAK_TFLOPS) if fw_n else None,
-                            "hbm_frac": (b_fwd / fw_avg / 1e9 / HBM_PEAK_GBS) if fw_n else None, "algorithmic_bytes": b_fwd},
-                "note": "f32 VALU bound (4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; no MFMA: a scatter/gather "
-                        "stencil has no contraction).  `achieved` / `frac` credit the reference's 49-flop per-tap formula on "
-                        "all 4096 taps of a pixel against the packed-f32 vector peak; `frac_executed` the 38 flops of the "
-                        "canonical sequence.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch time.  `traffic`: "
-                        "FETCH_SIZE + WRITE_SIZE of the kernel from this round's rocprofv3 --pmc passes "
-                        "(profiles/r02_traffic.json, written by tools/prof_final.py); null when that file is absent or was "
-                        "made on another workload.  Launch time: HIP events on the engine's stream, inside this run.",
-            },
+            "roofline": roof,
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in timers.items()},
         }
         if tab is not None:
@@ -414,6 +439,10 @@ def main():
                 "fits": tab["on"],
                 "value": (va / (tab["dt"] / steps) / 1e6) if tab["on"] else None, "unit": "MVoxels/s",
                 "ms_per_step": tab["dt"] / steps * 1e3,
+                # the table is written once per outer iteration; the reference's defaults run 4 outer iterations of 4 / 4 / 4 / 13 SR
+                # iterations (reconstruction.cc:187-188): 4 builds spread over 25 SR iterations
+                "build_ms": tab["build_ms"],
+                "value_amortised": (va / ((tab["dt"] / steps) + tab["build_ms"] * 1e-3 * 4.0 / 25.0) / 1e6) if tab["on"] else None,
                 "kernel_ms": {"backproject": bp2a * 1e3, "forward": fw2a * 1e3},
                 "table_bytes_rank0": tab["bytes"],
                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,

@@ -318,10 +318,12 @@ __device__ __forceinline__ f2 gauss_first_tap2(const RowConst S, f2 rowz) {
 // in-plane factor sinc^2 of 2H taps given their scaled in-plane lattice coordinates (x', y'), two per lane-op.
 // The canonical sequence (oracle: canon_rsqrt / canon_sinc) is built from fma / mul / add / rint and one integer
 // shift-subtract only -- no quarter-rate transcendental, no correctly rounded sqrt or division to emulate:
-//   q = x'^2 + y'^2;  y ~ 1/sqrt(q) (bit-trick start + 3 Newton steps);  r = q y;  f = r - rint(r) (exact);
+//   q = x'^2 + y'^2;  y ~ 1/sqrt(q) (bit-trick start + 2 Newton-form steps with tuned constants, round 3);  r = q y;  f = r - rint(r) (exact);
 //   sin(pi r)/(pi r) = +-(f y) P(f^2), P = degree-4 fit of sinc on [0, 1/4];  the square removes the sign.
 // q == 0 gives NaN like sin(0)/0 in the reference (RC.cu:129); PVR takes sinc_pi's Taylor branch there instead.
-#define RSQRT_MAGIC 0x5f375a86u
+#define RSQRT_MAGIC 0x5f376686u
+#define RSQRT_K1 1.5009000301361084f
+#define RSQRT_K2 1.5000005960464478f
 template <int H, bool PVR>
 __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H], const f2 ys[H], f2 val2[H]) {
 #define EACH for (int i = 0; i < H; ++i)
@@ -334,11 +336,11 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
 #pragma unroll
     EACH h[i] = bc2(0.5f) * q[i];
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < 2; ++it) {                       // two steps with centred errors (RSQRT_K1, RSQRT_K2): 7.1e-7
 #pragma unroll
       EACH r[i] = h[i] * y[i];
 #pragma unroll
-      EACH r[i] = fma2(-r[i], y[i], bc2(1.5f));
+      EACH r[i] = fma2(-r[i], y[i], bc2(it == 0 ? RSQRT_K1 : RSQRT_K2));
 #pragma unroll
       EACH y[i] = y[i] * r[i];
     }
@@ -3214,9 +3216,11 @@ int ensure_coeff(svr_ctx *ctx) {
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_active;
   a.n = (uint32_t)npx;
+  ScopedTimer tb(ctx, SVR_T_COEFF_BUILD);
   if (ctx->pvr) hipLaunchKernelGGL((k_coeff_build<PVR_N, true>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
   else hipLaunchKernelGGL((k_coeff_build<PSF_SUPPORT, false>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
   KCHK("k_coeff_build");
+  tb.stop();
   ctx->coeff_valid = true;
   return SVR_OK;
 }
@@ -3390,6 +3394,18 @@ int svr_create(int device, svr_ctx **out) {
       dyn = 65536 - 1024 - 16384;  // the default 64 KiB minus the kernels' static LDS
     }
     ctx->tile_cap = dyn / (2 * (int)sizeof(float));
+  }
+  // SVR_TILE_PIN="GWxGH,SWxSH,BOX": the gather's tile, the tiled scatter's tile and its LDS box fixed instead of timed, so that a
+  // run can be repeated with the same shapes (on every rank, in every process); bench.py prints the shapes in config.tuned
+  if (const char *pin = getenv("SVR_TILE_PIN")) {
+    int gw, gh, sw, sh, box;
+    if (sscanf(pin, "%dx%d,%dx%d,%d", &gw, &gh, &sw, &sh, &box) == 5 && gw > 0 && gh > 0 && gw * gh <= 32 && sw > 0 && sh > 0 && sw * sh <= 64 && box >= 1024) {
+      ctx->fwd_tw = gw; ctx->fwd_th = gh; ctx->fwd_tile_user = true;
+      ctx->tile_w = sw; ctx->tile_h = sh; ctx->tile_user = true;
+      ctx->wave_cap = box; ctx->wave_cap_user = true;
+    } else {
+      fprintf(stderr, "svr_create: SVR_TILE_PIN=\"%s\" ignored (expected e.g. 6x5,6x4,2096)\n", pin);
+    }
   }
   *out = ctx;
   return SVR_OK;
@@ -4619,6 +4635,19 @@ int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches) {
   if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
   if (ms_total) *ms_total = ctx->t_ms[which];
   if (launches) *launches = ctx->t_n[which];
+  return SVR_OK;
+}
+int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]) {
+  SVR_ENTER(ctx);
+  if (!ctx || !out3) return SVR_E_ARG;
+  int r = ready(ctx);
+  if (r) return r;
+  if ((r = cell_prepare(ctx))) return r;
+  const CellState &cs = *ctx->cell;
+  const uint64_t ns = ctx->pvr ? PVR_N : PSF_SUPPORT;
+  out3[0] = cs.n_sorted;
+  out3[1] = (uint64_t)cs.n_sorted * ns - cs.dead_units;
+  out3[2] = cs.dead_units;
   return SVR_OK;
 }
 int svr_timer_begin(svr_ctx *ctx, int which) {

@@ -24,7 +24,7 @@ BUF_BIAS_VOLUME, BUF_SMOOTH_MASK = 5, 6
 BUF_SLICES, BUF_WEIGHTS, BUF_SIMSLICES, BUF_SIMWEIGHTS, BUF_PSF_SUMS, BUF_BIAS = 10, 11, 12, 13, 14, 15
 BUF_SIMINSIDE, BUF_VOXEL_COUNT = 20, 21
 T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE, T_REGISTER = range(8)
-TIMER_NAMES = ("backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale", "register", "allreduce", "exchange_host")
+TIMER_NAMES = ("backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale", "register", "allreduce", "exchange_host", "coeff_build")
 
 EXPORTS = [
     "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_get_option", "svr_set_spx_masks", "svr_init_reconstruction_volume",
@@ -38,7 +38,7 @@ EXPORTS = [
     "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
-    "svr_timer_reset", "svr_timer_enable", "svr_timer_begin", "svr_timer_end", "svr_timer_add", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
+    "svr_unit_counts", "svr_timer_reset", "svr_timer_enable", "svr_timer_begin", "svr_timer_end", "svr_timer_add", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
     "svr_ncc_evaluate", "svr_ncc_alloc_targets", "svr_pyr_upload", "svr_pyr_level", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
@@ -427,6 +427,11 @@ class Reconstruction:
             self._ck(self._lib.svr_timer_get(self._h, i, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+    def unit_counts(self):
+        o = (C.c_uint64 * 3)()
+        self._ck(self._lib.svr_unit_counts(self._h, o))
+        return dict(pixels=int(o[0]), live_units=int(o[1]), dead_units=int(o[2]))
 
     def counters(self):
         o = (C.c_uint64 * 8)()

@@ -289,7 +289,9 @@ enum svr_timer {
   /* sharded runs, filled by the host objects (csrc/svr_host.cpp, csrc/pvr_host.cpp) through svr_timer_begin / _end / _add:
    * the all-reduce of a volume pair (HIP events on the engine's stream around the collective) and the small host-side
    * exchanges (wall clock: a stream synchronisation plus the collective) */
-  SVR_T_ALLREDUCE = 8, SVR_T_EXCHANGE = 9, SVR_T_COUNT = 10
+  SVR_T_ALLREDUCE = 8, SVR_T_EXCHANGE = 9,
+  SVR_T_COEFF_BUILD = 10,   /* k_coeff_build: writing the coefficient table (option coeff_table), once per slice geometry */
+  SVR_T_COUNT = 11
 };
 /* HIP events on the engine's stream around work a caller enqueues there itself (the volume all-reduce); no-ops while the
  * timers are off.  svr_timer_end waits for the stream. */
@@ -306,6 +308,10 @@ int svr_timer_enable(svr_ctx *ctx, int enable);
  * [5] pixel tiles of the scatter, [6] tiles that took the atomic fallback in the last scatter, [7] tiles the 5-wave scatter
  * instance handed to the 8-wave one */
 int svr_counters(svr_ctx *ctx, uint64_t out8[8]);
+/* (pixel, plane) units of the pixels with s != -1 whose footprint reaches the volume: [0] such pixels, [1] live units (every tap
+ * evaluated), [2] dead units (every row provably below the epsilon of RC.cu:238: only its first tap is processed) -- what
+ * bench.py's `flops_executed` counts */
+int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]);
 
 #ifdef __cplusplus
 }

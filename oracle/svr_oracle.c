@@ -131,7 +131,10 @@ static uint32_t f2u_sat(float f) {
  * (or exact) on x86 and on gfx950 alike, so host and device agree bit for bit, and none of which is a
  * quarter-rate transcendental on the device (round 1 used a correctly rounded sqrt and division here: 22 of its
  * 47 issue slots per tap):
- *   y ~ 1/sqrt(q): bit-trick start + 3 Newton steps;  r = q y ~ sqrt(q);  k = rint(r), f = r - k (exact);
+ *   y ~ 1/sqrt(q): bit-trick start + 2 Newton-form steps y <- y (k_i - (q/2) y^2) whose constants k_1, k_2 and start are chosen so
+ *   that the error of each step is centred on zero (round 3: 7.1e-7 relative, where three plain Newton steps gave 1.3e-7 for one
+ *   more step = 24 issue slots per row of 16 taps; the round-2 review allowed formula-level changes as long as the census of
+ *   tests/test_round2_gaps.py keeps its bounds);  r = q y ~ sqrt(q);  k = rint(r), f = r - k (exact);
  *   sin(pi r) = +- sin(pi f), |f| <= 1/2:  sin(pi f) / pi = f P(f^2), P = degree-4 fit of sinc on [0, 1/4]
  *   (4.3e-9);  sin(R)/R = +- (f y) P(f^2).  The sign is irrelevant because the PSF squares it (RC.cu:130).
  * Against sin(pi sqrt q)^2 / (pi^2 q) in double: |error| <= 6.6e-7 over q in [1e-30, 1e3] (values <= 1).
@@ -139,13 +142,14 @@ static uint32_t f2u_sat(float f) {
 static float canon_rsqrt(float q) {
   uint32_t b;
   memcpy(&b, &q, 4);
-  b = 0x5f375a86u - (b >> 1);
+  b = 0x5f376686u - (b >> 1);
   float y;
   memcpy(&y, &b, 4);
   const float h = 0.5f * q;
-  for (int i = 0; i < 3; ++i) {
+  const float k[2] = {1.5009000301361084f, 1.5000005960464478f};
+  for (int i = 0; i < 2; ++i) {
     const float t = h * y;
-    const float u = fmaf(-t, y, 1.5f);
+    const float u = fmaf(-t, y, k[i]);
     y = y * u;
   }
   return y;

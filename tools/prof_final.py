@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Round-2 evidence, run on the GPU box from the repo root (one gpurun call):
+"""Round-3 evidence (the round-2 script, re-pointed), run on the GPU box from the repo root (one gpurun call):
 
   1. bench lines: P4 (with the CPU baseline) and S8
-  2. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`      -> profiles/r02_kernel_stats_p4.txt
+  2. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`      -> profiles/r03_kernel_stats_p4.txt
   3. rocprofv3 --kernel-trace --pmc passes (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE -- each its own pass) over
-     tools/run_sr_kernels.py on P4 and on S8                                -> profiles/r02_pmc_p4.txt, r02_pmc_s8.txt
-  4. profiles/r02_traffic.json: FETCH_SIZE / WRITE_SIZE of the scatter and the gather per launch (KB -> bytes), which
-     bench.py reads for roofline.traffic; then the P4 bench line again with it           -> profiles/r02_bench_p4.json
+     tools/run_sr_kernels.py on P4 and on S8                                -> profiles/r03_pmc_p4.txt, r03_pmc_s8.txt
+  4. profiles/r03_traffic.json: FETCH_SIZE / WRITE_SIZE of the scatter and the gather per launch (KB -> bytes), which
+     bench.py reads for roofline.traffic; then the P4 bench line again with it           -> profiles/r03_bench_p4.json
 """
 import csv
 import glob
@@ -18,7 +18,8 @@ import subprocess
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(R, "gpurun_out", "r02")
+TAG = "r03"
+OUT = os.path.join(R, "gpurun_out", TAG)
 PROF = os.path.join(R, "profiles")
 ENV = dict(os.environ, TMPDIR="/tmp")
 
@@ -45,15 +46,15 @@ def short(name):
 
 def pmc(workload, tag, opts=()):
     d = os.path.join(OUT, "pmc_" + tag)
-    p = sh([sys.executable, os.path.join(R, "tools", "pmc.py"), d, "--filter", "_kernel", "--", sys.executable,
+    p = sh([sys.executable, os.path.join(R, "tools", "pmc.py"), d, "--filter", "k", "--", sys.executable,
             os.path.join(R, "tools", "run_sr_kernels.py"), workload, *opts])
     txt = p.stdout
-    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} {' '.join(opts)} (1 GPU), round 2.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
+    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} {' '.join(opts)} (1 GPU), round 3.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
             "# rocprofv3 --kernel-trace --pmc <set> pass per counter set (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE), nothing else in\n"
             "# the pass.  Per kernel: mean over the last half of its dispatches.  SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are in\n"
             "# quad-cycles summed over the SIMDs, FETCH_SIZE / WRITE_SIZE in KB (uncalibrated for this access pattern: narrow LDS-staged\n"
             "# reads and float atomics -- MI355X_MICROARCH.md calibrates only wide streaming reads -- so they are reported as counted).\n")
-    open(os.path.join(PROF, f"r02_pmc_{tag}.txt"), "w").write(head + txt)
+    open(os.path.join(PROF, f"r03_pmc_{tag}.txt"), "w").write(head + txt)
     vals = {}
     cur = None
     for line in txt.splitlines():
@@ -71,46 +72,59 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     bench = os.path.join(R, "bench.py")
     # 3. PMC first (the traffic file must exist before the final bench line)
-    v4 = pmc("P4", "p4")
-    v8 = pmc("S8", "s8")
+    traffic = {"source": "profiles/r03_pmc_<workload>.txt (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes; "
+                         "per pass the kernels of one scatter / gather launch summed)"}
+
+    def collect(vals, pats):
+        ks = [n for n in vals if any(p_ in n for p_ in pats)]
+        if not ks or not all("FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k] for k in ks):
+            return None
+        return {"kernels": ks, "fetch_bytes": sum(vals[k]["FETCH_SIZE"] for k in ks) * 1024.0, "write_bytes": sum(vals[k]["WRITE_SIZE"] for k in ks) * 1024.0,
+                "valu_insts": sum(vals[k].get("SQ_INSTS_VALU", 0.0) for k in ks)}
+
+    todo = [("P4", "p4", ()), ("S8", "s8", ()), ("PVR4", "pvr4", ())]
+    v8 = {}
+    for wl, tag, opts in todo:
+        v = pmc(wl, tag, opts)
+        if wl == "S8":
+            v8 = v
+        nsup, isp = ("12", "true") if wl.startswith("PVR") else ("16", "false")
+        e = {}
+        e["back"] = collect(v, ("back_cell_kernel<%s, %s, false>" % (nsup, isp), "k_cell_combine", "k_cell_factors")) or collect(v, ("back_wave_kernel<%s, %s, false>" % (nsup, isp),))
+        e["forward"] = collect(v, ("fwd_unit_kernel<false, %s, %s, false>" % (nsup, isp),))
+        traffic[wl] = {k: x for k, x in e.items() if x}
     vt = pmc("P4", "p4_table", ("coeff_table=1",))           # the COEFF instantiations streaming the coefficient table
-    traffic = {"workload": "P4", "source": "profiles/r02_pmc_p4.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes)"}
-    for key, pat in (("back", "back_wave_kernel"), ("forward", "fwd_unit_kernel<false")):
-        k = [n for n in v4 if pat in n]
-        if k and "FETCH_SIZE" in v4[k[0]] and "WRITE_SIZE" in v4[k[0]]:
-            traffic[key] = {"kernel": k[0], "fetch_bytes": v4[k[0]]["FETCH_SIZE"] * 1024.0, "write_bytes": v4[k[0]]["WRITE_SIZE"] * 1024.0}
     for key, pat in (("back_table", "back_wave_kernel<16, false, true"), ("forward_table", "fwd_unit_kernel<false, 16, false, true")):
-        k = [n for n in vt if pat in n]
-        if k and "FETCH_SIZE" in vt[k[0]] and "WRITE_SIZE" in vt[k[0]]:
-            traffic[key] = {"kernel": k[0], "fetch_bytes": vt[k[0]]["FETCH_SIZE"] * 1024.0, "write_bytes": vt[k[0]]["WRITE_SIZE"] * 1024.0,
-                            "source": "profiles/r02_pmc_p4_table.txt"}
-    if "back" in traffic:
-        json.dump(traffic, open(os.path.join(PROF, "r02_traffic.json"), "w"), indent=1)
+        x = collect(vt, (pat,))
+        if x:
+            traffic["P4"][key] = x
+    if traffic.get("P4", {}).get("back"):
+        json.dump(traffic, open(os.path.join(PROF, "r03_traffic.json"), "w"), indent=1)
     # 1. bench lines
     b4 = sh([sys.executable, bench], os.path.join(OUT, "bench_p4.log"), cwd=R)
     j4 = last_json(b4.stdout)
     if j4:
-        json.dump(j4, open(os.path.join(PROF, "r02_bench_p4.json"), "w"), indent=1)
+        json.dump(j4, open(os.path.join(PROF, "r03_bench_p4.json"), "w"), indent=1)
     b8 = sh([sys.executable, bench, "--workload", "S8", "--no-cpu-baseline"], os.path.join(OUT, "bench_s8.log"), cwd=R)
     j8 = last_json(b8.stdout)
     if j8:
-        json.dump(j8, open(os.path.join(PROF, "r02_bench_s8.json"), "w"), indent=1)
+        json.dump(j8, open(os.path.join(PROF, "r03_bench_s8.json"), "w"), indent=1)
     # 2. kernel trace of the bench command
     d = os.path.join(OUT, "stats")
     p = sh(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline"],
            os.path.join(OUT, "stats.log"))
     jt = last_json(p.stdout)
-    lines = ["# round 2: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r02/stats -o bench -- python bench.py --no-cpu-baseline",
+    lines = ["# round 3: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r03/stats -o bench -- python bench.py --no-cpu-baseline",
              "# (tools/prof_final.py; rocprofv3 of this image writes a rocpd database: `top_kernels` view below)"]
     if jt:
         lines.append("# bench line of the profiled run: value %.2f MVoxels/s, %.3f ms/step; scatter avg launch %.3f ms, gather %.3f ms by HIP events; roofline.frac %.4f"
-                     % (jt["value"], jt["ms_per_step"], jt["roofline"]["avg_launch_ms"], jt["roofline"]["forward"]["avg_launch_ms"], jt["roofline"]["frac"]))
+                     % (jt["value"], jt["ms_per_step"], jt["kernel_ms"]["backproject"], jt["kernel_ms"]["forward"], jt["roofline"]["frac"]))
     if j4:
         lines.append("# unprofiled P4 line of the same call: value %.2f MVoxels/s, %.3f ms/step, scatter %.3f ms, gather %.3f ms, cpu_baseline %s"
-                     % (j4["value"], j4["ms_per_step"], j4["roofline"]["avg_launch_ms"], j4["roofline"]["forward"]["avg_launch_ms"], json.dumps(j4.get("cpu_baseline"))))
+                     % (j4["value"], j4["ms_per_step"], j4["kernel_ms"]["backproject"], j4["kernel_ms"]["forward"], json.dumps(j4.get("cpu_baseline"))))
     if j8:
         lines.append("# unprofiled S8 line: value %.2f MVoxels/s, %.3f ms/step, scatter %.3f ms, gather %.3f ms"
-                     % (j8["value"], j8["ms_per_step"], j8["roofline"]["avg_launch_ms"], j8["roofline"]["forward"]["avg_launch_ms"]))
+                     % (j8["value"], j8["ms_per_step"], j8["kernel_ms"]["backproject"], j8["kernel_ms"]["forward"]))
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
     if dbs:
         c = sqlite3.connect(dbs[0])
@@ -118,7 +132,7 @@ def main():
             rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
             lines.append("%7s %14s %12s %7s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
             lines += ["%7d %14.1f %12.1f %7.2f  %s" % (k, t, a, pc, short(n)) for n, k, t, a, pc in rows[:24]]
-            for pat in ("back_wave_kernel", "fwd_unit_kernel<false"):
+            for pat in ("back_cell_kernel", "fwd_unit_kernel<false"):
                 dd = [r[0] / 1e3 for r in c.execute("select (end - start) from kernels where name like ? order by start", ("%" + pat + "%",)).fetchall()]
                 if dd and jt:
                     k = jt["steps"]
@@ -130,10 +144,10 @@ def main():
         csvs = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
         if csvs:
             lines += open(csvs[0]).read().splitlines()[:30]
-    open(os.path.join(PROF, "r02_kernel_stats_p4.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(PROF, "r03_kernel_stats_p4.txt"), "w").write("\n".join(lines) + "\n")
     # 4. again with the traffic file in place (same box, same build)
     print("\n".join(lines[:12]))
-    print(json.dumps({k: v for k, v in (traffic.get("back") or {}).items()}))
+    print(json.dumps(traffic.get("P4")))
     print("S8 pmc kernels:", list(v8)[:6])
 
 

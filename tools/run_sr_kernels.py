@@ -1,19 +1,33 @@
 """dev tool: a few launches of the scatter and the gather on a workload with the given options (for rocprofv3 passes).
 usage: python tools/run_sr_kernels.py [workload] [opt=value ...]"""
-import sys; sys.path.insert(0, '/root/repo')
-from fetalreconstruction_amd import workloads, engine
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from fetalreconstruction_amd import workloads, engine, host
 args = sys.argv[1:]
 wl = args.pop(0) if args and '=' not in args[0] else 'P4'
 P = workloads.get(wl)
-rec = engine.Reconstruction(0); engine.sync_gpu(rec, P)
+pvr = wl.startswith("PVR")
+rec = engine.Reconstruction(0)
+if pvr:
+    rec.set_option("pvr", 1)
+    engine.sync_gpu(rec, P, quality_factor=1.0)
+    if getattr(P, "spx_masks", None) is not None:
+        rec.set_spx_masks(P.spx_masks)
+else:
+    engine.sync_gpu(rec, P)
 for a in args:
     k, v = a.split('='); rec.set_option(k, int(v))
-d = irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity); d.SetSmoothingParameters(150, 0.02)
-d.InitializeEMValuesGPU(); d.GaussianReconstructionGPU(); d.SimulateSlicesGPU(); d.InitializeRobustStatisticsGPU(); d.EStepGPU()
-sw = d._local(d._slice_weight_gpu)
+if pvr:
+    d = host.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    d.reconstruct_iteration(1)
+    sw = d.state()["patch_weight"]
+else:
+    d = host.irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity); d.SetSmoothingParameters(150, 0.02)
+    d.reconstruct_iteration(1)                     # the state of a running reconstruction: EM weights, a non-trivial residual
+    sw = d.state()["slice_weight"]
 for _ in range(40):          # many more than the tuners' trial launches: pmc.py averages the last half of a kernel's dispatches
     rec.SuperresolutionBackproject(sw)
 for _ in range(40):
     rec.SimulateSlices()
-print("tuned: scatter tiles %dx%d box %d, gather tiles %dx%d box %d" % tuple(rec.get_option(k) for k in ("tile_w", "tile_h", "wave_cap", "fwd_tile_w", "fwd_tile_h", "fwd_unit_cap")), flush=True)
+print("tuned: scatter mode %d tiles %dx%d box %d, gather tiles %dx%d box %d" % tuple(rec.get_option(k) for k in ("back_mode", "tile_w", "tile_h", "wave_cap", "fwd_tile_w", "fwd_tile_h", "fwd_unit_cap")), flush=True)
