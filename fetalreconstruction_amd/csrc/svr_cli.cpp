@@ -29,7 +29,8 @@
 
 int main(int argc, char **argv) {
   std::string output, mask_name, tfolder, sfolder;
-  bool debug = false;
+  bool debug = false, dry_run = false;
+  std::string dump_name;
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
   std::vector<int> force_excluded, devices, packages;
@@ -79,6 +80,8 @@ int main(int argc, char **argv) {
     else if (o == "--sfolder") sfolder = one();
     else if (o == "--coeffTable") coeff_table = true;                     // not a reference option: keep the PSF taps in HBM (CoeffInit on the GPU path)
     else if (o == "--debug") debug = opt_bool(true);
+    else if (o == "--dumpProblem") dump_name = one();                     // test hooks: what the engine is about to receive [--dryRun: stop there]
+    else if (o == "--dryRun") dry_run = true;
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
     else if (o == "-d" || o == "--devices") { std::vector<std::string> v; multi(v); for (auto &s : v) devices.push_back(atoi(s.c_str())); }
     else if (o == "-h" || o == "--help") {
@@ -110,7 +113,7 @@ int main(int argc, char **argv) {
   StageClock clk;
   // the HIP runtime and the context come up (75 ms) while the stacks are read and cropped; first use: the stack registrations
   svr_ctx *ctx = nullptr;
-  std::future<int> ctx_ready = std::async(std::launch::async, [&] { return svr_create(devices.empty() ? 0 : devices[0], &ctx); });
+  std::future<int> ctx_ready = std::async(std::launch::async, [&] { return dry_run ? 1 : svr_create(devices.empty() ? 0 : devices[0], &ctx); });
   before_exit = [&] { if (ctx_ready.valid()) ctx_ready.wait(); };     // an error while reading must not exit under the runtime's feet
   auto need_ctx = [&] {
     if (ctx_ready.valid() && (ctx_ready.get() || !ctx)) die("no usable HIP device (svr_create failed)");
@@ -222,6 +225,25 @@ int main(int argc, char **argv) {
       dims[3 * (size_t)sl] = (float)r.a.dx; dims[3 * (size_t)sl + 1] = (float)r.a.dy; dims[3 * (size_t)sl + 2] = (float)r.a.dz;
       sizes_x[sl] = r.a.nx; sizes_y[sl] = r.a.ny; stack_index[sl] = srcs[sl].stack; sattr[sl] = r.a;
   }
+  if (!dump_name.empty()) {
+    // what the engine is about to receive, for the CPU tests (tests/test_prep_oracle.py compares it with the oracle's restatement
+    // of CreateTemplate / SetMask / TransformMask / CropImage / MatchStackIntensities / MaskSlices): header, the template's
+    // attributes, the volume mask, the cropped stacks' attributes, the slice grid, the slices' transformations, the factors
+    FILE *f = fopen(dump_name.c_str(), "wb");
+    if (!f) die("cannot write " + dump_name);
+    const int hdr[8] = {ns, mx, my, (int)n, tattr.nx, tattr.ny, tattr.nz, 2};
+    fwrite(hdr, sizeof(int), 8, f);
+    fwrite(&tattr, sizeof(svr_image_attr), 1, f);
+    fwrite(vol_mask.d.data(), sizeof(double), vol_mask.d.size(), f);
+    for (size_t k = 0; k < n; ++k) fwrite(&stacks[k].a, sizeof(svr_image_attr), 1, f);
+    fwrite(grid.data(), sizeof(float), grid.size(), f);
+    fwrite(T.data(), sizeof(double), T.size(), f);
+    fwrite(factors.data(), sizeof(float), factors.size(), f);
+    fwrite(sizes_x.data(), sizeof(int), sizes_x.size(), f);
+    fwrite(sizes_y.data(), sizeof(int), sizes_y.size(), f);
+    fclose(f);
+  }
+  if (dry_run) { fflush(nullptr); _exit(0); }             // (no context was made; skip the teardown of a runtime that never came up)
   if (!(vmax > 0)) die("no slice pixel lies inside the mask");
   fprintf(stderr, "%zu stacks, %d slices of up to %dx%d, volume %dx%dx%d at %g mm, stack factors", n, ns, mx, my, tattr.nx, tattr.ny, tattr.nz,
           resolution);

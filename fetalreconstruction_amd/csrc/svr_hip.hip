@@ -643,10 +643,11 @@ __device__ __forceinline__ bool pixel_active(const float *slices, const float *p
 
 __global__ void k_build_tiles(const float *slices, const float *psf_sums, const unsigned char *flag, int sx, int sy,
                               int ns, int tiles_x, int tiles_y, int TILE_W, int TILE_H, uint32_t *tiles,
-                              uint32_t *counter, const unsigned char *slice_sel = nullptr, int want = 0) {
+                              uint32_t *counter, const unsigned char *slice_sel = nullptr, int want = 0, uint32_t t0 = 0u,
+                              uint32_t t_end = 0xFFFFFFFFu) {
   const int lane = threadIdx.x & 63;
-  const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const uint32_t total = (uint32_t)tiles_x * tiles_y * ns;
+  const uint32_t t = t0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (t0 .. t_end: this dispatch's piece of the candidates)
+  const uint32_t total = min((uint32_t)tiles_x * tiles_y * ns, t_end);
   const uint32_t tt = t < total ? t : 0u;                  // (every wavefront reaches the barriers below)
   const int sl = tt / (tiles_x * tiles_y);
   const bool skip = slice_sel && slice_sel[sl] != want;
@@ -935,13 +936,14 @@ __device__ __forceinline__ float4 load_stream(const float4 *p) {
 // out as NS/4 x 16 float4: [tap quad q][row y], so that the 16 lanes of a slot write and later read 256 contiguous bytes
 // per instruction (SVR: 16 units of 1 KiB per pixel; PVR, support 12: 12 units of 768 bytes).  Dead units (unit_is_dead) are not stored: the kernels evaluate their first taps themselves.
 template <int NS, bool PVR>
-__global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, uint32_t *coeff_id) {
+__global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, uint32_t *coeff_id, uint32_t base) {
   constexpr int NC = (NS - 1) / 2, QUADS = NS / 4;
   static_assert(NS % 4 == 0 && NS <= 16, "tap quads, one row per lane of a 16-lane slot");
-  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (w >= a.n) return;
+  const uint32_t wl = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (wl >= a.n) return;
   const int lane = threadIdx.x & 63;
-  const uint32_t idx = a.list[w];
+  const uint32_t idx = a.list[wl];
+  const uint32_t w = base + wl;                          // the pixel's id in the table (the list goes out in pieces)
   const uint32_t n2 = (uint32_t)(a.sx * a.sy);
   const uint32_t sl = idx / n2, rem = idx - sl * n2;
   const int py = (int)(rem / (uint32_t)a.sx), px = (int)(rem - (uint32_t)py * (uint32_t)a.sx);
@@ -3001,6 +3003,42 @@ int prepare_slice_consts(svr_ctx *ctx) {
   return SVR_OK;
 }
 
+// A dispatch holds at most 2^32 - 1 work-items per dimension (launch_fwd_unit below tells how that was found): every kernel
+// that takes one workgroup per entry of a tile list sends long lists out in pieces.  f(offset, count) launches one piece.
+template <class F>
+int in_pieces(uint32_t n, uint32_t threads_per_tile, F &&f) {
+  const long env = getenv("SVR_LIST_PIECE") ? atol(getenv("SVR_LIST_PIECE")) : 0;     // test hook: short pieces on a small problem
+  uint32_t piece = (uint32_t)((((1ull << 32) - 1) / threads_per_tile) & ~1023ull);
+  if (env > 0) piece = (uint32_t)std::min<long>(env, piece);
+  for (uint32_t off = 0; off < n; off += piece) {
+    const int r = f(off, std::min(piece, n - off));
+    if (r) return r;
+  }
+  return SVR_OK;
+}
+// one wavefront per entry of a pixel list (psf_kernel, pvr_kernel, k_coeff_build): launch(args of one piece, offset of the piece)
+template <class L>
+int pixel_list_in_pieces(const PsfArgs &a0, L &&launch) {
+  return in_pieces(a0.n, 64, [&](uint32_t off, uint32_t cnt) {
+    PsfArgs a = a0;
+    a.list = a0.list + off;
+    a.n = cnt;
+    return launch(a, off);
+  });
+}
+// tiles of tw x th pixels that hold at least one active pixel (k_build_tiles: a wavefront per candidate tile)
+int build_tile_list(svr_ctx *ctx, const float *psf_sums, const unsigned char *flag, int tiles_x, int tiles_y, int tw, int th, uint32_t *tiles,
+                    uint32_t *counter) {
+  const uint64_t total64 = (uint64_t)tiles_x * tiles_y * ctx->ns;
+  if (total64 >= (1ull << 32)) return fail(ctx, SVR_E_ARG, "more than 2^32 candidate tiles");
+  return in_pieces((uint32_t)total64, 64, [&](uint32_t off, uint32_t cnt) {
+    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(cnt, 16)), dim3(1024), 0, ctx->stream, ctx->d_slices, psf_sums, flag, (int)ctx->sx, (int)ctx->sy,
+                       (int)ctx->ns, tiles_x, tiles_y, tw, th, tiles, counter, (const unsigned char *)nullptr, 0, off, off + cnt);
+    KCHK("k_build_tiles");
+    return (int)SVR_OK;
+  });
+}
+
 int build_list(svr_ctx *ctx, bool with_psf) {
   HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
   uint32_t *list = with_psf ? ctx->d_psf_list : ctx->d_active;
@@ -3016,10 +3054,7 @@ int build_list(svr_ctx *ctx, bool with_psf) {
     // tiles of TILE_W x TILE_H pixels that hold at least one pixel of the list
     const uint32_t total = (uint32_t)ctx->tiles_x * ctx->tiles_y * ctx->ns;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total, 16)), dim3(1024), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
-                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h,
-                       ctx->d_tiles, ctx->d_counter);
-    KCHK("k_build_tiles");
+    { const int rr = build_tile_list(ctx, ctx->d_psf_sums, nullptr, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles, ctx->d_counter); if (rr) return rr; }
     HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->n_tiles = n;
@@ -3030,10 +3065,7 @@ int build_list(svr_ctx *ctx, bool with_psf) {
     const uint32_t total_f = (uint32_t)ctx->fwd_tiles_x * ctx->fwd_tiles_y * ctx->ns;
     HIPCHK(hipMalloc(&ctx->d_tiles_fwd, (size_t)total_f * sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk(total_f, 16)), dim3(1024), 0, ctx->stream, ctx->d_slices, ctx->d_psf_sums,
-                       (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ctx->fwd_tiles_x,
-                       ctx->fwd_tiles_y, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_fwd, ctx->d_counter);
-    KCHK("k_build_tiles(fwd)");
+    { const int rr = build_tile_list(ctx, ctx->d_psf_sums, nullptr, ctx->fwd_tiles_x, ctx->fwd_tiles_y, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_fwd, ctx->d_counter); if (rr) return rr; }
     HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->n_tiles_fwd = n;
@@ -3217,27 +3249,20 @@ int ensure_coeff(svr_ctx *ctx) {
   a.list = ctx->d_active;
   a.n = (uint32_t)npx;
   ScopedTimer tb(ctx, SVR_T_COEFF_BUILD);
-  if (ctx->pvr) hipLaunchKernelGGL((k_coeff_build<PVR_N, true>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
-  else hipLaunchKernelGGL((k_coeff_build<PSF_SUPPORT, false>), dim3(nblk(a.n, 4)), dim3(256), 0, ctx->stream, a, ctx->d_coeff, ctx->d_coeff_id);
-  KCHK("k_coeff_build");
+  {
+    const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t off) {
+      if (ctx->pvr) hipLaunchKernelGGL((k_coeff_build<PVR_N, true>), dim3(nblk(ap.n, 4)), dim3(256), 0, ctx->stream, ap, ctx->d_coeff, ctx->d_coeff_id, off);
+      else hipLaunchKernelGGL((k_coeff_build<PSF_SUPPORT, false>), dim3(nblk(ap.n, 4)), dim3(256), 0, ctx->stream, ap, ctx->d_coeff, ctx->d_coeff_id, off);
+      KCHK("k_coeff_build");
+      return (int)SVR_OK;
+    });
+    if (rr) return rr;
+  }
   tb.stop();
   ctx->coeff_valid = true;
   return SVR_OK;
 }
 
-// A dispatch holds at most 2^32 - 1 work-items per dimension (launch_fwd_unit above tells how that was found): every kernel
-// that takes one workgroup per entry of a tile list sends long lists out in pieces.  f(offset, count) launches one piece.
-template <class F>
-int in_pieces(uint32_t n, uint32_t threads_per_tile, F &&f) {
-  static const long env = getenv("SVR_LIST_PIECE") ? atol(getenv("SVR_LIST_PIECE")) : 0;     // test hook: short pieces on a small problem
-  uint32_t piece = (uint32_t)((((1ull << 32) - 1) / threads_per_tile) & ~1023ull);
-  if (env > 0) piece = (uint32_t)std::min<long>(env, piece);
-  for (uint32_t off = 0; off < n; off += piece) {
-    const int r = f(off, std::min(piece, n - off));
-    if (r) return r;
-  }
-  return SVR_OK;
-}
 int launch_slot(svr_ctx *ctx, bool pvr, const PsfArgs &a, const TileArgs &ta_, uint32_t *fb, uint32_t *cnt) {
   const size_t lds = (size_t)ta_.cap * 2 * sizeof(float);
   return in_pieces(ta_.ntiles, 8 * 64, [&](uint32_t off, uint32_t cntp) {
@@ -3263,14 +3288,20 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
   if (level >= 4) {
     ta.tiles = cur; ta.ntiles = ncur; ta.cap = std::min(ctx->wave_cap, ctx->tile_cap);
     const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
-    if (pvr && a.coeff) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
-                                          ctx->wave_groups, ctx->d_tiles_fb, cnt);
-    else if (pvr) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
-                                     ctx->wave_groups, ctx->d_tiles_fb, cnt);
-    else if (a.coeff) hipLaunchKernelGGL((back_wave_kernel<PSF_SUPPORT, false, true>), dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
-                                         ctx->wave_groups, ctx->d_tiles_fb, cnt);
-    else hipLaunchKernelGGL(back_wave_kernel<>, dim3(ncur * (uint32_t)ctx->wave_groups), dim3(64), lds, ctx->stream, a, ta,
-                            ctx->wave_groups, ctx->d_tiles_fb, cnt);
+    {
+      const TileArgs ta1 = ta;
+      r = in_pieces(ncur, 64u * (uint32_t)ctx->wave_groups, [&](uint32_t off, uint32_t cntp) {
+        TileArgs tp = ta1;
+        tp.tiles = ta1.tiles + off; tp.ntiles = cntp;
+        const dim3 grid(cntp * (uint32_t)ctx->wave_groups);
+        if (pvr && a.coeff) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true, true>), grid, dim3(64), lds, ctx->stream, a, tp, ctx->wave_groups, ctx->d_tiles_fb, cnt);
+        else if (pvr) hipLaunchKernelGGL((back_wave_kernel<PVR_N, true>), grid, dim3(64), lds, ctx->stream, a, tp, ctx->wave_groups, ctx->d_tiles_fb, cnt);
+        else if (a.coeff) hipLaunchKernelGGL((back_wave_kernel<PSF_SUPPORT, false, true>), grid, dim3(64), lds, ctx->stream, a, tp, ctx->wave_groups, ctx->d_tiles_fb, cnt);
+        else hipLaunchKernelGGL(back_wave_kernel<>, grid, dim3(64), lds, ctx->stream, a, tp, ctx->wave_groups, ctx->d_tiles_fb, cnt);
+        return (int)SVR_OK;
+      });
+      if (r) return r;
+    }
     KCHK("back_wave_kernel");
     HIPCHK(hipMemcpyAsync(nfb, cnt, sizeof(nfb), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -3604,8 +3635,9 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   (void)dim;
   HIPCHK(hipSetDevice(ctx->device));
   size_t np = (size_t)size[0] * size[1] * size[2];
-  // a wavefront per pixel / per tile and 2^32 - 1 work-items per dispatch: 2^26 pixels per context (S8: 2^25; more slices go to more ranks)
-  if (np == 0 || np >= (1ull << 26)) return fail(ctx, SVR_E_ARG, "slice grid out of range: 1 .. 2^26 - 1 pixels per context (shard the slices over more ranks)");
+  // slice-grid indices are 32-bit; every launch that takes a wavefront per pixel or per tile goes out in pieces of < 2^32
+  // work-items (in_pieces), like the reference's MAX_SLICES_PER_RUN chunks (RC.cu:2207-2219, 2414-2432, 2701-2716)
+  if (np == 0 || np >= (1ull << 31)) return fail(ctx, SVR_E_ARG, "slice grid out of range: 1 .. 2^31 - 1 pixels per context (shard the slices over more ranks)");
   free_slices(ctx);
   free_dev(ctx->d_bias); free_dev(ctx->d_wb); free_dev(ctx->d_wr); free_dev(ctx->d_buffer);
   ctx->sx = size[0]; ctx->sy = size[1]; ctx->ns = size[2];
@@ -3824,10 +3856,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
     a.flag = nullptr; a.flag_out = ctx->d_gauss_flag;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ftx * fty * ctx->ns, 16)), dim3(1024), 0, ctx->stream, ctx->d_slices,
-                       (const float *)nullptr, (const unsigned char *)nullptr, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns, ftx,
-                       fty, gtw, gth, ctx->d_tiles_tmp, ctx->d_counter);
-    KCHK("k_build_tiles(gauss1)");
+    if ((r = build_tile_list(ctx, nullptr, nullptr, ftx, fty, gtw, gth, ctx->d_tiles_tmp, ctx->d_counter))) return r;
     HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ta.tiles = ctx->d_tiles_tmp; ta.ntiles = n1;
@@ -3837,10 +3866,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       KCHK("fwd_unit_kernel<GAUSS1>");
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_build_tiles, dim3(nblk((size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns, 16)), dim3(1024), 0, ctx->stream,
-                       ctx->d_slices, (const float *)nullptr, ctx->d_gauss_flag, (int)ctx->sx, (int)ctx->sy, (int)ctx->ns,
-                       ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter);
-    KCHK("k_build_tiles(gauss2)");
+    if ((r = build_tile_list(ctx, nullptr, ctx->d_gauss_flag, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter))) return r;
     HIPCHK(hipMemcpyAsync(&n2, ctx->d_counter, sizeof(n2), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     a.flag = ctx->d_gauss_flag;
@@ -3855,13 +3881,17 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     else r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, std::max(1, back_mode_eff(ctx))), a, ta, ctx->d_tiles_tmp, n2, MODE_GAUSS2);
     if (r) return r;
   } else if (a.n && ctx->pvr) {
-    hipLaunchKernelGGL(pvr_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                       ctx->stream, a);
-    KCHK("pvr_kernel<GAUSS>");
+    { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
+        hipLaunchKernelGGL(pvr_kernel<MODE_GAUSS>, dim3(nblk(ap.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, ap);
+        KCHK("pvr_kernel<GAUSS>");
+        return (int)SVR_OK; });
+      if (rr) return rr; }
   } else if (a.n) {
-    hipLaunchKernelGGL(psf_kernel<MODE_GAUSS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                       ctx->stream, a);
-    KCHK("psf_kernel<GAUSS>");
+    { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
+        hipLaunchKernelGGL(psf_kernel<MODE_GAUSS>, dim3(nblk(ap.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, ap);
+        KCHK("psf_kernel<GAUSS>");
+        return (int)SVR_OK; });
+      if (rr) return rr; }
   }
   t.stop();
   ctx->psf_list_valid = false;
@@ -3924,13 +3954,17 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       launch_fwd_unit<false>(ctx, a, ta, lds);
       KCHK("fwd_unit_kernel");
     } else if (a.n && ctx->pvr) {
-      hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                         ctx->stream, a);
-      KCHK("pvr_kernel<FWD>");
+      { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
+          hipLaunchKernelGGL(pvr_kernel<MODE_FWD>, dim3(nblk(ap.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, ap);
+          KCHK("pvr_kernel<FWD>");
+          return (int)SVR_OK; });
+        if (rr) return rr; }
     } else if (a.n) {
-      hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64),
-                         (size_t)ctx->dbg_fwd_lds, ctx->stream, a);
-      KCHK("psf_kernel<FWD>");
+      { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
+          hipLaunchKernelGGL(psf_kernel<MODE_FWD>, dim3(nblk(ap.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), (size_t)ctx->dbg_fwd_lds, ctx->stream, ap);
+          KCHK("psf_kernel<FWD>");
+          return (int)SVR_OK; });
+        if (rr) return rr; }
     }
     return SVR_OK;
   };
@@ -4222,13 +4256,17 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     else r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, back_mode_eff(ctx)), a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
     if (r) return r;
   } else if (a.n && ctx->pvr) {
-    hipLaunchKernelGGL(pvr_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                       ctx->stream, a);
-    KCHK("pvr_kernel<BACK>");
+    { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
+        hipLaunchKernelGGL(pvr_kernel<MODE_BACK>, dim3(nblk(ap.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, ap);
+        KCHK("pvr_kernel<BACK>");
+        return (int)SVR_OK; });
+      if (rr) return rr; }
   } else if (a.n) {
-    hipLaunchKernelGGL(psf_kernel<MODE_BACK>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                       ctx->stream, a);
-    KCHK("psf_kernel<BACK>");
+    { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
+        hipLaunchKernelGGL(psf_kernel<MODE_BACK>, dim3(nblk(ap.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, ap);
+        KCHK("psf_kernel<BACK>");
+        return (int)SVR_OK; });
+      if (rr) return rr; }
   }
   t.stop();
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -4497,9 +4535,11 @@ int svr_normalise_bias_local(svr_ctx *ctx) {
   a.recon = ctx->d_bias_vol;            // scattered value: psf/sume * (bias - log scale)
   a.volw = ctx->d_volume_weights;       // dev_volume_weights_: accumulates, never cleared (RC.cu:2633)
   if (a.n) {
-    hipLaunchKernelGGL(psf_kernel<MODE_BIAS>, dim3(nblk(a.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0,
-                       ctx->stream, a);
-    KCHK("psf_kernel<BIAS>");
+    { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
+        hipLaunchKernelGGL(psf_kernel<MODE_BIAS>, dim3(nblk(ap.n, WAVES_PER_BLOCK)), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, ap);
+        KCHK("psf_kernel<BIAS>");
+        return (int)SVR_OK; });
+      if (rr) return rr; }
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;

@@ -25,7 +25,9 @@
  * 262-277); which pixel a patch column reads is then rounding noise.  snap = 1 treats a coordinate within 1e-6 of an integer
  * as that integer (what both command lines do); snap = 0 is the literal truncation.
  */
+#include <float.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -238,38 +240,54 @@ int orc_generate_2d_patches(const orc_attr *attr, const float *stack, double thi
  * entries there, written past for larger segments, :461-462); a stack whose minimum equals its maximum gets grey value 0
  * (0/0 there, :738-740).
  * ======================================================================================================================= */
-static void slic_lab(const int *grey, int sz, double *lv, double *av, double *bv) {          /* rgbtolab :55-110, r = g = b */
-  const double epsilon = 0.008856, kappa = 903.3, Xr = 0.950456, Yr = 1.0, Zr = 1.088754;
-  for (int i = 0; i < sz; i++) {
-    const double C = grey[i] / 255.0;
-    const double c = C <= 0.04045 ? C / 12.92 : pow((C + 0.055) / 1.055, 2.4);
-    const double X = c * 0.4124564 + c * 0.3575761 + c * 0.1804375;
-    const double Y = c * 0.2126729 + c * 0.7151522 + c * 0.0721750;
-    const double Z = c * 0.0193339 + c * 0.1191920 + c * 0.9503041;
-    const double xr = X / Xr, yr = Y / Yr, zr = Z / Zr;
-    const double fx = xr > epsilon ? pow(xr, 1.0 / 3.0) : (kappa * xr + 16.0) / 116.0;
-    const double fy = yr > epsilon ? pow(yr, 1.0 / 3.0) : (kappa * yr + 16.0) / 116.0;
-    const double fz = zr > epsilon ? pow(zr, 1.0 / 3.0) : (kappa * zr + 16.0) / 116.0;
-    lv[i] = 116.0 * fy - 16.0; av[i] = 500.0 * (fx - fy); bv[i] = 200.0 * (fy - fz);
+/* rgbtolab (runSLIC_2D.c:55-110) for r = g = b: the input is an 8-bit grey level, so the conversion is a table of 256 entries.
+ * Written in round 3 from the colour-space definitions the reference's lines implement, independently of the product's
+ * csrc/svr_slic.h: sRGB companding (IEC 61966-2-1: linear below 0.04045, else ((C + 0.055) / 1.055)^2.4), the D65 sRGB -> XYZ
+ * matrix rows as the reference types them (each row applied to the same linear grey value, summed left to right), the white
+ * point (0.950456, 1, 1.088754), and CIE L*a*b* with epsilon = 0.008856, kappa = 903.3. */
+static void slic_lab(const int *grey, int sz, double *lv, double *av, double *bv) {
+  static const double M[3][3] = {{0.4124564, 0.3575761, 0.1804375}, {0.2126729, 0.7151522, 0.0721750}, {0.0193339, 0.1191920, 0.9503041}};
+  static const double white[3] = {0.950456, 1.0, 1.088754};
+  double tab[256][3];
+  for (int g = 0; g < 256; ++g) {
+    const double srgb = g / 255.0;
+    double lin;
+    if (srgb <= 0.04045) lin = srgb / 12.92;
+    else lin = pow((srgb + 0.055) / 1.055, 2.4);
+    double f[3];
+    for (int c = 0; c < 3; ++c) {
+      const double xyz = lin * M[c][0] + lin * M[c][1] + lin * M[c][2];
+      const double rel = xyz / white[c];
+      f[c] = rel > 0.008856 ? pow(rel, 1.0 / 3.0) : (903.3 * rel + 16.0) / 116.0;
+    }
+    tab[g][0] = 116.0 * f[1] - 16.0;
+    tab[g][1] = 500.0 * (f[0] - f[1]);
+    tab[g][2] = 200.0 * (f[1] - f[2]);
+  }
+  for (int i = 0; i < sz; ++i) {
+    const int g = grey[i] < 0 ? 0 : (grey[i] > 255 ? 255 : grey[i]);
+    lv[i] = tab[g][0]; av[i] = tab[g][1]; bv[i] = tab[g][2];
   }
 }
 
-static int slic_grid_seeds(int STEP, int width, int height, int *seed) {                       /* getLABXYSeeds :111-151 */
-  int xstrips = (int)(0.5 + (double)width / (double)STEP), ystrips = (int)(0.5 + (double)height / (double)STEP);
-  int xerr = width - STEP * xstrips;
-  if (xerr < 0) { xstrips--; xerr = width - STEP * xstrips; }
-  int yerr = height - STEP * ystrips;
-  if (yerr < 0) { ystrips--; yerr = height - STEP * ystrips; }
-  const double xeps = (double)xerr / (double)xstrips, yeps = (double)yerr / (double)ystrips;
-  const int off = STEP / 2;
+/* getLABXYSeeds (runSLIC_2D.c:111-151), square grid: along each axis the strips are STEP wide, their number is the extent over
+ * STEP rounded to nearest (one fewer if that overshoots), and the pixels left over are spread over the strips -- strip i starts
+ * i * STEP + STEP / 2 + trunc(i * leftover / strips).  The two axes are independent: positions per axis first, then the grid. */
+static int slic_axis_seeds(int STEP, int extent, int *pos) {
+  int strips = (int)(0.5 + (double)extent / (double)STEP);
+  if (extent - STEP * strips < 0) strips--;
+  const int left = extent - STEP * strips;
+  const double per = (double)left / (double)strips;
+  for (int i = 0; i < strips; ++i) pos[i] = i * STEP + STEP / 2 + (int)(i * per);
+  return strips;
+}
+static int slic_grid_seeds(int STEP, int width, int height, int *seed) {
+  int *sx = (int *)malloc((size_t)(width + 2) * sizeof(int)), *sy = (int *)malloc((size_t)(height + 2) * sizeof(int));
+  const int nx = slic_axis_seeds(STEP, width, sx), ny = slic_axis_seeds(STEP, height, sy);
   int n = 0;
-  for (int y = 0; y < ystrips; y++) {
-    const int ye = (int)(y * yeps);
-    for (int x = 0; x < xstrips; x++) {
-      const int xe = (int)(x * xeps);
-      seed[n++] = (y * STEP + off + ye) * width + (x * STEP + off + xe);
-    }
-  }
+  for (int j = 0; j < ny; ++j)
+    for (int i = 0; i < nx; ++i) seed[n++] = sy[j] * width + sx[i];
+  free(sx); free(sy);
   return n;
 }
 
@@ -520,4 +538,187 @@ int orc_generate_2d_superpixel_patches(const orc_attr *attr, const float *stack,
   free(patch);
   *n_out = n;
   return 0;
+}
+
+/* =====================================================================================================================
+ * The rest of the pre-processing chain of reconstruction.cc:386-815, restated from the reference's own loops (round 3):
+ * CreateTemplate (RG.cc:648-694 + irtkResampling<>::Initialize, irtkResampling.cc:74-130), SetMask (RG.cc:750-803: Gaussian
+ * blurring, threshold, nearest-neighbour transformation onto the template), TransformMask (RG.cc:805-821), CropImage
+ * (RG.cc:5205-5306 + GetRegion) and MaskSlices (RG.cc:1940-1988).  Written from the reference, not from csrc/svr_prep.h.
+ * ===================================================================================================================== */
+
+/* CreateTemplate: the stack's grid with two more planes (about the same origin = image centre), resampled to d x d x d:
+ * dims int(n * old / d), at least 1 (then the old voxel size is kept), same axes and origin.  Returns d. */
+double orc_create_template(const orc_attr *stack, double resolution, orc_attr *out) {
+  double d;
+  orc_attr a = *stack;
+  a.nz += 2;                                             /* attr._z += 2 */
+  if (resolution <= 0) {
+    if ((a.dx <= a.dy) && (a.dx <= a.dz)) d = a.dx;
+    else if (a.dy <= a.dz) d = a.dy;
+    else d = a.dz;
+  } else {
+    d = resolution;
+  }
+  int new_x = (int)(a.nx * a.dx / d), new_y = (int)(a.ny * a.dy / d), new_z = (int)(a.nz * a.dz / d);
+  double sx = d, sy = d, sz = d;
+  if (new_x < 1) { new_x = 1; sx = a.dx; }
+  if (new_y < 1) { new_y = 1; sy = a.dy; }
+  if (new_z < 1) { new_z = 1; sz = a.dz; }
+  *out = a;
+  out->nx = new_x; out->ny = new_y; out->nz = new_z;
+  out->dx = sx; out->dy = sy; out->dz = sz;
+  return d;
+}
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+/* irtkGaussianBlurring<irtkRealPixel>(sigma).Run() (irtkGaussianBlurring.cc:40-125): three 1-D passes (x, y, z -- the z pass
+ * only if the image has more than one plane), each irtkConvolution_1D with normalisation (irtkConvolution_1D.cc:42-90: the
+ * kernel is cut at the image border and the result divided by the sum of the weights that took part).  The kernel is
+ * irtkScalarGaussian(sigma / voxel, 1, 1) sampled at the integer offsets -h..h, h = round(4 sigma / voxel), through
+ * irtkScalarFunctionToImage (values below FLT_MIN become 0); its constant norm cancels in the normalisation but is kept. */
+void orc_gaussian_blur(const orc_attr *a, double *data, double sigma) {
+  const int n[3] = {a->nx, a->ny, a->nz};
+  const double vs[3] = {a->dx, a->dy, a->dz};
+  const size_t total = (size_t)a->nx * a->ny * a->nz;
+  double *buf = (double *)malloc(total * sizeof(double));
+  for (int axis = 0; axis < 3; ++axis) {
+    if (axis == 2 && a->nz == 1) continue;               /* `if (this->_output->GetX() != 1)` after the two flips */
+    const double s = sigma / vs[axis];
+    const int h = (int)irtk_round(4 * sigma / vs[axis]);
+    const int kn = 2 * h + 1;
+    double *k = (double *)malloc(kn * sizeof(double));
+    const double norm = 1.0 / (sqrt(2.0 * M_PI) * s * sqrt(2.0 * M_PI) * 1.0 * sqrt(2.0 * M_PI) * 1.0);
+    for (int i = 0; i < kn; ++i) {
+      const double x = (double)i - (kn - 1) / 2.0;       /* ImageToWorld of the kernel image: unit voxels about the origin */
+      double v = norm * exp(-(x * x) / (2.0 * s * s) - 0.0 / (2.0 * 1.0 * 1.0) - 0.0 / (2.0 * 1.0 * 1.0));
+      if (fabs(v) < FLT_MIN) v = 0;
+      k[i] = v;
+    }
+    const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)a->nx : (size_t)a->nx * a->ny);
+    for (int z = 0; z < a->nz; ++z)
+      for (int y = 0; y < a->ny; ++y)
+        for (int x = 0; x < a->nx; ++x) {
+          const int p = axis == 0 ? x : (axis == 1 ? y : z);
+          const size_t base = ((size_t)z * a->ny + y) * a->nx + x;
+          const int x1 = p - kn / 2, x2 = p + kn / 2;
+          double val = 0, sum = 0;
+          for (int q = x1; q <= x2; ++q)
+            if (q >= 0 && q < n[axis]) {
+              val += k[q - x1] * data[base + (ptrdiff_t)(q - p) * (ptrdiff_t)stride];
+              sum += k[q - x1];
+            }
+          buf[base] = sum > 0 ? val / sum : 0;
+        }
+    memcpy(data, buf, total * sizeof(double));
+    free(k);
+  }
+  free(buf);
+}
+
+/* irtkImageTransformation::Run (irtkImageTransformation.cc:200-324) with the nearest-neighbour interpolator: every target
+ * voxel above the target padding value is taken to world coordinates, through the transformation, into the source grid
+ * (three separate applications); inside the source's field of view (-0.5 < x < n - 0.5, strictly) it takes the nearest
+ * source voxel, everywhere else the source padding value.  target: in/out. */
+void orc_transform_nn(const orc_attr *src_attr, const double *src, const orc_attr *tgt_attr, double *tgt, const double *T,
+                      double target_padding, double source_padding) {
+  double t_i2w[16], s_w2i[16];
+  image_to_world(tgt_attr, t_i2w);
+  world_to_image(src_attr, s_w2i);
+  for (int k = 0; k < tgt_attr->nz; ++k)
+    for (int j = 0; j < tgt_attr->ny; ++j)
+      for (int i = 0; i < tgt_attr->nx; ++i) {
+        double *o = &tgt[((size_t)k * tgt_attr->ny + j) * tgt_attr->nx + i];
+        if (*o > target_padding) {
+          double x = i, y = j, z = k;
+          apply(t_i2w, &x, &y, &z);
+          apply(T, &x, &y, &z);
+          apply(s_w2i, &x, &y, &z);
+          if ((x > -0.5) && (x < src_attr->nx - 0.5) && (y > -0.5) && (y < src_attr->ny - 0.5) && (z > -0.5) && (z < src_attr->nz - 0.5)) {
+            const int a = (int)irtk_round(x), b = (int)irtk_round(y), c = (int)irtk_round(z);
+            *o = src[((size_t)c * src_attr->ny + b) * src_attr->nx + a];
+          } else {
+            *o = source_padding;
+          }
+        } else {
+          *o = source_padding;
+        }
+      }
+}
+
+/* SetMask (RG.cc:750-803).  mask: in/out like the reference's (it is blurred and binarised in place when sigma > 0);
+ * out: the mask on the template grid (the template is an all-zero image: every voxel is above the target padding -1).
+ * mask == NULL: ones. */
+void orc_set_mask(const orc_attr *tmpl, const orc_attr *mask_attr, double *mask, double sigma, double threshold, double *out) {
+  const size_t nt = (size_t)tmpl->nx * tmpl->ny * tmpl->nz;
+  if (!mask) { for (size_t i = 0; i < nt; ++i) out[i] = 1; return; }
+  if (sigma > 0) {
+    orc_gaussian_blur(mask_attr, mask, sigma);
+    const size_t nm = (size_t)mask_attr->nx * mask_attr->ny * mask_attr->nz;
+    for (size_t i = 0; i < nm; ++i) mask[i] = mask[i] > threshold ? 1 : 0;
+  }
+  double I[16];
+  ident(I);
+  for (size_t i = 0; i < nt; ++i) out[i] = 0;            /* _mask = _reconstructed: the zero template */
+  orc_transform_nn(mask_attr, mask, tmpl, out, I, -1, 0);
+}
+
+/* TransformMask (RG.cc:805-821): `m = image` -- the target starts as a COPY OF THE IMAGE, so a voxel of the image at or below
+ * the target padding -1 is not looked up but set to 0 -- then the mask is resampled onto it.  image_as_target: in/out. */
+void orc_transform_mask(const orc_attr *image_attr, double *image_as_target, const orc_attr *mask_attr, const double *mask, const double *T) {
+  orc_transform_nn(mask_attr, mask, image_attr, image_as_target, T, -1, 0);
+}
+
+/* CropImage (RG.cc:5205-5306): the bounding box of mask > 0, found plane by plane from either end of every axis;
+ * bounds6 = {x1, y1, z1, x2, y2, z2} (inclusive; the region cut is [x1, x2 + 1) ...).  A mask without a voxel > 0 leaves
+ * x2 = y2 = z2 = -1 and x1 = nx ... like the reference's loops.  region: the attributes of the cut image. */
+void orc_crop_bounds(const orc_attr *a, const double *mask, int bounds6[6], orc_attr *region) {
+  int i, j, k, sum;
+#define M_(i, j, k) mask[((size_t)(k) * a->ny + (j)) * a->nx + (i)]
+  for (k = a->nz - 1; k >= 0; k--) { sum = 0; for (j = a->ny - 1; j >= 0; j--) for (i = a->nx - 1; i >= 0; i--) if (M_(i, j, k) > 0) sum++; if (sum > 0) break; }
+  const int z2 = k;
+  for (k = 0; k <= a->nz - 1; k++) { sum = 0; for (j = a->ny - 1; j >= 0; j--) for (i = a->nx - 1; i >= 0; i--) if (M_(i, j, k) > 0) sum++; if (sum > 0) break; }
+  const int z1 = k;
+  for (j = a->ny - 1; j >= 0; j--) { sum = 0; for (k = a->nz - 1; k >= 0; k--) for (i = a->nx - 1; i >= 0; i--) if (M_(i, j, k) > 0) sum++; if (sum > 0) break; }
+  const int y2 = j;
+  for (j = 0; j <= a->ny - 1; j++) { sum = 0; for (k = a->nz - 1; k >= 0; k--) for (i = a->nx - 1; i >= 0; i--) if (M_(i, j, k) > 0) sum++; if (sum > 0) break; }
+  const int y1 = j;
+  for (i = a->nx - 1; i >= 0; i--) { sum = 0; for (k = a->nz - 1; k >= 0; k--) for (j = a->ny - 1; j >= 0; j--) if (M_(i, j, k) > 0) sum++; if (sum > 0) break; }
+  const int x2 = i;
+  for (i = 0; i <= a->nx - 1; i++) { sum = 0; for (k = a->nz - 1; k >= 0; k--) for (j = a->ny - 1; j >= 0; j--) if (M_(i, j, k) > 0) sum++; if (sum > 0) break; }
+  const int x1 = i;
+#undef M_
+  bounds6[0] = x1; bounds6[1] = y1; bounds6[2] = z1; bounds6[3] = x2; bounds6[4] = y2; bounds6[5] = z2;
+  if (region && x2 >= x1 && y2 >= y1 && z2 >= z1) region_attr(a, x1, y1, z1, x2 + 1, y2 + 1, z2 + 1, region);
+}
+
+/* MaskSlices (RG.cc:1940-1988) for one slice: values below 0.01 are padding (-1); a pixel whose position -- slice
+ * ImageToWorld, the slice's transformation, the mask's WorldToImage, rounded -- is outside the mask's grid or on a zero of
+ * the mask is -1.  slice: in/out [ny][nx]. */
+void orc_mask_slice(const orc_attr *slice_attr, double *slice, const double *T, const orc_attr *mask_attr, const double *mask) {
+  double s_i2w[16], m_w2i[16];
+  image_to_world(slice_attr, s_i2w);
+  world_to_image(mask_attr, m_w2i);
+  for (int i = 0; i < slice_attr->nx; i++)
+    for (int j = 0; j < slice_attr->ny; j++) {
+      double *v = &slice[(size_t)j * slice_attr->nx + i];
+      if (*v < 0.01) *v = -1;
+      double x = i, y = j, z = 0;
+      apply(s_i2w, &x, &y, &z);
+      apply(T, &x, &y, &z);
+      apply(m_w2i, &x, &y, &z);
+      x = irtk_round(x); y = irtk_round(y); z = irtk_round(z);
+      if ((x >= 0) && (x < mask_attr->nx) && (y >= 0) && (y < mask_attr->ny) && (z >= 0) && (z < mask_attr->nz)) {
+        if (mask[((size_t)(int)z * mask_attr->ny + (int)y) * mask_attr->nx + (int)x] == 0) *v = -1;
+      } else {
+        *v = -1;
+      }
+    }
+}
+
+/* attributes of image.GetRegion(i1, j1, k1, i2, j2, k2) (irtkGenericImage.cc:570-611), e.g. of one slice of a stack */
+void orc_get_region_attr(const orc_attr *src, int i1, int j1, int k1, int i2, int j2, int k2, orc_attr *out) {
+  region_attr(src, i1, j1, k1, i2, j2, k2, out);
 }

@@ -586,3 +586,71 @@ def generate_2d_superpixel_patches(stack, attr, labels, thickness, mask, mask_at
     assert (pxy[0], pxy[1]) == (px, py)
     k = n.value
     return data[:k].copy(), sm[:k].copy(), i2w[:k].copy(), w2i[:k].copy(), org[:k].copy(), int(total.value)
+
+
+# ---- the rest of the pre-processing chain (round 3: CreateTemplate, SetMask, TransformMask, CropImage, MaskSlices) ---------
+def _attr_to_py(a):
+    from fetalreconstruction_amd import geometry as geo
+    return geo.ImageAttributes(a.nx, a.ny, a.nz, a.dx, a.dy, a.dz, np.array(a.xaxis[:]), np.array(a.yaxis[:]), np.array(a.zaxis[:]), origin=np.array(a.origin[:]))
+
+
+def create_template(stack_attr, resolution):
+    """orc_create_template (CreateTemplate RG.cc:648-694) -> (template attributes, resolution used)"""
+    out = Attr()
+    lib().orc_create_template.restype = C.c_double
+    d = lib().orc_create_template(C.byref(Attr.of(stack_attr)), C.c_double(resolution), C.byref(out))
+    return _attr_to_py(out), float(d)
+
+
+def gaussian_blur(data, attr, sigma):
+    d = np.ascontiguousarray(data, np.float64).copy()
+    lib().orc_gaussian_blur(C.byref(Attr.of(attr)), _p(d), C.c_double(sigma))
+    return d
+
+
+def set_mask(template_attr, mask, mask_attr, sigma, threshold=0.5):
+    """orc_set_mask (SetMask RG.cc:750-803) -> (mask on the template grid [nz][ny][nx] float64, the blurred + binarised input)"""
+    out = np.zeros((template_attr.nz, template_attr.ny, template_attr.nx), np.float64)
+    if mask is None:
+        lib().orc_set_mask(C.byref(Attr.of(template_attr)), None, None, C.c_double(sigma), C.c_double(threshold), _p(out))
+        return out, None
+    m = np.ascontiguousarray(mask, np.float64).copy()
+    lib().orc_set_mask(C.byref(Attr.of(template_attr)), C.byref(Attr.of(mask_attr)), _p(m), C.c_double(sigma), C.c_double(threshold), _p(out))
+    return out, m
+
+
+def transform_mask(image, image_attr, mask, mask_attr, T):
+    """orc_transform_mask (TransformMask RG.cc:805-821): the mask on the image's grid (the target starts as a copy of the image)"""
+    tgt = np.ascontiguousarray(image, np.float64).copy()
+    m = np.ascontiguousarray(mask, np.float64)
+    t = np.ascontiguousarray(np.asarray(T, np.float64).reshape(16))
+    lib().orc_transform_mask(C.byref(Attr.of(image_attr)), _p(tgt), C.byref(Attr.of(mask_attr)), _p(m), _p(t))
+    return tgt
+
+
+def crop_image(image, image_attr, mask):
+    """orc_crop_bounds + GetRegion (CropImage RG.cc:5205-5306) -> (cropped image, its attributes, bounds6)"""
+    b = (C.c_int * 6)()
+    reg = Attr()
+    m = np.ascontiguousarray(mask, np.float64)
+    lib().orc_crop_bounds(C.byref(Attr.of(image_attr)), _p(m), b, C.byref(reg))
+    x1, y1, z1, x2, y2, z2 = b[:]
+    if x2 < x1 or y2 < y1 or z2 < z1:
+        raise ValueError("CropImage: the mask does not overlap the image")
+    return np.ascontiguousarray(np.asarray(image)[z1:z2 + 1, y1:y2 + 1, x1:x2 + 1]), _attr_to_py(reg), tuple(b[:])
+
+
+def mask_slice(slice2d, slice_attr, T, mask, mask_attr):
+    """orc_mask_slice (MaskSlices RG.cc:1940-1988) -> the masked slice [ny][nx] float64"""
+    s = np.ascontiguousarray(slice2d, np.float64).copy()
+    m = np.ascontiguousarray(mask, np.float64)
+    t = np.ascontiguousarray(np.asarray(T, np.float64).reshape(16))
+    lib().orc_mask_slice(C.byref(Attr.of(slice_attr)), _p(s), _p(t), C.byref(Attr.of(mask_attr)), _p(m))
+    return s
+
+
+def get_region_attr(attr, i1, j1, k1, i2, j2, k2):
+    """attributes of GetRegion(i1, j1, k1, i2, j2, k2) (irtkGenericImage.cc:570-611)"""
+    out = Attr()
+    lib().orc_get_region_attr(C.byref(Attr.of(attr)), int(i1), int(j1), int(k1), int(i2), int(j2), int(k2), C.byref(out))
+    return _attr_to_py(out)

@@ -321,12 +321,71 @@ def test_ragged_and_empty_inputs(oracle_mod):
 
 
 def test_too_many_pixels_for_one_context_are_refused():
-    """Every launch of the path is a wavefront per pixel or per tile and a dispatch holds 2^32 - 1 work-items: 2^26 slice
-    pixels per context and beyond are refused loudly instead of being processed modulo 2^32."""
+    """Slice-grid indices are 32-bit: 2^31 pixels per context and beyond are refused loudly (below that every launch that takes
+    a wavefront per pixel or per tile goes out in pieces, test_lists_go_out_in_pieces)."""
     from fetalreconstruction_amd import engine as E
     rec = E.Reconstruction(0)
-    with pytest.raises(E.SvrError, match="2\\^26"):
-        rec._ck(rec._lib.svr_init_storage_volumes(rec._h, E._p(np.array([4096, 4096, 4], np.uint32)), E._p(np.ones(3, np.float32))))
+    with pytest.raises(E.SvrError, match="2\\^31"):
+        rec._ck(rec._lib.svr_init_storage_volumes(rec._h, E._p(np.array([65536, 32768, 1], np.uint32)), E._p(np.ones(3, np.float32))))
+
+
+@pytest.mark.parametrize("modes", [dict(back_mode=5, fwd_mode=1, gauss_mode=1), dict(back_mode=4, fwd_mode=1, gauss_mode=1),
+                                   dict(back_mode=3, fwd_mode=0, gauss_mode=0), dict(back_mode=0, fwd_mode=0, gauss_mode=0)])
+def test_lists_go_out_in_pieces(tiny, oracle_mod, monkeypatch, modes):
+    """A dispatch holds 2^32 - 1 work-items: pixel lists (a wavefront per pixel), tile lists and the cell scatter's item list are
+    launched in pieces (the reference chunks its launches too: MAX_SLICES_PER_RUN, RC.cu:2207-2219, 2414-2432).  SVR_LIST_PIECE
+    shortens the pieces so that the tiny problem takes that path in every kernel family -- tile building, the tiled and the
+    cell-owned scatter, the wave-per-pixel kernels, the coefficient table -- and must still agree with the oracle."""
+    monkeypatch.setenv("SVR_LIST_PIECE", "40")
+    monkeypatch.setenv("SVR_FWD_PIECE", "48")
+    E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    for k, v in modes.items():
+        rec.set_option(k, v)
+    dg.reconstruct_iteration(2)
+    do.reconstruct_iteration(2)
+    g, o = rec.syncCPU(), orc.recon
+    assert np.array_equal(g == -1, o == -1) and rel_err(g, o) < 1e-4
+    assert np.array_equal(rec.debug_get(E.BUF_PSF_SUMS) != 0, orc.psf_sums != 0)
+    assert np.array_equal(rec.debug_get(E.BUF_CONFIDENCE_MAP) > 0, orc.cmap > 0)
+    if modes["back_mode"] == 4:                                            # ... and the table built and streamed in pieces
+        rec.set_option("coeff_table", 1)
+        sim0 = rec.debug_get(E.BUF_SIMSLICES).copy()
+        rec.SimulateSlices()
+        assert rec.get_option("coeff_table") == 1 and np.array_equal(rec.debug_get(E.BUF_SIMSLICES), sim0)
+
+
+def test_sixteen_stacks_on_one_context():
+    """16 stacks of 64 slices of 256^2 pixels = 2^26 slice pixels in ONE context (refused until round 3: a wavefront per pixel of
+    such a list does not fit one dispatch).  Too big for the oracle: forward projection and scatter are adjoint,
+    <A V, e> = <V, A^T e>, and every active pixel got its simulated value."""
+    from fetalreconstruction_amd import engine as E
+    P = phantom.make_problem(16, (256, 256, 64), 1.0, 2.5, 2.5, 0.75, 100.0, seed=3, orientations=("ax", "cor", "sag"), name="S16")
+    assert P.slices.size == 1 << 26
+    rec = _engine(P)
+    rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+    rec.InitializeEMValues()
+    rec.GaussianReconstruction()
+    rng = np.random.default_rng(0)
+    V = rng.uniform(0.5, 1.5, P.nvox).astype(np.float32)
+    rec.debug_set(E.BUF_RECONSTRUCTED, V)
+    rec.SimulateSlices()
+    sim = rec.debug_get(E.BUF_SIMSLICES).astype(np.float64)
+    sw = rec.debug_get(E.BUF_SIMWEIGHTS).astype(np.float64)
+    ps = rec.debug_get(E.BUF_PSF_SUMS)
+    act = (P.slices != -1) & (ps != 0)
+    assert act.sum() > 20e6 and (sw[act] > 0).mean() > 0.99
+    s = P.slices.astype(np.float32)
+    r = rng.uniform(-1, 1, P.slices.shape).astype(np.float32)
+    simp = np.where(act, s - r, 0.0).astype(np.float32)
+    e = np.where(act & (simp > 0), s.astype(np.float64) - simp.astype(np.float64), 0.0)
+    rec.debug_set(E.BUF_SIMSLICES, simp)
+    rec.debug_set(E.BUF_WEIGHTS, np.ones(P.slices.shape, np.float32))
+    rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+    addon = rec.debug_get(E.BUF_ADDON).astype(np.float64)
+    lhs, rhs = float(np.sum(sim * sw * e)), float(np.sum(addon * V.astype(np.float64)))
+    scale = float(np.sum(np.abs(sim * sw * e)))
+    assert abs(lhs - rhs) <= 2e-5 * scale, (lhs, rhs, scale)
+    assert rec.counters()["Va"] == int(act.sum())
 
 
 @pytest.mark.parametrize("workload", ["P4", "S8"])

@@ -196,3 +196,112 @@ def test_cpp_superpixel_patches_against_the_oracle(tmp_path, oracle_mod):
         assert np.array_equal(op, patches[at:at + len(op)]) and np.array_equal(om, masks[at:at + len(op)])
         at += len(op)
     assert at == ns > 20
+
+
+# ---- CreateTemplate / SetMask / TransformMask / CropImage / MaskSlices: the C++ command line against the oracle's restatement ----
+def _read_svr_dump(path):
+    import ctypes as C
+    from oracle import pyoracle as po
+    raw = open(path, "rb").read()
+    hdr = np.frombuffer(raw, np.int32, 8)
+    ns, mx, my, n, tx, ty, tz, ver = [int(v) for v in hdr]
+    assert ver == 2
+    o = 32
+    asz = C.sizeof(po.Attr)
+    tattr = po._attr_to_py(po.Attr.from_buffer_copy(raw[o:o + asz])); o += asz
+    vmask = np.frombuffer(raw, np.float64, tx * ty * tz, o).reshape(tz, ty, tx); o += 8 * tx * ty * tz
+    sattrs = []
+    for _ in range(n):
+        sattrs.append(po._attr_to_py(po.Attr.from_buffer_copy(raw[o:o + asz]))); o += asz
+    grid = np.frombuffer(raw, np.float32, ns * my * mx, o).reshape(ns, my, mx); o += 4 * ns * my * mx
+    T = np.frombuffer(raw, np.float64, 16 * ns, o).reshape(ns, 4, 4); o += 128 * ns
+    fac = np.frombuffer(raw, np.float32, n, o); o += 4 * n
+    sx = np.frombuffer(raw, np.int32, ns, o); o += 4 * ns
+    sy = np.frombuffer(raw, np.int32, ns, o); o += 4 * ns
+    assert o == len(raw)
+    return dict(tattr=tattr, vmask=vmask, sattrs=sattrs, grid=grid, T=T, factors=fac, sizes_x=sx, sizes_y=sy)
+
+
+def _same_attr(a, b, tol=1e-9):
+    return ((a.nx, a.ny, a.nz) == (b.nx, b.ny, b.nz) and np.allclose([a.dx, a.dy, a.dz], [b.dx, b.dy, b.dz], rtol=1e-12)
+            and np.allclose(a.origin, b.origin, atol=tol) and np.allclose(np.stack([a.xaxis, a.yaxis, a.zaxis]), np.stack([b.xaxis, b.yaxis, b.zaxis]), atol=1e-12))
+
+
+@pytest.mark.parametrize("case,smooth", [("oblique", 4.0), ("oblique", 0.0), ("aligned", 2.0)])
+def test_cpp_preprocessing_chain_against_the_oracle(tmp_path, oracle_mod, case, smooth):
+    """bin/SVRreconstructionGPU --dumpProblem --dryRun (csrc/svr_prep.h, csrc/svr_cli.cpp) against the oracle's restatement of the
+    reference's loops, step by step: TransformMask + CropImage of the template stack (RG.cc:805-821, 5205-5306), CreateTemplate
+    (RG.cc:648-694), SetMask with and without smoothing (RG.cc:750-803), TransformMask + CropImage of the other stacks,
+    MatchStackIntensitiesWithMasking (RG.cc:1375-1493), MaskSlices (RG.cc:1940-1988) -- on the reference's bundled mask geometry
+    (oblique, 300-400 mm off the origin, where an x.5 coordinate decides a voxel) and on an axis-aligned case."""
+    from fetalreconstruction_amd import build, nifti
+    po = oracle_mod
+    build.build()
+    if case == "oblique":
+        m, a, st, _ = _oblique_case(3)
+        stacks = [(d.astype(np.float64), sa) for d, sa in st]
+        mask, mattr = m.astype(np.float64), a
+        res, thick = 1.0, 2.5
+    else:
+        sts, mask_, mattr = _aligned_case()
+        stacks = [(s.data.astype(np.float64), s.attr) for s in sts]
+        mask = np.asarray(mask_, np.float64)
+        res, thick = 1.0, 2.2
+    paths = []
+    for k, (d, sa) in enumerate(stacks):
+        nifti.write(tmp_path / f"s{k}.nii", d.astype(np.float32), sa)
+        paths.append(str(tmp_path / f"s{k}.nii"))
+    nifti.write(tmp_path / "mask.nii", mask.astype(np.float32), mattr)
+    dump = tmp_path / "svr.bin"
+    r = subprocess.run([build.CLI, "-o", str(tmp_path / "x.nii"), "-i", *paths, "-m", str(tmp_path / "mask.nii"), "--thickness", *[str(thick)] * len(paths),
+                        "--resolution", str(res), "--smooth_mask", str(smooth), "--no_registration", "--dumpProblem", str(dump), "--dryRun"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    D = _read_svr_dump(str(dump))
+    # start the oracle chain from what the files hold: float32 voxels, and the geometry as NIfTI stores it
+    stacks = []
+    for pth in paths:
+        d_, a_ = nifti.read(pth)
+        stacks.append((d_.astype(np.float64), a_))
+    mask_f, mattr = nifti.read(tmp_path / "mask.nii")
+    mask = mask_f.astype(np.float64)
+    I = np.eye(4)
+    # 1. the template stack: TransformMask (with the UNSMOOTHED mask file) + CropImage
+    d0, a0 = stacks[0]
+    m0 = po.transform_mask(d0, a0, mask, mattr, I)
+    d0c, a0c, _ = po.crop_image(d0, a0, m0)
+    assert _same_attr(a0c, D["sattrs"][0])
+    # 2. CreateTemplate
+    tattr, d = po.create_template(a0c, res)
+    assert d == res and _same_attr(tattr, D["tattr"])
+    # 3. SetMask: blur + threshold + nearest-neighbour resampling onto the template
+    vmask, blurred = po.set_mask(tattr, mask, mattr, smooth)
+    assert vmask.shape == D["vmask"].shape and 0 < vmask.sum() < vmask.size
+    assert np.array_equal(vmask, D["vmask"])
+    if smooth > 0:
+        assert not np.array_equal(blurred, mask)                          # the smoothing changed the mask
+    # 4. the other stacks: the VOLUME mask transformed onto them, crop
+    cropped = [(d0c, a0c)]
+    for k in range(1, len(stacks)):
+        dk, ak = stacks[k]
+        mk = po.transform_mask(dk, ak, vmask, tattr, I)
+        dc, ac, _ = po.crop_image(dk, ak, mk)
+        assert _same_attr(ac, D["sattrs"][k]), k
+        cropped.append((dc, ac))
+    # 5. MatchStackIntensitiesWithMasking (already restated in round 2), 6. slices + MaskSlices
+    data, fac, avg = po.match_stack_intensities([c[0] for c in cropped], [c[1] for c in cropped], [I] * len(cropped), vmask, tattr, 700.0)
+    assert np.allclose(fac, D["factors"], rtol=2e-7)
+    import copy
+    sl = 0
+    for k, ((dc, ac), dm) in enumerate(zip(cropped, data)):
+        for j in range(ac.nz):
+            sa = po.get_region_attr(ac, 0, 0, j, ac.nx, ac.ny, j + 1)      # CreateSlicesAndTransformations RG.cc:1835-1880
+            sa.dz = thick
+            ms = po.mask_slice(dm[j], sa, I, vmask, tattr)
+            g = D["grid"][sl][:ac.ny, :ac.nx]
+            assert D["sizes_x"][sl] == ac.nx and D["sizes_y"][sl] == ac.ny
+            assert np.array_equal(g == -1, ms == -1), (k, j, int(((g == -1) != (ms == -1)).sum()))
+            assert np.allclose(g, ms.astype(np.float32), rtol=1e-6, atol=0)
+            assert (D["grid"][sl][ac.ny:, :] == -1).all() and (D["grid"][sl][:, ac.nx:] == -1).all()   # padding of the grid
+            sl += 1
+    assert sl == D["grid"].shape[0] and (D["grid"] != -1).sum() > 1000
