@@ -315,7 +315,7 @@ def main():
         va = int(round(comm.allreduce_sum(np.array([float(cnt["Va"])]))[0]))
     else:
         va = cnt["Va"]
-    tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode")}
+    tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode", "fwd_mode", "cell_w", "cell_h")}
 
     # ---- the same K steps once more with the coefficient table (reported next to the headline, not as it) ------------
     # `value` above is the reference GPU path's way: every tap evaluated in every pass.  With option coeff_table the taps of
@@ -398,7 +398,9 @@ def main():
         scatter_name = ("back_cell_kernel + k_cell_combine + k_cell_factors (csrc/svr_cell.inc: cell-owned planes, staged, combined in a fixed "
                         "order, no atomics)" if tuned["back_mode"] == 5 else "back_wave_kernel (wave-owned planes per slice tile, atomic flush)")
         e_back = entry(scatter_name + " = SuperresolutionKernel3D_tex, RC.cu:408-522", bp_avg, bp_n, b_back, "back")
-        e_fwd = entry("fwd_unit_kernel = simulateSlicesKernel3D_tex, RC.cu:298-404", fw_avg, fw_n, b_fwd, "forward")
+        gather_name = ("fwd_cell_kernel + k_cell_gather_finish + k_cell_gfactors (csrc/svr_cell.inc: the gather over the same (cell, plane) items)"
+                       if tuned.get("fwd_mode") == 2 and not pvr else "fwd_unit_kernel (unit-based gather per slice tile)")
+        e_fwd = entry(gather_name + " = simulateSlicesKernel3D_tex, RC.cu:298-404", fw_avg, fw_n, b_fwd, "forward")
         dom, other = (e_back, e_fwd) if bp_avg >= fw_avg else (e_fwd, e_back)
         roof = dict(dom)
         roof["dead_unit_share"] = dead_share
@@ -427,7 +429,10 @@ def main():
                                       if world > 1 else "1 GPU",
                        "comm": (args.comm if multi else None), "rccl_world": rccl_world,
                        "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",
-                                 "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "pin": os.environ.get("SVR_TILE_PIN")}},
+                                 "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "fwd_mode": tuned["fwd_mode"],
+                                 "cell": f"{tuned['cell_w']}x{tuned['cell_h']}", "pin": os.environ.get("SVR_TILE_PIN"),
+                                 "note": "back_mode 5 / fwd_mode 2 work on (cell, plane) items: no tile shape is timed, runs repeat bit for bit; the tile "
+                                         "shapes apply to the Gaussian pass, the coefficient table and the patch-based path"}},
             "ranks": ranks,
             "roofline": roof,
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in timers.items()},

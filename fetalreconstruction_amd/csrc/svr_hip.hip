@@ -2790,7 +2790,8 @@ struct svr_ctx {
   uint32_t n_tiles_fwd = 0;
   int fwd_tw = 4, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
   int fwd_unit_cap = 9300;  // box voxels (float2) of fwd_unit_kernel: 72.7 KiB + up to 6.6 KiB static = 64 LDS granules of 1280 B -> 2 workgroups of 8 waves per CU (9400 would push the GAUSS1 table instantiation to 65)
-  int fwd_mode = 1;         // >= 1 = unit-based gather (fwd_unit_kernel), 0 = wave-per-pixel kernel (psf_kernel<MODE_FWD>)
+  int fwd_mode = 2;         // 2 = the gather over (cell, plane) items (fwd_cell_kernel, svr_cell.inc; SVR on the fly -- patch-based runs and the
+                            // coefficient table take 1), >= 1 = unit-based gather per slice tile (fwd_unit_kernel), 0 = wave-per-pixel kernel (psf_kernel<MODE_FWD>)
   // The forward tile shape that suits a problem depends on how many voxels a pixel spans: at 2 voxels per pixel (0.5 mm
   // reconstructions of 1 mm pixels) the box of a 4x4 tile no longer fits the LDS and every tap falls back to global loads.  The first forward pass of a problem times the candidate shapes on the real data
   // and keeps the fastest; the results do not depend on the shape (per-pixel sums in a fixed order).
@@ -3943,9 +3944,18 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
     KCHK("k_pack_volm");
     a.volm = ctx->d_volm;
   }
+  // fwd_mode 2 (the default for SVR on the fly): the gather over the (cell, plane) items of the scatter without atomics
+  bool cells = false;
+  if (ctx->fwd_mode == 2 && !ctx->pvr && !a.coeff && a.n) {
+    if ((r = cell_prepare(ctx))) return r;
+    cells = ctx->cell->usable;
+  }
   auto launch_forward = [&]() -> int {
     const bool tiled_ = ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1;
-    if (a.n && tiled_) {
+    if (cells) {
+      const int rr = launch_cell_gather(ctx, a);
+      if (rr) return rr;
+    } else if (a.n && tiled_) {
       TileArgs ta;
       ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
       ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
@@ -3969,7 +3979,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
     return SVR_OK;
   };
   const bool tiled = a.n && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1);
-  if (tiled && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
+  if (tiled && !cells && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
     ctx->fwd_tune_pending = false;
     static const int cand[6][2] = {{4, 4}, {6, 4}, {6, 5}, {8, 4}, {4, 2}, {2, 2}};   // the first is the default; smaller boxes for finer volumes (at most FWDU_MAXPIX = 32 pixels)
     hipEvent_t e0, e1;

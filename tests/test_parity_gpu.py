@@ -138,9 +138,10 @@ def test_against_committed_golden(tiny, oracle_mod):
     assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), gold["siminside0"])
 
 
-@pytest.mark.parametrize("fwd_mode", [1, 0])
+@pytest.mark.parametrize("fwd_mode", [2, 1, 0])
 def test_forward_projection_parity(tiny, oracle_mod, fwd_mode):
-    """fwd_mode 1 = unit-based gather (default: float2 {V m, m} box, dead-unit shortcut), 0 = wave-per-pixel kernel."""
+    """fwd_mode 2 = the gather over the (cell, plane) items of the scatter without atomics (csrc/svr_cell.inc), 1 = unit-based
+    gather per slice tile (float2 {V m, m} box, dead-unit shortcut), 0 = wave-per-pixel kernel."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("fwd_mode", fwd_mode)
     run_to_state(dg, "sim")
@@ -610,3 +611,27 @@ def test_cell_scatter_is_bit_identical_from_run_to_run():
         for name, a, b in zip(("recon", "volw", "addon", "cmap"), o, outs[0]):
             assert np.array_equal(a, b, equal_nan=True), (n, name, int((a != b).sum()), float(np.nanmax(np.abs(a - b))))
     assert (outs[0][3] > 0).sum() > 100000
+
+
+@pytest.mark.parametrize("workload", ["tiny", "P4"])
+def test_cell_gather_gives_the_tile_gathers_bits(tiny, workload):
+    """fwd_mode 2 against fwd_mode 1: per unit and per pixel the operations and their order are the same (x taps in order, the
+    DPP tree over a unit's 16 rows, a pixel's units 0 .. 15), so the simulated slices, weights and inside flags are the same
+    bits -- on the tiny problem and on the bench workload."""
+    from fetalreconstruction_amd import engine as E, workloads
+    P = tiny if workload == "tiny" else workloads.get("P4")
+    rec = _engine(P)
+    rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+    rec.InitializeEMValues()
+    rec.GaussianReconstruction()
+    out = {}
+    for mode in (1, 2):
+        rec.set_option("fwd_mode", mode)
+        for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS):
+            rec.debug_set(b, np.zeros(P.slices.shape, np.float32))
+        rec.debug_set(E.BUF_SIMINSIDE, np.zeros(P.slices.shape, np.uint8))
+        inside = rec.SimulateSlices()
+        out[mode] = (rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy(), rec.debug_get(E.BUF_SIMINSIDE).copy(), np.asarray(inside).copy())
+    for a, b in zip(out[1], out[2]):
+        assert np.array_equal(a, b)
+    assert (out[2][1] > 0).sum() > 0.9 * ((P.slices != -1) & (rec.debug_get(E.BUF_PSF_SUMS) != 0)).sum()

@@ -32,7 +32,7 @@ def setup(P, pvr=False, table=False):
 
 OPTS = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}
 sys.argv = [a for a in sys.argv if "=" not in a]
-names = [a for a in sys.argv[1:] if a != "table"] or ["P4"]
+names = [a for a in sys.argv[1:] if a not in ("table", "gather")] or ["P4"]
 table = "table" in sys.argv
 for name in names:
     P = workloads.get(name) if name != "tiny" else phantom.problem_tiny()
@@ -50,6 +50,14 @@ for name in names:
         rec.debug_set(E.BUF_SIMSLICES, np.where(P.slices > 0, P.slices * rng.uniform(0.8, 1.2, P.slices.shape), 0).astype(np.float32))
         rec.debug_set(E.BUF_WEIGHTS, np.where(P.slices != -1, rng.uniform(0.2, 1.0, P.slices.shape), 0).astype(np.float32))
         ms = timed_scatter(rec, P.ns)
+        if "gather" in sys.argv:
+            for fm in (1, 2):
+                rec.set_option("fwd_mode", fm)
+                rec.SimulateSlices(); rec.timer_reset()
+                for _ in range(5):
+                    rec.SimulateSlices()
+                t = rec.timers()["forward"]
+                print(f"[{name}] fwd_mode {fm}: gather {t[0] / t[1]:.3f} ms", flush=True)
         a1, c1 = rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy()
         rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
         a2, c2 = rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy()
