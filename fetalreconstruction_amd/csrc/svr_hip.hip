@@ -361,7 +361,14 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
 #pragma unroll
     EACH p[i] = (f[i] * y[i]) * p[i];
     if (PVR) {
-      // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70)
+      // sinc_pi: Taylor branch below eps^(1/4) instead of the NaN at 0 (pointSpreadFunction.cuh:45-70).  Only a tap within
+      // 0.006 voxels of the PSF centre takes it: the branch (two IEEE divisions per tap) is entered when some lane has one
+      // (round 3: it used to run for every tap and was a third of the patch-based kernels' instructions)
+      // (the test is on q, a superset: pi sqrt(q) < 1.858e-2 needs q < 3.5e-5; q == 0 makes r NaN, which a minimum of r would skip)
+      float qmin = FLT_MAX;
+#pragma unroll
+      EACH qmin = __builtin_fminf(qmin, __builtin_fminf(q[i].x, q[i].y));
+      if (__any(!(qmin >= 4.0e-5f))) {
 #pragma unroll
       EACH {
         for (int c = 0; c < 2; ++c) {
@@ -374,6 +381,7 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
           if (c) p[i].y = (x >= 1.8581361323e-02f) ? p[i].y : t;
           else p[i].x = (x >= 1.8581361323e-02f) ? p[i].x : t;
         }
+      }
       }
     } else {
       // the R = 0 tap: only a pixel that sits exactly on a voxel centre of an aligned slice has one
