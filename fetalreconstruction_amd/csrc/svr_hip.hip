@@ -1738,7 +1738,7 @@ __global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, Ti
         const uint32_t vi = sat0(gx) + sat0(bw.y + loy) * (uint32_t)vg.vx + sat0(bw.z + loz) * sxy;
         // (SVR: the volume word is fetched whether or not the voxel is in the mask -- two independent loads instead of a
         // dependent pair; the PVR texture average is eight loads and stays behind the mask test)
-        if (!GAUSS1 && !PVR && a.volm) {                    // one 8-byte load of the packed pair
+        if (!GAUSS1 && a.volm) {                            // one 8-byte load of the packed pair (PVR: of the texture average)
           const float2 t = a.volm[vi];
           v = (f2){t.x, t.y};
         } else {
@@ -2530,6 +2530,17 @@ __global__ void k_pack_volm(const float *vol, const float *mask, float2 *out, si
   out[i] = make_float2(m != 0.0f ? vol[i] : 0.0f, m);
 }
 
+// the patch-based gather reads the volume through getReconValueFromTexture's 8-voxel average (pvr_tex, reconVolume.cu:170-187):
+// taken once per voxel and pass here instead of once per box voxel of every tile (eight loads each); same operations, same bits
+__global__ void k_pack_volm_pvr(const float *vol, const float *mask, float2 *out, VolGeom vg) {
+  const size_t n = (size_t)vg.vx * vg.vy * vg.vz;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float m = mask[i] != 0.0f ? 1.0f : 0.0f;
+  const int X = (int)(i % (size_t)vg.vx), Y = (int)((i / (size_t)vg.vx) % (size_t)vg.vy), Z = (int)(i / ((size_t)vg.vx * vg.vy));
+  out[i] = make_float2(m != 0.0f ? pvr_tex(vol, vg, X, Y, Z) : 0.0f, m);
+}
+
 __global__ void k_mask_volume(float *recon, const float *mask, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && mask[i] == 0) recon[i] = -1.0f;
@@ -2752,6 +2763,12 @@ struct svr_ctx {
   float *d_mask = nullptr, *d_snap = nullptr, *d_recon_new = nullptr;
   float2 *d_volm = nullptr;   // {V m, m}, refreshed before every SVR forward projection
   bool have_mask = false;
+  // bounding box of mask != 0 (inclusive), from the host copy handed to svr_set_mask: the scatter only ever writes mask voxels,
+  // so a sharded run need not all-reduce the rest of a volume pair (svr_pair_pack / svr_pair_unpack)
+  int mbox_lo[3] = {0, 0, 0}, mbox_hi[3] = {-1, -1, -1};
+  bool mbox_valid = false;
+  float *d_pair_pack = nullptr;
+  size_t pair_pack_cap = 0;
 
   // slice grid
   uint32_t sx = 0, sy = 0, ns = 0;
@@ -3549,7 +3566,7 @@ void svr_destroy(svr_ctx *ctx) {
   (void)hipDeviceSynchronize();
   free_volume(ctx);
   free_slices(ctx);
-  free_dev(ctx->d_mask);
+  free_dev(ctx->d_mask); free_dev(ctx->d_pair_pack);
   free_dev(ctx->d_bias); free_dev(ctx->d_wb); free_dev(ctx->d_wr); free_dev(ctx->d_buffer);
   free_dev(ctx->d_bias_vol); free_dev(ctx->d_volume_weights); free_dev(ctx->d_maskC); free_dev(ctx->d_mbuf);
   free_dev(ctx->d_reg_targets);
@@ -3635,6 +3652,74 @@ int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const
   ctx->have_mask = true;
   ctx->mask_sigma_bias = sigma_bias;
   ctx->maskC_valid = false;
+  {
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
+    const size_t sxy = (size_t)ctx->vx * ctx->vy;
+    for (uint32_t z = 0; z < ctx->vz; ++z)
+      for (uint32_t y = 0; y < ctx->vy; ++y) {
+        const float *row = data + z * sxy + (size_t)y * ctx->vx;
+        int x0 = -1, x1 = -1;
+        for (uint32_t x = 0; x < ctx->vx; ++x)
+          if (row[x] != 0.0f) { if (x0 < 0) x0 = (int)x; x1 = (int)x; }
+        if (x0 >= 0) {
+          lo[0] = std::min(lo[0], x0); hi[0] = std::max(hi[0], x1);
+          lo[1] = std::min(lo[1], (int)y); hi[1] = std::max(hi[1], (int)y);
+          lo[2] = std::min(lo[2], (int)z); hi[2] = std::max(hi[2], (int)z);
+        }
+      }
+    ctx->mbox_valid = hi[0] >= 0;
+    for (int k = 0; k < 3; ++k) { ctx->mbox_lo[k] = lo[k]; ctx->mbox_hi[k] = hi[k]; }
+  }
+  return SVR_OK;
+}
+
+// ---- the part of a volume pair a sharded run has to exchange -------------------------------------------------------------
+__global__ void k_pair_pack(const float *vol, float *packed, int nvols, size_t nv, int vx, int vy, int lx, int ly, int lz, int bx, int by, int bz, int unpack,
+                            float *vol_out) {
+  const size_t nb = (size_t)bx * by * bz;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * nvols) return;
+  const int v = (int)(i / nb);
+  const size_t r = i - (size_t)v * nb;
+  const int z = (int)(r / ((size_t)bx * by)), y = (int)((r / bx) % by), x = (int)(r % bx);
+  const size_t g = (size_t)v * nv + (size_t)(x + lx) + (size_t)(y + ly) * vx + (size_t)(z + lz) * vx * vy;
+  if (unpack) vol_out[g] = packed[i];
+  else packed[i] = vol[g];
+}
+int svr_pair_pack(svr_ctx *ctx, int which, size_t n_floats, void **packed, size_t *n_packed) {
+  SVR_ENTER(ctx);
+  if (!ctx || !packed || !n_packed) return SVR_E_ARG;
+  *packed = nullptr; *n_packed = 0;
+  float *vol = static_cast<float *>(svr_device_ptr(ctx, which));
+  if (!vol || !ctx->mbox_valid || !ctx->nv || n_floats % ctx->nv) return SVR_OK;          // nothing to gain: the caller reduces the whole buffer
+  const int nvols = (int)(n_floats / ctx->nv);
+  const int bx = ctx->mbox_hi[0] - ctx->mbox_lo[0] + 1, by = ctx->mbox_hi[1] - ctx->mbox_lo[1] + 1, bz = ctx->mbox_hi[2] - ctx->mbox_lo[2] + 1;
+  const size_t nb = (size_t)bx * by * bz;
+  if (nb * 5 > ctx->nv * 4) return SVR_OK;                // the box is more than 80 % of the volume: not worth two copies
+  if (nb * nvols > ctx->pair_pack_cap) {
+    free_dev(ctx->d_pair_pack);
+    ctx->pair_pack_cap = 0;
+    HIPCHK(hipMalloc(&ctx->d_pair_pack, nb * nvols * sizeof(float)));
+    ctx->pair_pack_cap = nb * nvols;
+  }
+  hipLaunchKernelGGL(k_pair_pack, dim3(nblk(nb * nvols)), dim3(256), 0, ctx->stream, vol, ctx->d_pair_pack, nvols, ctx->nv, (int)ctx->vx, (int)ctx->vy,
+                     ctx->mbox_lo[0], ctx->mbox_lo[1], ctx->mbox_lo[2], bx, by, bz, 0, (float *)nullptr);
+  KCHK("k_pair_pack");
+  *packed = ctx->d_pair_pack;
+  *n_packed = nb * nvols;
+  return SVR_OK;
+}
+int svr_pair_unpack(svr_ctx *ctx, int which, size_t n_floats) {
+  SVR_ENTER(ctx);
+  if (!ctx) return SVR_E_ARG;
+  float *vol = static_cast<float *>(svr_device_ptr(ctx, which));
+  NEED(vol && ctx->mbox_valid && ctx->d_pair_pack && ctx->nv && n_floats % ctx->nv == 0, "svr_pair_pack first");
+  const int nvols = (int)(n_floats / ctx->nv);
+  const int bx = ctx->mbox_hi[0] - ctx->mbox_lo[0] + 1, by = ctx->mbox_hi[1] - ctx->mbox_lo[1] + 1, bz = ctx->mbox_hi[2] - ctx->mbox_lo[2] + 1;
+  const size_t nb = (size_t)bx * by * bz;
+  hipLaunchKernelGGL(k_pair_pack, dim3(nblk(nb * nvols)), dim3(256), 0, ctx->stream, (const float *)nullptr, ctx->d_pair_pack, nvols, ctx->nv, (int)ctx->vx,
+                     (int)ctx->vy, ctx->mbox_lo[0], ctx->mbox_lo[1], ctx->mbox_lo[2], bx, by, bz, 1, vol);
+  KCHK("k_pair_unpack");
   return SVR_OK;
 }
 
@@ -3950,6 +4035,11 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
     if (!ctx->d_volm) HIPCHK(hipMalloc(&ctx->d_volm, ctx->nv * sizeof(float2)));
     hipLaunchKernelGGL(k_pack_volm, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_mask, ctx->d_volm, ctx->nv);
     KCHK("k_pack_volm");
+    a.volm = ctx->d_volm;
+  } else if (ctx->pvr && ctx->pvr_mode == 1 && a.n) {
+    if (!ctx->d_volm) HIPCHK(hipMalloc(&ctx->d_volm, ctx->nv * sizeof(float2)));
+    hipLaunchKernelGGL(k_pack_volm_pvr, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_mask, ctx->d_volm, a.vg);
+    KCHK("k_pack_volm_pvr");
     a.volm = ctx->d_volm;
   }
   // fwd_mode 2 (the default for SVR on the fly): the gather over the (cell, plane) items of the scatter without atomics
@@ -4438,7 +4528,8 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   HIPCHK(hipMemcpyAsync(p, host_in, b, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
-  if (which == SVR_BUF_SLICES) ctx->coeff_valid = false; cell_invalidate(ctx);   // the table covers the pixels with s != -1
+  if (which == SVR_BUF_SLICES) { ctx->coeff_valid = false; cell_invalidate(ctx); }   // the table and the cell lists cover the pixels with s != -1
+  if (which == SVR_BUF_MASK) ctx->mbox_valid = false;                               // (a mask set behind svr_set_mask's back: the whole pair is exchanged)
   if (which == SVR_BUF_SLICES) return build_list(ctx, false);
   return SVR_OK;
 }

@@ -36,8 +36,18 @@ struct Shard {
   int allreduce_pair(int buffer, size_t n_floats) {
     int rc = svr_timer_begin(e, SVR_T_ALLREDUCE);
     if (rc) return rc;
-    rc = coll.allreduce_volume_pair(coll.user, svr_device_ptr(e, buffer), n_floats);
-    if (rc) return rc;
+    // only the mask's bounding box travels (the scatter writes mask voxels only: 47 % of the S8 volume; two device copies of
+    // the box against half of a 320 MB ring all-reduce); the whole buffer where that gains nothing
+    void *packed = nullptr;
+    size_t n_packed = 0;
+    if ((rc = svr_pair_pack(e, buffer, n_floats, &packed, &n_packed))) return rc;
+    if (packed) {
+      if ((rc = coll.allreduce_volume_pair(coll.user, packed, n_packed))) return rc;
+      if ((rc = svr_pair_unpack(e, buffer, n_floats))) return rc;
+    } else {
+      rc = coll.allreduce_volume_pair(coll.user, svr_device_ptr(e, buffer), n_floats);
+      if (rc) return rc;
+    }
     return svr_timer_end(e, SVR_T_ALLREDUCE);
   }
 

@@ -142,9 +142,9 @@ class irtkReconstruction:
             def ar_pair(user, ptr, n):
                 try:
                     from .reconstruction import _device_view
-                    if ptr not in self._views:
-                        self._views[ptr] = _device_view(comm.torch, ptr, n, comm.device)
-                    comm.dist.all_reduce(self._views[ptr], op=comm.dist.ReduceOp.SUM)
+                    if (ptr, n) not in self._views:
+                        self._views[(ptr, n)] = _device_view(comm.torch, ptr, n, comm.device)
+                    comm.dist.all_reduce(self._views[(ptr, n)], op=comm.dist.ReduceOp.SUM)
                     comm.torch.cuda.synchronize()
                     return 0
                 except Exception as ex:      # never let an exception cross the C boundary

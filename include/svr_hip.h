@@ -178,6 +178,12 @@ int svr_debug_probe_pixel(svr_ctx *ctx, int slice, int px, int py, float *vals40
 /* device pointer of a buffer; ADDON is followed contiguously by CONFIDENCE_MAP, and
  * RECONSTRUCTED by VOL_WEIGHTS, so each pair all-reduces as one float[2*Nvox] message */
 void *svr_device_ptr(svr_ctx *ctx, int which);
+/* Sharded runs: the scatter only ever writes voxels of the mask, so the ranks need not exchange the rest of a volume pair.
+ * svr_pair_pack copies the mask's bounding box of the n_floats / Nv volumes at svr_device_ptr(ctx, which) into a contiguous device
+ * buffer (*packed, *n_packed floats) on the engine's stream; the caller all-reduces that buffer in place and calls svr_pair_unpack.
+ * *packed == NULL: nothing to gain (no mask box, or the box is more than 80 % of the volume) -- reduce the whole buffer. */
+int svr_pair_pack(svr_ctx *ctx, int which, size_t n_floats, void **packed, size_t *n_packed);
+int svr_pair_unpack(svr_ctx *ctx, int which, size_t n_floats);
 size_t svr_volume_voxels(const svr_ctx *ctx);
 /* run all kernels on this hipStream_t (e.g. the caller's torch stream); NULL = default */
 int svr_set_stream(svr_ctx *ctx, void *hip_stream);

@@ -134,3 +134,40 @@ def test_bench_pvr_workload_through_the_sharded_path():
     assert k["backproject_ms"][0] > 0 and k["forward_ms"][0] > 0 and k["allreduce_ms"][0] > 0 and k["exchange_host_ms"][0] > 0
     assert k["exchanges_per_step"][0] == 2.0                 # M-step, E-step (the scale vector rides along)
     assert set(a["config"]["tuned"]) >= {"gather_tile", "scatter_tile", "scatter_box"}
+
+
+@pytest.mark.gpu
+def test_only_the_masks_bounding_box_is_exchanged(tiny):
+    """A sharded run all-reduces the mask's bounding box of a volume pair, not the pair (svr_pair_pack / svr_pair_unpack,
+    csrc/svr_shard.h): the scatter only ever writes mask voxels.  On the tiny problem the box is 56 % of the volume: pack ->
+    (the collective would run on the packed buffer) -> unpack gives the pair back bit for bit, and nothing outside the box is
+    non-zero to begin with."""
+    import ctypes as C
+    import numpy as np
+    from fetalreconstruction_amd import engine as E
+    rec = E.Reconstruction(0)
+    E.sync_gpu(rec, tiny)
+    ones = np.ones(tiny.ns, np.float32)
+    rec.UpdateScaleVector(ones, ones)
+    rec.InitializeEMValues()
+    rec.GaussianReconstruction()
+    rec.SimulateSlices()
+    rec.debug_set(E.BUF_WEIGHTS, np.where(tiny.slices != -1, 0.5, 0).astype(np.float32))
+    rec.SuperresolutionBackproject(ones)
+    a0, c0 = rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy()
+    vx, vy, vz = tiny.vsize
+    m = tiny.mask.reshape(vz, vy, vx) > 0
+    nzv = np.argwhere(m)
+    lo, hi = nzv.min(0), nzv.max(0)
+    box = np.zeros_like(m)
+    box[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] = True
+    assert (a0.reshape(vz, vy, vx)[~box] == 0).all() and (c0.reshape(vz, vy, vx)[~box] == 0).all() and (c0 > 0).sum() > 1000
+    ptr, n = C.c_void_p(), C.c_size_t()
+    rec._ck(rec._lib.svr_pair_pack(rec._h, E.BUF_ADDON, C.c_size_t(2 * tiny.nvox), C.byref(ptr), C.byref(n)))
+    assert ptr.value and n.value == 2 * int(box.sum()) and n.value < 0.8 * 2 * tiny.nvox
+    rec.debug_set(E.BUF_ADDON, np.full(tiny.nvox, 7.0, np.float32))        # (what unpack must overwrite inside the box)
+    rec._ck(rec._lib.svr_pair_unpack(rec._h, E.BUF_ADDON, C.c_size_t(2 * tiny.nvox)))
+    a1, c1 = rec.debug_get(E.BUF_ADDON), rec.debug_get(E.BUF_CONFIDENCE_MAP)
+    assert np.array_equal(a1.reshape(vz, vy, vx)[box], a0.reshape(vz, vy, vx)[box]) and np.array_equal(c1, c0)
+    assert (a1.reshape(vz, vy, vx)[~box] == 7.0).all()
+    rec.close()
