@@ -46,6 +46,7 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")     # written 
                                                                       # per pass: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
 VALU_ISSUE_PER_S = 0.6e9     # wave-instructions a SIMD issues per second: 2.4 GHz / 4 cycles per 64-lane instruction
+SR_PER_OUTER = 4             # rec_iterations_first (reconstruction.cc:115,187): SR iterations per outer iteration
 METRIC = "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR, 1/2/4/8 GPU"
 
 
@@ -272,8 +273,31 @@ def main():
     # SimulateSlicesGPU above, this untimed scatter keeps the other one out of the timed region whatever --warmup is (it
     # only writes addon|cmap and the slice weights, which every SR iteration rebuilds / uploads)
     rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
+
+    # The steps follow the reference's schedule: an outer iteration re-initialises the EM state and runs rec_iterations_first
+    # = 4 SR iterations (reconstruction.cc:115,187,930-1001,1013; irtkPatchBasedReconstruction.cpp:490-504).  Run on without
+    # that, the slice-level EM of this workload drops more and more slices (12 of 280 after 2 SR iterations, 117 after 24, 236
+    # after 46: tools/check_bench_drift.py) and with them their pixels from the scatter -- a step that gets cheaper the later it
+    # is timed.  So every SR_PER_OUTER steps (warm-up and timed alike, by the running step count) the EM part of the outer
+    # iteration's preamble runs INSIDE the timed region: InitializeEMValues, InitializeRobustStatistics, EStep -- three small
+    # kernels and one host exchange; the volume carries on (registration + Gaussian reconstruction are not part of the metric).
+    def em_reinit():
+        if pvr:
+            drv.initializeEMValues(); drv.InitializeRobustStatistics(); drv.EStep()
+        else:
+            drv.InitializeEMValuesGPU(); drv.InitializeRobustStatisticsGPU(); drv.EStepGPU()
+
+    done = [0]
+
+    def step():
+        k = done[0] % SR_PER_OUTER
+        if done[0] and k == 0:
+            em_reinit()
+        drv.sr_iteration(k)
+        done[0] += 1
+
     for i in range(args.warmup):
-        drv.sr_iteration(i)
+        step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -286,7 +310,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        drv.sr_iteration(args.warmup + i)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     timers = rec.timers()
@@ -329,14 +353,16 @@ def main():
             rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
             build_ms = rec.timers()["coeff_build"][0]
             rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
+            done[0] = 0                                           # the same schedule from the same EM state as above
+            em_reinit()
             for i in range(args.warmup):
-                drv.sr_iteration(args.warmup + args.steps + i)
+                step()
             on = rec.get_option("coeff_table") == 1               # it switches itself off when it does not fit the free memory
             rec.timer_reset()
             barrier()
             t1 = time.perf_counter()
             for i in range(args.steps):
-                drv.sr_iteration(2 * args.warmup + args.steps + i)
+                step()
             barrier()
             dt2 = time.perf_counter() - t1
             tm2 = rec.timers()
@@ -425,6 +451,9 @@ def main():
                                    + (" -- patch-to-volume loop (BASELINE configs[2]: 32x32 patches, stride 16)" if prob.name == "PVR4" else "")
                                    + (" -- patch-to-volume loop (BASELINE configs[4]: superpixel patches, --spxSize 32 --spxExtend 2)" if prob.name == "PVR8spx" else ""),
                        "Vs": vs, "Va_rank0": va_l, "Va_total": va, "Nv": nv, "slices": prob.ns,
+                       "schedule": f"outer iterations of {SR_PER_OUTER} SR iterations (rec_iterations_first, reconstruction.cc:115,187): every "
+                                   f"{SR_PER_OUTER} steps InitializeEMValues + InitializeRobustStatistics + EStep run inside the timed region, so that "
+                                   "the slices the EM drops do not pile up from step to step (24 steps on: 117 of 280 slices at weight 0)",
                        "parallelism": f"{'patch' if pvr else 'slice'}-sharded x{world}, 1 in-place RCCL all-reduce of addon|cmap (float[2 Nv]) per scatter pass"
                                       if world > 1 else "1 GPU",
                        "comm": (args.comm if multi else None), "rccl_world": rccl_world,

@@ -2924,12 +2924,12 @@ int fail(svr_ctx *c, int code, const std::string &msg) {
     if (!(cond)) return fail(ctx, SVR_E_STATE, std::string(__func__) + ": " + what);      \
   } while (0)
 
-// The scatter variant in effect: the cell-owned scatter (5) is the default for SVR with the taps evaluated on the fly; the
-// patch-based path (runs of a dozen pixels per patch and cell: 22.0 against 20.3 ms on PVR4) and the coefficient table (its
-// pass waits for memory and needs the deeper request pipeline of back_wave_kernel) take the wave-owned scatter with the
-// atomic flush (4) unless the caller named a mode.
+// The scatter variant in effect: the cell-owned scatter (5) is the default for SVR and for every run with the coefficient
+// table (P4 table 4.63 -> 3.59 ms, PVR4 table 10.4 -> 8.5 ms against the wave-owned scatter); patches evaluated on the fly
+// (runs of a dozen pixels per patch and cell: 11.45 against 11.35 ms on PVR4, 38.3 against 36.6 ms on PVR8spx) take the
+// wave-owned scatter with the atomic flush (4) unless the caller named a mode.
 inline int back_mode_eff(const svr_ctx *ctx) {
-  if (ctx->back_mode == 5 && !ctx->back_mode_user && (ctx->pvr || ctx->coeff_mode)) return 4;
+  if (ctx->back_mode == 5 && !ctx->back_mode_user && ctx->pvr && !ctx->coeff_mode) return 4;   // patches on the fly: a tie (PVR4) or a loss (PVR8spx)
   return ctx->back_mode;
 }
 void reg_free(RegState *r);

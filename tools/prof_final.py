@@ -94,8 +94,9 @@ def main():
         e["forward"] = collect(v, ("fwd_cell_kernel<%s, %s>" % (nsup, isp), "k_cell_gather_finish", "k_cell_gfactors")) or collect(v, ("fwd_unit_kernel<false, %s, %s, false>" % (nsup, isp),))
         traffic[wl] = {k: x for k, x in e.items() if x}
     vt = pmc("P4", "p4_table", ("coeff_table=1",))           # the COEFF instantiations streaming the coefficient table
-    for key, pat in (("back_table", "back_wave_kernel<16, false, true"), ("forward_table", "fwd_unit_kernel<false, 16, false, true")):
-        x = collect(vt, (pat,))
+    for key, pats in (("back_table", ("back_cell_kernel<16, false, true", "k_cell_combine", "k_cell_factors")),
+                      ("forward_table", ("fwd_unit_kernel<false, 16, false, true",))):
+        x = collect(vt, pats) or (collect(vt, ("back_wave_kernel<16, false, true",)) if key == "back_table" else None)
         if x:
             traffic["P4"][key] = x
     if traffic.get("P4", {}).get("back"):
