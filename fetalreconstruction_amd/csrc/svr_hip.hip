@@ -2783,6 +2783,15 @@ struct svr_ctx {
   unsigned char *d_slice_inside = nullptr;
   std::vector<float> h_scales, h_slice_weights;   // RC.cu:1345-1346
   bool have_scales = false;
+  // per-slice vectors go up through pinned slots without a stream synchronisation (upload_ns); what each device vector holds
+  // is mirrored on the host, and a vector that is already there is not sent again (the SR loop sends the slice weights twice
+  // and the previous scale vector once per iteration: RC.cu:2123, 3238)
+  static constexpr int UP_SLOTS = 4;
+  float *h_up = nullptr;                          // [UP_SLOTS][ns], pinned
+  hipEvent_t up_ev[UP_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  bool up_busy[UP_SLOTS] = {false, false, false, false};
+  int up_next = 0;
+  std::vector<float> mir_scales, mir_slice_weights, mir_scales_copy;
 
   // geometry
   std::vector<float> slice_dims;   // ns*3
@@ -2884,7 +2893,13 @@ struct svr_ctx {
 
   // timers
   bool timers = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;        // tile tuning
+  // kernel timers: event pairs are recorded on the stream and read back later (svr_timer_get / reset / every TIMER_BATCH
+  // pairs) -- timing a pass does not synchronise the stream
+  struct TimedSpan { int which; hipEvent_t a, b; };
+  std::vector<hipEvent_t> ev_free;
+  std::vector<TimedSpan> ev_pending;
+  hipEvent_t ev_open = nullptr;                   // svr_timer_begin .. svr_timer_end
   double t_ms[SVR_T_COUNT] = {0};
   long t_n[SVR_T_COUNT] = {0};
 
@@ -2942,21 +2957,48 @@ void free_dev(T *&p) {
   p = nullptr;
 }
 
+constexpr size_t TIMER_BATCH = 256;
+inline hipEvent_t timer_event(svr_ctx *c) {
+  if (!c->ev_free.empty()) { hipEvent_t e = c->ev_free.back(); c->ev_free.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+// the recorded pairs -> t_ms / t_n (waits for the last one)
+inline void timers_resolve(svr_ctx *c) {
+  for (const auto &sp : c->ev_pending) {
+    float ms = 0;
+    if (sp.a && sp.b && hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      c->t_ms[sp.which] += ms;
+      c->t_n[sp.which] += 1;
+    }
+    if (sp.a) c->ev_free.push_back(sp.a);
+    if (sp.b) c->ev_free.push_back(sp.b);
+  }
+  c->ev_pending.clear();
+}
+inline void timer_close(svr_ctx *c, int which, hipEvent_t a) {
+  hipEvent_t b = timer_event(c);
+  if (b) (void)hipEventRecord(b, c->stream);
+  c->ev_pending.push_back({which, a, b});
+  if (c->ev_pending.size() >= TIMER_BATCH) timers_resolve(c);
+}
 struct ScopedTimer {
   svr_ctx *c;
   int which;
+  hipEvent_t a = nullptr;
   ScopedTimer(svr_ctx *c_, int w) : c(c_), which(w) {
-    if (c->timers) (void)hipEventRecord(c->ev0, c->stream);
+    if (c->timers) {
+      a = timer_event(c);
+      if (a) (void)hipEventRecord(a, c->stream);
+    }
   }
   void stop() {
-    if (c->timers) {
-      (void)hipEventRecord(c->ev1, c->stream);
-      (void)hipEventSynchronize(c->ev1);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-      c->t_ms[which] += ms;
-      c->t_n[which] += 1;
-    }
+    if (a) timer_close(c, which, a);
+    a = nullptr;
+  }
+  ~ScopedTimer() {                                  // an error path left before stop(): the event goes back unused
+    if (a) c->ev_free.push_back(a);
   }
 };
 
@@ -2973,6 +3015,12 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_slices); free_dev(c->d_weights); free_dev(c->d_simslices); free_dev(c->d_simweights);
   free_dev(c->d_psf_sums); free_dev(c->d_siminside); free_dev(c->d_voxcount); free_dev(c->d_scales);
   free_dev(c->d_slice_weights); free_dev(c->d_scales_host_copy); free_dev(c->d_tmp_ns);
+  c->mir_scales.clear(); c->mir_slice_weights.clear(); c->mir_scales_copy.clear();
+  if (c->h_up) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->h_up); c->h_up = nullptr; }
+  for (int k = 0; k < svr_ctx::UP_SLOTS; ++k) {
+    if (c->up_ev[k]) { (void)hipEventDestroy(c->up_ev[k]); c->up_ev[k] = nullptr; }
+    c->up_busy[k] = false;
+  }
   free_dev(c->d_slice_inside); free_dev(c->d_sc); free_dev(c->d_active); free_dev(c->d_psf_list);
   free_dev(c->d_tiles);
   free_dev(c->d_tiles_fwd);
@@ -3395,9 +3443,24 @@ int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
   return SVR_OK;
 }
 
-int upload_ns(svr_ctx *ctx, float *dst, const float *src) {
-  HIPCHK(hipMemcpyAsync(dst, src, ctx->ns * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+// a per-slice vector to the device, asynchronously: through a pinned slot (the caller's memory is free again on return), no
+// stream synchronisation; `mirror` = what the device vector holds, an identical vector is not sent again
+int upload_ns(svr_ctx *ctx, float *dst, const float *src, std::vector<float> &mirror) {
+  const size_t n = ctx->ns;
+  if (mirror.size() == n && !memcmp(mirror.data(), src, n * sizeof(float))) return SVR_OK;
+  if (!ctx->h_up) {
+    HIPCHK(hipHostMalloc((void **)&ctx->h_up, (size_t)svr_ctx::UP_SLOTS * n * sizeof(float), hipHostMallocDefault));
+    for (int k = 0; k < svr_ctx::UP_SLOTS; ++k) HIPCHK(hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming));
+  }
+  const int k = ctx->up_next;
+  ctx->up_next = (k + 1) % svr_ctx::UP_SLOTS;
+  if (ctx->up_busy[k]) HIPCHK(hipEventSynchronize(ctx->up_ev[k]));       // the copy that last used the slot (long done)
+  float *slot = ctx->h_up + (size_t)k * n;
+  memcpy(slot, src, n * sizeof(float));
+  HIPCHK(hipMemcpyAsync(dst, slot, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->up_ev[k], ctx->stream));
+  ctx->up_busy[k] = true;
+  mirror.assign(src, src + n);
   return SVR_OK;
 }
 
@@ -3579,6 +3642,10 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
+  timers_resolve(ctx);
+  if (ctx->ev_open) (void)hipEventDestroy(ctx->ev_open);
+  for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
+  ctx->ev_free.clear();
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -3839,9 +3906,9 @@ int svr_update_scale_vector(svr_ctx *ctx, const float *scales, const float *slic
   NEED(ctx->ns > 0, "initStorageVolumes first");
   ctx->h_scales.assign(scales, scales + ctx->ns);
   ctx->h_slice_weights.assign(slice_weights, slice_weights + ctx->ns);
-  int r = upload_ns(ctx, ctx->d_scales, scales);
+  int r = upload_ns(ctx, ctx->d_scales, scales, ctx->mir_scales);
   if (r) return r;
-  r = upload_ns(ctx, ctx->d_slice_weights, slice_weights);
+  r = upload_ns(ctx, ctx->d_slice_weights, slice_weights, ctx->mir_slice_weights);
   if (r) return r;
   ctx->have_scales = true;
   return SVR_OK;
@@ -3852,7 +3919,7 @@ int svr_update_slice_weights(svr_ctx *ctx, const float *slice_weights) {
   if (!ctx || !slice_weights) return SVR_E_ARG;
   NEED(ctx->have_scales, "UpdateScaleVector first");
   ctx->h_slice_weights.assign(slice_weights, slice_weights + ctx->ns);
-  return upload_ns(ctx, ctx->d_slice_weights, slice_weights);
+  return upload_ns(ctx, ctx->d_slice_weights, slice_weights, ctx->mir_slice_weights);
 }
 
 int svr_update_reconstructed(svr_ctx *ctx, const uint32_t size[3], const float *data) {
@@ -4192,7 +4259,7 @@ int svr_mstep_sums(svr_ctx *ctx, double out5[5]) {
   if (!ctx || !out5) return SVR_E_ARG;
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   // the reference fills its per-pixel scale buffer from the HOST copy h_scales (RC.cu:3091-3094)
-  int r = upload_ns(ctx, ctx->d_scales_host_copy, ctx->h_scales.data());
+  int r = upload_ns(ctx, ctx->d_scales_host_copy, ctx->h_scales.data(), ctx->mir_scales_copy);
   if (r) return r;
   ScopedTimer t(ctx, SVR_T_MSTEP);
   hipLaunchKernelGGL(k_mstep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
@@ -4247,7 +4314,7 @@ int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
   // scale vector -- to the device (RC.cu:3238) and only afterwards h_scales = scale_vec
   // (RC.cu:3195).  The E-step / back-projection kernels therefore see scales that lag one call
   // behind; the M-step reads h_scales (RC.cu:3093) and sees the new ones.
-  r = upload_ns(ctx, ctx->d_scales, ctx->h_scales.data());
+  r = upload_ns(ctx, ctx->d_scales, ctx->h_scales.data(), ctx->mir_scales);
   if (r) return r;
   ctx->h_scales.assign(scale_vec, scale_vec + ctx->ns);
   return SVR_OK;
@@ -4770,18 +4837,21 @@ int svr_ncc_evaluate(svr_ctx *ctx, int n_eval, const int *target_index, const do
 int svr_timer_enable(svr_ctx *ctx, int enable) {
   SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
+  timers_resolve(ctx);
   ctx->timers = enable != 0;
   return SVR_OK;
 }
 int svr_timer_reset(svr_ctx *ctx) {
   SVR_ENTER(ctx);
   if (!ctx) return SVR_E_ARG;
+  timers_resolve(ctx);
   for (int i = 0; i < SVR_T_COUNT; ++i) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
   return SVR_OK;
 }
 int svr_timer_get(svr_ctx *ctx, int which, double *ms_total, long *launches) {
   SVR_ENTER(ctx);
   if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
+  timers_resolve(ctx);
   if (ms_total) *ms_total = ctx->t_ms[which];
   if (launches) *launches = ctx->t_n[which];
   return SVR_OK;
@@ -4802,19 +4872,18 @@ int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]) {
 int svr_timer_begin(svr_ctx *ctx, int which) {
   SVR_ENTER(ctx);
   if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
-  if (ctx->timers) HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->timers) {
+    if (!ctx->ev_open) ctx->ev_open = timer_event(ctx);
+    if (ctx->ev_open) HIPCHK(hipEventRecord(ctx->ev_open, ctx->stream));
+  }
   return SVR_OK;
 }
 int svr_timer_end(svr_ctx *ctx, int which) {
   SVR_ENTER(ctx);
   if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;
-  if (ctx->timers) {
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipEventSynchronize(ctx->ev1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->t_ms[which] += ms;
-    ctx->t_n[which] += 1;
+  if (ctx->timers && ctx->ev_open) {
+    timer_close(ctx, which, ctx->ev_open);
+    ctx->ev_open = nullptr;
   }
   return SVR_OK;
 }
