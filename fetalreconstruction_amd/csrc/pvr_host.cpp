@@ -64,6 +64,7 @@ class irtkPatchBasedReconstruction {
   static float G_(float x, float s) { return 0.00001f * expf(-x * x / (2.0f * s)) / sqrtf(6.28f * s); }   // PRS.cu:97-101
 
   int initializeEMValues() {                                                 // PRS.cu:78-95
+    if (int rc = settle()) return rc;
     scale.assign(n, 1.0f);
     patch_weight.assign(n, 1.0f);
     PENG(svr_update_scale_vector(e, scale.data() + lo, patch_weight.data() + lo));
@@ -78,13 +79,31 @@ class irtkPatchBasedReconstruction {
     scale_stale = false;
     return 0;
   }
+  // One rank: the scale vector and the M-step's scalars stay on the device until the E-step fetches them with its
+  // potentials in one wait (svr_mstep_estep); `settle` brings them over for anything else that reads them.
+  bool scale_pending = false;
+  int mstep_pending = 0;
+  int settle() {
+    if (mstep_pending) {
+      const int iter = mstep_pending;
+      mstep_pending = 0;
+      if (int rc = MStepNow(iter)) return rc;
+    }
+    if (scale_pending) {
+      PENG(svr_get_scale_vector(e, scale.data() + lo));
+      scale_pending = false;
+    }
+    return 0;
+  }
   int flush() {
+    if (int rc = settle()) return rc;
     if (!sh.on || !scale_stale) return 0;
     std::vector<double> none;
     return exchange(nullptr, 0, none, nullptr);
   }
 
   int InitializeRobustStatistics() {                                         // PRS.cu:793-845
+    if (int rc = settle()) return rc;
     double s2[2];
     PENG(svr_robust_statistics_sums(e, s2));
     if (sh.on) {
@@ -104,7 +123,17 @@ class irtkPatchBasedReconstruction {
 
   int EStep() {                                                              // PRS.cu:224-556
     std::vector<float> pot(n, 0.0f);
-    PENG(svr_estep(e, m_m_gpu, m_sigma_gpu, m_mix_gpu, pot.data() + lo));
+    if (mstep_pending) {                             // one rank: M-step + E-step + the scale vector, one wait for the device
+      const int iter = mstep_pending;
+      mstep_pending = 0;
+      float em3[3] = {m_sigma_gpu, m_mix_gpu, m_m_gpu};
+      PENG(svr_mstep_estep(e, iter, m_step, em3, pot.data() + lo, scale_pending ? scale.data() + lo : nullptr, nullptr));
+      m_sigma_gpu = em3[0]; m_mix_gpu = em3[1]; m_m_gpu = em3[2];
+      scale_pending = false;
+    } else {
+      if (int rc = settle()) return rc;
+      PENG(svr_estep(e, m_m_gpu, m_sigma_gpu, m_mix_gpu, pot.data() + lo));
+    }
     if (sh.on) { std::vector<double> none; if (int rc = exchange(nullptr, 0, none, &pot)) return rc; }   // (and the scale vector)
     std::vector<float> pp(n, 0.0f);
     int ofs = 0;
@@ -174,6 +203,14 @@ class irtkPatchBasedReconstruction {
   }
 
   int MStep(int iter) {                                                      // PRS.cu:570-640
+    if (!sh.on && iter > 0) {
+      if (int rc = settle()) return rc;
+      mstep_pending = iter;                          // runs with the E-step that follows (PBR.cpp:540-545), or in settle
+      return 0;
+    }
+    return MStepNow(iter);
+  }
+  int MStepNow(int iter) {
     double s5[5];
     PENG(svr_mstep_sums(e, s5));
     if (sh.on) {
@@ -195,6 +232,12 @@ class irtkPatchBasedReconstruction {
   }
 
   int Scale() {                                                              // PRS.cu:672-745
+    if (!sh.on) {
+      PENG(svr_calculate_scale_vector(e, nullptr));
+      PENG(svr_adopt_scale_vector(e));                                       // copyToScales: no lag
+      scale_pending = true;
+      return 0;
+    }
     PENG(svr_calculate_scale_vector(e, scale.data() + lo));
     PENG(svr_update_scale_vector(e, scale.data() + lo, patch_weight.data() + lo));     // copyToScales: no lag
     scale_stale = sh.on;                                                     // read next in the E-step, whose exchange completes it
@@ -222,8 +265,7 @@ class irtkPatchBasedReconstruction {
       PENG(sh.allreduce_pair(SVR_BUF_RECONSTRUCTED, 2 * svr_volume_voxels(e)));
       PENG(svr_gaussian_reconstruction_finish(e, &nvox));
     }
-    std::vector<unsigned char> inside(hi - lo);
-    PENG(svr_simulate_slices(e, inside.data()));
+    PENG(svr_simulate_slices(e, nullptr));          // (the patch-based loop never reads the inside flags: no wait)
     if ((rc = InitializeRobustStatistics())) return rc;
     if ((rc = EStep())) return rc;
     for (int i = 0; i < rec_iterations; ++i) {
@@ -235,7 +277,6 @@ class irtkPatchBasedReconstruction {
   // one SR iteration (PBR.cpp:505-546): Scale, resetAddonCmap + run + regularize, simulate, M-step, E-step
   int sr_iteration(int i) {
     int rc;
-    std::vector<unsigned char> inside(hi - lo);
     {
       if ((rc = Scale())) return rc;
       if (!sh.on) {
@@ -246,7 +287,7 @@ class irtkPatchBasedReconstruction {
         PENG(sh.allreduce_pair(SVR_BUF_ADDON, 2 * svr_volume_voxels(e)));
         PENG(svr_superresolution_update(e, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta, m_lambda));
       }
-      PENG(svr_simulate_slices(e, inside.data()));
+      PENG(svr_simulate_slices(e, nullptr));
       if ((rc = MStep(i + 1))) return rc;
       if ((rc = EStep())) return rc;
     }
@@ -277,7 +318,7 @@ pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, i
   if (coll && coll->world > 1 && (!coll->allreduce_volume_pair || !coll->allreduce_host)) return nullptr;
   return new pvrh_recon(engine, patches_per_stack, n_stacks, min_intensity, max_intensity, patch_lo, patch_hi, coll);
 }
-void pvrh_force_collectives(pvrh_recon *r, int on) { if (r) r->impl.sh.force(on != 0); }
+void pvrh_force_collectives(pvrh_recon *r, int on) { if (r) { (void)r->impl.settle(); r->impl.sh.force(on != 0); } }
 int pvrh_sr_iteration(pvrh_recon *r, int i) { return r->impl.sr_iteration(i); }
 void pvrh_destroy(pvrh_recon *r) { delete r; }
 const char *pvrh_last_error(const pvrh_recon *r) { return r ? r->impl.err.c_str() : "null"; }

@@ -2240,7 +2240,8 @@ __global__ void k_init_em(const float *slices, float *weights, size_t n, int pvr
 __global__ __launch_bounds__(256) void k_estep(const float *slices, const float *simslices,
                                                const float *simweights, const float *scales,
                                                const float *bias, float m_, float sigma_, float mix_, int n2,
-                                               float *weights, double *partial, int pvr) {
+                                               float *weights, double *partial, int pvr, const float *em) {
+  if (em) { sigma_ = em[0]; mix_ = em[1]; m_ = em[2]; }   // svr_mstep_estep: the M-step's scalars never left the device
   const int sl = blockIdx.y;
   const float scale = scales[sl];
   if (pvr) {
@@ -2781,7 +2782,7 @@ struct svr_ctx {
   float *d_scales = nullptr, *d_slice_weights = nullptr, *d_scales_host_copy = nullptr,
         *d_tmp_ns = nullptr;
   unsigned char *d_slice_inside = nullptr;
-  std::vector<float> h_scales, h_slice_weights;   // RC.cu:1345-1346
+  std::vector<float> h_slice_weights;             // RC.cu:1346.  h_scales (RC.cu:1345) lives on the device: d_scales_host_copy
   bool have_scales = false;
   // per-slice vectors go up through pinned slots without a stream synchronisation (upload_ns); what each device vector holds
   // is mirrored on the host, and a vector that is already there is not sent again (the SR loop sends the slice weights twice
@@ -2792,6 +2793,13 @@ struct svr_ctx {
   bool up_busy[UP_SLOTS] = {false, false, false, false};
   int up_next = 0;
   std::vector<float> mir_scales, mir_slice_weights, mir_scales_copy;
+  // small results come down through one pinned arena: the copies are queued on the stream, ONE synchronisation, then they
+  // are handed to the caller's memory (down_queue / down_flush)
+  unsigned char *h_down = nullptr;
+  size_t down_cap = 0, down_used = 0;
+  struct DownItem { void *dst; size_t off, bytes; };
+  std::vector<DownItem> down_items;
+  float *d_em = nullptr;                          // {sigma, mix, m} of the fused M-step + E-step (svr_mstep_estep)
 
   // geometry
   std::vector<float> slice_dims;   // ns*3
@@ -3017,6 +3025,8 @@ void free_slices(svr_ctx *c) {
   free_dev(c->d_slice_weights); free_dev(c->d_scales_host_copy); free_dev(c->d_tmp_ns);
   c->mir_scales.clear(); c->mir_slice_weights.clear(); c->mir_scales_copy.clear();
   if (c->h_up) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->h_up); c->h_up = nullptr; }
+  if (c->h_down) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->h_down); c->h_down = nullptr; c->down_cap = c->down_used = 0; c->down_items.clear(); }
+  free_dev(c->d_em);
   for (int k = 0; k < svr_ctx::UP_SLOTS; ++k) {
     if (c->up_ev[k]) { (void)hipEventDestroy(c->up_ev[k]); c->up_ev[k] = nullptr; }
     c->up_busy[k] = false;
@@ -3464,6 +3474,32 @@ int upload_ns(svr_ctx *ctx, float *dst, const float *src, std::vector<float> &mi
   return SVR_OK;
 }
 
+// queue a small device -> host copy; nothing is in `dst` before down_flush
+int down_queue(svr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  const size_t need = ctx->down_used + ((bytes + 63) & ~(size_t)63);
+  if (need > ctx->down_cap) {
+    if (!ctx->down_items.empty()) return fail(ctx, SVR_E_STATE, "down_queue: arena too small for the queued copies");
+    const size_t cap = std::max<size_t>(need, (size_t)ctx->ns * 12 + 4096);
+    if (ctx->h_down) HIPCHK(hipHostFree(ctx->h_down));
+    ctx->h_down = nullptr; ctx->down_cap = 0;
+    HIPCHK(hipHostMalloc((void **)&ctx->h_down, cap, hipHostMallocDefault));
+    ctx->down_cap = cap;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->h_down + ctx->down_used, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->down_items.push_back({dst, ctx->down_used, bytes});
+  ctx->down_used = need;
+  return SVR_OK;
+}
+int down_flush(svr_ctx *ctx) {
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess)
+    for (const auto &it : ctx->down_items) memcpy(it.dst, ctx->h_down + it.off, it.bytes);
+  ctx->down_items.clear();
+  ctx->down_used = 0;
+  if (e != hipSuccess) return fail(ctx, (int)e, std::string("down_flush: ") + hipGetErrorString(e));
+  return SVR_OK;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -3904,9 +3940,10 @@ int svr_update_scale_vector(svr_ctx *ctx, const float *scales, const float *slic
   SVR_ENTER(ctx);
   if (!ctx || !scales || !slice_weights) return SVR_E_ARG;
   NEED(ctx->ns > 0, "initStorageVolumes first");
-  ctx->h_scales.assign(scales, scales + ctx->ns);
   ctx->h_slice_weights.assign(slice_weights, slice_weights + ctx->ns);
   int r = upload_ns(ctx, ctx->d_scales, scales, ctx->mir_scales);
+  if (r) return r;
+  r = upload_ns(ctx, ctx->d_scales_host_copy, scales, ctx->mir_scales_copy);    // the device's copy of h_scales (below)
   if (r) return r;
   r = upload_ns(ctx, ctx->d_slice_weights, slice_weights, ctx->mir_slice_weights);
   if (r) return r;
@@ -4188,10 +4225,21 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   hipLaunchKernelGGL(k_slice_inside, dim3(ctx->ns), dim3(256), 0, ctx->stream, ctx->d_siminside,
                      (int)(ctx->sx * ctx->sy), ctx->d_slice_inside);
   KCHK("k_slice_inside");
-  if (slice_inside)
-    HIPCHK(hipMemcpyAsync(slice_inside, ctx->d_slice_inside, ctx->ns, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // slice_inside == NULL: the flags stay on the device (svr_get_slice_inside, svr_mstep_estep) and the call does not wait
+  if (slice_inside) {
+    if ((r = down_queue(ctx, slice_inside, ctx->d_slice_inside, ctx->ns))) return r;
+    return down_flush(ctx);
+  }
   return SVR_OK;
+}
+
+int svr_get_slice_inside(svr_ctx *ctx, uint8_t *slice_inside) {
+  SVR_ENTER(ctx);
+  if (!ctx || !slice_inside) return SVR_E_ARG;
+  NEED(ctx->have_slices, "slices not filled");
+  int r = down_queue(ctx, slice_inside, ctx->d_slice_inside, ctx->ns);
+  if (r) return r;
+  return down_flush(ctx);
 }
 
 // ---- EM --------------------------------------------------------------------------------
@@ -4234,14 +4282,13 @@ int svr_initialize_robust_statistics(svr_ctx *ctx, float *sigma) {
   return SVR_OK;
 }
 
-int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potential) {
-  SVR_ENTER(ctx);
-  if (!ctx || !slice_potential) return SVR_E_ARG;
-  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+namespace {
+// the E-step's kernels; em = NULL: (m, sigma, mix) by value, else {sigma, mix, m} read from the device (svr_mstep_estep)
+int launch_estep(svr_ctx *ctx, float m, float sigma, float mix, const float *em) {
   ScopedTimer t(ctx, SVR_T_ESTEP);
   hipLaunchKernelGGL(k_estep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_simslices,
                      ctx->d_simweights, ctx->d_scales, ctx->disable_bias ? (const float *)nullptr : ctx->d_bias, m, sigma,
-                     mix, (int)(ctx->sx * ctx->sy), ctx->d_weights, ctx->d_partial, ctx->pvr);
+                     mix, (int)(ctx->sx * ctx->sy), ctx->d_weights, ctx->d_partial, ctx->pvr, em);
   KCHK("k_estep");
   int r = reduce_partials(ctx, 2, 0, 0, false);
   if (r) return r;
@@ -4249,29 +4296,60 @@ int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potent
                      (int)ctx->ns, ctx->d_tmp_ns);
   KCHK("k_potential_finish");
   t.stop();
-  HIPCHK(hipMemcpyAsync(slice_potential, ctx->d_tmp_ns, ctx->ns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
+}
+// the M-step's sums -> d_out[5]
+int launch_mstep(svr_ctx *ctx) {
+  // the reference fills its per-pixel scale buffer from the HOST copy h_scales (RC.cu:3091-3094): d_scales_host_copy
+  ScopedTimer t(ctx, SVR_T_MSTEP);
+  hipLaunchKernelGGL(k_mstep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
+                     ctx->d_simslices, ctx->d_simweights, ctx->d_scales_host_copy,
+                     ctx->disable_bias ? (const float *)nullptr : ctx->d_bias, (int)(ctx->sx * ctx->sy), ctx->d_partial);
+  KCHK("k_mstep");
+  int r = reduce_partials(ctx, 5, 1 << 3, 1 << 4, true);
+  if (r) return r;
+  t.stop();
+  return SVR_OK;
+}
+// Reconstruction::MStep's host part RC.cu:3016-3071 (patch-based: patchBasedRobustStatistics_gpu.cu:570-640, no FLT_MAX /
+// FLT_MIN clamps), the same float operations on either side
+__host__ __device__ inline void mstep_scalars(const double s5[5], int iter, float step, int pvr, float &sigma_io, float &mix_io, float &m_out) {
+  const float sigma = (float)s5[0], mix = (float)s5[1], num = (float)s5[2];
+  float min_ = (float)s5[3], max_ = (float)s5[4];
+  if (!pvr) {
+    min_ = min_ < 3.402823466e+38f ? min_ : 3.402823466e+38f;       // std::min(FLT_MAX, .), std::max(FLT_MIN, .)
+    max_ = 1.175494351e-38f < max_ ? max_ : 1.175494351e-38f;
+  }
+  if (mix > 0) sigma_io = sigma / mix;
+  if (sigma_io < step * step / 6.28f) sigma_io = step * step / 6.28f;
+  if (iter > 1) mix_io = mix / num;
+  m_out = 1.0f / (max_ - min_);
+}
+__global__ void k_mstep_scalars(const double *s5, int iter, float step, int pvr, float sigma, float mix, float *em) {
+  float m = 0.0f;
+  mstep_scalars(s5, iter, step, pvr, sigma, mix, m);
+  em[0] = sigma; em[1] = mix; em[2] = m;
+}
+}  // namespace
+
+int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potential) {
+  SVR_ENTER(ctx);
+  if (!ctx || !slice_potential) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  int r = launch_estep(ctx, m, sigma, mix, nullptr);
+  if (r) return r;
+  if ((r = down_queue(ctx, slice_potential, ctx->d_tmp_ns, ctx->ns * sizeof(float)))) return r;
+  return down_flush(ctx);
 }
 
 int svr_mstep_sums(svr_ctx *ctx, double out5[5]) {
   SVR_ENTER(ctx);
   if (!ctx || !out5) return SVR_E_ARG;
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
-  // the reference fills its per-pixel scale buffer from the HOST copy h_scales (RC.cu:3091-3094)
-  int r = upload_ns(ctx, ctx->d_scales_host_copy, ctx->h_scales.data(), ctx->mir_scales_copy);
+  int r = launch_mstep(ctx);
   if (r) return r;
-  ScopedTimer t(ctx, SVR_T_MSTEP);
-  hipLaunchKernelGGL(k_mstep, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
-                     ctx->d_simslices, ctx->d_simweights, ctx->d_scales_host_copy,
-                     ctx->disable_bias ? (const float *)nullptr : ctx->d_bias, (int)(ctx->sx * ctx->sy), ctx->d_partial);
-  KCHK("k_mstep");
-  r = reduce_partials(ctx, 5, 1 << 3, 1 << 4, true);
-  if (r) return r;
-  t.stop();
-  HIPCHK(hipMemcpyAsync(out5, ctx->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return SVR_OK;
+  if ((r = down_queue(ctx, out5, ctx->d_out, 5 * sizeof(double)))) return r;
+  return down_flush(ctx);
 }
 
 int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma_io, float *mix_io, float *m_out) {
@@ -4280,22 +4358,37 @@ int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma_io, float *mix_io
   double s5[5];
   int r = svr_mstep_sums(ctx, s5);
   if (r) return r;
-  // Reconstruction::MStep host part RC.cu:3016-3071
-  float sigma = (float)s5[0], mix = (float)s5[1], num = (float)s5[2];
-  float min_ = FLT_MAX, max_ = FLT_MIN;
-  min_ = std::min(min_, (float)s5[3]);
-  max_ = std::max(max_, (float)s5[4]);
-  if (mix > 0) *sigma_io = sigma / mix;
-  else fprintf(stderr, "Something went wrong: sigma= %f mix= %f\n", sigma, mix);
-  if (*sigma_io < step * step / 6.28f) *sigma_io = step * step / 6.28f;
-  if (iter > 1) *mix_io = mix / num;
-  *m_out = 1.0f / (max_ - min_);
+  if (!((float)s5[1] > 0)) fprintf(stderr, "Something went wrong: sigma= %f mix= %f\n", (float)s5[0], (float)s5[1]);
+  mstep_scalars(s5, iter, step, 0, *sigma_io, *mix_io, *m_out);
+  return SVR_OK;
+}
+
+// MStep followed by EStep (reconstruction.cc:1093-1108, irtkPatchBasedReconstruction.cpp:540-545) with ONE wait for the
+// device: the M-step's scalars are worked out by a one-thread kernel with the host's float operations and read by the
+// E-step's kernel from device memory.  em3 = {sigma, mix, m} in/out.  scale_vec / slice_inside (each may be NULL): what
+// a deferred svr_calculate_scale_vector(ctx, NULL) / svr_simulate_slices(ctx, NULL) left on the device, in the same wait.
+int svr_mstep_estep(svr_ctx *ctx, int iter, float step, float em3[3], float *slice_potential, float *scale_vec, uint8_t *slice_inside) {
+  SVR_ENTER(ctx);
+  if (!ctx || !em3 || !slice_potential) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  if (!ctx->d_em) HIPCHK(hipMalloc(&ctx->d_em, 4 * sizeof(float)));
+  int r = launch_mstep(ctx);
+  if (r) return r;
+  hipLaunchKernelGGL(k_mstep_scalars, dim3(1), dim3(1), 0, ctx->stream, ctx->d_out, iter, step, ctx->pvr ? 1 : 0, em3[0], em3[1], ctx->d_em);
+  KCHK("k_mstep_scalars");
+  if ((r = launch_estep(ctx, 0.0f, 0.0f, 0.0f, ctx->d_em))) return r;
+  if ((r = down_queue(ctx, slice_potential, ctx->d_tmp_ns, ctx->ns * sizeof(float)))) return r;
+  if ((r = down_queue(ctx, em3, ctx->d_em, 3 * sizeof(float)))) return r;
+  if (scale_vec && (r = down_queue(ctx, scale_vec, ctx->d_scales_host_copy, ctx->ns * sizeof(float)))) return r;
+  if (slice_inside && (r = down_queue(ctx, slice_inside, ctx->d_slice_inside, ctx->ns))) return r;
+  if ((r = down_flush(ctx))) return r;
+  if (scale_vec) ctx->mir_scales_copy.assign(scale_vec, scale_vec + ctx->ns);
   return SVR_OK;
 }
 
 int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
   SVR_ENTER(ctx);
-  if (!ctx || !scale_vec) return SVR_E_ARG;
+  if (!ctx) return SVR_E_ARG;
   NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
   ScopedTimer t(ctx, SVR_T_SCALE);
   hipLaunchKernelGGL(k_scale, dim3(ctx->chunks, ctx->ns), dim3(256), 0, ctx->stream, ctx->d_slices, ctx->d_weights,
@@ -4308,15 +4401,43 @@ int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
                      ctx->d_tmp_ns);
   KCHK("k_scale_finish");
   t.stop();
-  HIPCHK(hipMemcpyAsync(scale_vec, ctx->d_tmp_ns, ctx->ns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   // Reference quirk, reproduced: CalculateScaleVectorOnX uploads h_scales -- still the PREVIOUS
   // scale vector -- to the device (RC.cu:3238) and only afterwards h_scales = scale_vec
   // (RC.cu:3195).  The E-step / back-projection kernels therefore see scales that lag one call
-  // behind; the M-step reads h_scales (RC.cu:3093) and sees the new ones.
-  r = upload_ns(ctx, ctx->d_scales, ctx->h_scales.data(), ctx->mir_scales);
+  // behind; the M-step reads h_scales (RC.cu:3093) and sees the new ones.  h_scales is d_scales_host_copy here: both
+  // moves are device-to-device, and with scale_vec == NULL (svr_get_scale_vector / svr_mstep_estep fetch it later) the
+  // call does not wait for the device.
+  HIPCHK(hipMemcpyAsync(ctx->d_scales, ctx->d_scales_host_copy, ctx->ns * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_scales_host_copy, ctx->d_tmp_ns, ctx->ns * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->mir_scales = ctx->mir_scales_copy;          // (empty = unknown: the next upload is not skipped)
+  ctx->mir_scales_copy.clear();
+  if (scale_vec) {
+    if ((r = down_queue(ctx, scale_vec, ctx->d_scales_host_copy, ctx->ns * sizeof(float)))) return r;
+    if ((r = down_flush(ctx))) return r;
+    ctx->mir_scales_copy.assign(scale_vec, scale_vec + ctx->ns);
+  }
+  return SVR_OK;
+}
+
+int svr_get_scale_vector(svr_ctx *ctx, float *scale_vec) {
+  SVR_ENTER(ctx);
+  if (!ctx || !scale_vec) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  int r = down_queue(ctx, scale_vec, ctx->d_scales_host_copy, ctx->ns * sizeof(float));
   if (r) return r;
-  ctx->h_scales.assign(scale_vec, scale_vec + ctx->ns);
+  if ((r = down_flush(ctx))) return r;
+  ctx->mir_scales_copy.assign(scale_vec, scale_vec + ctx->ns);
+  return SVR_OK;
+}
+
+// the scale vector last calculated becomes the one the kernels see (the patch-based loop's copyToScales: no lag,
+// patchBasedRobustStatistics_gpu.cu:672-745) -- svr_update_scale_vector(scale_vec, unchanged weights) without the host
+int svr_adopt_scale_vector(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  HIPCHK(hipMemcpyAsync(ctx->d_scales, ctx->d_scales_host_copy, ctx->ns * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->mir_scales = ctx->mir_scales_copy;
   return SVR_OK;
 }
 

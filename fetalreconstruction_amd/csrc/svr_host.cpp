@@ -87,8 +87,34 @@ class irtkReconstruction {
     _scale_stale = _inside_stale = false;
     return 0;
   }
+  // One rank, nothing to exchange: the scale vector, slice_inside and the M-step's scalars stay on the device until the
+  // E-step fetches them with its potentials in one wait (svr_mstep_estep) -- one wait per SR iteration instead of four.
+  // `settle` brings over whatever is still there when something else wants to read it.
+  bool _scale_pending = false, _inside_pending = false;
+  int _mstep_pending = 0;                            // iteration number of an M-step not yet run, or 0
+  int settle() {
+    if (_mstep_pending) {
+      const int iter = _mstep_pending;
+      _mstep_pending = 0;
+      ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
+    }
+    if (_scale_pending) {
+      std::vector<float> loc(hi - lo);
+      ENG(svr_get_scale_vector(reconstructionGPU, loc.data()));
+      std::copy(loc.begin(), loc.end(), _scale_gpu.begin() + lo);
+      _scale_pending = false;
+    }
+    if (_inside_pending) {
+      std::vector<unsigned char> inside(hi - lo);
+      ENG(svr_get_slice_inside(reconstructionGPU, inside.data()));
+      for (int i = 0; i < hi - lo; ++i) _slice_inside_gpu[lo + i] = inside[i] != 0;
+      _inside_pending = false;
+    }
+    return 0;
+  }
   // completes the vectors of which a rank only holds its own part (collective: every rank calls it); svrh_get_state does
   int flush() {
+    if (int rc = settle()) return rc;
     if (!sh.on || (!_scale_stale && !_inside_stale)) return 0;
     std::vector<double> none;
     return exchange(nullptr, 0, none, nullptr);
@@ -104,6 +130,7 @@ class irtkReconstruction {
 
   // RG.cc:2905-2919
   int InitializeEMValuesGPU() {
+    if (int rc = settle()) return rc;
     _slice_weight_gpu.assign(ns, 1);
     _scale_gpu.assign(ns, 1);
     ENG(svr_update_scale_vector(reconstructionGPU, local(_scale_gpu), local(_slice_weight_gpu)));
@@ -129,6 +156,11 @@ class irtkReconstruction {
 
   // RG.cc:1163-1175
   int SimulateSlicesGPU() {
+    if (!sh.on) {
+      ENG(svr_simulate_slices(reconstructionGPU, nullptr));
+      _inside_pending = true;
+      return 0;
+    }
     std::vector<unsigned char> inside(hi - lo);
     ENG(svr_simulate_slices(reconstructionGPU, inside.data()));
     for (int i = 0; i < hi - lo; ++i) _slice_inside_gpu[lo + i] = inside[i] != 0;
@@ -138,6 +170,7 @@ class irtkReconstruction {
 
   // RG.cc:2988-3019
   int InitializeRobustStatisticsGPU() {
+    if (int rc = settle()) return rc;
     if (!sh.on) {
       ENG(svr_initialize_robust_statistics(reconstructionGPU, &_sigma_gpu));
     } else {
@@ -164,7 +197,22 @@ class irtkReconstruction {
   // RG.cc:3184-3440: voxel posteriors on the GPU, slice-level EM on the host
   int EStepGPU() {
     std::vector<float> loc(hi - lo);
-    ENG(svr_estep(reconstructionGPU, _m_gpu, _sigma_gpu, _mix_gpu, loc.data()));
+    if (_mstep_pending) {                              // one rank: M-step + E-step + whatever is still on the device, one wait
+      const int iter = _mstep_pending;
+      _mstep_pending = 0;
+      float em3[3] = {_sigma_gpu, _mix_gpu, _m_gpu};
+      std::vector<float> sc(_scale_pending ? ns : 0);
+      std::vector<unsigned char> inside(_inside_pending ? ns : 0);
+      ENG(svr_mstep_estep(reconstructionGPU, iter, (float)_step, em3, loc.data(), _scale_pending ? sc.data() : nullptr,
+                          _inside_pending ? inside.data() : nullptr));
+      _sigma_gpu = em3[0]; _mix_gpu = em3[1]; _m_gpu = em3[2];
+      if (_scale_pending) _scale_gpu = sc;
+      if (_inside_pending) for (int i = 0; i < ns; ++i) _slice_inside_gpu[i] = inside[i] != 0;
+      _scale_pending = _inside_pending = false;
+    } else {
+      if (int rc = settle()) return rc;
+      ENG(svr_estep(reconstructionGPU, _m_gpu, _sigma_gpu, _mix_gpu, loc.data()));
+    }
     std::vector<float> &slice_potential_gpu = _slice_potential_gpu;
     slice_potential_gpu.assign(ns, 0.0f);
     std::copy(loc.begin(), loc.end(), slice_potential_gpu.begin() + lo);
@@ -243,6 +291,11 @@ class irtkReconstruction {
 
   // RG.cc:3751-3757
   int ScaleGPU() {
+    if (!sh.on) {
+      ENG(svr_calculate_scale_vector(reconstructionGPU, nullptr));
+      _scale_pending = true;
+      return 0;
+    }
     std::vector<float> loc(hi - lo);
     ENG(svr_calculate_scale_vector(reconstructionGPU, loc.data()));
     std::copy(loc.begin(), loc.end(), _scale_gpu.begin() + lo);
@@ -268,6 +321,11 @@ class irtkReconstruction {
   // RG.cc:4214-4223 + Reconstruction::MStep host part (reconstruction_cuda2.cu:3016-3071)
   int MStepGPU(int iter) {
     if (!sh.on) {
+      if (int rc = settle()) return rc;              // (an M-step after an M-step)
+      if (iter > 0) {
+        _mstep_pending = iter;                         // runs with the E-step that follows (reconstruction.cc:1093-1108), or in settle
+        return 0;
+      }
       ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
       return 0;
     }
@@ -534,7 +592,7 @@ int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_nul
   return 0;
 }
 
-void svrh_force_collectives(svrh_recon *r, int on) { if (r) r->impl.sh.force(on != 0); }
+void svrh_force_collectives(svrh_recon *r, int on) { if (r) { (void)r->impl.settle(); r->impl.sh.force(on != 0); } }
 
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
                    unsigned char *slice_inside, double s[8]) {

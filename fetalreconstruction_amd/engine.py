@@ -43,6 +43,7 @@ EXPORTS = [
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
     "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches", "svr_pvr_register_patches",
+    "svr_get_scale_vector", "svr_adopt_scale_vector", "svr_get_slice_inside", "svr_mstep_estep",
 ]
 
 
@@ -212,6 +213,36 @@ class Reconstruction:
         sc = np.zeros(self.sgrid[0], np.float32)
         self._ck(self._lib.svr_calculate_scale_vector(self._h, _p(sc)))
         return sc
+
+    # the deferred forms (the C++ host objects use them: one wait for the device per SR iteration instead of four)
+    def SimulateSlicesDeferred(self):
+        self._ck(self._lib.svr_simulate_slices(self._h, None))
+
+    def GetSliceInside(self):
+        inside = np.zeros(self.sgrid[0], np.uint8)
+        self._ck(self._lib.svr_get_slice_inside(self._h, _p(inside)))
+        return inside.astype(bool)
+
+    def CalculateScaleVectorDeferred(self):
+        self._ck(self._lib.svr_calculate_scale_vector(self._h, None))
+
+    def GetScaleVector(self):
+        sc = np.zeros(self.sgrid[0], np.float32)
+        self._ck(self._lib.svr_get_scale_vector(self._h, _p(sc)))
+        return sc
+
+    def AdoptScaleVector(self):
+        self._ck(self._lib.svr_adopt_scale_vector(self._h))
+
+    def MStepEStep(self, it, step, sigma, mix, want_scale=False, want_inside=False):
+        """MStep + EStep with one wait -> (sigma, mix, m, slice_potential, scale_vec | None, slice_inside | None)"""
+        em = np.array([sigma, mix, 0.0], np.float32)
+        pot = np.zeros(self.sgrid[0], np.float32)
+        sc = np.zeros(self.sgrid[0], np.float32) if want_scale else None
+        ins = np.zeros(self.sgrid[0], np.uint8) if want_inside else None
+        self._ck(self._lib.svr_mstep_estep(self._h, int(it), C.c_float(step), _p(em), _p(pot), None if sc is None else _p(sc),
+                                           None if ins is None else _p(ins)))
+        return float(em[0]), float(em[1]), float(em[2]), pot, sc, None if ins is None else ins.astype(bool)
 
     def Superresolution(self, it, slice_weight, adaptive, alpha, min_intensity, max_intensity, delta, lam,
                         global_bias_correction=False, sigma_bias=12.0, low_intensity_cutoff=0.01):

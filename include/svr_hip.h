@@ -117,7 +117,8 @@ int svr_update_stack_sizes(svr_ctx *ctx, const uint32_t *sizes3, int n_stacks);
 /* GaussianReconstruction(std::vector<int>& voxel_num): voxel_num[0] = #pixels that hit the ROI
  * RC.cuh:274, RC.cu:2329-2493 */
 int svr_gaussian_reconstruction(svr_ctx *ctx, int *voxel_num);
-/* SimulateSlices(std::vector<bool>& slice_inside)  RC.cuh:257, RC.cu:2654-2763 */
+/* SimulateSlices(std::vector<bool>& slice_inside)  RC.cuh:257, RC.cu:2654-2763.  slice_inside may be NULL: the flags stay
+ * on the device and the call does not wait for it (svr_get_slice_inside / svr_mstep_estep) */
 int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside);
 /* InitializeEMValues()  RC.cuh:211, RC.cu:3241-3310 */
 int svr_initialize_em_values(svr_ctx *ctx);
@@ -127,8 +128,21 @@ int svr_initialize_robust_statistics(svr_ctx *ctx, float *sigma);
 int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potential);
 /* MStep(int iter, float step, float& sigma, float& mix, float& m)  RC.cuh:255, RC.cu:2927-3112 */
 int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma, float *mix, float *m);
-/* CalculateScaleVector(std::vector<float>& scale_vec)  RC.cuh:238, RC.cu:3114-3239 */
+/* CalculateScaleVector(std::vector<float>& scale_vec)  RC.cuh:238, RC.cu:3114-3239.  scale_vec may be NULL: the vector stays
+ * on the device (it is what the next kernels read anyway) and the call does not wait; svr_get_scale_vector or
+ * svr_mstep_estep hand it over later. */
 int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec);
+int svr_get_scale_vector(svr_ctx *ctx, float *scale_vec);
+/* the scale vector last calculated becomes the one the kernels see: the patch-based loop's copyToScales
+ * (patchBasedRobustStatistics_gpu.cu:672-745) without a trip through the host */
+int svr_adopt_scale_vector(svr_ctx *ctx);
+/* slice_inside of the last SimulateSlices when that was called with slice_inside == NULL (no wait for the device there) */
+int svr_get_slice_inside(svr_ctx *ctx, uint8_t *slice_inside);
+/* MStep then EStep (reconstruction.cc:1093-1108, irtkPatchBasedReconstruction.cpp:540-545) with ONE wait for the device instead
+ * of two: the M-step's scalars (Reconstruction::MStep's host part RC.cu:3016-3071; for a patch-based context
+ * patchBasedRobustStatistics_gpu.cu:570-640) are worked out on the device with the same float operations.
+ * em3 = {sigma, mix, m} in/out; scale_vec / slice_inside: NULL or what the deferred calls above left on the device. */
+int svr_mstep_estep(svr_ctx *ctx, int iter, float step, float em3[3], float *slice_potential, float *scale_vec, uint8_t *slice_inside);
 /* Superresolution(int iter, std::vector<float> slice_weight, bool adaptive, float alpha, float min_intensity,
  *                 float max_intensity, float delta, float lambda, bool global_bias_correction,
  *                 float sigma_bias, float low_intensity_cutoff)  RC.cuh:263-265, RC.cu:2119-2241 */

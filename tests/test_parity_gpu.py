@@ -232,6 +232,63 @@ def test_em_steps_parity(tiny, oracle_mod):
     assert np.allclose(a, b, rtol=TOL_SCALAR)
 
 
+@pytest.mark.parametrize("pvr", [False, True])
+def test_deferred_reads_and_the_fused_m_e_step_give_the_separate_calls_bits(tiny, pvr):
+    """svr_calculate_scale_vector / svr_simulate_slices with NULL (nothing comes back, no wait), svr_get_scale_vector,
+    svr_get_slice_inside, svr_adopt_scale_vector and svr_mstep_estep (the M-step's scalars worked out on the device) against
+    CalculateScaleVector -> SimulateSlices -> MStep -> EStep one after the other: every number bit for bit, over three rounds
+    (the scale vector lags one call behind on the device, RC.cu:3238)."""
+    from fetalreconstruction_amd import engine as E
+
+    def fresh():
+        rec = E.Reconstruction(0)
+        if pvr:
+            rec.set_option("pvr", 1)
+            E.sync_gpu(rec, tiny, quality_factor=1.0)
+        else:
+            E.sync_gpu(rec, tiny)
+        ones = np.ones(tiny.ns, np.float32)
+        rec.UpdateScaleVector(ones, ones)
+        rec.InitializeEMValues()
+        rec.GaussianReconstruction()
+        rec.SimulateSlices()
+        return rec
+
+    a, b = fresh(), fresh()
+    for r in (a, b):
+        r.set_option("back_mode", 5)                                       # the scatter without atomics: the two engines stay bit-identical
+    for buf in (E.BUF_RECONSTRUCTED, E.BUF_VOL_WEIGHTS, E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE, E.BUF_PSF_SUMS):
+        b.debug_set(buf, a.debug_get(buf))                                 # (the Gaussian pass of the patch-based path adds with atomics)
+    sigma = a.InitializeRobustStatistics()
+    assert sigma == b.InitializeRobustStatistics()
+    m = 1.0 / (2.1 * tiny.max_intensity - 1.9 * tiny.min_intensity)
+    pa, pb = a.EStep(m, sigma, 0.9), b.EStep(m, sigma, 0.9)
+    assert np.array_equal(pa, pb)
+    sa, mixa, sb, mixb = sigma, 0.9, sigma, 0.9
+    w = np.ones(tiny.ns, np.float32)
+    for it in range(1, 4):
+        sc_a = a.CalculateScaleVector()
+        b.CalculateScaleVectorDeferred()
+        if pvr:
+            a.UpdateScaleVector(sc_a, w)                                   # copyToScales
+            b.AdoptScaleVector()
+        for r in (a, b):
+            r.Superresolution(it, w, False, 2.5, tiny.min_intensity, tiny.max_intensity, 150.0, 450.0)
+        in_a = a.SimulateSlices()
+        b.SimulateSlicesDeferred()
+        sa, mixa, ma = a.MStep(it, 1e-4, sa, mixa)
+        pa = a.EStep(ma, sa, mixa)
+        sb, mixb, mb, pb, sc_b, in_b = b.MStepEStep(it, 1e-4, sb, mixb, want_scale=True, want_inside=True)
+        if pvr:                                                            # the patch-based M-step has no FLT_MAX / FLT_MIN clamps: same numbers here
+            assert np.isfinite(mb)
+        assert (sa, mixa, ma) == (sb, mixb, mb), (it, sa, mixa, ma, sb, mixb, mb)
+        assert np.array_equal(pa, pb) and np.array_equal(sc_a, sc_b) and np.array_equal(in_a, in_b)
+        assert np.array_equal(sc_a, b.GetScaleVector()) and np.array_equal(in_a, b.GetSliceInside())
+        assert np.array_equal(a.debug_get(E.BUF_WEIGHTS), b.debug_get(E.BUF_WEIGHTS))
+        assert np.array_equal(a.syncCPU(), b.syncCPU())
+    a.close(); b.close()
+
+
 def test_full_iteration_tracks_the_oracle(tiny, oracle_mod):
     """Gaussian init + 2 SR iterations end to end, each side on its own state."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
