@@ -339,7 +339,7 @@ def main():
         va = int(round(comm.allreduce_sum(np.array([float(cnt["Va"])]))[0]))
     else:
         va = cnt["Va"]
-    tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode", "fwd_mode", "cell_w", "cell_h")}
+    tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode", "fwd_mode", "cell_w", "cell_h", "cell_gw", "cell_gh")}
 
     # ---- the same K steps once more with the coefficient table (reported next to the headline, not as it) ------------
     # `value` above is the reference GPU path's way: every tap evaluated in every pass.  With option coeff_table the taps of
@@ -459,7 +459,7 @@ def main():
                        "comm": (args.comm if multi else None), "rccl_world": rccl_world,
                        "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",
                                  "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "fwd_mode": tuned["fwd_mode"],
-                                 "cell": f"{tuned['cell_w']}x{tuned['cell_h']}", "pin": os.environ.get("SVR_TILE_PIN"),
+                                 "cell": f"{tuned['cell_w']}x{tuned['cell_h']}", "gather_cell": f"{tuned['cell_gw']}x{tuned['cell_gh']}", "pin": os.environ.get("SVR_TILE_PIN"),
                                  "note": "back_mode 5 / fwd_mode 2 work on (cell, plane) items: no tile shape is timed, runs repeat bit for bit; the tile "
                                          "shapes apply to the Gaussian pass, the coefficient table and the patch-based path"}},
             "ranks": ranks,

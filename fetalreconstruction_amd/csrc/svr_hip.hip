@@ -2857,6 +2857,7 @@ struct svr_ctx {
   uint32_t *d_tiles_fb2 = nullptr;
   bool wave_cap_user = false;
   bool back_mode_user = false;   // svr_set_option("back_mode") was called: no automatic choice between 5 and 4
+  bool fwd_mode_user = false;    // likewise "fwd_mode"
   // The coefficient table: what irtkReconstruction::CoeffInit keeps as _volcoeffs on the CPU path (RG.cc:2305-2673) --
   // every PSF pixel's evaluated taps, 16 KiB per pixel, written once per slice geometry by k_coeff_build and streamed by
   // the COEFF instantiations of the scatter and the gather instead of being re-evaluated in every SR iteration.  The
@@ -2896,8 +2897,10 @@ struct svr_ctx {
   RegState *reg = nullptr;
 
   // the scatter without atomics (back_mode 5, svr_cell.inc): cell size in voxels (x, lane axis), wavefronts per item
-  CellState *cell = nullptr;
-  int cell_w = 6, cell_h = 4, cell_split = 1, cell_qx = 1, cell_band = 3;   // cell_qx: cells of a quad along x (1, 2 or 4; the other factor along the lane axis)
+  CellState *cell = nullptr;      // the scatter's cell lists
+  CellState *cell_g = nullptr;    // the gather's, when it works on another cell size (cell_prepare_gather)
+  int cell_w = 0, cell_h = 0, cell_gw = 0, cell_gh = 0;   // 0: by the pixel density (cell_auto_size); cell_gw / cell_gh: the gather's own
+  int cell_split = 1, cell_qx = 1, cell_band = 3;   // cell_qx: cells of a quad along x (1, 2 or 4; the other factor along the lane axis)
 
   // timers
   bool timers = false;
@@ -2947,14 +2950,10 @@ int fail(svr_ctx *c, int code, const std::string &msg) {
     if (!(cond)) return fail(ctx, SVR_E_STATE, std::string(__func__) + ": " + what);      \
   } while (0)
 
-// The scatter variant in effect: the cell-owned scatter (5) is the default for SVR and for every run with the coefficient
-// table (P4 table 4.63 -> 3.59 ms, PVR4 table 10.4 -> 8.5 ms against the wave-owned scatter); patches evaluated on the fly
-// (runs of a dozen pixels per patch and cell: 11.45 against 11.35 ms on PVR4, 38.3 against 36.6 ms on PVR8spx) take the
-// wave-owned scatter with the atomic flush (4) unless the caller named a mode.
-inline int back_mode_eff(const svr_ctx *ctx) {
-  if (ctx->back_mode == 5 && !ctx->back_mode_user && ctx->pvr && !ctx->coeff_mode) return 4;   // patches on the fly: a tie (PVR4) or a loss (PVR8spx)
-  return ctx->back_mode;
-}
+// The scatter variant in effect: the cell-owned scatter (5) unless the caller named another (4 = wave-owned planes per
+// slice tile with the atomic flush, the default until round 3; patch-based runs took it until the cell kernels got five
+// slots of 12 lanes for support 12 and cell sizes that follow the pixel density: PVR4 11.3 -> 9.4 ms, PVR8spx 36.6 -> 27.3 ms).
+inline int back_mode_eff(const svr_ctx *ctx) { return ctx->back_mode; }
 void reg_free(RegState *r);
 void cell_free(CellState *c);
 void cell_invalidate(svr_ctx *ctx);
@@ -3571,7 +3570,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   SVR_ENTER(ctx);
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; ctx->back_mode_user = true; return SVR_OK; }
-  if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
+  if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; ctx->fwd_mode_user = true; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
   if (!strcmp(name, "pvr_mode")) { ctx->pvr_mode = value; return SVR_OK; }
   if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_unit_cap")) { ctx->fwd_unit_cap = std::max(2048, value); return SVR_OK; }
@@ -3606,9 +3605,15 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     cell_invalidate(ctx);
     return SVR_OK;
   }
-  if (!strcmp(name, "cell_w") || !strcmp(name, "cell_h") || !strcmp(name, "cell_split")) {
-    if (value < 1 || value > 32) return fail(ctx, SVR_E_ARG, "cell_w / cell_h / cell_split: 1..32");
-    (!strcmp(name, "cell_w") ? ctx->cell_w : !strcmp(name, "cell_h") ? ctx->cell_h : ctx->cell_split) = value;
+  if (!strcmp(name, "cell_w") || !strcmp(name, "cell_h") || !strcmp(name, "cell_gw") || !strcmp(name, "cell_gh")) {
+    if (value < 0 || value > 32) return fail(ctx, SVR_E_ARG, "cell_w / cell_h / cell_gw / cell_gh: 1..32, 0 = by the pixel density");
+    (!strcmp(name, "cell_w") ? ctx->cell_w : !strcmp(name, "cell_h") ? ctx->cell_h : !strcmp(name, "cell_gw") ? ctx->cell_gw : ctx->cell_gh) = value;
+    cell_invalidate(ctx);
+    return SVR_OK;
+  }
+  if (!strcmp(name, "cell_split")) {
+    if (value < 1 || value > 32) return fail(ctx, SVR_E_ARG, "cell_split: 1..32");
+    ctx->cell_split = value;
     cell_invalidate(ctx);
     return SVR_OK;
   }
@@ -3650,10 +3655,12 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
 int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
   SVR_ENTER(ctx);
   if (!ctx || !name || !value) return SVR_E_ARG;
+  int csw, csh, cgw, cgh;
+  cell_sizes(ctx, csw, csh, cgw, cgh);                   // the cell sizes in effect (0 = automatic resolved)
   const struct { const char *n; int v; } tab[] = {
       {"back_mode", back_mode_eff(ctx)}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
       {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
-      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", ctx->cell_w}, {"cell_h", ctx->cell_h}, {"cell_split", ctx->cell_split}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
+      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", csw}, {"cell_h", csh}, {"cell_gw", cgw}, {"cell_gh", cgh}, {"cell_split", ctx->cell_split}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
   for (const auto &e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return SVR_OK; }
   return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);
@@ -3675,6 +3682,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_coeff); free_dev(ctx->d_coeff_id);
   reg_free(ctx->reg);
   cell_free(ctx->cell);
+  cell_free(ctx->cell_g);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
@@ -4148,14 +4156,15 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   }
   // fwd_mode 2 (the default for SVR on the fly): the gather over the (cell, plane) items of the scatter without atomics
   bool cells = false;
-  if (ctx->fwd_mode == 2 && !ctx->pvr && !a.coeff && a.n) {
-    if ((r = cell_prepare(ctx))) return r;
-    cells = ctx->cell->usable;
+  CellState *gcs = nullptr;
+  if (ctx->fwd_mode == 2 && (!ctx->pvr || ctx->pvr_mode == 1) && !a.coeff && a.n) {
+    if ((r = cell_prepare_gather(ctx, gcs))) return r;
+    cells = gcs->usable;
   }
   auto launch_forward = [&]() -> int {
     const bool tiled_ = ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1;
     if (cells) {
-      const int rr = launch_cell_gather(ctx, a);
+      const int rr = launch_cell_gather(ctx, *gcs, a);
       if (rr) return rr;
     } else if (a.n && tiled_) {
       TileArgs ta;
