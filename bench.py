@@ -425,7 +425,7 @@ def main():
                         "order, no atomics)" if tuned["back_mode"] == 5 else "back_wave_kernel (wave-owned planes per slice tile, atomic flush)")
         e_back = entry(scatter_name + " = SuperresolutionKernel3D_tex, RC.cu:408-522", bp_avg, bp_n, b_back, "back")
         gather_name = ("fwd_cell_kernel + k_cell_gather_finish + k_cell_gfactors (csrc/svr_cell.inc: the gather over the same (cell, plane) items)"
-                       if tuned.get("fwd_mode") == 2 and not pvr else "fwd_unit_kernel (unit-based gather per slice tile)")
+                       if tuned.get("fwd_mode") == 2 else "fwd_unit_kernel (unit-based gather per slice tile)")
         e_fwd = entry(gather_name + " = simulateSlicesKernel3D_tex, RC.cu:298-404", fw_avg, fw_n, b_fwd, "forward")
         dom, other = (e_back, e_fwd) if bp_avg >= fw_avg else (e_fwd, e_back)
         roof = dict(dom)

@@ -82,7 +82,7 @@ def main():
         return {"kernels": ks, "fetch_bytes": sum(vals[k]["FETCH_SIZE"] for k in ks) * 1024.0, "write_bytes": sum(vals[k]["WRITE_SIZE"] for k in ks) * 1024.0,
                 "valu_insts": sum(vals[k].get("SQ_INSTS_VALU", 0.0) for k in ks)}
 
-    todo = [("P4", "p4", ()), ("S8", "s8", ()), ("PVR4", "pvr4", ())]
+    todo = [("P4", "p4", ()), ("S8", "s8", ()), ("PVR4", "pvr4", ()), ("PVR8spx", "pvr8spx", ())]
     v8 = {}
     for wl, tag, opts in todo:
         v = pmc(wl, tag, opts)
