@@ -37,7 +37,7 @@ struct Shard {
     int rc = svr_timer_begin(e, SVR_T_ALLREDUCE);
     if (rc) return rc;
     // only the mask's bounding box travels (the scatter writes mask voxels only: 47 % of the S8 volume; two device copies of
-    // the box against half of a 320 MB ring all-reduce); the whole buffer where that gains nothing
+    // the box against half of a 163 MB ring all-reduce); the whole buffer where that gains nothing
     void *packed = nullptr;
     size_t n_packed = 0;
     if ((rc = svr_pair_pack(e, buffer, n_floats, &packed, &n_packed))) return rc;
