@@ -117,6 +117,48 @@ def test_pvr_psf_kernels_parity(tiny, oracle_mod, use_spx, pvr_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cells", [(2, 2, 3, 5), (5, 3, 16, 16), (16, 16, 2, 2), (7, 4, 7, 4)])
+@pytest.mark.parametrize("pvr", [True, False])
+def test_cell_sizes_do_not_change_the_results(tiny, oracle_mod, pvr, cells):
+    """The cell kernels (csrc/svr_cell.inc) on cells of any size -- the scatter's (cell_w x cell_h) and the gather's own
+    (cell_gw x cell_gh, a second set of lists unless the sizes agree) -- against the oracle, and the gather bit for bit
+    against the unit gather: five slots of 12 lanes (patch-based) and four of 16, chunks of 60 / 64 records, boxes from
+    13 x 13 to 31 x 31 voxels."""
+    from fetalreconstruction_amd import engine as E
+    if pvr:
+        E_, rec, orc = _pair(tiny, oracle_mod, None, 1)
+    else:
+        rec = E.Reconstruction(0)
+        E.sync_gpu(rec, tiny)
+        orc = oracle_mod.OracleReconstruction(tiny, oracle_mod.CANON)
+        ones = np.ones(tiny.ns, np.float32)
+        for r in (rec, orc):
+            r.UpdateScaleVector(ones, ones)
+            r.InitializeEMValues()
+    for k, v in zip(("cell_w", "cell_h", "cell_gw", "cell_gh"), cells):
+        rec.set_option(k, v)
+    assert rec.get_option("back_mode") == 5 and rec.get_option("fwd_mode") == 2
+    assert tuple(rec.get_option(k) for k in ("cell_w", "cell_h", "cell_gw", "cell_gh")) == cells
+    rec.GaussianReconstruction(); orc.GaussianReconstruction()
+    assert rel_err(rec.getVolWeights(), orc.volw) < 2e-5 and rel_err(rec.syncCPU(), orc.recon) < 2e-5
+    rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon)
+    rec.SimulateSlices(); orc.SimulateSlices()
+    sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
+    assert np.array_equal(si, orc.siminside) and rel_err(sim, orc.simslices) < 2e-5 and rel_err(sw, orc.simweights) < 2e-5
+    rec.set_option("fwd_mode", 1)                                          # the unit gather per slice tile: the same bits
+    rec.SimulateSlices()
+    assert np.array_equal(rec.debug_get(E.BUF_SIMSLICES), sim) and np.array_equal(rec.debug_get(E.BUF_SIMWEIGHTS), sw)
+    rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+    w = np.full(tiny.ns, 0.8, np.float32)
+    rec.SuperresolutionBackproject(w); orc.SuperresolutionBackproject(w)
+    cm, ad = rec.debug_get(E.BUF_CONFIDENCE_MAP).copy(), rec.debug_get(E.BUF_ADDON).copy()
+    assert np.array_equal(cm > 0, orc.cmap > 0) and rel_err(cm, orc.cmap) < 2e-5 and rel_err(ad, orc.addon) < 2e-5
+    rec.SuperresolutionBackproject(w)                                      # no atomics: the same bits again
+    assert np.array_equal(rec.debug_get(E.BUF_CONFIDENCE_MAP), cm) and np.array_equal(rec.debug_get(E.BUF_ADDON), ad)
+    rec.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("use_spx", [False, True])
 def test_pvr_coefficient_table(tiny, oracle_mod, use_spx):
     """Option coeff_table with the patch-to-volume constants (support 12: 12 units of 12 x 12 taps per patch pixel, no dead
