@@ -403,7 +403,9 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
 
 // ZERO: skipped taps come out as -0.0f instead of -1: adding them changes nothing, and a processed tap whose value is
 // exactly +0 (an underflowed Gaussian factor, sin(pi r) at an integer r) can still be told from a skipped one by its bits
-template <int N, bool PVR, bool ZERO = false>
+// HP: pairs evaluated side by side (0 = the default below); the cell kernels ask for a whole row at once (no pixel tables, no
+// tile state: they have the registers, and the longer independent stages are worth 3-4 % of their time)
+template <int N, bool PVR, bool ZERO = false, int HP = 0>
 __device__ __forceinline__ void eval_row_t(const RowConst S, float bx, float by, float bz, float fy,
                                            float fz, float out[N]) {
   // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage of eval_pairs_xyz
@@ -414,7 +416,7 @@ __device__ __forceinline__ void eval_row_t(const RowConst S, float bx, float by,
 #ifndef SVR_EVAL_H16
 #define SVR_EVAL_H16 4
 #endif
-  constexpr int H = N == 16 ? SVR_EVAL_H16 : NP / 2;   // pairs evaluated side by side (instruction-level parallelism against registers)
+  constexpr int H = HP ? HP : (N == 16 ? SVR_EVAL_H16 : NP / 2);   // pairs evaluated side by side (instruction-level parallelism against registers)
   constexpr int CENTRE = (N - 1) / 2;
   static_assert(NP % H == 0 && CENTRE == NP - 1, "pairs (-j, 1 + j) around the central taps");
   const float rowx = __builtin_fmaf(S.Lp[1], fy, __builtin_fmaf(S.Lp[2], fz, bx));
