@@ -2867,6 +2867,8 @@ struct svr_ctx {
   // BASELINE.json (P4: 19 GB, S8: 174 GB).  Values are bit-identical to the on-the-fly evaluation by construction.
   float4 *d_coeff = nullptr;
   uint32_t *d_coeff_id = nullptr;
+  uint32_t *d_coeff_order = nullptr;   // the active pixels in the order of their places in the table (coeff_order)
+  size_t coeff_order_cap = 0;
   size_t coeff_cap = 0;        // pixels the allocation holds
   bool coeff_valid = false;
   int coeff_mode = 0;          // option "coeff_table": 0 = evaluate on the fly, 1 = stream the table (SVR only; falls back to 0 if it does not fit)
@@ -3306,6 +3308,7 @@ struct TileSample {
 // workgroup kernel (8 wavefronts, the largest box the CU can hold); what fits neither -- strongly oblique tiles of very fine
 // volumes -- takes LDS atomics (SVR: back_tiled_kernel) or device atomics per tap (PVR: pvr_tiles_kernel).
 // level: 4 = start with the wave-owned kernel, 3 = with the workgroup kernel, 1 = the last resort for every tile.
+int coeff_order(svr_ctx *ctx, uint32_t n_active, const uint32_t **list);
 // (Re)build the coefficient table if the option is on and the table does not match the current PSF pixels / geometry.
 // Returns with ctx->coeff_valid set, or with the mode switched off when the table does not fit the free memory.
 int ensure_coeff(svr_ctx *ctx) {
@@ -3333,6 +3336,13 @@ int ensure_coeff(svr_ctx *ctx) {
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_active;
   a.n = (uint32_t)npx;
+  // The pixels get their places in the table in the order of the scatter's cell lists (cell, slice, band, position): what a
+  // (cell, plane) item of the scatter or a slice tile of the gather reads next then lies within a few megabytes instead of one
+  // KiB per slice all over the table (a TLB miss per unit); pixels the cell lists dropped (footprint beyond the volume) follow.
+  if (!getenv("SVR_COEFF_UNSORTED")) {
+    const int r = coeff_order(ctx, (uint32_t)npx, &a.list);
+    if (r) return r;
+  }
   ScopedTimer tb(ctx, SVR_T_COEFF_BUILD);
   {
     const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t off) {
@@ -3681,7 +3691,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_reg_source);
   free_dev(ctx->d_pyr_full[0]); free_dev(ctx->d_pyr_full[1]); free_dev(ctx->d_pyr_a); free_dev(ctx->d_pyr_b); free_dev(ctx->d_pyr_meta);
   free_dev(ctx->d_ncc_idx); free_dev(ctx->d_ncc_m); free_dev(ctx->d_ncc_s);
-  free_dev(ctx->d_coeff); free_dev(ctx->d_coeff_id);
+  free_dev(ctx->d_coeff); free_dev(ctx->d_coeff_id); free_dev(ctx->d_coeff_order);
   reg_free(ctx->reg);
   cell_free(ctx->cell);
   cell_free(ctx->cell_g);
