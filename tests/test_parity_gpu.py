@@ -232,6 +232,53 @@ def test_em_steps_parity(tiny, oracle_mod):
     assert np.allclose(a, b, rtol=TOL_SCALAR)
 
 
+def test_slices_of_different_thickness_side_by_side_in_the_cell_lists(tiny, oracle_mod):
+    """The cell lists put pixels of different slices next to each other (sorted by cell first), and the records' dead-unit
+    bits are worked out one pixel per thread: every thread needs ITS slice's constants.  (Round 3 read inv2s2 / invD through
+    readfirstlane there -- the first lane's slice decided for all 64 -- which no test saw while all slices had one thickness:
+    a unit wrongly declared dead drops its taps.)  Every other slice gets 1.8 x the thickness: scatter and gather on the
+    cells against the oracle, and the table scatter (which reads what k_coeff_build stored for the units IT found live) bit for
+    bit against the on-the-fly scatter."""
+    import copy
+    from fetalreconstruction_amd import engine as E
+    P = copy.copy(tiny)
+    P.slice_dim = tiny.slice_dim.copy()
+    P.slice_dim[1::2, 2] *= 1.8
+    orc = oracle_mod.OracleReconstruction(P, oracle_mod.CANON)
+    rng = np.random.default_rng(5)
+    ones = np.ones(P.ns, np.float32)
+    outs = {}
+    for tab in (0, 1):
+        rec = E.Reconstruction(0)
+        E.sync_gpu(rec, P)
+        for r in ((rec, orc) if tab == 0 else (rec,)):
+            r.UpdateScaleVector(ones, ones)
+            r.InitializeEMValues()
+            r.GaussianReconstruction()
+        assert rec.get_option("back_mode") == 5 and rec.get_option("fwd_mode") == 2
+        assert np.array_equal(rec.debug_get(E.BUF_PSF_SUMS) != 0, orc.psf_sums != 0)
+        assert rel_err(rec.getVolWeights(), orc.volw) < TOL_SUM and np.array_equal(rec.getVolWeights() > 0, orc.volw > 0)
+        rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon)
+        rec.set_option("coeff_table", tab)
+        if tab == 0:
+            orc.SimulateSlices()
+            orc.weights[...] = np.where(orc.slices != -1, rng.uniform(0.2, 1.0, orc.slices.shape), 0).astype(np.float32)
+            sim_in = np.where(orc.slices > 0, orc.slices * rng.uniform(0.8, 1.2, orc.slices.shape), 0).astype(np.float32)
+        rec.SimulateSlices()
+        assert rec.get_option("coeff_table") == tab
+        assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), orc.siminside) and rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
+        rec.debug_set(E.BUF_SIMSLICES, sim_in)
+        rec.debug_set(E.BUF_WEIGHTS, orc.weights)
+        rec.SuperresolutionBackproject(ones)
+        outs[tab] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
+        rec.close()
+    orc.simslices[...] = sim_in
+    orc.SuperresolutionBackproject(ones)
+    assert np.array_equal(outs[0][1] > 0, orc.cmap > 0)
+    assert rel_err(outs[0][1], orc.cmap) < TOL_SUM and rel_err(outs[0][0], orc.addon) < TOL_SUM
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("pvr", [False, True])
 def test_deferred_reads_and_the_fused_m_e_step_give_the_separate_calls_bits(tiny, pvr):
     """svr_calculate_scale_vector / svr_simulate_slices with NULL (nothing comes back, no wait), svr_get_scale_vector,

@@ -133,12 +133,16 @@ def main():
             rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
             lines.append("%7s %14s %12s %7s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
             lines += ["%7d %14.1f %12.1f %7.2f  %s" % (k, t, a, pc, short(n)) for n, k, t, a, pc in rows[:24]]
-            for pat in ("back_cell_kernel", "fwd_cell_kernel"):
+            # the on-the-fly instantiations; the bench times its K steps on the fly first, then the same K with the table
+            for pat in ("back_cell_kernel<16, false, false>", "fwd_cell_kernel<16, false>"):
                 dd = [r[0] / 1e3 for r in c.execute("select (end - start) from kernels where name like ? order by start", ("%" + pat + "%",)).fetchall()]
                 if dd and jt:
                     k = jt["steps"]
+                    w = jt["warmup"]
+                    onfly = dd[:-1] if pat.startswith("fwd") else dd      # (the table phase starts with one on-the-fly gather... none for the scatter)
                     lines.append("# %s dispatches in order, us: %s" % (pat, " ".join("%.0f" % v for v in dd)))
-                    lines.append("#   the last %d are the timed steps: average %.1f us (kernel trace) vs the bench line's HIP-event figure" % (k, sum(dd[-k:]) / k))
+                    timed = [v for v in dd if True][-(k):] if len(dd) >= k else dd
+                    lines.append("#   the last %d dispatches: average %.1f us (kernel trace) vs the bench line's HIP-event figure for the whole pass" % (len(timed), sum(timed) / max(len(timed), 1)))
         except Exception as ex:
             lines.append("# could not read the rocpd database: %r" % (ex,))
     else:
