@@ -232,7 +232,8 @@ def test_em_steps_parity(tiny, oracle_mod):
     assert np.allclose(a, b, rtol=TOL_SCALAR)
 
 
-def test_slices_of_different_thickness_side_by_side_in_the_cell_lists(tiny, oracle_mod):
+@pytest.mark.parametrize("modes", [(5, 2), (4, 1), (3, 0)])
+def test_slices_of_different_thickness_side_by_side_in_the_cell_lists(tiny, oracle_mod, modes):
     """The cell lists put pixels of different slices next to each other (sorted by cell first), and the records' dead-unit
     bits are worked out one pixel per thread: every thread needs ITS slice's constants.  (Round 3 read inv2s2 / invD through
     readfirstlane there -- the first lane's slice decided for all 64 -- which no test saw while all slices had one thickness:
@@ -251,11 +252,12 @@ def test_slices_of_different_thickness_side_by_side_in_the_cell_lists(tiny, orac
     for tab in (0, 1):
         rec = E.Reconstruction(0)
         E.sync_gpu(rec, P)
+        assert rec.get_option("back_mode") == 5 and rec.get_option("fwd_mode") == 2      # the defaults: the cell kernels
+        rec.set_option("back_mode", modes[0]); rec.set_option("fwd_mode", modes[1]); rec.set_option("gauss_mode", 1 if modes[0] >= 3 else 0)
         for r in ((rec, orc) if tab == 0 else (rec,)):
             r.UpdateScaleVector(ones, ones)
             r.InitializeEMValues()
             r.GaussianReconstruction()
-        assert rec.get_option("back_mode") == 5 and rec.get_option("fwd_mode") == 2
         assert np.array_equal(rec.debug_get(E.BUF_PSF_SUMS) != 0, orc.psf_sums != 0)
         assert rel_err(rec.getVolWeights(), orc.volw) < TOL_SUM and np.array_equal(rec.getVolWeights() > 0, orc.volw > 0)
         rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon)
@@ -276,7 +278,10 @@ def test_slices_of_different_thickness_side_by_side_in_the_cell_lists(tiny, orac
     orc.SuperresolutionBackproject(ones)
     assert np.array_equal(outs[0][1] > 0, orc.cmap > 0)
     assert rel_err(outs[0][1], orc.cmap) < TOL_SUM and rel_err(outs[0][0], orc.addon) < TOL_SUM
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    if modes[0] == 5:                                                      # no atomics: table and on-the-fly scatter give the same bits
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    else:
+        assert rel_err(outs[1][1], orc.cmap) < TOL_SUM and rel_err(outs[1][0], orc.addon) < TOL_SUM
 
 
 @pytest.mark.parametrize("pvr", [False, True])
