@@ -245,6 +245,8 @@ def test_slices_of_different_thickness_side_by_side_in_the_cell_lists(tiny, orac
     P = copy.copy(tiny)
     P.slice_dim = tiny.slice_dim.copy()
     P.slice_dim[1::2, 2] *= 1.8
+    P.slice_dim[2::3, 0] *= 1.3                                            # ... and every third other in-plane voxel sizes (the PSF's kx, ky)
+    P.slice_dim[2::3, 1] *= 1.2
     orc = oracle_mod.OracleReconstruction(P, oracle_mod.CANON)
     rng = np.random.default_rng(5)
     ones = np.ones(P.ns, np.float32)
