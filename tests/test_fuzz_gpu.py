@@ -1,0 +1,78 @@
+"""Randomised geometry against the oracle on the default kernels (the cell-owned scatter and gather, csrc/svr_cell.inc):
+resolutions from 0.6 to 1.4 mm (pixel densities 0.3 .. 1.6: every automatic cell size), large slice motion (oblique
+footprints, pixels off the volume), per-slice thickness and in-plane dimensions that differ from slice to slice, a volume
+shifted so that footprints hang over its low and high ends, slice-to-volume and patch-to-volume constants.  What the fixed
+problems of the other tests do not vary."""
+import copy
+
+import numpy as np
+import pytest
+
+from fetalreconstruction_amd import phantom
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_stacks = int(rng.integers(2, 4))
+    orient = tuple(rng.choice(["ax", "cor", "sag", "ax30"], n_stacks, replace=True))
+    res = float(rng.uniform(0.6, 1.4))
+    P = phantom.make_problem(n_stacks, (int(rng.integers(16, 30)), int(rng.integers(16, 30)), int(rng.integers(3, 7))),
+                             float(rng.uniform(0.8, 1.3)), float(rng.uniform(1.8, 3.0)), None, res, float(rng.uniform(9.0, 13.0)),
+                             motion_frac=0.6, motion_mm=3.0, motion_deg=8.0, seed=seed, orientations=orient, name=f"fuzz{seed}")
+    P = copy.copy(P)
+    P.slice_dim = P.slice_dim.copy()
+    P.slice_dim[:, 2] *= rng.uniform(0.7, 1.9, P.ns).astype(np.float32)        # a thickness of its own for every slice
+    P.slice_dim[:, 0] *= rng.uniform(0.9, 1.3, P.ns).astype(np.float32)
+    P.slice_dim[:, 1] *= rng.uniform(0.9, 1.3, P.ns).astype(np.float32)
+    # the volume's frame moved by a few voxels: footprints beyond both ends (negative coordinates alias to 0, RC.cu:382 / 508)
+    sh = np.eye(4, dtype=np.float64)
+    sh[:3, 3] = rng.uniform(-4.0, 4.0, 3) * res
+    i2w = np.asarray(P.recon_i2w, np.float64).reshape(4, 4)
+    P.recon_i2w = (sh @ i2w).astype(np.float32).reshape(16)
+    P.recon_w2i = np.linalg.inv(sh @ i2w).astype(np.float32).reshape(16)
+    return P, rng
+
+
+@pytest.mark.parametrize("pvr", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_random_geometry_against_the_oracle(seed, pvr, oracle_mod):
+    from fetalreconstruction_amd import engine as E
+    P, rng = _case(seed)
+    rec = E.Reconstruction(0)
+    if pvr:
+        rec.set_option("pvr", 1)
+        E.sync_gpu(rec, P, quality_factor=1.0)
+    else:
+        E.sync_gpu(rec, P)
+    orc = oracle_mod.OracleReconstruction(P, oracle_mod.CANON, pvr=pvr)
+    assert rec.get_option("back_mode") == 5 and rec.get_option("fwd_mode") == 2
+    ones = np.ones(P.ns, np.float32)
+    for r in (rec, orc):
+        r.UpdateScaleVector(ones, ones)
+        r.InitializeEMValues()
+        r.GaussianReconstruction()
+    ps = rec.debug_get(E.BUF_PSF_SUMS)
+    assert np.array_equal(ps != 0, orc.psf_sums != 0)
+    assert np.allclose(ps, orc.psf_sums, rtol=1e-6, atol=0, equal_nan=True)
+    vw = rec.getVolWeights()
+    assert np.array_equal(vw > 0, orc.volw > 0) and rel_err(vw, orc.volw) < TOL
+    rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon)
+    rec.SimulateSlices(); orc.SimulateSlices()
+    assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), orc.siminside)
+    assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL and rel_err(rec.debug_get(E.BUF_SIMWEIGHTS), orc.simweights) < TOL
+    orc.weights[...] = np.where(orc.slices != -1, rng.uniform(0.0, 1.0, orc.slices.shape) * (rng.uniform(0, 1, orc.slices.shape) > 0.2), 0).astype(np.float32)
+    orc.simslices[...] = np.where(orc.slices > 0, orc.slices * rng.uniform(0.8, 1.2, orc.slices.shape), 0).astype(np.float32)
+    rec.debug_set(E.BUF_WEIGHTS, orc.weights)
+    rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+    sw = rng.uniform(0.0, 1.0, P.ns).astype(np.float32)
+    sw[rng.integers(0, P.ns)] = 0.0
+    rec.SuperresolutionBackproject(sw); orc.SuperresolutionBackproject(sw)
+    cm, ad = rec.debug_get(E.BUF_CONFIDENCE_MAP), rec.debug_get(E.BUF_ADDON)
+    assert (orc.cmap > 0).sum() > 100
+    assert np.array_equal(cm > 0, orc.cmap > 0)
+    assert rel_err(cm, orc.cmap) < TOL and rel_err(ad, orc.addon) < TOL
+    rec.close()
