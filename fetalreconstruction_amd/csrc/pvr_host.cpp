@@ -73,6 +73,7 @@ class irtkPatchBasedReconstruction {
   }
 
   int exchange(const double *mine, int n_mine, std::vector<double> &all, std::vector<float> *pot) {
+    if (int rc = settle()) return rc;                  // this rank's own part of the scale vector
     std::vector<float> *vec[3] = {scale_stale ? &scale : nullptr, nullptr, pot};
     const int rc = sh.exchange(mine, n_mine, all, vec);
     if (rc) { err = rc == SVR_E_STATE ? "exchange: the ranks are not in the same step of the reconstruction" : "exchange: the collective failed"; return rc; }
@@ -212,7 +213,8 @@ class irtkPatchBasedReconstruction {
   }
   int MStepNow(int iter) {
     double s5[5];
-    PENG(svr_mstep_sums(e, s5));
+    PENG(svr_mstep_sums_fetch(e, s5, scale_pending ? scale.data() + lo : nullptr, nullptr));
+    scale_pending = false;
     if (sh.on) {
       std::vector<double> all;
       if (int rc = exchange(s5, 5, all, nullptr)) return rc;                 // three sums, a minimum, a maximum: one collective
@@ -232,14 +234,9 @@ class irtkPatchBasedReconstruction {
   }
 
   int Scale() {                                                              // PRS.cu:672-745
-    if (!sh.on) {
-      PENG(svr_calculate_scale_vector(e, nullptr));
-      PENG(svr_adopt_scale_vector(e));                                       // copyToScales: no lag
-      scale_pending = true;
-      return 0;
-    }
-    PENG(svr_calculate_scale_vector(e, scale.data() + lo));
-    PENG(svr_update_scale_vector(e, scale.data() + lo, patch_weight.data() + lo));     // copyToScales: no lag
+    PENG(svr_calculate_scale_vector(e, nullptr));                            // stays on the device: fetched with the E-step's potentials
+    PENG(svr_adopt_scale_vector(e));                                         // (sharded: with the M-step's sums), or by settle.  copyToScales: no lag
+    scale_pending = true;
     scale_stale = sh.on;                                                     // read next in the E-step, whose exchange completes it
     return 0;
   }

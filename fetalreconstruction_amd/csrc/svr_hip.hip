@@ -4373,6 +4373,22 @@ int svr_mstep_sums(svr_ctx *ctx, double out5[5]) {
   return down_flush(ctx);
 }
 
+// svr_mstep_sums plus what deferred calls left on the device (each may be NULL), in the same wait: for a sharded host, which needs
+// the sums on the host for its exchange anyway
+int svr_mstep_sums_fetch(svr_ctx *ctx, double out5[5], float *scale_vec, uint8_t *slice_inside) {
+  SVR_ENTER(ctx);
+  if (!ctx || !out5) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  int r = launch_mstep(ctx);
+  if (r) return r;
+  if ((r = down_queue(ctx, out5, ctx->d_out, 5 * sizeof(double)))) return r;
+  if (scale_vec && (r = down_queue(ctx, scale_vec, ctx->d_scales_host_copy, ctx->ns * sizeof(float)))) return r;
+  if (slice_inside && (r = down_queue(ctx, slice_inside, ctx->d_slice_inside, ctx->ns))) return r;
+  if ((r = down_flush(ctx))) return r;
+  if (scale_vec) ctx->mir_scales_copy.assign(scale_vec, scale_vec + ctx->ns);
+  return SVR_OK;
+}
+
 int svr_mstep(svr_ctx *ctx, int iter, float step, float *sigma_io, float *mix_io, float *m_out) {
   SVR_ENTER(ctx);
   if (!ctx || !sigma_io || !mix_io || !m_out) return SVR_E_ARG;

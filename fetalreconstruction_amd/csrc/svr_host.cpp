@@ -78,6 +78,7 @@ class irtkReconstruction {
   //   mine[n_mine] -> all[world][n_mine];  pot (or NULL): the slice potentials, this rank's range filled -> complete
   bool _scale_stale = false, _inside_stale = false;
   int exchange(const double *mine, int n_mine, std::vector<double> &all, std::vector<float> *pot) {
+    if (int rc = settle()) return rc;                  // this rank's own parts of the vectors that travel
     std::vector<float> inside;
     if (_inside_stale) inside.assign(_slice_inside_gpu.begin(), _slice_inside_gpu.end());
     std::vector<float> *vec[3] = {_scale_stale ? &_scale_gpu : nullptr, _inside_stale ? &inside : nullptr, pot};
@@ -161,10 +162,9 @@ class irtkReconstruction {
       _inside_pending = true;
       return 0;
     }
-    std::vector<unsigned char> inside(hi - lo);
-    ENG(svr_simulate_slices(reconstructionGPU, inside.data()));
-    for (int i = 0; i < hi - lo; ++i) _slice_inside_gpu[lo + i] = inside[i] != 0;
-    _inside_stale = sh.on;                             // the other ranks' flags arrive with the next exchange
+    ENG(svr_simulate_slices(reconstructionGPU, nullptr));   // sharded: this rank's flags come over with the M-step's sums,
+    _inside_pending = true;                                 // the other ranks' with the exchange that follows
+    _inside_stale = true;
     return 0;
   }
 
@@ -296,10 +296,9 @@ class irtkReconstruction {
       _scale_pending = true;
       return 0;
     }
-    std::vector<float> loc(hi - lo);
-    ENG(svr_calculate_scale_vector(reconstructionGPU, loc.data()));
-    std::copy(loc.begin(), loc.end(), _scale_gpu.begin() + lo);
-    _scale_stale = sh.on;                              // read next in the E-step, whose exchange completes it
+    ENG(svr_calculate_scale_vector(reconstructionGPU, nullptr));   // sharded: fetched with the M-step's sums (or by settle)
+    _scale_pending = true;
+    _scale_stale = true;                               // read next in the E-step, whose exchange completes it
     return 0;
   }
 
@@ -330,7 +329,14 @@ class irtkReconstruction {
       return 0;
     }
     double s5[5];
-    ENG(svr_mstep_sums(reconstructionGPU, s5));
+    {
+      std::vector<float> sc(_scale_pending ? hi - lo : 0);
+      std::vector<unsigned char> inside(_inside_pending ? hi - lo : 0);
+      ENG(svr_mstep_sums_fetch(reconstructionGPU, s5, _scale_pending ? sc.data() : nullptr, _inside_pending ? inside.data() : nullptr));
+      if (_scale_pending) std::copy(sc.begin(), sc.end(), _scale_gpu.begin() + lo);
+      if (_inside_pending) for (int i = 0; i < hi - lo; ++i) _slice_inside_gpu[lo + i] = inside[i] != 0;
+      _scale_pending = _inside_pending = false;
+    }
     std::vector<double> all;
     ENG(exchange(s5, 5, all, nullptr));           // three sums, a minimum, a maximum: one collective
     s5[0] = s5[1] = s5[2] = 0;

@@ -43,7 +43,7 @@ EXPORTS = [
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
     "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches", "svr_pvr_register_patches",
-    "svr_get_scale_vector", "svr_adopt_scale_vector", "svr_get_slice_inside", "svr_mstep_estep",
+    "svr_get_scale_vector", "svr_adopt_scale_vector", "svr_get_slice_inside", "svr_mstep_estep", "svr_mstep_sums_fetch",
 ]
 
 

@@ -143,6 +143,8 @@ int svr_get_slice_inside(svr_ctx *ctx, uint8_t *slice_inside);
  * patchBasedRobustStatistics_gpu.cu:570-640) are worked out on the device with the same float operations.
  * em3 = {sigma, mix, m} in/out; scale_vec / slice_inside: NULL or what the deferred calls above left on the device. */
 int svr_mstep_estep(svr_ctx *ctx, int iter, float step, float em3[3], float *slice_potential, float *scale_vec, uint8_t *slice_inside);
+/* the M-step's five sums (svr_mstep_sums: what a sharded host exchanges) together with the deferred vectors, one wait */
+int svr_mstep_sums_fetch(svr_ctx *ctx, double out5[5], float *scale_vec, uint8_t *slice_inside);
 /* Superresolution(int iter, std::vector<float> slice_weight, bool adaptive, float alpha, float min_intensity,
  *                 float max_intensity, float delta, float lambda, bool global_bias_correction,
  *                 float sigma_bias, float low_intensity_cutoff)  RC.cuh:263-265, RC.cu:2119-2241 */
