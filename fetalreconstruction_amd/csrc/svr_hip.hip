@@ -2860,6 +2860,7 @@ struct svr_ctx {
   bool wave_cap_user = false;
   bool back_mode_user = false;   // svr_set_option("back_mode") was called: no automatic choice between 5 and 4
   bool fwd_mode_user = false;    // likewise "fwd_mode"
+  bool sr_no_wait = false;       // inside svr_superresolution: its two halves do not wait for the device
   // The coefficient table: what irtkReconstruction::CoeffInit keeps as _volcoeffs on the CPU path (RG.cc:2305-2673) --
   // every PSF pixel's evaluated taps, 16 KiB per pixel, written once per slice geometry by k_coeff_build and streamed by
   // the COEFF instantiations of the scatter and the gather instead of being re-evaluated in every SR iteration.  The
@@ -4604,7 +4605,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
       if (rr) return rr; }
   }
   t.stop();
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (!ctx->sr_no_wait) HIPCHK(hipStreamSynchronize(ctx->stream));   // (svr_superresolution: the update follows on the same stream)
   return SVR_OK;
 }
 
@@ -4625,7 +4626,7 @@ int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float mi
   KCHK("k_regularize");
   HIPCHK(hipMemcpyAsync(ctx->recon(), ctx->d_recon_new, ctx->nv * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   t.stop();
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (!ctx->sr_no_wait) HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
 }
 
@@ -4634,9 +4635,12 @@ int svr_superresolution(svr_ctx *ctx, int iter, const float *slice_weight, int a
                         int global_bias_correction, float sigma_bias, float low_intensity_cutoff) {
   SVR_ENTER(ctx);
   (void)iter; (void)sigma_bias; (void)low_intensity_cutoff;
+  // back-projection and update without a wait for the device in between or after: whatever reads the volume next is ordered
+  // behind them on the stream, and every call that hands results to the host waits itself (down_flush, svr_sync_cpu, debug_get)
+  ctx->sr_no_wait = true;
   int r = svr_superresolution_backproject(ctx, slice_weight);
-  if (r) return r;
-  r = svr_superresolution_update(ctx, adaptive, alpha, min_intensity, max_intensity, delta, lambda);
+  if (!r) r = svr_superresolution_update(ctx, adaptive, alpha, min_intensity, max_intensity, delta, lambda);
+  ctx->sr_no_wait = false;
   if (r) return r;
   if (global_bias_correction) printf("_global_bias_correction not implemented\n");   // RC.cu:2182-2185
   return SVR_OK;
