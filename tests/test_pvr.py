@@ -159,12 +159,17 @@ def test_cell_sizes_do_not_change_the_results(tiny, oracle_mod, pvr, cells):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("table_gather", ["default", "cells"])
 @pytest.mark.parametrize("use_spx", [False, True])
-def test_pvr_coefficient_table(tiny, oracle_mod, use_spx):
+def test_pvr_coefficient_table(tiny, oracle_mod, use_spx, table_gather):
     """Option coeff_table with the patch-to-volume constants (support 12: 12 units of 12 x 12 taps per patch pixel, no dead
-    units): the gather bit-identical to the on-the-fly gather, both kernels against the oracle."""
+    units): the gather bit-identical to the on-the-fly gather, both kernels against the oracle.  The table gather runs on the
+    tile kernel for small cells (this problem) and on the cell kernel for large ones (fine volumes) or when fwd_mode 2 is
+    named: both here."""
     spx = _spx(tiny) if use_spx else None
     E, rec, orc = _pair(tiny, oracle_mod, spx, 1)
+    if table_gather == "cells":
+        rec.set_option("fwd_mode", 2)
     rec.GaussianReconstruction(); orc.GaussianReconstruction()
     rec.SimulateSlices(); orc.SimulateSlices()
     sim0, sw0 = rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy()
