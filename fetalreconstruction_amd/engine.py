@@ -300,6 +300,14 @@ class Reconstruction:
         self._ck(self._lib.svr_mstep_sums(self._h, _p(o)))
         return o
 
+    def MStepSumsFetch(self, want_scale=False, want_inside=False):
+        """the M-step's five sums with the deferred vectors in the same wait (what a sharded host calls)"""
+        o = np.zeros(5, np.float64)
+        sc = np.zeros(self.sgrid[0], np.float32) if want_scale else None
+        ins = np.zeros(self.sgrid[0], np.uint8) if want_inside else None
+        self._ck(self._lib.svr_mstep_sums_fetch(self._h, _p(o), None if sc is None else _p(sc), None if ins is None else _p(ins)))
+        return o, sc, None if ins is None else ins.astype(bool)
+
     def ScaleVolumeSums(self):
         o = np.zeros(2, np.float64)
         self._ck(self._lib.svr_scale_volume_sums(self._h, _p(o)))

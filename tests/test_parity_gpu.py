@@ -330,6 +330,8 @@ def test_deferred_reads_and_the_fused_m_e_step_give_the_separate_calls_bits(tiny
             r.Superresolution(it, w, False, 2.5, tiny.min_intensity, tiny.max_intensity, 150.0, 450.0)
         in_a = a.SimulateSlices()
         b.SimulateSlicesDeferred()
+        s5_b, sc_f, in_f = b.MStepSumsFetch(want_scale=True, want_inside=True)   # the sharded hosts' form: sums + deferred vectors
+        assert np.array_equal(s5_b, a.MStepSums()) and np.array_equal(sc_f, sc_a) and np.array_equal(in_f, in_a)
         sa, mixa, ma = a.MStep(it, 1e-4, sa, mixa)
         pa = a.EStep(ma, sa, mixa)
         sb, mixb, mb, pb, sc_b, in_b = b.MStepEStep(it, 1e-4, sb, mixb, want_scale=True, want_inside=True)
