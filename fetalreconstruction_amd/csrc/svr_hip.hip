@@ -2523,6 +2523,7 @@ __global__ __launch_bounds__(256) void k_regularize(int vx, int vy, int vz, floa
   valW = c_p + k * valW;
   out[p] = (valW > 0.0f) ? val / valW : 0.0f;
 }
+#include "svr_regul.inc"
 // maskVolumeKernel RC.cu:3313-3326
 // {V m, m} per voxel (m = 1 inside the mask, else 0): what the gather's LDS boxes hold, packed once per pass so that a
 // box voxel is one 8-byte load instead of two loads and a select
@@ -2764,6 +2765,11 @@ struct svr_ctx {
   float *d_recon_volw = nullptr;   // recon | volw
   float *d_addon_cmap = nullptr;   // addon | cmap
   float *d_mask = nullptr, *d_snap = nullptr, *d_recon_new = nullptr;
+  float *recon_cur = nullptr;   // the volume: d_recon_volw or d_recon_new (the fused volume update writes the other one, svr_regul.inc)
+  int reg_tile = -1;            // k_regul_fused's tile: -1 = by the volume's extent, 0 = 64 x 8, 1 = 32 x 16, 2 = 32 x 8
+  int reg_mode = 1;             // volume update: 1 = k_regul_fused (one kernel, LDS planes, float32 weights), 0 = k_reg_prep + k_regularize (fp64 weights)
+  bool prep_pending = false;    // reg_mode 1, non-adaptive: Prep's own changes of addon / cmap are applied when somebody reads the buffers
+  bool cmap_from_scatter = false;   // cmap is what the scatter wrote (zero outside the mask): the update skips tiles outside the mask's box
   float2 *d_volm = nullptr;   // {V m, m}, refreshed before every SVR forward projection
   bool have_mask = false;
   // bounding box of mask != 0 (inclusive), from the host copy handed to svr_set_mask: the scatter only ever writes mask voxels,
@@ -2919,7 +2925,7 @@ struct svr_ctx {
   double t_ms[SVR_T_COUNT] = {0};
   long t_n[SVR_T_COUNT] = {0};
 
-  float *recon() { return d_recon_volw; }
+  float *recon() { return recon_cur; }
   float *volw() { return d_recon_volw + nv; }
   float *addon() { return d_addon_cmap; }
   float *cmap() { return d_addon_cmap + nv; }
@@ -3017,6 +3023,7 @@ struct ScopedTimer {
 inline unsigned nblk(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
 
 void free_volume(svr_ctx *c) {
+  c->recon_cur = nullptr;
   free_dev(c->d_recon_volw);
   free_dev(c->d_addon_cmap);
   free_dev(c->d_snap);
@@ -3583,6 +3590,8 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   SVR_ENTER(ctx);
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; ctx->back_mode_user = true; return SVR_OK; }
+  if (!strcmp(name, "reg_tile")) { if (value < -1 || value > 2) return fail(ctx, SVR_E_ARG, "reg_tile: -1 .. 2"); ctx->reg_tile = value; return SVR_OK; }
+  if (!strcmp(name, "reg_mode")) { if (value < 0 || value > 1) return fail(ctx, SVR_E_ARG, "reg_mode: 0 or 1"); ctx->reg_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; ctx->fwd_mode_user = true; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
   if (!strcmp(name, "pvr_mode")) { ctx->pvr_mode = value; return SVR_OK; }
   if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
@@ -3671,7 +3680,7 @@ int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
   int csw, csh, cgw, cgh;
   cell_sizes(ctx, csw, csh, cgw, cgh);                   // the cell sizes in effect (0 = automatic resolved)
   const struct { const char *n; int v; } tab[] = {
-      {"back_mode", back_mode_eff(ctx)}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
+      {"back_mode", back_mode_eff(ctx)}, {"reg_mode", ctx->reg_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
       {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
       {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", csw}, {"cell_h", csh}, {"cell_gw", cgw}, {"cell_gh", cgh}, {"cell_split", ctx->cell_split}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
   for (const auto &e : tab)
@@ -3752,8 +3761,9 @@ int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const f
   ctx->coeff_valid = false; cell_invalidate(ctx);
   HIPCHK(hipMalloc(&ctx->d_recon_volw, 2 * nv * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_addon_cmap, 2 * nv * sizeof(float)));
-  HIPCHK(hipMalloc(&ctx->d_snap, nv * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_recon_new, nv * sizeof(float)));
+  ctx->recon_cur = ctx->d_recon_volw;
+  ctx->prep_pending = false; ctx->cmap_from_scatter = false;
   HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * nv * sizeof(float), ctx->stream));   // RC.cu:1199-1229
   HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * nv * sizeof(float), ctx->stream));
   if (data) HIPCHK(hipMemcpyAsync(ctx->recon(), data, nv * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -4044,6 +4054,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     HIPCHK(hipMemsetAsync(ctx->d_siminside, 0, ctx->np, ctx->stream));
   }
   HIPCHK(hipMemsetAsync(ctx->d_voxcount, 0, ctx->np * sizeof(int), ctx->stream));
+  ctx->recon_cur = ctx->d_recon_volw;      // recon | volw as one allocation again (the pair a sharded run all-reduces); the old volume is not read
   HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * ctx->nv * sizeof(float), ctx->stream));
   const bool tiled = ctx->gauss_mode == 1 && (!ctx->pvr || ctx->pvr_mode == 1);
   if (tiled) {
@@ -4580,6 +4591,8 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   r = ensure_coeff(ctx);
   if (r) return r;
   HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream));   // RC.cu:2202-2203
+  ctx->prep_pending = false;
+  ctx->cmap_from_scatter = true;
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
@@ -4616,6 +4629,78 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   return SVR_OK;
 }
 
+// (double)r < (double)min * 0.9 and (double)r > (double)max * 1.1 (RC.cu:1964-1967) for a float r, as float comparisons
+static void regul_thresholds(float min_i, float max_i, RegulArgs &ra) {
+  const double dlo = (double)min_i * 0.9, dhi = (double)max_i * 1.1;
+  ra.val_lo = (float)dlo;
+  ra.val_hi = (float)dhi;
+  ra.thr_lo = (double)ra.val_lo >= dlo ? ra.val_lo : nextafterf(ra.val_lo, INFINITY);
+  ra.thr_hi = (double)ra.val_hi <= dhi ? ra.val_hi : nextafterf(ra.val_hi, -INFINITY);
+}
+
+// Prep's own changes of addon / cmap, left out by k_regul_fused, for whoever reads the two buffers
+static int regul_settle(svr_ctx *ctx) {
+  if (!ctx->prep_pending) return SVR_OK;
+  ctx->prep_pending = false;
+  hipLaunchKernelGGL(k_regul_settle, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->addon(), ctx->cmap(), ctx->nv);
+  KCHK("k_regul_settle");
+  return SVR_OK;
+}
+
+static int superresolution_update_planes(svr_ctx *ctx, int adaptive, float alpha, float min_intensity, float max_intensity, float delta,
+                                         float lambda, int z_lo, int z_hi) {
+  if (ctx->reg_mode == 0) {
+    if (!ctx->d_snap) HIPCHK(hipMalloc(&ctx->d_snap, ctx->nv * sizeof(float)));
+    if (z_lo != 0 || z_hi != (int)ctx->vz) return fail(ctx, SVR_E_ARG, "reg_mode 0 updates whole volumes only");
+    float *out = ctx->recon_cur == ctx->d_recon_volw ? ctx->d_recon_new : ctx->d_recon_volw;
+    hipLaunchKernelGGL(k_reg_prep, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, adaptive, alpha, ctx->recon(),
+                       ctx->addon(), ctx->cmap(), min_intensity, max_intensity, ctx->d_snap, ctx->nv);
+    KCHK("k_reg_prep");
+    hipLaunchKernelGGL(k_regularize, dim3((ctx->vx + 63) / 64, (ctx->vy + 3) / 4, ctx->vz), dim3(256), 0, ctx->stream,
+                       (int)ctx->vx, (int)ctx->vy, (int)ctx->vz, delta, alpha, lambda, ctx->d_snap, ctx->recon(),
+                       ctx->cmap(), out);
+    KCHK("k_regularize");
+    return SVR_OK;
+  }
+  RegulArgs ra;
+  ra.recon = ctx->recon(); ra.addon = ctx->addon(); ra.cmap = ctx->cmap();
+  ra.out = ctx->recon_cur == ctx->d_recon_volw ? ctx->d_recon_new : ctx->d_recon_volw;
+  ra.vx = (int)ctx->vx; ra.vy = (int)ctx->vy; ra.vz = (int)ctx->vz;
+  ra.z_lo = z_lo; ra.z_hi = z_hi;
+  // tile of a workgroup (option reg_tile).  Measured on one MI355X (tools/exp_regul_tile.py; 64 x 8 / 32 x 16 / 32 x 8): P4 19.4 / 20.2 /
+  // 18.2 us, S8 (273^3) 189 / 177 / 164 us, PVR8spx (400 x 400 x 320) 429 / 394 / 395 us: the small tile wastes the fewest lanes
+  // beyond the volume's extent and keeps more workgroups per CU between its barriers
+  static const int shapes[3][2] = {{64, 8}, {32, 16}, {32, 8}};
+  const int pick = ctx->reg_tile < 0 ? 2 : ctx->reg_tile;
+  const int TW = shapes[pick][0], TH = shapes[pick][1];
+  const int tiles = (int)((ctx->vx + TW - 1) / TW * ((ctx->vy + TH - 1) / TH));
+  const int nz = z_hi - z_lo;
+  const int want = std::max(1, (2048 * 512 / (TW * TH) + tiles - 1) / tiles);   // chunks along z for >= 2048 workgroups of 512 lanes
+  ra.zc = std::min(32, std::max(4, (nz + want - 1) / want));
+  const int chunks = (nz + ra.zc - 1) / ra.zc;
+  for (int k = 0; k < 3; ++k) { ra.blo[k] = 0; ra.bhi[k] = -1; }
+  if (ctx->mbox_valid && ctx->cmap_from_scatter) {
+    const int dims[3] = {ra.vx, ra.vy, ra.vz};
+    for (int k = 0; k < 3; ++k) { ra.blo[k] = std::max(0, ctx->mbox_lo[k] - 1); ra.bhi[k] = std::min(dims[k] - 1, ctx->mbox_hi[k] + 1); }
+  }
+  ra.alpha = alpha;
+  regul_thresholds(min_intensity, max_intensity, ra);
+  ra.k = alpha * lambda / (delta * delta);                                // RC.cu:2107 (float)
+  const double d2 = (double)delta * (double)delta;
+  ra.kap1 = (float)(1.0 / d2); ra.kap2 = (float)(0.5 / d2); ra.kap3 = (float)((double)(1.0f / 3.0f) / d2);
+  if (nz > 0) {
+    const dim3 grid((ctx->vx + TW - 1) / TW, (ctx->vy + TH - 1) / TH, chunks);
+    const dim3 block(TW * TH);
+#define REGUL_LAUNCH(AD, W, H) hipLaunchKernelGGL((k_regul_fused<AD, W, H>), grid, block, 0, ctx->stream, ra)
+    if (adaptive) { if (pick == 0) REGUL_LAUNCH(true, 64, 8); else if (pick == 1) REGUL_LAUNCH(true, 32, 16); else REGUL_LAUNCH(true, 32, 8); }
+    else { if (pick == 0) REGUL_LAUNCH(false, 64, 8); else if (pick == 1) REGUL_LAUNCH(false, 32, 16); else REGUL_LAUNCH(false, 32, 8); }
+#undef REGUL_LAUNCH
+    KCHK("k_regul_fused");
+  }
+  if (!adaptive) ctx->prep_pending = true;
+  return SVR_OK;
+}
+
 int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity,
                                float max_intensity, float delta, float lambda) {
   SVR_ENTER(ctx);
@@ -4624,14 +4709,9 @@ int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float mi
   if (alpha * lambda / (delta * delta) > 0.068)   // RC.cu:2124-2127
     fprintf(stderr, "Warning: regularization might not have smoothing effect! Ensure that alpha*lambda/delta^2 is below 0.068.");
   ScopedTimer t(ctx, SVR_T_REGULARIZE);
-  hipLaunchKernelGGL(k_reg_prep, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, adaptive, alpha, ctx->recon(),
-                     ctx->addon(), ctx->cmap(), min_intensity, max_intensity, ctx->d_snap, ctx->nv);
-  KCHK("k_reg_prep");
-  hipLaunchKernelGGL(k_regularize, dim3((ctx->vx + 63) / 64, (ctx->vy + 3) / 4, ctx->vz), dim3(256), 0, ctx->stream,
-                     (int)ctx->vx, (int)ctx->vy, (int)ctx->vz, delta, alpha, lambda, ctx->d_snap, ctx->recon(),
-                     ctx->cmap(), ctx->d_recon_new);
-  KCHK("k_regularize");
-  HIPCHK(hipMemcpyAsync(ctx->recon(), ctx->d_recon_new, ctx->nv * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  int r = superresolution_update_planes(ctx, adaptive, alpha, min_intensity, max_intensity, delta, lambda, 0, (int)ctx->vz);
+  if (r) return r;
+  ctx->recon_cur = ctx->recon_cur == ctx->d_recon_volw ? ctx->d_recon_new : ctx->d_recon_volw;   // the update wrote the other buffer
   t.stop();
   if (!ctx->sr_no_wait) HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
@@ -4723,6 +4803,10 @@ int svr_restore_slice_intensities(svr_ctx *ctx, const float *stack_factors, int 
 
 // ---- buffers ---------------------------------------------------------------------------
 static int buffer_info(svr_ctx *ctx, int which, void **ptr, size_t *bytes) {
+  if ((which == SVR_BUF_ADDON || which == SVR_BUF_CONFIDENCE_MAP) && ctx->nv) {
+    const int rs = regul_settle(ctx);      // (the fused volume update leaves Prep's changes of the two buffers to their readers)
+    if (rs) return rs;
+  }
   switch (which) {
     case SVR_BUF_RECONSTRUCTED: *ptr = ctx->nv ? ctx->recon() : nullptr; *bytes = ctx->nv * 4; break;
     case SVR_BUF_VOL_WEIGHTS: *ptr = ctx->nv ? ctx->volw() : nullptr; *bytes = ctx->nv * 4; break;
@@ -4768,6 +4852,7 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
   if (which == SVR_BUF_SLICES) { ctx->coeff_valid = false; cell_invalidate(ctx); }   // the table and the cell lists cover the pixels with s != -1
   if (which == SVR_BUF_MASK) ctx->mbox_valid = false;                               // (a mask set behind svr_set_mask's back: the whole pair is exchanged)
+  if (which == SVR_BUF_ADDON || which == SVR_BUF_CONFIDENCE_MAP) ctx->cmap_from_scatter = false;   // (no longer known to vanish outside the mask)
   if (which == SVR_BUF_SLICES) return build_list(ctx, false);
   return SVR_OK;
 }

@@ -195,20 +195,61 @@ def test_backprojection_parity(tiny, oracle_mod, back_mode):
     assert rel_err(ad, orc.addon) < TOL_SUM
 
 
-def test_regulariser_parity(tiny, oracle_mod):
+@pytest.mark.parametrize("reg_mode", [1, 0])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_regulariser_parity(tiny, oracle_mod, reg_mode, adaptive):
+    """reg_mode 1 = k_regul_fused (csrc/svr_regul.inc: Prep + regulariser in one kernel, LDS planes, float32 weights through
+    v_rsq_f32), 0 = k_reg_prep + k_regularize (the reference's operations: fp64 sqrt and division per neighbour pair).  Row a7's
+    tolerance: 1e-6 of the volume's maximum against the oracle's double-precision weights, for both."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    rec.set_option("reg_mode", reg_mode)
     run_to_state(do, "scale")
     orc.SuperresolutionBackproject(orc.slice_weights)
+    if adaptive:                                                      # confidences other than {0, 1} reach the regulariser only then
+        assert len(np.unique(orc.cmap)) > 100
     rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon)
     rec.debug_set(E.BUF_ADDON, orc.addon)
     rec.debug_set(E.BUF_CONFIDENCE_MAP, orc.cmap)
-    args = (do._adaptive, do._alpha, do._min_intensity, do._max_intensity, do._delta, do._lambda)
+    args = (adaptive, do._alpha, do._min_intensity, do._max_intensity, do._delta, do._lambda)
     rec.SuperresolutionUpdate(*args)
     orc.SuperresolutionUpdate(*args)
-    # pure elementwise / stencil float math: identical operation order -> essentially exact
     assert rel_err(rec.syncCPU(), orc.recon) < 1e-6
-    assert rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < 1e-6
+    assert rel_err(rec.debug_get(E.BUF_ADDON), orc.addon) < 1e-6      # Prep's own changes of the two buffers (settled for the reader in mode 1)
     assert np.array_equal(rec.debug_get(E.BUF_CONFIDENCE_MAP), orc.cmap)
+    # a second update on top of the first (the volume lives in the other buffer now), strong smoothing, clamped range
+    args2 = (adaptive, do._alpha, float(np.percentile(orc.recon, 30)), float(np.percentile(orc.recon, 90)), 40.0, 0.5 * 40.0 ** 2 * 0.06 / do._alpha)
+    rec.debug_set(E.BUF_ADDON, orc.addon); rec.debug_set(E.BUF_CONFIDENCE_MAP, orc.cmap)
+    rec.SuperresolutionUpdate(*args2)
+    orc.SuperresolutionUpdate(*args2)
+    assert rel_err(rec.syncCPU(), orc.recon) < 1e-6
+
+
+def test_fused_update_skips_nothing_it_should_not(tiny, oracle_mod):
+    """With cmap straight from the scatter the fused update writes zeros for tiles outside the mask's box without loading
+    anything; the same update with the shortcut off (cmap handed in through debug_set), the two-kernel form and the oracle
+    give the same volume, through two SR iterations of the whole loop, on a volume whose mask sits in one corner."""
+    import copy
+    from fetalreconstruction_amd import engine as E
+    P = copy.copy(tiny)
+    P.mask = tiny.mask.copy()
+    P.mask[:, :, : tiny.mask.shape[2] // 2] = 0                      # (z, y, x): the mask's box ends mid-volume
+    P.mask[: tiny.mask.shape[0] // 3] = 0
+    outs = []
+    for reg_mode in (1, 0):
+        rec = E.Reconstruction(0)
+        E.sync_gpu(rec, P)
+        rec.set_option("reg_mode", reg_mode)
+        d = irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
+        d.SetSmoothingParameters(150, 0.02)
+        d.reconstruct_iteration(2)
+        outs.append(rec.syncCPU())
+    orc = oracle_mod.OracleReconstruction(P, oracle_mod.CANON)
+    do = irtkReconstruction(orc, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
+    do.SetSmoothingParameters(150, 0.02)
+    do.reconstruct_iteration(2)
+    assert rel_err(outs[0], outs[1]) < 2e-6
+    assert rel_err(outs[0], orc.recon) < 1e-4                            # whole iterations, each side evolving its own state
+    assert np.array_equal(outs[0] != 0, outs[1] != 0)
 
 
 def test_em_steps_parity(tiny, oracle_mod):
