@@ -5125,6 +5125,23 @@ int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]) {
   out3[2] = cs.dead_units;
   return SVR_OK;
 }
+// what the cell lists of the current slice geometry hold (the per-item fixed costs of a sharded run: bench.py --shard)
+int svr_cell_stats(svr_ctx *ctx, uint64_t out8[8]) {
+  SVR_ENTER(ctx);
+  if (!ctx || !out8) return SVR_E_ARG;
+  int r = ready(ctx);
+  if (r) return r;
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  if ((r = cell_prepare(ctx))) return r;
+  const CellState &cs = *ctx->cell;
+  out8[0] = cs.a.nitems; out8[1] = cs.n_runs; out8[2] = cs.n_sorted;
+  out8[3] = (uint64_t)cs.a.nitems * cs.a.split * cs.a.PP * sizeof(f2);      // staging bytes written by the scatter, read by the combine
+  CellState *g = nullptr;
+  if ((r = cell_prepare_gather(ctx, g))) return r;
+  if (g) { out8[4] = g->a.nitems; out8[5] = g->n_runs; out8[6] = (uint64_t)g->n_sorted * (ctx->pvr ? PVR_N : PSF_SUPPORT) * sizeof(f2); }
+  out8[7] = (uint64_t)cs.a.CX << 32 | (uint64_t)cs.a.CL;
+  return SVR_OK;
+}
 int svr_timer_begin(svr_ctx *ctx, int which) {
   SVR_ENTER(ctx);
   if (!ctx || which < 0 || which >= SVR_T_COUNT) return SVR_E_ARG;

@@ -334,6 +334,9 @@ int svr_counters(svr_ctx *ctx, uint64_t out8[8]);
  * evaluated), [2] dead units (every row provably below the epsilon of RC.cu:238: only its first tap is processed) -- what
  * bench.py's `flops_executed` counts */
 int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]);
+/* the cell lists of the current slice geometry (csrc/svr_cell.inc): out8 = {scatter items, runs, sorted pixels, staging bytes per
+ * launch, gather items, gather runs, gather partial-sum bytes per launch, scatter cell size w << 32 | h} */
+int svr_cell_stats(svr_ctx *ctx, uint64_t out8[8]);
 
 #ifdef __cplusplus
 }

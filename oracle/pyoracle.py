@@ -302,6 +302,15 @@ class OracleReconstruction:
                                  _p(vals) if with_vals else None, _p(c))
         return n, bits, vals, c
 
+    def fastmath_census(self, pixels):
+        """orc_fastmath_census over pixels [(slice, py, px), ...] (np.argwhere order) -> dict; see svr_oracle.c"""
+        pix = np.ascontiguousarray(np.asarray(pixels, np.int32)[:, [0, 2, 1]])
+        out = np.zeros(16, np.float64)
+        lib().orc_fastmath_census(C.byref(self.g), int(len(pix)), _p(pix), _p(out))
+        names = ("taps", "kept", "uncertain", "pixels_uncertain", "mass_kept", "mass_uncertain", "sume_rel_max", "env_max", "env_mean",
+                 "canon_outside", "canon_dmax", "canon_over_env_max", "canon_flips_explained", "canon_flips")
+        return {k: float(v) for k, v in zip(names, out)}
+
     def psf_values(self, sl, px, py):
         v = np.zeros(4096, np.float32)
         lib().orc_psf_values(C.byref(self.g), int(sl), int(px), int(py), _p(v))

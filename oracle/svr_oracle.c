@@ -28,6 +28,11 @@
  *       accumulation so it can serve as the high-precision reference for sums.
  *   The two agree to float round-off in PSF values; tests quantify the difference and
  *   the rate of epsilon-skip decisions that flip between them.
+ *   Neither is what the reference BINARY computes: its build uses `--use_fast_math`
+ *   (source/cmake/FindSciCuda.cmake:65-68): __sinf / __expf / __fdividef / sqrt.approx, FTZ, FMA
+ *   contraction.  orc_fastmath_census bounds, per tap, how far any arithmetic inside that build's
+ *   documented error envelope may lie from the literal sequence, and measures the canonical
+ *   sequence against the same envelope (tests/census.py::fastmath_census).
  *
  * Reference behaviours deliberately reproduced (quirks):
  *   - float->uint casts saturate: negative coordinates alias to index 0 and pass the
@@ -625,6 +630,109 @@ void orc_psf_values(const orc_geom *g, int sl, int px, int py, float *vals4096) 
           : psf_canon(g, &sp, &pp, x - Cn, y - Cn, z - Cn, gz[x], ofs);
     }
   }
+}
+
+/* ---- the reference BINARY's arithmetic: an error envelope around the literal sequence ----------------------
+ * The reference compiles its CUDA path with `-O3 --use_fast_math` (source/cmake/FindSciCuda.cmake:65-68, pulled in by
+ * reconstructionGPU2/CMakeLists.txt:17), i.e. -ftz=true -prec-div=false -prec-sqrt=false -fmad=true: in calcPSF
+ * (RC.cu:112-130) sin -> __sinf, exp -> __expf, every `/` -> __fdividef / div.approx, sqrt -> sqrt.approx, denormals
+ * flushed, and the affine products of getPSFParamsPrecomp (RC.cu:164-174, RVH:134-145) contracted into FMAs at nvcc's
+ * discretion.  None of that can be reproduced off an NVIDIA GPU, and psf_literal above (libm, no contraction) is only ONE
+ * arithmetic the source admits.  This census measures how much room the reference's own build leaves: per tap, a first-order
+ * bound E on |psf_binary - psf_literal| from the error bounds NVIDIA documents (CUDA C Programming Guide, "Mathematical
+ * functions: intrinsic functions"; PTX ISA, sin.approx / ex2.approx / sqrt.approx / div.approx):
+ *   __sinf(x): absolute error 2^-21.41 on [-pi, pi], "larger otherwise" -- modelled as 2^-21.41 + |x| 2^-23 outside (the
+ *              range reduction multiplies by a float 1/2pi: a relative error of 2^-23 in the phase);
+ *   __expf(x): 2 + floor(|1.16 x|) ulp;   __fdividef(x, y): 2 ulp;   sqrt.approx.ftz.f32: relative 2^-23;
+ *   FMA contraction of a0 o0 + a1 o1 + a2 o2 + a3: each product rounded or not, at most half an ulp of each product;
+ *   flush-to-zero only touches values below 1.2e-38, eleven orders below the epsilon of the skip test: ignored.
+ * A skip decision |oldPSF - psf| < 1e-5 (RC.cu:238) is UNCERTAIN when it can go either way inside the envelope,
+ * | |old - psf| - 1e-5 | <= E(old) + E(psf): an upper bound on the decisions that ANY arithmetic inside the reference's own
+ * error envelope may take differently from the literal sequence (first order: the chain of oldPSF follows the literal walk).
+ * The canonical sequence is measured against the same envelope: the taps where |psf_canon - psf_literal| > E.
+ * out16: [0] taps, [1] taps kept (literal), [2] uncertain decisions, [3] pixels with one, [4] sum of kept psf, [5] sum of
+ * psf over uncertain taps, [6] max over pixels of (uncertain mass / the pixel's kept mass), [7] max E, [8] mean E,
+ * [9] taps with |canon - literal| > E, [10] max |canon - literal|, [11] max |canon - literal| / E over taps with psf > 1e-6,
+ * [12] uncertain decisions among the taps where canon and literal disagree (canon's flips explained by the envelope),
+ * [13] taps where canon and literal disagree. */
+typedef struct { double v, e; } psf_env;
+static psf_env psf_literal_envelope(const orc_geom *g, const slice_psf *sp, const pixel_psf *pp, int ox, int oy, int oz) {
+  const double u = ldexp(1.0, -24);                       /* half an ulp, relative */
+  float ofs[3] = {(float)ox + pp->c[0], (float)oy + pp->c[1], (float)oz + pp->c[2]};
+  double q[3], eq[3];
+  for (int k = 0; k < 3; ++k) {
+    double ep = 0;
+    for (int j = 0; j < 3; ++j) ep += u * fabs((double)sp->A[4 * k + j] * ofs[j]);   /* contracted or not */
+    float p2 = sp->A[4 * k + 0] * ofs[0] + sp->A[4 * k + 1] * ofs[1] + sp->A[4 * k + 2] * ofs[2] + sp->A[4 * k + 3];
+    q[k] = (double)((p2 - pp->pos[k]) * sp->dim[k]);
+    eq[k] = ep * fabs((double)sp->dim[k]);
+  }
+  if (g->pvr) { q[2] /= 2.5; eq[2] = eq[2] / 2.5 + fabs(q[2]) * 4 * u; }
+  for (int k = 0; k < 3; ++k) q[k] -= g->psf_c0[k];
+  const double sigmaz = g->pvr ? sp->dim[2] : sp->dim[2] / 2.3548;
+  const double x_ = q[0] * sp->dim[0] / 2.3548, y_ = q[1] * sp->dim[1] / 2.3548;
+  const double ex_ = eq[0] * sp->dim[0] / 2.3548 + fabs(x_) * 4 * u, ey_ = eq[1] * sp->dim[1] / 2.3548 + fabs(y_) * 4 * u;
+  const double x = sqrt(x_ * x_ + y_ * y_);
+  const double ex = (x > 0 ? (fabs(x_) * ex_ + fabs(y_) * ey_) / x : ex_ + ey_) + x * (2 * u + 0.5 * u);
+  const double R = 3.14159265359 * x, eR = 3.14159265359 * ex;
+  const double es0 = ldexp(1.0, -21) * 0.7526 /* 2^-21.41 */ + (R > 3.14159265359 ? R * ldexp(1.0, -23) : 0.0);
+  const double sn = sin(R), es = es0 + fabs(cos(R)) * eR;
+  psf_env o;
+  if (R == 0) { o.v = NAN; o.e = 0; return o; }
+  const double si = sn / R, esi = es / R + fabs(si) * (eR / R + 4 * u);
+  const double in2 = si * si, ein2 = 2 * fabs(si) * esi;
+  const double a = (q[2] * q[2]) / (2 * sigmaz * sigmaz);
+  const double ea = 2 * fabs(q[2]) * eq[2] / (2 * sigmaz * sigmaz) + a * 4 * u;
+  const double gz = exp(-a), egz = gz * (ea + (2 + floor(1.16 * a)) * 2 * u);
+  o.v = in2 * gz;
+  o.e = ein2 * gz + in2 * egz;
+  return o;
+}
+void orc_fastmath_census(const orc_geom *g, int n, const int *pix3, double *out16) {
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+  const int S = psf_support(g), Cn = psf_centre(g);
+  const double eps = g->pvr ? (double)0.00001f : PSF_EPSILON;
+  double esum = 0;
+  for (int i = 0; i < n; ++i) {
+    const int sl = pix3[3 * i], px = pix3[3 * i + 1], py = pix3[3 * i + 2];
+    slice_psf sp; slice_setup(g, sl, &sp);
+    pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
+    double kept = 0, unc = 0;
+    int any = 0;
+    for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) {
+      float gz[16];
+      canon_gauss_row(&sp, canon_rowz(&sp, &pp, y - Cn, z - Cn), S, gz);
+      float oldL = FLT_MAX, oldC = FLT_MAX;
+      double eold = 0;
+      for (int xx = 0; xx < S; ++xx) {
+        float ofs[3];
+        const float vl = psf_literal(g, &sp, &pp, xx - Cn, y - Cn, z - Cn, ofs);
+        const float vc = psf_canon(g, &sp, &pp, xx - Cn, y - Cn, z - Cn, gz[xx], ofs);
+        const psf_env en = psf_literal_envelope(g, &sp, &pp, xx - Cn, y - Cn, z - Cn);
+        out16[0] += 1;
+        if (en.e > out16[7]) out16[7] = en.e;
+        esum += en.e;
+        const double dcl = fabs((double)vc - (double)vl);
+        if (isfinite(dcl)) {
+          if (dcl > en.e) out16[9] += 1;
+          if (dcl > out16[10]) out16[10] = dcl;
+          if (vl > 1e-6f && en.e > 0 && dcl / en.e > out16[11]) out16[11] = dcl / en.e;
+        }
+        const double d = fabs((double)oldL - (double)vl);
+        const int keepL = !(d < eps), keepC = !(fabs((double)oldC - (double)vc) < eps);
+        const int uncertain = oldL != FLT_MAX && fabs(d - eps) <= eold + en.e;
+        if (uncertain) { out16[2] += 1; any = 1; unc += isfinite(vl) ? (double)vl : 0; }
+        if (keepL != keepC) { out16[13] += 1; if (uncertain) out16[12] += 1; }
+        if (keepL) { out16[1] += 1; kept += isfinite(vl) ? (double)vl : 0; oldL = vl; eold = en.e; }
+        if (keepC) oldC = vc;
+      }
+    }
+    out16[3] += any;
+    out16[4] += kept;
+    out16[5] += unc;
+    if (kept > 0 && unc / kept > out16[6]) out16[6] = unc / kept;
+  }
+  out16[8] = out16[0] > 0 ? esum / out16[0] : 0;
 }
 
 /* ================================ regulariser ============================== */

@@ -47,3 +47,21 @@ def census(prob, oracle_mod, n_pixels, seed=0, pvr=False):
     return dict(pixels=len(pick), taps=taps, kept_lit=kl, kept_can=kc, flips=flips, flip_rate=flips / max(taps, 1),
                 flips_per_kept=flips / max(kl, 1), flipped_mass_rel=mass_flip / max(mass_all, 1e-30), max_abs_dpsf=dmax,
                 pixels_with_flips=int(pw), sume_rel_max=srel)
+
+
+def fastmath_census(prob, oracle_mod, n_pixels, seed=0, pvr=False):
+    """The error envelope of the reference's own build (`--use_fast_math`, source/cmake/FindSciCuda.cmake:65-68) around the
+    literal sequence, on the same sampled pixels as `census`: how many skip decisions ANY arithmetic inside the envelope may
+    take differently (an upper bound), the PSF mass behind them, and where the canonical sequence lies relative to the envelope.
+    -> dict(pixels, taps, uncertain_rate, pixels_uncertain, uncertain_mass_rel, sume_rel_max, env_max, env_mean, canon_outside_rate,
+    canon_dmax, canon_over_env_max, canon_flips, canon_flips_explained)"""
+    lit = oracle_mod.OracleReconstruction(prob, oracle_mod.LITERAL, pvr=pvr)
+    act = np.argwhere(prob.slices != -1)
+    rng = np.random.default_rng(seed)
+    pick = act[rng.choice(len(act), min(n_pixels, len(act)), replace=False)]
+    r = lit.fastmath_census(pick)
+    return dict(pixels=len(pick), taps=int(r["taps"]), uncertain=int(r["uncertain"]), uncertain_rate=r["uncertain"] / max(r["taps"], 1),
+                pixels_uncertain=int(r["pixels_uncertain"]), uncertain_mass_rel=r["mass_uncertain"] / max(r["mass_kept"], 1e-30),
+                sume_rel_max=r["sume_rel_max"], env_max=r["env_max"], env_mean=r["env_mean"],
+                canon_outside_rate=r["canon_outside"] / max(r["taps"], 1), canon_dmax=r["canon_dmax"],
+                canon_over_env_max=r["canon_over_env_max"], canon_flips=int(r["canon_flips"]), canon_flips_explained=int(r["canon_flips_explained"]))

@@ -10,7 +10,7 @@ import pytest
 
 from fetalreconstruction_amd import phantom, workloads
 from fetalreconstruction_amd.reconstruction import irtkReconstruction
-from tests.census import census
+from tests.census import census, fastmath_census
 from tests.util import rel_err, run_to_state
 
 # HIP (canonical arithmetic, bit-identical to the oracle's CANON mode) against the oracle's LITERAL mode: PSF values
@@ -125,6 +125,37 @@ def test_literal_vs_canonical_skip_census(oracle_mod, capsys):
                   f"flipped PSF mass {r['flipped_mass_rel']:.1e} of the total, max |dPSF| {r['max_abs_dpsf']:.1e}, "
                   f"max relative change of a pixel's processed sum {r['sume_rel_max']:.1e}")
     assert total["pixels"] >= 10000
+
+
+def test_canonical_sequence_against_the_reference_builds_own_error_envelope(oracle_mod, capsys):
+    """The reference BINARY is not the literal sequence either: it is built with `-O3 --use_fast_math`
+    (source/cmake/FindSciCuda.cmake:65-68 via reconstructionGPU2/CMakeLists.txt:17) -- __sinf / __expf / __fdividef / sqrt.approx,
+    flush-to-zero, FMA contraction.  orc_fastmath_census puts NVIDIA's documented error bounds of those around every tap of
+    the literal sequence and counts the skip decisions (RC.cu:238) that can go either way inside that envelope: an upper bound
+    on what ANY admissible arithmetic of the reference's own build may decide differently.  Stated here: (i) that bound, (ii) the
+    canonical sequence's own flips stay below it -- it perturbs the reference's result less than the reference's compiler flags
+    may -- and most of them are decisions the envelope leaves open anyway, (iii) where |canonical - literal| exceeds the per-tap
+    bound (it does, at a few per cent of the taps: the literal form rounds its absolute lattice coordinates, the canonical one
+    does not) it does so by less than 4 x and by less than 3e-5 absolute."""
+    rows = []
+    for name, prob in (("P4 (bundled mask frame)", workloads.problem_p4()), ("P4s (axis-aligned)", phantom.problem_p4()),
+                       ("S8 geometry", phantom.problem_s8(slices_per_stack=6))):
+        f = fastmath_census(prob, oracle_mod, 4000, seed=7)
+        c = census(prob, oracle_mod, 4000, seed=7)
+        rows.append((name, f, c))
+        assert f["canon_flips"] == c["flips"]                                    # the C walk and the Python census count the same thing
+        assert f["uncertain"] >= 3 * f["canon_flips"], (name, f)                # the build's own latitude is several times the canonical sequence's distance
+        assert f["canon_flips_explained"] >= 0.6 * f["canon_flips"], (name, f)
+        assert f["uncertain_rate"] < 3e-4 and f["uncertain_mass_rel"] < 5e-4 and f["sume_rel_max"] < 0.25, (name, f)
+        assert f["canon_outside_rate"] < 0.05 and f["canon_over_env_max"] < 4.0 and f["canon_dmax"] < 3e-5, (name, f)
+    with capsys.disabled():
+        print()
+        for name, f, c in rows:
+            print(f"[fast-math envelope] {name}: {f['pixels']} px, {f['taps']} taps: {f['uncertain']} decisions open inside the envelope "
+                  f"({f['uncertain_rate']:.2e} of taps, {f['pixels_uncertain']} pixels), PSF mass behind them {f['uncertain_mass_rel']:.1e}, "
+                  f"largest possible change of one pixel's sum {f['sume_rel_max']:.1e}; envelope mean {f['env_mean']:.1e} max {f['env_max']:.1e}; "
+                  f"canonical: {f['canon_flips']} flips ({c['flip_rate']:.2e}), {f['canon_flips_explained']} of them open decisions, "
+                  f"outside the per-tap bound at {f['canon_outside_rate']:.1e} of the taps by <= {f['canon_over_env_max']:.1f} x, max |d| {f['canon_dmax']:.1e}")
 
 
 @pytest.mark.gpu

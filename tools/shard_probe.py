@@ -1,0 +1,181 @@
+"""What one rank of an N-rank run costs, measured on ONE GPU (there is no second one on the gpurun box).
+
+The whole workload first runs on one context to a representative state (the reference's preamble + two SR iterations: EM weights,
+scales, slice weights, simulated slices, the volume).  Then, for every rank r of N, a fresh context takes rank r's slice / patch
+range (the same ranges bench.py --gpus N would use), the donor's state for those units and the donor's volume, and the kernels of
+one SR iteration are timed there with HIP events (svr_timer_*): the scatter incl. its combine, the volume update (whole volume =
+what a replicated run pays, and the rank's z-slab = what reduce-scatter -> slab -> all-gather pays), the gather, the EM kernels.
+Nothing here is a scaling measurement: no collective runs; the projection adds bytes / a STATED link rate and is labelled so.
+
+usage: python tools/shard_probe.py WORKLOAD N [--reps K] [--out FILE]    (also reached as bench.py --shard all/N)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+# xGMI on MI355X: 7 links per GPU, ~153 GB/s each bidirectional = 76.8 GB/s per direction (MI355X_MICROARCH.md).  A reduce-scatter
+# or all-gather over a fully connected node moves (N - 1) / N of the message through the N - 1 links of a GPU side by side; ring
+# algorithms reach less.  The projection assumes the direct exchange at XGMI_EFF of the wire rate -- an assumption, stated in the output.
+XGMI_LINK_GBS = 76.8
+XGMI_EFF = 0.5
+HOST_EXCHANGE_MS = 0.08      # one stream synchronisation + one small collective (60-100 us measured at world 1)
+
+
+def build(wl):
+    from fetalreconstruction_amd import workloads, phantom
+    return workloads.get(wl) if wl != "tiny" else phantom.problem_tiny()
+
+
+def make_engine(prob, pvr, spx=None, opts=()):
+    from fetalreconstruction_amd import engine
+    rec = engine.Reconstruction(0)
+    if pvr:
+        rec.set_option("pvr", 1)
+        engine.sync_gpu(rec, prob, quality_factor=1.0)
+        if spx is not None:
+            rec.set_spx_masks(np.ascontiguousarray(spx))
+    else:
+        engine.sync_gpu(rec, prob)
+    for k, v in opts:
+        rec.set_option(k, v)
+    return rec
+
+
+def kernel_ms(rec, keys=("backproject", "forward", "regularize", "estep", "mstep", "scale")):
+    t = rec.timers()
+    return {k: (t[k][0] / t[k][1] if t[k][1] else 0.0) for k in keys}
+
+
+def collective_ms(bytes_per_rank_out, world):
+    """direct exchange: a rank sends (N - 1) / N of its message over its N - 1 links side by side"""
+    if world <= 1:
+        return 0.0
+    links = min(world - 1, 7)
+    return bytes_per_rank_out * (world - 1) / world / (links * XGMI_LINK_GBS * 1e9 * XGMI_EFF) * 1e3
+
+
+def probe(wl, world, reps=6, opts=()):
+    from fetalreconstruction_amd import engine as E, phantom, host
+    from fetalreconstruction_amd.reconstruction import shard_slices, slice_cost_weights
+    prob = build(wl)
+    pvr = wl.startswith("PVR")
+    spx = getattr(prob, "spx_masks", None)
+    if pvr:
+        work = (prob.slices > 0).reshape(prob.ns, -1).sum(1).astype(np.float64)
+    else:
+        act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
+        work = slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0])
+    ranges = shard_slices(work, world)
+
+    # ---- the donor: the whole workload on one context ------------------------------------------------------------------------
+    rec = make_engine(prob, pvr, spx, opts)
+    if pvr:
+        d = host.irtkPatchBasedReconstruction(rec, prob.patches_per_stack, prob.min_intensity, prob.max_intensity)
+        d.reconstruct_iteration(0)
+        upd = (False, 0.5, float(prob.min_intensity), float(prob.max_intensity), 1.0, 0.1)      # patchBasedSuperresolution_gpu.cu:293-295
+    else:
+        d = host.irtkReconstruction(rec, prob.ns, max_intensity=prob.max_intensity, min_intensity=prob.min_intensity)
+        d.SetSmoothingParameters(150, 0.02)
+        d.InitializeEMValuesGPU(); d.GaussianReconstructionGPU(); d.SimulateSlicesGPU(); d.InitializeRobustStatisticsGPU(); d.EStepGPU()
+        upd = (False, 0.8, float(prob.min_intensity), float(prob.max_intensity), 150.0, 0.02 * 150.0 ** 2)
+    for i in range(2):
+        d.sr_iteration(i)
+    st = d.state()
+    sw = np.asarray(st["patch_weight" if pvr else "slice_weight"], np.float32)
+    scales = np.asarray(st["scale"], np.float32)
+    donor = {b: rec.debug_get(b) for b in (E.BUF_WEIGHTS, E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_PSF_SUMS, E.BUF_SIMINSIDE)}
+    vol = rec.syncCPU().copy()
+    cnt = rec.counters()
+    n2 = prob.slices.shape[1] * prob.slices.shape[2]
+
+    def time_kernels(rec_, sw_, z_slab=None):
+        rec_.timer_enable(True)
+        for k in range(reps + 1):
+            if k == 1:
+                rec_.timer_reset()
+            rec_.SuperresolutionBackproject(sw_)
+            rec_.SuperresolutionUpdate(*upd)
+            rec_.SimulateSlices()
+            rec_.UpdateReconstructed(rec_.vsize, vol)              # (untimed: every repetition updates the donor's volume)
+        out = kernel_ms(rec_)
+        rec_.timer_enable(False)
+        return out
+
+    full = time_kernels(rec, sw)
+    full["cells"] = rec.cell_stats()
+    full["Va"] = cnt["Va"]
+    nv = cnt["Nv"]
+    vsize = [int(v) for v in rec.vsize]
+    rec.close()
+
+    # ---- rank by rank --------------------------------------------------------------------------------------------------------
+    shards = []
+    for r, (lo, hi) in enumerate(ranges):
+        sub = phantom.sub_problem(prob, lo, hi)
+        rs = make_engine(sub, pvr, None if spx is None else spx[lo:hi], opts)
+        rs.UpdateScaleVector(scales[lo:hi], sw[lo:hi])
+        for b, a in donor.items():
+            rs.debug_set(b, np.ascontiguousarray(a.reshape(prob.ns, -1)[lo:hi]).reshape(-1))
+        rs.UpdateReconstructed(rs.vsize, vol)
+        k = time_kernels(rs, sw[lo:hi])
+        k.update(rank=r, units=[int(lo), int(hi)], Va=rs.counters()["Va"], cells=rs.cell_stats())
+        shards.append(k)
+        rs.close()
+    return dict(workload=wl, world=world, Nv=nv, volume=vsize, full=full, shards=shards)
+
+
+def project(res):
+    """projected step of the sharded run from the per-shard kernel times -- a projection, not a measurement"""
+    W, nv = res["world"], res["Nv"]
+    full, sh = res["full"], res["shards"]
+    em = lambda k: k["estep"] + k["mstep"] + k["scale"]
+    one = full["backproject"] + full["regularize"] + full["forward"] + em(full)
+    psf = max(k["backproject"] + k["forward"] + em(k) for k in sh)
+    reg_full = max(k["regularize"] for k in sh)
+    # replicated: all-reduce of addon|cmap (2 Nv floats: reduce-scatter + all-gather of the whole message), whole-volume update
+    ar = 2 * collective_ms(2 * nv * 4, W)
+    replicated = psf + ar + reg_full + 2 * HOST_EXCHANGE_MS
+    # slab: reduce-scatter of addon|cmap over the mask's voxels (+ halo planes), update of the rank's slab, all-gather of the volume
+    mfrac = res.get("mask_fraction", 1.0)
+    rs_ms = collective_ms(2 * nv * 4 * mfrac, W)
+    ag_ms = collective_ms(nv * 4 * min(1.0, mfrac * 1.15), W)
+    slab = psf + rs_ms + reg_full / W + ag_ms + 2 * HOST_EXCHANGE_MS
+    return dict(label="PROJECTION from one-GPU per-shard kernel times; no collective was run",
+                assumptions=dict(xgmi_link_GBs_per_direction=XGMI_LINK_GBS, links_used=min(W - 1, 7), efficiency=XGMI_EFF,
+                                 host_exchange_ms=HOST_EXCHANGE_MS, host_exchanges_per_step=2),
+                one_gpu_kernels_ms=one, max_rank_psf_em_ms=psf, sum_rank_psf_ms=sum(k["backproject"] + k["forward"] for k in sh),
+                shard_overhead=sum(k["backproject"] + k["forward"] for k in sh) / (full["backproject"] + full["forward"]),
+                replicated=dict(allreduce_ms=ar, update_ms=reg_full, step_ms=replicated, speedup=one / replicated),
+                slab=dict(reduce_scatter_ms=rs_ms, update_ms=reg_full / W, allgather_ms=ag_ms, step_ms=slab, speedup=one / slab))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload")
+    ap.add_argument("world", type=int)
+    ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--out")
+    ap.add_argument("opts", nargs="*", help="engine options name=value")
+    a = ap.parse_args()
+    opts = [(o.split("=")[0], int(o.split("=")[1])) for o in a.opts]
+    t0 = time.time()
+    res = probe(a.workload, a.world, a.reps, opts)
+    P = build(a.workload)
+    res["mask_fraction"] = float((np.asarray(P.mask) != 0).mean())
+    res["projection"] = project(res)
+    res["wall_s"] = round(time.time() - t0, 1)
+    line = json.dumps(res)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
+    print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
