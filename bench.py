@@ -321,8 +321,9 @@ def main():
         all-reduce (HIP events around the collective on the engine's stream: the wait for the slowest rank + the ring) and of
         the small host-side exchanges (wall clock), plus the rank's share of the work -- so that a scaling shortfall can be
         put down to imbalance, RCCL or the host exchanges from the line alone"""
-        keys = ("backproject", "forward", "allreduce", "exchange_host", "regularize")
+        keys = ("backproject", "forward", "allreduce", "reduce_scatter", "allgather", "exchange_host", "regularize")
         mine = [tm[k][0] / max(tm[k][1], 1) for k in keys] + [float(tm["exchange_host"][1]) / max(args.steps, 1), float(cnt["Va"]), float(hi - lo)]
+        mine.append(float(coll_bytes))
         n = len(mine)
         v = np.zeros(world * n)
         v[rank * n:(rank + 1) * n] = mine
@@ -331,8 +332,23 @@ def main():
         out["exchanges_per_step"] = [round(float(x), 2) for x in v[:, len(keys)]]
         out["Va"] = [int(x) for x in v[:, len(keys) + 1]]
         out["units"] = [int(x) for x in v[:, len(keys) + 2]]
+        # what a rank sends per SR iteration through the volume collectives (slab update: (N-1)/N of reduce-scatter + all-gather
+        # messages; replicated update: the ring all-reduce's 2 (N-1)/N of the pair)
+        out["collective_bytes_sent"] = [int(x) for x in v[:, len(keys) + 3]]
         return out
 
+    # bytes of the volume collectives per SR iteration and rank
+    nvv = float(cnt["Nv"])
+    if not multi:
+        coll_bytes = 0.0
+    elif timers["reduce_scatter"][1]:
+        try:
+            rsn, agn = rec.slab_chunks(world if world > 1 else 1, rank)
+        except Exception:
+            rsn, agn = 0, 0
+        coll_bytes = 4.0 * (world - 1) * (rsn + agn) if world > 1 else 4.0 * (rsn + agn)
+    else:
+        coll_bytes = 2.0 * (world - 1) / max(world, 1) * 2.0 * nvv * 4.0
     ranks = per_rank(timers)
     if multi:
         dt = float(comm.allreduce_max(np.array([dt]))[0])
@@ -454,7 +470,9 @@ def main():
                        "schedule": f"outer iterations of {SR_PER_OUTER} SR iterations (rec_iterations_first, reconstruction.cc:115,187): every "
                                    f"{SR_PER_OUTER} steps InitializeEMValues + InitializeRobustStatistics + EStep run inside the timed region, so that "
                                    "the slices the EM drops do not pile up from step to step (24 steps on: 117 of 280 slices at weight 0)",
-                       "parallelism": f"{'patch' if pvr else 'slice'}-sharded x{world}, 1 in-place RCCL all-reduce of addon|cmap (float[2 Nv]) per scatter pass"
+                       "parallelism": (f"{'patch' if pvr else 'slice'}-sharded x{world}; volume update by z-slabs: reduce-scatter of addon|cmap at the mask's voxels -> every rank "
+                                       f"updates its own planes -> all-gather of the new volume (csrc/svr_slab.inc)" if timers["reduce_scatter"][1] else
+                                       f"{'patch' if pvr else 'slice'}-sharded x{world}, 1 in-place all-reduce of addon|cmap (float[2 Nv]) per scatter pass, update replicated")
                                       if world > 1 else "1 GPU",
                        "comm": (args.comm if multi else None), "rccl_world": rccl_world,
                        "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",

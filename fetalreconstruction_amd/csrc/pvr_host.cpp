@@ -280,9 +280,7 @@ class irtkPatchBasedReconstruction {
         PENG(svr_superresolution(e, i + 1, patch_weight.data() + lo, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta,
                                  m_lambda, 0, 12.0f, 0.01f));
       } else {
-        PENG(svr_superresolution_backproject(e, patch_weight.data() + lo));
-        PENG(sh.allreduce_pair(SVR_BUF_ADDON, 2 * svr_volume_voxels(e)));
-        PENG(svr_superresolution_update(e, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta, m_lambda));
+        PENG(sh.superresolution(patch_weight.data() + lo, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta, m_lambda));
       }
       PENG(svr_simulate_slices(e, nullptr));
       if ((rc = MStep(i + 1))) return rc;
@@ -316,6 +314,7 @@ pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, i
   return new pvrh_recon(engine, patches_per_stack, n_stacks, min_intensity, max_intensity, patch_lo, patch_hi, coll);
 }
 void pvrh_force_collectives(pvrh_recon *r, int on) { if (r) { (void)r->impl.settle(); r->impl.sh.force(on != 0); } }
+void pvrh_set_slab_update(pvrh_recon *r, int on) { if (r) r->impl.sh.slabs = on != 0; }
 int pvrh_sr_iteration(pvrh_recon *r, int i) { return r->impl.sr_iteration(i); }
 void pvrh_destroy(pvrh_recon *r) { delete r; }
 const char *pvrh_last_error(const pvrh_recon *r) { return r ? r->impl.err.c_str() : "null"; }

@@ -251,7 +251,7 @@ int main(int argc, char **argv) {
   fprintf(stderr, "\n");
 
   // ---- ranks: one engine context per device of -d (main.cc:191), the slices sharded over them in contiguous ranges
-  // balanced by estimated PSF work = active pixels x (9.4 + live planes of the 16, see reconstruction.py slice_cost_weights;
+  // balanced by estimated PSF work = active pixels x (9.4 + live planes of the 16) x (1 + 0.2 n_x^2), see reconstruction.py slice_cost_weights;
   // reconstruction_cuda2.cu:1413-1457 shards by slice count and drops the remainder) -----------------------------------
   const int nr = (int)std::max<size_t>(1, devices.size());
   std::vector<int> rlo(nr, 0), rhi(nr, ns);
@@ -270,7 +270,7 @@ int main(int argc, char **argv) {
       const double ax = fabs(nv[0]) / len, ay = fabs(nv[1]) / len, az = fabs(nv[2]) / len;
       const double ne = std::max(ay, az), no = std::min(ay, az), sigma = dims[3 * (size_t)s + 2] / 2.3548 / tattr.dx;
       const double live = std::min(16.0, 2.0 * (5.1 * sigma + 8.0 * (ax + no)) / std::max(ne, 1e-3) + 1.0);
-      cum[s + 1] = cum[s] + (double)c * (9.4 + live);
+      cum[s + 1] = cum[s] + (double)c * (9.4 + live) * (1.0 + 0.2 * ax * ax);
     }
     int at = 0;
     for (int r = 0; r < nr; ++r) {

@@ -2749,7 +2749,7 @@ __global__ __launch_bounds__(256) void k_ncc(const short *targets, int tx, int t
 // context
 // ==========================================================================================
 struct RegState;   // GPU slice-to-volume registration state (svr_reg.inc)
-namespace { struct CellState; }  // sorted pixels, runs, items and staging of the scatter without atomics (svr_cell.inc)
+namespace { struct CellState; struct SlabPlan; }  // sorted pixels, runs, items and staging of the scatter without atomics (svr_cell.inc)
 
 struct svr_ctx {
   int device = 0;
@@ -2908,6 +2908,8 @@ struct svr_ctx {
   RegState *reg = nullptr;
 
   // the scatter without atomics (back_mode 5, svr_cell.inc): cell size in voxels (x, lane axis), wavefronts per item
+  SlabPlan *slab = nullptr;       // sharded runs: the index lists and slab boundaries of reduce-scatter -> slab update -> all-gather (svr_slab.inc)
+  bool vol_clean[2] = {false, false};   // d_recon_volw / d_recon_new known to be zero outside the dilated mask (svr_slab.inc)
   CellState *cell = nullptr;      // the scatter's cell lists
   CellState *cell_g = nullptr;    // the gather's, when it works on another cell size (cell_prepare_gather)
   int cell_w = 0, cell_h = 0, cell_gw = 0, cell_gh = 0;   // 0: by the pixel density (cell_auto_size); cell_gw / cell_gh: the gather's own
@@ -3458,6 +3460,7 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
 }
 
 #include "svr_cell.inc"
+#include "svr_slab.inc"
 
 // reduce partial[ns*chunks][K] -> per_slice[ns][K] (+ optionally -> d_out[K])
 int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
@@ -3590,6 +3593,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   SVR_ENTER(ctx);
   if (!ctx || !name) return SVR_E_ARG;
   if (!strcmp(name, "back_mode")) { ctx->back_mode = value; ctx->back_mode_user = true; return SVR_OK; }
+  if (!strcmp(name, "sr_no_wait")) { ctx->sr_no_wait = value != 0; return SVR_OK; }   // svr_superresolution_backproject / _update / svr_slab_finish return without waiting for the device (a sharded run whose collectives share the stream)
   if (!strcmp(name, "reg_tile")) { if (value < -1 || value > 2) return fail(ctx, SVR_E_ARG, "reg_tile: -1 .. 2"); ctx->reg_tile = value; return SVR_OK; }
   if (!strcmp(name, "reg_mode")) { if (value < 0 || value > 1) return fail(ctx, SVR_E_ARG, "reg_mode: 0 or 1"); ctx->reg_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; ctx->fwd_mode_user = true; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
@@ -3705,6 +3709,7 @@ void svr_destroy(svr_ctx *ctx) {
   reg_free(ctx->reg);
   cell_free(ctx->cell);
   cell_free(ctx->cell_g);
+  slab_free(ctx->slab);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
@@ -3739,6 +3744,12 @@ int svr_set_stream(svr_ctx *ctx, void *hip_stream) {
 }
 
 void *svr_get_stream(svr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int svr_stream_sync(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
+  if (!ctx) return SVR_E_ARG;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
 int svr_device(svr_ctx *ctx) { return ctx ? ctx->device : -1; }
 int svr_device_count(void) {
   int n = 0;
@@ -3764,6 +3775,8 @@ int svr_init_reconstruction_volume(svr_ctx *ctx, const uint32_t size[3], const f
   HIPCHK(hipMalloc(&ctx->d_recon_new, nv * sizeof(float)));
   ctx->recon_cur = ctx->d_recon_volw;
   ctx->prep_pending = false; ctx->cmap_from_scatter = false;
+  ctx->vol_clean[0] = ctx->vol_clean[1] = false;
+  if (ctx->slab) ctx->slab->valid = false;
   HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * nv * sizeof(float), ctx->stream));   // RC.cu:1199-1229
   HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * nv * sizeof(float), ctx->stream));
   if (data) HIPCHK(hipMemcpyAsync(ctx->recon(), data, nv * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -3784,6 +3797,7 @@ int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const
   HIPCHK(hipMemcpyAsync(ctx->d_mask, data, ctx->nv * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->have_mask = true;
+  if (ctx->slab) ctx->slab->valid = false;
   ctx->mask_sigma_bias = sigma_bias;
   ctx->maskC_valid = false;
   {
@@ -4717,6 +4731,72 @@ int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float mi
   return SVR_OK;
 }
 
+// ---- the volume update of a sharded run: reduce-scatter -> the rank's z-slab -> all-gather (svr_slab.inc) ----------------
+int svr_slab_plan(svr_ctx *ctx, int world, int rank, size_t *rs_floats_per_rank, size_t *ag_floats_per_rank) {
+  SVR_ENTER(ctx);
+  if (!ctx) return SVR_E_ARG;
+  const int r = slab_plan(ctx, world, rank);
+  if (r) return r;
+  if (rs_floats_per_rank) *rs_floats_per_rank = (size_t)2 * ctx->slab->rs_chunk;
+  if (ag_floats_per_rank) *ag_floats_per_rank = ctx->slab->ag_chunk;
+  return SVR_OK;
+}
+int svr_slab_rs_pack(svr_ctx *ctx, void **send, void **recv) {
+  SVR_ENTER(ctx);
+  if (!ctx || !send || !recv) return SVR_E_ARG;
+  NEED(ctx->slab && ctx->slab->valid && ctx->slab->world > 0, "svr_slab_plan first");
+  NEED(ctx->cmap_from_scatter, "svr_slab_rs_pack: addon | cmap must come from svr_superresolution_backproject");
+  SlabPlan &p = *ctx->slab;
+  hipLaunchKernelGGL(k_slab_rs_pack, dim3(nblk((size_t)p.world * 2 * p.rs_chunk)), dim3(256), 0, ctx->stream, ctx->addon(), ctx->cmap(), p.d_midx, p.d_tab,
+                     p.world, p.rs_chunk, p.d_send);
+  KCHK("k_slab_rs_pack");
+  *send = p.d_send; *recv = p.d_recv;
+  return SVR_OK;
+}
+int svr_slab_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity, float max_intensity, float delta, float lambda,
+                    void **send, void **recv) {
+  SVR_ENTER(ctx);
+  if (!ctx || !send || !recv) return SVR_E_ARG;
+  NEED(ctx->slab && ctx->slab->valid && ctx->slab->world > 0, "svr_slab_plan first");
+  if (ctx->reg_mode == 0) return fail(ctx, SVR_E_STATE, "svr_slab_update needs reg_mode 1");
+  SlabPlan &p = *ctx->slab;
+  const int R = p.rank;
+  ScopedTimer t(ctx, SVR_T_REGULARIZE);
+  if (p.rs_count[R]) {
+    hipLaunchKernelGGL(k_slab_rs_unpack, dim3(nblk((size_t)2 * p.rs_count[R])), dim3(256), 0, ctx->stream, ctx->addon(), ctx->cmap(), p.d_midx, p.rs_start[R],
+                       p.rs_count[R], p.rs_chunk, p.d_recv);
+    KCHK("k_slab_rs_unpack");
+  }
+  const int ob = ctx->recon_cur == ctx->d_recon_volw ? 1 : 0;           // the buffer the update writes
+  float *out = ob ? ctx->d_recon_new : ctx->d_recon_volw;
+  if (!ctx->vol_clean[ob]) {
+    HIPCHK(hipMemsetAsync(out, 0, ctx->nv * sizeof(float), ctx->stream));
+    ctx->vol_clean[ob] = true;
+  }
+  int r = superresolution_update_planes(ctx, adaptive, alpha, min_intensity, max_intensity, delta, lambda, p.zb[R], p.zb[R + 1]);
+  if (r) return r;
+  hipLaunchKernelGGL(k_slab_ag_pack, dim3(nblk(p.ag_chunk)), dim3(256), 0, ctx->stream, out, p.d_didx, p.ag_start[R], p.ag_count[R], p.ag_chunk, p.d_send);
+  KCHK("k_slab_ag_pack");
+  t.stop();
+  *send = p.d_send; *recv = p.d_recv;
+  return SVR_OK;
+}
+int svr_slab_finish(svr_ctx *ctx) {
+  SVR_ENTER(ctx);
+  if (!ctx) return SVR_E_ARG;
+  NEED(ctx->slab && ctx->slab->valid && ctx->slab->world > 0, "svr_slab_plan first");
+  SlabPlan &p = *ctx->slab;
+  float *out = ctx->recon_cur == ctx->d_recon_volw ? ctx->d_recon_new : ctx->d_recon_volw;
+  hipLaunchKernelGGL(k_slab_ag_unpack, dim3(nblk((size_t)p.world * p.ag_chunk)), dim3(256), 0, ctx->stream, out, p.d_didx, p.d_tab, p.world, p.rank, p.ag_chunk, p.d_recv);
+  KCHK("k_slab_ag_unpack");
+  ctx->recon_cur = out;
+  // addon | cmap now hold the sums of this rank's slab only: not a state a reader should see as "the scatter's result"
+  ctx->cmap_from_scatter = false;
+  ctx->prep_pending = false;
+  if (!ctx->sr_no_wait) HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
 int svr_superresolution(svr_ctx *ctx, int iter, const float *slice_weight, int adaptive, float alpha,
                         float min_intensity, float max_intensity, float delta, float lambda,
                         int global_bias_correction, float sigma_bias, float low_intensity_cutoff) {
@@ -4852,6 +4932,8 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
   if (which == SVR_BUF_SLICES) { ctx->coeff_valid = false; cell_invalidate(ctx); }   // the table and the cell lists cover the pixels with s != -1
   if (which == SVR_BUF_MASK) ctx->mbox_valid = false;                               // (a mask set behind svr_set_mask's back: the whole pair is exchanged)
+  if (which == SVR_BUF_MASK && ctx->slab) ctx->slab->valid = false;
+  if (which == SVR_BUF_RECONSTRUCTED) ctx->vol_clean[ctx->recon_cur == ctx->d_recon_new ? 1 : 0] = false;
   if (which == SVR_BUF_ADDON || which == SVR_BUF_CONFIDENCE_MAP) ctx->cmap_from_scatter = false;   // (no longer known to vanish outside the mask)
   if (which == SVR_BUF_SLICES) return build_list(ctx, false);
   return SVR_OK;

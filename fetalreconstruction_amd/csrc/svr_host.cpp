@@ -309,10 +309,8 @@ class irtkReconstruction {
                               (float)_min_intensity, (float)_max_intensity, (float)_delta, (float)_lambda,
                               _global_bias_correction, _sigma_bias, _low_intensity_cutoff));
     } else {
-      ENG(svr_superresolution_backproject(reconstructionGPU, local(_slice_weight_gpu)));
-      ENG(sh.allreduce_pair(SVR_BUF_ADDON, 2 * svr_volume_voxels(reconstructionGPU)));
-      ENG(svr_superresolution_update(reconstructionGPU, _adaptive, (float)_alpha, (float)_min_intensity,
-                                     (float)_max_intensity, (float)_delta, (float)_lambda));
+      ENG(sh.superresolution(local(_slice_weight_gpu), _adaptive, (float)_alpha, (float)_min_intensity, (float)_max_intensity, (float)_delta,
+                             (float)_lambda));
     }
     return 0;
   }
@@ -599,6 +597,7 @@ int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_nul
 }
 
 void svrh_force_collectives(svrh_recon *r, int on) { if (r) { (void)r->impl.settle(); r->impl.sh.force(on != 0); } }
+void svrh_set_slab_update(svrh_recon *r, int on) { if (r) r->impl.sh.slabs = on != 0; }
 
 int svrh_get_state(svrh_recon *r, float *scale, float *slice_weight, float *slice_potential,
                    unsigned char *slice_inside, double s[8]) {

@@ -43,6 +43,7 @@ struct Rccl {
   int (*CommCount)(ncclComm_t, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
@@ -69,7 +70,7 @@ bool rccl_load() {
   g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.h, name)); \
   if (!g_rccl.field) { g_rccl.err = std::string("librccl lacks ") + name; g_rccl.h = nullptr; return; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
-    SYM(CommCount, "ncclCommCount") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather")
+    SYM(CommCount, "ncclCommCount") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(ReduceScatter, "ncclReduceScatter")
     SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
   });
@@ -112,6 +113,20 @@ int cb_allreduce_volume_pair(void *user, void *device_ptr, size_t n_floats) {
   HIPCHK_(c, hipSetDevice(c->device));
   NCCLCHK(c, g_rccl.AllReduce(device_ptr, device_ptr, n_floats, ncclFloat32, ncclSum, c->comm, c->stream));
   return 0;                            // no host synchronisation: the next engine call runs on the same stream
+}
+
+// the two collectives of the slab update (csrc/svr_slab.inc): on the engine's stream, no host synchronisation
+int cb_reduce_scatter_device(void *user, const void *send, void *recv, size_t n_per_rank) {
+  svr_comm *c = static_cast<svr_comm *>(user);
+  HIPCHK_(c, hipSetDevice(c->device));
+  NCCLCHK(c, g_rccl.ReduceScatter(send, recv, n_per_rank, ncclFloat32, ncclSum, c->comm, c->stream));
+  return 0;
+}
+int cb_allgather_device(void *user, const void *send, void *recv, size_t n_per_rank) {
+  svr_comm *c = static_cast<svr_comm *>(user);
+  HIPCHK_(c, hipSetDevice(c->device));
+  NCCLCHK(c, g_rccl.AllGather(send, recv, n_per_rank, ncclFloat32, c->comm, c->stream));
+  return 0;
 }
 
 int cb_allreduce_host(void *user, double *data, int n, int op) {
@@ -204,6 +219,9 @@ svr_comm *svr_comm_create(int rank, int world, const char id128[128], svr_ctx *e
   c->coll.allreduce_volume_pair = cb_allreduce_volume_pair;
   c->coll.allreduce_host = cb_allreduce_host;
   c->coll.allgather_slices = cb_allgather_slices;
+  c->coll.reduce_scatter_device = cb_reduce_scatter_device;
+  c->coll.allgather_device = cb_allgather_device;
+  c->coll.on_engine_stream = 1;
   return c;
 }
 
@@ -298,6 +316,64 @@ int g_pair(void *user, void *device_ptr, size_t n) {
   g->bar.wait();                                           // fsum is free again; the flag is final for this exchange
   return g->failed.load();
 }
+// reduce-scatter / all-gather through host memory (the same device named more than once): sums in rank order like g_pair, so the
+// slab update gives the replicated update's bits
+int g_rs(void *user, const void *send, void *recv, size_t n) {
+  auto *m = static_cast<svr_group::Member *>(user);
+  svr_group *g = m->g;
+  const int W = g->world;
+  hipStream_t st = static_cast<hipStream_t>(svr_get_stream(m->engine));
+  std::vector<float> &mine = g->fstage[m->rank];
+  mine.resize(n * W);
+  if (hipSetDevice(svr_device(m->engine)) != hipSuccess ||
+      hipMemcpyAsync(mine.data(), send, n * W * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    g->failed.store(1);
+  g->bar.wait();
+  std::vector<float> sum(n, 0.0f);
+  if (!g->failed.load()) {
+    for (int r = 0; r < W; ++r) {
+      if (g->fstage[r].size() != n * W) { g->failed.store(1); break; }
+      const float *src = g->fstage[r].data() + (size_t)m->rank * n;
+      for (size_t i = 0; i < n; ++i) sum[i] += src[i];
+    }
+  }
+  if (!g->failed.load() &&
+      (hipMemcpyAsync(recv, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+    g->failed.store(1);
+  g->bar.wait();                                           // every rank has read the stages
+  return g->failed.load();
+}
+int g_ag(void *user, const void *send, void *recv, size_t n) {
+  auto *m = static_cast<svr_group::Member *>(user);
+  svr_group *g = m->g;
+  const int W = g->world;
+  hipStream_t st = static_cast<hipStream_t>(svr_get_stream(m->engine));
+  std::vector<float> &mine = g->fstage[m->rank];
+  mine.resize(n);
+  if (hipSetDevice(svr_device(m->engine)) != hipSuccess ||
+      hipMemcpyAsync(mine.data(), send, n * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    g->failed.store(1);
+  g->bar.wait();
+  if (!g->failed.load()) {
+    for (int r = 0; r < W; ++r) {
+      if (g->fstage[r].size() != n) { g->failed.store(1); break; }
+      if (hipMemcpyAsync(static_cast<float *>(recv) + (size_t)r * n, g->fstage[r].data(), n * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) { g->failed.store(1); break; }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) g->failed.store(1);
+  }
+  g->bar.wait();
+  return g->failed.load();
+}
+int g_rs_rccl(void *user, const void *send, void *recv, size_t n) {
+  auto *m = static_cast<svr_group::Member *>(user);
+  return cb_reduce_scatter_device(m->g->comms[m->rank], send, recv, n);
+}
+int g_ag_rccl(void *user, const void *send, void *recv, size_t n) {
+  auto *m = static_cast<svr_group::Member *>(user);
+  return cb_allgather_device(m->g->comms[m->rank], send, recv, n);
+}
 int g_pair_rccl(void *user, void *device_ptr, size_t n) {
   auto *m = static_cast<svr_group::Member *>(user);
   return cb_allreduce_volume_pair(m->g->comms[m->rank], device_ptr, n);
@@ -380,11 +456,17 @@ const svr_collectives *svr_group_join(svr_group *g, int rank, svr_ctx *engine) {
     m.coll.allreduce_volume_pair = g_pair_rccl;
     m.coll.allreduce_host = g_host;
     m.coll.allgather_slices = g_gather;
+    m.coll.reduce_scatter_device = g_rs_rccl;
+    m.coll.allgather_device = g_ag_rccl;
+    m.coll.on_engine_stream = 1;
     return &m.coll;
   }
   m.coll.allreduce_volume_pair = g_pair;
   m.coll.allreduce_host = g_host;
   m.coll.allgather_slices = g_gather;
+  m.coll.reduce_scatter_device = g_rs;
+  m.coll.allgather_device = g_ag;
+  m.coll.on_engine_stream = 1;          // (they copy through the engine's stream and wait for it themselves)
   return &m.coll;
 }
 

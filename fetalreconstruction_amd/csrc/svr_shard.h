@@ -9,6 +9,7 @@
 #define SVR_SHARD_H
 
 #include <chrono>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/svr_host.h"
@@ -26,10 +27,15 @@ struct Shard {
     given = c != nullptr;
     if (c) coll = *c;
     else { coll.user = nullptr; coll.rank = 0; coll.world = 1; coll.allreduce_volume_pair = nullptr;
-           coll.allreduce_host = nullptr; coll.allgather_slices = nullptr; }
+           coll.allreduce_host = nullptr; coll.allgather_slices = nullptr; coll.reduce_scatter_device = nullptr; coll.allgather_device = nullptr; coll.on_engine_stream = 0; }
     on = given && coll.world > 1;
+    if (const char *v = getenv("SVR_SLAB_UPDATE")) slabs = atoi(v) != 0;     // (tests: the two forms of the volume update side by side)
   }
   void force(bool f) { on = given && (coll.world > 1 || f); }   // test hook: world 1 through the callbacks
+
+  // a collective that does not run on the engine's stream must not start before what the engine has queued there (the pack
+  // kernel, the scatter) is done
+  int before_device_collective() { return coll.on_engine_stream ? 0 : svr_stream_sync(e); }
 
   // in-place sum of a device buffer of the engine over the ranks, on the engine's stream; HIP events around it when the
   // engine's timers are on (SVR_T_ALLREDUCE: what a rank waits for = its own wait for the slowest rank + the ring)
@@ -41,6 +47,7 @@ struct Shard {
     void *packed = nullptr;
     size_t n_packed = 0;
     if ((rc = svr_pair_pack(e, buffer, n_floats, &packed, &n_packed))) return rc;
+    if ((rc = before_device_collective())) return rc;
     if (packed) {
       if ((rc = coll.allreduce_volume_pair(coll.user, packed, n_packed))) return rc;
       if ((rc = svr_pair_unpack(e, buffer, n_floats))) return rc;
@@ -49,6 +56,42 @@ struct Shard {
       if (rc) return rc;
     }
     return svr_timer_end(e, SVR_T_ALLREDUCE);
+  }
+
+  // The volume update of an SR iteration (after svr_superresolution_backproject).  By z-slabs when the launcher supplies the two device
+  // collectives: reduce-scatter of addon | cmap at the mask's voxels -> the rank's slab -> all-gather of the new volume
+  // (csrc/svr_slab.inc: less than half the bytes of the all-reduce, and the update's time divides by the ranks).  Otherwise
+  // all-reduce of the pair + the update replicated on every rank.  Same bits either way.
+  bool slabs = true;       // (svrh_set_slab_update / pvrh_set_slab_update: tests compare the two forms)
+  // scatter + update of a sharded SR iteration; nothing waits for the device when the collectives run on the engine's stream
+  int superresolution(const float *unit_weights, int adaptive, float alpha, float min_i, float max_i, float delta, float lambda) {
+    const int async = coll.on_engine_stream ? 1 : 0;
+    int rc = svr_set_option(e, "sr_no_wait", async);
+    if (!rc) rc = svr_superresolution_backproject(e, unit_weights);
+    if (!rc) rc = update(adaptive, alpha, min_i, max_i, delta, lambda);
+    const int rc2 = svr_set_option(e, "sr_no_wait", 0);
+    return rc ? rc : rc2;
+  }
+  int update(int adaptive, float alpha, float min_i, float max_i, float delta, float lambda) {
+    int rc;
+    if (!(slabs && coll.reduce_scatter_device && coll.allgather_device)) {
+      if ((rc = allreduce_pair(SVR_BUF_ADDON, 2 * svr_volume_voxels(e)))) return rc;
+      return svr_superresolution_update(e, adaptive, alpha, min_i, max_i, delta, lambda);
+    }
+    size_t nrs = 0, nag = 0;
+    void *send = nullptr, *recv = nullptr;
+    if ((rc = svr_slab_plan(e, coll.world, coll.rank, &nrs, &nag))) return rc;
+    if ((rc = svr_timer_begin(e, SVR_T_REDUCE_SCATTER))) return rc;
+    if ((rc = svr_slab_rs_pack(e, &send, &recv))) return rc;
+    if ((rc = before_device_collective())) return rc;
+    if ((rc = coll.reduce_scatter_device(coll.user, send, recv, nrs))) return rc;
+    if ((rc = svr_timer_end(e, SVR_T_REDUCE_SCATTER))) return rc;
+    if ((rc = svr_slab_update(e, adaptive, alpha, min_i, max_i, delta, lambda, &send, &recv))) return rc;
+    if ((rc = svr_timer_begin(e, SVR_T_ALLGATHER))) return rc;
+    if ((rc = before_device_collective())) return rc;
+    if ((rc = coll.allgather_device(coll.user, send, recv, nag))) return rc;
+    if ((rc = svr_slab_finish(e))) return rc;
+    return svr_timer_end(e, SVR_T_ALLGATHER);
   }
 
   // ONE host collective per exchange.  Every host-side collective is a stream synchronisation plus a small collective

@@ -24,7 +24,7 @@ BUF_BIAS_VOLUME, BUF_SMOOTH_MASK = 5, 6
 BUF_SLICES, BUF_WEIGHTS, BUF_SIMSLICES, BUF_SIMWEIGHTS, BUF_PSF_SUMS, BUF_BIAS = 10, 11, 12, 13, 14, 15
 BUF_SIMINSIDE, BUF_VOXEL_COUNT = 20, 21
 T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE, T_REGISTER = range(8)
-TIMER_NAMES = ("backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale", "register", "allreduce", "exchange_host", "coeff_build")
+TIMER_NAMES = ("backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale", "register", "allreduce", "exchange_host", "coeff_build", "reduce_scatter", "allgather")
 
 EXPORTS = [
     "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_get_option", "svr_set_spx_masks", "svr_init_reconstruction_volume",
@@ -43,6 +43,7 @@ EXPORTS = [
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
     "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches", "svr_pvr_register_patches",
+    "svr_slab_plan", "svr_slab_rs_pack", "svr_slab_update", "svr_slab_finish", "svr_stream_sync",
     "svr_get_scale_vector", "svr_adopt_scale_vector", "svr_get_slice_inside", "svr_mstep_estep", "svr_mstep_sums_fetch",
 ]
 
@@ -471,6 +472,12 @@ class Reconstruction:
         o = (C.c_uint64 * 3)()
         self._ck(self._lib.svr_unit_counts(self._h, o))
         return dict(pixels=int(o[0]), live_units=int(o[1]), dead_units=int(o[2]))
+
+    def slab_chunks(self, world, rank):
+        """svr_slab_plan: floats per rank of the slab update's reduce-scatter and all-gather messages"""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self._lib.svr_slab_plan(self._h, int(world), int(rank), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def cell_stats(self):
         o = (C.c_uint64 * 8)()

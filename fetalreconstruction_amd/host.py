@@ -22,11 +22,11 @@ HOST_EXPORTS = [
     "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
     "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state", "svrh_set_bias_correction", "svrh_bias_gpu",
     "svrh_normalise_bias_gpu", "svrh_prepare_registration_slices", "svrh_slice_to_volume_registration_gpu",
-    "svrh_get_registration_slices", "svrh_force_collectives",
+    "svrh_get_registration_slices", "svrh_force_collectives", "svrh_set_slab_update",
 ]
 PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_initialize_em_values", "pvrh_initialize_robust_statistics",
                     "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_register_patches", "pvrh_get_state",
-                    "pvrh_create_sharded", "pvrh_force_collectives", "pvrh_sr_iteration"]      # csrc/pvr_host.cpp
+                    "pvrh_create_sharded", "pvrh_force_collectives", "pvrh_set_slab_update", "pvrh_sr_iteration"]      # csrc/pvr_host.cpp
 IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_package_to_volume", "svrh_irtk_resample_with_padding",
                 "svrh_irtk_blur_with_padding", "svrh_irtk_rigid_parameters"]                                  # csrc/irtk_reg.cpp
 IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write", "svr_host_threads"]      # csrc/svr_io.cpp, declared in svr_host.h
@@ -48,7 +48,10 @@ class ImageAttr(C.Structure):
 
 class _Coll(C.Structure):
     _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("allreduce_volume_pair", _AR_PAIR),
-                ("allreduce_host", _AR_HOST), ("allgather_slices", _AG)]
+                ("allreduce_host", _AR_HOST), ("allgather_slices", _AG),
+                # device-buffer reduce-scatter / all-gather of the slab update: not supplied by the torch.distributed callbacks (NULL ->
+                # all-reduce + replicated update); on_engine_stream 0: the C++ host synchronises the engine's stream before ar_pair
+                ("reduce_scatter_device", C.c_void_p), ("allgather_device", C.c_void_p), ("on_engine_stream", C.c_int)]
 
 
 class RcclComm:
@@ -172,7 +175,7 @@ class irtkReconstruction:
                     return 1
 
             self._cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag))     # keep the thunks alive
-            self._coll = _Coll(None, comm.rank, comm.world, *self._cbs)
+            self._coll = _Coll(None, comm.rank, comm.world, *self._cbs, None, None, 0)
         if self._coll is not None:
             coll_ptr = C.byref(self._coll)
         h = self._lib.svrh_create(rec._h, self.ns, int(self.lo), int(self.hi), coll_ptr)

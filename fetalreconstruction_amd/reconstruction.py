@@ -130,13 +130,17 @@ def shard_slices(active_per_slice, world):
 
 
 def slice_cost_weights(active_per_slice, slice_i2w, slice_t, recon_w2i, slice_dim, voxel):
-    """Estimated PSF work of every slice for the sharding: active pixels x (9.4 + live planes).  A (pixel, plane) unit of
+    """Estimated PSF work of every slice for the sharding: active pixels x (9.4 + live planes) x (1 + 0.2 n_x^2).  A (pixel, plane) unit of
     the owned axis e (the volume axis y or z closest to the slice normal n) is evaluated in full unless all of its taps
     lie further than 5.1 sigma_z from the slice plane: |d n_e| - 8 (|n_x| + |n_o|) > 5.1 sigma_z (csrc/svr_hip.hip,
     unit_is_dead).  Axial / coronal slices keep ~12 of their 16 planes, sagittal ones (normal along x, the axis of the
     sequential epsilon-chain, which cannot be owned) all 16.  Measured per stack on P4 (scatter + gather, ns per active
-    pixel): axial 8.1, coronal 8.2, sagittal 9.6, in-plane rotated axial 8.8 -- the constant 9.4 is fitted to the first
-    three; sharding by pixel count alone leaves the ranks that hold the sagittal stack with 1.19x the work."""
+    pixel): axial 8.1, coronal 8.2, sagittal 9.6, in-plane rotated axial 8.8 -- the constant 9.4 is fitted to the first three.  Round 4 measured what a
+    RANK pays (tools/shard_probe.py: 8 ranks, each with its own range, one after the other on one GPU): sagittal / axial per pixel 1.26
+    on S8 -- where the thick slices keep 15.4 of 16 planes alive whatever their orientation, so the live planes explain nothing -- and
+    1.37 on P4, and the ranks holding the sagittal stacks were the slowest by 17 %.  A run of a slice whose normal is the x axis
+    spans a band of 8 centre planes (svr_cell.inc): its pixels are live on 16 of the 23 planes the run visits.  Hence the last
+    factor (S8 1.02 x 1.2, P4 1.19 x 1.2); sharding by pixel count alone leaves the ranks that hold the sagittal stack with 1.19x the work."""
     act = np.asarray(active_per_slice, np.float64)
     i2w = np.asarray(slice_i2w, np.float64).reshape(-1, 4, 4)
     t = np.asarray(slice_t, np.float64).reshape(-1, 4, 4)
@@ -147,7 +151,7 @@ def slice_cost_weights(active_per_slice, slice_i2w, slice_t, recon_w2i, slice_di
     ne, no = np.maximum(ay, az), np.minimum(ay, az)
     sigma = np.asarray(slice_dim, np.float64).reshape(-1, 3)[:, 2] / 2.3548 / float(voxel)
     live = np.minimum(16.0, 2.0 * (5.1 * sigma + 8.0 * (ax + no)) / np.maximum(ne, 1e-3) + 1.0)
-    return act * (9.4 + live)
+    return act * (9.4 + live) * (1.0 + 0.2 * ax * ax)
 
 
 class irtkReconstruction:

@@ -206,6 +206,7 @@ int svr_set_stream(svr_ctx *ctx, void *hip_stream);
 /* the hipStream_t every kernel of the context is enqueued on, and the context's device (for collectives that must be ordered
  * with the kernels: csrc/svr_rccl.cpp) */
 void *svr_get_stream(svr_ctx *ctx);
+int svr_stream_sync(svr_ctx *ctx);   /* wait for everything queued on the engine's stream */
 int svr_device(svr_ctx *ctx);
 /* number of HIP devices visible to this process (hipGetDeviceCount; 0 on error): what `-d` / --gpus can name */
 int svr_device_count(void);
@@ -214,6 +215,22 @@ int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num_local); /* e
 int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight); /* addon|cmap */
 int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity,
                                float max_intensity, float delta, float lambda);
+/* The volume update of a SHARDED run by z-slabs (csrc/svr_slab.inc) instead of all-reduce + svr_superresolution_update on every
+ * rank -- replaces the reduce on GPU 0 + AdaptiveRegularization there, reconstruction_cuda2.cu:2225-2239, 2138-2181:
+ *   svr_slab_plan(world, rank)   once per (mask, world): slab boundaries, index lists; chunk sizes in floats PER RANK
+ *   svr_slab_rs_pack             after svr_superresolution_backproject: *send = float[world][rs_floats_per_rank] (addon | cmap at the
+ *                                mask's voxels of every rank's slab + halo planes), *recv = float[rs_floats_per_rank]
+ *   -- the caller reduce-scatters (sum) send -> recv over the ranks, on the engine's stream or ordered behind it --
+ *   svr_slab_update              the sums go into addon | cmap, the rank's planes are updated, *send = float[ag_floats_per_rank] (its part
+ *                                of the new volume), *recv = float[world][ag_floats_per_rank]
+ *   -- the caller all-gathers send -> recv --
+ *   svr_slab_finish              every rank's part goes into the new volume, which becomes the reconstructed volume.
+ * Same bits as the replicated update.  Needs option reg_mode 1 (the default) and a mask set through svr_set_mask. */
+int svr_slab_plan(svr_ctx *ctx, int world, int rank, size_t *rs_floats_per_rank, size_t *ag_floats_per_rank);
+int svr_slab_rs_pack(svr_ctx *ctx, void **send, void **recv);
+int svr_slab_update(svr_ctx *ctx, int adaptive, float alpha, float min_intensity, float max_intensity, float delta, float lambda,
+                    void **send, void **recv);
+int svr_slab_finish(svr_ctx *ctx);
 /* NormaliseBias halves: scatter into SVR_BUF_BIAS_VOLUME (all-reduce it), then normalise + apply */
 int svr_normalise_bias_local(svr_ctx *ctx);
 int svr_normalise_bias_finish(svr_ctx *ctx, float sigma_bias);
@@ -313,7 +330,8 @@ enum svr_timer {
    * exchanges (wall clock: a stream synchronisation plus the collective) */
   SVR_T_ALLREDUCE = 8, SVR_T_EXCHANGE = 9,
   SVR_T_COEFF_BUILD = 10,   /* k_coeff_build: writing the coefficient table (option coeff_table), once per slice geometry */
-  SVR_T_COUNT = 11
+  SVR_T_REDUCE_SCATTER = 11, SVR_T_ALLGATHER = 12,   /* the two collectives of the slab update (svr_slab_*), HIP events like SVR_T_ALLREDUCE */
+  SVR_T_COUNT = 13
 };
 /* HIP events on the engine's stream around work a caller enqueues there itself (the volume all-reduce); no-ops while the
  * timers are off.  svr_timer_end waits for the stream. */

@@ -37,6 +37,16 @@ typedef struct svr_collectives {
   int (*allreduce_host)(void *user, double *data, int n, int op);
   /* gather the per-slice vectors of all ranks (rank order = slice order) into global[n_global] */
   int (*allgather_slices)(void *user, const float *local, int n_local, float *global_out, int n_global);
+  /* device buffers, on the engine's stream or ordered behind it (NULL: the host objects all-reduce the volume pair and run the volume
+   * update replicated instead of by z-slabs, csrc/svr_slab.inc):
+   * recv[n] = sum over ranks r' of send_{r'}[rank * n .. rank * n + n)   (send = float[world * n]) */
+  int (*reduce_scatter_device)(void *user, const void *send, void *recv, size_t n_floats_per_rank);
+  /* recv[r * n .. r * n + n) = send_r[0 .. n) for every rank r   (recv = float[world * n]) */
+  int (*allgather_device)(void *user, const void *send, void *recv, size_t n_floats_per_rank);
+  /* 1: the three device-buffer callbacks enqueue on the engine's stream (svr_get_stream) -- the host objects then launch scatter,
+   * collective and volume update back to back without waiting for the device.  0: the host objects synchronise the engine's stream
+   * before every device-buffer callback (its input may still be in flight there), and the callback returns with its result complete. */
+  int on_engine_stream;
 } svr_collectives;
 
 /* ---- the collectives on RCCL, bound directly (csrc/svr_rccl.cpp) ---------------------------------------------------
@@ -142,6 +152,9 @@ int svr_host_threads(void);
 
 /* test hook: a world-1 run goes through the launcher's collectives like a sharded one (instead of an environment variable) */
 void svrh_force_collectives(svrh_recon *r, int on);
+/* sharded runs: 1 (default) = the volume update by z-slabs when the launcher supplies reduce_scatter_device / allgather_device
+ * (csrc/svr_slab.inc), 0 = all-reduce of the pair + the update replicated on every rank.  Same results. */
+void svrh_set_slab_update(svrh_recon *r, int on);
 
 /* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
  * scalars8 = {sigma, mix, m, mean_s, mean_s2, sigma_s, sigma_s2, mix_s}.  Sharded runs: COLLECTIVE -- the scale vector and
@@ -210,6 +223,7 @@ pvrh_recon *pvrh_create(svr_ctx *engine, const int *patches_per_stack, int n_sta
 pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_intensity, float max_intensity,
                                 int patch_lo, int patch_hi, const svr_collectives *coll_or_null);
 void pvrh_force_collectives(pvrh_recon *r, int on);
+void pvrh_set_slab_update(pvrh_recon *r, int on);
 void pvrh_destroy(pvrh_recon *r);
 const char *pvrh_last_error(const pvrh_recon *r);
 int pvrh_initialize_em_values(pvrh_recon *r);

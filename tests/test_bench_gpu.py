@@ -97,7 +97,9 @@ def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
         rec.timer_reset()
         d.sr_iteration(2)
         tm = rec.timers()
-        assert tm["allreduce"][1] == 1 and tm["exchange_host"][1] == 2 and tm["allreduce"][0] > 0
+        # (the volume update by z-slabs: one reduce-scatter and one all-gather instead of the all-reduce of the pair)
+        assert tm["allreduce"][1] == 0 and tm["reduce_scatter"][1] == 1 and tm["allgather"][1] == 1 and tm["exchange_host"][1] == 2
+        assert tm["reduce_scatter"][0] > 0 and tm["allgather"][0] > 0
     recs[1][1].close()
 
 
@@ -131,7 +133,8 @@ def test_bench_pvr_workload_through_the_sharded_path():
     assert a["value"] > 0 and a["config"]["comm"] == "rccl" and a["config"]["rccl_world"] == 1 and "patches" in a["config"]["workload"]
     k = a["ranks"]
     assert len(k["Va"]) == 1 and k["Va"][0] == a["config"]["Va_total"] and k["units"][0] == a["config"]["slices"]
-    assert k["backproject_ms"][0] > 0 and k["forward_ms"][0] > 0 and k["allreduce_ms"][0] > 0 and k["exchange_host_ms"][0] > 0
+    assert k["backproject_ms"][0] > 0 and k["forward_ms"][0] > 0 and k["exchange_host_ms"][0] > 0
+    assert k["reduce_scatter_ms"][0] > 0 and k["allgather_ms"][0] > 0 and k["collective_bytes_sent"][0] > 0       # the slab update's two collectives
     assert k["exchanges_per_step"][0] == 2.0                 # M-step, E-step (the scale vector rides along)
     assert set(a["config"]["tuned"]) >= {"gather_tile", "scatter_tile", "scatter_box"}
 

@@ -213,7 +213,7 @@ def test_slice_cost_weights_follow_the_live_planes():
     eye = np.eye(4).reshape(16)
     w = slice_cost_weights([100, 100, 100, 100], [i2w(2), i2w(1), i2w(0), i2w(2)], [eye] * 4, eye,
                            [[1, 1, 2.5], [1, 1, 2.5], [1, 1, 2.5], [1, 1, 5.0]], 1.0)
-    assert np.isclose(w[0], w[1]) and np.isclose(w[2], 100 * (9.4 + 16.0))
+    assert np.isclose(w[0], w[1]) and np.isclose(w[2], 100 * (9.4 + 16.0) * 1.2)
     assert np.isclose(w[0], 100 * (9.4 + 2 * 5.1 * 2.5 / 2.3548 + 1)) and w[3] > w[0]
 
 

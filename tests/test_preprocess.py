@@ -322,6 +322,37 @@ def test_command_line_shards_the_slices_over_the_devices_of_d(tmp_path, registra
         assert np.corrcoef(v1[ok], v3[ok])[0, 1] > 0.98
 
 
+@pytest.mark.gpu
+def test_slab_update_gives_the_replicated_updates_bits(tmp_path):
+    """A sharded run updates the volume by z-slabs: reduce-scatter of addon | cmap at the mask's voxels, every rank regularises
+    its own planes, all-gather of the new volume (csrc/svr_slab.inc) -- instead of all-reducing the pair and running the update
+    on every rank (SVR_SLAB_UPDATE=0).  Three ranks on one device exchange through host memory, where both collectives add the
+    ranks' values in rank order: the written volumes must be identical bit for bit, SVR and patch-based."""
+    import os
+    import subprocess
+    from fetalreconstruction_amd import build, nifti
+    paths, mpath, rattr, rmask = _write_case(tmp_path)
+    common = ["-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "2",
+              "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2", "--no_registration", "-d", "0", "0", "0"]
+    outs = {}
+    for slab in ("1", "0"):
+        env = dict(os.environ, SVR_SLAB_UPDATE=slab, SVR_CLI_TIMING="1")
+        r = subprocess.run([build.CLI, "-o", str(tmp_path / f"svr{slab}.nii.gz"), *common], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[slab] = nifti.read(tmp_path / f"svr{slab}.nii.gz")[0]
+    assert np.abs(outs["1"]).max() > 0
+    assert np.array_equal(outs["1"], outs["0"])
+    pcommon = ["-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8", "--resolution", "1.0", "--iterations", "1",
+               "--sr_iterations", "3", "--no_registration", "-d", "0", "0", "0"]
+    for slab in ("1", "0"):
+        env = dict(os.environ, SVR_SLAB_UPDATE=slab)
+        r = subprocess.run([build.PVR_CLI, "-o", str(tmp_path / f"pvr{slab}.nii.gz"), *pcommon], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs["p" + slab] = nifti.read(tmp_path / f"pvr{slab}.nii.gz")[0]
+    assert np.abs(outs["p1"]).max() > 0
+    assert np.array_equal(outs["p1"], outs["p0"])
+
+
 def test_template_must_be_identified(tmp_path):
     """reconstruction.cc:452-457: with transformations given and none of them `id`, the reference stops with 'Please identify
     the template by assigning id transformation' -- both command lines do (before any GPU work)."""

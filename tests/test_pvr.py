@@ -878,8 +878,8 @@ def test_pvr_command_line_shards_the_patches_over_the_devices_of_d(tmp_path, reg
 @pytest.mark.gpu
 def test_cpp_pvr_host_through_the_collectives_at_world_one():
     """pvrh_create_sharded with the C library's RCCL communicator at world 1 (forced through the callbacks): the sharded code
-    path -- local Gaussian pass + all-reduce + finish, scatter + all-reduce + regulariser, the three exchanges per SR
-    iteration -- gives the volume and the host state of the plain one-rank object."""
+    path -- local Gaussian pass + all-reduce + finish, scatter + reduce-scatter + the rank's slab of the volume update + all-gather
+    (csrc/svr_slab.inc), the exchanges of an SR iteration -- gives the volume and the host state of the plain one-rank object."""
     from fetalreconstruction_amd import engine as E, host
     pvr, stacks, P = _small_pvr()
     out = []
@@ -896,7 +896,8 @@ def test_cpp_pvr_host_through_the_collectives_at_world_one():
         if comm:
             comm.close()
     (v0, s0, t0), (v1, s1, t1) = out
-    assert t0["allreduce"][1] == 0 and t1["allreduce"][1] == 3 and t1["exchange_host"][1] == 1 + 1 + 2 * 2   # robust stats, E-step, 2 x (M-step, E-step)
+    assert t0["allreduce"][1] == 0 and t1["allreduce"][1] == 1 and t1["exchange_host"][1] == 1 + 1 + 2 * 2   # Gaussian pass; robust stats, E-step, 2 x (M-step, E-step)
+    assert t1["reduce_scatter"][1] == 2 and t1["allgather"][1] == 2 and t0["reduce_scatter"][1] == 0          # one of each per SR iteration
     assert np.array_equal(v0 > 0, v1 > 0) and np.abs(v0 - v1).max() <= 2e-5 * np.abs(v0).max()
     for k in ("scale", "patch_weight", "patch_potential"):
         assert np.allclose(s0[k], s1[k], rtol=2e-5, atol=1e-6), k
