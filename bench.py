@@ -163,7 +163,20 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="dev/test: all ranks use cuda:0 (--comm torch --backend gloo only)")
     ap.add_argument("--force-comm", action="store_true",
                     help="dev/test: run the multi-rank code path (rendezvous, communicator, every exchange of the host loop) at world size 1")
+    ap.add_argument("--shard", metavar="r/N | all/N",
+                    help="what rank r of an N-rank run costs, measured on THIS one GPU: the workload runs whole to a representative state, then "
+                         "rank r's slice / patch range runs alone on a fresh context with that state and the kernels of one SR iteration are timed "
+                         "(tools/shard_probe.py).  all/N: every rank in turn + the projected step (kernels + bytes / a stated xGMI rate; labelled a projection)")
     args = ap.parse_args()
+
+    if args.shard:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import shard_probe
+        which, n = args.shard.split("/")
+        only = None if which == "all" else [int(which)]
+        res = shard_probe.run(args.workload, int(n), reps=max(2, args.steps // 2), only=only)
+        print(json.dumps(res), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched plainly: become the launcher -- N ranks of this script, one per GPU, on this node

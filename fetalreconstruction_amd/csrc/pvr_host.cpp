@@ -205,7 +205,7 @@ class irtkPatchBasedReconstruction {
 
   int MStep(int iter) {                                                      // PRS.cu:570-640
     if (!sh.on && iter > 0) {
-      if (int rc = settle()) return rc;
+      if (mstep_pending) { if (int rc = settle()) return rc; }   // (only an M-step still waiting; the scale vector stays pending for the fused fetch)
       mstep_pending = iter;                          // runs with the E-step that follows (PBR.cpp:540-545), or in settle
       return 0;
     }

@@ -147,6 +147,7 @@ int main(int argc, char **argv) {
   clk.mark("mask, crop, template");
   auto stack_registrations = [&]() {                                                             // StackRegistrations, RG.cc:849-1001
     if (no_registration || n < 2 || !sfolder.empty()) return;                                    // main.cc:658, 708
+    if (dry_run) die("--dryRun makes no engine context and cannot register the stacks: add --no_registration (or --sfolder)");
     need_ctx();
     std::vector<svr_image_attr> at(n);
     std::vector<const double *> ptr(n);

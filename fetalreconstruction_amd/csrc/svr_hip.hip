@@ -3496,18 +3496,22 @@ int upload_ns(svr_ctx *ctx, float *dst, const float *src, std::vector<float> &mi
   return SVR_OK;
 }
 
-// queue a small device -> host copy; nothing is in `dst` before down_flush
+// queue a small device -> host copy; nothing is in `dst` before down_flush.  A call that fails drops everything queued so far
+// (the destinations are the caller's memory: a later, unrelated down_flush must not write to them)
 int down_queue(svr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  auto drop = [&](int code, const std::string &msg) { ctx->down_items.clear(); ctx->down_used = 0; return fail(ctx, code, msg); };
   const size_t need = ctx->down_used + ((bytes + 63) & ~(size_t)63);
   if (need > ctx->down_cap) {
-    if (!ctx->down_items.empty()) return fail(ctx, SVR_E_STATE, "down_queue: arena too small for the queued copies");
+    if (!ctx->down_items.empty()) return drop(SVR_E_STATE, "down_queue: arena too small for the queued copies");
     const size_t cap = std::max<size_t>(need, (size_t)ctx->ns * 12 + 4096);
-    if (ctx->h_down) HIPCHK(hipHostFree(ctx->h_down));
+    if (ctx->h_down) (void)hipHostFree(ctx->h_down);
     ctx->h_down = nullptr; ctx->down_cap = 0;
-    HIPCHK(hipHostMalloc((void **)&ctx->h_down, cap, hipHostMallocDefault));
+    const hipError_t e = hipHostMalloc((void **)&ctx->h_down, cap, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->h_down = nullptr; return drop((int)e, std::string("down_queue: hipHostMalloc: ") + hipGetErrorString(e)); }
     ctx->down_cap = cap;
   }
-  HIPCHK(hipMemcpyAsync(ctx->h_down + ctx->down_used, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  const hipError_t e = hipMemcpyAsync(ctx->h_down + ctx->down_used, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e != hipSuccess) return drop((int)e, std::string("down_queue: hipMemcpyAsync: ") + hipGetErrorString(e));
   ctx->down_items.push_back({dst, ctx->down_used, bytes});
   ctx->down_used = need;
   return SVR_OK;

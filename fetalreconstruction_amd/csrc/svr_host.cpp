@@ -318,7 +318,7 @@ class irtkReconstruction {
   // RG.cc:4214-4223 + Reconstruction::MStep host part (reconstruction_cuda2.cu:3016-3071)
   int MStepGPU(int iter) {
     if (!sh.on) {
-      if (int rc = settle()) return rc;              // (an M-step after an M-step)
+      if (_mstep_pending) { if (int rc = settle()) return rc; }   // (an M-step after an M-step; the scale vector and slice_inside stay pending for the fused fetch)
       if (iter > 0) {
         _mstep_pending = iter;                         // runs with the E-step that follows (reconstruction.cc:1093-1108), or in settle
         return 0;

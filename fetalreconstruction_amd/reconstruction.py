@@ -53,11 +53,12 @@ class TorchComm:
     xGMI); small host vectors go through the same backend.
     """
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, slabs=False):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
+        self.slabs = slabs            # the volume update by z-slabs on the CPU stand-in engines (slab_update_numpy)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
         self._views = {}
@@ -101,6 +102,79 @@ class TorchComm:
                                             self.device)
         self.dist.all_reduce(self._views[key], op=self.dist.ReduceOp.SUM)
         self.torch.cuda.synchronize()
+
+
+def slab_plan_numpy(mask_zyx, world):
+    """The plan of csrc/svr_slab.inc (slab_lists + slab_plan) in numpy: index lists of the mask's voxels and of its 3 x 3 x 3
+    dilation in natural order, slabs of equal mask-voxel count, per rank the index range of its slab + one halo plane either
+    side (reduce-scatter) and of its slab in the dilated list (all-gather)."""
+    m = np.asarray(mask_zyx) != 0
+    vz = m.shape[0]
+    d = np.zeros_like(m)
+    p = np.pad(m, 1)
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                d |= p[dz:dz + vz, dy:dy + m.shape[1], dx:dx + m.shape[2]]
+    midx, didx = np.flatnonzero(m), np.flatnonzero(d)
+    mcum = np.concatenate([[0], np.cumsum(m.reshape(vz, -1).sum(1))]).astype(np.int64)
+    dcum = np.concatenate([[0], np.cumsum(d.reshape(vz, -1).sum(1))]).astype(np.int64)
+    nm = int(mcum[-1])
+    zb = [0]
+    for r in range(1, world):
+        target = nm * r // world
+        z = zb[-1]
+        while z < vz and mcum[z] < target:
+            z += 1
+        zb.append(z)
+    zb.append(vz)
+    rs, ag = [], []
+    for r in range(world):
+        lo, hi = max(0, zb[r] - 1), min(vz, zb[r + 1] + 1)
+        rs.append((int(mcum[lo]), 0 if zb[r] >= zb[r + 1] else int(mcum[hi] - mcum[lo])))
+        ag.append((int(dcum[zb[r]]), int(dcum[zb[r + 1]] - dcum[zb[r]])))
+    return dict(midx=midx, didx=didx, zb=zb, rs=rs, ag=ag, rs_chunk=max(1, max(c for _, c in rs)), ag_chunk=max(1, max(c for _, c in ag)))
+
+
+def slab_update_numpy(e, comm, args):
+    """reduce-scatter of addon | cmap at the mask's voxels -> the rank's planes of the volume update -> all-gather of the new volume,
+    on an engine that keeps its volumes as numpy arrays (the oracle): what Shard::update does with the svr_slab_* entry points.  The
+    reduce-scatter is an all-reduce of the send buffer of which a rank keeps its chunk (gloo has no reduce-scatter): the sums and
+    their order are those of the replicated path's all-reduce."""
+    torch, dist = comm.torch, comm.dist
+    W, R = comm.world, comm.rank
+    vx, vy, vz = (int(v) for v in e.vsize)
+    plan = getattr(e, "_slab_plan", None)
+    if plan is None or plan["world"] != W:
+        plan = slab_plan_numpy(np.asarray(e.mask).reshape(vz, vy, vx), W)
+        plan["world"] = W
+        e._slab_plan = plan
+    CH, DCH = plan["rs_chunk"], plan["ag_chunk"]
+    send = np.zeros((W, 2, CH), np.float32)
+    for r, (st, cnt) in enumerate(plan["rs"]):
+        idx = plan["midx"][st:st + cnt]
+        send[r, 0, :cnt] = e.addon[idx]
+        send[r, 1, :cnt] = e.cmap[idx]
+    t = torch.from_numpy(send)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    st, cnt = plan["rs"][R]
+    idx = plan["midx"][st:st + cnt]
+    e.addon[idx] = send[R, 0, :cnt]
+    e.cmap[idx] = send[R, 1, :cnt]
+    e.SuperresolutionUpdate(*args)                 # whole volume; only this rank's planes are kept (a plane depends on its neighbours only)
+    new = e.recon.copy()
+    plane = vx * vy
+    z0, z1 = plan["zb"][R], plan["zb"][R + 1]
+    mine = np.zeros(DCH, np.float32)
+    st, cnt = plan["ag"][R]
+    mine[:cnt] = new[plan["didx"][st:st + cnt]]
+    outs = [torch.zeros(DCH, dtype=torch.float32) for _ in range(W)]
+    dist.all_gather(outs, torch.from_numpy(mine))
+    e.recon[...] = 0
+    e.recon[z0 * plane:z1 * plane] = new[z0 * plane:z1 * plane]
+    for r, (st, cnt) in enumerate(plan["ag"]):
+        if r != R:
+            e.recon[plan["didx"][st:st + cnt]] = outs[r].numpy()[:cnt]
 
 
 class _CAI:
@@ -353,9 +427,12 @@ class irtkReconstruction:
                               self._global_bias_correction, self._sigma_bias, self._low_intensity_cutoff)
         else:
             e.SuperresolutionBackproject(self._local(self._slice_weight_gpu))
-            self.comm.allreduce_volume_pair(e, 2)
-            e.SuperresolutionUpdate(self._adaptive, self._alpha, self._min_intensity, self._max_intensity,
-                                    self._delta, self._lambda)
+            args = (self._adaptive, self._alpha, self._min_intensity, self._max_intensity, self._delta, self._lambda)
+            if getattr(self.comm, "slabs", False) and hasattr(e, "addon_cmap"):
+                slab_update_numpy(e, self.comm, args)            # csrc/svr_slab.inc restated on the CPU stand-in engines (gloo tests)
+            else:
+                self.comm.allreduce_volume_pair(e, 2)
+                e.SuperresolutionUpdate(*args)
 
     def MStepGPU(self, it):
         """RG.cc:4214-4223 + Reconstruction::MStep host part (RC.cu:3016-3071)"""

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, slabs=False, iters=1):
     import torch.distributed as dist
     from fetalreconstruction_amd.reconstruction import TorchComm
     from oracle import pyoracle as po
@@ -34,9 +34,9 @@ def _worker(rank, world, port, outdir):
         act = (P.slices != -1).reshape(P.ns, -1).sum(1)
         lo, hi = shard_slices(act, world)[rank]
         eng = po.OracleReconstruction(phantom.sub_problem(P, lo, hi), po.CANON)
-        drv = irtkReconstruction(eng, P.ns, (lo, hi), TorchComm(), P.max_intensity, P.min_intensity)
+        drv = irtkReconstruction(eng, P.ns, (lo, hi), TorchComm(slabs=slabs), P.max_intensity, P.min_intensity)
         drv.SetSmoothingParameters(150, 0.02)
-        drv.reconstruct_iteration(1)
+        drv.reconstruct_iteration(iters)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), recon=eng.recon, scale=drv._scale_gpu,
                  sw=drv._slice_weight_gpu, em=np.array([drv._sigma_gpu, drv._mix_gpu, drv._m_gpu, drv._mix_s_gpu]),
                  lohi=np.array([lo, hi]))
@@ -65,6 +65,65 @@ def test_world_size_2_matches_single_process(oracle_mod):
     assert np.allclose(r0["scale"], ref._scale_gpu, rtol=1e-5)
     assert np.allclose(r0["sw"], ref._slice_weight_gpu, atol=1e-4)
     assert np.allclose(r0["em"], [ref._sigma_gpu, ref._mix_gpu, ref._m_gpu, ref._mix_s_gpu], rtol=1e-5)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_update_is_the_replicated_update_bit_for_bit(world):
+    """The volume update of a sharded run by z-slabs (csrc/svr_slab.inc; restated in numpy for the oracle engines:
+    reconstruction.slab_plan_numpy / slab_update_numpy): reduce-scatter of addon | cmap at the mask's voxels of every rank's slab
+    and its two halo planes, the rank's planes of Prep + regulariser, all-gather of the new volume at the dilated mask's voxels.
+    Two SR iterations at world 2 and 3 (a middle slab has two halos): every rank ends with the volume of the run that
+    all-reduces the pair and updates the whole volume on every rank -- bit for bit at world 2, where a + b = b + a; at world 3
+    gloo's ring adds a voxel's three values in an order that depends on where the voxel sits in the message, and the two runs
+    lay their messages out differently: float round-off of that one sum (the in-process group of the command lines adds in rank
+    order in both forms: tests/test_preprocess.py::test_slab_update_gives_the_replicated_updates_bits, three ranks, bit for bit)."""
+    import torch.multiprocessing as mp
+    vols = {}
+    for slabs in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker, args=(world, _free_port(), d, slabs, 2), nprocs=world, join=True)
+            rs = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+            for r in rs[1:]:
+                assert np.array_equal(rs[0]["recon"], r["recon"])
+            vols[slabs] = (rs[0]["recon"].copy(), rs[0]["scale"].copy(), rs[0]["em"].copy())
+    assert np.abs(vols[True][0]).max() > 0
+    if world == 2:
+        assert np.array_equal(vols[True][0], vols[False][0])
+        assert np.array_equal(vols[True][1], vols[False][1]) and np.array_equal(vols[True][2], vols[False][2])
+    else:
+        assert np.array_equal(vols[True][0] == -1, vols[False][0] == -1) and np.array_equal(vols[True][0] != 0, vols[False][0] != 0)
+        assert np.abs(vols[True][0] - vols[False][0]).max() <= 1e-6 * np.abs(vols[False][0]).max()
+        assert np.allclose(vols[True][1], vols[False][1], rtol=1e-6) and np.allclose(vols[True][2], vols[False][2], rtol=1e-6)
+
+
+def test_slab_plan_covers_every_voxel_once():
+    """slab boundaries by mask-voxel count; reduce-scatter ranges = slab + one halo plane either side; all-gather ranges partition
+    the dilated mask"""
+    from fetalreconstruction_amd.reconstruction import slab_plan_numpy
+    rng = np.random.default_rng(3)
+    z, y, x = np.mgrid[:23, :17, :19]
+    mask = (((z - 11) / 9.0) ** 2 + ((y - 8) / 6.5) ** 2 + ((x - 9) / 7.0) ** 2 < 1).astype(np.float32)
+    mask[rng.integers(0, 23, 40), rng.integers(0, 17, 40), rng.integers(0, 19, 40)] = 0
+    for world in (1, 2, 3, 5, 8, 23, 40):
+        p = slab_plan_numpy(mask, world)
+        zb = p["zb"]
+        assert zb[0] == 0 and zb[-1] == 23 and all(a <= b for a, b in zip(zb, zb[1:]))
+        cover = np.zeros(len(p["didx"]), int)
+        for st, cnt in p["ag"]:
+            cover[st:st + cnt] += 1
+        assert (cover == 1).all()
+        planes = p["midx"] // (17 * 19)
+        for r, (st, cnt) in enumerate(p["rs"]):
+            if zb[r] < zb[r + 1]:
+                pl = planes[st:st + cnt]
+                want = (planes >= zb[r] - 1) & (planes <= zb[r + 1])
+                assert cnt == want.sum() and (len(pl) == 0 or (pl.min() >= zb[r] - 1 and pl.max() <= zb[r + 1]))
+            else:
+                assert cnt == 0
+        counts = [((planes >= zb[r]) & (planes < zb[r + 1])).sum() for r in range(world)]
+        if world <= 8:
+            assert max(counts) - min(counts) <= 2 * (mask != 0).reshape(23, -1).sum(1).max()      # equal shares up to whole planes
 
 
 # ---- the patch-to-volume loop sharded by patches (SURVEY 8e: "PVR: identical with patches as the unit") ----------------

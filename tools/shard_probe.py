@@ -59,7 +59,7 @@ def collective_ms(bytes_per_rank_out, world):
     return bytes_per_rank_out * (world - 1) / world / (links * XGMI_LINK_GBS * 1e9 * XGMI_EFF) * 1e3
 
 
-def probe(wl, world, reps=6, opts=()):
+def probe(wl, world, reps=6, opts=(), only=None):
     from fetalreconstruction_amd import engine as E, phantom, host
     from fetalreconstruction_amd.reconstruction import shard_slices, slice_cost_weights
     prob = build(wl)
@@ -93,7 +93,9 @@ def probe(wl, world, reps=6, opts=()):
     cnt = rec.counters()
     n2 = prob.slices.shape[1] * prob.slices.shape[2]
 
-    def time_kernels(rec_, sw_, z_slab=None):
+    em3 = tuple(float(st[k]) for k in (("m_m_gpu", "m_sigma_gpu", "m_mix_gpu") if pvr else ("m", "sigma", "mix")))
+
+    def time_kernels(rec_, sw_, sc_, w_):
         rec_.timer_enable(True)
         for k in range(reps + 1):
             if k == 1:
@@ -101,12 +103,17 @@ def probe(wl, world, reps=6, opts=()):
             rec_.SuperresolutionBackproject(sw_)
             rec_.SuperresolutionUpdate(*upd)
             rec_.SimulateSlices()
+            rec_.MStepSums()                                       # the EM kernels of the step: M-step sums, E-step, scale
+            rec_.EStep(*em3)
+            rec_.CalculateScaleVector()
+            rec_.UpdateScaleVector(sc_, sw_)                       # (the state the scatter started from)
+            rec_.debug_set(E.BUF_WEIGHTS, w_)
             rec_.UpdateReconstructed(rec_.vsize, vol)              # (untimed: every repetition updates the donor's volume)
         out = kernel_ms(rec_)
         rec_.timer_enable(False)
         return out
 
-    full = time_kernels(rec, sw)
+    full = time_kernels(rec, sw, scales, donor[E.BUF_WEIGHTS])
     full["cells"] = rec.cell_stats()
     full["Va"] = cnt["Va"]
     nv = cnt["Nv"]
@@ -116,17 +123,21 @@ def probe(wl, world, reps=6, opts=()):
     # ---- rank by rank --------------------------------------------------------------------------------------------------------
     shards = []
     for r, (lo, hi) in enumerate(ranges):
+        if only is not None and r not in only:
+            continue
         sub = phantom.sub_problem(prob, lo, hi)
         rs = make_engine(sub, pvr, None if spx is None else spx[lo:hi], opts)
         rs.UpdateScaleVector(scales[lo:hi], sw[lo:hi])
         for b, a in donor.items():
             rs.debug_set(b, np.ascontiguousarray(a.reshape(prob.ns, -1)[lo:hi]).reshape(-1))
         rs.UpdateReconstructed(rs.vsize, vol)
-        k = time_kernels(rs, sw[lo:hi])
+        k = time_kernels(rs, sw[lo:hi], scales[lo:hi], np.ascontiguousarray(donor[E.BUF_WEIGHTS].reshape(prob.ns, -1)[lo:hi]).reshape(-1))
         k.update(rank=r, units=[int(lo), int(hi)], Va=rs.counters()["Va"], cells=rs.cell_stats())
         shards.append(k)
         rs.close()
-    return dict(workload=wl, world=world, Nv=nv, volume=vsize, full=full, shards=shards)
+    # what the slab update's collectives carry (svr_slab_plan on a fresh context would need the mask only; the donor's is gone)
+    mask_fraction = float((np.asarray(prob.mask) != 0).mean())
+    return dict(workload=wl, world=world, Nv=nv, volume=vsize, mask_fraction=mask_fraction, full=full, shards=shards)
 
 
 def project(res):
@@ -154,6 +165,13 @@ def project(res):
                 slab=dict(reduce_scatter_ms=rs_ms, update_ms=reg_full / W, allgather_ms=ag_ms, step_ms=slab, speedup=one / slab))
 
 
+def run(workload, world, reps=6, opts=(), only=None):
+    res = probe(workload, world, reps, opts, only)
+    if only is None or len(res["shards"]) == world:
+        res["projection"] = project(res)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload")
@@ -164,10 +182,7 @@ def main():
     a = ap.parse_args()
     opts = [(o.split("=")[0], int(o.split("=")[1])) for o in a.opts]
     t0 = time.time()
-    res = probe(a.workload, a.world, a.reps, opts)
-    P = build(a.workload)
-    res["mask_fraction"] = float((np.asarray(P.mask) != 0).mean())
-    res["projection"] = project(res)
+    res = run(a.workload, a.world, a.reps, opts)
     res["wall_s"] = round(time.time() - t0, 1)
     line = json.dumps(res)
     if a.out:
