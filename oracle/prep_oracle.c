@@ -722,3 +722,100 @@ void orc_mask_slice(const orc_attr *slice_attr, double *slice, const double *T, 
 void orc_get_region_attr(const orc_attr *src, int i1, int j1, int k1, int i2, int j2, int k2, orc_attr *out) {
   region_attr(src, i1, j1, k1, i2, j2, k2, out);
 }
+
+/* ---- packages: SplitImage / SplitImageEvenOdd / SplitImageEvenOddHalf / HalfImage and the slice assignment of
+ * PackageToVolume (RG.cc:4980-5192) -------------------------------------------------------------------------------------
+ * A package is carried as its attributes and the list of the STACK slices its planes hold (plane k of a package made by
+ * SplitImage(image, packages) from its package l is plane k * packages + l of `image`, RG.cc:5013; HalfImage's GetRegion keeps
+ * planes [0, nz/2) and [nz/2, nz), RG.cc:5083-5086).  Voxel data follow their planes and are not carried here. */
+typedef struct { orc_attr a; int n; int src[1024]; } orc_pack;
+
+/* SplitImage RG.cc:4980-5038: package l takes planes l, l + packages, ...; its dz is packages * dz; the origin is moved so that its
+ * voxel (0,0,0) sits where voxel (0,0,l) of the image sits */
+static int split_image(const orc_pack *img, int packages, orc_pack *out) {
+  const int pkg_z = img->a.nz / packages;
+  const double pkg_dz = img->a.dz * packages;
+  for (int l = 0; l < packages; l++) {
+    orc_pack *p = &out[l];
+    p->a = img->a;
+    p->a.nz = (pkg_z * packages + l) < img->a.nz ? pkg_z + 1 : pkg_z;
+    p->a.dz = pkg_dz;
+    p->n = p->a.nz;
+    for (int k = 0; k < p->a.nz; k++) p->src[k] = img->src[k * packages + l];
+    double i2w[16], s2w[16];
+    double x = 0, y = 0, z = l, sx = 0, sy = 0, sz = 0;
+    image_to_world(&img->a, i2w);
+    apply(i2w, &x, &y, &z);
+    image_to_world(&p->a, s2w);                      /* (the stack still carries the image's origin: PutOrigin(ox, oy, oz)) */
+    apply(s2w, &sx, &sy, &sz);
+    p->a.origin[0] += x - sx; p->a.origin[1] += y - sy; p->a.origin[2] += z - sz;
+  }
+  return packages;
+}
+/* HalfImage RG.cc:5072-5091 */
+static int half_image(const orc_pack *img, orc_pack *out) {
+  if (img->a.nz >= 4) {
+    const int h = img->a.nz / 2;
+    region_attr(&img->a, 0, 0, 0, img->a.nx, img->a.ny, h, &out[0].a);
+    out[0].n = h;
+    for (int k = 0; k < h; k++) out[0].src[k] = img->src[k];
+    region_attr(&img->a, 0, 0, h, img->a.nx, img->a.ny, img->a.nz, &out[1].a);
+    out[1].n = img->a.nz - h;
+    for (int k = h; k < img->a.nz; k++) out[1].src[k - h] = img->src[k];
+    return 2;
+  }
+  out[0] = *img;
+  return 1;
+}
+static int split_even_odd(const orc_pack *img, int packages, orc_pack *out) {          /* RG.cc:5040-5058 */
+  orc_pack *packs = (orc_pack *)malloc(sizeof(orc_pack) * (size_t)packages);
+  const int n = split_image(img, packages, packs);
+  int m = 0;
+  for (int i = 0; i < n; i++) m += split_image(&packs[i], 2, out + m);
+  free(packs);
+  return m;
+}
+static int split_even_odd_half(const orc_pack *img, int packages, orc_pack *out, int iter) {   /* RG.cc:5060-5079 */
+  orc_pack *packs = (orc_pack *)malloc(sizeof(orc_pack) * 1024);
+  const int n = iter > 1 ? split_even_odd_half(img, packages, packs, iter - 1) : split_even_odd(img, packages, packs);
+  int m = 0;
+  for (int i = 0; i < n; i++) m += half_image(&packs[i], out + m);
+  free(packs);
+  return m;
+}
+/* The packages of one stack and, as PackageToVolume finds them (RG.cc:5131-5138, 5167-5172: ImageToWorld of the package's plane,
+ * WorldToImage of the stack, round), the stack slice every package plane is assigned to.
+ * out: n_packages; pack_nz[p]; slice_of[p * max_nz + k] = assigned slice (from the geometry), plane_src[...] = the stack plane whose
+ * voxels the package plane holds (from the splitting); pack_attr[p].  Returns the number of packages, or -1 (more than max_packs
+ * packages, more than max_nz planes, or more than 1024 slices). */
+int orc_split_packages(const orc_attr *stack, int packages, int evenodd, int half, int half_iter, int max_packs, int max_nz, int *pack_nz,
+                       int *slice_of, int *plane_src, orc_attr *pack_attr) {
+  if (stack->nz > 1024 || packages < 1) return -1;
+  orc_pack *img = (orc_pack *)malloc(sizeof(orc_pack)), *out = (orc_pack *)malloc(sizeof(orc_pack) * 1024);
+  img->a = *stack;
+  img->n = stack->nz;
+  for (int k = 0; k < stack->nz; k++) img->src[k] = k;
+  int n;
+  if (evenodd) n = half ? split_even_odd_half(img, packages, out, half_iter) : split_even_odd(img, packages, out);
+  else n = split_image(img, packages, out);
+  int rc = n;
+  if (n > max_packs) rc = -1;
+  double s_w2i[16];
+  world_to_image(stack, s_w2i);
+  for (int p = 0; p < n && rc >= 0; p++) {
+    if (out[p].a.nz > max_nz) { rc = -1; break; }
+    pack_nz[p] = out[p].a.nz;
+    pack_attr[p] = out[p].a;
+    double p_i2w[16];
+    image_to_world(&out[p].a, p_i2w);
+    for (int k = 0; k < out[p].a.nz; k++) {
+      double x = 0, y = 0, z = k;
+      apply(p_i2w, &x, &y, &z);
+      apply(s_w2i, &x, &y, &z);
+      slice_of[p * max_nz + k] = (int)irtk_round(z);
+      plane_src[p * max_nz + k] = out[p].src[k];
+    }
+  }
+  free(img); free(out);
+  return rc;
+}

@@ -603,6 +603,21 @@ def _attr_to_py(a):
     return geo.ImageAttributes(a.nx, a.ny, a.nz, a.dx, a.dy, a.dz, np.array(a.xaxis[:]), np.array(a.yaxis[:]), np.array(a.zaxis[:]), origin=np.array(a.origin[:]))
 
 
+def split_packages(stack_attr, packages, evenodd=False, half=False, half_iter=1, max_packs=256, max_nz=1024):
+    """orc_split_packages (SplitImage / SplitImageEvenOdd / SplitImageEvenOddHalf / HalfImage and PackageToVolume's slice assignment,
+    RG.cc:4980-5192) -> list of (attributes, slices assigned from the geometry, stack planes held by construction)"""
+    nz = np.zeros(max_packs, np.int32)
+    sl = np.full((max_packs, max_nz), -1, np.int32)
+    src = np.full((max_packs, max_nz), -1, np.int32)
+    at = (Attr * max_packs)()
+    lib().orc_split_packages.restype = C.c_int
+    n = lib().orc_split_packages(C.byref(Attr.of(stack_attr)), int(packages), int(bool(evenodd)), int(bool(half)), int(half_iter), int(max_packs),
+                                 int(max_nz), _p(nz), _p(sl), _p(src), at)
+    if n < 0:
+        raise ValueError("orc_split_packages: too many packages / planes")
+    return [(_attr_to_py(at[p]), sl[p, :nz[p]].copy(), src[p, :nz[p]].copy()) for p in range(n)]
+
+
 def create_template(stack_attr, resolution):
     """orc_create_template (CreateTemplate RG.cc:648-694) -> (template attributes, resolution used)"""
     out = Attr()

@@ -264,3 +264,40 @@ def test_package_to_volume_recovers_package_motion(oracle_mod):
     # halves of the even/odd packages (HalfImage: packages of >= 4 slices are cut in two)
     t3, _ = host.PackageToVolume(None, [data], [a], [1], start, ra, vol, evenodd=True, half=True, half_iter=1, backend=_oracle_backend(oracle_mod))
     assert len({tuple(np.round(m.reshape(-1), 9)) for m in t3}) == 4          # 1 package -> even/odd (7 + 7 slices) -> halves (3 + 4 each)
+
+
+@pytest.mark.parametrize("nz,packages,evenodd,half,half_iter", [(14, 2, False, False, 1), (15, 4, False, False, 1), (14, 2, True, False, 1), (17, 3, True, False, 1),
+                                                                 (14, 1, True, True, 1), (29, 2, True, True, 1), (40, 2, True, True, 2), (7, 3, True, True, 1)])
+def test_package_splitting_against_the_oracle(oracle_mod, nz, packages, evenodd, half, half_iter):
+    """SplitImage / SplitImageEvenOdd / SplitImageEvenOddHalf / HalfImage and the slice assignment of PackageToVolume
+    (irtkReconstructionGPU.cc:4980-5192) restated in oracle/prep_oracle.c (orc_split_packages), against the C++ product
+    (csrc/irtk_reg.cpp svrh_package_to_volume) on an oblique stack.  The product is observed from outside: every slice starts with
+    its own transformation, the similarity backend is flat (no registration step is accepted), so on return every slice of a package
+    carries the start transformation of the package's FIRST slice -- the membership of every package and its first slice, which is
+    what the oracle lists.  The oracle's two routes to a package's slices must agree too: by construction (plane k of package l is
+    plane k * packages + l, halves keep their planes) and by the reference's geometry (ImageToWorld of the package, WorldToImage of
+    the stack, round)."""
+    rot = geo.rigid_matrix(0, 0, 0, 17.0, -23.0, 31.0)[:3, :3]
+    a = geo.ImageAttributes(12, 10, nz, 1.1, 1.3, 2.2, rot[:, 0].copy(), rot[:, 1].copy(), rot[:, 2].copy(), origin=np.array([13.7, -41.2, 88.9]))
+    packs = oracle_mod.split_packages(a, packages, evenodd, half, half_iter)
+    seen = np.zeros(nz, int)
+    for attr, assigned, held in packs:
+        assert np.array_equal(assigned, held)                       # the geometry finds the planes the splitting put there
+        seen[held] += 1
+    assert (seen == 1).all()                                        # every slice in exactly one package
+    rng = np.random.default_rng(5)
+    data = rng.uniform(100, 900, (nz, a.ny, a.nx))
+    start = np.stack([geo.rigid_matrix(0.01 * (k + 1), -0.02 * (k + 1), 0.005 * k, 0.1 * k, 0, 0) for k in range(nz)])
+    ra = geo.ImageAttributes(20, 20, 20, 1.0, 1.0, 1.0, origin=a.origin.copy())
+    vol = rng.uniform(100, 900, (20, 20, 20)).astype(np.float32)
+
+    # a similarity that never improves: every optimiser stops where it started
+    be = host.NccBackend(lambda t, M, s: np.array([1.0, 1.0, 1.0, 1.0, 1.0, 4.0]))
+    t, nev = host.PackageToVolume(None, [data], [a], [packages], start, ra, vol, evenodd=evenodd, half=half, half_iter=half_iter, backend=be)
+    for attr, assigned, held in packs:
+        first = int(assigned[0])
+        for sl in assigned:                                         # (the other slices get the first one's PARAMETERS: a rebuilt matrix)
+            assert np.allclose(t[sl], start[first], atol=1e-9), (first, sl)
+    # distinct packages kept distinct transformations (the start transformations are all different)
+    firsts = sorted(int(p[1][0]) for p in packs)
+    assert len({tuple(np.round(t[f].reshape(-1), 8)) for f in firsts}) == len(packs)
