@@ -42,7 +42,7 @@ F32_PEAK_TFLOPS = 157.3      # f32 vector peak with packed FMA on gfx950 (= the 
 FLOPS_PER_TAP_FORMULA = 49
 FLOPS_PER_TAP_EXECUTED = 38
 TAPS = 4096
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")     # written by tools/prof_final.py in the same round: per workload,
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_traffic.json")     # written by tools/prof_final.py in the same round: per workload,
                                                                       # per pass: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
 VALU_ISSUE_PER_S = 0.6e9     # wave-instructions a SIMD issues per second: 2.4 GHz / 4 cycles per 64-lane instruction
@@ -468,7 +468,7 @@ def main():
                         "SQ_INSTS_VALU per launch / (launch time x 1024 SIMDs x 0.6e9 wave-instructions/s): the share of VALU issue slots "
                         "used, the figure that explains the time.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch time.  "
                         "`traffic`: FETCH_SIZE + WRITE_SIZE per launch; counters from this round's separate rocprofv3 --pmc passes "
-                        "(profiles/r03_traffic.json, tools/prof_final.py), null when that file has no entry for the workload.")
+                        "(profiles/r04_traffic.json, tools/prof_final.py), null when that file has no entry for the workload.")
         out = {
             "metric": METRIC,
             "value": value, "unit": "MVoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -497,6 +497,15 @@ def main():
             "roofline": roof,
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in timers.items()},
         }
+        # the volume update (Prep + regulariser, RC.cu:1944-1969, 2046-2117): the one HBM-bound kernel of the step; SURVEY 8d: 24 B / voxel
+        up_ms, up_n = timers["regularize"]
+        if up_n:
+            up_avg = up_ms / up_n * 1e-3
+            out["update"] = {"kernel": "k_regul_fused (csrc/svr_regul.inc: Prep + regulariser in one pass, LDS plane ring, float32 rsq weights)"
+                                       + (" on this rank's z-slab (csrc/svr_slab.inc)" if timers["reduce_scatter"][1] else ""),
+                             "bound": "hbm", "algorithmic_bytes": 24.0 * nv, "avg_launch_ms": up_avg * 1e3,
+                             "achieved": 24.0 * nv / up_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 24.0 * nv / up_avg / 1e9 / HBM_PEAK_GBS,
+                             "note": "whole-volume algorithmic bytes over the launch time (a sharded rank updates 1 / N of the planes); round 3: frac 0.05"}
         if tab is not None:
             bp2, fw2 = tab["timers"]["backproject"], tab["timers"]["forward"]
             bp2a, fw2a = bp2[0] / max(bp2[1], 1) * 1e-3, fw2[0] / max(fw2[1], 1) * 1e-3
@@ -514,7 +523,11 @@ def main():
                              "traffic": table_traffic(prob.name, world),
                              "bytes_per_launch_upper": tab["bytes"] + b_back,
                              "achieved_upper": ((tab["bytes"] + b_back) / bp2a / 1e9) if bp2[1] else None,
-                             "frac_upper": ((tab["bytes"] + b_back) / bp2a / 1e9 / HBM_PEAK_GBS) if bp2[1] else None},
+                             "frac_upper": ((tab["bytes"] + b_back) / bp2a / 1e9 / HBM_PEAK_GBS) if bp2[1] else None,
+                             # what the counters saw of the table scatter (FETCH_SIZE with the guide's x 2 for 16 B / lane streaming reads,
+                             # + WRITE_SIZE) over the same launch time: the fraction to quote; *_upper divides bytes that are not read
+                             "frac_counters": (lambda t_: ((t_["scatter"]["fetch_corrected"] + t_["scatter"]["write_counted"]) / bp2a / 1e9 / HBM_PEAK_GBS)
+                                               if (t_ and t_.get("scatter") and bp2[1]) else None)(table_traffic(prob.name, world))},
                 "note": "the same K steps with svr_set_option(coeff_table, 1): every live (pixel, plane) unit's 256 taps are "
                         "written once per slice geometry (16 KiB per PSF pixel, outside the timed region like the Gaussian pass "
                         "and the tile lists) and streamed by the scatter and the gather -- CoeffInit's _volcoeffs of the "

@@ -20,9 +20,12 @@ pytestmark = pytest.mark.gpu
 
 TOL_SUM = 2e-5          # tests/test_parity_gpu.py
 TOL_LITERAL = 3e-3      # tests/test_round2_gaps.py
-MAX_SHARE_BEYOND_TOL = 1.0      # (set from the first full-size run, see the test)
-MAX_REL_L2 = 1.0
-MAX_WORST = 1.0
+# observed on the MI355X box (psf_sums / volw / recon / sim / simw / addon / cmap): share beyond TOL_LITERAL 1.0e-4 / 6.4e-5 / 0 / 1.7e-5 /
+# 4.3e-6 / 1.7e-4 / 6.4e-5; relative L2 1.9e-4 / 1.3e-4 / 1.4e-5 / 5.7e-5 / 2.5e-5 / 1.7e-3 (addon: a residual, sums that cancel) /
+# 1.4e-4; worst element 7.4e-2 / 1.9e-2 / 2.0e-3 / 2.1e-2 / 2.2e-2 / 1.5e-1 / 2.9e-2 of the buffer's maximum
+MAX_SHARE_BEYOND_TOL = 1e-3
+MAX_REL_L2 = 5e-3
+MAX_WORST = 0.5
 
 
 def _deal(prob, parts):

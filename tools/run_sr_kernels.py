@@ -28,6 +28,12 @@ else:
     sw = d.state()["slice_weight"]
 for _ in range(40):          # many more than the tuners' trial launches: pmc.py averages the last half of a kernel's dispatches
     rec.SuperresolutionBackproject(sw)
+upd = (False, 0.5, float(P.min_intensity), float(P.max_intensity), 1.0, 0.1) if pvr else (False, 0.8, float(P.min_intensity), float(P.max_intensity), 150.0, 0.02 * 150.0 ** 2)
+v0 = rec.syncCPU().copy()
+for _ in range(20):          # the volume update (k_regul_fused) on the scatter's addon | cmap
+    rec.SuperresolutionUpdate(*upd)
+    rec.SuperresolutionBackproject(sw)
+rec.UpdateReconstructed(rec.vsize, v0)
 for _ in range(40):
     rec.SimulateSlices()
 print("tuned: scatter mode %d tiles %dx%d box %d, gather tiles %dx%d box %d" % tuple(rec.get_option(k) for k in ("back_mode", "tile_w", "tile_h", "wave_cap", "fwd_tile_w", "fwd_tile_h", "fwd_unit_cap")), flush=True)
