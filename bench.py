@@ -187,7 +187,7 @@ def main():
     import torch                                                      # before the engine: one RCCL copy per process
     from fetalreconstruction_amd import engine, phantom, workloads
     from fetalreconstruction_amd.host import RcclComm, irtkPatchBasedReconstruction, irtkReconstruction      # the C++ host objects
-    from fetalreconstruction_amd.reconstruction import TorchComm, shard_slices, slice_cost_weights
+    from fetalreconstruction_amd.reconstruction import TorchComm, patch_cost_weights, shard_slices, slice_cost_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -222,7 +222,7 @@ def main():
         if args.comm == "torch":
             raise SystemExit("bench.py: the patch-based host (csrc/pvr_host.cpp) takes the C library's RCCL communicator; --comm torch is SVR only")
         # contiguous patch ranges balanced by the pixels that carry data (patches of one stack share their geometry)
-        work = (prob.slices > 0).reshape(prob.ns, -1).sum(1).astype(np.float64)
+        work = patch_cost_weights((prob.slices > 0).reshape(prob.ns, -1).sum(1), prob.slice_i2w, prob.slice_t, prob.recon_w2i)
     else:
         act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
         # contiguous slice ranges balanced by estimated PSF work (active pixels x live planes), not by pixel count alone

@@ -508,7 +508,7 @@ int main(int argc, char **argv) {
   first_level = false;
 
   // ---- ranks: one engine context per device of -d, the patches sharded over them in contiguous ranges of the global
-  // numbering (stack after stack) balanced by the pixels that carry data.  The reference's patch-based path is single-GPU
+  // numbering (stack after stack) balanced by the pixels that carry data, weighted by orientation.  The reference's patch-based path is single-GPU
   // (patchBasedReconMain.cpp:78,177-179, irtkPatchBasedReconstruction.cpp:402); SURVEY 8e: "identical with patches as the unit"
   const int nr = (int)std::max<size_t>(1, devices.size());
   if (ns < nr) die("fewer patches than devices");
@@ -519,7 +519,15 @@ int main(int argc, char **argv) {
     parallel_for(ns, [&](int q) {
       long c = 0;
       for (size_t i = 0; i < pp; ++i) c += P.data[(size_t)q * pp + i] > 0.0f;
-      cum[q + 1] = (double)c;
+      // a patch whose normal is the volume's x axis costs more per pixel (its runs span a band of centre planes, csrc/svr_cell.inc;
+      // measured per rank: tools/shard_probe.py, reconstruction.py slice_cost_weights): x (1 + 0.2 n_x^2)
+      const M4 rw = world_to_image(tattr);
+      double nw[3], nt[3], nv[3], len = 0;
+      for (int k = 0; k < 3; ++k) nw[k] = P.i2w[16 * (size_t)q + 4 * k + 2];
+      for (int k = 0; k < 3; ++k) nt[k] = st[16 * (size_t)q + 4 * k] * nw[0] + st[16 * (size_t)q + 4 * k + 1] * nw[1] + st[16 * (size_t)q + 4 * k + 2] * nw[2];
+      for (int k = 0; k < 3; ++k) { nv[k] = rw.m[4 * k] * nt[0] + rw.m[4 * k + 1] * nt[1] + rw.m[4 * k + 2] * nt[2]; len += nv[k] * nv[k]; }
+      const double ax2 = len > 0 ? nv[0] * nv[0] / len : 0.0;
+      cum[q + 1] = (double)c * (1.0 + 0.2 * ax2);
     });
     for (int q = 0; q < ns; ++q) cum[q + 1] += cum[q];
     int at = 0;

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fetalreconstruction_amd import phantom
-from fetalreconstruction_amd.reconstruction import shard_slices, slice_cost_weights
+from fetalreconstruction_amd.reconstruction import patch_cost_weights, shard_slices, slice_cost_weights
 from tools.shard_probe import build, make_engine
 
 wl, r, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
@@ -14,7 +14,7 @@ opts = [(o.split("=")[0], int(o.split("=")[1])) for o in rest]
 prob = build(wl)
 pvr = wl.startswith("PVR")
 if pvr:
-    work = (prob.slices > 0).reshape(prob.ns, -1).sum(1).astype(np.float64)
+    work = patch_cost_weights((prob.slices > 0).reshape(prob.ns, -1).sum(1), prob.slice_i2w, prob.slice_t, prob.recon_w2i)
 else:
     act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
     work = slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0])

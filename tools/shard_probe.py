@@ -61,12 +61,12 @@ def collective_ms(bytes_per_rank_out, world):
 
 def probe(wl, world, reps=6, opts=(), only=None):
     from fetalreconstruction_amd import engine as E, phantom, host
-    from fetalreconstruction_amd.reconstruction import shard_slices, slice_cost_weights
+    from fetalreconstruction_amd.reconstruction import patch_cost_weights, shard_slices, slice_cost_weights
     prob = build(wl)
     pvr = wl.startswith("PVR")
     spx = getattr(prob, "spx_masks", None)
     if pvr:
-        work = (prob.slices > 0).reshape(prob.ns, -1).sum(1).astype(np.float64)
+        work = patch_cost_weights((prob.slices > 0).reshape(prob.ns, -1).sum(1), prob.slice_i2w, prob.slice_t, prob.recon_w2i)
     else:
         act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
         work = slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0])
