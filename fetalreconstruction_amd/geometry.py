@@ -142,3 +142,8 @@ def psf_centre_offset(recon_dim, psf_size=128) -> np.ndarray:
         acc = np.float32(acc + m[k, 3])
         out[k] = acc
     return out
+
+
+def irtk_round(x: float) -> int:
+    """round() of irtkCommon.h:85-88 (half away from zero)."""
+    return int(x + 0.5) if x > 0 else int(x - 0.5)

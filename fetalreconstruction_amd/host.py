@@ -144,7 +144,7 @@ class irtkReconstruction:
 
             def ar_pair(user, ptr, n):
                 try:
-                    from .reconstruction import _device_view
+                    from .sharding import _device_view
                     if (ptr, n) not in self._views:
                         self._views[(ptr, n)] = _device_view(comm.torch, ptr, n, comm.device)
                     comm.dist.all_reduce(self._views[(ptr, n)], op=comm.dist.ReduceOp.SUM)

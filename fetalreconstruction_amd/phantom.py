@@ -15,6 +15,15 @@ from . import geometry as geo
 
 
 @dataclass
+class Stack:
+    """one acquired stack as the patch-based hosts hold it (m_stacks / m_stack_transformations)"""
+    data: np.ndarray                 # [nz][ny][nx]
+    attr: geo.ImageAttributes
+    transformation: np.ndarray       # 4x4 float64 (m_stack_transformations[i])
+    thickness: float
+
+
+@dataclass
 class Problem:
     # volume
     vsize: tuple            # (vx, vy, vz)
@@ -196,7 +205,6 @@ def make_stacks(n_stacks=3, stack_shape=(32, 32, 8), in_plane=1.1, spacing=2.2, 
     """Whole stacks (3-D images + one rigid transformation each) for the patch-based path: what
     irtkPatchBasedReconstruction holds in m_stacks / m_stack_transformations / m_mask before patch
     extraction.  Returns (stacks, mask [z][y][x] uint8, mask_attr, recon_attr, recon_mask)."""
-    from .pvr import Stack
     rng = np.random.default_rng(seed)
     nx, ny, nsl = stack_shape
     thickness = float(thickness if thickness is not None else spacing)

@@ -22,7 +22,7 @@ import numpy as np
 
 from . import geometry as geo
 from .phantom import Problem
-from .registration import irtk_round
+from .geometry import irtk_round
 
 
 @dataclass

@@ -67,7 +67,7 @@ def _f32(a):
 class OracleReconstruction:
     """CPU stand-in for `class Reconstruction` with the same method names as
     fetalreconstruction_amd.engine.Reconstruction, so the host driver
-    (fetalreconstruction_amd.reconstruction.irtkReconstruction) can run on either and the parity
+    (tests.twins.reconstruction.irtkReconstruction) can run on either and the parity
     tests compare buffer by buffer.  Includes the reference's host-glue quirks that live below the
     boundary (e.g. the one-call lag of the device scale vector, RC.cu:3195,3238)."""
 

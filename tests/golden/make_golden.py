@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from fetalreconstruction_amd import phantom  # noqa: E402
-from fetalreconstruction_amd.reconstruction import irtkReconstruction  # noqa: E402
+from tests.twins.reconstruction import irtkReconstruction  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 from tests.util import run_to_state  # noqa: E402
 

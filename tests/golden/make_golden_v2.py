@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from fetalreconstruction_amd import geometry as geo  # noqa: E402
-from fetalreconstruction_amd import phantom, pvr  # noqa: E402
-from fetalreconstruction_amd import registration as R  # noqa: E402
+from fetalreconstruction_amd import phantom  # noqa: E402
+from tests.twins import pvr  # noqa: E402
+from tests.twins import registration as R  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 

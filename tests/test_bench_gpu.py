@@ -107,7 +107,7 @@ def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
 def test_bench_launches_its_own_rccl_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment spawns two ranks (one GPU each) whose collectives run
     on RCCL, and says which world size RCCL saw.  Needs two visible devices (the gpurun box has one: skipped there)."""
-    from fetalreconstruction_amd import engine         # (not torch: a second RCCL copy in this process, after the C library opened its own)
+    from fetalreconstruction_amd import engine  # (not torch: a second RCCL copy in this process, after the C library opened its own)
     if engine.device_count() < 2:
         pytest.skip("one visible device")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}

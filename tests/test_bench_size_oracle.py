@@ -91,7 +91,7 @@ def test_sampled_pixels_of_the_bench_workloads_against_the_oracle(name, oracle_m
     assert rel_err(g_sim, osim) < TOL_SUM and np.abs(g_sw - ow).max() < TOL_SUM * max(1.0, float(np.abs(ow).max()))
 
 
-@pytest.mark.parametrize("name,count", [("P4", 4), ("S8", 3), ("PVR4", 12), ("PVR8spx", 6)]      # P4: one slice of every stack; S8: one per orientation (ax, cor, sag))
+@pytest.mark.parametrize("name,count", [("P4", 4), ("S8", 3), ("PVR4", 12), ("PVR8spx", 6)])     # P4: one slice of every stack; S8: one per orientation (ax, cor, sag)
 def test_scatter_of_a_few_slices_of_the_bench_workloads_against_the_oracle(name, count, oracle_mod, capsys):
     pvr = name.startswith("PVR")
     P = _workload(name)

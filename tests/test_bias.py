@@ -3,7 +3,7 @@ CorrectBias + NormaliseBias and the exp(-bias) variants of the scatter / EM kern
 import numpy as np
 import pytest
 
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from tests.twins.reconstruction import irtkReconstruction
 from tests.util import rel_err, run_to_state
 
 

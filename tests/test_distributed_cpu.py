@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from fetalreconstruction_amd import phantom
-from fetalreconstruction_amd.reconstruction import irtkReconstruction, shard_slices
+from fetalreconstruction_amd.sharding import shard_slices
+from tests.twins.reconstruction import irtkReconstruction
 
 
 def _problem():
@@ -26,7 +27,7 @@ def _free_port():
 
 def _worker(rank, world, port, outdir, slabs=False, iters=1):
     import torch.distributed as dist
-    from fetalreconstruction_amd.reconstruction import TorchComm
+    from fetalreconstruction_amd.sharding import TorchComm
     from oracle import pyoracle as po
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
@@ -100,7 +101,7 @@ def test_slab_update_is_the_replicated_update_bit_for_bit(world):
 def test_slab_plan_covers_every_voxel_once():
     """slab boundaries by mask-voxel count; reduce-scatter ranges = slab + one halo plane either side; all-gather ranges partition
     the dilated mask"""
-    from fetalreconstruction_amd.reconstruction import slab_plan_numpy
+    from tests.twins.reconstruction import slab_plan_numpy
     rng = np.random.default_rng(3)
     z, y, x = np.mgrid[:23, :17, :19]
     mask = (((z - 11) / 9.0) ** 2 + ((y - 8) / 6.5) ** 2 + ((x - 9) / 7.0) ** 2 < 1).astype(np.float32)
@@ -128,7 +129,7 @@ def test_slab_plan_covers_every_voxel_once():
 
 # ---- the patch-to-volume loop sharded by patches ("PVR: identical with patches as the unit") ----------------
 def _pvr_problem():
-    from fetalreconstruction_amd import pvr
+    from tests.twins import pvr
     stacks, mask, mattr, rattr, rmask = phantom.make_stacks(3, (24, 24, 4), 1.1, 2.2, None, 1.0, 11.0, seed=4, orientations=("ax", "sag", "cor"))
     return pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (16, 16), (8, 8))
 
@@ -140,8 +141,8 @@ def shard_patches(P, world):
 
 def _pvr_worker(rank, world, port, outdir):
     import torch.distributed as dist
-    from fetalreconstruction_amd import pvr
-    from fetalreconstruction_amd.reconstruction import TorchComm
+    from tests.twins import pvr
+    from fetalreconstruction_amd.sharding import TorchComm
     from oracle import pyoracle as po
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
@@ -163,7 +164,7 @@ def test_pvr_world_size_2_matches_single_process(oracle_mod):
     exchange each -- and the reference's within-stack indexing of the potentials (patchBasedRobustStatistics_gpu.cu:256-276)
     applied to the GLOBAL patch numbering on every rank."""
     import torch.multiprocessing as mp
-    from fetalreconstruction_amd import pvr
+    from tests.twins import pvr
     P = _pvr_problem()
     eng = oracle_mod.OracleReconstruction(P, oracle_mod.CANON, pvr=True)
     ref = pvr.irtkPatchBasedReconstruction(eng, P.patches_per_stack, P.min_intensity, P.max_intensity)

@@ -83,7 +83,7 @@ def test_cpp_host_on_random_geometry_matches_the_python_driver(seed):
     """svr::irtkReconstruction (one wait per SR iteration: deferred vectors, M-step + E-step fused) against the Python mirror
     of the operator surface (one wait per method) on a second engine: an outer iteration of three SR iterations."""
     from fetalreconstruction_amd import engine as E, host
-    from fetalreconstruction_amd.reconstruction import irtkReconstruction
+    from tests.twins.reconstruction import irtkReconstruction
     P, _ = _case(seed)
     kw = dict(max_intensity=P.max_intensity, min_intensity=P.min_intensity)
     ra, rb = E.Reconstruction(0), E.Reconstruction(0)

@@ -7,7 +7,7 @@ import pytest
 
 from fetalreconstruction_amd import geometry as geo
 from fetalreconstruction_amd import host, phantom
-from fetalreconstruction_amd import registration as reg
+from tests.twins import registration as reg
 
 
 def _oracle_backend(oracle_mod, log=None):

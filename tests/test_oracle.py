@@ -7,7 +7,8 @@ import pytest
 
 from fetalreconstruction_amd import geometry as geo
 from fetalreconstruction_amd import phantom
-from fetalreconstruction_amd.reconstruction import irtkReconstruction, shard_slices
+from fetalreconstruction_amd.sharding import shard_slices
+from tests.twins.reconstruction import irtkReconstruction
 from tests.util import popcount_xor, rel_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_v1.npz")
@@ -201,7 +202,7 @@ def test_shard_slices_is_a_balanced_partition():
 def test_slice_cost_weights_follow_the_live_planes():
     """Sharding weights: a slice whose normal is the volume's x axis keeps all 16 planes of its footprints (x is the axis of the
     sequential skip chain and cannot be owned), an axial one about 12; thicker slices keep more."""
-    from fetalreconstruction_amd.reconstruction import slice_cost_weights
+    from fetalreconstruction_amd.sharding import slice_cost_weights
     def i2w(normal_axis):
         m = np.eye(4)
         cols = {2: [0, 1, 2], 0: [1, 2, 0], 1: [2, 0, 1]}[normal_axis]      # slice x, y, z directions in world axes

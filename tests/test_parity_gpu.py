@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from fetalreconstruction_amd import phantom
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from tests.twins.reconstruction import irtkReconstruction
 from tests.util import rel_err, run_to_state
 
 pytestmark = pytest.mark.gpu

@@ -15,7 +15,8 @@ import pytest
 
 import real_mask as rm
 from fetalreconstruction_amd import geometry as geo
-from fetalreconstruction_amd import phantom, pvr
+from fetalreconstruction_amd import phantom
+from tests.twins import pvr
 from fetalreconstruction_amd import preprocess as pp
 
 
@@ -115,7 +116,7 @@ def test_cpp_patches_against_the_oracle(tmp_path, oracle_mod):
     # the same pre-processed stacks (mask binarisation, cropping, iso mask, intensity matching: the Python chain, which the
     # dump test of test_pvr.py ties to the C++ one), cut by the oracle
     P, _, _ = _python_pvr_problem(paths, mpath, (16, 16), (8, 8), 1.0)
-    from fetalreconstruction_amd import pvr_cli
+    from tests.twins import pvr_cli
     md, mat = nifti.read(mpath)
     ims = [pp.Image(nifti.read(p)[0].astype(np.float64), nifti.read(p)[1]) for p in paths]
     st2, ts, iso_mask, tattr, recon_mask = pvr_cli.prepare(ims, [np.eye(4)] * len(ims), pp.Image(md.astype(np.float64), mat), 1.0, 0, False)
@@ -133,7 +134,7 @@ def test_cpp_patches_against_the_oracle(tmp_path, oracle_mod):
 def test_slico_labels_and_superpixel_patches_against_the_oracle(oracle_mod, case):
     """SLICO labels (seeds, ten zero-parameter iterations on the transposed slice, connectivity pass) and the 64 x 64 patches cut
     around the superpixels with their dilated spxMask: slic.py against the oracle's literal loops."""
-    from fetalreconstruction_amd import slic
+    from tests.twins import slic
     if case == "oblique":
         m, a, st, _ = _oblique_case(2)
         stacks = [pvr.Stack(d.astype(np.float32), sa, np.eye(4), sa.dz) for d, sa in st]
@@ -163,7 +164,8 @@ def test_slico_labels_and_superpixel_patches_against_the_oracle(oracle_mod, case
 def test_cpp_superpixel_patches_against_the_oracle(tmp_path, oracle_mod):
     """bin/PVRreconstructionGPU -s --dumpProblem --dryRun: the superpixel patches and masks the C++ command line cuts
     (csrc/svr_slic.h) are the oracle's cut of the same pre-processed stacks."""
-    from fetalreconstruction_amd import build, nifti, pvr_cli
+    from fetalreconstruction_amd import build, nifti
+    from tests.twins import pvr_cli
     build.build()
     stacks, mask, mattr, rattr, rmask = phantom.make_stacks(2, (48, 40, 6), 1.1, 2.2, None, 1.0, 16.0, seed=4, orientations=("ax", "sag"),
                                                             stack_motion_mm=0.0, stack_motion_deg=0.0)

@@ -113,7 +113,7 @@ def _correlation_with_phantom(path, radius, to_anatomy=np.eye(4)):
 @pytest.mark.gpu
 def test_command_line_end_to_end(tmp_path):
     """NIfTI stacks + mask -> reconstructed NIfTI volume that matches the analytic phantom (motion-free stacks, no registration)."""
-    from fetalreconstruction_amd import cli
+    from tests.twins import cli
     paths, mpath, rattr, rmask = _write_case(tmp_path)
     out = tmp_path / "recon.nii.gz"
     rc = cli.main(["-o", str(out), "-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--no_registration",
@@ -132,7 +132,8 @@ def test_command_line_registration_recovers_stack_motion(tmp_path):
     registration, then the IRTK slice-to-volume schedule between the iterations, every similarity on the GPU) against
     --no_registration.  Measured on MI355X: 0.61 without, 0.90 with; the reference's experimental --useGPUReg path, restated
     literally (half-voxel texture offset and all), reaches 0.60 from the same stack alignment."""
-    from fetalreconstruction_amd import cli, nifti
+    from fetalreconstruction_amd import nifti
+    from tests.twins import cli
     R = 26.0
     stacks, mask, mattr, rattr, rmask = phantom.make_stacks(4, (64, 64, 26), 1.1, 2.2, None, 1.0, R, seed=7, stack_motion_mm=2.5,
                                                             stack_motion_deg=4.0)
@@ -156,7 +157,8 @@ def test_command_line_registration_recovers_stack_motion(tmp_path):
 def test_cpp_command_line_matches_the_python_one(tmp_path, registration):
     """bin/SVRreconstructionGPU (csrc/svr_cli.cpp: C++ pre-processing + the C++ host object) against cli.py."""
     import subprocess
-    from fetalreconstruction_amd import build, cli, nifti
+    from fetalreconstruction_amd import build, nifti
+    from tests.twins import cli
     paths, mpath, rattr, rmask = _write_case(tmp_path)
     common = ["-i", *paths, "-m", mpath, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "2",
               "--rec_iterations_first", "2", "--rec_iterations_last", "3", "--smooth_mask", "2"] + {"none": ["--no_registration", "--no_log", "1", "--log_prefix", "x", "--global_bias_correction", "0",
@@ -194,7 +196,8 @@ def test_transformations_round_trip_through_tfolder(tmp_path):
     """--debug writes transformation<i>.dof per slice (SaveTransformations), --tfolder reads them back (ReadTransformation): a
     second run that starts from the first run's registered slices and does not register reproduces its last iteration's input."""
     import subprocess
-    from fetalreconstruction_amd import build, cli, nifti
+    from fetalreconstruction_amd import build, nifti
+    from tests.twins import cli
     paths, mpath, rattr, rmask = _write_case(tmp_path)
     first = tmp_path / "a"
     first.mkdir()
@@ -284,7 +287,7 @@ def test_command_line_with_the_coefficient_table(tmp_path):
 def test_command_line_boolean_options_follow_the_reference():
     """`--debug`, `--no_intensity_matching`, `--no_log` are po::value<bool> in the reference (reconstruction.cc:186-205): they take
     a value, and the value of --no_intensity_matching lands in `intensity_matching` itself (0 switches the matching off)."""
-    from fetalreconstruction_amd import cli
+    from tests.twins import cli
     p = cli._parser()
     a = p.parse_args("-o x -i a b --no_intensity_matching 1 --debug 0 --no_log 1 --log_prefix q --num_stacks_tuner 1".split())
     assert a.no_intensity_matching is True and a.debug is False and a.num_stacks_tuner == 1
@@ -357,7 +360,8 @@ def test_template_must_be_identified(tmp_path):
     """reconstruction.cc:452-457: with transformations given and none of them `id`, the reference stops with 'Please identify
     the template by assigning id transformation' -- both command lines do (before any GPU work)."""
     import subprocess
-    from fetalreconstruction_amd import build, cli, nifti
+    from fetalreconstruction_amd import build, nifti
+    from tests.twins import cli
     build.build()
     img = _stack()
     paths = []
@@ -378,7 +382,8 @@ def test_no_mask_option_builds_the_mask_from_the_template(tmp_path):
     runs the normal mask path (TransformMask, CropImage, SetMask); both command lines, same volume, and nothing is reconstructed
     where the template stack was padding."""
     import subprocess
-    from fetalreconstruction_amd import build, cli, nifti
+    from fetalreconstruction_amd import build, nifti
+    from tests.twins import cli
     paths, mpath, rattr, rmask = _write_case(tmp_path)
     common = ["-i", *paths, "--thickness", "2.2", "2.2", "2.2", "--resolution", "1.0", "--iterations", "1", "--rec_iterations_last", "2",
               "--no_registration", "--smooth_mask", "0"]
@@ -402,7 +407,7 @@ def test_no_intensity_matching_keeps_the_scales_at_one(tiny):
     """`--no_intensity_matching 0` (intensity_matching = false, reconstruction.cc:183, 1018-1045): no Scale (and no Bias /
     NormaliseBias) in the SR iterations -- the per-slice scales stay 1 in both hosts."""
     from fetalreconstruction_amd import engine as E, host
-    from fetalreconstruction_amd.reconstruction import irtkReconstruction
+    from tests.twins.reconstruction import irtkReconstruction
     out = {}
     for on in (True, False):
         rec = E.Reconstruction(0)

@@ -193,7 +193,8 @@ def test_pvr_kernel_variants_agree_at_full_size(superpixel):
     """BASELINE.json configs[2] (PVR, 32x32 patches stride 16 on the 4-stack 1.0 mm case; too big for the oracle) and the
     superpixel variant of configs[4] (--spxSize 32 --spxExtend 2) on the same stacks: the LDS-tiled gather / plane-owned
     scatter (pvr_mode 1) against the wave-per-pixel kernels (pvr_mode 0) on the device.  Hit sets exact, sums to round-off."""
-    from fetalreconstruction_amd import engine as E, pvr
+    from fetalreconstruction_amd import engine as E
+    from tests.twins import pvr
     stacks, mask, mattr, rattr, rmask = phantom.make_stacks(4, (100, 93, 70), 1.17647, 1.25, 2.5, 1.0, 50.0, seed=1,
                                                             orientations=("ax", "cor", "sag", "ax"))
     if superpixel:
@@ -252,14 +253,14 @@ def _sub_attr(a, z0, z1, step):
 
 # ---- patch extraction + the PVR loop (host side: fetalreconstruction_amd/pvr.py) ----------------
 def _small_pvr():
-    from fetalreconstruction_amd import pvr
+    from tests.twins import pvr
     stacks, mask, mattr, rattr, rmask = phantom.make_stacks(2, (24, 24, 5), 1.1, 2.2, None, 1.0, 11.0, seed=4,
                                                             orientations=("ax", "sag"))
     return pvr, stacks, pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (16, 16), (8, 8))
 
 
 def test_generate_2d_patches_rules():
-    from fetalreconstruction_amd import pvr
+    from tests.twins import pvr
     stacks, mask, mattr, rattr, rmask = phantom.make_stacks(1, (24, 24, 3), 1.1, 2.2, None, 1.0, 11.0, seed=4,
                                                             orientations=("ax",))
     st = stacks[0]
@@ -430,7 +431,8 @@ def _check_pvr_volume(path, stacks, min_cc=0.6):
 def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
     """File reading, mask handling, cropping, intensity matching, template, patches and the loop, with the test
     oracle standing in for the engine (CPU suite)."""
-    from fetalreconstruction_amd import host, nifti, pvr_cli
+    from fetalreconstruction_amd import host, nifti
+    from tests.twins import pvr_cli
     from fetalreconstruction_amd import preprocess as pp
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     seen = {}
@@ -459,7 +461,7 @@ def test_pvr_command_line_pipeline_on_the_oracle(tmp_path, oracle_mod):
 def test_pvr_hierarchical_levels_on_the_oracle(tmp_path, oracle_mod, capsys):
     """--hierarchical (pvrmain:359-432): iterations + 1 levels of one reconstruction iteration each with patches 4 pixels
     (stride 2) smaller per level; the registration side of it runs in the GPU suite."""
-    from fetalreconstruction_amd import pvr_cli
+    from tests.twins import pvr_cli
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     sizes = []
 
@@ -483,7 +485,8 @@ def test_pvr_hierarchical_levels_on_the_oracle(tmp_path, oracle_mod, capsys):
 def test_pvr_hierarchical_and_existing_target(tmp_path, capsys):
     """--hierarchical with registration: level 0 reconstructs, registers, reconstructs; level 1 registers to the level-0 volume
     first.  --existingReconTarget (PBR.cpp:185-191, 296-314, 456): the given volume is the grid and the target of iteration 0."""
-    from fetalreconstruction_amd import nifti, pvr_cli
+    from fetalreconstruction_amd import nifti
+    from tests.twins import pvr_cli
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     common = ["-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8", "--resolution", "1.0", "--sr_iterations", "3"]
     out = tmp_path / "h.nii.gz"
@@ -503,7 +506,7 @@ def test_pvr_hierarchical_and_existing_target(tmp_path, capsys):
 
 def test_full_slice_patches_of_stacks_of_different_sizes_share_a_padded_grid():
     """--useFullSlices (patchBasedObject.cuh:183-189): patch = slice, stride = size + 1; the engine's slice grid is padded with -1."""
-    from fetalreconstruction_amd import pvr
+    from tests.twins import pvr
     a, mask, mattr, rattr, rmask = phantom.make_stacks(2, (30, 30, 7), 1.1, 2.2, None, 1.0, 14.0, seed=4, orientations=("ax", "sag"),
                                                        stack_motion_mm=0.0, stack_motion_deg=0.0)
     b = phantom.make_stacks(2, (36, 26, 7), 1.1, 2.2, None, 1.0, 14.0, seed=4, orientations=("ax", "sag"), stack_motion_mm=0.0,
@@ -525,7 +528,7 @@ def test_full_slice_patches_of_stacks_of_different_sizes_share_a_padded_grid():
 
 
 def test_pvr_intensity_matching_rules():
-    from fetalreconstruction_amd import pvr_cli
+    from tests.twins import pvr_cli
     from fetalreconstruction_amd import preprocess as pp
     a = geo.ImageAttributes(8, 8, 4, 1.0, 1.0, 2.0)
     rng = np.random.default_rng(0)
@@ -552,7 +555,7 @@ def test_pvr_intensity_matching_rules():
 
 @pytest.mark.gpu
 def test_pvr_command_line_end_to_end(tmp_path):
-    from fetalreconstruction_amd import pvr_cli
+    from tests.twins import pvr_cli
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     out = tmp_path / "o.nii.gz"
     assert pvr_cli.main(["-o", str(out), "-i", *paths, "-m", mpath, "--patchSize", "16", "16", "--patchStride", "8", "8",
@@ -562,7 +565,8 @@ def test_pvr_command_line_end_to_end(tmp_path):
 
 def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=False, dilate=0, packages=None, resample=False):
     """What pvr_cli.main builds before it touches the engine."""
-    from fetalreconstruction_amd import nifti, pvr, pvr_cli
+    from fetalreconstruction_amd import nifti
+    from tests.twins import pvr, pvr_cli
     from fetalreconstruction_amd import preprocess as pp
     stacks = []
     for p in paths:
@@ -586,7 +590,7 @@ def _python_pvr_problem(paths, mpath, psize, pstride, resolution, full_slices=Fa
 def test_dilate_mask_rule():
     """irtkDilation, 26-connectivity (irtkDilation.cc:50-78): binary dilation by a 3x3x3 box, the faces of the image untouched."""
     from scipy import ndimage
-    from fetalreconstruction_amd import pvr_cli
+    from tests.twins import pvr_cli
     rng = np.random.default_rng(3)
     m = (rng.random((9, 10, 11)) > 0.97).astype(np.float64)
     d = pvr_cli.dilate_mask(m, 2)
@@ -600,7 +604,7 @@ def test_dilate_mask_rule():
 
 def test_split_packages_rule():
     """patchBasedPackageSplitter.cpp:76-146: package l = slices l, l + p, ... at p times the spacing, each slice where it was."""
-    from fetalreconstruction_amd import pvr_cli
+    from tests.twins import pvr_cli
     from fetalreconstruction_amd import preprocess as pp
     st = phantom.make_stacks(2, (12, 10, 7), 1.1, 2.2, None, 1.0, 11.0, seed=4, orientations=("ax", "sag"))[0][1]
     img = pp.Image(st.data.astype(np.float64), st.attr)
@@ -617,7 +621,7 @@ def test_bspline_resampling_rule():
     recursive prefilter with mirror boundaries, 4x4x4 taps, mirrored indices, clamped to the input range -- which is what
     scipy's spline_filter / map_coordinates(order=3, mode="mirror") compute."""
     from scipy import ndimage
-    from fetalreconstruction_amd import pvr_cli
+    from tests.twins import pvr_cli
     from fetalreconstruction_amd import preprocess as pp
     st = phantom.make_stacks(2, (30, 26, 7), 1.1, 2.2, None, 1.0, 11.0, seed=4, orientations=("ax", "sag"))[0][0]
     img = pp.Image(st.data.astype(np.float64), st.attr)
@@ -723,7 +727,8 @@ def test_cpp_pvr_loop_matches_the_python_loop():
     (True, False, True, []), (False, False, False, ["--packages", "2", "1", "--dilateMask", "1"]), (False, False, False, ["--resample"])])
 def test_cpp_pvr_command_line_matches_the_python_one(tmp_path, registration, full_slices, hierarchical, extra):
     import subprocess
-    from fetalreconstruction_amd import build, nifti, pvr_cli
+    from fetalreconstruction_amd import build, nifti
+    from tests.twins import pvr_cli
     paths, mpath, stacks = _write_pvr_case(tmp_path)
     common = ["-i", *paths, "-m", mpath, *(["--useFullSlices"] if full_slices else ["--patchSize", "16", "16", "--patchStride", "8", "8"]),
               "--resolution", "1.0", "--iterations", "1", "--sr_iterations", "3"] + ([] if registration else ["--no_registration"]) \
@@ -750,7 +755,7 @@ def test_cpp_pvr_command_line_matches_the_python_one(tmp_path, registration, ful
 
 # ---- patch-to-volume registration (PatchBased2D3DRegistration_gpu2::run; engine: svr_pvr_register_patches) ----------------
 def _patch_reg_case(knock=True, small=False):
-    from fetalreconstruction_amd import pvr
+    from tests.twins import pvr
     if small:
         pvr, stacks, P = _small_pvr()
         R = 11.0

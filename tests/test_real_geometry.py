@@ -107,7 +107,8 @@ def _correlation(path, c, mask, mattr):
 def test_svr_command_lines_on_the_oblique_grid(tmp_path):
     """bin/SVRreconstructionGPU and cli.py on three mutually oblique stacks on the bundled mask's grid, 300-400 mm from the
     origin: the reconstruction lands on the mask (float32 transform chains hold up) and shows the phantom."""
-    from fetalreconstruction_amd import build, cli
+    from fetalreconstruction_amd import build
+    from tests.twins import cli
     paths, mpath, stacks, c, (m, a) = _write_case(tmp_path, 3)
     common = ["-i", *paths, "-m", mpath, "--thickness", "2.5", "2.5", "2.5", "--resolution", "1.0", "--iterations", "2",
               "--rec_iterations_first", "3", "--rec_iterations_last", "5", "--no_registration"]

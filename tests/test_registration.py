@@ -5,7 +5,7 @@ import pytest
 
 from fetalreconstruction_amd import geometry as geo
 from fetalreconstruction_amd import phantom
-from fetalreconstruction_amd import registration as R
+from tests.twins import registration as R
 
 
 def _analytic_volume(P, radius=14.0):
@@ -260,7 +260,7 @@ def test_reduction_width_does_not_change_the_decisions(tiny, oracle_mod):
 def test_registration_on_a_reconstructed_volume(tiny, oracle_mod):
     """End to end on the engine's own reconstruction: reconstruct, register, push the new matrices."""
     from fetalreconstruction_amd import engine as E
-    from fetalreconstruction_amd.reconstruction import irtkReconstruction
+    from tests.twins.reconstruction import irtkReconstruction
     rec = E.Reconstruction(0)
     E.sync_gpu(rec, tiny)
     d = irtkReconstruction(rec, tiny.ns, max_intensity=tiny.max_intensity, min_intensity=tiny.min_intensity)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from fetalreconstruction_amd import phantom, workloads
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from tests.twins.reconstruction import irtkReconstruction
 from tests.census import census, fastmath_census
 from tests.util import rel_err, run_to_state
 

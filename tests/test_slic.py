@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 
 from fetalreconstruction_amd import geometry as geo
-from fetalreconstruction_amd import phantom, pvr, slic
+from fetalreconstruction_amd import phantom
+from tests.twins import pvr, slic
 
 
 def _stacks():
@@ -66,7 +67,8 @@ def test_superpixel_patches_and_masks():
 
 
 def test_pvr_command_line_with_superpixels_on_the_oracle(tmp_path, oracle_mod):
-    from fetalreconstruction_amd import nifti, pvr_cli
+    from fetalreconstruction_amd import nifti
+    from tests.twins import pvr_cli
     stacks, mask, mattr, rattr, rmask = _stacks()
     paths = []
     for k, st in enumerate(stacks):
@@ -94,7 +96,8 @@ def test_pvr_command_line_with_superpixels_on_the_oracle(tmp_path, oracle_mod):
 
 @pytest.mark.gpu
 def test_pvr_command_line_with_superpixels_end_to_end(tmp_path):
-    from fetalreconstruction_amd import nifti, pvr_cli
+    from fetalreconstruction_amd import nifti
+    from tests.twins import pvr_cli
     stacks, mask, mattr, rattr, rmask = _stacks()
     paths = []
     for k, st in enumerate(stacks):
@@ -123,7 +126,8 @@ def test_pvr_command_line_with_superpixels_end_to_end(tmp_path):
 def test_cpp_superpixel_patches_match_the_python_ones(tmp_path):
     """bin/PVRreconstructionGPU -s --dumpProblem --dryRun (csrc/svr_slic.h) against slic.py through the same pre-processing."""
     import subprocess
-    from fetalreconstruction_amd import build, nifti, pvr_cli
+    from fetalreconstruction_amd import build, nifti
+    from tests.twins import pvr_cli
     from fetalreconstruction_amd import preprocess as pp
     build.build()
     stacks, mask, mattr, rattr, rmask = _stacks()

@@ -4,7 +4,7 @@ option names and defaults of main.cc:164-211, the set-up of main.cc:386-815 (tem
 intensity matching, slices, masking) and the registration-reconstruction loop of main.cc:816-1237 with its
 smoothing schedule.
 
-    python -m fetalreconstruction_amd.cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz s3.nii.gz -m mask.nii.gz \\
+    python -m tests.twins.cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz s3.nii.gz -m mask.nii.gz \\
         [--thickness 2.5 2.5 2.5] [--resolution 0.75] [--iterations 4] [--useGPUReg]
 
 Stack transformations (`id`, IRTK rigid `dof` files or 4x4 text matrices) start the stack-to-stack registration
@@ -20,8 +20,8 @@ import sys
 
 import numpy as np
 
-from . import engine, host, nifti
-from . import preprocess as pp
+from fetalreconstruction_amd import engine, host, nifti
+from fetalreconstruction_amd import preprocess as pp
 from . import registration as reg
 from .reconstruction import irtkReconstruction
 

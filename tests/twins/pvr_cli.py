@@ -6,7 +6,7 @@ crop the stacks to it, resample the mask to the isotropic voxel size, match the 
 template stack's grid resampled, no extra slices), extract the patches, then `iterations + 1` passes of
 Gaussian reconstruction -> robust statistics -> `sr_iterations` SR iterations.
 
-    python -m fetalreconstruction_amd.pvr_cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz -m mask.nii.gz \\
+    python -m tests.twins.pvr_cli -o recon.nii.gz -i s1.nii.gz s2.nii.gz -m mask.nii.gz \\
         [--patchSize 32 32] [--patchStride 16 16] [--resolution 0.75] [--iterations 7] [--sr_iterations 7]
 
 The stack-to-stack registration (irtkStack3D3DRegistration, PBR.cpp:280-285) runs through csrc/irtk_reg.cpp with every
@@ -26,9 +26,10 @@ import sys
 
 import numpy as np
 
-from . import engine, nifti, pvr
-from . import geometry as geo
-from . import preprocess as pp
+from fetalreconstruction_amd import engine, nifti
+from . import pvr
+from fetalreconstruction_amd import geometry as geo
+from fetalreconstruction_amd import preprocess as pp
 from .cli import _load_transformation
 
 
@@ -268,7 +269,7 @@ def main(argv=None, _engine_factory=_hip_engine, _ncc_backend=None):
         n = len(stacks)
     md, mat = nifti.read(a.mask)
     def register(st, tr, iso):                                                            # irtkStack3D3DRegistration<T>::run
-        from . import host
+        from fetalreconstruction_amd import host
         rec = engine.Reconstruction(a.devices[0]) if _engine_factory is _hip_engine else None
         out, evals = host.StackRegistrations(rec, [s.data for s in st], [s.attr for s in st], tr, template, mask=iso.data,
                                              mask_attr=iso.attr, keep_origin=True, backend=_ncc_backend)

@@ -15,12 +15,10 @@ import copy
 
 import numpy as np
 
-from . import geometry as geo
+from fetalreconstruction_amd import geometry as geo
 
 
-def irtk_round(x: float) -> int:
-    """round() of irtkCommon.h:85-88 (half away from zero)."""
-    return int(x + 0.5) if x > 0 else int(x - 0.5)
+from fetalreconstruction_amd.geometry import irtk_round  # noqa: E402,F401
 
 
 def resample_with_padding(img: np.ndarray, attr: geo.ImageAttributes, new_size, pad=-1.0):

@@ -17,7 +17,7 @@ import copy
 
 import numpy as np
 
-from . import geometry as geo
+from fetalreconstruction_amd import geometry as geo
 from .registration import irtk_round
 
 

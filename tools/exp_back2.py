@@ -3,7 +3,7 @@ usage: python tools/exp_back2.py [workload] -- "opt=v opt=v" "opt=v" ..."""
 import os, sys; sys.path.insert(0, '/root/repo')
 import numpy as np
 from fetalreconstruction_amd import workloads, engine
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from tests.twins.reconstruction import irtkReconstruction
 wl = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != '--' else 'P4'
 sets = sys.argv[sys.argv.index('--') + 1:] if '--' in sys.argv else ['']
 P = workloads.get(wl)

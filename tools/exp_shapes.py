@@ -2,7 +2,7 @@
 usage: python tools/exp_shapes.py [workload]"""
 import sys; sys.path.insert(0, '/root/repo')
 from fetalreconstruction_amd import workloads, engine
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from tests.twins.reconstruction import irtkReconstruction
 wl = sys.argv[1] if len(sys.argv) > 1 else 'P4'
 P = workloads.get(wl)
 rec = engine.Reconstruction(0); engine.sync_gpu(rec, P)

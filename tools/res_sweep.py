@@ -3,7 +3,7 @@ volume box stops fitting LDS.  4 stacks of 128x128x32, 1.0 mm pixels."""
 import sys; sys.path.insert(0, '/root/repo')
 import numpy as np
 from fetalreconstruction_amd import phantom, engine
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from tests.twins.reconstruction import irtkReconstruction
 for res in (1.5, 1.0, 0.75, 0.5, 0.4, 0.35):
     P = phantom.make_problem(4, (128, 128, 32), 1.0, 2.5, 2.5, res, 50.0, orientations=("ax", "cor", "sag"), name="r")
     rec = engine.Reconstruction(0); engine.sync_gpu(rec, P)

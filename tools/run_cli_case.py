@@ -8,7 +8,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
-from fetalreconstruction_amd import cli, geometry as geo, nifti, phantom  # noqa: E402
+from fetalreconstruction_amd import geometry as geo, nifti, phantom
+from tests.twins import cli  # noqa: E402
 
 tmp = pathlib.Path(tempfile.mkdtemp())
 R = 26.0

@@ -7,7 +7,7 @@ sys.path.insert(0, '/root/repo')
 import numpy as np  # noqa: E402
 
 from fetalreconstruction_amd import engine, geometry as geo, host, phantom  # noqa: E402
-from fetalreconstruction_amd.reconstruction import irtkReconstruction  # noqa: E402
+from tests.twins.reconstruction import irtkReconstruction  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "p4"
 P = phantom.problem_p4() if which == "p4" else phantom.problem_tiny()

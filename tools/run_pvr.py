@@ -3,7 +3,8 @@ BASELINE.json configs[4]), one outer iteration with 3 SR iterations; kernel time
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
-from fetalreconstruction_amd import phantom, engine, pvr
+from fetalreconstruction_amd import phantom, engine
+from tests.twins import pvr
 
 t0 = time.time()
 RES = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0

@@ -3,8 +3,9 @@ counters, with the batched gradient and one evaluation at a time.  usage: run_re
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
-from fetalreconstruction_amd import phantom, engine, registration as R
-from fetalreconstruction_amd.reconstruction import irtkReconstruction
+from fetalreconstruction_amd import phantom, engine
+from tests.twins import registration as R
+from tests.twins.reconstruction import irtkReconstruction
 
 which = sys.argv[1] if len(sys.argv) > 1 else "p4"
 P = phantom.problem_p4() if which == "p4" else phantom.problem_tiny()

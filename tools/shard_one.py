@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fetalreconstruction_amd import phantom
-from fetalreconstruction_amd.reconstruction import patch_cost_weights, shard_slices, slice_cost_weights
+from fetalreconstruction_amd.sharding import patch_cost_weights, shard_slices, slice_cost_weights
 from tools.shard_probe import build, make_engine
 
 wl, r, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

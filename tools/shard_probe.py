@@ -61,7 +61,7 @@ def collective_ms(bytes_per_rank_out, world):
 
 def probe(wl, world, reps=6, opts=(), only=None):
     from fetalreconstruction_amd import engine as E, phantom, host
-    from fetalreconstruction_amd.reconstruction import patch_cost_weights, shard_slices, slice_cost_weights
+    from fetalreconstruction_amd.sharding import patch_cost_weights, shard_slices, slice_cost_weights
     prob = build(wl)
     pvr = wl.startswith("PVR")
     spx = getattr(prob, "spx_masks", None)
