@@ -196,6 +196,7 @@ def main():
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dist = None
     multi = world > 1 or args.force_comm
+    env_at_start = set(os.environ)
     if args.force_comm:                                               # (the C++ hosts then go through their callbacks at world 1 too)
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("RANK", "0")
@@ -210,10 +211,21 @@ def main():
             raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()}: one GPU per rank "
                              f"(--share-gpu runs every rank on GPU 0 for a functional check)")
         torch.cuda.set_device(local_rank)
-        if args.comm == "torch" and args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")                           # rendezvous + barrier only
+
+        def rendezvous():
+            if args.comm == "torch" and args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")                       # rendezvous + barrier only
+        own_port = args.force_comm and world == 1 and "MASTER_PORT" not in env_at_start
+        for attempt in range(4):
+            try:
+                rendezvous()
+                break
+            except Exception as e:                                    # noqa: BLE001 -- DistNetworkError: the port picked above was taken meanwhile
+                if not own_port or attempt == 3 or "EADDRINUSE" not in str(e) and "address already in use" not in str(e):
+                    raise
+                os.environ["MASTER_PORT"] = str(free_port())
 
     # ---- the workload: fixed, whatever the world size --------------------------------------------------------------
     prob = workloads.get(args.workload) if args.workload != "tiny" else phantom.problem_tiny()

@@ -2858,6 +2858,7 @@ struct svr_ctx {
                             // 4 = wave-owned LDS planes (back_wave_kernel), 3 = the workgroup kernel for every tile (back_slot_kernel<8>),
                             // 1 = LDS tiles with ds_add_f32 (back_tiled_kernel), 0 = direct device-scope atomics per tap (psf_kernel<MODE_BACK>)
   int tile_cap = 0;         // voxels of LDS accumulator per workgroup
+  int n_cu = 0;             // compute units of the device (the grids of the persistent cell kernels)
   int dbg_back = 0;
   int dbg_fwd_lds = 0;      // dev experiment: extra dynamic LDS on the forward launch (limits occupancy)
   uint32_t n_tiles_fb = 0;
@@ -2913,6 +2914,8 @@ struct svr_ctx {
   CellState *cell = nullptr;      // the scatter's cell lists
   CellState *cell_g = nullptr;    // the gather's, when it works on another cell size (cell_prepare_gather)
   int cell_w = 0, cell_h = 0, cell_gw = 0, cell_gh = 0;   // 0: by the pixel density (cell_auto_size); cell_gw / cell_gh: the gather's own
+  int cell_order = 1;       // > 0: items in order of falling work, in classes of 2^(cell_order - 1) pixels (0: (cell, plane) order)
+  int cell_balance = 0;     // an item heavier than the launch's work / (1024 x cell_balance) is cut into parts (0: never)
   int cell_split = 1, cell_qx = 1, cell_band = 3;   // cell_qx: cells of a quad along x (1, 2 or 4; the other factor along the lane axis)
 
   // timers
@@ -3556,6 +3559,8 @@ int svr_create(int device, svr_ctx **out) {
   {
     // LDS accumulator of the tiled scatter: everything the CU has minus the static part
     int lds_max = 0;
+    (void)hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    if (ctx->n_cu <= 0) ctx->n_cu = 256;
     (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     if (lds_max <= 0) lds_max = 65536;
     int dyn = lds_max - 1024;
@@ -3579,6 +3584,8 @@ int svr_create(int device, svr_ctx **out) {
   }
   // SVR_TILE_PIN="GWxGH,SWxSH,BOX": the gather's tile, the tiled scatter's tile and its LDS box fixed instead of timed, so that a
   // run can be repeated with the same shapes (on every rank, in every process); bench.py prints the shapes in config.tuned
+  if (const char *v = getenv("SVR_CELL_ORDER")) ctx->cell_order = std::min(20, std::max(0, atoi(v)));   // (experiments: the options' defaults)
+  if (const char *v = getenv("SVR_CELL_BALANCE")) ctx->cell_balance = std::min(1024, std::max(0, atoi(v)));
   if (const char *pin = getenv("SVR_TILE_PIN")) {
     int gw, gh, sw, sh, box;
     if (sscanf(pin, "%dx%d,%dx%d,%d", &gw, &gh, &sw, &sh, &box) == 5 && gw > 0 && gh > 0 && gw * gh <= 32 && sw > 0 && sh > 0 && sw * sh <= 64 && box >= 1024) {
@@ -3638,6 +3645,18 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "cell_w") || !strcmp(name, "cell_h") || !strcmp(name, "cell_gw") || !strcmp(name, "cell_gh")) {
     if (value < 0 || value > 32) return fail(ctx, SVR_E_ARG, "cell_w / cell_h / cell_gw / cell_gh: 1..32, 0 = by the pixel density");
     (!strcmp(name, "cell_w") ? ctx->cell_w : !strcmp(name, "cell_h") ? ctx->cell_h : !strcmp(name, "cell_gw") ? ctx->cell_gw : ctx->cell_gh) = value;
+    cell_invalidate(ctx);
+    return SVR_OK;
+  }
+  if (!strcmp(name, "cell_order")) {
+    if (value < 0 || value > 20) return fail(ctx, SVR_E_ARG, "cell_order: 0..20");
+    ctx->cell_order = value;
+    cell_invalidate(ctx);
+    return SVR_OK;
+  }
+  if (!strcmp(name, "cell_balance")) {
+    if (value < 0 || value > 1024) return fail(ctx, SVR_E_ARG, "cell_balance: 0..1024");
+    ctx->cell_balance = value;
     cell_invalidate(ctx);
     return SVR_OK;
   }
@@ -5221,7 +5240,7 @@ int svr_cell_stats(svr_ctx *ctx, uint64_t out8[8]) {
   if ((r = cell_prepare(ctx))) return r;
   const CellState &cs = *ctx->cell;
   out8[0] = cs.a.nitems; out8[1] = cs.n_runs; out8[2] = cs.n_sorted;
-  out8[3] = (uint64_t)cs.a.nitems * cs.a.split * cs.a.PP * sizeof(f2);      // staging bytes written by the scatter, read by the combine
+  out8[3] = (uint64_t)cs.a.nents * cs.a.PP * sizeof(f2);      // staging bytes written by the scatter, read by the combine
   CellState *g = nullptr;
   if ((r = cell_prepare_gather(ctx, g))) return r;
   if (g) { out8[4] = g->a.nitems; out8[5] = g->n_runs; out8[6] = (uint64_t)g->n_sorted * (ctx->pvr ? PVR_N : PSF_SUPPORT) * sizeof(f2); }

@@ -159,6 +159,60 @@ def test_cell_sizes_do_not_change_the_results(tiny, oracle_mod, pvr, cells):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pvr", [False, True])
+def test_launch_order_and_parts_of_the_cell_items(tiny, oracle_mod, pvr):
+    """The entries of the cell kernels (csrc/svr_cell.inc, k_cell_item_work): items go out in order of falling work (cell_order) and a
+    heavy item is cut into parts (cell_balance / cell_split), each part taking every parts-th run that reaches the plane.  None of it
+    may change a result beyond the order of float additions in the scatter's combine: the gather's partial sums belong to one
+    (pixel, plane) unit each, so the simulated slices are the SAME BITS in every order and for any number of parts; the scatter
+    keeps its hit set exactly, stays within the float-sum tolerance of the oracle, repeats bit for bit, and without parts gives
+    the natural order's bits."""
+    from fetalreconstruction_amd import engine as E
+    outs = {}
+    for name, opts in (("natural", {"cell_order": 0, "cell_balance": 0}), ("by work", {"cell_order": 1, "cell_balance": 0}),
+                       ("classes of 16", {"cell_order": 5, "cell_balance": 0}), ("parts", {"cell_order": 1, "cell_balance": 1024}),
+                       ("three parts each", {"cell_order": 1, "cell_balance": 0, "cell_split": 3})):
+        if pvr:
+            E_, rec, orc = _pair(tiny, oracle_mod, None, 1)
+        else:
+            rec = E.Reconstruction(0)
+            E.sync_gpu(rec, tiny)
+            orc = oracle_mod.OracleReconstruction(tiny, oracle_mod.CANON)
+            ones = np.ones(tiny.ns, np.float32)
+            for r in (rec, orc):
+                r.UpdateScaleVector(ones, ones)
+                r.InitializeEMValues()
+        for k, v in opts.items():
+            rec.set_option(k, v)
+        rec.GaussianReconstruction(); orc.GaussianReconstruction()
+        assert rel_err(rec.getVolWeights(), orc.volw) < 2e-5 and rel_err(rec.syncCPU(), orc.recon) < 2e-5, name
+        rec.debug_set(E.BUF_RECONSTRUCTED, orc.recon)
+        rec.SimulateSlices(); orc.SimulateSlices()
+        sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
+        assert np.array_equal(si, orc.siminside) and rel_err(sim, orc.simslices) < 2e-5 and rel_err(sw, orc.simweights) < 2e-5, name
+        rec.debug_set(E.BUF_SIMSLICES, orc.simslices)
+        w = np.full(tiny.ns, 0.8, np.float32)
+        rec.SuperresolutionBackproject(w); orc.SuperresolutionBackproject(w)
+        cm, ad = rec.debug_get(E.BUF_CONFIDENCE_MAP).copy(), rec.debug_get(E.BUF_ADDON).copy()
+        assert np.array_equal(cm > 0, orc.cmap > 0) and rel_err(cm, orc.cmap) < 2e-5 and rel_err(ad, orc.addon) < 2e-5, name
+        rec.SuperresolutionBackproject(w)
+        assert np.array_equal(rec.debug_get(E.BUF_CONFIDENCE_MAP), cm) and np.array_equal(rec.debug_get(E.BUF_ADDON), ad), name
+        st = rec.cell_stats()
+        outs[name] = (sim, sw, cm, ad, st)
+        rec.close()
+    nat = outs["natural"]
+    for name, o in outs.items():
+        assert np.array_equal(o[0], nat[0]) and np.array_equal(o[1], nat[1]), name            # the gather: the same bits always
+        assert np.array_equal(o[2] > 0, nat[2] > 0), name
+        if name in ("by work", "classes of 16"):                                              # one slab per item: the combine adds the same slabs in the same order
+            assert np.array_equal(o[2], nat[2]) and np.array_equal(o[3], nat[3]), name
+    # the parts exist: more staged slabs than items
+    slab = outs["natural"][4]["staging_bytes"] // outs["natural"][4]["items"]
+    assert outs["three parts each"][4]["staging_bytes"] == 3 * outs["natural"][4]["staging_bytes"]
+    assert outs["parts"][4]["staging_bytes"] > outs["natural"][4]["staging_bytes"] and outs["parts"][4]["staging_bytes"] % slab == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("table_gather", ["default", "cells"])
 @pytest.mark.parametrize("use_spx", [False, True])
 def test_pvr_coefficient_table(tiny, oracle_mod, use_spx, table_gather):

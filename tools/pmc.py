@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """rocprofv3 counter passes over a command, summarised per kernel.
 
-usage: python tools/pmc.py OUTDIR [--filter substr] [--sets "A B C" "D E" ...] -- <command ...>
+usage: python tools/pmc.py OUTDIR [--filter substr] [--by-grid] [--sets "A B C" "D E" ...] -- <command ...>
+(--by-grid: launches of one kernel with different grid sizes are reported apart, e.g. the whole workload and one rank's range)
 Each set is one rocprofv3 pass (--kernel-trace --pmc <set>, nothing else: gpurun refuses --pmc next to the sys/hip/hsa
 trace domains).  Per kernel (short name) the mean over the LAST HALF of its dispatches is printed: the first dispatches
 hold warm-up and tile-shape timing.  Durations come from the same passes (End - Start of the dispatch)."""
@@ -35,6 +36,7 @@ def main():
     argv = argv[:argv.index("--")]
     flt = argv[argv.index("--filter") + 1] if "--filter" in argv else ""
     sets = DEFAULT_SETS
+    by_grid = "--by-grid" in argv
     if "--sets" in argv:
         i = argv.index("--sets") + 1
         sets = []
@@ -58,6 +60,8 @@ def main():
             k = short(r["Kernel_Name"])
             if flt and flt not in k:
                 continue
+            if by_grid:
+                k += "  grid " + r.get("Grid_Size", "?")
             did = int(r["Dispatch_Id"])
             res[k][r["Counter_Name"]][did] = res[k][r["Counter_Name"]].get(did, 0.0) + float(r["Counter_Value"])
             dur[k][(f, did)] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
