@@ -294,9 +294,8 @@ def main():
         drv.SimulateSlicesGPU()
         drv.InitializeRobustStatisticsGPU()
         drv.EStepGPU()
-    # the engine times its tile shapes / box sizes on the first gather / scatter after new geometry; the gather was tuned by
-    # SimulateSlicesGPU above, this untimed scatter keeps the other one out of the timed region whatever --warmup is (it
-    # only writes addon|cmap and the slice weights, which every SR iteration rebuilds / uploads)
+    # the first scatter after new geometry builds its work lists (cell lists, launch order); this untimed one keeps that out of the
+    # timed region whatever --warmup is (it only writes addon|cmap and the slice weights, which every SR iteration rebuilds / uploads)
     rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
 
     # The steps follow the reference's schedule: an outer iteration re-initialises the EM state and runs rec_iterations_first
@@ -503,8 +502,10 @@ def main():
                        "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",
                                  "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "fwd_mode": tuned["fwd_mode"],
                                  "cell": f"{tuned['cell_w']}x{tuned['cell_h']}", "gather_cell": f"{tuned['cell_gw']}x{tuned['cell_gh']}", "pin": os.environ.get("SVR_TILE_PIN"),
-                                 "note": "back_mode 5 / fwd_mode 2 work on (cell, plane) items: no tile shape is timed, runs repeat bit for bit; the tile "
-                                         "shapes apply to the Gaussian pass, the coefficient table and the patch-based path"}},
+                                 "cell_order": rec.get_option("cell_order"),
+                                 "note": "nothing is picked by timing (fwd_autotune 0): cell sizes and tile shapes follow from the geometry, the (cell, plane) items "
+                                         "are launched in order of falling work; runs repeat bit for bit.  The tile shapes apply to pass 1 of the Gaussian "
+                                         "reconstruction, the coefficient table's gather and the fallback modes"}},
             "ranks": ranks,
             "roofline": roof,
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in timers.items()},

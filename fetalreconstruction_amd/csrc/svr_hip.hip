@@ -2845,11 +2845,11 @@ struct svr_ctx {
   // The forward tile shape that suits a problem depends on how many voxels a pixel spans: at 2 voxels per pixel (0.5 mm
   // reconstructions of 1 mm pixels) the box of a 4x4 tile no longer fits the LDS and every tap falls back to global loads.  The first forward pass of a problem times the candidate shapes on the real data
   // and keeps the fastest; the results do not depend on the shape (per-pixel sums in a fixed order).
-  bool fwd_tune_pending = true, fwd_tile_user = false;
-  int fwd_autotune = 1;
+  bool fwd_tune_pending = false, fwd_tile_user = false;
+  int fwd_autotune = 0;     // 1: tile shapes by timed trial launches (rounds 1-3); 0: from the geometry (tile_shape_rule): every run, every rank the same
   // the same for the scatter's tile (4x4 pixels; 4x2 and 2x2 once a pixel spans more than ~2.4 voxels), timed on the first
   // back-projection after new slice geometry.  The scatter's sums are float atomics in run-dependent order with any shape.
-  bool back_tune_pending = true, tile_user = false, in_tune = false;
+  bool back_tune_pending = false, tile_user = false, in_tune = false;
   int pvr = 0;              // 1: patch-to-volume constants and kernels (svr_set_option "pvr")
   int pvr_mode = 1;         // PVR kernels: 1 = the unit-based gather / wave-owned scatter with support 12, 0 = wave-per-pixel (pvr_kernel)
   unsigned char *d_spx = nullptr;
@@ -3709,7 +3709,7 @@ int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
   const struct { const char *n; int v; } tab[] = {
       {"back_mode", back_mode_eff(ctx)}, {"reg_mode", ctx->reg_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
       {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
-      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", csw}, {"cell_h", csh}, {"cell_gw", cgw}, {"cell_gh", cgh}, {"cell_split", ctx->cell_split}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
+      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", csw}, {"cell_h", csh}, {"cell_gw", cgw}, {"cell_gh", cgh}, {"cell_split", ctx->cell_split}, {"cell_order", ctx->cell_order}, {"cell_balance", ctx->cell_balance}, {"fwd_autotune", ctx->fwd_autotune}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
   for (const auto &e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return SVR_OK; }
   return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);
@@ -4190,6 +4190,21 @@ int svr_gaussian_reconstruction(svr_ctx *ctx, int *voxel_num) {
   return svr_gaussian_reconstruction_finish(ctx, voxel_num);
 }
 
+// The tile shape of the unit gather (fwd_unit_kernel: fwd_mode 1, and the coefficient table's gather) from the geometry, not from a
+// timed trial: what the trials of rounds 1-3 picked, as a rule of the pixel density d = voxel area / pixel area in the slice plane.
+// With the table (the pass waits for HBM; 24-32 pixels per tile keep two workgroups per CU): P4 (d 0.72) 6 x 4 2.79 ms against 2.85 for
+// 6 x 5 and 3.07 for 4 x 4; S8 (d 0.56) 6 x 5 26.8 against 28.6 / 28.4 for 6 x 4 / 8 x 4; patches (support 12: smaller boxes) 8 x 4
+// 8.1 against 9.0-9.5 ms.  On the fly: 6 x 4 (round 2: 4.21 against 4.60 ms for 4 x 4 on P4).  Near-ties all (2-6 %): a rule that
+// repeats is worth more than the last per cent -- the table line of round 3 moved by 4 % from run to run with the trials' picks.
+void tile_shape_rule(const svr_ctx *ctx, bool table, int &w, int &h) {
+  double d = 1.0;
+  if (ctx->slice_dims.size() >= 3 && ctx->slice_dims[0] > 0 && ctx->slice_dims[1] > 0)
+    d = (double)ctx->vdim[0] * ctx->vdim[1] / ((double)ctx->slice_dims[0] * ctx->slice_dims[1]);
+  if (ctx->pvr) { w = 8; h = 4; }
+  else if (table && d < 0.65) { w = 6; h = 5; }
+  else { w = 6; h = 4; }
+}
+
 // ---- forward projection ----------------------------------------------------------------
 int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   SVR_ENTER(ctx);
@@ -4260,6 +4275,16 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
     return SVR_OK;
   };
   const bool tiled = a.n && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1);
+  if (tiled && !cells && !ctx->fwd_autotune && !ctx->fwd_tile_user) {
+    int w, h;
+    tile_shape_rule(ctx, a.coeff != nullptr, w, h);
+    if (w != ctx->fwd_tw || h != ctx->fwd_th) {
+      ctx->fwd_tw = w; ctx->fwd_th = h; ctx->psf_list_valid = false;
+      r = ensure_psf_list(ctx);
+      if (r) return r;
+      a.list = ctx->d_psf_list; a.n = ctx->n_psf;
+    }
+  }
   if (tiled && !cells && ctx->fwd_tune_pending && !ctx->fwd_tile_user) {
     ctx->fwd_tune_pending = false;
     static const int cand[6][2] = {{4, 4}, {6, 4}, {6, 5}, {8, 4}, {4, 2}, {2, 2}};   // the first is the default; smaller boxes for finer volumes (at most FWDU_MAXPIX = 32 pixels)
@@ -4544,6 +4569,17 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   if (r) return r;
   if (slice_weight) {
     r = svr_update_slice_weights(ctx, slice_weight);   // RC.cu:2123
+    if (r) return r;
+  }
+  if (!ctx->fwd_autotune && !ctx->tile_user && !ctx->in_tune && back_mode_eff(ctx) != 5 && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 3) &&
+      (ctx->tile_w != 6 || ctx->tile_h != 4)) {
+    // the tiled scatters (back_mode 3 / 4: fallbacks of the cell scatter, and what a caller names) without trials: 6 x 4 pixels with
+    // the 2096-voxel box -- the trials' pick or within 2 % of it on P4 (4.97 ms against 4.96-5.08) and S8 (6 x 5 / 2096: 50.5 against 52.2)
+    ctx->in_tune = true;
+    r = svr_set_option(ctx, "tile_w", 6);
+    if (!r) r = svr_set_option(ctx, "tile_h", 4);
+    ctx->tile_user = false;
+    ctx->in_tune = false;
     if (r) return r;
   }
   if (ctx->back_tune_pending && !ctx->tile_user && !ctx->in_tune && back_mode_eff(ctx) != 5 && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 3)) {   // (mode 5: cells, no tile shape to time)

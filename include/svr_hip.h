@@ -51,15 +51,22 @@ int svr_set_flags(svr_ctx *ctx, int disable_bias_correction, int debug_gpu);
  *   slice geometry, and stream them in the scatter and the gather instead of evaluating them in every SR iteration --
  *   irtkReconstruction::CoeffInit's _volcoeffs (irtkReconstructionGPU.cc:2305-2673) on the GPU path; 16 KiB per PSF
  *   pixel; switches itself off when that does not fit the free memory; results are those of the on-the-fly kernels.
- * "back_mode": 4 = wave-owned LDS planes (default), 3 = the workgroup kernel for every tile, 1 = LDS tiles with
- *   ds_add_f32, 0 = direct device-scope atomics per tap.  "fwd_mode": 1 = unit-based LDS gather (default), 0 = wave-per-pixel
- *   kernel.  "gauss_mode", "pvr_mode": the same choice for the Gaussian pass / the patch-to-volume kernels (tests).
- * "tile_w"/"tile_h", "wave_cap", "fwd_tile_w"/"fwd_tile_h", "fwd_unit_cap": tile shapes and LDS box sizes.
- * "fwd_autotune" (default 1): the first forward projection / back-projection after new slice geometry times the
+ * "back_mode": 5 = cell-owned planes, staged and combined in a fixed order, no float atomics (default; csrc/svr_cell.inc),
+ *   4 = wave-owned LDS planes flushed with float atomics (the fallback when the cell lists cannot hold a geometry), 3 = the
+ *   workgroup kernel for every tile, 1 = LDS tiles with ds_add_f32, 0 = direct device-scope atomics per tap.  "fwd_mode": 2 = the
+ *   gather over the same (cell, plane) items (default), 1 = unit-based LDS gather per slice tile, 0 = wave-per-pixel kernel.
+ *   "gauss_mode", "pvr_mode": the same choice for the Gaussian pass / the patch-to-volume kernels (tests).
+ * "cell_w"/"cell_h", "cell_gw"/"cell_gh" (0 = from the pixel density), "cell_band": cell sizes of the scatter / the gather.
+ * "cell_order" (default 1): the (cell, plane) items of a launch go out in order of falling work, in classes of 2^(value - 1)
+ *   pixels; 0 = (cell, plane) order.  "cell_balance" (default 0 = never): an item heavier than the launch's work /
+ *   (1024 x value) is cut into parts, each a workgroup of its own; "cell_split": at least that many parts per item.
+ * "tile_w"/"tile_h", "wave_cap", "fwd_tile_w"/"fwd_tile_h", "fwd_unit_cap": tile shapes and LDS box sizes of the tile kernels.
+ * "fwd_autotune" (default 0 since round 4: the shapes follow from the geometry, every run and every rank picks the same):
+ *   1 = the first forward projection / back-projection after new slice geometry times the
  *   candidate shapes and box sizes on the data and keeps the fastest; an explicit shape switches that off.
  *   Long tile lists are timed on runs of consecutive tiles (one run out of every stride, about 131072 tiles per trial;
- *   "tune_tiles" sets another number -- the command lines, whose whole job is a few dozen launches, ask for 32768); environment: SVR_TUNE_TILES (tiles per trial, 0 = always the whole list), SVR_TUNE_RUN, SVR_TUNE_DEBUG=1 (the
- *   candidates' times on stderr).
+ *   "tune_tiles" sets another number); environment: SVR_TUNE_TILES (tiles per trial, 0 = always the whole list), SVR_TUNE_RUN,
+ *   SVR_TUNE_DEBUG=1 (the candidates' times on stderr).
  * "pvr": 1 selects the patch-to-volume constants and kernels.
  * Other environment variables: SVR_COEFF_MAX_GB (ceiling of the coefficient table), SVR_FWD_PIECE (test hook: tiles per
  *   dispatch of the gather, at most 2^22). */

@@ -706,7 +706,7 @@ def test_coefficient_table_at_full_size(workload):
 
 
 def test_tile_shapes_do_not_change_results(tiny, oracle_mod):
-    """The gather's and the scatter's tile shapes are timed per problem (svr_set_option "fwd_autotune"): the simulated slices
+    """The gather's and the scatter's tile shapes are chosen per problem (from the geometry; timed with svr_set_option "fwd_autotune" 1): the simulated slices
     must not depend on the shape at all (fixed per-pixel summation order), the scatter only through the order of its float
     atomics -- and every shape must still agree with the oracle."""
     from fetalreconstruction_amd import engine as E
