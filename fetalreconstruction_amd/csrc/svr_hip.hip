@@ -2915,6 +2915,7 @@ struct svr_ctx {
   CellState *cell_g = nullptr;    // the gather's, when it works on another cell size (cell_prepare_gather)
   int cell_w = 0, cell_h = 0, cell_gw = 0, cell_gh = 0;   // 0: by the pixel density (cell_auto_size); cell_gw / cell_gh: the gather's own
   int cell_order = 1;       // > 0: items in order of falling work, in classes of 2^(cell_order - 1) pixels (0: (cell, plane) order)
+  int cell_combine = 1;     // 1: the combine asks for a voxel's slabs in two batches (k_cell_combine_fast), 0: the general form (same bits)
   int cell_balance = 0;     // an item heavier than the launch's work / (1024 x cell_balance) is cut into parts (0: never)
   int cell_split = 1, cell_qx = 1, cell_band = 3;   // cell_qx: cells of a quad along x (1, 2 or 4; the other factor along the lane axis)
 
@@ -3654,6 +3655,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     cell_invalidate(ctx);
     return SVR_OK;
   }
+  if (!strcmp(name, "cell_combine")) { ctx->cell_combine = value ? 1 : 0; return SVR_OK; }
   if (!strcmp(name, "cell_balance")) {
     if (value < 0 || value > 1024) return fail(ctx, SVR_E_ARG, "cell_balance: 0..1024");
     ctx->cell_balance = value;
@@ -3709,7 +3711,7 @@ int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
   const struct { const char *n; int v; } tab[] = {
       {"back_mode", back_mode_eff(ctx)}, {"reg_mode", ctx->reg_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
       {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
-      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", csw}, {"cell_h", csh}, {"cell_gw", cgw}, {"cell_gh", cgh}, {"cell_split", ctx->cell_split}, {"cell_order", ctx->cell_order}, {"cell_balance", ctx->cell_balance}, {"fwd_autotune", ctx->fwd_autotune}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
+      {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", csw}, {"cell_h", csh}, {"cell_gw", cgw}, {"cell_gh", cgh}, {"cell_split", ctx->cell_split}, {"cell_order", ctx->cell_order}, {"cell_balance", ctx->cell_balance}, {"cell_combine", ctx->cell_combine}, {"fwd_autotune", ctx->fwd_autotune}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
   for (const auto &e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return SVR_OK; }
   return fail(ctx, SVR_E_ARG, std::string("unknown option ") + name);

@@ -166,12 +166,13 @@ def test_launch_order_and_parts_of_the_cell_items(tiny, oracle_mod, pvr):
     may change a result beyond the order of float additions in the scatter's combine: the gather's partial sums belong to one
     (pixel, plane) unit each, so the simulated slices are the SAME BITS in every order and for any number of parts; the scatter
     keeps its hit set exactly, stays within the float-sum tolerance of the oracle, repeats bit for bit, and without parts gives
-    the natural order's bits."""
+    the natural order's bits.  The combine in its general form (cell_combine 0) and in two batches gives the same bits too."""
     from fetalreconstruction_amd import engine as E
     outs = {}
     for name, opts in (("natural", {"cell_order": 0, "cell_balance": 0}), ("by work", {"cell_order": 1, "cell_balance": 0}),
                        ("classes of 16", {"cell_order": 5, "cell_balance": 0}), ("parts", {"cell_order": 1, "cell_balance": 1024}),
-                       ("three parts each", {"cell_order": 1, "cell_balance": 0, "cell_split": 3})):
+                       ("three parts each", {"cell_order": 1, "cell_balance": 0, "cell_split": 3}),
+                       ("general combine", {"cell_combine": 0}), ("general combine, parts", {"cell_combine": 0, "cell_split": 3})):
         if pvr:
             E_, rec, orc = _pair(tiny, oracle_mod, None, 1)
         else:
@@ -204,8 +205,9 @@ def test_launch_order_and_parts_of_the_cell_items(tiny, oracle_mod, pvr):
     for name, o in outs.items():
         assert np.array_equal(o[0], nat[0]) and np.array_equal(o[1], nat[1]), name            # the gather: the same bits always
         assert np.array_equal(o[2] > 0, nat[2] > 0), name
-        if name in ("by work", "classes of 16"):                                              # one slab per item: the combine adds the same slabs in the same order
-            assert np.array_equal(o[2], nat[2]) and np.array_equal(o[3], nat[3]), name
+        if name in ("by work", "classes of 16", "general combine"):                           # one slab per item: the combine adds the same slabs in the same order,
+            assert np.array_equal(o[2], nat[2]) and np.array_equal(o[3], nat[3]), name        # whether it asks for them one by one or in two batches (k_cell_combine_fast)
+    assert np.array_equal(outs["general combine, parts"][2], outs["three parts each"][2]) and np.array_equal(outs["general combine, parts"][3], outs["three parts each"][3])
     # the parts exist: more staged slabs than items
     slab = outs["natural"][4]["staging_bytes"] // outs["natural"][4]["items"]
     assert outs["three parts each"][4]["staging_bytes"] == 3 * outs["natural"][4]["staging_bytes"]
