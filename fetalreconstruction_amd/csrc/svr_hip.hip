@@ -367,7 +367,7 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
       // (the test is on q, a superset: pi sqrt(q) < 1.858e-2 needs q < 3.5e-5; q == 0 makes r NaN, which a minimum of r would skip)
       float qmin = FLT_MAX;
 #pragma unroll
-      EACH qmin = __builtin_fminf(qmin, __builtin_fminf(q[i].x, q[i].y));
+      EACH qmin = __builtin_fminf(__builtin_fminf(qmin, q[i].x), q[i].y);
       if (__any(!(qmin >= 4.0e-5f))) {
 #pragma unroll
       EACH {
@@ -384,11 +384,15 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
       }
       }
     } else {
-      // the R = 0 tap: only a pixel that sits exactly on a voxel centre of an aligned slice has one
+      // the R = 0 tap: only a pixel that sits exactly on a voxel centre of an aligned slice has one.  One v_min3_f32 per pair and a
+      // branch that is never taken on real data -- the empty asm keeps it a branch: the compiler used to turn the fix-up into 2 H
+      // compares + 2 H selects executed for every row (with the 1.5 H minimum operations: 44 of a row's ~460 VALU instructions
+      // at H = 8, round 4)
       float qmin = FLT_MAX;
 #pragma unroll
-      EACH qmin = __builtin_fminf(qmin, __builtin_fminf(q[i].x, q[i].y));
-      if (__any(qmin == 0.0f)) {
+      EACH qmin = __builtin_fminf(__builtin_fminf(qmin, q[i].x), q[i].y);
+      if (__builtin_expect(__any(qmin == 0.0f), 0)) {
+        asm volatile("" ::: "memory");
 #pragma unroll
         EACH {
           p[i].x = (q[i].x == 0.0f) ? __builtin_nanf("") : p[i].x;
