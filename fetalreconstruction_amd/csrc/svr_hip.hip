@@ -385,9 +385,7 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
       }
     } else {
       // the R = 0 tap: only a pixel that sits exactly on a voxel centre of an aligned slice has one.  One v_min3_f32 per pair and a
-      // branch that is never taken on real data -- the empty asm keeps it a branch: the compiler used to turn the fix-up into 2 H
-      // compares + 2 H selects executed for every row (with the 1.5 H minimum operations: 44 of a row's ~460 VALU instructions
-      // at H = 8, round 4)
+      // branch that is never taken on real data (the empty asm keeps it one)
       float qmin = FLT_MAX;
 #pragma unroll
       EACH qmin = __builtin_fminf(__builtin_fminf(qmin, q[i].x), q[i].y);
