@@ -4126,6 +4126,18 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     ta.tiles_x = ftx; ta.tiles_y = fty; ta.tw = gtw; ta.th = gth; ta.gauss = 1;
     ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back;
     a.flag = nullptr; a.flag_out = ctx->d_gauss_flag;
+    // pass 1 follows the gather: over the (cell, plane) items when that is the gather's mode (fwd_mode 2; round 4), per slice tile
+    // otherwise (fwd_mode 1, the coefficient table, geometries the cell lists cannot hold).  The same bits.
+    bool pass1_cells = false;
+    if (ctx->fwd_mode == 2 && !a.coeff) {
+      CellState *gcs = nullptr;
+      if ((r = cell_prepare_gather(ctx, gcs))) return r;
+      if (gcs && gcs->usable) {
+        if ((r = launch_cell_gauss1(ctx, *gcs, a))) return r;
+        pass1_cells = true;
+      }
+    }
+    if (!pass1_cells) {
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
     if ((r = build_tile_list(ctx, nullptr, nullptr, ftx, fty, gtw, gth, ctx->d_tiles_tmp, ctx->d_counter))) return r;
     HIPCHK(hipMemcpyAsync(&n1, ctx->d_counter, sizeof(n1), hipMemcpyDeviceToHost, ctx->stream));
@@ -4135,6 +4147,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       const size_t lds = (size_t)ta.cap * 2 * sizeof(float);
       launch_fwd_unit<true>(ctx, a, ta, lds);
       KCHK("fwd_unit_kernel<GAUSS1>");
+    }
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
     if ((r = build_tile_list(ctx, nullptr, ctx->d_gauss_flag, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter))) return r;

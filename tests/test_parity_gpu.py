@@ -107,9 +107,10 @@ def test_thin_slices_take_the_exponential_per_tap(oracle_mod, thickness):
     assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
 
 
-@pytest.mark.parametrize("gauss_mode,fwd_mode", [(1, 1), (0, 1), (0, 0)])
+@pytest.mark.parametrize("gauss_mode,fwd_mode", [(1, 2), (1, 1), (0, 1), (0, 0)])
 def test_gaussian_reconstruction_parity(tiny, oracle_mod, gauss_mode, fwd_mode):
-    """gauss_mode 1 = unit-based pass 1 (dead-unit shortcut) + the LDS scatter, 0 = wave-per-pixel kernel with atomics."""
+    """gauss_mode 1 = unit-based pass 1 (dead-unit shortcut; over (cell, plane) items with fwd_mode 2, per slice tile with fwd_mode 1)
+    + the LDS scatter, 0 = wave-per-pixel kernel with atomics."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("gauss_mode", gauss_mode)
     rec.set_option("fwd_mode", fwd_mode)
@@ -789,3 +790,25 @@ def test_cell_gather_gives_the_tile_gathers_bits(tiny, workload):
     for a, b in zip(out[1], out[2]):
         assert np.array_equal(a, b)
     assert (out[2][1] > 0).sum() > 0.9 * ((P.slices != -1) & (rec.debug_get(E.BUF_PSF_SUMS) != 0)).sum()
+
+
+@pytest.mark.parametrize("workload", ["tiny", "P4"])
+def test_cell_pass_one_gives_the_tile_kernels_bits(tiny, workload):
+    """Pass 1 of the Gaussian reconstruction over the (cell, plane) items (fwd_cell_kernel<.., G1>, the default) against the same pass
+    per slice tile (fwd_unit_kernel<GAUSS1>, fwd_mode 1): every tap is added in double in the same order (x taps, the tree over a
+    unit's rows, a pixel's units 0 .. 15), so v_PSF_sums, the gate, the voxel-count flags -- and with them the reconstructed volume
+    and its weights -- are the same bits."""
+    from fetalreconstruction_amd import engine as E, workloads
+    P = tiny if workload == "tiny" else workloads.get("P4")
+    out = {}
+    for mode in (1, 2):
+        rec = _engine(P)
+        rec.set_option("fwd_mode", mode)
+        rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+        rec.InitializeEMValues()
+        n = rec.GaussianReconstruction()
+        out[mode] = (rec.debug_get(E.BUF_PSF_SUMS).copy(), rec.debug_get(E.BUF_VOXEL_COUNT).copy(), rec.getVolWeights().copy(), rec.syncCPU().copy(), n)
+        rec.close()
+    for a, b in zip(out[1][:4], out[2][:4]):
+        assert np.array_equal(a, b)
+    assert out[1][4] == out[2][4] and (out[2][0] != 0).sum() > 0.9 * (P.slices != -1).sum()
