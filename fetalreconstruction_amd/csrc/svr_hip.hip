@@ -2915,6 +2915,11 @@ struct svr_ctx {
   bool vol_clean[2] = {false, false};   // d_recon_volw / d_recon_new known to be zero outside the dilated mask (svr_slab.inc)
   CellState *cell = nullptr;      // the scatter's cell lists
   CellState *cell_g = nullptr;    // the gather's, when it works on another cell size (cell_prepare_gather)
+  int *d_cellc = nullptr;         // centre voxel + class of every active pixel (k_cell_centres), shared by the two
+  size_t cellc_cap = 0;
+  uint32_t cellc_n = 0;
+  bool cellc_valid = false;
+  int cellc_range[16] = {0};
   int cell_w = 0, cell_h = 0, cell_gw = 0, cell_gh = 0;   // 0: by the pixel density (cell_auto_size); cell_gw / cell_gh: the gather's own
   int cell_order = 1;       // > 0: items in order of falling work, in classes of 2^(cell_order - 1) pixels (0: (cell, plane) order)
   int cell_combine = 1;     // 1: the combine asks for a voxel's slabs in two batches (k_cell_combine_fast), 0: the general form (same bits)
@@ -3736,6 +3741,7 @@ void svr_destroy(svr_ctx *ctx) {
   reg_free(ctx->reg);
   cell_free(ctx->cell);
   cell_free(ctx->cell_g);
+  free_dev(ctx->d_cellc);
   slab_free(ctx->slab);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
