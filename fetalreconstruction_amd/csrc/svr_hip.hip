@@ -2135,20 +2135,31 @@ __global__ __launch_bounds__(64) void k_probe_pixel(PsfArgs a, uint32_t idx, flo
 // list compaction
 // ------------------------------------------------------------------------------------------
 // keep pixel i if slices[i] != -1 (and psf_sums[i] != 0 when psf_sums given)
-__global__ void k_compact(const float *slices, const float *psf_sums, uint32_t n, uint32_t *list,
-                          uint32_t *counter) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool keep = false;
-  if (i < n) {
-    keep = slices[i] != -1.0f;
-    if (keep && psf_sums) keep = psf_sums[i] != 0.0f;
+// (one atomic on the counter per workgroup of 1024 and chunk, not per wavefront: 524 k wavefronts queueing on one address took
+// 3.4 ms on S8's 33.5 M slice pixels, 0.34 ms on P4)
+__global__ __launch_bounds__(1024) void k_compact(const float *slices, const float *psf_sums, uint32_t n, uint32_t *list,
+                                                  uint32_t *counter) {
+  __shared__ uint32_t sh_cnt[16], sh_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t c0 = (uint64_t)blockIdx.x * 1024u; c0 < n; c0 += (uint64_t)gridDim.x * 1024u) {
+    const uint64_t i = c0 + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+      keep = slices[i] != -1.0f;
+      if (keep && psf_sums) keep = psf_sums[i] != 0.0f;
+    }
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) sh_cnt[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int w = 0; w < 16; ++w) { const uint32_t t = sh_cnt[w]; sh_cnt[w] = tot; tot += t; }
+      sh_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    if (keep) list[sh_base + sh_cnt[wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    __syncthreads();
   }
-  unsigned long long b = __ballot(keep);
-  int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == 0 && b) base = atomicAdd(counter, (uint32_t)__popcll(b));
-  base = __shfl(base, 0, 64);
-  if (keep) list[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2420,10 +2431,12 @@ __global__ __launch_bounds__(256) void k_slice_inside(const unsigned char *simin
 }
 // count_if(sliceVoxel_count > 0) RC.cu:2472-2474
 __global__ void k_count_positive(const int *v, size_t n, unsigned long long *out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool p = i < n && v[i] > 0;
-  unsigned long long b = __ballot(p);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+  // grid-stride: a thread counts its own, a wavefront adds up and touches the counter once (an atomic per 64 elements: 3.5 ms on S8)
+  unsigned int cnt = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) cnt += v[i] > 0 ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);
 }
 // RestoreSliceIntensitiesKernel RC.cu:3349-3367
 __global__ void k_restore(float *slices, const float *stack_factors, const int *stack_index, int n2,
@@ -2840,6 +2853,7 @@ struct svr_ctx {
   int gauss_mode = 1;                      // 1 = unit-based pass 1 (fwd_unit_kernel<GAUSS1>) + the LDS scatter, 0 = psf_kernel<MODE_GAUSS>
   uint32_t *d_tiles_fwd = nullptr;   // tiles of fwd_tw x fwd_th pixels for fwd_unit_kernel
   uint32_t n_tiles_fwd = 0;
+  bool tiles_back_valid = false, tiles_fwd_valid = false;   // the tile lists belong to the current PSF list (ensure_tiles_back / ensure_tiles_fwd)
   int fwd_tw = 4, fwd_th = 4, fwd_tiles_x = 0, fwd_tiles_y = 0;
   int fwd_unit_cap = 9300;  // box voxels (float2) of fwd_unit_kernel: 72.7 KiB + up to 6.6 KiB static = 64 LDS granules of 1280 B -> 2 workgroups of 8 waves per CU (9400 would push the GAUSS1 table instantiation to 65)
   int fwd_mode = 2;         // 2 = the gather over (cell, plane) items (fwd_cell_kernel, svr_cell.inc; SVR on the fly -- patch-based runs and the
@@ -3150,7 +3164,7 @@ int build_tile_list(svr_ctx *ctx, const float *psf_sums, const unsigned char *fl
 int build_list(svr_ctx *ctx, bool with_psf) {
   HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
   uint32_t *list = with_psf ? ctx->d_psf_list : ctx->d_active;
-  hipLaunchKernelGGL(k_compact, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_slices,
+  hipLaunchKernelGGL(k_compact, dim3(std::min(nblk(ctx->np, 1024), 4096u)), dim3(1024), 0, ctx->stream, ctx->d_slices,
                      with_psf ? ctx->d_psf_sums : (const float *)nullptr, (uint32_t)ctx->np, list, ctx->d_counter);
   KCHK("k_compact");
   uint32_t n = 0;
@@ -3159,27 +3173,44 @@ int build_list(svr_ctx *ctx, bool with_psf) {
   if (with_psf) {
     ctx->n_psf = n;
     ctx->psf_list_valid = true;
-    // tiles of TILE_W x TILE_H pixels that hold at least one pixel of the list
-    const uint32_t total = (uint32_t)ctx->tiles_x * ctx->tiles_y * ctx->ns;
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    { const int rr = build_tile_list(ctx, ctx->d_psf_sums, nullptr, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles, ctx->d_counter); if (rr) return rr; }
-    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_tiles = n;
-    // forward tiles
-    free_dev(ctx->d_tiles_fwd);
-    ctx->fwd_tiles_x = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw);
-    ctx->fwd_tiles_y = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
-    const uint32_t total_f = (uint32_t)ctx->fwd_tiles_x * ctx->fwd_tiles_y * ctx->ns;
-    HIPCHK(hipMalloc(&ctx->d_tiles_fwd, (size_t)total_f * sizeof(uint32_t)));
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    { const int rr = build_tile_list(ctx, ctx->d_psf_sums, nullptr, ctx->fwd_tiles_x, ctx->fwd_tiles_y, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_fwd, ctx->d_counter); if (rr) return rr; }
-    HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n_tiles_fwd = n;
+    // the tile lists of the tile kernels (the table's gather, the fallback modes) are built when one of them asks (round 4: the default
+    // path works on (cell, plane) items and used to pay for both lists, two more waits and an allocation per slice geometry)
+    ctx->tiles_back_valid = ctx->tiles_fwd_valid = false;
   } else {
     ctx->n_active = n;
   }
+  return SVR_OK;
+}
+int ensure_psf_list(svr_ctx *ctx);
+// tiles of tile_w x tile_h pixels that hold at least one pixel of the PSF list (the tiled scatters)
+int ensure_tiles_back(svr_ctx *ctx) {
+  int r = ensure_psf_list(ctx);
+  if (r || ctx->tiles_back_valid) return r;
+  uint32_t n = 0;
+  HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+  if ((r = build_tile_list(ctx, ctx->d_psf_sums, nullptr, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles, ctx->d_counter))) return r;
+  HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_tiles = n;
+  ctx->tiles_back_valid = true;
+  return SVR_OK;
+}
+// ... of fwd_tw x fwd_th pixels (fwd_unit_kernel)
+int ensure_tiles_fwd(svr_ctx *ctx) {
+  int r = ensure_psf_list(ctx);
+  if (r || ctx->tiles_fwd_valid) return r;
+  uint32_t n = 0;
+  free_dev(ctx->d_tiles_fwd);
+  ctx->fwd_tiles_x = (int)((ctx->sx + ctx->fwd_tw - 1) / ctx->fwd_tw);
+  ctx->fwd_tiles_y = (int)((ctx->sy + ctx->fwd_th - 1) / ctx->fwd_th);
+  const uint32_t total_f = (uint32_t)ctx->fwd_tiles_x * ctx->fwd_tiles_y * ctx->ns;
+  HIPCHK(hipMalloc(&ctx->d_tiles_fwd, (size_t)total_f * sizeof(uint32_t)));
+  HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+  if ((r = build_tile_list(ctx, ctx->d_psf_sums, nullptr, ctx->fwd_tiles_x, ctx->fwd_tiles_y, ctx->fwd_tw, ctx->fwd_th, ctx->d_tiles_fwd, ctx->d_counter))) return r;
+  HIPCHK(hipMemcpyAsync(&n, ctx->d_counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_tiles_fwd = n;
+  ctx->tiles_fwd_valid = true;
   return SVR_OK;
 }
 
@@ -4155,10 +4186,6 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       KCHK("fwd_unit_kernel<GAUSS1>");
     }
     }
-    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    if ((r = build_tile_list(ctx, nullptr, ctx->d_gauss_flag, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter))) return r;
-    HIPCHK(hipMemcpyAsync(&n2, ctx->d_counter, sizeof(n2), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     a.flag = ctx->d_gauss_flag;
     a.addon = ctx->recon(); a.cmap = ctx->volw();       // scatter targets of pass 2 (RC.cu:279-282)
     ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.tw = ctx->tile_w; ta.th = ctx->tile_h; ta.dbg = 0;
@@ -4168,7 +4195,14 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       cells = ctx->cell->usable;
     }
     if (cells) r = launch_cell_scatter(ctx, a, 1, ctx->recon(), ctx->volw());
-    else r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, std::max(1, back_mode_eff(ctx))), a, ta, ctx->d_tiles_tmp, n2, MODE_GAUSS2);
+    else {
+      // the tiles of the pixels that passed the gate (the tiled scatters only)
+      HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+      if ((r = build_tile_list(ctx, nullptr, ctx->d_gauss_flag, ctx->tiles_x, ctx->tiles_y, ctx->tile_w, ctx->tile_h, ctx->d_tiles_tmp, ctx->d_counter))) return r;
+      HIPCHK(hipMemcpyAsync(&n2, ctx->d_counter, sizeof(n2), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, std::max(1, back_mode_eff(ctx))), a, ta, ctx->d_tiles_tmp, n2, MODE_GAUSS2);
+    }
     if (r) return r;
   } else if (a.n && ctx->pvr) {
     { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
@@ -4198,7 +4232,7 @@ int svr_gaussian_reconstruction_finish(svr_ctx *ctx, int *voxel_num) {
   unsigned long long cnt = 0;
   unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(ctx->d_out);
   HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(cnt), ctx->stream));
-  hipLaunchKernelGGL(k_count_positive, dim3(nblk(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_voxcount, ctx->np, d_cnt);
+  hipLaunchKernelGGL(k_count_positive, dim3(std::min(nblk(ctx->np), 2048u)), dim3(256), 0, ctx->stream, ctx->d_voxcount, ctx->np, d_cnt);
   KCHK("k_count_positive");
   HIPCHK(hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -4275,6 +4309,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       const int rr = launch_cell_gather(ctx, *gcs, a);
       if (rr) return rr;
     } else if (a.n && tiled_) {
+      { const int rr = ensure_tiles_fwd(ctx); if (rr) return rr; }
       TileArgs ta;
       ta.tiles = ctx->d_tiles_fwd; ta.ntiles = ctx->n_tiles_fwd; ta.tiles_x = ctx->fwd_tiles_x; ta.tiles_y = ctx->fwd_tiles_y;
       ta.cap = std::min(ctx->fwd_unit_cap, ctx->tile_cap); ta.dbg = ctx->dbg_back; ta.tw = ctx->fwd_tw; ta.th = ctx->fwd_th;
@@ -4322,6 +4357,8 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       if (r) return r;
       a.list = ctx->d_psf_list; a.n = ctx->n_psf;
       TileSample sample;
+      if (!r) r = ensure_tiles_fwd(ctx);
+      if (r) return r;
       r = sample.begin(ctx, ctx->d_tiles_fwd, ctx->n_tiles_fwd);
       float ms = 0.0f;
       for (int rep = 0; rep < 2 && !r; ++rep) {          // the second run is the one that counts (a new tile list costs its first launch)
@@ -4655,6 +4692,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
       if (!r) r = svr_set_option(ctx, "tile_h", cand[c][1]);
       if (!r) r = ensure_psf_list(ctx);                  // the list of this shape, so that the trials below find it valid
       TileSample sample;
+      if (!r) r = ensure_tiles_back(ctx);
       if (!r) r = sample.begin(ctx, ctx->d_tiles, ctx->n_tiles);
       float shape_best = 3.0e38f;
       warm = false;
@@ -4705,7 +4743,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
       cells = ctx->cell->usable;
     }
     if (cells) r = launch_cell_scatter(ctx, a, 0, ctx->addon(), ctx->cmap());
-    else r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, back_mode_eff(ctx)), a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
+    else if (!(r = ensure_tiles_back(ctx))) r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, back_mode_eff(ctx)), a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
     if (r) return r;
   } else if (a.n && ctx->pvr) {
     { const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t) {
@@ -5332,8 +5370,8 @@ int svr_timer_add(svr_ctx *ctx, int which, double ms) {
 int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
   SVR_ENTER(ctx);
   if (!ctx || !out5) return SVR_E_ARG;
-  if (ctx->have_slices && !ctx->psf_list_valid) {
-    int r = build_list(ctx, true);
+  if (ctx->have_slices) {
+    int r = ensure_tiles_back(ctx);
     if (r) return r;
   }
   out5[0] = ctx->np; out5[1] = ctx->n_active; out5[2] = ctx->n_psf; out5[3] = ctx->nv; out5[4] = ctx->ns;
