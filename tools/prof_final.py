@@ -91,7 +91,7 @@ def main():
         nsup, isp = ("12", "true") if wl.startswith("PVR") else ("16", "false")
         e = {}
         e["back"] = collect(v, ("back_cell_kernel<%s, %s, false>" % (nsup, isp), "k_cell_combine", "k_cell_factors")) or collect(v, ("back_wave_kernel<%s, %s, false>" % (nsup, isp),))
-        e["forward"] = collect(v, ("fwd_cell_kernel<%s, %s, false>" % (nsup, isp), "k_cell_gather_finish", "k_cell_gfactors")) or collect(v, ("fwd_unit_kernel<false, %s, %s, false>" % (nsup, isp),))
+        e["forward"] = collect(v, ("fwd_cell_kernel<%s, %s, false, false>" % (nsup, isp), "k_cell_gather_finish", "k_cell_gfactors")) or collect(v, ("fwd_unit_kernel<false, %s, %s, false>" % (nsup, isp),))
         e["update"] = collect(v, ("k_regul_fused",))
         traffic[wl] = {k: x for k, x in e.items() if x}
     vt = pmc("P4", "p4_table", ("coeff_table=1",))           # the COEFF instantiations streaming the coefficient table
@@ -140,7 +140,7 @@ def main():
             lines.append("%7s %14s %12s %7s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
             lines += ["%7d %14.1f %12.1f %7.2f  %s" % (k, t, a, pc, short(n)) for n, k, t, a, pc in rows[:24]]
             # the on-the-fly instantiations; the bench times its K steps on the fly first, then the same K with the table
-            for pat in ("back_cell_kernel<16, false, false>", "fwd_cell_kernel<16, false, false>"):
+            for pat in ("back_cell_kernel<16, false, false>", "fwd_cell_kernel<16, false, false, false>"):
                 dd = [r[0] / 1e3 for r in c.execute("select (end - start) from kernels where name like ? order by start", ("%" + pat + "%",)).fetchall()]
                 if dd and jt:
                     k = jt["steps"]
