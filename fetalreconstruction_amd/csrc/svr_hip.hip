@@ -407,9 +407,31 @@ __device__ __forceinline__ void eval_pairs_xyz(const RowConst S, const f2 xs[H],
 // exactly +0 (an underflowed Gaussian factor, sin(pi r) at an integer r) can still be told from a skipped one by its bits
 // HP: pairs evaluated side by side (0 = the default below); the cell kernels ask for a whole row at once (no pixel tables, no
 // tile state: they have the registers, and the longer independent stages are worth 3-4 % of their time)
+// (the two halves of eval_row_t: the values of a row's taps, and the epsilon-walk over them -- a kernel that has loads to issue in
+// between calls them one after the other)
+template <int N, bool PVR, int HP = 0>
+__device__ __forceinline__ void eval_row_vals(const RowConst S, float bx, float by, float bz, float fy, float fz, float val[N]);
+template <int N, bool PVR, bool ZERO>
+__device__ __forceinline__ void eps_walk(const float val[N], float out[N]) {
+  float old = FLT_MAX;
+#pragma unroll
+  for (int x = 0; x < N; ++x) {
+    const float v = val[x];
+    // SVR: |d| < 0.00001 (double) == |d| <= 0.00001f; PVR: |d| < 0.00001f.  NaN compares false -> processed
+    const bool skip = PVR ? (__builtin_fabsf(old - v) < PSF_EPS_F) : (__builtin_fabsf(old - v) <= PSF_EPS_F);
+    out[x] = skip ? (ZERO ? -0.0f : -1.0f) : v;
+    old = skip ? old : v;
+  }
+}
 template <int N, bool PVR, bool ZERO = false, int HP = 0>
 __device__ __forceinline__ void eval_row_t(const RowConst S, float bx, float by, float bz, float fy,
                                            float fz, float out[N]) {
+  float val[N];
+  eval_row_vals<N, PVR, HP>(S, bx, by, bz, fy, fz, val);
+  eps_walk<N, PVR, ZERO>(val, out);
+}
+template <int N, bool PVR, int HP>
+__device__ __forceinline__ void eval_row_vals(const RowConst S, float bx, float by, float bz, float fy, float fz, float val[N]) {
   // Taps are evaluated two per lane in float2 registers: every fma / mul / add stage of eval_pairs_xyz
   // compiles to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (half the issue slots for the same cycles);
   // sqrt, rcp, rint and the selects stay per component.  Pair j holds the taps at lattice offsets -j and 1 + j
@@ -425,7 +447,6 @@ __device__ __forceinline__ void eval_row_t(const RowConst S, float bx, float by,
   const float rowy = __builtin_fmaf(S.Lp[4], fy, __builtin_fmaf(S.Lp[5], fz, by));
   const float rowz = __builtin_fmaf(S.Lp[7], fy, __builtin_fmaf(S.Lp[8], fz, bz));
   GaussStep st = gauss_start(S, rowz);
-  float val[N];
 #pragma unroll
   for (int c0 = 0; c0 < NP; c0 += H) {
     f2 xs[H], ys[H], v2[H], g[H];
@@ -443,15 +464,6 @@ __device__ __forceinline__ void eval_row_t(const RowConst S, float bx, float by,
       val[CENTRE - (c0 + i)] = v.x;
       val[CENTRE + 1 + c0 + i] = v.y;
     }
-  }
-  float old = FLT_MAX;
-#pragma unroll
-  for (int x = 0; x < N; ++x) {
-    const float v = val[x];
-    // SVR: |d| < 0.00001 (double) == |d| <= 0.00001f; PVR: |d| < 0.00001f.  NaN compares false -> processed
-    const bool skip = PVR ? (__builtin_fabsf(old - v) < PSF_EPS_F) : (__builtin_fabsf(old - v) <= PSF_EPS_F);
-    out[x] = skip ? (ZERO ? -0.0f : -1.0f) : v;
-    old = skip ? old : v;
   }
 }
 // Can every tap of the (fy, fz) row be proven to lie below the epsilon of the skip test?  Then the
