@@ -73,10 +73,13 @@ def _oracle_pass(prob, oracle_mod, mode, V, weights, simslices, threads):
     return out
 
 
+# SVR_FULL_WORKLOADS=P4,S8: the same comparison on other bench workloads (S8: 10.6 M active pixels, 20 M voxels -- about ten minutes per
+# mode on 16 host threads: a one-off run, recorded in DESIGN 6, not part of the default suite)
+@pytest.mark.parametrize("workload", __import__("os").environ.get("SVR_FULL_WORKLOADS", "P4").split(","))
 @pytest.mark.parametrize("mode_name", ["CANON", "LITERAL"])
-def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, oracle_mod, capsys):
+def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, workload, oracle_mod, capsys):
     from fetalreconstruction_amd import engine as E
-    P = workloads.get("P4")
+    P = workloads.get(workload)
     ns, sy, sx = P.slices.shape
     rng = np.random.default_rng(17)
     V = rng.uniform(0.5, 1.5, P.nvox).astype(np.float32)
@@ -111,7 +114,7 @@ def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, oracle_mod, c
     sym = {k: (int(((g[k] != 0) != (o[k] != 0)).sum()), int((o[k] != 0).sum())) for k in ("psf_sums", "voxcount", "inside", "volw", "cmap")}
     errs = {k: rel_err(g[k], o[k]) for k in ("psf_sums", "volw", "recon", "sim", "simw", "addon", "cmap")}
     with capsys.disabled():
-        print(f"\n[P4 whole, HIP vs {mode_name} oracle on {threads} threads] {va} PSF pixels of {int((P.slices != -1).sum())}; hit-set differences "
+        print(f"\n[{workload} whole, HIP vs {mode_name} oracle on {threads} threads] {va} PSF pixels of {int((P.slices != -1).sum())}; hit-set differences "
               + ", ".join(f"{k}: {a}/{b}" for k, (a, b) in sym.items()) + "; max |diff| / max |ref| "
               + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
     assert va > 1_000_000
@@ -134,7 +137,7 @@ def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, oracle_mod, c
             nz = ref > 0
             stats[k] = (float((d[nz] > TOL_LITERAL * ref.max()).mean()), float(np.sqrt((d ** 2).sum() / max((ref ** 2).sum(), 1e-300))), errs[k])
         with capsys.disabled():
-            print("[P4 whole, LITERAL] share of elements beyond %.0e of the maximum / relative L2 / worst element: " % TOL_LITERAL
+            print(f"[{workload} whole, LITERAL] share of elements beyond %.0e of the maximum / relative L2 / worst element: " % TOL_LITERAL
                   + ", ".join(f"{k} {a:.1e} / {b:.1e} / {c:.1e}" for k, (a, b, c) in stats.items()))
         for k, (a, b) in sym.items():
             assert a <= max(2, b // 2000), (k, a, b)                         # a flipped tap adds or drops a voxel at the rim of a footprint
