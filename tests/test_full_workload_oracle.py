@@ -7,7 +7,12 @@ mask frame) through the oracle, dealt over the host threads, against the HIP pat
     values within TOL_LITERAL -- asserted at BASELINE size, not only on `tiny`.
 
 The slices are dealt to one oracle instance per host thread (its own partial volume, like slice-sharded ranks; the C calls
-release the GIL); partial volumes are added in double.  About a minute per mode on the gpurun box's 16 threads."""
+release the GIL); partial volumes are added in double.  About a minute per mode on the gpurun box's 16 threads.
+
+The same for PVR4 (BASELINE configs[2]: the patch-to-volume kernels, support 12, 5.27 M patch pixels) by default, and for the 8-stack
+workloads on request (SVR_FULL_WORKLOADS).  Recorded one-off runs on the MI355X box (round 4, final kernels): S8 CANON -- all 10 607 524
+PSF pixels, every hit set identical (0 differences of 10.6 M pixels / 9.93 M voxels), v_PSF_sums identical, sums within 6.3e-7 of the
+buffer's maximum; S8 LITERAL -- every hit set identical, share beyond 3e-3 max <= 4.0e-4, relative L2 <= 2.6e-3."""
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -38,7 +43,7 @@ def _deal(prob, parts):
     return [np.array(sorted(b)) for b in bins if b]
 
 
-def _oracle_pass(prob, oracle_mod, mode, V, weights, simslices, threads):
+def _oracle_pass(prob, oracle_mod, mode, V, weights, simslices, threads, pvr=False):
     """Gaussian reconstruction, forward projection of V, scatter with the given per-pixel state: every slice, one oracle
     instance per thread -> full-size slice-grid arrays and summed volumes"""
     parts = _deal(prob, threads)
@@ -50,7 +55,8 @@ def _oracle_pass(prob, oracle_mod, mode, V, weights, simslices, threads):
 
     def run(idx):
         sub = phantom.sub_problem(prob, 0, 0, select=idx)
-        o = oracle_mod.OracleReconstruction(sub, mode)
+        spx = getattr(prob, "spx_masks", None)
+        o = oracle_mod.OracleReconstruction(sub, mode, pvr=pvr, spx_masks=None if spx is None else np.ascontiguousarray(spx[idx]))
         ones = np.ones(sub.ns, np.float32)
         o.UpdateScaleVector(ones, ones)
         o.InitializeEMValues()
@@ -73,9 +79,10 @@ def _oracle_pass(prob, oracle_mod, mode, V, weights, simslices, threads):
     return out
 
 
-# SVR_FULL_WORKLOADS=P4,S8: the same comparison on other bench workloads (S8: 10.6 M active pixels, 20 M voxels -- about ten minutes per
-# mode on 16 host threads: a one-off run, recorded in DESIGN 6, not part of the default suite)
-@pytest.mark.parametrize("workload", __import__("os").environ.get("SVR_FULL_WORKLOADS", "P4").split(","))
+# By default P4 (BASELINE configs[1]) and PVR4 (configs[2]: 5 149 patches of 32 x 32, 5.27 M pixels, support 12: a minute per mode).
+# SVR_FULL_WORKLOADS=S8 or PVR8spx: the same comparison on the 8-stack workloads (S8: 10.6 M active pixels, 20 M voxels -- 4.4 minutes per
+# mode on 16 host threads: one-off runs, recorded in DESIGN 6, not part of the default suite)
+@pytest.mark.parametrize("workload", __import__("os").environ.get("SVR_FULL_WORKLOADS", "P4,PVR4").split(","))
 @pytest.mark.parametrize("mode_name", ["CANON", "LITERAL"])
 def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, workload, oracle_mod, capsys):
     from fetalreconstruction_amd import engine as E
@@ -86,8 +93,15 @@ def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, workload, ora
     weights = np.where(P.slices != -1, rng.uniform(0.2, 1.0, P.slices.shape), 0).astype(np.float32)
     simslices = np.where(P.slices > 0, P.slices * rng.uniform(0.8, 1.2, P.slices.shape), 0).astype(np.float32)
 
+    pvr = workload.startswith("PVR")                       # (patches as the units: support 12, the patch-to-volume constants)
     rec = E.Reconstruction(0)
-    E.sync_gpu(rec, P)
+    if pvr:
+        rec.set_option("pvr", 1)
+        E.sync_gpu(rec, P, quality_factor=1.0)
+        if getattr(P, "spx_masks", None) is not None:
+            rec.set_spx_masks(P.spx_masks)
+    else:
+        E.sync_gpu(rec, P)
     ones = np.ones(P.ns, np.float32)
     rec.UpdateScaleVector(ones, ones)
     rec.InitializeEMValues()
@@ -108,7 +122,7 @@ def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, workload, ora
     rec.close()
 
     mode = getattr(oracle_mod, mode_name)
-    o = _oracle_pass(P, oracle_mod, mode, V, weights, simslices, threads)
+    o = _oracle_pass(P, oracle_mod, mode, V, weights, simslices, threads, pvr)
     o["recon"] = np.where(o["volw"] != 0, o["recon"] / np.where(o["volw"] != 0, o["volw"], 1), o["recon"])      # equalizeVol RC.cu:2312-2327
     va = int(((P.slices != -1) & (o["psf_sums"] != 0)).sum())
     sym = {k: (int(((g[k] != 0) != (o[k] != 0)).sum()), int((o[k] != 0).sum())) for k in ("psf_sums", "voxcount", "inside", "volw", "cmap")}
