@@ -12,7 +12,8 @@ release the GIL); partial volumes are added in double.  About a minute per mode 
 The same for PVR4 (BASELINE configs[2]: the patch-to-volume kernels, support 12, 5.27 M patch pixels) by default, and for the 8-stack
 workloads on request (SVR_FULL_WORKLOADS).  Recorded one-off runs on the MI355X box (round 4, final kernels): S8 CANON -- all 10 607 524
 PSF pixels, every hit set identical (0 differences of 10.6 M pixels / 9.93 M voxels), v_PSF_sums identical, sums within 6.3e-7 of the
-buffer's maximum; S8 LITERAL -- every hit set identical, share beyond 3e-3 max <= 4.0e-4, relative L2 <= 2.6e-3."""
+buffer's maximum; S8 LITERAL -- every hit set identical, share beyond 3e-3 max <= 4.0e-4, relative L2 <= 2.6e-3; PVR8spx CANON -- 12 237 835 PSF
+pixels, every hit set identical (31.6 M voxels), v_PSF_sums identical, sums within 3.3e-6."""
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
