@@ -158,3 +158,113 @@ def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, workload, ora
             assert a <= max(2, b // 2000), (k, a, b)                         # a flipped tap adds or drops a voxel at the rim of a footprint
         for k, (share, l2, worst) in stats.items():
             assert share < MAX_SHARE_BEYOND_TOL and l2 < MAX_REL_L2 and worst < MAX_WORST, (k, share, l2, worst)
+
+
+# ---- a whole outer iteration at BASELINE size -----------------------------------------------------------------------------------
+class _ThreadGroup:
+    """ranks = threads of this process (the oracle engines release the GIL in their C calls): what the launcher's communicator is to
+    the slice-sharded host loop (tests/twins/reconstruction.py), with sums taken in rank order"""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.slots = [None] * world
+        self.barrier = threading.Barrier(world)
+
+    def gather(self, rank, a):
+        self.slots[rank] = a
+        self.barrier.wait(timeout=900)                         # (a rank that failed breaks the barrier for the others instead of hanging them)
+        out = list(self.slots)
+        self.barrier.wait(timeout=900)
+        return out
+
+
+class _ThreadComm:
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world = group, rank, group.world
+
+    def _all(self, a):
+        return self.g.gather(self.rank, np.array(a, np.float64))
+
+    def allreduce_sum(self, a):
+        parts = self._all(a)
+        out = parts[0].copy()
+        for p in parts[1:]:
+            out = out + p
+        return out
+
+    def allreduce_min(self, a):
+        return np.min(np.stack(self._all(a)), axis=0)
+
+    def allreduce_max(self, a):
+        return np.max(np.stack(self._all(a)), axis=0)
+
+    def allgather_slices(self, local, counts):
+        parts = self.g.gather(self.rank, np.asarray(local, np.float32).copy())
+        return np.concatenate([p[:c] for p, c in zip(parts, counts)])
+
+    def allreduce_volume_pair(self, engine, which):
+        buf = engine.recon_volw if which == 0 else engine.addon_cmap
+        parts = self.g.gather(self.rank, buf.astype(np.float64))
+        tot = parts[0].copy()
+        for p in parts[1:]:
+            tot += p
+        buf[...] = tot.astype(buf.dtype)
+
+
+@pytest.mark.timeout(1800)
+def test_a_whole_outer_iteration_of_p4_tracks_the_oracle(oracle_mod, capsys):
+    """BASELINE configs[1] end to end: InitializeEMValues, Gaussian reconstruction, forward projection, robust-statistics
+    initialisation, E-step and TWO super-resolution iterations (Scale, back-projection, the volume update, forward projection,
+    M-step, E-step) -- the C++ host on the HIP engine against the Python mirror of the host loop on the oracle (CANON), the oracle's
+    slices sharded over the host threads as ranks of an in-process group.  Each side evolves its own state; the tolerances are those of
+    the tiny problem's `test_full_iteration_tracks_the_oracle`."""
+    from concurrent.futures import ThreadPoolExecutor
+    from fetalreconstruction_amd import engine as E, host
+    from fetalreconstruction_amd.sharding import shard_slices
+    from tests.twins.reconstruction import irtkReconstruction
+    P = workloads.get("P4")
+    rec = E.Reconstruction(0)
+    E.sync_gpu(rec, P)
+    dg = host.irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
+    dg.SetSmoothingParameters(150, 0.02)
+    dg.reconstruct_iteration(2)
+    sg = dg.state()
+    vol_g = rec.syncCPU().copy()
+    threads = max(2, min(int(E.load_library().svr_host_threads()), 16))
+    rec.close()
+
+    act = (P.slices != -1).reshape(P.ns, -1).sum(1)
+    ranges = shard_slices(act, threads)
+    group = _ThreadGroup(threads)
+
+    def rank_main(r):
+        lo, hi = ranges[r]
+        eng = oracle_mod.OracleReconstruction(phantom.sub_problem(P, lo, hi), oracle_mod.CANON)
+        drv = irtkReconstruction(eng, P.ns, (lo, hi), _ThreadComm(group, r), P.max_intensity, P.min_intensity)
+        drv.SetSmoothingParameters(150, 0.02)
+        drv.reconstruct_iteration(2)
+        return eng.recon.copy(), np.asarray(drv._scale_gpu).copy(), np.asarray(drv._slice_weight_gpu).copy(), (drv._sigma_gpu, drv._mix_gpu, drv._m_gpu)
+
+    def guarded(r):
+        try:
+            return rank_main(r)
+        except BaseException:
+            group.barrier.abort()
+            raise
+
+    with ThreadPoolExecutor(threads) as pool:
+        outs = list(pool.map(guarded, range(threads)))
+    vol_o, scale_o, sw_o, em_o = outs[0]
+    for o in outs[1:]:
+        assert np.array_equal(o[0], vol_o)                                 # every rank ends with the same volume
+    err = rel_err(vol_g, vol_o)
+    with capsys.disabled():
+        print(f"\n[P4, one outer iteration with 2 SR iterations, HIP (C++ host) vs oracle on {threads} thread-ranks] volume max |diff| / max |ref| {err:.1e}; "
+              f"sigma {sg['sigma']:.6g} / {em_o[0]:.6g}, mix {sg['mix']:.6g} / {em_o[1]:.6g}, m {sg['m']:.6g} / {em_o[2]:.6g}; "
+              f"slices at weight < 0.5: {int((np.asarray(sg['slice_weight']) < 0.5).sum())} / {int((sw_o < 0.5).sum())}")
+    assert np.allclose(sg["scale"], scale_o, rtol=1e-4)
+    assert np.allclose(sg["slice_weight"], sw_o, atol=1e-3)
+    assert np.allclose([sg["sigma"], sg["mix"], sg["m"]], em_o, rtol=1e-4)
+    assert np.array_equal(vol_g == -1, vol_o == -1)
+    assert err < 1e-4
