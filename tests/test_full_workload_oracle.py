@@ -268,3 +268,65 @@ def test_a_whole_outer_iteration_of_p4_tracks_the_oracle(oracle_mod, capsys):
     assert np.allclose([sg["sigma"], sg["mix"], sg["m"]], em_o, rtol=1e-4)
     assert np.array_equal(vol_g == -1, vol_o == -1)
     assert err < 1e-4
+
+
+@pytest.mark.timeout(1800)
+def test_a_whole_outer_iteration_of_pvr4_tracks_the_oracle(oracle_mod, capsys):
+    """BASELINE configs[2] end to end, as above with patches as the units: the C++ patch-based host (csrc/pvr_host.cpp) on the HIP engine
+    against the Python mirror (tests/twins/pvr.py) on the oracle, 5 149 patches sharded over the host threads; Gaussian reconstruction,
+    robust statistics and two super-resolution iterations.  Tolerances of `test_pvr_loop_parity` (the small phantom), except that a few in a
+    thousand of the patches' scale factors may differ by up to 2e-3 (observed: 2 of 5 149 at 3e-4 and 5e-4; volume 7.4e-6)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from fetalreconstruction_amd import engine as E, host
+    from fetalreconstruction_amd.sharding import shard_slices
+    from tests.twins import pvr
+    P = workloads.get("PVR4")
+    rec = E.Reconstruction(0)
+    rec.set_option("pvr", 1)
+    E.sync_gpu(rec, P, quality_factor=1.0)
+    dg = host.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    dg.reconstruct_iteration(2)
+    sg = dg.state()
+    vol_g = rec.syncCPU().copy()
+    threads = max(2, min(int(E.load_library().svr_host_threads()), 16))
+    rec.close()
+
+    ranges = shard_slices((P.slices > 0).reshape(P.ns, -1).sum(1), threads)
+    group = _ThreadGroup(threads)
+
+    def rank_main(r):
+        lo, hi = ranges[r]
+        eng = oracle_mod.OracleReconstruction(phantom.sub_problem(P, lo, hi), oracle_mod.CANON, pvr=True)
+        drv = pvr.irtkPatchBasedReconstruction(eng, P.patches_per_stack, P.min_intensity, P.max_intensity, patch_range=(lo, hi), comm=_ThreadComm(group, r))
+        drv.reconstruct_iteration(2)
+        return eng.recon.copy(), np.asarray(drv.scale).copy(), np.asarray(drv.patch_weight).copy(), (drv.m_sigma_gpu, drv.m_mix_gpu, drv.m_m_gpu)
+
+    def guarded(r):
+        try:
+            return rank_main(r)
+        except BaseException:
+            group.barrier.abort()
+            raise
+
+    with ThreadPoolExecutor(threads) as pool:
+        outs = list(pool.map(guarded, range(threads)))
+    vol_o, scale_o, pw_o, em_o = outs[0]
+    for o in outs[1:]:
+        assert np.array_equal(o[0], vol_o)
+    err = rel_err(vol_g, vol_o)
+    em_g = [sg["m_sigma_gpu"], sg["m_mix_gpu"], sg["m_m_gpu"]]
+    with capsys.disabled():
+        print(f"\n[PVR4, one outer iteration with 2 SR iterations, HIP (C++ host) vs oracle on {threads} thread-ranks] volume max |diff| / max |ref| {err:.1e}; "
+              f"sigma {em_g[0]:.6g} / {em_o[0]:.6g}, mix {em_g[1]:.6g} / {em_o[1]:.6g}, m {em_g[2]:.6g} / {em_o[2]:.6g}")
+    bad = ~np.isclose(sg["scale"], scale_o, rtol=1e-4)
+    with capsys.disabled():
+        if bad.any():
+            i = np.flatnonzero(bad)
+            print(f"  scale differs at {len(i)} of {len(bad)} patches, e.g. {i[:6]}: HIP {np.asarray(sg['scale'])[i[:6]]} oracle {scale_o[i[:6]]}; "
+                  f"weights there HIP {np.asarray(sg['patch_weight'])[i[:6]]} oracle {pw_o[i[:6]]}; data pixels {(P.slices > 0).reshape(P.ns, -1).sum(1)[i[:6]]}")
+    assert np.allclose(em_g, em_o, rtol=1e-4)
+    # each side evolves its own state: of 5 149 scale factors two sit at 3e-4 / 5e-4 on the MI355X box (patches whose pixels lie where the
+    # E-step's weights are steep), the rest within 1e-4
+    assert bad.mean() < 2e-3 and np.allclose(sg["scale"], scale_o, rtol=2e-3)
+    assert np.allclose(sg["patch_weight"], pw_o, atol=1e-3)
+    assert err < 1e-4
