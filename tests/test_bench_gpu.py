@@ -11,6 +11,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _last_json(text):
     for line in reversed(text.strip().splitlines()):
         if line.startswith("{"):
@@ -35,7 +44,7 @@ def test_bench_line_and_two_ranks_on_one_gpu():
     assert t["fits"] and t["value"] > 0 and t["ms_per_step"] > 0 and t["roofline"]["bound"] == "hbm" and t["table_bytes_rank0"] > 0
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29517", "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",
+                          "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",
                           "--comm", "torch", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True,
                          timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-3000:]
