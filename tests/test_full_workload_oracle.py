@@ -225,7 +225,8 @@ def test_a_whole_outer_iteration_of_p4_tracks_the_oracle(oracle_mod, capsys):
     from fetalreconstruction_amd import engine as E, host
     from fetalreconstruction_amd.sharding import shard_slices
     from tests.twins.reconstruction import irtkReconstruction
-    P = workloads.get("P4")
+    wl = __import__("os").environ.get("SVR_OUTER_WORKLOAD", "P4")      # (S8: a one-off run of ten minutes, recorded in DESIGN 6)
+    P = workloads.get(wl)
     rec = E.Reconstruction(0)
     E.sync_gpu(rec, P)
     dg = host.irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
@@ -262,7 +263,7 @@ def test_a_whole_outer_iteration_of_p4_tracks_the_oracle(oracle_mod, capsys):
         assert np.array_equal(o[0], vol_o)                                 # every rank ends with the same volume
     err = rel_err(vol_g, vol_o)
     with capsys.disabled():
-        print(f"\n[P4, one outer iteration with 2 SR iterations, HIP (C++ host) vs oracle on {threads} thread-ranks] volume max |diff| / max |ref| {err:.1e}; "
+        print(f"\n[{wl}, one outer iteration with 2 SR iterations, HIP (C++ host) vs oracle on {threads} thread-ranks] volume max |diff| / max |ref| {err:.1e}; "
               f"sigma {sg['sigma']:.6g} / {em_o[0]:.6g}, mix {sg['mix']:.6g} / {em_o[1]:.6g}, m {sg['m']:.6g} / {em_o[2]:.6g}; "
               f"slices at weight < 0.5: {int((np.asarray(sg['slice_weight']) < 0.5).sum())} / {int((sw_o < 0.5).sum())}")
     assert np.allclose(sg["scale"], scale_o, rtol=1e-4)
