@@ -2912,6 +2912,8 @@ struct svr_ctx {
 
   // reductions
   double *d_partial = nullptr, *d_per_slice = nullptr, *d_out = nullptr;
+  double *d_em_all = nullptr;       // [world][8]: every rank's M-step sums (svr_mstep_partial / svr_mstep_estep_ranks)
+  size_t em_all_cap = 0;
   int chunks = 0;
 
   // bias correction (allocated only when bias correction is enabled)
@@ -3789,6 +3791,7 @@ void svr_destroy(svr_ctx *ctx) {
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
+  free_dev(ctx->d_em_all);
   timers_resolve(ctx);
   if (ctx->ev_open) (void)hipEventDestroy(ctx->ev_open);
   for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
@@ -4506,6 +4509,19 @@ __global__ void k_mstep_scalars(const double *s5, int iter, float step, int pvr,
   mstep_scalars(s5, iter, step, pvr, sigma, mix, m);
   em[0] = sigma; em[1] = mix; em[2] = m;
 }
+// ... of a sharded run: all[world][8] = every rank's five sums (an all-gather on the device), added up in rank order exactly like
+// the hosts do after their exchange (svr::irtkReconstruction::mstep_exchange) -- the same bits on every rank
+__global__ void k_mstep_scalars_ranks(const double *all, int world, int iter, float step, int pvr, float sigma, float mix, float *em) {
+  double s5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int r = 0; r < world; ++r) {
+    for (int k = 0; k < 3; ++k) s5[k] += all[8 * r + k];
+    s5[3] = r ? fmin(s5[3], all[8 * r + 3]) : all[3];
+    s5[4] = r ? fmax(s5[4], all[8 * r + 4]) : all[4];
+  }
+  float m = 0.0f;
+  mstep_scalars(s5, iter, step, pvr, sigma, mix, m);
+  em[0] = sigma; em[1] = mix; em[2] = m;
+}
 }  // namespace
 
 int svr_estep(svr_ctx *ctx, float m, float sigma, float mix, float *slice_potential) {
@@ -4568,6 +4584,44 @@ int svr_mstep_estep(svr_ctx *ctx, int iter, float step, float em3[3], float *sli
   if (r) return r;
   hipLaunchKernelGGL(k_mstep_scalars, dim3(1), dim3(1), 0, ctx->stream, ctx->d_out, iter, step, ctx->pvr ? 1 : 0, em3[0], em3[1], ctx->d_em);
   KCHK("k_mstep_scalars");
+  if ((r = launch_estep(ctx, 0.0f, 0.0f, 0.0f, ctx->d_em))) return r;
+  if ((r = down_queue(ctx, slice_potential, ctx->d_tmp_ns, ctx->ns * sizeof(float)))) return r;
+  if ((r = down_queue(ctx, em3, ctx->d_em, 3 * sizeof(float)))) return r;
+  if (scale_vec && (r = down_queue(ctx, scale_vec, ctx->d_scales_host_copy, ctx->ns * sizeof(float)))) return r;
+  if (slice_inside && (r = down_queue(ctx, slice_inside, ctx->d_slice_inside, ctx->ns))) return r;
+  if ((r = down_flush(ctx))) return r;
+  if (scale_vec) ctx->mir_scales_copy.assign(scale_vec, scale_vec + ctx->ns);
+  return SVR_OK;
+}
+
+// The same for a SHARDED run without a wait in between: svr_mstep_partial leaves this rank's five sums in *send (8 doubles = 16
+// floats, device memory) and names the buffer the launcher's all-gather fills (*recv: world x 8 doubles); svr_mstep_estep_ranks
+// adds the ranks' sums up on the device in rank order, works the scalars out there, runs the E-step on them and fetches this rank's
+// potentials, the scalars and the deferred vectors in ONE wait.  The host's exchange of the M-step's sums is gone.
+int svr_mstep_partial(svr_ctx *ctx, int world, void **send, void **recv) {
+  SVR_ENTER(ctx);
+  if (!ctx || !send || !recv || world < 1) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales, "slices / scales not set");
+  if ((size_t)world > ctx->em_all_cap) {
+    free_dev(ctx->d_em_all);
+    ctx->em_all_cap = 0;
+    HIPCHK(hipMalloc(&ctx->d_em_all, (size_t)world * 8 * sizeof(double)));
+    ctx->em_all_cap = world;
+  }
+  int r = launch_mstep(ctx);
+  if (r) return r;
+  *send = ctx->d_out;
+  *recv = ctx->d_em_all;
+  return SVR_OK;
+}
+int svr_mstep_estep_ranks(svr_ctx *ctx, int world, int iter, float step, float em3[3], float *slice_potential, float *scale_vec, uint8_t *slice_inside) {
+  SVR_ENTER(ctx);
+  if (!ctx || !em3 || !slice_potential || world < 1) return SVR_E_ARG;
+  NEED(ctx->have_slices && ctx->have_scales && ctx->d_em_all && (size_t)world <= ctx->em_all_cap, "svr_mstep_partial first");
+  if (!ctx->d_em) HIPCHK(hipMalloc(&ctx->d_em, 4 * sizeof(float)));
+  hipLaunchKernelGGL(k_mstep_scalars_ranks, dim3(1), dim3(1), 0, ctx->stream, ctx->d_em_all, world, iter, step, ctx->pvr ? 1 : 0, em3[0], em3[1], ctx->d_em);
+  KCHK("k_mstep_scalars_ranks");
+  int r;
   if ((r = launch_estep(ctx, 0.0f, 0.0f, 0.0f, ctx->d_em))) return r;
   if ((r = down_queue(ctx, slice_potential, ctx->d_tmp_ns, ctx->ns * sizeof(float)))) return r;
   if ((r = down_queue(ctx, em3, ctx->d_em, 3 * sizeof(float)))) return r;

@@ -97,7 +97,8 @@ class irtkReconstruction {
     if (_mstep_pending) {
       const int iter = _mstep_pending;
       _mstep_pending = 0;
-      ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
+      if (sh.on) { if (int rc = mstep_exchange(iter)) return rc; }       // (collective: the ranks run the same operator sequence)
+      else ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
     }
     if (_scale_pending) {
       std::vector<float> loc(hi - lo);
@@ -197,7 +198,26 @@ class irtkReconstruction {
   // RG.cc:3184-3440: voxel posteriors on the GPU, slice-level EM on the host
   int EStepGPU() {
     std::vector<float> loc(hi - lo);
-    if (_mstep_pending) {                              // one rank: M-step + E-step + whatever is still on the device, one wait
+    if (_mstep_pending && sh.on) {
+      // sharded (round 4): the M-step's five sums of every rank meet ON THE DEVICE (the launcher's all-gather on the engine's stream),
+      // are added up there in rank order, and the E-step runs on the result: one wait and one host exchange (the potentials') per SR
+      // iteration instead of two of each
+      const int iter = _mstep_pending;
+      _mstep_pending = 0;
+      void *send = nullptr, *recv = nullptr;
+      ENG(svr_mstep_partial(reconstructionGPU, sh.coll.world, &send, &recv));
+      if (int rc = sh.before_device_collective()) return fail(rc, "svr_stream_sync");
+      if (int rc = sh.coll.allgather_device(sh.coll.user, send, recv, 16)) return fail(rc, "allgather_device (M-step sums)");
+      float em3[3] = {_sigma_gpu, _mix_gpu, _m_gpu};
+      std::vector<float> sc(_scale_pending ? hi - lo : 0);
+      std::vector<unsigned char> inside(_inside_pending ? hi - lo : 0);
+      ENG(svr_mstep_estep_ranks(reconstructionGPU, sh.coll.world, iter, (float)_step, em3, loc.data(), _scale_pending ? sc.data() : nullptr,
+                                _inside_pending ? inside.data() : nullptr));
+      _sigma_gpu = em3[0]; _mix_gpu = em3[1]; _m_gpu = em3[2];
+      if (_scale_pending) std::copy(sc.begin(), sc.end(), _scale_gpu.begin() + lo);
+      if (_inside_pending) for (int i = 0; i < hi - lo; ++i) _slice_inside_gpu[lo + i] = inside[i] != 0;
+      _scale_pending = _inside_pending = false;
+    } else if (_mstep_pending) {                       // one rank: M-step + E-step + whatever is still on the device, one wait
       const int iter = _mstep_pending;
       _mstep_pending = 0;
       float em3[3] = {_sigma_gpu, _mix_gpu, _m_gpu};
@@ -326,6 +346,16 @@ class irtkReconstruction {
       ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
       return 0;
     }
+    if (device_em && sh.coll.allgather_device && iter > 0) {
+      if (_mstep_pending) { if (int rc = settle()) return rc; }
+      _mstep_pending = iter;                           // runs with the E-step that follows, its sums meeting on the device (EStepGPU), or in settle
+      return 0;
+    }
+    return mstep_exchange(iter);
+  }
+  // the M-step of a sharded run through the hosts: this rank's five sums, one exchange, the scalars on the host
+  bool device_em = getenv("SVR_DEVICE_EM") ? atoi(getenv("SVR_DEVICE_EM")) != 0 : true;
+  int mstep_exchange(int iter) {
     double s5[5];
     {
       std::vector<float> sc(_scale_pending ? hi - lo : 0);

@@ -44,7 +44,7 @@ EXPORTS = [
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
     "svr_reg_set_schedule", "svr_reg_evaluate_costs", "svr_reg_counters", "svr_pvr_cc_patches", "svr_pvr_register_patches",
     "svr_slab_plan", "svr_slab_rs_pack", "svr_slab_update", "svr_slab_finish", "svr_stream_sync",
-    "svr_get_scale_vector", "svr_adopt_scale_vector", "svr_get_slice_inside", "svr_mstep_estep", "svr_mstep_sums_fetch",
+    "svr_get_scale_vector", "svr_adopt_scale_vector", "svr_get_slice_inside", "svr_mstep_estep", "svr_mstep_sums_fetch", "svr_mstep_partial", "svr_mstep_estep_ranks",
 ]
 
 

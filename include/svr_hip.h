@@ -152,6 +152,13 @@ int svr_get_slice_inside(svr_ctx *ctx, uint8_t *slice_inside);
 int svr_mstep_estep(svr_ctx *ctx, int iter, float step, float em3[3], float *slice_potential, float *scale_vec, uint8_t *slice_inside);
 /* the M-step's five sums (svr_mstep_sums: what a sharded host exchanges) together with the deferred vectors, one wait */
 int svr_mstep_sums_fetch(svr_ctx *ctx, double out5[5], float *scale_vec, uint8_t *slice_inside);
+/* ... and without the wait in between (round 4): svr_mstep_partial runs the M-step's sums of this rank's slices and names two device
+ * buffers -- *send: its 8 doubles (16 floats), *recv: world x 8 doubles -- for the launcher's all-gather on the engine's stream;
+ * svr_mstep_estep_ranks then adds the ranks' sums up on the device in rank order (what the hosts do after their exchange), works the
+ * scalars out there, runs the E-step and fetches potentials, {sigma, mix, m} and the deferred vectors in one wait: svr_mstep_estep of
+ * a sharded run.  The reference keeps all of this on one GPU (reconstruction_cuda2.cu:3016-3071, 2766-2960). */
+int svr_mstep_partial(svr_ctx *ctx, int world, void **send, void **recv);
+int svr_mstep_estep_ranks(svr_ctx *ctx, int world, int iter, float step, float em3[3], float *slice_potential, float *scale_vec, uint8_t *slice_inside);
 /* Superresolution(int iter, std::vector<float> slice_weight, bool adaptive, float alpha, float min_intensity,
  *                 float max_intensity, float delta, float lambda, bool global_bias_correction,
  *                 float sigma_bias, float low_intensity_cutoff)  RC.cuh:263-265, RC.cu:2119-2241 */

@@ -107,7 +107,8 @@ def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
         d.sr_iteration(2)
         tm = rec.timers()
         # (the volume update by z-slabs: one reduce-scatter and one all-gather instead of the all-reduce of the pair)
-        assert tm["allreduce"][1] == 0 and tm["reduce_scatter"][1] == 1 and tm["allgather"][1] == 1 and tm["exchange_host"][1] == 2
+        # ... and ONE host exchange (the E-step's potentials): the M-step's sums meet on the device (svr_mstep_partial / svr_mstep_estep_ranks)
+        assert tm["allreduce"][1] == 0 and tm["reduce_scatter"][1] == 1 and tm["allgather"][1] == 1 and tm["exchange_host"][1] == 1
         assert tm["reduce_scatter"][0] > 0 and tm["allgather"][0] > 0
     recs[1][1].close()
 
@@ -183,3 +184,34 @@ def test_only_the_masks_bounding_box_is_exchanged(tiny):
     assert np.array_equal(a1.reshape(vz, vy, vx)[box], a0.reshape(vz, vy, vx)[box]) and np.array_equal(c1, c0)
     assert (a1.reshape(vz, vy, vx)[~box] == 7.0).all()
     rec.close()
+
+
+@pytest.mark.gpu
+def test_m_step_sums_meeting_on_the_device_give_the_host_exchanges_bits(tiny, monkeypatch):
+    """A sharded SR iteration makes ONE host exchange since round 4: the M-step's five sums of every rank are all-gathered on the device,
+    added up there in rank order and fed to the E-step (svr_mstep_partial / svr_mstep_estep_ranks, csrc/svr_host.cpp EStepGPU) instead of
+    travelling through the hosts (SVR_DEVICE_EM=0: the round-3 form).  Same operations in the same order: the volume and the EM state are
+    the same bits.  World 1 through the C library's RCCL communicator (the gpurun box has one GPU)."""
+    import numpy as np
+    from fetalreconstruction_amd import engine as E, host
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SVR_DEVICE_EM", mode)
+        rec = E.Reconstruction(0)
+        E.sync_gpu(rec, tiny)
+        comm = host.RcclComm(rec, 0, 1, host.RcclComm.unique_id())
+        d = host.irtkReconstruction(rec, tiny.ns, (0, tiny.ns), comm, tiny.max_intensity, tiny.min_intensity, force_collectives=True)
+        d.SetSmoothingParameters(150, 0.02)
+        d.reconstruct_iteration(3)
+        rec.timer_enable(True)
+        rec.timer_reset()
+        d.sr_iteration(3)
+        n_exchanges = rec.timers()["exchange_host"][1]
+        st = d.state()
+        out[mode] = (rec.syncCPU().copy(), st["scale"].copy(), st["slice_weight"].copy(), (st["sigma"], st["mix"], st["m"]), n_exchanges)
+        comm.close()
+        rec.close()
+    assert out["0"][4] == 2 and out["1"][4] == 1
+    for a, b in zip(out["0"][:3], out["1"][:3]):
+        assert np.array_equal(a, b)
+    assert out["0"][3] == out["1"][3]

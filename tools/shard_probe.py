@@ -24,6 +24,7 @@ import numpy as np
 XGMI_LINK_GBS = 76.8
 XGMI_EFF = 0.5
 HOST_EXCHANGE_MS = 0.08      # one stream synchronisation + one small collective (60-100 us measured at world 1)
+HOST_EXCHANGES = {"svr": 1, "pvr": 2}   # per SR iteration: the E-step's potentials (SVR: the M-step's sums meet on the device, csrc/svr_host.cpp); PVR: M-step + E-step
 
 
 def build(wl):
@@ -156,15 +157,16 @@ def project(res):
     reg_full = max(k["regularize"] for k in sh)
     # replicated: all-reduce of addon|cmap (2 Nv floats: reduce-scatter + all-gather of the whole message), whole-volume update
     ar = 2 * collective_ms(2 * nv * 4, W)
-    replicated = psf + ar + reg_full + 2 * HOST_EXCHANGE_MS
+    nex = HOST_EXCHANGES["pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"]
+    replicated = psf + ar + reg_full + nex * HOST_EXCHANGE_MS
     # slab: reduce-scatter of addon|cmap over the mask's voxels (+ halo planes), update of the rank's slab, all-gather of the volume
     mfrac = res.get("mask_fraction", 1.0)
     rs_ms = collective_ms(2 * nv * 4 * mfrac, W)
     ag_ms = collective_ms(nv * 4 * min(1.0, mfrac * 1.15), W)
-    slab = psf + rs_ms + reg_full / W + ag_ms + 2 * HOST_EXCHANGE_MS
+    slab = psf + rs_ms + reg_full / W + ag_ms + nex * HOST_EXCHANGE_MS
     return dict(label="PROJECTION from one-GPU per-shard kernel times; no collective was run",
                 assumptions=dict(xgmi_link_GBs_per_direction=XGMI_LINK_GBS, links_used=min(W - 1, 7), efficiency=XGMI_EFF,
-                                 host_exchange_ms=HOST_EXCHANGE_MS, host_exchanges_per_step=2),
+                                 host_exchange_ms=HOST_EXCHANGE_MS, host_exchanges_per_step=nex),
                 one_gpu_kernels_ms=one, max_rank_psf_em_ms=psf, sum_rank_psf_ms=sum(k["backproject"] + k["forward"] for k in sh),
                 shard_overhead=sum(k["backproject"] + k["forward"] for k in sh) / (full["backproject"] + full["forward"]),
                 replicated=dict(allreduce_ms=ar, update_ms=reg_full, step_ms=replicated, speedup=one / replicated),
