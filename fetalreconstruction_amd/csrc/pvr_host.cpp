@@ -124,7 +124,19 @@ class irtkPatchBasedReconstruction {
 
   int EStep() {                                                              // PRS.cu:224-556
     std::vector<float> pot(n, 0.0f);
-    if (mstep_pending) {                             // one rank: M-step + E-step + the scale vector, one wait for the device
+    if (mstep_pending && sh.on) {
+      // sharded (round 4; svr_host.cpp EStepGPU): the ranks' M-step sums meet on the device, one wait and one host exchange per SR iteration
+      const int iter = mstep_pending;
+      mstep_pending = 0;
+      void *send = nullptr, *recv = nullptr;
+      PENG(svr_mstep_partial(e, sh.coll.world, &send, &recv));
+      if (int rc = sh.before_device_collective()) return fail(rc, "svr_stream_sync");
+      if (int rc = sh.coll.allgather_device(sh.coll.user, send, recv, 16)) return fail(rc, "allgather_device (M-step sums)");
+      float em3[3] = {m_sigma_gpu, m_mix_gpu, m_m_gpu};
+      PENG(svr_mstep_estep_ranks(e, sh.coll.world, iter, m_step, em3, pot.data() + lo, scale_pending ? scale.data() + lo : nullptr, nullptr));
+      m_sigma_gpu = em3[0]; m_mix_gpu = em3[1]; m_m_gpu = em3[2];
+      scale_pending = false;
+    } else if (mstep_pending) {                      // one rank: M-step + E-step + the scale vector, one wait for the device
       const int iter = mstep_pending;
       mstep_pending = 0;
       float em3[3] = {m_sigma_gpu, m_mix_gpu, m_m_gpu};
@@ -204,13 +216,14 @@ class irtkPatchBasedReconstruction {
   }
 
   int MStep(int iter) {                                                      // PRS.cu:570-640
-    if (!sh.on && iter > 0) {
+    if (iter > 0 && (!sh.on || (device_em && sh.coll.allgather_device))) {
       if (mstep_pending) { if (int rc = settle()) return rc; }   // (only an M-step still waiting; the scale vector stays pending for the fused fetch)
       mstep_pending = iter;                          // runs with the E-step that follows (PBR.cpp:540-545), or in settle
       return 0;
     }
     return MStepNow(iter);
   }
+  bool device_em = getenv("SVR_DEVICE_EM") ? atoi(getenv("SVR_DEVICE_EM")) != 0 : true;   // sharded: the M-step's sums meet on the device
   int MStepNow(int iter) {
     double s5[5];
     PENG(svr_mstep_sums_fetch(e, s5, scale_pending ? scale.data() + lo : nullptr, nullptr));

@@ -145,7 +145,7 @@ def test_bench_pvr_workload_through_the_sharded_path():
     assert len(k["Va"]) == 1 and k["Va"][0] == a["config"]["Va_total"] and k["units"][0] == a["config"]["slices"]
     assert k["backproject_ms"][0] > 0 and k["forward_ms"][0] > 0 and k["exchange_host_ms"][0] > 0
     assert k["reduce_scatter_ms"][0] > 0 and k["allgather_ms"][0] > 0 and k["collective_bytes_sent"][0] > 0       # the slab update's two collectives
-    assert k["exchanges_per_step"][0] == 2.0                 # M-step, E-step (the scale vector rides along)
+    assert k["exchanges_per_step"][0] == 1.0                 # the E-step's potentials (the scale vector rides along; the M-step's sums meet on the device)
     assert set(a["config"]["tuned"]) >= {"gather_tile", "scatter_tile", "scatter_box"}
 
 

@@ -24,7 +24,7 @@ import numpy as np
 XGMI_LINK_GBS = 76.8
 XGMI_EFF = 0.5
 HOST_EXCHANGE_MS = 0.08      # one stream synchronisation + one small collective (60-100 us measured at world 1)
-HOST_EXCHANGES = {"svr": 1, "pvr": 2}   # per SR iteration: the E-step's potentials (SVR: the M-step's sums meet on the device, csrc/svr_host.cpp); PVR: M-step + E-step
+HOST_EXCHANGES = {"svr": 1, "pvr": 1}   # per SR iteration: the E-step's potentials (the M-step's sums meet on the device: csrc/svr_host.cpp, csrc/pvr_host.cpp)
 
 
 def build(wl):
