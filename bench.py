@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--workload", default="P4", choices=["P4", "P4s", "S8", "S8h", "tiny", "PVR4", "PVR8spx"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coeff-table", action="store_true", help="skip the second measurement with the coefficient table")
+    ap.add_argument("--no-s8", action="store_true", help="skip the S8 record (BASELINE configs[3], measured after the default workload in the same launch)")
+    ap.add_argument("--layout", choices=["spatial", "contiguous"], default=None,
+                    help="N > 1: how the units are dealt to the ranks (sharding.shard_units): spatial (default) = the r-th part of every stack, contiguous = ranges of the reference's order")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the C library's own RCCL collectives; torch: torch.distributed callbacks (--backend)")
     ap.add_argument("--backend", default="nccl", help="--comm torch: torch.distributed backend (nccl = RCCL, gloo)")
@@ -187,7 +190,7 @@ def main():
     import torch                                                      # before the engine: one RCCL copy per process
     from fetalreconstruction_amd import engine, phantom, workloads
     from fetalreconstruction_amd.host import RcclComm, irtkPatchBasedReconstruction, irtkReconstruction      # the C++ host objects
-    from fetalreconstruction_amd.sharding import TorchComm, patch_cost_weights, shard_slices, slice_cost_weights
+    from fetalreconstruction_amd.sharding import TorchComm, patch_cost_weights, shard_units, slice_cost_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -227,101 +230,7 @@ def main():
                     raise
                 os.environ["MASTER_PORT"] = str(free_port())
 
-    # ---- the workload: fixed, whatever the world size --------------------------------------------------------------
-    prob = workloads.get(args.workload) if args.workload != "tiny" else phantom.problem_tiny()
-    pvr = args.workload.startswith("PVR")
-    if pvr:
-        if args.comm == "torch":
-            raise SystemExit("bench.py: the patch-based host (csrc/pvr_host.cpp) takes the C library's RCCL communicator; --comm torch is SVR only")
-        # contiguous patch ranges balanced by the pixels that carry data (patches of one stack share their geometry)
-        work = patch_cost_weights((prob.slices > 0).reshape(prob.ns, -1).sum(1), prob.slice_i2w, prob.slice_t, prob.recon_w2i)
-    else:
-        act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
-        # contiguous slice ranges balanced by estimated PSF work (active pixels x live planes), not by pixel count alone
-        work = slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0])
-    lo, hi = shard_slices(work, world)[rank]
-    local = phantom.sub_problem(prob, lo, hi) if world > 1 else prob
-    spx = getattr(prob, "spx_masks", None)
-
-    rec = engine.Reconstruction(local_rank)
-    if pvr:
-        rec.set_option("pvr", 1)
-        engine.sync_gpu(rec, local, quality_factor=1.0)                # m_quality_factor = 1 (irtkPatchBasedReconstruction.cpp:415)
-        if spx is not None:
-            rec.set_spx_masks(np.ascontiguousarray(spx[lo:hi]))
-    else:
-        engine.sync_gpu(rec, local)
-    comm, rccl_world = None, None
-    if multi:
-        if args.comm == "rccl":
-            # every rank first proves it can open librccl (a rank that cannot would leave the others waiting inside
-            # ncclCommInitRank); if one cannot, all ranks fall back to host-staged exchanges over gloo and say so
-            try:
-                uid, why = RcclComm.unique_id(), None
-            except Exception as ex:
-                uid, why = None, repr(ex)
-            oks = [None] * world
-            dist.all_gather_object(oks, why)
-            if any(w is not None for w in oks):
-                if rank == 0:
-                    print(f"note: RCCL unavailable on some rank ({[w for w in oks if w][0]}); exchanging through gloo", file=sys.stderr)
-                args.comm = "gloo-fallback"
-                comm = TorchComm(device=None)
-            else:
-                box = [uid if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm = RcclComm(rec, rank, world, box[0])
-                rccl_world = comm.rccl_world()
-        else:
-            comm = TorchComm(device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
-    if multi:
-        try:                                          # RCCL's version banner (C stdio, every rank) goes out now, not at exit
-            import ctypes                             # after rank 0's JSON line
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-    if pvr:
-        drv = irtkPatchBasedReconstruction(rec, prob.patches_per_stack, prob.min_intensity, prob.max_intensity, patch_range=(lo, hi),
-                                           comm=comm, force_collectives=args.force_comm)
-        # untimed set-up: the part of an outer iteration before the SR loop (irtkPatchBasedReconstruction.cpp:490-504)
-        drv.reconstruct_iteration(0)
-    else:
-        drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity, force_collectives=args.force_comm)
-        drv.SetSmoothingParameters(150, 0.02)      # reconstruction.cc:99-100 defaults (delta, lambda)
-        # untimed set-up: the part of an outer iteration before the SR loop (reconstruction.cc:930-1001)
-        drv.InitializeEMValuesGPU()
-        drv.GaussianReconstructionGPU()
-        drv.SimulateSlicesGPU()
-        drv.InitializeRobustStatisticsGPU()
-        drv.EStepGPU()
-    # the first scatter after new geometry builds its work lists (cell lists, launch order); this untimed one keeps that out of the
-    # timed region whatever --warmup is (it only writes addon|cmap and the slice weights, which every SR iteration rebuilds / uploads)
-    rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
-
-    # The steps follow the reference's schedule: an outer iteration re-initialises the EM state and runs rec_iterations_first
-    # = 4 SR iterations (reconstruction.cc:115,187,930-1001,1013; irtkPatchBasedReconstruction.cpp:490-504).  Run on without
-    # that, the slice-level EM of this workload drops more and more slices (12 of 280 after 2 SR iterations, 117 after 24, 236
-    # after 46: tools/check_bench_drift.py) and with them their pixels from the scatter -- a step that gets cheaper the later it
-    # is timed.  So every SR_PER_OUTER steps (warm-up and timed alike, by the running step count) the EM part of the outer
-    # iteration's preamble runs INSIDE the timed region: InitializeEMValues, InitializeRobustStatistics, EStep -- three small
-    # kernels and one host exchange; the volume carries on (registration + Gaussian reconstruction are not part of the metric).
-    def em_reinit():
-        if pvr:
-            drv.initializeEMValues(); drv.InitializeRobustStatistics(); drv.EStep()
-        else:
-            drv.InitializeEMValuesGPU(); drv.InitializeRobustStatisticsGPU(); drv.EStepGPU()
-
-    done = [0]
-
-    def step():
-        k = done[0] % SR_PER_OUTER
-        if done[0] and k == 0:
-            em_reinit()
-        drv.sr_iteration(k)
-        done[0] += 1
-
-    for i in range(args.warmup):
-        step()
+    state = {"comm": None, "rccl_world": None}
 
     def barrier():
         torch.cuda.synchronize()
@@ -329,98 +238,249 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    rec.timer_enable(True)       # HIP events on the engine's own stream around each hot kernel (svr_timer_*)
-    rec.timer_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timers = rec.timers()
-    cnt = rec.counters()
+    def measure(workload, with_table):
+        """one workload through the steps of the contract on this launch's ranks and communicator: W untimed steps, K timed ones between
+        barriers -> everything the line reports about it"""
+        comm, rccl_world = state["comm"], state["rccl_world"]
+        # ---- the workload: fixed, whatever the world size --------------------------------------------------------------
+        prob = workloads.get(workload) if workload != "tiny" else phantom.problem_tiny()
+        pvr = workload.startswith("PVR")
+        if pvr:
+            if args.comm == "torch":
+                raise SystemExit("bench.py: the patch-based host (csrc/pvr_host.cpp) takes the C library's RCCL communicator; --comm torch is SVR only")
+            # work of a patch: the pixels that carry data, weighted by orientation (patches of one stack share their geometry)
+            work = patch_cost_weights((prob.slices > 0).reshape(prob.ns, -1).sum(1), prob.slice_i2w, prob.slice_t, prob.recon_w2i)
+        else:
+            act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
+            # work of a slice: estimated PSF work (active pixels x live planes), not the pixel count alone
+            work = slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0])
+        # rank r takes the r-th of `world` work-balanced segments of EVERY stack (sharding.shard_units, layout "spatial": a rank's units
+        # are neighbours in space -- about 1 / world of the volume's (cell, plane) items per orientation to stage and to combine instead
+        # of all the items of the stacks it holds); `order` = the sharded numbering, which the host object is told
+        order, ranges = shard_units(work, prob.stack_index, world, args.layout)
+        lo, hi = ranges[rank]
+        local = phantom.sub_problem(prob, 0, 0, select=order[lo:hi]) if world > 1 else prob
+        spx = getattr(prob, "spx_masks", None)
 
-    def per_rank(tm):
-        """what every rank measured on its own engine: average milliseconds per launch of the two PSF kernels, of the volume
-        all-reduce (HIP events around the collective on the engine's stream: the wait for the slowest rank + the ring) and of
-        the small host-side exchanges (wall clock), plus the rank's share of the work -- so that a scaling shortfall can be
-        put down to imbalance, RCCL or the host exchanges from the line alone"""
-        keys = ("backproject", "forward", "allreduce", "reduce_scatter", "allgather", "exchange_host", "regularize")
-        mine = [tm[k][0] / max(tm[k][1], 1) for k in keys] + [float(tm["exchange_host"][1]) / max(args.steps, 1), float(cnt["Va"]), float(hi - lo)]
-        mine.append(float(coll_bytes))
-        n = len(mine)
-        v = np.zeros(world * n)
-        v[rank * n:(rank + 1) * n] = mine
-        v = comm.allreduce_sum(v).reshape(world, n) if multi else v.reshape(1, n)
-        out = {f"{k}_ms": [round(float(x), 4) for x in v[:, j]] for j, k in enumerate(keys)}
-        out["exchanges_per_step"] = [round(float(x), 2) for x in v[:, len(keys)]]
-        out["Va"] = [int(x) for x in v[:, len(keys) + 1]]
-        out["units"] = [int(x) for x in v[:, len(keys) + 2]]
-        # what a rank sends per SR iteration through the volume collectives (slab update: (N-1)/N of reduce-scatter + all-gather
-        # messages; replicated update: the ring all-reduce's 2 (N-1)/N of the pair)
-        out["collective_bytes_sent"] = [int(x) for x in v[:, len(keys) + 3]]
-        return out
-
-    # bytes of the volume collectives per SR iteration and rank
-    nvv = float(cnt["Nv"])
-    if not multi:
-        coll_bytes = 0.0
-    elif timers["reduce_scatter"][1]:
-        try:
-            rsn, agn = rec.slab_chunks(world if world > 1 else 1, rank)
-        except Exception:
-            rsn, agn = 0, 0
-        coll_bytes = 4.0 * (world - 1) * (rsn + agn) if world > 1 else 4.0 * (rsn + agn)
-    else:
-        coll_bytes = 2.0 * (world - 1) / max(world, 1) * 2.0 * nvv * 4.0
-    ranks = per_rank(timers)
-    if multi:
-        dt = float(comm.allreduce_max(np.array([dt]))[0])
-        va = int(round(comm.allreduce_sum(np.array([float(cnt["Va"])]))[0]))
-    else:
-        va = cnt["Va"]
-    tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode", "fwd_mode", "cell_w", "cell_h", "cell_gw", "cell_gh")}
-
-    # ---- the same K steps once more with the coefficient table (reported next to the headline, not as it) ------------
-    # `value` above is the reference GPU path's way: every tap evaluated in every pass.  With option coeff_table the taps of
-    # every live unit are written once per slice geometry -- what irtkReconstruction::CoeffInit keeps as _volcoeffs on the
-    # reference's CPU path (irtkReconstructionGPU.cc:2305-2673) -- and the scatter and the gather stream them from HBM.
-    tab = None
-    if not args.no_coeff_table:
-        try:
-            rec.set_option("coeff_table", 1)
-            rec.timer_reset()
-            rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
-            build_ms = rec.timers()["coeff_build"][0]
-            rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
-            done[0] = 0                                           # the same schedule from the same EM state as above
-            em_reinit()
-            for i in range(args.warmup):
-                step()
-            on = rec.get_option("coeff_table") == 1               # it switches itself off when it does not fit the free memory
-            rec.timer_reset()
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                step()
-            barrier()
-            dt2 = time.perf_counter() - t1
-            tm2 = rec.timers()
-            if multi:
-                dt2 = float(comm.allreduce_max(np.array([dt2]))[0])
-                on = bool(comm.allreduce_min(np.array([1.0 if on else 0.0]))[0] > 0.5)
-            tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 16 * 1024.0, "build_ms": build_ms}
-            rec.set_option("coeff_table", 0)
-        except Exception as ex:                              # the headline line must still be printed
-            if multi:
-                raise                                         # (a rank that carried on alone would leave the others in a barrier)
-            tab = None
-            if rank == 0:
-                print(f"note: the coefficient-table measurement failed: {ex!r}", file=sys.stderr)
-            try:
-                rec.set_option("coeff_table", 0)
+        rec = engine.Reconstruction(local_rank)
+        if pvr:
+            rec.set_option("pvr", 1)
+            engine.sync_gpu(rec, local, quality_factor=1.0)                # m_quality_factor = 1 (irtkPatchBasedReconstruction.cpp:415)
+            if spx is not None:
+                rec.set_spx_masks(np.ascontiguousarray(spx[order[lo:hi]]))
+        else:
+            engine.sync_gpu(rec, local)
+        if comm is not None:                              # a second workload in the same launch: the same communicator on the new engine's stream
+            if hasattr(comm, "rebind"):
+                comm.rebind(rec)
+        elif multi:
+            if args.comm == "rccl":
+                # every rank first proves it can open librccl (a rank that cannot would leave the others waiting inside
+                # ncclCommInitRank); if one cannot, all ranks fall back to host-staged exchanges over gloo and say so
+                try:
+                    uid, why = RcclComm.unique_id(), None
+                except Exception as ex:
+                    uid, why = None, repr(ex)
+                oks = [None] * world
+                dist.all_gather_object(oks, why)
+                if any(w is not None for w in oks):
+                    if rank == 0:
+                        print(f"note: RCCL unavailable on some rank ({[w for w in oks if w][0]}); exchanging through gloo", file=sys.stderr)
+                    args.comm = "gloo-fallback"
+                    comm = TorchComm(device=None)
+                else:
+                    box = [uid if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    comm = RcclComm(rec, rank, world, box[0])
+                    rccl_world = comm.rccl_world()
+            else:
+                comm = TorchComm(device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+        if multi:
+            try:                                          # RCCL's version banner (C stdio, every rank) goes out now, not at exit
+                import ctypes                             # after rank 0's JSON line
+                ctypes.CDLL(None).fflush(None)
             except Exception:
                 pass
+        if pvr:
+            drv = irtkPatchBasedReconstruction(rec, prob.patches_per_stack, prob.min_intensity, prob.max_intensity, patch_range=(lo, hi),
+                                               comm=comm, force_collectives=args.force_comm)
+            if world > 1:
+                drv.set_unit_order(order)
+            # untimed set-up: the part of an outer iteration before the SR loop (irtkPatchBasedReconstruction.cpp:490-504)
+            drv.reconstruct_iteration(0)
+        else:
+            drv = irtkReconstruction(rec, prob.ns, (lo, hi), comm, prob.max_intensity, prob.min_intensity, force_collectives=args.force_comm)
+            if world > 1:
+                drv.set_unit_order(order)
+            drv.SetSmoothingParameters(150, 0.02)      # reconstruction.cc:99-100 defaults (delta, lambda)
+            # untimed set-up: the part of an outer iteration before the SR loop (reconstruction.cc:930-1001)
+            drv.InitializeEMValuesGPU()
+            drv.GaussianReconstructionGPU()
+            drv.SimulateSlicesGPU()
+            drv.InitializeRobustStatisticsGPU()
+            drv.EStepGPU()
+        # the first scatter after new geometry builds its work lists (cell lists, launch order); this untimed one keeps that out of the
+        # timed region whatever --warmup is (it only writes addon|cmap and the slice weights, which every SR iteration rebuilds / uploads)
+        rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
+
+        # The steps follow the reference's schedule: an outer iteration re-initialises the EM state and runs rec_iterations_first
+        # = 4 SR iterations (reconstruction.cc:115,187,930-1001,1013; irtkPatchBasedReconstruction.cpp:490-504).  Run on without
+        # that, the slice-level EM of this workload drops more and more slices (12 of 280 after 2 SR iterations, 117 after 24, 236
+        # after 46: tools/check_bench_drift.py) and with them their pixels from the scatter -- a step that gets cheaper the later it
+        # is timed.  So every SR_PER_OUTER steps (warm-up and timed alike, by the running step count) the EM part of the outer
+        # iteration's preamble runs INSIDE the timed region: InitializeEMValues, InitializeRobustStatistics, EStep -- three small
+        # kernels and one host exchange; the volume carries on (registration + Gaussian reconstruction are not part of the metric).
+        def em_reinit():
+            if pvr:
+                drv.initializeEMValues(); drv.InitializeRobustStatistics(); drv.EStep()
+            else:
+                drv.InitializeEMValuesGPU(); drv.InitializeRobustStatisticsGPU(); drv.EStepGPU()
+
+        done = [0]
+
+        def step():
+            k = done[0] % SR_PER_OUTER
+            if done[0] and k == 0:
+                em_reinit()
+            drv.sr_iteration(k)
+            done[0] += 1
+
+        for i in range(args.warmup):
+            step()
+
+        rec.timer_enable(True)       # HIP events on the engine's own stream around each hot kernel (svr_timer_*)
+        rec.timer_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        timers = rec.timers()
+        cnt = rec.counters()
+
+        def per_rank(tm):
+            """what every rank measured on its own engine: average milliseconds per launch of the two PSF kernels, of the volume
+            all-reduce (HIP events around the collective on the engine's stream: the wait for the slowest rank + the ring) and of
+            the small host-side exchanges (wall clock), plus the rank's share of the work -- so that a scaling shortfall can be
+            put down to imbalance, RCCL or the host exchanges from the line alone"""
+            keys = ("backproject", "forward", "allreduce", "reduce_scatter", "allgather", "exchange_host", "regularize")
+            mine = [tm[k][0] / max(tm[k][1], 1) for k in keys] + [float(tm["exchange_host"][1]) / max(args.steps, 1), float(cnt["Va"]), float(hi - lo)]
+            mine.append(float(coll_bytes))
+            n = len(mine)
+            v = np.zeros(world * n)
+            v[rank * n:(rank + 1) * n] = mine
+            v = comm.allreduce_sum(v).reshape(world, n) if multi else v.reshape(1, n)
+            out = {f"{k}_ms": [round(float(x), 4) for x in v[:, j]] for j, k in enumerate(keys)}
+            out["exchanges_per_step"] = [round(float(x), 2) for x in v[:, len(keys)]]
+            out["Va"] = [int(x) for x in v[:, len(keys) + 1]]
+            out["units"] = [int(x) for x in v[:, len(keys) + 2]]
+            # what a rank sends per SR iteration through the volume collectives (slab update: (N-1)/N of reduce-scatter + all-gather
+            # messages; replicated update: the ring all-reduce's 2 (N-1)/N of the pair)
+            out["collective_bytes_sent"] = [int(x) for x in v[:, len(keys) + 3]]
+            return out
+
+        # bytes of the volume collectives per SR iteration and rank
+        nvv = float(cnt["Nv"])
+        if not multi:
+            coll_bytes = 0.0
+        elif timers["reduce_scatter"][1]:
+            try:
+                rsn, agn = rec.slab_chunks(world if world > 1 else 1, rank)
+            except Exception:
+                rsn, agn = 0, 0
+            coll_bytes = 4.0 * (world - 1) * (rsn + agn) if world > 1 else 4.0 * (rsn + agn)
+        else:
+            coll_bytes = 2.0 * (world - 1) / max(world, 1) * 2.0 * nvv * 4.0
+        ranks = per_rank(timers)
+        if multi:
+            dt = float(comm.allreduce_max(np.array([dt]))[0])
+            va = int(round(comm.allreduce_sum(np.array([float(cnt["Va"])]))[0]))
+        else:
+            va = cnt["Va"]
+        tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode", "fwd_mode", "cell_w", "cell_h", "cell_gw", "cell_gh")}
+
+        # ---- the same K steps once more with the coefficient table (reported next to the headline, not as it) ------------
+        # `value` above is the reference GPU path's way: every tap evaluated in every pass.  With option coeff_table the taps of
+        # every live unit are written once per slice geometry -- what irtkReconstruction::CoeffInit keeps as _volcoeffs on the
+        # reference's CPU path (irtkReconstructionGPU.cc:2305-2673) -- and the scatter and the gather stream them from HBM.
+        tab = None
+        if with_table:
+            try:
+                rec.set_option("coeff_table", 1)
+                rec.timer_reset()
+                rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
+                build_ms = rec.timers()["coeff_build"][0]
+                rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
+                done[0] = 0                                           # the same schedule from the same EM state as above
+                em_reinit()
+                for i in range(args.warmup):
+                    step()
+                on = rec.get_option("coeff_table") == 1               # it switches itself off when it does not fit the free memory
+                rec.timer_reset()
+                barrier()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    step()
+                barrier()
+                dt2 = time.perf_counter() - t1
+                tm2 = rec.timers()
+                if multi:
+                    dt2 = float(comm.allreduce_max(np.array([dt2]))[0])
+                    on = bool(comm.allreduce_min(np.array([1.0 if on else 0.0]))[0] > 0.5)
+                tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 16 * 1024.0, "build_ms": build_ms}
+                rec.set_option("coeff_table", 0)
+            except Exception as ex:                              # the headline line must still be printed
+                if multi:
+                    raise                                         # (a rank that carried on alone would leave the others in a barrier)
+                tab = None
+                if rank == 0:
+                    print(f"note: the coefficient-table measurement failed: {ex!r}", file=sys.stderr)
+                try:
+                    rec.set_option("coeff_table", 0)
+                except Exception:
+                    pass
+
+        state["comm"], state["rccl_world"] = comm, rccl_world
+        try:
+            uc = rec.unit_counts()
+        except Exception:
+            uc = None
+        # launches that left the cell path (svr_fallbacks): a non-zero entry on a benchmarked workload means float atomics (a scatter) or
+        # the slower tile kernels took over without the line's kernel names saying so -- summed over the ranks
+        fb = rec.fallbacks()
+        if multi:
+            fbv = comm.allreduce_sum(np.array([float(fb[k]) for k in sorted(fb)]))
+            fb = {k: int(round(x)) for k, x in zip(sorted(fb), fbv)}
+        return dict(prob=prob, pvr=pvr, rec=rec, drv=drv, local=local, lo=lo, hi=hi, dt=dt, timers=timers, cnt=cnt, ranks=ranks, va=va, tuned=tuned,
+                    tab=tab, order=order, unit_counts=uc, cell_order=rec.get_option("cell_order"), fallbacks=fb)
+
+    m = measure(args.workload, not args.no_coeff_table)
+    prob, pvr, rec, dt, timers, cnt, ranks, va, tuned, tab = (m[k] for k in ("prob", "pvr", "rec", "dt", "timers", "cnt", "ranks", "va", "tuned", "tab"))
+    unit_counts, cell_order, fallbacks = m["unit_counts"], m["cell_order"], m["fallbacks"]
+    comm, rccl_world = state["comm"], state["rccl_world"]
+    # ---- BASELINE's multi-GPU target is quoted on S8 (configs[3]: 8 stacks of 64 x 256^2, 0.75 mm), the metric on P4: every line also
+    # carries an "s8" record measured in the SAME launch after the headline -- same ranks, same communicator (svr_comm_rebind), same
+    # steps and warm-up -- so that a scaling run of the default command answers the S8 question as well.  The headline is unchanged.
+    s8 = None
+    if not args.no_s8 and args.workload == "P4":
+        del m
+        rec.close()
+        try:
+            m8 = measure("S8", False)
+            s8 = {"workload": f"S8: {int(m8['prob'].stack_index.max()) + 1} synthetic stacks, volume {tuple(m8['prob'].vsize)}, {m8['prob'].ns} slices of "
+                              f"{m8['prob'].slices.shape[2]}x{m8['prob'].slices.shape[1]}, recon {m8['prob'].vdim[0]:.3g} mm (BASELINE configs[3])",
+                  "value": m8["va"] / (m8["dt"] / max(args.steps, 1)) / 1e6, "unit": "MVoxels/s", "ms_per_step": m8["dt"] / max(args.steps, 1) * 1e3,
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "Va_total": m8["va"], "Nv": m8["cnt"]["Nv"], "slices": m8["prob"].ns,
+                  "ranks": m8["ranks"], "collective_bytes_sent": m8["ranks"]["collective_bytes_sent"],
+                  "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in m8["timers"].items()},
+                  "fallbacks": m8["fallbacks"],
+                  "note": "measured in the same launch after the headline workload, on the same ranks and the same communicator; on the fly (no coefficient table)"}
+            m8["rec"].close()
+        except Exception as ex:                                  # the headline line must still be printed
+            if multi:
+                raise
+            s8 = {"error": repr(ex)}
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -438,7 +498,7 @@ def main():
         flops = float(va_l) * taps * FLOPS_PER_TAP_FORMULA
         # taps actually evaluated: every tap of a live (pixel, plane) unit, the first tap of every row of a dead one
         try:
-            uc = rec.unit_counts()
+            uc = unit_counts
             nsup = 12 if pvr else 16
             taps_exec = (uc["live_units"] * nsup * nsup + uc["dead_units"] * nsup) / max(uc["pixels"], 1)
             dead_share = uc["dead_units"] / max(uc["live_units"] + uc["dead_units"], 1)
@@ -502,11 +562,12 @@ def main():
                        "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",
                                  "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "fwd_mode": tuned["fwd_mode"],
                                  "cell": f"{tuned['cell_w']}x{tuned['cell_h']}", "gather_cell": f"{tuned['cell_gw']}x{tuned['cell_gh']}", "pin": os.environ.get("SVR_TILE_PIN"),
-                                 "cell_order": rec.get_option("cell_order"),
+                                 "cell_order": cell_order, "fallbacks": fallbacks,
                                  "note": "nothing is picked by timing (fwd_autotune 0): cell sizes and tile shapes follow from the geometry, the (cell, plane) items "
                                          "are launched in order of falling work; runs repeat bit for bit.  The tile shapes apply to pass 1 of the Gaussian "
                                          "reconstruction, the coefficient table's gather and the fallback modes"}},
             "ranks": ranks,
+            "s8": s8,
             "roofline": roof,
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in timers.items()},
         }
@@ -514,11 +575,16 @@ def main():
         up_ms, up_n = timers["regularize"]
         if up_n:
             up_avg = up_ms / up_n * 1e-3
+            slab = bool(timers["reduce_scatter"][1])
+            # the roofline figure only where the timer holds the update kernel alone on the whole volume: in a slab run it also covers the
+            # unpack / memset / pack kernels around it and 1 / N of the planes, and whole-volume bytes over it would overstate the rate N-fold
             out["update"] = {"kernel": "k_regul_fused (csrc/svr_regul.inc: Prep + regulariser in one pass, LDS plane ring, float32 rsq weights)"
-                                       + (" on this rank's z-slab (csrc/svr_slab.inc)" if timers["reduce_scatter"][1] else ""),
-                             "bound": "hbm", "algorithmic_bytes": 24.0 * nv, "avg_launch_ms": up_avg * 1e3,
-                             "achieved": 24.0 * nv / up_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 24.0 * nv / up_avg / 1e9 / HBM_PEAK_GBS,
-                             "note": "whole-volume algorithmic bytes over the launch time (a sharded rank updates 1 / N of the planes); round 3: frac 0.05"}
+                                       + (" on this rank's z-slab, with the slab update's unpack and pack kernels (csrc/svr_slab.inc)" if slab else ""),
+                             "bound": "hbm", "algorithmic_bytes": None if slab else 24.0 * nv, "avg_launch_ms": up_avg * 1e3,
+                             "achieved": None if slab else 24.0 * nv / up_avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": None if slab else 24.0 * nv / up_avg / 1e9 / HBM_PEAK_GBS,
+                             "note": "whole-volume algorithmic bytes (SURVEY 8d: 24 B per voxel) over the launch time; not computed for a slab run (N > 1 or "
+                                     "--force-comm): the timer then covers 1 / N of the planes plus the unpack / pack kernels"}
         if tab is not None:
             bp2, fw2 = tab["timers"]["backproject"], tab["timers"]["forward"]
             bp2a, fw2a = bp2[0] / max(bp2[1], 1) * 1e-3, fw2[0] / max(fw2[1], 1) * 1e-3

@@ -23,6 +23,7 @@
 #include <future>
 
 #include "svr_prep.h"
+#include "svr_shard.h"
 #include "svr_slic.h"
 
 namespace {
@@ -507,40 +508,39 @@ int main(int argc, char **argv) {
   if (dry_run) return false;
   first_level = false;
 
-  // ---- ranks: one engine context per device of -d, the patches sharded over them in contiguous ranges of the global
-  // numbering (stack after stack) balanced by the pixels that carry data, weighted by orientation.  The reference's patch-based path is single-GPU
-  // (patchBasedReconMain.cpp:78,177-179, irtkPatchBasedReconstruction.cpp:402); SURVEY 8e: "identical with patches as the unit"
+  // ---- ranks: one engine context per device of -d.  Rank r takes the r-th of nr work-balanced segments of EVERY stack's patches
+  // (svr_shard.h spatial_order: a rank's patches are neighbours in space), work = the pixels that carry data, weighted by orientation.
+  // From here on the per-patch arrays are in the SHARDED numbering (rank after rank); order[k] = patch k's index in the global numbering
+  // (stack after stack), which the host object keeps using where the reference's arithmetic depends on it (pvrh_set_unit_order).  The
+  // reference's patch-based path is single-GPU (patchBasedReconMain.cpp:78,177-179, irtkPatchBasedReconstruction.cpp:402); SURVEY 8e:
+  // "identical with patches as the unit"
   const int nr = (int)std::max<size_t>(1, devices.size());
   if (ns < nr) die("fewer patches than devices");
-  std::vector<int> rlo(nr, 0), rhi(nr, ns);
-  {
-    std::vector<double> cum(ns + 1, 0.0);
+  std::vector<int> rlo(nr, 0), rhi(nr, ns), order;
+  if (nr > 1) {
+    std::vector<double> work(ns, 0.0);
     const size_t pp = (size_t)px * py;
     parallel_for(ns, [&](int q) {
       long c = 0;
       for (size_t i = 0; i < pp; ++i) c += P.data[(size_t)q * pp + i] > 0.0f;
       // a patch whose normal is the volume's x axis costs more per pixel (its runs span a band of centre planes, csrc/svr_cell.inc;
-      // measured per rank: tools/shard_probe.py, reconstruction.py slice_cost_weights): x (1 + 0.2 n_x^2)
+      // measured per rank: tools/shard_probe.py, sharding.py slice_cost_weights): x (1 + 0.2 n_x^2)
       const M4 rw = world_to_image(tattr);
       double nw[3], nt[3], nv[3], len = 0;
       for (int k = 0; k < 3; ++k) nw[k] = P.i2w[16 * (size_t)q + 4 * k + 2];
       for (int k = 0; k < 3; ++k) nt[k] = st[16 * (size_t)q + 4 * k] * nw[0] + st[16 * (size_t)q + 4 * k + 1] * nw[1] + st[16 * (size_t)q + 4 * k + 2] * nw[2];
       for (int k = 0; k < 3; ++k) { nv[k] = rw.m[4 * k] * nt[0] + rw.m[4 * k + 1] * nt[1] + rw.m[4 * k + 2] * nt[2]; len += nv[k] * nv[k]; }
       const double ax2 = len > 0 ? nv[0] * nv[0] / len : 0.0;
-      cum[q + 1] = (double)c * (1.0 + 0.2 * ax2);
+      work[q] = (double)c * (1.0 + 0.2 * ax2);
     });
-    for (int q = 0; q < ns; ++q) cum[q + 1] += cum[q];
-    int at = 0;
-    for (int r = 0; r < nr; ++r) {
-      rlo[r] = at;
-      if (r == nr - 1) at = ns;
-      else {
-        const double want = cum[ns] * (r + 1) / nr;
-        while (at < ns - (nr - 1 - r) && cum[at] < want) ++at;
-        at = std::max(at, rlo[r] + 1);
-      }
-      rhi[r] = std::min(at, ns);
-    }
+    std::vector<int> stack_of;
+    for (size_t k = 0; k < counts.size(); ++k) stack_of.insert(stack_of.end(), counts[k], (int)k);
+    svr::spatial_order(work, stack_of, nr, order, rlo, rhi);
+    for (int r = 0; r < nr; ++r) if (rhi[r] <= rlo[r]) die("a device would get no patch: fewer devices, please");
+    svr::permute_rows(P.data, pp, order);
+    svr::permute_rows(P.i2w, 16, order); svr::permute_rows(P.w2i, 16, order); svr::permute_rows(P.attr, 1, order);
+    if (superpixel) svr::permute_rows(spx_masks, 4096, order);
+    svr::permute_rows(st, 16, order); svr::permute_rows(sti, 16, order); svr::permute_rows(dims, 3, order); svr::permute_rows(Td, 16, order);
   }
   std::vector<svr_ctx *> ctxs(nr, nullptr);
   std::vector<pvrh_recon *> hosts(nr, nullptr);
@@ -598,6 +598,7 @@ int main(int argc, char **argv) {
     hosts[r] = pvrh_create_sharded(ctxs[r], counts.data(), (int)counts.size(), vmin, vmax, rlo[r], rhi[r],
                                    group ? svr_group_join(group, r, ctxs[r]) : nullptr);
     if (!hosts[r]) die("pvrh_create_sharded failed" + std::string(group ? " (the rank group could not be joined)" : ""));
+    if (nr > 1 && pvrh_set_unit_order(hosts[r], order.data())) die("pvrh_set_unit_order failed");
   });
   if (nr > 1)
     fprintf(stderr, "%d ranks on devices%s, patches per rank%s, collectives: %s\n", nr,

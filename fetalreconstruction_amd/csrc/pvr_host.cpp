@@ -36,6 +36,22 @@ class irtkPatchBasedReconstruction {
   std::vector<float> scale, patch_weight, patch_potential;
   Shard sh;
   int lo, hi;
+  // order[k] = the reference's index (stack after stack) of patch k of this object's numbering; empty = the same numbering
+  // (pvrh_set_unit_order; csrc/svr_host.cpp has the why).  The patch-level EM -- sums in patch order, and the reference's within-stack
+  // indexing of the potentials (PRS.cu:256-276), which only means something in its own numbering -- runs in the reference's order.
+  std::vector<int> order;
+  std::vector<float> to_ref(const std::vector<float> &v) const {
+    if (order.empty()) return v;
+    std::vector<float> r(v.size());
+    for (size_t k = 0; k < v.size(); ++k) r[order[k]] = v[k];
+    return r;
+  }
+  std::vector<float> from_ref(const std::vector<float> &r) const {
+    if (order.empty()) return r;
+    std::vector<float> v(r.size());
+    for (size_t k = 0; k < r.size(); ++k) v[k] = r[order[k]];
+    return v;
+  }
   bool scale_stale = false;            // the other ranks' scales arrive with the next exchange (the E-step's)
 
   irtkPatchBasedReconstruction(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_i, float max_i, int lo_ = 0,
@@ -150,11 +166,13 @@ class irtkPatchBasedReconstruction {
     if (sh.on) { std::vector<double> none; if (int rc = exchange(nullptr, 0, none, &pot)) return rc; }   // (and the scale vector)
     std::vector<float> pp(n, 0.0f);
     int ofs = 0;
+    pot = to_ref(pot);                                                       // from here on in the reference's patch order
+    const std::vector<float> scale = to_ref(this->scale);
+    std::vector<float> pw = to_ref(patch_weight);
     for (int c : counts) {                                                   // :256-276: no stack offset on the left
       for (int j = 0; j < c; ++j) pp[j] = pot[ofs + j];
       ofs += c;
     }
-    std::vector<float> &pw = patch_weight;
     for (int i = 0; i < n; ++i)
       if (scale[i] < 0.2 || scale[i] > 5) pp[i] = -1;                       // :307-311
     double sum = 0, den = 0, sum2 = 0, den2 = 0, maxs = 0, mins = 1;
@@ -210,8 +228,9 @@ class irtkPatchBasedReconstruction {
     for (int i = 0; i < n; ++i)
       if (pp[i] >= 0) { sum += pw[i]; num++; }
     m_mix_s_gpu = num > 0 ? (float)(sum / num) : 0.9f;                       // :455-468
-    patch_potential = pp;
-    PENG(svr_update_scale_vector(e, scale.data() + lo, patch_weight.data() + lo));     // copyToWeightsAndScales :486-491
+    patch_potential = from_ref(pp);
+    patch_weight = from_ref(pw);
+    PENG(svr_update_scale_vector(e, this->scale.data() + lo, patch_weight.data() + lo));     // copyToWeightsAndScales :486-491
     return 0;
   }
 
@@ -323,8 +342,22 @@ pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, i
   long total = 0;
   for (int k = 0; k < n_stacks; ++k) total += patches_per_stack[k];
   if (patch_lo < 0 || patch_hi < patch_lo || patch_hi > total) return nullptr;
+  if (coll && coll->struct_size < SVR_COLLECTIVES_MIN_SIZE) return nullptr;
   if (coll && coll->world > 1 && (!coll->allreduce_volume_pair || !coll->allreduce_host)) return nullptr;
   return new pvrh_recon(engine, patches_per_stack, n_stacks, min_intensity, max_intensity, patch_lo, patch_hi, coll);
+}
+int pvrh_set_unit_order(pvrh_recon *r, const int *order_or_null) {
+  if (!r) return SVR_E_ARG;
+  svr::irtkPatchBasedReconstruction &m = r->impl;
+  if (!order_or_null) { m.order.clear(); return SVR_OK; }
+  std::vector<char> seen(m.n, 0);
+  for (int k = 0; k < m.n; ++k) {
+    const int i = order_or_null[k];
+    if (i < 0 || i >= m.n || seen[i]) { m.err = "pvrh_set_unit_order: not a permutation of the patches"; return SVR_E_ARG; }
+    seen[i] = 1;
+  }
+  m.order.assign(order_or_null, order_or_null + m.n);
+  return SVR_OK;
 }
 void pvrh_force_collectives(pvrh_recon *r, int on) { if (r) { (void)r->impl.settle(); r->impl.sh.force(on != 0); } }
 void pvrh_set_slab_update(pvrh_recon *r, int on) { if (r) r->impl.sh.slabs = on != 0; }

@@ -25,6 +25,7 @@
 #include <future>
 
 #include "svr_prep.h"
+#include "svr_shard.h"
 
 
 int main(int argc, char **argv) {
@@ -251,18 +252,23 @@ int main(int argc, char **argv) {
   for (float f : factors) fprintf(stderr, " %.9g", f);
   fprintf(stderr, "\n");
 
-  // ---- ranks: one engine context per device of -d (main.cc:191), the slices sharded over them in contiguous ranges
-  // balanced by estimated PSF work = active pixels x (9.4 + live planes of the 16) x (1 + 0.2 n_x^2), see reconstruction.py slice_cost_weights;
-  // reconstruction_cuda2.cu:1413-1457 shards by slice count and drops the remainder) -----------------------------------
+  // ---- ranks: one engine context per device of -d (main.cc:191).  Rank r takes the r-th of nr work-balanced segments of EVERY stack
+  // (svr_shard.h spatial_order: a rank's slices are neighbours in space), work = estimated PSF work = active pixels x (9.4 + live
+  // planes of the 16) x (1 + 0.2 n_x^2), see sharding.py slice_cost_weights.  (reconstruction_cuda2.cu:1413-1457 shards by slice count
+  // in slice order and drops the remainder.)  From here on every per-slice array is in the SHARDED numbering -- rank after rank --
+  // and `order[k]` is slice k's index in the reference's order: files named by slice number (--tfolder, --debug), --force_exclude
+  // and the package registration, which works on whole stacks, go through it. -----------------------------------------------
   const int nr = (int)std::max<size_t>(1, devices.size());
-  std::vector<int> rlo(nr, 0), rhi(nr, ns);
-  {
-    std::vector<double> cum(ns + 1, 0.0);
+  std::vector<int> rlo(nr, 0), rhi(nr, ns), order(ns), inv_order(ns);
+  for (int s = 0; s < ns; ++s) order[s] = inv_order[s] = s;
+  if (nr > 1) {
+    if (ns < nr) die("fewer slices than devices");
+    std::vector<double> work(ns, 0.0);
+    const M4 rw = world_to_image(tattr);
     for (int s = 0; s < ns; ++s) {
       long c = 0;
       for (size_t i = 0; i < (size_t)mx * my; ++i) c += grid[(size_t)s * mx * my + i] != -1.0f;
       // slice normal in volume axes: reconW2I * T * sliceI2W applied to the slice's z direction
-      const M4 rw = world_to_image(tattr);
       double nw[3], nt[3], nv[3], len = 0;
       for (int k = 0; k < 3; ++k) nw[k] = i2w[16 * (size_t)s + 4 * k + 2];
       for (int k = 0; k < 3; ++k) nt[k] = T[16 * (size_t)s + 4 * k] * nw[0] + T[16 * (size_t)s + 4 * k + 1] * nw[1] + T[16 * (size_t)s + 4 * k + 2] * nw[2];
@@ -271,20 +277,16 @@ int main(int argc, char **argv) {
       const double ax = fabs(nv[0]) / len, ay = fabs(nv[1]) / len, az = fabs(nv[2]) / len;
       const double ne = std::max(ay, az), no = std::min(ay, az), sigma = dims[3 * (size_t)s + 2] / 2.3548 / tattr.dx;
       const double live = std::min(16.0, 2.0 * (5.1 * sigma + 8.0 * (ax + no)) / std::max(ne, 1e-3) + 1.0);
-      cum[s + 1] = cum[s] + (double)c * (9.4 + live) * (1.0 + 0.2 * ax * ax);
+      work[s] = (double)c * (9.4 + live) * (1.0 + 0.2 * ax * ax);
     }
-    int at = 0;
-    for (int r = 0; r < nr; ++r) {
-      rlo[r] = at;
-      if (r == nr - 1) at = ns;
-      else {
-        const double want = cum[ns] * (r + 1) / nr;
-        while (at < ns - (nr - 1 - r) && cum[at] < want) ++at;
-        at = std::max(at, rlo[r] + 1);
-      }
-      rhi[r] = std::min(at, ns);
-    }
-    if (ns < nr) die("fewer slices than devices");
+    svr::spatial_order(work, stack_index, nr, order, rlo, rhi);
+    for (int r = 0; r < nr; ++r) if (rhi[r] <= rlo[r]) die("a device would get no slice: fewer devices, please");
+    for (int k = 0; k < ns; ++k) inv_order[order[k]] = k;
+    svr::permute_rows(grid, (size_t)mx * my, order);
+    svr::permute_rows(i2w, 16, order); svr::permute_rows(w2i, 16, order); svr::permute_rows(st, 16, order); svr::permute_rows(sti, 16, order);
+    svr::permute_rows(dims, 3, order); svr::permute_rows(sizes_x, 1, order); svr::permute_rows(sizes_y, 1, order);
+    svr::permute_rows(stack_index, 1, order); svr::permute_rows(sattr, 1, order); svr::permute_rows(T, 16, order);
+    for (int &s : force_excluded) if (s >= 0 && s < ns) s = inv_order[s];
   }
   need_ctx();
   std::vector<svr_ctx *> ctxs(nr, nullptr);
@@ -340,6 +342,7 @@ int main(int argc, char **argv) {
     if (!hosts[r]) die("svrh_create failed");
     svrh_set_intensity_range(hosts[r], vmin, vmax);                      // InitializeEMGPU RG.cc:2937-2951
     svrh_set_intensity_matching(hosts[r], no_matching ? 0 : 1);         // main.cc:1018, 1062
+    if (nr > 1 && svrh_set_unit_order(hosts[r], order.data())) die("svrh_set_unit_order failed");
     if (!force_excluded.empty()) svrh_set_force_excluded(hosts[r], force_excluded.data(), (int)force_excluded.size());
     if (use_gpu_reg) HOSTR(r, svrh_prepare_registration_slices(hosts[r], grid.data() + o * mx * my, mx, my, sattr.data() + o, resolution));
   });
@@ -360,7 +363,7 @@ int main(int argc, char **argv) {
     for (int s = 0; s < ns; ++s) {
       double p6[6];
       char e[256] = {0};
-      const std::string path = tfolder + "/transformation" + std::to_string(s) + ".dof";
+      const std::string path = tfolder + "/transformation" + std::to_string(order[s]) + ".dof";       // (files are named in the reference's slice order)
       if (svr_dof_read(path.c_str(), p6, &T[16 * (size_t)s], e)) die(path + ": " + e);
     }
     update_matrices_from_T();
@@ -379,9 +382,11 @@ int main(int argc, char **argv) {
       ENG(svr_sync_cpu(ctx, vol.data()));
       long evals = 0;
       char e[256] = {0};
+      svr::unpermute_rows(T, 16, order);                                   // (packages are sub-stacks: one transformation per slice, stack after stack)
       if (svrh_package_to_volume(ctx, nullptr, (int)n, at.data(), ptr.data(), packages.data(), it >= 2, it >= 3, it >= 4 ? it - 2 : 1, T.data(),
                                  &tattr, vol.data(), &evals, e))
         die(std::string("package-to-volume registration: ") + e);
+      svr::permute_rows(T, 16, order);
       fprintf(stderr, "package-to-volume registration: %ld similarity evaluations\n", evals);
       slice_reg = it >= 4;
       if (!slice_reg) update_matrices_from_T();
@@ -435,7 +440,7 @@ int main(int argc, char **argv) {
       double p6[6];
       svrh_irtk_rigid_parameters(&T[16 * (size_t)s], p6, nullptr);
       char e[256] = {0};
-      const std::string path = folder + "/transformation" + std::to_string(s) + ".dof";
+      const std::string path = folder + "/transformation" + std::to_string(order[s]) + ".dof";
       if (svr_dof_write(path.c_str(), p6, e)) die(path + ": " + e);
     }
   }

@@ -2891,6 +2891,14 @@ struct svr_ctx {
   int dbg_fwd_lds = 0;      // dev experiment: extra dynamic LDS on the forward launch (limits occupancy)
   uint32_t n_tiles_fb = 0;
   uint32_t n_tiles_fb8 = 0;   // tiles of the last scatter that the wave-owned kernel handed to the workgroup kernel (box larger than wave_cap)
+  // PSF launches that were asked for on the cell path (back_mode 5 / fwd_mode 2: no atomics, bit-identical from run to run) and left it
+  // because the cell lists cannot hold the geometry (svr_cell.inc cell_prepare: `usable`): [0] scatters (-> back_mode 4: float atomics,
+  // run-dependent last bits), [1] gathers, [2] pass 1 of the Gaussian reconstruction (-> the tile kernels: same bits, slower);
+  // [3] tiles of tiled scatters re-run by a workgroup kernel.  svr_fallbacks() reads them; the first of each kind says so on stderr.
+  uint64_t fallbacks[4] = {0, 0, 0, 0};
+  void note_fallback(int kind, const char *what) {
+    if (!fallbacks[kind]++) fprintf(stderr, "svr: %s -- counted in svr_fallbacks()[%d]\n", what, kind);
+  }
   uint32_t *d_tiles_fb2 = nullptr;
   bool wave_cap_user = false;
   bool back_mode_user = false;   // svr_set_option("back_mode") was called: no automatic choice between 5 and 4
@@ -2950,7 +2958,7 @@ struct svr_ctx {
   int cellc_range[16] = {0};
   int cell_w = 0, cell_h = 0, cell_gw = 0, cell_gh = 0;   // 0: by the pixel density (cell_auto_size); cell_gw / cell_gh: the gather's own
   int cell_order = 1;       // > 0: items in order of falling work, in classes of 2^(cell_order - 1) pixels (0: (cell, plane) order)
-  int cell_combine = 1;     // 1: the combine asks for a voxel's slabs in two batches (k_cell_combine_fast), 0: the general form (same bits)
+  int cell_combine = 2;     // 2: one item_of load per wavefront and class, early out where nothing is staged (k_cell_combine_wave); 1: a voxel's slabs in two batches (k_cell_combine_fast); 0: the general form.  Same bits
   int cell_balance = 0;     // an item heavier than the launch's work / (1024 x cell_balance) is cut into parts (0: never)
   int cell_split = 1, cell_qx = 1, cell_band = 3;   // cell_qx: cells of a quad along x (1, 2 or 4; the other factor along the lane axis)
 
@@ -3486,6 +3494,7 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
       }
     }
     ctx->n_tiles_fb8 = ncur;
+    ctx->fallbacks[3] += ncur;
   }
   if (ncur && level >= 3) {
     ta.tiles = cur; ta.ntiles = ncur; ta.cap = ctx->tile_cap;
@@ -3707,7 +3716,7 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     cell_invalidate(ctx);
     return SVR_OK;
   }
-  if (!strcmp(name, "cell_combine")) { ctx->cell_combine = value ? 1 : 0; return SVR_OK; }
+  if (!strcmp(name, "cell_combine")) { if (value < 0 || value > 2) return fail(ctx, SVR_E_ARG, "cell_combine: 0, 1 or 2"); ctx->cell_combine = value; return SVR_OK; }
   if (!strcmp(name, "cell_balance")) {
     if (value < 0 || value > 1024) return fail(ctx, SVR_E_ARG, "cell_balance: 0..1024");
     ctx->cell_balance = value;
@@ -3877,6 +3886,7 @@ int svr_set_mask(svr_ctx *ctx, const uint32_t size[3], const float dim[3], const
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->have_mask = true;
   if (ctx->slab) ctx->slab->valid = false;
+  ctx->vol_clean[0] = ctx->vol_clean[1] = false;      // "zero outside the dilated mask" was a statement about the old mask
   ctx->mask_sigma_bias = sigma_bias;
   ctx->maskC_valid = false;
   {
@@ -4187,6 +4197,8 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       if (gcs && gcs->usable) {
         if ((r = launch_cell_gauss1(ctx, *gcs, a))) return r;
         pass1_cells = true;
+      } else {
+        ctx->note_fallback(2, "pass 1 of the Gaussian reconstruction left the cell path (the cell lists cannot hold this geometry): tile kernel, same bits");
       }
     }
     if (!pass1_cells) {
@@ -4208,6 +4220,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     if (back_mode_eff(ctx) == 5) {
       if ((r = cell_prepare(ctx))) return r;
       cells = ctx->cell->usable;
+      if (!cells) ctx->note_fallback(0, "the scatter left the cell path (the cell lists cannot hold this geometry): back_mode 4, float atomics, last bits depend on the run");
     }
     if (cells) r = launch_cell_scatter(ctx, a, 1, ctx->recon(), ctx->volw());
     else {
@@ -4317,6 +4330,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   if (ctx->fwd_mode == 2 && (!ctx->pvr || ctx->pvr_mode == 1) && (!a.coeff || table_on_cells) && a.n) {
     if ((r = cell_prepare_gather(ctx, gcs))) return r;
     cells = gcs->usable;
+    if (!cells) ctx->note_fallback(1, "the gather left the cell path (the cell lists cannot hold this geometry): tile kernel, same bits");
   }
   auto launch_forward = [&]() -> int {
     const bool tiled_ = ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1;
@@ -4807,6 +4821,7 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     if (back_mode_eff(ctx) == 5) {
       if ((r = cell_prepare(ctx))) return r;
       cells = ctx->cell->usable;
+      if (!cells) ctx->note_fallback(0, "the scatter left the cell path (the cell lists cannot hold this geometry): back_mode 4, float atomics, last bits depend on the run");
     }
     if (cells) r = launch_cell_scatter(ctx, a, 0, ctx->addon(), ctx->cmap());
     else if (!(r = ensure_tiles_back(ctx))) r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, back_mode_eff(ctx)), a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
@@ -4912,6 +4927,9 @@ int svr_superresolution_update(svr_ctx *ctx, int adaptive, float alpha, float mi
   int r = superresolution_update_planes(ctx, adaptive, alpha, min_intensity, max_intensity, delta, lambda, 0, (int)ctx->vz);
   if (r) return r;
   ctx->recon_cur = ctx->recon_cur == ctx->d_recon_volw ? ctx->d_recon_new : ctx->d_recon_volw;   // the update wrote the other buffer
+  // a whole-volume update carries whatever the old volume held outside the dilated mask over into the buffer it wrote: the slab update
+  // (svr_slab.inc), which only writes inside it, must clear that buffer before it uses it next
+  ctx->vol_clean[ctx->recon_cur == ctx->d_recon_new ? 1 : 0] = false;
   t.stop();
   if (!ctx->sr_no_wait) HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
@@ -5119,6 +5137,7 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   if (which == SVR_BUF_SLICES) { ctx->coeff_valid = false; cell_invalidate(ctx); }   // the table and the cell lists cover the pixels with s != -1
   if (which == SVR_BUF_MASK) ctx->mbox_valid = false;                               // (a mask set behind svr_set_mask's back: the whole pair is exchanged)
   if (which == SVR_BUF_MASK && ctx->slab) ctx->slab->valid = false;
+  if (which == SVR_BUF_MASK) ctx->vol_clean[0] = ctx->vol_clean[1] = false;
   if (which == SVR_BUF_RECONSTRUCTED) ctx->vol_clean[ctx->recon_cur == ctx->d_recon_new ? 1 : 0] = false;
   if (which == SVR_BUF_ADDON || which == SVR_BUF_CONFIDENCE_MAP) ctx->cmap_from_scatter = false;   // (no longer known to vanish outside the mask)
   if (which == SVR_BUF_SLICES) return build_list(ctx, false);
@@ -5433,6 +5452,13 @@ int svr_timer_add(svr_ctx *ctx, int which, double ms) {
   if (ctx->timers) { ctx->t_ms[which] += ms; ctx->t_n[which] += 1; }
   return SVR_OK;
 }
+int svr_fallbacks(svr_ctx *ctx, uint64_t out4[4]) {
+  SVR_ENTER(ctx);
+  if (!ctx || !out4) return SVR_E_ARG;
+  for (int k = 0; k < 4; ++k) out4[k] = ctx->fallbacks[k];
+  return SVR_OK;
+}
+
 int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
   SVR_ENTER(ctx);
   if (!ctx || !out5) return SVR_E_ARG;

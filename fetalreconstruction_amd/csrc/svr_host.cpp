@@ -72,6 +72,25 @@ class irtkReconstruction {
 
   // -- sharding helpers ------------------------------------------------------------------
   const float *local(const std::vector<float> &v) const { return v.data() + lo; }
+  // The numbering of a sharded run need not be the reference's (svrh_set_unit_order): a launcher that deals the r-th part of EVERY
+  // stack to rank r (spatially compact shards, sharding.shard_units / csrc/svr_shard.h spatial_order) uploads the slices rank after
+  // rank.  order[k] = the reference's index of slice k of this object's numbering; empty = the same numbering.  Everything per slice is
+  // indifferent to the numbering; what the reference does ACROSS slices in slice order -- the sums of the slice-level EM -- is done in
+  // the reference's order (to_ref / from_ref), so a permuted run adds the same numbers in the same order as an unpermuted one.
+  std::vector<int> order;
+  template <class T> std::vector<T> to_ref(const std::vector<T> &v) const {
+    if (order.empty()) return v;
+    std::vector<T> r(v.size());
+    for (size_t k = 0; k < v.size(); ++k) r[order[k]] = v[k];
+    return r;
+  }
+  template <class T> std::vector<T> from_ref(const std::vector<T> &r) const {
+    if (order.empty()) return r;
+    std::vector<T> v(r.size());
+    for (size_t k = 0; k < r.size(); ++k) v[k] = r[order[k]];
+    return v;
+  }
+  int ref_index(int k) const { return order.empty() ? k : order[k]; }
   // The ns-sized vectors a rank has only its own part of (`_scale_stale`, `_inside_stale`) ride along with the next exchange
   // that every rank makes anyway (Shard::exchange: one collective): the M-step's sums, the E-step's potentials, the
   // robust-statistics sums.
@@ -233,13 +252,16 @@ class irtkReconstruction {
       if (int rc = settle()) return rc;
       ENG(svr_estep(reconstructionGPU, _m_gpu, _sigma_gpu, _mix_gpu, loc.data()));
     }
-    std::vector<float> &slice_potential_gpu = _slice_potential_gpu;
-    slice_potential_gpu.assign(ns, 0.0f);
-    std::copy(loc.begin(), loc.end(), slice_potential_gpu.begin() + lo);
-    if (sh.on) { std::vector<double> none; ENG(exchange(nullptr, 0, none, &slice_potential_gpu)); }   // (and the scale vector)
+    _slice_potential_gpu.assign(ns, 0.0f);
+    std::copy(loc.begin(), loc.end(), _slice_potential_gpu.begin() + lo);
+    if (sh.on) { std::vector<double> none; ENG(exchange(nullptr, 0, none, &_slice_potential_gpu)); }   // (and the scale vector)
+    // from here on in the reference's slice order (identity unless svrh_set_unit_order): RG.cc:3282-3420 op for op
+    std::vector<float> slice_potential_gpu = to_ref(_slice_potential_gpu);
+    const std::vector<float> _scale_gpu = to_ref(this->_scale_gpu);
+    std::vector<float> _slice_weight_gpu = to_ref(this->_slice_weight_gpu);
     int inputIndex;
-    for (size_t i = 0; i < _force_excluded.size(); i++) slice_potential_gpu[_force_excluded[i]] = -1;
-    for (size_t i = 0; i < _small_slices.size(); i++) slice_potential_gpu[_small_slices[i]] = -1;
+    for (size_t i = 0; i < _force_excluded.size(); i++) slice_potential_gpu[ref_index(_force_excluded[i])] = -1;
+    for (size_t i = 0; i < _small_slices.size(); i++) slice_potential_gpu[ref_index(_small_slices[i])] = -1;
     for (inputIndex = 0; inputIndex < ns; inputIndex++)
       if ((_scale_gpu[inputIndex] < 0.2) || (_scale_gpu[inputIndex] > 5)) slice_potential_gpu[inputIndex] = -1;
 
@@ -305,7 +327,9 @@ class irtkReconstruction {
       if (slice_potential_gpu[inputIndex] >= 0) { sum += _slice_weight_gpu[inputIndex]; num++; }
     if (num > 0) _mix_s_gpu = (float)(sum / num);
     else _mix_s_gpu = 0.9f;
-    ENG(svr_update_slice_weights(reconstructionGPU, local(_slice_weight_gpu)));
+    this->_slice_weight_gpu = from_ref(_slice_weight_gpu);
+    _slice_potential_gpu = from_ref(slice_potential_gpu);
+    ENG(svr_update_slice_weights(reconstructionGPU, local(this->_slice_weight_gpu)));
     return 0;
   }
 
@@ -580,6 +604,7 @@ extern "C" {
 svrh_recon *svrh_create(svr_ctx *engine, int n_slices_global, int slice_lo, int slice_hi,
                         const svr_collectives *coll) {
   if (!engine || n_slices_global <= 0 || slice_lo < 0 || slice_hi > n_slices_global || slice_lo > slice_hi) return nullptr;
+  if (coll && coll->struct_size < SVR_COLLECTIVES_MIN_SIZE) return nullptr;      // (a launcher built against the struct of rounds 1-4)
   if (coll && coll->world > 1 && (!coll->allreduce_volume_pair || !coll->allreduce_host || !coll->allgather_slices))
     return nullptr;
   return new svrh_recon(engine, n_slices_global, slice_lo, slice_hi, coll);
@@ -626,6 +651,19 @@ int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_nul
   return 0;
 }
 
+int svrh_set_unit_order(svrh_recon *r, const int *order_or_null) {
+  if (!r) return SVR_E_ARG;
+  svr::irtkReconstruction &m = r->impl;
+  if (!order_or_null) { m.order.clear(); return SVR_OK; }
+  std::vector<char> seen(m.ns, 0);
+  for (int k = 0; k < m.ns; ++k) {
+    const int i = order_or_null[k];
+    if (i < 0 || i >= m.ns || seen[i]) { m.err = "svrh_set_unit_order: not a permutation of the slices"; return SVR_E_ARG; }
+    seen[i] = 1;
+  }
+  m.order.assign(order_or_null, order_or_null + m.ns);
+  return SVR_OK;
+}
 void svrh_force_collectives(svrh_recon *r, int on) { if (r) { (void)r->impl.settle(); r->impl.sh.force(on != 0); } }
 void svrh_set_slab_update(svrh_recon *r, int on) { if (r) r->impl.sh.slabs = on != 0; }
 

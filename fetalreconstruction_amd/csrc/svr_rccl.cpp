@@ -213,6 +213,7 @@ svr_comm *svr_comm_create(int rank, int world, const char id128[128], svr_ctx *e
     delete c;
     return nullptr;
   }
+  c->coll.struct_size = sizeof(svr_collectives);
   c->coll.user = c;
   c->coll.rank = rank;
   c->coll.world = world;
@@ -223,6 +224,18 @@ svr_comm *svr_comm_create(int rank, int world, const char id128[128], svr_ctx *e
   c->coll.allgather_device = cb_allgather_device;
   c->coll.on_engine_stream = 1;
   return c;
+}
+
+/* the same communicator for another engine context on the SAME device: its collectives run on that engine's stream from now on
+ * (bench.py measures a second workload in the same launch, on the same ranks and the same communicator) */
+int svr_comm_rebind(svr_comm *c, svr_ctx *engine) {
+  if (!c || !engine) return 1;
+  if (svr_device(engine) != c->device) return cfail(c, "svr_comm_rebind: the engine lives on another device");
+  if (hipSetDevice(c->device) != hipSuccess) return cfail(c, "svr_comm_rebind: hipSetDevice");
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->stream = static_cast<hipStream_t>(svr_get_stream(engine));
+  c->counts.clear();
+  return 0;
 }
 
 const svr_collectives *svr_comm_collectives(svr_comm *c) { return c ? &c->coll : nullptr; }
@@ -440,6 +453,7 @@ const svr_collectives *svr_group_join(svr_group *g, int rank, svr_ctx *engine) {
   if (!g || rank < 0 || rank >= g->world || !engine || g->world == 1) return nullptr;
   svr_group::Member &m = g->members[rank];
   m.g = g; m.rank = rank; m.engine = engine;
+  m.coll.struct_size = sizeof(svr_collectives);
   m.coll.user = &m; m.coll.rank = rank; m.coll.world = g->world;
   if (g->rccl) {
     // the volume pairs over RCCL on the engine's stream; the small host vectors through the memory the rank threads share

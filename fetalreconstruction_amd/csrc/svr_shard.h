@@ -8,13 +8,75 @@
 #ifndef SVR_SHARD_H
 #define SVR_SHARD_H
 
+#include <math.h>
+
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/svr_host.h"
 
 namespace svr {
+
+// The numbering of a sharded run and every rank's range of it (the launchers: csrc/svr_cli.cpp, csrc/pvr_cli.cpp; bench.py does the
+// same through fetalreconstruction_amd/sharding.py shard_units, operation for operation).  work[i], stack[i]: estimated PSF work and
+// stack of unit i in the reference's order (stack after stack).  Rank r takes the r-th of `world` work-balanced segments of EVERY
+// stack: a rank's units are neighbours in space, so it touches about 1 / world of the volume's (cell, plane) items per stack
+// orientation instead of all the items of the stacks it holds (less to stage, less to combine: csrc/svr_cell.inc), and every rank
+// holds the same mix of orientations.  The cut points of a stack are placed against the running total over the stacks before it, so
+// the ranks' totals differ by about one unit's work whatever the number of stacks.  order[k] = reference index of unit k of the
+// sharded numbering (rank after rank; inside a rank stack after stack), [lo[r], hi[r]) = rank r's range of it.
+// (The reference shards by slice count in slice order and drops the remainder: reconstruction_cuda2.cu:1413-1457.)
+inline void spatial_order(const std::vector<double> &work, const std::vector<int> &stack, int world, std::vector<int> &order, std::vector<int> &lo,
+                          std::vector<int> &hi) {
+  const int n = (int)work.size();
+  std::vector<std::vector<int>> parts(world);
+  std::vector<double> done(world + 1, 0.0);
+  double total = 0.0;
+  int at = 0;
+  while (at < n) {
+    int end = at;
+    while (end < n && stack[end] == stack[at]) ++end;                  // the units of one stack: [at, end)
+    const int m = end - at;
+    std::vector<double> cum(m + 1, 0.0);
+    for (int i = 0; i < m; ++i) cum[i + 1] = cum[i] + (work[at + i] + 1e-9);
+    total += cum[m];
+    std::vector<int> cuts(1, 0);
+    for (int r = 1; r < world; ++r) {
+      const double want = total * r / world - done[r];
+      int b = 0;
+      double best = fabs(cum[0] - want);
+      for (int i = 1; i <= m; ++i) { const double d = fabs(cum[i] - want); if (d < best) { best = d; b = i; } }
+      b = std::min(std::max(b, cuts.back()), m);
+      cuts.push_back(b);
+    }
+    cuts.push_back(m);
+    for (int r = 0; r < world; ++r) {
+      for (int i = cuts[r]; i < cuts[r + 1]; ++i) parts[r].push_back(at + i);
+      done[r + 1] += cum[cuts[r + 1]];
+    }
+    at = end;
+  }
+  order.clear(); lo.assign(world, 0); hi.assign(world, 0);
+  for (int r = 0; r < world; ++r) {
+    lo[r] = (int)order.size();
+    order.insert(order.end(), parts[r].begin(), parts[r].end());
+    hi[r] = (int)order.size();
+  }
+}
+// rows of `width` elements of a per-unit array, from the reference's order into the sharded numbering: out[k] = in[order[k]]
+template <class T> void permute_rows(std::vector<T> &v, size_t width, const std::vector<int> &order) {
+  std::vector<T> out(v.size());
+  for (size_t k = 0; k < order.size(); ++k) std::copy(v.begin() + (size_t)order[k] * width, v.begin() + ((size_t)order[k] + 1) * width, out.begin() + k * width);
+  v.swap(out);
+}
+template <class T> void unpermute_rows(std::vector<T> &v, size_t width, const std::vector<int> &order) {      // back: out[order[k]] = in[k]
+  std::vector<T> out(v.size());
+  for (size_t k = 0; k < order.size(); ++k) std::copy(v.begin() + k * width, v.begin() + (k + 1) * width, out.begin() + (size_t)order[k] * width);
+  v.swap(out);
+}
 
 struct Shard {
   svr_ctx *e = nullptr;
@@ -25,9 +87,11 @@ struct Shard {
   void init(svr_ctx *engine, int n_global, int lo_, int hi_, const svr_collectives *c) {
     e = engine; n = n_global; lo = lo_; hi = hi_;
     given = c != nullptr;
-    if (c) coll = *c;
-    else { coll.user = nullptr; coll.rank = 0; coll.world = 1; coll.allreduce_volume_pair = nullptr;
-           coll.allreduce_host = nullptr; coll.allgather_slices = nullptr; coll.reduce_scatter_device = nullptr; coll.allgather_device = nullptr; coll.on_engine_stream = 0; }
+    // the launcher's struct may be shorter than this build's (svr_collectives::struct_size): members it does not have are NULL / 0
+    memset(&coll, 0, sizeof(coll));
+    coll.world = 1;
+    if (c) memcpy(&coll, c, std::min(c->struct_size, sizeof(coll)));
+    coll.struct_size = sizeof(coll);
     on = given && coll.world > 1;
     if (const char *v = getenv("SVR_SLAB_UPDATE")) slabs = atoi(v) != 0;     // (tests: the two forms of the volume update side by side)
   }
@@ -61,7 +125,8 @@ struct Shard {
   // The volume update of an SR iteration (after svr_superresolution_backproject).  By z-slabs when the launcher supplies the two device
   // collectives: reduce-scatter of addon | cmap at the mask's voxels -> the rank's slab -> all-gather of the new volume
   // (csrc/svr_slab.inc: less than half the bytes of the all-reduce, and the update's time divides by the ranks).  Otherwise
-  // all-reduce of the pair + the update replicated on every rank.  Same bits either way.
+  // all-reduce of the pair + the update replicated on every rank (also when the engine's update is not the fused kernel, reg_mode 0, which
+  // only updates whole volumes).  Identical on every rank either way; bit-equal to each other with rank-ordered collectives.
   bool slabs = true;       // (svrh_set_slab_update / pvrh_set_slab_update: tests compare the two forms)
   // scatter + update of a sharded SR iteration; nothing waits for the device when the collectives run on the engine's stream
   int superresolution(const float *unit_weights, int adaptive, float alpha, float min_i, float max_i, float delta, float lambda) {
@@ -74,7 +139,9 @@ struct Shard {
   }
   int update(int adaptive, float alpha, float min_i, float max_i, float delta, float lambda) {
     int rc;
-    if (!(slabs && coll.reduce_scatter_device && coll.allgather_device)) {
+    int reg_mode = 1;
+    (void)svr_get_option(e, "reg_mode", &reg_mode);
+    if (!(slabs && coll.reduce_scatter_device && coll.allgather_device && reg_mode == 1)) {
       if ((rc = allreduce_pair(SVR_BUF_ADDON, 2 * svr_volume_voxels(e)))) return rc;
       return svr_superresolution_update(e, adaptive, alpha, min_i, max_i, delta, lambda);
     }

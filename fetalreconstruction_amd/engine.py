@@ -38,7 +38,7 @@ EXPORTS = [
     "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
-    "svr_unit_counts", "svr_cell_stats", "svr_pair_pack", "svr_pair_unpack", "svr_timer_reset", "svr_timer_enable", "svr_timer_begin", "svr_timer_end", "svr_timer_add", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
+    "svr_unit_counts", "svr_fallbacks", "svr_cell_stats", "svr_pair_pack", "svr_pair_unpack", "svr_timer_reset", "svr_timer_enable", "svr_timer_begin", "svr_timer_end", "svr_timer_add", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
     "svr_ncc_evaluate", "svr_ncc_alloc_targets", "svr_pyr_upload", "svr_pyr_level", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
@@ -484,6 +484,12 @@ class Reconstruction:
         self._ck(self._lib.svr_cell_stats(self._h, o))
         return dict(items=int(o[0]), runs=int(o[1]), sorted_pixels=int(o[2]), staging_bytes=int(o[3]), gather_items=int(o[4]),
                     gather_runs=int(o[5]), gather_partial_bytes=int(o[6]), cell=(int(o[7]) >> 32, int(o[7]) & 0xFFFFFFFF))
+
+    def fallbacks(self):
+        """launches that left the cell path since the context was made (svr_fallbacks): zeros on every bench workload"""
+        o = (C.c_uint64 * 4)()
+        self._ck(self._lib.svr_fallbacks(self._h, o))
+        return dict(scatter_to_atomics=int(o[0]), gather_to_tiles=int(o[1]), gauss1_to_tiles=int(o[2]), tiles_rerun=int(o[3]))
 
     def counters(self):
         o = (C.c_uint64 * 8)()

@@ -13,7 +13,7 @@ _AR_PAIR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _AR_HOST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int)
 
-COMM_EXPORTS = ["svr_comm_unique_id", "svr_comm_create", "svr_comm_collectives", "svr_comm_world", "svr_comm_allreduce_host",
+COMM_EXPORTS = ["svr_comm_unique_id", "svr_comm_create", "svr_comm_rebind", "svr_comm_collectives", "svr_comm_world", "svr_comm_allreduce_host",
                 "svr_comm_last_error", "svr_comm_destroy", "svr_group_create", "svr_group_uses_rccl", "svr_group_join", "svr_group_destroy"]                                                  # csrc/svr_rccl.cpp
 HOST_EXPORTS = [
     "svrh_create", "svrh_destroy", "svrh_last_error", "svrh_set_intensity_range", "svrh_set_intensity_matching", "svrh_set_smoothing_parameters",
@@ -22,11 +22,11 @@ HOST_EXPORTS = [
     "svrh_superresolution_gpu", "svrh_mstep_gpu", "svrh_mask_volume_gpu", "svrh_scale_volume_gpu",
     "svrh_sr_iteration", "svrh_reconstruct_iteration", "svrh_get_state", "svrh_set_bias_correction", "svrh_bias_gpu",
     "svrh_normalise_bias_gpu", "svrh_prepare_registration_slices", "svrh_slice_to_volume_registration_gpu",
-    "svrh_get_registration_slices", "svrh_force_collectives", "svrh_set_slab_update",
+    "svrh_get_registration_slices", "svrh_force_collectives", "svrh_set_slab_update", "svrh_set_unit_order",
 ]
 PVR_HOST_EXPORTS = ["pvrh_create", "pvrh_destroy", "pvrh_last_error", "pvrh_initialize_em_values", "pvrh_initialize_robust_statistics",
                     "pvrh_estep", "pvrh_mstep", "pvrh_scale", "pvrh_reconstruct_iteration", "pvrh_register_patches", "pvrh_get_state",
-                    "pvrh_create_sharded", "pvrh_force_collectives", "pvrh_set_slab_update", "pvrh_sr_iteration"]      # csrc/pvr_host.cpp
+                    "pvrh_create_sharded", "pvrh_force_collectives", "pvrh_set_slab_update", "pvrh_sr_iteration", "pvrh_set_unit_order"]      # csrc/pvr_host.cpp
 IRTK_EXPORTS = ["svrh_stack_registrations", "svrh_slice_to_volume_registration", "svrh_package_to_volume", "svrh_irtk_resample_with_padding",
                 "svrh_irtk_blur_with_padding", "svrh_irtk_rigid_parameters"]                                  # csrc/irtk_reg.cpp
 IO_EXPORTS = ["svr_nifti_read", "svr_nifti_write", "svr_free", "svr_dof_read", "svr_dof_write", "svr_host_threads"]      # csrc/svr_io.cpp, declared in svr_host.h
@@ -47,7 +47,8 @@ class ImageAttr(C.Structure):
 
 
 class _Coll(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("allreduce_volume_pair", _AR_PAIR),
+    _fields_ = [("struct_size", C.c_size_t),          # sizeof of the struct the launcher knows (include/svr_host.h)
+                ("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("allreduce_volume_pair", _AR_PAIR),
                 ("allreduce_host", _AR_HOST), ("allgather_slices", _AG),
                 # device-buffer reduce-scatter / all-gather of the slab update: not supplied by the torch.distributed callbacks (NULL ->
                 # all-reduce + replicated update); on_engine_stream 0: the C++ host synchronises the engine's stream before ar_pair
@@ -82,6 +83,12 @@ class RcclComm:
         self._h = C.c_void_p(h)
         self.collectives = C.c_void_p(self._lib.svr_comm_collectives(self._h))
         self._rec = rec                                   # the engine must outlive the communicator's use of its stream
+
+    def rebind(self, rec):
+        """the same communicator for another engine context on the same device (bench.py: a second workload in the same launch)"""
+        if self._lib.svr_comm_rebind(self._h, rec._h):
+            raise _engine.SvrError("svr_comm_rebind: " + self._lib.svr_comm_last_error(self._h).decode())
+        self._rec = rec
 
     def rccl_world(self):
         """the communicator's size as RCCL reports it (ncclCommCount)"""
@@ -175,7 +182,7 @@ class irtkReconstruction:
                     return 1
 
             self._cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag))     # keep the thunks alive
-            self._coll = _Coll(None, comm.rank, comm.world, *self._cbs, None, None, 0)
+            self._coll = _Coll(C.sizeof(_Coll), None, comm.rank, comm.world, *self._cbs, None, None, 0)
         if self._coll is not None:
             coll_ptr = C.byref(self._coll)
         h = self._lib.svrh_create(rec._h, self.ns, int(self.lo), int(self.hi), coll_ptr)
@@ -201,6 +208,12 @@ class irtkReconstruction:
 
     def SetSmoothingParameters(self, delta, lam):
         self._lib.svrh_set_smoothing_parameters(self._h, C.c_double(delta), C.c_double(lam))
+
+    def set_unit_order(self, order):
+        """order[k] = the reference's index of slice k of this object's numbering (sharding.shard_units); None = the same numbering"""
+        a = None if order is None else np.ascontiguousarray(order, np.int32)
+        assert a is None or len(a) == self.ns
+        self._ck(self._lib.svrh_set_unit_order(self._h, None if a is None else a.ctypes.data_as(C.c_void_p)))
 
     def SetIntensityMatching(self, on):
         self._lib.svrh_set_intensity_matching.restype = None
@@ -339,6 +352,12 @@ class irtkPatchBasedReconstruction:
     def _ck(self, rc):
         if rc != 0:
             raise _engine.SvrError(f"host status {rc}: {self._lib.pvrh_last_error(self._h).decode()}")
+
+    def set_unit_order(self, order):
+        """order[k] = the global (stack after stack) index of patch k of this object's numbering; None = the same numbering"""
+        a = None if order is None else np.ascontiguousarray(order, np.int32)
+        assert a is None or len(a) == self.n
+        self._ck(self._lib.pvrh_set_unit_order(self._h, None if a is None else a.ctypes.data_as(C.c_void_p)))
 
     def initializeEMValues(self):
         self._ck(self._lib.pvrh_initialize_em_values(self._h))

@@ -22,6 +22,62 @@ def shard_slices(active_per_slice, world):
     return [(bounds[i], bounds[i + 1]) for i in range(world)]
 
 
+DEFAULT_LAYOUT = "spatial"          # (SVR_SHARD_LAYOUT=contiguous brings the ranges of rounds 1-4 back: A/B measurements)
+
+
+def shard_units(work, stack_index, world, layout=None):
+    """-> (order, ranges): the numbering of a sharded run and every rank's contiguous range of it.
+
+    order[k] = index, in the reference's order (stack after stack, slice after slice), of unit k of the sharded numbering;
+    ranges[r] = (lo, hi) of that numbering.  The launcher uploads the units in the sharded numbering, tells the host objects `order`
+    (svrh_set_unit_order / pvrh_set_unit_order: whatever the host arithmetic does in the reference's order it keeps doing in that
+    order) and maps per-unit results back.
+
+    layout "contiguous": order = identity, ranges balanced by work (rounds 1-4; what the reference's own sharding looks like,
+    RC.cu:1413-1457).  layout "spatial" (round 5): rank r takes the r-th of `world` work-balanced segments of EVERY stack, so that
+    a rank's units are neighbours in space: it then touches about 1 / world of the volume's (cell, plane) items per stack
+    orientation instead of all the items of the stacks it holds -- less to stage and to combine per rank (csrc/svr_cell.inc), and
+    every rank holds the same mix of orientations.  The cut points of a stack are placed against the running total over the stacks
+    before it (error diffusion), so the ranks' totals differ by at most about one unit's work, whatever the number of stacks."""
+    import os
+    layout = layout or os.environ.get("SVR_SHARD_LAYOUT", DEFAULT_LAYOUT)
+    w = np.asarray(work, np.float64) + 1e-9
+    si = np.asarray(stack_index)
+    n = len(w)
+    if layout == "contiguous" or world <= 1:
+        return np.arange(n, dtype=np.int32), shard_slices(w, world)
+    if layout != "spatial":
+        raise ValueError(layout)
+    assert np.all(np.diff(si) >= 0), "units are expected stack after stack"
+    parts = [[] for _ in range(world)]
+    done = np.zeros(world + 1)                      # work handed out so far to the left of cut r, over the stacks so far
+    total = 0.0
+    for s in np.unique(si):
+        idx = np.nonzero(si == s)[0]
+        ws = w[idx]
+        cum = np.concatenate([[0.0], np.cumsum(ws)])
+        total += cum[-1]
+        cuts = [0]
+        for r in range(1, world):
+            # cut r of this stack: the running total to the left of cut r comes closest to r / world of the running total
+            want = total * r / world - done[r]
+            b = int(np.argmin(np.abs(cum - want)))
+            b = min(max(b, cuts[-1]), len(ws))
+            cuts.append(b)
+        cuts.append(len(ws))
+        for r in range(world):
+            parts[r].extend(idx[cuts[r]:cuts[r + 1]].tolist())
+            done[r + 1] += cum[cuts[r + 1]]
+        done[0] = 0.0
+    order = np.array([i for q in parts for i in q], dtype=np.int32)
+    ranges, at = [], 0
+    for q in parts:
+        ranges.append((at, at + len(q)))
+        at += len(q)
+    assert at == n and len(set(order.tolist())) == n
+    return order, ranges
+
+
 def patch_cost_weights(data_pixels_per_patch, patch_i2w, patch_t, recon_w2i):
     """Work of every patch for the sharding of the patch-based path: pixels that carry data x (1 + 0.2 n_x^2), n = the patch normal in
     volume axes (the same last factor as slice_cost_weights; csrc/pvr_cli.cpp does the same)."""

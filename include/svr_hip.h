@@ -366,6 +366,13 @@ int svr_counters(svr_ctx *ctx, uint64_t out8[8]);
  * evaluated), [2] dead units (every row provably below the epsilon of RC.cu:238: only its first tap is processed) -- what
  * bench.py's `flops_executed` counts */
 int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]);
+/* PSF launches since svr_create that were asked for on the cell path (back_mode 5 / fwd_mode 2: no float atomics, the same bits from run
+ * to run) and LEFT it because the cell lists cannot hold the geometry (centre coordinates beyond int16, more than 2^18 cells or 1024
+ * planes per class, slices of more than 2^20 pixels, more than 2^17 slices, a staging buffer that does not fit): out4 = {scatters that
+ * ran as back_mode 4 (float atomics: last bits depend on the run), gathers and Gaussian pass-1 launches that ran on the tile kernels
+ * (same bits, slower), tiles of tiled scatters re-run by a workgroup kernel}.  The first of each kind is also reported on stderr;
+ * bench.py puts the four numbers into config.tuned.fallbacks and the tests of the bench workloads require zeros. */
+int svr_fallbacks(svr_ctx *ctx, uint64_t out4[4]);
 /* the cell lists of the current slice geometry (csrc/svr_cell.inc): out8 = {scatter items, runs, sorted pixels, staging bytes per
  * launch, gather items, gather runs, gather partial-sum bytes per launch, scatter cell size w << 32 | h} */
 int svr_cell_stats(svr_ctx *ctx, uint64_t out8[8]);

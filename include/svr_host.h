@@ -21,14 +21,21 @@
 #ifndef SVR_HOST_H
 #define SVR_HOST_H
 
+#include <stddef.h>
+
 #include "svr_hip.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-/* collectives supplied by the launcher; every callback returns 0 on success */
+/* collectives supplied by the launcher; every callback returns 0 on success.
+ * struct_size (first member, since round 5): sizeof(svr_collectives) of the header the LAUNCHER was built against.  The host objects copy
+ * that many bytes and take every member beyond them as NULL / 0 -- a launcher built against an older (shorter) version of this struct
+ * keeps working and simply gets the all-reduce + replicated update; 0 or anything smaller than the members up to allgather_slices is
+ * refused by svrh_create / pvrh_create_sharded.  (Rounds 1-4 had no such member: launchers of that age must be rebuilt, INTEGRATION.md.) */
 typedef struct svr_collectives {
+  size_t struct_size;
   void *user;
   int rank, world;
   /* in-place sum of the float[2*Nv] device buffer at `device_ptr` over all ranks */
@@ -48,6 +55,8 @@ typedef struct svr_collectives {
    * before every device-buffer callback (its input may still be in flight there), and the callback returns with its result complete. */
   int on_engine_stream;
 } svr_collectives;
+/* the smallest struct_size the host objects accept: everything up to and including allgather_slices */
+#define SVR_COLLECTIVES_MIN_SIZE (offsetof(svr_collectives, allgather_slices) + sizeof(void *))
 
 /* ---- the collectives on RCCL, bound directly (csrc/svr_rccl.cpp) ---------------------------------------------------
  * One communicator per rank = per GPU: a process of its own (bench.py) or a thread of the command line (`-d 0 1 ..`).
@@ -57,6 +66,7 @@ typedef struct svr_collectives {
 typedef struct svr_comm svr_comm;
 int svr_comm_unique_id(char id128[128]);
 svr_comm *svr_comm_create(int rank, int world, const char id128[128], svr_ctx *engine);
+int svr_comm_rebind(svr_comm *c, svr_ctx *engine);                  /* the same communicator for another engine context on the same device */
 const svr_collectives *svr_comm_collectives(svr_comm *c);
 int svr_comm_world(svr_comm *c);                                     /* ncclCommCount */
 int svr_comm_allreduce_host(svr_comm *c, double *data, int n, int op); /* op: 0 sum, 1 min, 2 max */
@@ -150,10 +160,21 @@ int svr_dof_write(const char *path, const double params6[6], char err[256]);
  * pool, the pre-processing of the command lines and the NIfTI writer. */
 int svr_host_threads(void);
 
+/* The numbering of a sharded run (round 5).  A launcher may deal the units to the ranks in any order -- e.g. the r-th part of EVERY stack
+ * to rank r, so that a rank's slices are neighbours in space and it stages 1/N of the volume's work items instead of those of whole
+ * stacks (csrc/svr_shard.h spatial_order; fetalreconstruction_amd/sharding.py shard_units) -- by uploading them in that order and
+ * telling the host object: order[k] = index in the REFERENCE's order (stack after stack, slice after slice) of unit k of the numbering
+ * this object and its engine use (n_slices_global entries, a permutation; NULL = the same numbering).  Per-unit vectors handed to or
+ * returned by svrh_* / pvrh_* (scale, weights, potentials, force-excluded indices, transformations) are in the object's numbering;
+ * whatever the reference computes ACROSS units in unit order -- the sums of the slice-level EM (RG.cc:3282-3420), the patch-based
+ * path's within-stack indexing of the potentials (patchBasedRobustStatistics_gpu.cu:256-276) -- is computed in the reference's order. */
+int svrh_set_unit_order(svrh_recon *r, const int *order_or_null);
 /* test hook: a world-1 run goes through the launcher's collectives like a sharded one (instead of an environment variable) */
 void svrh_force_collectives(svrh_recon *r, int on);
 /* sharded runs: 1 (default) = the volume update by z-slabs when the launcher supplies reduce_scatter_device / allgather_device
- * (csrc/svr_slab.inc), 0 = all-reduce of the pair + the update replicated on every rank.  Same results. */
+ * (csrc/svr_slab.inc), 0 = all-reduce of the pair + the update replicated on every rank.  Identical on every rank either way; the two
+ * forms are bit-equal to each other when the collectives add the ranks in rank order (host-staged / gloo), equal to a float sum's last
+ * bits over RCCL. */
 void svrh_set_slab_update(svrh_recon *r, int on);
 
 /* state read-back: global per-slice vectors (length n_slices_global) and the EM scalars
@@ -222,6 +243,7 @@ pvrh_recon *pvrh_create(svr_ctx *engine, const int *patches_per_stack, int n_sta
  * potentials (patchBasedRobustStatistics_gpu.cu:256-276). */
 pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_intensity, float max_intensity,
                                 int patch_lo, int patch_hi, const svr_collectives *coll_or_null);
+int pvrh_set_unit_order(pvrh_recon *r, const int *order_or_null);    /* as svrh_set_unit_order, with patches */
 void pvrh_force_collectives(pvrh_recon *r, int on);
 void pvrh_set_slab_update(pvrh_recon *r, int on);
 void pvrh_destroy(pvrh_recon *r);

@@ -75,6 +75,33 @@ def test_bench_multi_rank_path_at_world_one():
 
 
 @pytest.mark.gpu
+def test_bench_line_carries_the_s8_record_and_no_fallbacks():
+    """The default command line (P4) also measures S8 -- BASELINE configs[3], the workload the >= 6x target is quoted on -- in the same
+    launch, on the same ranks and the same communicator (svr_comm_rebind), and reports it as the line's "s8" record next to the unchanged
+    headline; here through the forced-collective path at world 1 (reduce-scatter -> slab -> all-gather on RCCL, one host exchange per
+    step).  Neither workload may leave the cell path: a fallback (float atomics in the scatter, the tile kernels elsewhere) is counted by
+    svr_fallbacks and reported in config.tuned.fallbacks / s8.fallbacks."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-coeff-table", "--force-comm"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = _last_json(r.stdout)
+    assert a["config"]["workload"].startswith("P4") and a["config"]["comm"] == "rccl" and a["config"]["rccl_world"] == 1
+    assert a["config"]["tuned"]["fallbacks"] == dict(scatter_to_atomics=0, gather_to_tiles=0, gauss1_to_tiles=0, tiles_rerun=0)
+    s8 = a["s8"]
+    assert "error" not in s8, s8
+    assert s8["workload"].startswith("S8") and s8["slices"] == 512 and s8["n_gpus"] == 1 and s8["steps"] == 3
+    assert 100 < s8["value"] < 400 and abs(s8["value"] - s8["Va_total"] / s8["ms_per_step"] / 1e3) < 1e-6 * s8["value"]
+    k = s8["ranks"]
+    assert k["Va"] == [s8["Va_total"]] and k["units"] == [512]
+    assert k["exchanges_per_step"] == [1.0]                  # (steps 1..3 of an outer iteration: no EM re-initialisation inside the timed region)
+    assert k["backproject_ms"][0] > 5 and k["forward_ms"][0] > 5 and k["reduce_scatter_ms"][0] > 0 and k["allgather_ms"][0] > 0 and k["allreduce_ms"][0] == 0
+    assert s8["collective_bytes_sent"] == k["collective_bytes_sent"] and k["collective_bytes_sent"][0] > 1e7
+    assert s8["fallbacks"] == dict(scatter_to_atomics=0, gather_to_tiles=0, gauss1_to_tiles=0, tiles_rerun=0)
+    # the headline is the P4 figure, not S8's
+    assert a["config"]["Va_total"] < 2e6 < s8["Va_total"] and a["ms_per_step"] < 0.5 * s8["ms_per_step"]
+
+
+@pytest.mark.gpu
 def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
     """csrc/svr_rccl.cpp on the one GPU of the box: librccl is opened, a communicator of world size 1 is made on the engine's
     stream, and the sharded C++ host runs a whole iteration through its three collectives (identity at world 1) -- the same

@@ -462,6 +462,48 @@ def test_cpp_host_object_matches_python_driver_and_oracle(tiny, oracle_mod):
     assert rel_err(rec2.syncCPU(), orc.recon) < 1e-4
 
 
+def test_cpp_host_in_a_sharded_numbering_gives_the_references_order_its_results(tiny):
+    """svrh_set_unit_order (round 5): a launcher that deals the r-th part of EVERY stack to rank r uploads the slices in that order and tells
+    the host object; everything per slice is indifferent to the numbering, and the slice-level EM (RG.cc:3282-3420), whose sums run over the
+    slices in slice order, keeps running in the reference's order.  The whole problem in the numbering of a 3-rank spatial sharding on one
+    engine against the plain order on another: the same volume (up to the order of float additions inside a cell's runs), the same EM scalars,
+    and per-slice vectors that are each other's permutation -- force-excluded slices named in the object's numbering."""
+    from fetalreconstruction_amd import host, phantom
+    from fetalreconstruction_amd.sharding import shard_units
+    act = (tiny.slices != -1).reshape(tiny.ns, -1).sum(1)
+    order, ranges = shard_units(act, tiny.stack_index, 3, "spatial")
+    assert not np.array_equal(order, np.arange(tiny.ns))
+    inv = np.argsort(order)
+    excluded = [2, tiny.ns - 3]                                  # reference indices
+    out = []
+    for perm in (None, order):
+        P = tiny if perm is None else phantom.sub_problem(tiny, 0, 0, select=perm)
+        rec = _engine(P)
+        hc = host.irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
+        if perm is not None:
+            hc.set_unit_order(perm)
+        hc.SetForceExcludedSlices(excluded if perm is None else [int(inv[i]) for i in excluded])
+        hc.SetSmoothingParameters(150, 0.02)
+        hc.reconstruct_iteration(3)
+        out.append((rec.syncCPU().copy(), hc.state()))
+        rec.close()
+    (v0, s0), (v1, s1) = out
+    assert rel_err(v1, v0) < 2e-5
+    for k in ("sigma", "mix", "m", "mean_s", "mean_s2", "sigma_s", "sigma_s2", "mix_s"):
+        assert s1[k] == pytest.approx(s0[k], rel=1e-5), k
+    assert np.allclose(s1["scale"], s0["scale"][order], rtol=1e-5) and np.allclose(s1["slice_weight"], s0["slice_weight"][order], atol=1e-4)
+    assert np.allclose(s1["slice_potential"], s0["slice_potential"][order], rtol=1e-4, atol=1e-7)
+    assert (s0["slice_weight"][excluded] == 0).all() and (s1["slice_weight"][inv[excluded]] == 0).all()
+    assert 0 < (s0["slice_weight"] > 0.5).sum() < tiny.ns or (s0["slice_weight"] > 0).sum() == tiny.ns - 2
+    # not a permutation: refused
+    rec = _engine(tiny)
+    hc = host.irtkReconstruction(rec, tiny.ns, max_intensity=tiny.max_intensity, min_intensity=tiny.min_intensity)
+    bad = order.copy(); bad[0] = bad[1]
+    with pytest.raises(Exception):
+        hc.set_unit_order(bad)
+    rec.close()
+
+
 def test_ragged_and_empty_inputs(oracle_mod):
     """Slices of different sizes padded with -1 (RG.cc:269-311), an all-padding slice and a slice
     grid that is not a multiple of any block size."""
@@ -766,6 +808,37 @@ def test_cell_scatter_is_bit_identical_from_run_to_run():
         for name, a, b in zip(("recon", "volw", "addon", "cmap"), o, outs[0]):
             assert np.array_equal(a, b, equal_nan=True), (n, name, int((a != b).sum()), float(np.nanmax(np.abs(a - b))))
     assert (outs[0][3] > 0).sum() > 100000
+
+
+@pytest.mark.parametrize("part", ["whole", "a rank's eighth"])
+def test_the_three_forms_of_the_combine_give_the_same_bits_at_full_size(part):
+    """k_cell_combine (general), k_cell_combine_fast (a voxel's slabs in two batches) and k_cell_combine_wave (round 5, the default: one
+    item_of load per wavefront and class, early out where nothing is staged) add the same slabs in the same order: addon | cmap are the
+    same bits on the bench workload -- whole, and with a rank's share of the slices (the r-th eighth of every stack, where most of the
+    volume has nothing staged around it and the early out is what runs)."""
+    from fetalreconstruction_amd import engine as E, phantom, workloads
+    from fetalreconstruction_amd.sharding import shard_units
+    P = workloads.get("P4")
+    if part != "whole":
+        order, ranges = shard_units((P.slices != -1).reshape(P.ns, -1).sum(1), P.stack_index, 8, "spatial")
+        P = phantom.sub_problem(P, 0, 0, select=order[ranges[3][0]:ranges[3][1]])
+    rec = _engine(P)
+    rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
+    rec.InitializeEMValues()
+    rec.GaussianReconstruction()
+    rec.SimulateSlices()
+    rec.debug_set(E.BUF_WEIGHTS, np.where(P.slices != -1, 0.75, 0).astype(np.float32))
+    outs = {}
+    for form in (2, 1, 0):
+        rec.set_option("cell_combine", form)
+        assert rec.get_option("cell_combine") == form
+        rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
+        outs[form] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
+    rec.close()
+    for form in (1, 0):
+        for name, a, b in zip(("addon", "cmap"), outs[form], outs[2]):
+            assert np.array_equal(a, b, equal_nan=True), (form, name, int((a != b).sum()))
+    assert (outs[2][1] > 0).sum() > (100000 if part == "whole" else 10000)
 
 
 @pytest.mark.parametrize("workload", ["tiny", "P4"])

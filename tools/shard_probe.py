@@ -60,9 +60,10 @@ def collective_ms(bytes_per_rank_out, world):
     return bytes_per_rank_out * (world - 1) / world / (links * XGMI_LINK_GBS * 1e9 * XGMI_EFF) * 1e3
 
 
-def probe(wl, world, reps=6, opts=(), only=None):
+def probe(wl, world, reps=6, opts=(), only=None, layout=None):
     from fetalreconstruction_amd import engine as E, phantom, host
-    from fetalreconstruction_amd.sharding import patch_cost_weights, shard_slices, slice_cost_weights
+    from fetalreconstruction_amd.sharding import DEFAULT_LAYOUT, patch_cost_weights, shard_units, slice_cost_weights
+    layout = layout or os.environ.get("SVR_SHARD_LAYOUT", DEFAULT_LAYOUT)
     prob = build(wl)
     pvr = wl.startswith("PVR")
     spx = getattr(prob, "spx_masks", None)
@@ -71,7 +72,7 @@ def probe(wl, world, reps=6, opts=(), only=None):
     else:
         act = (prob.slices != -1).reshape(prob.ns, -1).sum(1)
         work = slice_cost_weights(act, prob.slice_i2w, prob.slice_t, prob.recon_w2i, prob.slice_dim, prob.vdim[0])
-    ranges = shard_slices(work, world)
+    order, ranges = shard_units(work, prob.stack_index, world, layout)     # the numbering and ranges bench.py --gpus N uses
 
     # ---- the donor: the whole workload on one context ------------------------------------------------------------------------
     rec = make_engine(prob, pvr, spx, opts)
@@ -132,19 +133,21 @@ def probe(wl, world, reps=6, opts=(), only=None):
     for r, (lo, hi) in enumerate(ranges):
         if only is not None and r not in only:
             continue
-        sub = phantom.sub_problem(prob, lo, hi)
-        rs = make_engine(sub, pvr, None if spx is None else spx[lo:hi], opts)
-        rs.UpdateScaleVector(scales[lo:hi], sw[lo:hi])
+        idx = order[lo:hi]
+        sub = phantom.sub_problem(prob, 0, 0, select=idx)
+        rs = make_engine(sub, pvr, None if spx is None else spx[idx], opts)
+        rs.UpdateScaleVector(scales[idx], sw[idx])
         for b, a in donor.items():
-            rs.debug_set(b, np.ascontiguousarray(a.reshape(prob.ns, -1)[lo:hi]).reshape(-1))
+            rs.debug_set(b, np.ascontiguousarray(a.reshape(prob.ns, -1)[idx]).reshape(-1))
         rs.UpdateReconstructed(rs.vsize, vol)
-        k = time_kernels(rs, sw[lo:hi], scales[lo:hi], np.ascontiguousarray(donor[E.BUF_WEIGHTS].reshape(prob.ns, -1)[lo:hi]).reshape(-1))
+        k = time_kernels(rs, np.ascontiguousarray(sw[idx]), np.ascontiguousarray(scales[idx]),
+                         np.ascontiguousarray(donor[E.BUF_WEIGHTS].reshape(prob.ns, -1)[idx]).reshape(-1))
         k.update(rank=r, units=[int(lo), int(hi)], Va=rs.counters()["Va"], cells=rs.cell_stats())
         shards.append(k)
         rs.close()
     # what the slab update's collectives carry (svr_slab_plan on a fresh context would need the mask only; the donor's is gone)
     mask_fraction = float((np.asarray(prob.mask) != 0).mean())
-    return dict(workload=wl, world=world, Nv=nv, volume=vsize, mask_fraction=mask_fraction, full=full, shards=shards)
+    return dict(workload=wl, world=world, layout=layout, Nv=nv, volume=vsize, mask_fraction=mask_fraction, full=full, shards=shards)
 
 
 def project(res):
@@ -173,8 +176,8 @@ def project(res):
                 slab=dict(reduce_scatter_ms=rs_ms, update_ms=reg_full / W, allgather_ms=ag_ms, step_ms=slab, speedup=one / slab))
 
 
-def run(workload, world, reps=6, opts=(), only=None):
-    res = probe(workload, world, reps, opts, only)
+def run(workload, world, reps=6, opts=(), only=None, layout=None):
+    res = probe(workload, world, reps, opts, only, layout)
     if only is None or len(res["shards"]) == world:
         res["projection"] = project(res)
     return res
@@ -186,11 +189,12 @@ def main():
     ap.add_argument("world", type=int)
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--out")
+    ap.add_argument("--layout", choices=["spatial", "contiguous"], help="how the units are dealt to the ranks (sharding.shard_units); default: the product's")
     ap.add_argument("opts", nargs="*", help="engine options name=value")
     a = ap.parse_args()
     opts = [(o.split("=")[0], int(o.split("=")[1])) for o in a.opts]
     t0 = time.time()
-    res = run(a.workload, a.world, a.reps, opts)
+    res = run(a.workload, a.world, a.reps, opts, layout=a.layout)
     res["wall_s"] = round(time.time() - t0, 1)
     line = json.dumps(res)
     if a.out:
