@@ -323,6 +323,10 @@ class Reconstruction:
     def device_ptr(self, which):
         return self._lib.svr_device_ptr(self._h, int(which))
 
+    def stream_sync(self):
+        """wait for everything queued on the engine's stream"""
+        self._ck(self._lib.svr_stream_sync(self._h))
+
     # ---- debug getters (debugWeights/Simslices/... RC.cuh:192-207) ------------------------
     def debug_get(self, which):
         ns, sy, sx = self.sgrid if self.sgrid else (0, 0, 0)

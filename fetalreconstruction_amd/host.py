@@ -12,6 +12,7 @@ from . import engine as _engine
 _AR_PAIR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _AR_HOST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int)
+_DEV2 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)      # reduce_scatter_device / allgather_device
 
 COMM_EXPORTS = ["svr_comm_unique_id", "svr_comm_create", "svr_comm_rebind", "svr_comm_collectives", "svr_comm_world", "svr_comm_allreduce_host",
                 "svr_comm_last_error", "svr_comm_destroy", "svr_group_create", "svr_group_uses_rccl", "svr_group_join", "svr_group_destroy"]                                                  # csrc/svr_rccl.cpp
@@ -52,7 +53,7 @@ class _Coll(C.Structure):
                 ("allreduce_host", _AR_HOST), ("allgather_slices", _AG),
                 # device-buffer reduce-scatter / all-gather of the slab update: not supplied by the torch.distributed callbacks (NULL ->
                 # all-reduce + replicated update); on_engine_stream 0: the C++ host synchronises the engine's stream before ar_pair
-                ("reduce_scatter_device", C.c_void_p), ("allgather_device", C.c_void_p), ("on_engine_stream", C.c_int)]
+                ("reduce_scatter_device", _DEV2), ("allgather_device", _DEV2), ("on_engine_stream", C.c_int)]
 
 
 class RcclComm:
@@ -181,8 +182,43 @@ class irtkReconstruction:
                     print("allgather_slices failed:", ex)
                     return 1
 
-            self._cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag))     # keep the thunks alive
-            self._coll = _Coll(C.sizeof(_Coll), None, comm.rank, comm.world, *self._cbs, None, None, 0)
+            # the two device-buffer collectives of the slab update (csrc/svr_slab.inc), staged through the host and added IN RANK ORDER
+            # (TorchComm(slabs=True): what two ranks that share one GPU can run -- RCCL refuses them -- and, like the in-process group of
+            # the command lines, bit for bit the replicated update).  on_engine_stream 0: the C++ host synchronises the engine's stream first.
+            def rs_dev(user, send, recv, n):
+                try:
+                    from .sharding import _device_view
+                    W = comm.world
+                    mine = _device_view(comm.torch, send, W * n, comm.device or "cuda").cpu()
+                    outs = [comm.torch.zeros_like(mine) for _ in range(W)]
+                    comm.dist.all_gather(outs, mine)
+                    acc = outs[0][comm.rank * n:(comm.rank + 1) * n].clone()
+                    for r in range(1, W):
+                        acc += outs[r][comm.rank * n:(comm.rank + 1) * n]
+                    _device_view(comm.torch, recv, n, comm.device or "cuda").copy_(acc)
+                    comm.torch.cuda.synchronize()
+                    return 0
+                except Exception as ex:
+                    print("reduce_scatter_device failed:", ex)
+                    return 1
+
+            def ag_dev(user, send, recv, n):
+                try:
+                    from .sharding import _device_view
+                    W = comm.world
+                    mine = _device_view(comm.torch, send, n, comm.device or "cuda").cpu()
+                    outs = [comm.torch.zeros_like(mine) for _ in range(W)]
+                    comm.dist.all_gather(outs, mine)
+                    _device_view(comm.torch, recv, W * n, comm.device or "cuda").copy_(comm.torch.cat(outs))
+                    comm.torch.cuda.synchronize()
+                    return 0
+                except Exception as ex:
+                    print("allgather_device failed:", ex)
+                    return 1
+
+            slab_cbs = (_DEV2(rs_dev), _DEV2(ag_dev)) if getattr(comm, "slabs", False) else (_DEV2(0), _DEV2(0))
+            self._cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag)) + slab_cbs     # keep the thunks alive
+            self._coll = _Coll(C.sizeof(_Coll), None, comm.rank, comm.world, *self._cbs, 0)
         if self._coll is not None:
             coll_ptr = C.byref(self._coll)
         h = self._lib.svrh_create(rec._h, self.ns, int(self.lo), int(self.hi), coll_ptr)

@@ -15,3 +15,5 @@ for f in sys.argv[1:]:
     print("   back", [round(k["backproject"], 3) for k in sh], "sum %.2f" % sum(k["backproject"] for k in sh))
     print("   fwd ", [round(k["forward"], 3) for k in sh], "sum %.2f" % sum(k["forward"] for k in sh))
     print("   items", [k["cells"]["items"] for k in sh], "of", r["full"]["cells"]["items"], "| staging MB", [k["cells"]["staging_bytes"] >> 20 for k in sh])
+    for name, v in p.get("at_link_rates", {}).items():
+        print("   link %-50s slab %.2fx (step %.2f ms, collectives %.2f ms)   replicated %.2fx" % (name, v["speedup_slab"], v["step_slab_ms"], v["collectives_slab_ms"], v["speedup_replicated"]))

@@ -64,6 +64,9 @@ def probe(wl, world, reps=6, opts=(), only=None, layout=None):
     from fetalreconstruction_amd import engine as E, phantom, host
     from fetalreconstruction_amd.sharding import DEFAULT_LAYOUT, patch_cost_weights, shard_units, slice_cost_weights
     layout = layout or os.environ.get("SVR_SHARD_LAYOUT", DEFAULT_LAYOUT)
+    if not os.environ.get("SHARD_HOST_RESTORE"):
+        import torch                                   # before the engine's library brings the HIP runtime up: torch carries its own copy
+        torch.cuda.init()
     prob = build(wl)
     pvr = wl.startswith("PVR")
     spx = getattr(prob, "spx_masks", None)
@@ -98,6 +101,19 @@ def probe(wl, world, reps=6, opts=(), only=None, layout=None):
     em3 = tuple(float(st[k]) for k in (("m_m_gpu", "m_sigma_gpu", "m_mix_gpu") if pvr else ("m", "sigma", "mix")))
 
     def time_kernels(rec_, sw_, sc_, w_):
+        # The state a repetition starts from is put back DEVICE TO DEVICE (saved copies of the weights and the volume; round 5).  Rounds 3-4
+        # uploaded them from the host between repetitions: 5-100 ms in which the device sat idle, so that every timed kernel of a rank -- a
+        # 5 ms launch -- started on a chip coming out of idle, where a rank of a real run launches its kernels back to back (the first
+        # launch after a gap is 5-15 % slower than the following ones: profiles/r05_shard_probe_notes.txt).  SHARD_HOST_RESTORE=1: the old way.
+        fast = not os.environ.get("SHARD_HOST_RESTORE")
+        if fast:
+            import torch
+            from fetalreconstruction_amd.sharding import _device_view
+            n_w = int(np.asarray(w_).size)
+            dev = torch.device("cuda", 0)
+            w_saved = torch.from_numpy(np.ascontiguousarray(w_, np.float32).reshape(-1)).to(dev)
+            v_saved = torch.from_numpy(np.ascontiguousarray(vol, np.float32).reshape(-1)).to(dev)
+            torch.cuda.synchronize()
         rec_.timer_enable(True)
         for k in range(reps + 1):
             if k == 1:
@@ -115,8 +131,14 @@ def probe(wl, world, reps=6, opts=(), only=None, layout=None):
             rec_.EStep(*em3)
             rec_.CalculateScaleVector()
             rec_.UpdateScaleVector(sc_, sw_)                       # (the state the scatter started from)
-            rec_.debug_set(E.BUF_WEIGHTS, w_)
-            rec_.UpdateReconstructed(rec_.vsize, vol)              # (untimed: every repetition updates the donor's volume)
+            if fast:
+                rec_.stream_sync()
+                _device_view(torch, rec_.device_ptr(E.BUF_WEIGHTS), n_w, dev).copy_(w_saved)
+                _device_view(torch, rec_.device_ptr(E.BUF_RECONSTRUCTED), int(v_saved.numel()), dev).copy_(v_saved)   # (the volume buffers flip: ask every time)
+                torch.cuda.synchronize()
+            else:
+                rec_.debug_set(E.BUF_WEIGHTS, w_)
+                rec_.UpdateReconstructed(rec_.vsize, vol)          # (untimed: every repetition updates the donor's volume)
         out = kernel_ms(rec_)
         rec_.timer_enable(False)
         return out
@@ -150,6 +172,31 @@ def probe(wl, world, reps=6, opts=(), only=None, layout=None):
     return dict(workload=wl, world=world, layout=layout, Nv=nv, volume=vsize, mask_fraction=mask_fraction, full=full, shards=shards)
 
 
+def project_at(res, gbs_per_direction):
+    """the projection with the collectives priced at ONE stated rate (GB/s a rank can send, all links together): speed-ups slab / replicated"""
+    W, nv = res["world"], res["Nv"]
+    full, sh = res["full"], res["shards"]
+    em = lambda k: k["estep"] + k["mstep"] + k["scale"]
+    one = full["backproject"] + full["regularize"] + full["forward"] + em(full)
+    psf = max(k["backproject"] + k["forward"] + em(k) for k in sh)
+    reg_full = max(k["regularize"] for k in sh)
+    ms = lambda nbytes: nbytes * (W - 1) / W / (gbs_per_direction * 1e9) * 1e3 if W > 1 else 0.0
+    nex = HOST_EXCHANGES["pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"]
+    mfrac = res.get("mask_fraction", 1.0)
+    rs_ms, ag_ms, ar_ms = ms(2 * nv * 4 * mfrac), ms(nv * 4 * min(1.0, mfrac * 1.15)), 2 * ms(2 * nv * 4)
+    slab = psf + rs_ms + reg_full / W + ag_ms + nex * HOST_EXCHANGE_MS
+    repl = psf + ar_ms + reg_full + nex * HOST_EXCHANGE_MS
+    return dict(rate_GBs=gbs_per_direction, collectives_slab_ms=rs_ms + ag_ms, step_slab_ms=slab, speedup_slab=one / slab, allreduce_ms=ar_ms,
+                step_replicated_ms=repl, speedup_replicated=one / repl)
+
+
+# what a rank can send per direction, three ways to look at MI355X's 7 xGMI links of 76.8 GB/s per direction (153.6 bidirectional):
+# all 7 side by side at 50 % (a direct exchange: the figure of rounds 3-4), one link's bidirectional figure as a per-direction budget
+# (SURVEY 5's ring estimate), and one link in one direction (a ring that keeps a single link busy)
+LINK_RATES_GBS = {"7 links x 76.8 GB/s x 0.5 (direct exchange)": 7 * 76.8 * 0.5, "153 GB/s (SURVEY 5: ring over one link pair)": 153.0,
+                  "76.8 GB/s (one link, one direction)": 76.8}
+
+
 def project(res):
     """projected step of the sharded run from the per-shard kernel times -- a projection, not a measurement"""
     W, nv = res["world"], res["Nv"]
@@ -172,6 +219,8 @@ def project(res):
                                  host_exchange_ms=HOST_EXCHANGE_MS, host_exchanges_per_step=nex),
                 one_gpu_kernels_ms=one, max_rank_psf_em_ms=psf, sum_rank_psf_ms=sum(k["backproject"] + k["forward"] for k in sh),
                 shard_overhead=sum(k["backproject"] + k["forward"] for k in sh) / (full["backproject"] + full["forward"]),
+                at_link_rates={name: project_at(res, (min(W - 1, 7) * XGMI_LINK_GBS * XGMI_EFF) if name.startswith("7 links") else rate)
+                               for name, rate in LINK_RATES_GBS.items()},
                 replicated=dict(allreduce_ms=ar, update_ms=reg_full, step_ms=replicated, speedup=one / replicated),
                 slab=dict(reduce_scatter_ms=rs_ms, update_ms=reg_full / W, allgather_ms=ag_ms, step_ms=slab, speedup=one / slab))
 
