@@ -74,8 +74,58 @@ def table_traffic(workload, world):
     return out or None
 
 
-def cpu_baseline(prob, target_seconds=12.0):
-    """The CPU port (oracle, literal float32 mode = the reference's own arithmetic) timed on a bounded sample of the same
+def cpu_baseline(prob):
+    """What the line reports as `cpu_baseline`.  SVR workloads: THE REFERENCE'S CPU RECONSTRUCTION PATH -- irtkReconstruction::CoeffInit
+    (explicit coefficient lists, once per outer iteration) and one SR iteration = Scale, Superresolution (+ AdaptiveRegularization),
+    SimulateSlices, MStep, EStep (reconstruction.cc:1013-1108 with --useCPU, bias correction off; irtkReconstructionGPU.cc:2305-2673,
+    1090-1161, 3076-3160, 3442-3695, 3697-3749, 3940-4119, 4121-4263, 4265-4428) -- restated in plain C with pthreads where the reference
+    uses TBB (oracle/cpu_twin.c, kind "port": the reference's own sources need GSL / boost / TBB headers this image lacks and are not
+    built against stand-ins), on the host cores of this box, on the WHOLE of P4 (every slice; other SVR workloads: every k-th slice so
+    that the coefficient lists stay below ~8 GB, said in `sample`).  It is a different algorithm from the GPU path's (Gaussian PSF,
+    trilinear splat: README.md:117-119): a reported baseline, not a target and not a parity oracle.  The port of the GPU kernels
+    (oracle/svr_oracle.c in literal mode, rounds 1-4's figure) stays beside it as `port_of_gpu_kernels`; patch-based workloads, which
+    have no CPU path in the reference, report only that."""
+    from fetalreconstruction_amd import engine as _engine
+    cores = max(1, min(int(_engine.load_library().svr_host_threads()), 64))     # affinity mask cut to the cgroup CPU quota (16 of 256 on the gpurun boxes)
+    port = cpu_baseline_port(prob, target_seconds=6.0)
+    if hasattr(prob, "patches_per_stack"):
+        return port
+    from fetalreconstruction_amd.phantom import sub_problem
+    from oracle import cputwin
+    ns = prob.ns
+    act = int((prob.slices != -1).sum())
+    # coefficients per active pixel ~ the transformed PSF's box: (2 d / res + 2)^3 voxels over the three axes, about a third non-zero
+    res = float(prob.vdim[0])
+    per_px = np.prod([2.0 * float(prob.slice_dim[0][k]) / res + 2.0 for k in range(3)]) / 3.0
+    step = max(1, int(np.ceil(act * per_px * 8.0 / 8e9)))
+    sub = prob if step == 1 else sub_problem(prob, 0, 0, select=np.arange(0, ns, step))
+    tw = cputwin.CpuTwin(sub, threads=cores)
+    tw.SetSmoothingParameters(150, 0.02)
+    tw.preamble()                          # InitializeEMValues, CoeffInit, GaussianReconstruction, SimulateSlices, InitializeRobustStatistics, EStep
+    n_it = 5
+    its = []
+    for i in range(n_it):
+        t0 = time.perf_counter()
+        tw.sr_iteration(i % SR_PER_OUTER)
+        its.append(time.perf_counter() - t0)
+    med = float(np.median(its))
+    va = tw.active_pixels
+    out = {"value": va / med / 1e6, "unit": "MVoxels/s per SR iteration", "cores": cores, "kind": "port",
+           "algorithm": "the reference's CPU reconstruction path (irtkReconstruction::CoeffInit + Scale / Superresolution / SimulateSlices / MStep / EStep, "
+                        "irtkReconstructionGPU.cc; Gaussian PSF, trilinear splat, explicit coefficient lists, double) restated in C with pthreads: oracle/cpu_twin.c",
+           "coeff_init_s": float(tw.times["CoeffInit"][0]), "sr_iteration_s": med, "sr_iterations_timed": n_it,
+           "coefficients": tw.coefficients, "active_pixels": va,
+           "sample": (f"the whole workload ({sub.ns} slices, {va} active pixels)" if step == 1 else
+                      f"every {step}th slice of the workload ({sub.ns} slices, {va} active pixels: the coefficient lists of all {ns} would need ~{act * per_px * 8 / 1e9:.0f} GB)")
+                     + f": CoeffInit once ({tw.times['CoeffInit'][0]:.2f} s, not in `value`), then the median of {n_it} SR iterations ({med:.3f} s) on {cores} threads",
+           "per_function_s": {k: float(np.mean(v)) for k, v in tw.times.items()},
+           "port_of_gpu_kernels": port}
+    tw.close()
+    return out
+
+
+def cpu_baseline_port(prob, target_seconds=12.0):
+    """The CPU port of the GPU kernels (oracle, literal float32 mode = the reference's own arithmetic) timed on a bounded sample of the same
     workload on the host cores: ONE WHOLE SR ITERATION (Scale, back-projection, Prep + regulariser, forward projection,
     M-step, E-step -- the Python mirror of the host driver on the oracle engine) of every k-th slice.  The sample's
     slices are dealt to one oracle instance per core (its own volume, like the slice-sharded ranks); the C calls
@@ -136,6 +186,7 @@ def cpu_baseline(prob, target_seconds=12.0):
         list(pool.map(lambda od: od[1].sr_iteration(0), pairs))
         dt = time.perf_counter() - t0
     return {"value": va / dt / 1e6, "unit": "MVoxels/s per SR iteration", "cores": cores, "kind": "port",
+            "algorithm": "the GPU path's kernels (reconstruction_cuda2.cu: 16^3 sinc^2 x Gauss taps evaluated in every pass) restated in C: oracle/svr_oracle.c, literal mode",
             "sample": f"every {step}th slice of the workload ({len(sel)} slices, {va} active pixels) dealt to {cores} oracle "
                       f"instances, one thread each: one whole SR iteration (Scale, back-projection, regulariser, forward "
                       f"projection, M-step, E-step) in literal mode in {dt:.1f} s"}

@@ -212,6 +212,17 @@ def pvr_problem(name, workdir=None):
             own.cleanup()
 
 
+def p4_truth(prob, average=700.0, mask_path=MASK_FIXTURE):
+    """the analytic phantom of problem_p4 sampled at the voxel centres of the problem's volume grid (what a perfect reconstruction of
+    the noise-free, motion-corrected stacks would hold, up to the stacks' intensity scale): float32 [vz * vy * vx]"""
+    _, c = load_bundled_mask(mask_path)
+    vx, vy, vz = (int(v) for v in prob.vsize)
+    kk, jj, ii = np.meshgrid(np.arange(vz), np.arange(vy), np.arange(vx), indexing="ij")
+    i2w = np.asarray(prob.recon_i2w, np.float64).reshape(4, 4)
+    w = np.stack([ii, jj, kk, np.ones_like(ii)], -1).astype(np.float64) @ i2w.T
+    return (phantom.phantom_intensity(w[..., :3] - c, RADIUS) * average / 0.55).astype(np.float32).reshape(-1)
+
+
 def get(name, **kw):
     """workload by the name bench.py / the tests use"""
     if name in ("PVR4", "PVR8spx"):
