@@ -232,7 +232,8 @@ int svr_comm_rebind(svr_comm *c, svr_ctx *engine) {
   if (!c || !engine) return 1;
   if (svr_device(engine) != c->device) return cfail(c, "svr_comm_rebind: the engine lives on another device");
   if (hipSetDevice(c->device) != hipSuccess) return cfail(c, "svr_comm_rebind: hipSetDevice");
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  // (the previous engine may be gone already, and with it its stream: nothing of the communicator's is pending there -- every host-vector
+  // collective waits for its own result, and the volume collectives are followed by a wait of the host objects before they return)
   c->stream = static_cast<hipStream_t>(svr_get_stream(engine));
   c->counts.clear();
   return 0;

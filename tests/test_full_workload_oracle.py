@@ -277,8 +277,14 @@ def test_a_whole_outer_iteration_of_p4_tracks_the_oracle(oracle_mod, capsys):
 def test_a_whole_outer_iteration_of_pvr4_tracks_the_oracle(oracle_mod, capsys):
     """BASELINE configs[2] end to end, as above with patches as the units: the C++ patch-based host (csrc/pvr_host.cpp) on the HIP engine
     against the Python mirror (tests/twins/pvr.py) on the oracle, 5 149 patches sharded over the host threads; Gaussian reconstruction,
-    robust statistics and two super-resolution iterations.  Tolerances of `test_pvr_loop_parity` (the small phantom), except that a few in a
-    thousand of the patches' scale factors may differ by up to 2e-3 (observed: 2 of 5 149 at 3e-4 and 5e-4; volume 7.4e-6)."""
+    robust statistics and two super-resolution iterations.  Tolerances of `test_pvr_loop_parity` (the small phantom), except for the scale
+    factor of a patch ONE OF WHOSE PIXELS CROSSES A GATE between the two sides.  A patch's factor is sum w s sim / sum w s^2 over its pixels with
+    simulated weight > 0.99 (patchBasedRobustStatistics_gpu.cu:672-745); the simulated weight of a pixel is a float sum of up to 1728 taps and
+    agrees between the device and the oracle to 3e-7, so a pixel whose weight is 0.99 on one side and 0.99000007 on the other is in one sum and
+    not in the other -- one of ~590 pixels: the factor moves by a few 1e-4 (profiles/r05_pvr4_scale_diag.txt, tools/pvr4_scale_diag.py: patches
+    838 and 839, one such pixel each; over the COMMON pixels the two sides agree to 1e-4 and 5e-5).  The reference's own float atomics would put
+    such a pixel on either side from run to run.  So: every patch beyond 1e-4 must have a gate-crossing pixel in the final state, and stay
+    within 3 / (pixels in its sum); everything else holds the small phantom's tolerances (volume: observed 7.4e-6)."""
     from concurrent.futures import ThreadPoolExecutor
     from fetalreconstruction_amd import engine as E, host
     from fetalreconstruction_amd.sharding import shard_slices
@@ -291,6 +297,7 @@ def test_a_whole_outer_iteration_of_pvr4_tracks_the_oracle(oracle_mod, capsys):
     dg.reconstruct_iteration(2)
     sg = dg.state()
     vol_g = rec.syncCPU().copy()
+    simw_g = rec.debug_get(E.BUF_SIMWEIGHTS).reshape(P.slices.shape).copy()
     threads = max(2, min(int(E.load_library().svr_host_threads()), 16))
     rec.close()
 
@@ -302,7 +309,7 @@ def test_a_whole_outer_iteration_of_pvr4_tracks_the_oracle(oracle_mod, capsys):
         eng = oracle_mod.OracleReconstruction(phantom.sub_problem(P, lo, hi), oracle_mod.CANON, pvr=True)
         drv = pvr.irtkPatchBasedReconstruction(eng, P.patches_per_stack, P.min_intensity, P.max_intensity, patch_range=(lo, hi), comm=_ThreadComm(group, r))
         drv.reconstruct_iteration(2)
-        return eng.recon.copy(), np.asarray(drv.scale).copy(), np.asarray(drv.patch_weight).copy(), (drv.m_sigma_gpu, drv.m_mix_gpu, drv.m_m_gpu)
+        return eng.recon.copy(), np.asarray(drv.scale).copy(), np.asarray(drv.patch_weight).copy(), (drv.m_sigma_gpu, drv.m_mix_gpu, drv.m_m_gpu), eng.simweights.copy()
 
     def guarded(r):
         try:
@@ -313,9 +320,15 @@ def test_a_whole_outer_iteration_of_pvr4_tracks_the_oracle(oracle_mod, capsys):
 
     with ThreadPoolExecutor(threads) as pool:
         outs = list(pool.map(guarded, range(threads)))
-    vol_o, scale_o, pw_o, em_o = outs[0]
+    vol_o, scale_o, pw_o, em_o = outs[0][:4]
     for o in outs[1:]:
         assert np.array_equal(o[0], vol_o)
+    simw_o = np.concatenate([o[4] for o in outs])
+    data = P.slices > 0
+    gate_g, gate_o = (simw_g > 0.99) & data, (simw_o > 0.99) & data
+    crossing = (gate_g != gate_o).reshape(P.ns, -1).sum(1)                  # pixels on different sides of the gate, per patch (final state)
+    in_sum = np.maximum(gate_o.reshape(P.ns, -1).sum(1), 1)
+    assert np.abs(simw_g - simw_o)[data].max() < 2e-6
     err = rel_err(vol_g, vol_o)
     em_g = [sg["m_sigma_gpu"], sg["m_mix_gpu"], sg["m_m_gpu"]]
     with capsys.disabled():
@@ -326,10 +339,11 @@ def test_a_whole_outer_iteration_of_pvr4_tracks_the_oracle(oracle_mod, capsys):
         if bad.any():
             i = np.flatnonzero(bad)
             print(f"  scale differs at {len(i)} of {len(bad)} patches, e.g. {i[:6]}: HIP {np.asarray(sg['scale'])[i[:6]]} oracle {scale_o[i[:6]]}; "
-                  f"weights there HIP {np.asarray(sg['patch_weight'])[i[:6]]} oracle {pw_o[i[:6]]}; data pixels {(P.slices > 0).reshape(P.ns, -1).sum(1)[i[:6]]}")
+                  f"weights there HIP {np.asarray(sg['patch_weight'])[i[:6]]} oracle {pw_o[i[:6]]}; pixels in the sum {in_sum[i[:6]]}, gate-crossing pixels {crossing[i[:6]]} "
+                  f"(of {int(crossing.sum())} in {int((crossing > 0).sum())} patches overall)")
     assert np.allclose(em_g, em_o, rtol=1e-4)
-    # each side evolves its own state: of 5 149 scale factors two sit at 3e-4 / 5e-4 on the MI355X box (patches whose pixels lie where the
-    # E-step's weights are steep), the rest within 1e-4
-    assert bad.mean() < 2e-3 and np.allclose(sg["scale"], scale_o, rtol=2e-3)
+    # every patch beyond 1e-4 has a pixel on different sides of the `simulated weight > 0.99` gate, and stays within 3 / n of its sum
+    assert bad.mean() < 2e-3 and (crossing[bad] > 0).all(), np.flatnonzero(bad & (crossing == 0))
+    assert (np.abs(np.asarray(sg["scale"]) / scale_o - 1.0)[bad] <= 3.0 / in_sum[bad]).all()
     assert np.allclose(sg["patch_weight"], pw_o, atol=1e-3)
     assert err < 1e-4
