@@ -42,7 +42,7 @@ F32_PEAK_TFLOPS = 157.3      # f32 vector peak with packed FMA on gfx950 (= the 
 FLOPS_PER_TAP_FORMULA = 49
 FLOPS_PER_TAP_EXECUTED = 38
 TAPS = 4096
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_traffic.json")     # written by tools/prof_final.py in the same round: per workload,
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_traffic.json")     # written by tools/prof_final.py in the same round: per workload,
                                                                       # per pass: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
 VALU_ISSUE_PER_S = 0.6e9     # wave-instructions a SIMD issues per second: 2.4 GHz / 4 cycles per 64-lane instruction
@@ -590,7 +590,7 @@ def main():
                         "SQ_INSTS_VALU per launch / (launch time x 1024 SIMDs x 0.6e9 wave-instructions/s): the share of VALU issue slots "
                         "used, the figure that explains the time.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch time.  "
                         "`traffic`: FETCH_SIZE + WRITE_SIZE per launch; counters from this round's separate rocprofv3 --pmc passes "
-                        "(profiles/r04_traffic.json, tools/prof_final.py), null when that file has no entry for the workload.")
+                        "(profiles/r05_traffic.json, tools/prof_final.py), null when that file has no entry for the workload.")
         out = {
             "metric": METRIC,
             "value": value, "unit": "MVoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

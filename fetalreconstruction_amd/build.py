@@ -22,6 +22,7 @@ SRC_PREP = os.path.join(HERE, "csrc", "svr_prep.h")       # pre-processing share
 SRC_SLIC = os.path.join(HERE, "csrc", "svr_slic.h")
 SRC_CELL = os.path.join(HERE, "csrc", "svr_cell.inc")     # the scatter without atomics (cell-owned planes + combine), #included by svr_hip.hip
 SRC_SORT = os.path.join(HERE, "csrc", "svr_sort.hip")     # radix sort / prefix sum from hipCUB for its work lists (own translation unit)
+SRC_EM = os.path.join(HERE, "csrc", "svr_em.inc")         # the slice-level EM on the device, #included by svr_hip.hip
 SRC_REGUL = os.path.join(HERE, "csrc", "svr_regul.inc")     # the fused volume update (Prep + edge-preserving regulariser), #included by svr_hip.hip
 SRC_SHARD = os.path.join(HERE, "csrc", "svr_shard.h")     # unit ranges + the one exchange per step, shared by the two host objects       # SLICO superpixel patches of the PVR command line
 INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
@@ -54,7 +55,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_PYR, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_SHARD, SRC_REGUL, SRC_CELL, SRC_SORT, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_PYR, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_SHARD, SRC_REGUL, SRC_EM, SRC_CELL, SRC_SORT, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
                                                __file__)) or not (os.path.exists(CLI) and os.path.exists(PVR_CLI))
 
 

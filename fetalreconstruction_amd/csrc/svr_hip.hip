@@ -2776,7 +2776,7 @@ __global__ __launch_bounds__(256) void k_ncc(const short *targets, int tx, int t
 // context
 // ==========================================================================================
 struct RegState;   // GPU slice-to-volume registration state (svr_reg.inc)
-namespace { struct CellState; struct SlabPlan; }  // sorted pixels, runs, items and staging of the scatter without atomics (svr_cell.inc)
+namespace { struct CellState; struct SlabPlan; struct SliceEm; void slice_em_free(SliceEm *); }  // sorted pixels, runs, items and staging of the scatter without atomics (svr_cell.inc)
 
 struct svr_ctx {
   int device = 0;
@@ -2947,6 +2947,7 @@ struct svr_ctx {
   RegState *reg = nullptr;
 
   // the scatter without atomics (back_mode 5, svr_cell.inc): cell size in voxels (x, lane axis), wavefronts per item
+  SliceEm *sem = nullptr;         // the slice-level EM on the device (svr_em.inc)
   SlabPlan *slab = nullptr;       // sharded runs: the index lists and slab boundaries of reduce-scatter -> slab update -> all-gather (svr_slab.inc)
   bool vol_clean[2] = {false, false};   // d_recon_volw / d_recon_new known to be zero outside the dilated mask (svr_slab.inc)
   CellState *cell = nullptr;      // the scatter's cell lists
@@ -3797,6 +3798,7 @@ void svr_destroy(svr_ctx *ctx) {
   cell_free(ctx->cell_g);
   free_dev(ctx->d_cellc);
   slab_free(ctx->slab);
+  slice_em_free(ctx->sem);
   free_dev(ctx->d_spx);
   free_dev(ctx->d_counter);
   free_dev(ctx->d_out);
@@ -5475,3 +5477,4 @@ int svr_counters(svr_ctx *ctx, uint64_t out5[8]) {
 
 #include "svr_reg.inc"
 #include "svr_pyr.inc"
+#include "svr_em.inc"

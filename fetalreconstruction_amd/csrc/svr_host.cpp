@@ -91,6 +91,50 @@ class irtkReconstruction {
     return v;
   }
   int ref_index(int k) const { return order.empty() ? k : order[k]; }
+
+  // ---- the slice-level EM on the device (round 5; csrc/svr_em.inc) --------------------------------------------------------------
+  // The host half of EStepGPU below -- potentials down, a two-class EM over the slices, slice weights up -- was the one wait of an SR
+  // iteration and, sharded, its one host exchange.  With SVR_DEVICE_SLICE_EM (default on; sharded: when the launcher supplies
+  // allgather_device) the E-step's potentials, the scale vector and slice_inside of every rank meet on the device (one all-gather of
+  // 3 x maxn floats) and the EM runs there as one workgroup: an SR iteration only queues launches.  `_em_on_host` says whose copy of
+  // the slice-level state (_scale_gpu, _slice_weight_gpu, _slice_potential_gpu, _slice_inside_gpu, the eight scalars) is current;
+  // pull_state() brings the device's over in one wait when somebody reads it, push_state() sends the host's when it changed it.
+  bool dev_slice_em = getenv("SVR_DEVICE_SLICE_EM") ? atoi(getenv("SVR_DEVICE_SLICE_EM")) != 0 : true;
+  bool _sem_ready = false, _em_on_host = true;
+  bool use_device_slice_em() const { return dev_slice_em && device_em && (!sh.on || sh.coll.allgather_device); }
+  int push_state() {
+    if (!_sem_ready) {
+      const int W = sh.on ? sh.coll.world : 1, R = sh.on ? sh.coll.rank : 0;
+      std::vector<double> b((size_t)W + 1, 0.0);                       // every rank's range of this numbering: one small exchange, once
+      b[R] = lo;
+      if (R == W - 1) b[W] = hi;
+      if (sh.on && W > 1) ENG(sh.coll.allreduce_host(sh.coll.user, b.data(), W + 1, 0));
+      std::vector<int> rlo((size_t)W + 1);
+      for (int r = 0; r <= W; ++r) rlo[r] = (int)b[r];
+      ENG(svr_slice_em_setup(reconstructionGPU, ns, W, R, rlo.data(), order.empty() ? nullptr : order.data(), _step));
+      _sem_ready = true;
+      _em_on_host = true;
+    }
+    if (_em_on_host) {
+      std::vector<unsigned char> excl(ns, 0);
+      for (int i : _force_excluded) if (i >= 0 && i < ns) excl[i] = 1;
+      for (int i : _small_slices) if (i >= 0 && i < ns) excl[i] = 1;
+      const double s5[5] = {_mean_s_gpu, _mean_s2_gpu, _sigma_s_gpu, _sigma_s2_gpu, _mix_s_gpu};
+      const float em3[3] = {_sigma_gpu, _mix_gpu, _m_gpu};
+      ENG(svr_slice_em_set_state(reconstructionGPU, _slice_weight_gpu.data(), excl.data(), s5, em3));
+    }
+    return 0;
+  }
+  int pull_state() {
+    if (_em_on_host) return 0;
+    double s5[5];
+    float em3[3];
+    ENG(svr_slice_em_fetch(reconstructionGPU, _scale_gpu.data(), _slice_weight_gpu.data(), _slice_potential_gpu.data(), _slice_inside_gpu.data(), s5, em3));
+    _mean_s_gpu = (float)s5[0]; _mean_s2_gpu = (float)s5[1]; _sigma_s_gpu = (float)s5[2]; _sigma_s2_gpu = (float)s5[3]; _mix_s_gpu = (float)s5[4];
+    _sigma_gpu = em3[0]; _mix_gpu = em3[1]; _m_gpu = em3[2];
+    _em_on_host = true;
+    return 0;
+  }
   // The ns-sized vectors a rank has only its own part of (`_scale_stale`, `_inside_stale`) ride along with the next exchange
   // that every rank makes anyway (Shard::exchange: one collective): the M-step's sums, the E-step's potentials, the
   // robust-statistics sums.
@@ -113,6 +157,7 @@ class irtkReconstruction {
   bool _scale_pending = false, _inside_pending = false;
   int _mstep_pending = 0;                            // iteration number of an M-step not yet run, or 0
   int settle() {
+    if (int rc = pull_state()) return rc;              // (the device's slice-level state, if it is the current one)
     if (_mstep_pending) {
       const int iter = _mstep_pending;
       _mstep_pending = 0;
@@ -216,6 +261,28 @@ class irtkReconstruction {
 
   // RG.cc:3184-3440: voxel posteriors on the GPU, slice-level EM on the host
   int EStepGPU() {
+    if (use_device_slice_em()) {
+      // [M-step] + E-step + the slice-level EM without a wait and without a host exchange (csrc/svr_em.inc)
+      if (int rc = push_state()) return rc;
+      const int iter = _mstep_pending;
+      _mstep_pending = 0;
+      void *send = nullptr, *recv = nullptr;
+      if (iter > 0 && sh.on) {                         // the ranks' M-step sums meet on the device (round 4)
+        ENG(svr_mstep_partial(reconstructionGPU, sh.coll.world, &send, &recv));
+        if (int rc = sh.before_device_collective()) return fail(rc, "svr_stream_sync");
+        if (int rc = sh.coll.allgather_device(sh.coll.user, send, recv, 16)) return fail(rc, "allgather_device (M-step sums)");
+      }
+      size_t n = 0;
+      ENG(svr_mstep_estep_device(reconstructionGPU, iter, (float)_step, &send, &recv, &n));
+      if (sh.on) {                                     // every rank's potentials, scales and slice_inside: one all-gather of 3 x maxn floats
+        if (int rc = sh.before_device_collective()) return fail(rc, "svr_stream_sync");
+        if (int rc = sh.coll.allgather_device(sh.coll.user, send, recv, n)) return fail(rc, "allgather_device (slice potentials)");
+      }
+      ENG(svr_slice_em_run(reconstructionGPU));
+      _em_on_host = false;
+      _scale_pending = _inside_pending = _scale_stale = _inside_stale = false;   // (they travelled with the gather)
+      return 0;
+    }
     std::vector<float> loc(hi - lo);
     if (_mstep_pending && sh.on) {
       // sharded (round 4): the M-step's five sums of every rank meet ON THE DEVICE (the launcher's all-gather on the engine's stream),
@@ -348,12 +415,14 @@ class irtkReconstruction {
 
   // RG.cc:4024-4036
   int SuperresolutionGPU(int iter) {
+    // (the slice weights of a device-side EM are already where the scatter reads them: NULL = keep the device's)
+    const float *sw = _em_on_host ? local(_slice_weight_gpu) : nullptr;
     if (!sh.on) {
-      ENG(svr_superresolution(reconstructionGPU, iter, local(_slice_weight_gpu), _adaptive, (float)_alpha,
+      ENG(svr_superresolution(reconstructionGPU, iter, sw, _adaptive, (float)_alpha,
                               (float)_min_intensity, (float)_max_intensity, (float)_delta, (float)_lambda,
                               _global_bias_correction, _sigma_bias, _low_intensity_cutoff));
     } else {
-      ENG(sh.superresolution(local(_slice_weight_gpu), _adaptive, (float)_alpha, (float)_min_intensity, (float)_max_intensity, (float)_delta,
+      ENG(sh.superresolution(sw, _adaptive, (float)_alpha, (float)_min_intensity, (float)_max_intensity, (float)_delta,
                              (float)_lambda));
     }
     return 0;
@@ -613,7 +682,7 @@ void svrh_destroy(svrh_recon *r) { delete r; }
 const char *svrh_last_error(const svrh_recon *r) { return r ? r->impl.err.c_str() : "null"; }
 void svrh_set_intensity_range(svrh_recon *r, double mn, double mx) { r->impl._min_intensity = mn; r->impl._max_intensity = mx; }
 void svrh_set_smoothing_parameters(svrh_recon *r, double delta, double lambda) { r->impl.SetSmoothingParameters(delta, lambda); }
-void svrh_set_force_excluded(svrh_recon *r, const int *idx, int n) { r->impl._force_excluded.assign(idx, idx + n); }
+void svrh_set_force_excluded(svrh_recon *r, const int *idx, int n) { (void)r->impl.settle(); r->impl._force_excluded.assign(idx, idx + n); }
 int svrh_set_bias_correction(svrh_recon *r, int enable, double sigma_bias) {
   r->impl._disableBiasC = !enable;
   r->impl._sigma_bias = (float)sigma_bias;

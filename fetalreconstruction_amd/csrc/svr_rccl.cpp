@@ -255,7 +255,7 @@ const char *svr_comm_last_error(const svr_comm *c) { return c ? c->err.c_str() :
 void svr_comm_destroy(svr_comm *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipDeviceSynchronize();         // (not the engine's stream: the engine -- and its stream -- may be gone before its communicator)
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   delete c;

@@ -245,6 +245,11 @@ class irtkReconstruction:
     def SetSmoothingParameters(self, delta, lam):
         self._lib.svrh_set_smoothing_parameters(self._h, C.c_double(delta), C.c_double(lam))
 
+    def set_slab_update(self, on):
+        """sharded runs: the volume update by z-slabs (default) or all-reduce + the update replicated on every rank"""
+        self._lib.svrh_set_slab_update.restype = None
+        self._lib.svrh_set_slab_update(self._h, int(bool(on)))
+
     def set_unit_order(self, order):
         """order[k] = the reference's index of slice k of this object's numbering (sharding.shard_units); None = the same numbering"""
         a = None if order is None else np.ascontiguousarray(order, np.int32)

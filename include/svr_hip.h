@@ -365,6 +365,26 @@ int svr_counters(svr_ctx *ctx, uint64_t out8[8]);
 /* (pixel, plane) units of the pixels with s != -1 whose footprint reaches the volume: [0] such pixels, [1] live units (every tap
  * evaluated), [2] dead units (every row provably below the epsilon of RC.cu:238: only its first tap is processed) -- what
  * bench.py's `flops_executed` counts */
+/* ---- the slice-level EM of an SR iteration on the device (csrc/svr_em.inc; round 5) -------------------------------------------------
+ * The host half of irtkReconstruction::EStepGPU (irtkReconstructionGPU.cc:3282-3420: potentials down, a two-class EM over the slices on the
+ * host, slice weights up) as one workgroup behind the E-step's kernels: no wait for the device and no host exchange inside an SR iteration.
+ * An extension beside the methods of class Reconstruction (the adaptor of INTEGRATION.md 2 does not need it); csrc/svr_host.cpp uses it.
+ *   setup      ns_global slices in the caller's numbering, rank_lo[world + 1] = the ranks' ranges of it (this engine holds rank `rank`'s),
+ *              order_or_null[k] = the reference's index of slice k (sums over slices run in the reference's order), step = _step
+ *   set_state  the caller's copy of the state, when the caller changed it: global slice weights, force-excluded flags, {mean_s, mean_s2,
+ *              sigma_s, sigma_s2, mix_s}, {sigma, mix, m}
+ *   svr_mstep_estep_device  iter > 0: the M-step first (one rank: this engine's sums; more: svr_mstep_partial + the launcher's all-gather
+ *              before this call); the E-step; *send = {potential, scale, slice_inside} of this rank's slices, 3 x maxn floats, *recv = where
+ *              the launcher's all-gather puts every rank's (world x 3 x maxn; one rank: *recv == *send, nothing to do)
+ *   run        unpack, the EM, the new slice weights (this rank's part straight into the vector svr_superresolution_backproject(ctx, NULL) reads)
+ *   fetch      any of the outputs (NULL = not wanted) in ONE wait: global vectors in the caller's numbering, the scalars */
+int svr_slice_em_setup(svr_ctx *ctx, int ns_global, int world, int rank, const int *rank_lo, const int *order_or_null, double step);
+int svr_slice_em_set_state(svr_ctx *ctx, const float *slice_weights_global, const unsigned char *excluded_global, const double scalars5[5],
+                           const float em3[3]);
+int svr_mstep_estep_device(svr_ctx *ctx, int iter, float step, void **send, void **recv, size_t *n_floats_per_rank);
+int svr_slice_em_run(svr_ctx *ctx);
+int svr_slice_em_fetch(svr_ctx *ctx, float *scale_global, float *slice_weight_global, float *slice_potential_global,
+                       unsigned char *slice_inside_global, double scalars5[5], float em3[3]);
 int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]);
 /* PSF launches since svr_create that were asked for on the cell path (back_mode 5 / fwd_mode 2: no float atomics, the same bits from run
  * to run) and LEFT it because the cell lists cannot hold the geometry (centre coordinates beyond int16, more than 2^18 cells or 1024

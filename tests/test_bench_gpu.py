@@ -93,7 +93,7 @@ def test_bench_line_carries_the_s8_record_and_no_fallbacks():
     assert 100 < s8["value"] < 400 and abs(s8["value"] - s8["Va_total"] / s8["ms_per_step"] / 1e3) < 1e-6 * s8["value"]
     k = s8["ranks"]
     assert k["Va"] == [s8["Va_total"]] and k["units"] == [512]
-    assert k["exchanges_per_step"] == [1.0]                  # (steps 1..3 of an outer iteration: no EM re-initialisation inside the timed region)
+    assert k["exchanges_per_step"] == [0.0]                  # no host exchange inside an SR iteration: the slice-level EM runs on the device (csrc/svr_em.inc; steps 1..3: no EM re-initialisation in the timed region)
     assert k["backproject_ms"][0] > 5 and k["forward_ms"][0] > 5 and k["reduce_scatter_ms"][0] > 0 and k["allgather_ms"][0] > 0 and k["allreduce_ms"][0] == 0
     assert s8["collective_bytes_sent"] == k["collective_bytes_sent"] and k["collective_bytes_sent"][0] > 1e7
     assert s8["fallbacks"] == dict(scatter_to_atomics=0, gather_to_tiles=0, gauss1_to_tiles=0, tiles_rerun=0)
@@ -134,8 +134,8 @@ def test_rccl_communicator_of_the_c_library(tiny, oracle_mod):
         d.sr_iteration(2)
         tm = rec.timers()
         # (the volume update by z-slabs: one reduce-scatter and one all-gather instead of the all-reduce of the pair)
-        # ... and ONE host exchange (the E-step's potentials): the M-step's sums meet on the device (svr_mstep_partial / svr_mstep_estep_ranks)
-        assert tm["allreduce"][1] == 0 and tm["reduce_scatter"][1] == 1 and tm["allgather"][1] == 1 and tm["exchange_host"][1] == 1
+        # ... and NO host exchange: the M-step's sums (round 4) and the E-step's potentials (round 5: the slice-level EM, csrc/svr_em.inc) meet on the device
+        assert tm["allreduce"][1] == 0 and tm["reduce_scatter"][1] == 1 and tm["allgather"][1] == 1 and tm["exchange_host"][1] == 0
         assert tm["reduce_scatter"][0] > 0 and tm["allgather"][0] > 0
     recs[1][1].close()
 
@@ -214,6 +214,52 @@ def test_only_the_masks_bounding_box_is_exchanged(tiny):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("through_comm", [False, True])
+def test_slice_level_em_on_the_device_against_the_host_form(tiny, monkeypatch, through_comm):
+    """Round 5 (csrc/svr_em.inc): the host half of EStepGPU -- the two-class EM over the slices, irtkReconstructionGPU.cc:3282-3420 -- as one
+    workgroup behind the E-step's kernels, fed by the launcher's all-gather of every rank's potentials / scales / slice_inside: an SR iteration
+    makes NO host exchange and waits for nothing.  Against the host form (SVR_DEVICE_SLICE_EM=0) on the same problem: the same excluded
+    slices, slice weights within 1e-6 (the five sums over the slices are taken by 256 threads and a tree instead of one after the other:
+    ~1e-15 before they are rounded to float), EM scalars to 1e-6 relative, the volume to the float-sum tolerance -- one rank without a
+    communicator, and through the C library's RCCL communicator at world 1 (all-gather, reduce-scatter, slab update).  A force-excluded slice
+    stays excluded; reading the state in the middle of the loop (svrh_get_state: the device's copy comes over in one wait) changes nothing."""
+    import numpy as np
+    from fetalreconstruction_amd import engine as E, host
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SVR_DEVICE_SLICE_EM", mode)
+        rec = E.Reconstruction(0)
+        E.sync_gpu(rec, tiny)
+        comm = host.RcclComm(rec, 0, 1, host.RcclComm.unique_id()) if through_comm else None
+        d = host.irtkReconstruction(rec, tiny.ns, (0, tiny.ns), comm, tiny.max_intensity, tiny.min_intensity, force_collectives=through_comm)
+        d.SetForceExcludedSlices([3])
+        d.SetSmoothingParameters(150, 0.02)
+        d.reconstruct_iteration(2)
+        mid = d.state()                                            # (a read in the middle: pull, then the host's copy goes back up)
+        rec.timer_enable(True)
+        rec.timer_reset()
+        for i in range(2, 4):
+            d.sr_iteration(i)
+        n_exchanges = rec.timers()["exchange_host"][1]
+        st = d.state()
+        out[mode] = (rec.syncCPU().copy(), st, mid, n_exchanges)
+        if comm:
+            comm.close()
+        rec.close()
+    (v0, s0, m0, x0), (v1, s1, m1, x1) = out["0"], out["1"]
+    assert x1 == 0 and x0 == (2 if through_comm else 0)           # host form, sharded path: one exchange per SR iteration
+    for a, b in ((m0, m1), (s0, s1)):
+        assert np.array_equal(a["slice_weight"] == 0, b["slice_weight"] == 0) and a["slice_weight"][3] == 0 and b["slice_weight"][3] == 0
+        assert np.abs(a["slice_weight"] - b["slice_weight"]).max() <= 1e-6
+        assert np.allclose(a["scale"], b["scale"], rtol=1e-6) and np.array_equal(a["slice_inside"], b["slice_inside"])
+        assert np.allclose(a["slice_potential"], b["slice_potential"], rtol=1e-5, atol=1e-7)
+        for k in ("sigma", "mix", "m", "mean_s", "mean_s2", "sigma_s", "sigma_s2", "mix_s"):
+            assert a[k] == pytest.approx(b[k], rel=1e-6), k
+    assert 0 < (s1["slice_weight"] > 0).sum() < tiny.ns
+    assert np.array_equal(v0 == -1, v1 == -1) and np.abs(v0 - v1).max() <= 2e-5 * np.abs(v0).max()
+
+
+@pytest.mark.gpu
 def test_m_step_sums_meeting_on_the_device_give_the_host_exchanges_bits(tiny, monkeypatch):
     """A sharded SR iteration makes ONE host exchange since round 4: the M-step's five sums of every rank are all-gathered on the device,
     added up there in rank order and fed to the E-step (svr_mstep_partial / svr_mstep_estep_ranks, csrc/svr_host.cpp EStepGPU) instead of
@@ -222,6 +268,7 @@ def test_m_step_sums_meeting_on_the_device_give_the_host_exchanges_bits(tiny, mo
     import numpy as np
     from fetalreconstruction_amd import engine as E, host
     out = {}
+    monkeypatch.setenv("SVR_DEVICE_SLICE_EM", "0")        # (the slice-level EM on the host: what this test compares are the two ways of the M-step's sums)
     for mode in ("0", "1"):
         monkeypatch.setenv("SVR_DEVICE_EM", mode)
         rec = E.Reconstruction(0)

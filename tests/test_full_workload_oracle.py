@@ -89,6 +89,12 @@ def test_every_pixel_and_voxel_of_p4_against_the_oracle(mode_name, workload, ora
     from fetalreconstruction_amd import engine as E
     if workload == "PVR4" and mode_name == "LITERAL" and "SVR_FULL_WORKLOADS" not in __import__("os").environ:
         pytest.skip("a minute of the default suite: runs with SVR_FULL_WORKLOADS=PVR4 (recorded: every hit set identical, share beyond 3e-3 max <= 5.6e-5)")
+    if workload == "P4" and mode_name == "LITERAL" and "SVR_FULL_WORKLOADS" not in __import__("os").environ:
+        # round 5: the suite is held under 12 minutes on the MI355X box (the driver's step has 20).  The LITERAL comparison stays in the suite on the
+        # tiny problem and in the bundled mask's frame (tests/test_round2_gaps.py, tests/test_real_geometry.py); at full size it runs with
+        # SVR_FULL_WORKLOADS=P4 (recorded in round 4: share of elements beyond 3e-3 max <= 1.7e-4, relative L2 <= 1.7e-3) and S8 / PVR8spx are
+        # committed logs (profiles/r05_full_workload_*.txt)
+        pytest.skip("half a minute of the default suite: runs with SVR_FULL_WORKLOADS=P4")
     P = workloads.get(workload)
     ns, sy, sx = P.slices.shape
     rng = np.random.default_rng(17)

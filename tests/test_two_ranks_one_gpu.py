@@ -11,7 +11,7 @@ import tempfile
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.gpu if __name__ != "__main__" else None
 
 
 def _free_port():
@@ -27,8 +27,8 @@ def _problem():
     return phantom.make_problem(3, (40, 36, 10), 1.1, 2.2, None, 1.0, 15.0, seed=11, orientations=("ax", "cor", "sag"), name="two-rank")
 
 
-def _worker(rank, world, port, outdir, slabs):
-    import torch
+def _worker(rank, world, port, outdir, slabs, slab_update=True):
+    import torch                                       # before the engine's library: torch carries its own copy of the HIP runtime
     import torch.distributed as dist
     from fetalreconstruction_amd import engine as E, host, phantom
     from fetalreconstruction_amd.sharding import TorchComm, shard_units, slice_cost_weights
@@ -45,6 +45,8 @@ def _worker(rank, world, port, outdir, slabs):
         E.sync_gpu(rec, phantom.sub_problem(P, 0, 0, select=order[lo:hi]))
         d = host.irtkReconstruction(rec, P.ns, (lo, hi), TorchComm(device=None, slabs=slabs), P.max_intensity, P.min_intensity)
         d.set_unit_order(order)
+        if not slab_update:                               # the replicated form of the update with the same launcher (device collectives and all)
+            d.set_slab_update(False)
         d.SetSmoothingParameters(150, 0.02)
         rec.timer_enable(True)
         d.reconstruct_iteration(3)
@@ -58,9 +60,23 @@ def _worker(rank, world, port, outdir, slabs):
         dist.destroy_process_group()
 
 
+
+def _spawn(world, slabs, slab_update, outdir):
+    """two worker PROCESSES of this file (not torch.multiprocessing: importing torch into the pytest process next to the engine's library
+    puts two HIP runtimes into one process, which corrupts the heap at exit)"""
+    import subprocess
+    import sys
+    port = _free_port()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), str(world), str(port), outdir, str(int(slabs)), str(int(slab_update))],
+                              cwd=root, env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
 @pytest.mark.timeout(900)
 def test_two_processes_on_one_gpu_through_the_cpp_sharded_host():
-    import torch.multiprocessing as mp
     from fetalreconstruction_amd import engine as E, host
     P = _problem()
     rec = E.Reconstruction(0)
@@ -71,21 +87,22 @@ def test_two_processes_on_one_gpu_through_the_cpp_sharded_host():
     v_ref, s_ref = rec.syncCPU().copy(), ref.state()
     rec.close()
     runs = {}
-    for slabs in (True, False):
+    for key, slabs, slab_update in (("slab", True, True), ("replicated", True, False), ("no device collectives", False, True)):
         with tempfile.TemporaryDirectory() as d:
-            mp.spawn(_worker, args=(2, _free_port(), d, slabs), nprocs=2, join=True)
-            runs[slabs] = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(2)]
-    for slabs, (r0, r1) in runs.items():
+            _spawn(2, slabs, slab_update, d)
+            runs[key] = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(2)]
+    for key, (r0, r1) in runs.items():
+        slabs = key != "no device collectives"
         # both ranks end with the same volume and the same host state
         for k in ("recon", "scale", "sw", "pot", "em"):
             assert np.array_equal(r0[k], r1[k]), (slabs, k)
         assert r0["lohi"][0] == 0 and r0["lohi"][1] == r1["lohi"][0] and r1["lohi"][1] == P.ns
         # Gaussian pass: one all-reduce; per SR iteration: reduce-scatter + all-gather (slab) or one all-reduce (replicated), ONE host exchange
         rs, ag, ar, ex = (int(v) for v in r0["counts"])
-        assert (rs, ag, ar) == ((3, 3, 1) if slabs else (0, 0, 4)), (slabs, rs, ag, ar)
-        # robust statistics + the first E-step, then per SR iteration ONE exchange (the M-step's sums meet on the device through the launcher's
-        # all-gather) -- or two where the launcher supplies no device collectives and the sums travel through the hosts
-        assert ex == (2 + 3 if slabs else 2 + 2 * 3), (slabs, ex)
+        assert (rs, ag, ar) == ((3, 3, 1) if key == "slab" else (0, 0, 4)), (key, rs, ag, ar)
+        # with the launcher's device collectives: ONE exchange in all (the robust statistics' two sums) -- the M-step's sums and the slice-level
+        # EM's potentials meet on the device (csrc/svr_em.inc); without them: robust statistics + the first E-step + two per SR iteration
+        assert ex == (1 if slabs else 2 + 2 * 3), (slabs, ex)
         # ... which is the one-rank result up to the float rounding of the per-rank partial sums; per-slice vectors in the sharded numbering
         order = r0["order"]
         assert np.abs(r0["recon"] - v_ref).max() <= 2e-5 * np.abs(v_ref).max()
@@ -93,5 +110,10 @@ def test_two_processes_on_one_gpu_through_the_cpp_sharded_host():
         assert np.allclose(r0["scale"], s_ref["scale"][order], rtol=1e-5) and np.allclose(r0["sw"], s_ref["slice_weight"][order], atol=1e-4)
         assert np.allclose(r0["em"], [s_ref[k] for k in ("sigma", "mix", "m", "mean_s", "mean_s2", "sigma_s", "sigma_s2", "mix_s")], rtol=1e-4)
     # the slab update against the replicated one: rank-ordered sums either way -> the same bits
-    a, b = runs[True][0], runs[False][0]
+    a, b = runs["slab"][0], runs["replicated"][0]
     assert np.array_equal(a["recon"], b["recon"]) and np.array_equal(a["scale"], b["scale"]) and np.array_equal(a["sw"], b["sw"]) and np.array_equal(a["em"], b["em"])
+
+
+if __name__ == "__main__":
+    import sys
+    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], bool(int(sys.argv[5])), bool(int(sys.argv[6])))

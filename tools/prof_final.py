@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Round-4 evidence (the round-2 script, re-pointed), run on the GPU box from the repo root (one gpurun call):
+"""Round-5 evidence (the round-2 script, re-pointed), run on the GPU box from the repo root (one gpurun call):
 
   1. bench lines: P4 (with the CPU baseline) and S8
-  2. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`      -> profiles/r04_kernel_stats_p4.txt
+  2. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`      -> profiles/r05_kernel_stats_p4.txt
   3. rocprofv3 --kernel-trace --pmc passes (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE -- each its own pass) over
-     tools/run_sr_kernels.py on P4 and on S8                                -> profiles/r04_pmc_p4.txt, r04_pmc_s8.txt
-  4. profiles/r04_traffic.json: FETCH_SIZE / WRITE_SIZE of the scatter and the gather per launch (KB -> bytes), which
-     bench.py reads for roofline.traffic; then the P4 bench line again with it           -> profiles/r04_bench_p4.json
+     tools/run_sr_kernels.py on P4 and on S8                                -> profiles/r05_pmc_p4.txt, r05_pmc_s8.txt
+  4. profiles/r05_traffic.json: FETCH_SIZE / WRITE_SIZE of the scatter and the gather per launch (KB -> bytes), which
+     bench.py reads for roofline.traffic; then the P4 bench line again with it           -> profiles/r05_bench_p4.json
 """
 import csv
 import glob
@@ -18,7 +18,7 @@ import subprocess
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r04"
+TAG = "r05"
 OUT = os.path.join(R, "gpurun_out", TAG)
 PROF = os.path.join(R, "profiles")
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -49,12 +49,12 @@ def pmc(workload, tag, opts=()):
     p = sh([sys.executable, os.path.join(R, "tools", "pmc.py"), d, "--filter", "k", "--", sys.executable,
             os.path.join(R, "tools", "run_sr_kernels.py"), workload, *opts])
     txt = p.stdout
-    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} {' '.join(opts)} (1 GPU), round 4.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
+    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} {' '.join(opts)} (1 GPU), round 5.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
             "# rocprofv3 --kernel-trace --pmc <set> pass per counter set (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE), nothing else in\n"
             "# the pass.  Per kernel: mean over the last half of its dispatches.  SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are in\n"
             "# quad-cycles summed over the SIMDs, FETCH_SIZE / WRITE_SIZE in KB (uncalibrated for this access pattern: narrow LDS-staged\n"
             "# reads and float atomics -- MI355X_MICROARCH.md calibrates only wide streaming reads -- so they are reported as counted).\n")
-    open(os.path.join(PROF, f"r04_pmc_{tag}.txt"), "w").write(head + txt)
+    open(os.path.join(PROF, f"r05_pmc_{tag}.txt"), "w").write(head + txt)
     vals = {}
     cur = None
     for line in txt.splitlines():
@@ -72,7 +72,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     bench = os.path.join(R, "bench.py")
     # 3. PMC first (the traffic file must exist before the final bench line)
-    traffic = {"source": "profiles/r04_pmc_<workload>.txt (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes; "
+    traffic = {"source": "profiles/r05_pmc_<workload>.txt (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes; "
                          "per pass the kernels of one scatter / gather launch summed)"}
 
     def collect(vals, pats):
@@ -101,27 +101,27 @@ def main():
         if x:
             traffic["P4"][key] = x
     if traffic.get("P4", {}).get("back"):
-        json.dump(traffic, open(os.path.join(PROF, "r04_traffic.json"), "w"), indent=1)
+        json.dump(traffic, open(os.path.join(PROF, "r05_traffic.json"), "w"), indent=1)
     # 1. bench lines
     b4 = sh([sys.executable, bench], os.path.join(OUT, "bench_p4.log"), cwd=R)
     j4 = last_json(b4.stdout)
     if j4:
-        json.dump(j4, open(os.path.join(PROF, "r04_bench_p4.json"), "w"), indent=1)
+        json.dump(j4, open(os.path.join(PROF, "r05_bench_p4.json"), "w"), indent=1)
     b8 = sh([sys.executable, bench, "--workload", "S8", "--no-cpu-baseline"], os.path.join(OUT, "bench_s8.log"), cwd=R)
     j8 = last_json(b8.stdout)
     if j8:
-        json.dump(j8, open(os.path.join(PROF, "r04_bench_s8.json"), "w"), indent=1)
+        json.dump(j8, open(os.path.join(PROF, "r05_bench_s8.json"), "w"), indent=1)
     for wl in ("PVR4", "PVR8spx"):
         bp = sh([sys.executable, bench, "--workload", wl, "--no-cpu-baseline"], os.path.join(OUT, f"bench_{wl.lower()}.log"), cwd=R)
         jp = last_json(bp.stdout)
         if jp:
-            json.dump(jp, open(os.path.join(PROF, f"r04_bench_{wl.lower()}.json"), "w"), indent=1)
+            json.dump(jp, open(os.path.join(PROF, f"r05_bench_{wl.lower()}.json"), "w"), indent=1)
     # 2. kernel trace of the bench command
     d = os.path.join(OUT, "stats")
     p = sh(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline"],
            os.path.join(OUT, "stats.log"))
     jt = last_json(p.stdout)
-    lines = ["# round 4: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r04/stats -o bench -- python bench.py --no-cpu-baseline",
+    lines = ["# round 5: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r05/stats -o bench -- python bench.py --no-cpu-baseline",
              "# (tools/prof_final.py; rocprofv3 of this image writes a rocpd database: `top_kernels` view below)"]
     if jt:
         lines.append("# bench line of the profiled run: value %.2f MVoxels/s, %.3f ms/step; scatter avg launch %.3f ms, gather %.3f ms by HIP events; roofline.frac %.4f"
@@ -155,7 +155,7 @@ def main():
         csvs = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
         if csvs:
             lines += open(csvs[0]).read().splitlines()[:30]
-    open(os.path.join(PROF, "r04_kernel_stats_p4.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(PROF, "r05_kernel_stats_p4.txt"), "w").write("\n".join(lines) + "\n")
     # 4. again with the traffic file in place (same box, same build)
     print("\n".join(lines[:12]))
     print(json.dumps(traffic.get("P4")))

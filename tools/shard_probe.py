@@ -24,7 +24,12 @@ import numpy as np
 XGMI_LINK_GBS = 76.8
 XGMI_EFF = 0.5
 HOST_EXCHANGE_MS = 0.08      # one stream synchronisation + one small collective (60-100 us measured at world 1)
-HOST_EXCHANGES = {"svr": 1, "pvr": 1}   # per SR iteration: the E-step's potentials (the M-step's sums meet on the device: csrc/svr_host.cpp, csrc/pvr_host.cpp)
+# per SR iteration.  Patch-based host: the E-step's potentials (the M-step's sums meet on the device).  SVR host since round 5: none -- the
+# slice-level EM runs on the device (csrc/svr_em.inc); what it costs instead are two SMALL device collectives on the engine's stream (the
+# M-step's 16 floats per rank, the potentials' 3 x maxn floats per rank), priced at a stated latency each
+HOST_EXCHANGES = {"svr": 0, "pvr": 1}
+SMALL_COLLECTIVES = {"svr": 2, "pvr": 1}
+SMALL_COLLECTIVE_MS = 0.02   # an assumption (RCCL's small-message latency on one node); stated in the output
 
 
 def build(wl):
@@ -181,11 +186,12 @@ def project_at(res, gbs_per_direction):
     psf = max(k["backproject"] + k["forward"] + em(k) for k in sh)
     reg_full = max(k["regularize"] for k in sh)
     ms = lambda nbytes: nbytes * (W - 1) / W / (gbs_per_direction * 1e9) * 1e3 if W > 1 else 0.0
-    nex = HOST_EXCHANGES["pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"]
+    kind = "pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"
+    small = HOST_EXCHANGES[kind] * HOST_EXCHANGE_MS + SMALL_COLLECTIVES[kind] * SMALL_COLLECTIVE_MS
     mfrac = res.get("mask_fraction", 1.0)
     rs_ms, ag_ms, ar_ms = ms(2 * nv * 4 * mfrac), ms(nv * 4 * min(1.0, mfrac * 1.15)), 2 * ms(2 * nv * 4)
-    slab = psf + rs_ms + reg_full / W + ag_ms + nex * HOST_EXCHANGE_MS
-    repl = psf + ar_ms + reg_full + nex * HOST_EXCHANGE_MS
+    slab = psf + rs_ms + reg_full / W + ag_ms + small
+    repl = psf + ar_ms + reg_full + small
     return dict(rate_GBs=gbs_per_direction, collectives_slab_ms=rs_ms + ag_ms, step_slab_ms=slab, speedup_slab=one / slab, allreduce_ms=ar_ms,
                 step_replicated_ms=repl, speedup_replicated=one / repl)
 
@@ -207,16 +213,19 @@ def project(res):
     reg_full = max(k["regularize"] for k in sh)
     # replicated: all-reduce of addon|cmap (2 Nv floats: reduce-scatter + all-gather of the whole message), whole-volume update
     ar = 2 * collective_ms(2 * nv * 4, W)
-    nex = HOST_EXCHANGES["pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"]
-    replicated = psf + ar + reg_full + nex * HOST_EXCHANGE_MS
+    kind = "pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"
+    nex = HOST_EXCHANGES[kind]
+    small = nex * HOST_EXCHANGE_MS + SMALL_COLLECTIVES[kind] * SMALL_COLLECTIVE_MS
+    replicated = psf + ar + reg_full + small
     # slab: reduce-scatter of addon|cmap over the mask's voxels (+ halo planes), update of the rank's slab, all-gather of the volume
     mfrac = res.get("mask_fraction", 1.0)
     rs_ms = collective_ms(2 * nv * 4 * mfrac, W)
     ag_ms = collective_ms(nv * 4 * min(1.0, mfrac * 1.15), W)
-    slab = psf + rs_ms + reg_full / W + ag_ms + nex * HOST_EXCHANGE_MS
+    slab = psf + rs_ms + reg_full / W + ag_ms + small
     return dict(label="PROJECTION from one-GPU per-shard kernel times; no collective was run",
                 assumptions=dict(xgmi_link_GBs_per_direction=XGMI_LINK_GBS, links_used=min(W - 1, 7), efficiency=XGMI_EFF,
-                                 host_exchange_ms=HOST_EXCHANGE_MS, host_exchanges_per_step=nex),
+                                 host_exchange_ms=HOST_EXCHANGE_MS, host_exchanges_per_step=nex, small_device_collectives_per_step=SMALL_COLLECTIVES[kind],
+                                 small_device_collective_ms=SMALL_COLLECTIVE_MS),
                 one_gpu_kernels_ms=one, max_rank_psf_em_ms=psf, sum_rank_psf_ms=sum(k["backproject"] + k["forward"] for k in sh),
                 shard_overhead=sum(k["backproject"] + k["forward"] for k in sh) / (full["backproject"] + full["forward"]),
                 at_link_rates={name: project_at(res, (min(W - 1, 7) * XGMI_LINK_GBS * XGMI_EFF) if name.startswith("7 links") else rate)
