@@ -30,7 +30,7 @@
 
 int main(int argc, char **argv) {
   std::string output, mask_name, tfolder, sfolder;
-  bool debug = false, dry_run = false;
+  bool debug = false, dry_run = false, save_slice_transformations = false;
   std::string dump_name;
   std::vector<std::string> inputs, tspecs;
   std::vector<double> thickness;
@@ -81,6 +81,7 @@ int main(int argc, char **argv) {
     else if (o == "--sfolder") sfolder = one();
     else if (o == "--coeffTable") coeff_table = true;                     // not a reference option: keep the PSF taps in HBM (CoeffInit on the GPU path)
     else if (o == "--debug") debug = opt_bool(true);
+    else if (o == "--saveSliceTransformations") save_slice_transformations = true;   // main.cc:211, 1213-1217
     else if (o == "--dumpProblem") dump_name = one();                     // test hooks: what the engine is about to receive [--dryRun: stop there]
     else if (o == "--dryRun") dry_run = true;
     else if (o == "--useCPUReg" || o == "--disableBiasCorrection" || o == "--debug_gpu") {}
@@ -89,7 +90,8 @@ int main(int argc, char **argv) {
       printf("usage: SVRreconstructionGPU -o <volume> -i <stack_1> .. <stack_N> [-m <mask>] [-t id|<4x4.txt> ..] [--thickness th_1 ..]\n"
              "       [--iterations 4] [--resolution 0.75] [--multires 3] [--average 700] [--delta 150] [--lambda 0.02]\n"
              "       [--lastIterLambda 0.01] [--smooth_mask 4] [--no_intensity_matching] [--force_exclude i ..]\n"
-             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [--tfolder dir] [--sfolder dir] [--coeffTable] [-d device_1 .. device_N]\n");
+             "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [--tfolder dir] [--sfolder dir]\n"
+             "       [--saveSliceTransformations] [--coeffTable] [-d device_1 .. device_N]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/svr_cli.cpp)");
@@ -422,6 +424,29 @@ int main(int argc, char **argv) {
     svrh_get_state(host, nullptr, nullptr, nullptr, nullptr, sc);
     fprintf(stderr, "iteration %d: sigma %.4g mix %.3f\n", it, sc[0], sc[1]);
     clk.mark("reconstruction iteration");
+    if (save_slice_transformations) {
+      // SaveSlices + SaveTransformations after every iteration (main.cc:1213-1217; RG.cc:4884-4892, 4903-4919), into the working
+      // directory like the reference: slice<i>.nii.gz (the masked slice), croppedSliceTransformation<i>.dof (the slice's transformation)
+      // and croppedSliceToVolumeTransformation<i>.dof (reconstructed W2I x transformation x slice I2W squeezed into a rigid
+      // transformation by PutMatrix, as the reference does) -- <i> = the slice's index in the reference's order
+      const M4 rw2i = world_to_image(tattr);
+      for (int s = 0; s < ns; ++s) {
+        const int i = order[s];
+        const svr_image_attr &a = sattr[s];
+        std::vector<float> img((size_t)a.nx * a.ny);
+        for (int y = 0; y < a.ny; ++y) memcpy(&img[(size_t)y * a.nx], &grid[((size_t)s * my + y) * mx], a.nx * sizeof(float));
+        char e[256] = {0};
+        if (svr_nifti_write(("slice" + std::to_string(i) + ".nii.gz").c_str(), &a, img.data(), e)) die(std::string("slice file: ") + e);
+        M4 t;
+        for (int q = 0; q < 16; ++q) t.m[q] = T[16 * (size_t)s + q];
+        double p6[6];
+        svrh_irtk_rigid_parameters(t.m, p6, nullptr);
+        if (svr_dof_write(("croppedSliceTransformation" + std::to_string(i) + ".dof").c_str(), p6, e)) die(std::string("dof file: ") + e);
+        const M4 c = mul(rw2i, mul(t, image_to_world(a)));
+        svrh_irtk_rigid_parameters(c.m, p6, nullptr);
+        if (svr_dof_write(("croppedSliceToVolumeTransformation" + std::to_string(i) + ".dof").c_str(), p6, e)) die(std::string("dof file: ") + e);
+      }
+    }
   }
   par([&](int r) {                                                       // main.cc:1189-1193
     ENGR(r, svr_restore_slice_intensities(ctxs[r], factors.data(), (int)factors.size(), stack_index.data() + rlo[r]));

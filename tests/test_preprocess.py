@@ -219,6 +219,19 @@ def test_transformations_round_trip_through_tfolder(tmp_path):
     va, _ = nifti.read(first / "r.nii.gz")
     ok = (va > 0) & (vb > 0)
     assert np.corrcoef(va[ok], vb[ok])[0, 1] > 0.95                       # same registered slices, same last-iteration settings
+    # --saveSliceTransformations (reconstruction.cc:211, 1213-1217): SaveSlices + SaveTransformations after every iteration, into the working
+    # directory -- the masked slices and, per slice, its transformation and the slice-to-volume composite as rigid dof files
+    work = tmp_path / "w"
+    work.mkdir()
+    r3 = subprocess.run([build.CLI, "-o", str(work / "d.nii.gz"), *common, "--iterations", "1", "--no_registration", "--tfolder", str(first),
+                         "--saveSliceTransformations"], capture_output=True, text=True, timeout=300, cwd=work)
+    assert r3.returncode == 0, r3.stderr
+    assert len(list(work.glob("slice*.nii.gz"))) == 36 and len(list(work.glob("croppedSliceTransformation*.dof"))) == 36
+    assert len(list(work.glob("croppedSliceToVolumeTransformation*.dof"))) == 36
+    q6, _ = nifti.read_dof(work / "croppedSliceTransformation7.dof")
+    assert np.allclose(q6, p6, atol=1e-9)                                 # what --tfolder read is what is written back
+    sl, sa = nifti.read(work / "slice7.nii.gz")
+    assert sa.nz == 1 and (sl == -1).any() and (sl > 0).any()             # the masked slice: -1 outside the mask
 
 
 @pytest.mark.gpu

@@ -68,7 +68,18 @@ def pmc(workload, tag, opts=()):
     return vals
 
 
+def stats_only():
+    """2. alone: the kernel trace of the bench command (headline workload only: `--no-s8`, so that the per-kernel averages are P4's)"""
+    os.makedirs(OUT, exist_ok=True)
+    bench = os.path.join(R, "bench.py")
+    j4 = json.load(open(os.path.join(PROF, "r05_bench_p4.json"))) if os.path.exists(os.path.join(PROF, "r05_bench_p4.json")) else None
+    j8 = json.load(open(os.path.join(PROF, "r05_bench_s8.json"))) if os.path.exists(os.path.join(PROF, "r05_bench_s8.json")) else None
+    kernel_stats(bench, j4, j8)
+
+
 def main():
+    if "--stats-only" in sys.argv:
+        return stats_only()
     os.makedirs(OUT, exist_ok=True)
     bench = os.path.join(R, "bench.py")
     # 3. PMC first (the traffic file must exist before the final bench line)
@@ -116,13 +127,22 @@ def main():
         jp = last_json(bp.stdout)
         if jp:
             json.dump(jp, open(os.path.join(PROF, f"r05_bench_{wl.lower()}.json"), "w"), indent=1)
+    kernel_stats(bench, j4, j8)
+    print(json.dumps(traffic.get("P4")))
+    print("S8 pmc kernels:", list(v8)[:6])
+
+
+def kernel_stats(bench, j4, j8):
     # 2. kernel trace of the bench command
+    import shutil
     d = os.path.join(OUT, "stats")
-    p = sh(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline"],
+    shutil.rmtree(d, ignore_errors=True)
+    p = sh(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline", "--no-s8"],
            os.path.join(OUT, "stats.log"))
     jt = last_json(p.stdout)
-    lines = ["# round 5: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r05/stats -o bench -- python bench.py --no-cpu-baseline",
-             "# (tools/prof_final.py; rocprofv3 of this image writes a rocpd database: `top_kernels` view below)"]
+    lines = ["# round 5: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r05/stats -o bench -- python bench.py --no-cpu-baseline --no-s8",
+             "# (tools/prof_final.py; rocprofv3 of this image writes a rocpd database: `top_kernels` view below.  --no-s8: the default command also measures S8",
+             "#  after the headline workload in the same launch -- with it the per-kernel averages below would mix P4's 3 ms launches with S8's 33 ms ones)"]
     if jt:
         lines.append("# bench line of the profiled run: value %.2f MVoxels/s, %.3f ms/step; scatter avg launch %.3f ms, gather %.3f ms by HIP events; roofline.frac %.4f"
                      % (jt["value"], jt["ms_per_step"], jt["kernel_ms"]["backproject"], jt["kernel_ms"]["forward"], jt["roofline"]["frac"]))
@@ -156,10 +176,7 @@ def main():
         if csvs:
             lines += open(csvs[0]).read().splitlines()[:30]
     open(os.path.join(PROF, "r05_kernel_stats_p4.txt"), "w").write("\n".join(lines) + "\n")
-    # 4. again with the traffic file in place (same box, same build)
     print("\n".join(lines[:12]))
-    print(json.dumps(traffic.get("P4")))
-    print("S8 pmc kernels:", list(v8)[:6])
 
 
 if __name__ == "__main__":
