@@ -417,6 +417,7 @@ class irtkReconstruction {
   int SuperresolutionGPU(int iter) {
     // (the slice weights of a device-side EM are already where the scatter reads them: NULL = keep the device's)
     const float *sw = _em_on_host ? local(_slice_weight_gpu) : nullptr;
+    if (!sw) ENG(svr_slice_em_apply_weights(reconstructionGPU));   // (whatever anybody sent the engine in between: the EM's weights, device to device)
     if (!sh.on) {
       ENG(svr_superresolution(reconstructionGPU, iter, sw, _adaptive, (float)_alpha,
                               (float)_min_intensity, (float)_max_intensity, (float)_delta, (float)_lambda,
@@ -723,6 +724,8 @@ int svrh_get_registration_slices(svrh_recon *r, int size3[3], float *data_or_nul
 int svrh_set_unit_order(svrh_recon *r, const int *order_or_null) {
   if (!r) return SVR_E_ARG;
   svr::irtkReconstruction &m = r->impl;
+  if (int rc = m.settle()) return rc;                  // (the device's copy of the slice-level state, if it is the current one, in the old numbering)
+  m._sem_ready = false;                                // the device-side EM learns the new numbering at its next use
   if (!order_or_null) { m.order.clear(); return SVR_OK; }
   std::vector<char> seen(m.ns, 0);
   for (int k = 0; k < m.ns; ++k) {

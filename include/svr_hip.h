@@ -383,6 +383,7 @@ int svr_slice_em_set_state(svr_ctx *ctx, const float *slice_weights_global, cons
                            const float em3[3]);
 int svr_mstep_estep_device(svr_ctx *ctx, int iter, float step, void **send, void **recv, size_t *n_floats_per_rank);
 int svr_slice_em_run(svr_ctx *ctx);
+int svr_slice_em_apply_weights(svr_ctx *ctx);   /* the EM's weights of this rank's slices -> the scatter's vector again (device to device) */
 int svr_slice_em_fetch(svr_ctx *ctx, float *scale_global, float *slice_weight_global, float *slice_potential_global,
                        unsigned char *slice_inside_global, double scalars5[5], float em3[3]);
 int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]);
