@@ -559,9 +559,13 @@ def main():
 
         def entry(kernel, avg, n, alg_bytes, key):
             e = pmc_entry(prob.name, world, key)
-            ach = flops / avg / 1e12 if n else None
+            # achieved / frac: the flops the kernel EXECUTES (38 per evaluated tap; dead units one tap per row) -- the conservative figure, the one
+            # the round-4 review carried; *_formula: the reference's 49-flop formula credited on all taps of every pixel (rounds 1-4's `frac`)
+            ach = flops_exec / avg / 1e12 if n else None
+            ach_f = flops / avg / 1e12 if n else None
             out_ = {"kernel": kernel, "bound": "valu_f32", "achieved": ach, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": (ach / F32_PEAK_TFLOPS) if ach else None,
+                    "achieved_formula": ach_f, "frac_formula": (ach_f / F32_PEAK_TFLOPS) if ach_f else None,
                     "flops_executed": flops_exec, "frac_executed": (flops_exec / avg / 1e12 / F32_PEAK_TFLOPS) if n else None,
                     "valu_issue_frac": (e["valu_insts"] / (avg * SIMDS * VALU_ISSUE_PER_S)) if (e and n and e.get("valu_insts")) else None,
                     "hbm_achieved_gbs": alg_bytes / avg / 1e9 if n else None, "hbm_peak_gbs": HBM_PEAK_GBS,
@@ -584,9 +588,10 @@ def main():
         roof["backproject" if dom is e_fwd else "forward"] = other
         roof["note"] = ("The dominant kernel of the step, measured live (HIP events on the engine's stream); the other PSF pass next to it.  "
                         "f32 VALU bound (4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; no MFMA: a scatter/gather stencil with a "
-                        "sequential epsilon-chain per row has no contraction).  `achieved` / `frac` credit the reference's 49-flop per-tap "
-                        "formula on all taps of a pixel against the packed-f32 vector peak; `flops_executed` / `frac_executed` the 38 flops "
-                        "of the canonical sequence on the taps that are evaluated (dead units: one tap per row).  `valu_issue_frac` = "
+                        "sequential epsilon-chain per row has no contraction).  `achieved` / `frac` (= `frac_executed`): the 38 flops of the "
+                        "canonical sequence on the taps that are evaluated (dead units: one tap per row) against the packed-f32 vector peak; "
+                        "`achieved_formula` / `frac_formula` credit the reference's 49-flop per-tap formula on all taps of a pixel (what rounds 1-4 "
+                        "called `frac`).  `valu_issue_frac` = "
                         "SQ_INSTS_VALU per launch / (launch time x 1024 SIMDs x 0.6e9 wave-instructions/s): the share of VALU issue slots "
                         "used, the figure that explains the time.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch time.  "
                         "`traffic`: FETCH_SIZE + WRITE_SIZE per launch; counters from this round's separate rocprofv3 --pmc passes "
@@ -651,19 +656,17 @@ def main():
                 "table_bytes_rank0": tab["bytes"],
                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                              "traffic": table_traffic(prob.name, world),
-                             "bytes_per_launch_upper": tab["bytes"] + b_back,
-                             "achieved_upper": ((tab["bytes"] + b_back) / bp2a / 1e9) if bp2[1] else None,
-                             "frac_upper": ((tab["bytes"] + b_back) / bp2a / 1e9 / HBM_PEAK_GBS) if bp2[1] else None,
                              # what the counters saw of the table scatter (FETCH_SIZE with the guide's x 2 for 16 B / lane streaming reads,
-                             # + WRITE_SIZE) over the same launch time: the fraction to quote; *_upper divides bytes that are not read
+                             # + WRITE_SIZE) over the same launch time.  (Rounds 2-4 also printed *_upper figures: the whole table's bytes over
+                             # the launch time -- bytes that are not all read: dropped.)
                              "frac_counters": (lambda t_: ((t_["scatter"]["fetch_corrected"] + t_["scatter"]["write_counted"]) / bp2a / 1e9 / HBM_PEAK_GBS)
                                                if (t_ and t_.get("scatter") and bp2[1]) else None)(table_traffic(prob.name, world))},
                 "note": "the same K steps with svr_set_option(coeff_table, 1): every live (pixel, plane) unit's 256 taps are "
                         "written once per slice geometry (16 KiB per PSF pixel, outside the timed region like the Gaussian pass "
                         "and the tile lists) and streamed by the scatter and the gather -- CoeffInit's _volcoeffs of the "
                         "reference's CPU path on the GPU path.  Same results (gather bit for bit).  Not the headline: `value` "
-                        "above evaluates every tap in every pass like the reference's GPU kernels.  roofline.*_upper count "
-                        "the whole table per launch; dead units (about a third on P4) are neither stored nor read.",
+                        "above evaluates every tap in every pass like the reference's GPU kernels.  Dead units (about a third on P4) are neither "
+                        "stored nor read.",
             }
         if not args.no_cpu_baseline and world == 1:
             try:
