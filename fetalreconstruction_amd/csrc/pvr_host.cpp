@@ -54,6 +54,60 @@ class irtkPatchBasedReconstruction {
   }
   bool scale_stale = false;            // the other ranks' scales arrive with the next exchange (the E-step's)
 
+  int fail(int rc, const char *what) {
+    err = std::string(what) + ": " + std::to_string(rc) + " " + svr_last_error(e);
+    return rc;
+  }
+#define PENG(call) do { int rc_ = (call); if (rc_) return fail(rc_, #call); } while (0)
+
+  // ---- the patch-level EM on the device (round 5; csrc/svr_em.inc, patch form) -------------------------------------------------
+  // As in csrc/svr_host.cpp: the host half of EStep below -- potentials down, the two-class EM over the patches, patch weights up -- was
+  // the one wait of an SR iteration and, sharded, its one host exchange.  With SVR_DEVICE_SLICE_EM (default on; sharded: when the
+  // launcher supplies allgather_device) every rank's potentials and scales meet on the device and the EM runs there as one workgroup;
+  // `em_on_host` says whose copy of {scale, patch_weight, patch_potential, the eight scalars} is current: pull_state() brings the
+  // device's over in one wait when somebody reads it, push_state() sends the host's when the host changed it.
+  bool dev_patch_em = getenv("SVR_DEVICE_SLICE_EM") ? atoi(getenv("SVR_DEVICE_SLICE_EM")) != 0 : true;
+  bool sem_ready = false, em_on_host = true;
+  bool use_device_patch_em() const { return dev_patch_em && device_em && (!sh.on || sh.coll.allgather_device); }
+  int push_state() {
+    if (!sem_ready) {
+      const int W = sh.on ? sh.coll.world : 1, R = sh.on ? sh.coll.rank : 0;
+      std::vector<double> b((size_t)W + 1, 0.0);                       // every rank's range of this numbering: one small exchange, once
+      b[R] = lo;
+      if (R == W - 1) b[W] = hi;
+      if (sh.on && W > 1) { if (int rc = sh.coll.allreduce_host(sh.coll.user, b.data(), W + 1, 0)) return fail(rc, "allreduce_host (patch ranges)"); }
+      std::vector<int> rlo((size_t)W + 1);
+      for (int r = 0; r <= W; ++r) rlo[r] = (int)b[r];
+      PENG(svr_slice_em_setup(e, n, W, R, rlo.data(), order.empty() ? nullptr : order.data(), (double)m_step));
+      std::vector<int> src(n, -1);                                     // PRS.cu:256-276: no stack offset on the left
+      int ofs = 0;
+      for (int c : counts) {
+        for (int j = 0; j < c; ++j) src[j] = ofs + j;
+        ofs += c;
+      }
+      PENG(svr_slice_em_set_patch_form(e, src.data()));
+      sem_ready = true;
+      em_on_host = true;
+    }
+    if (em_on_host) {
+      const std::vector<unsigned char> excl(n, 0);
+      const double s5[5] = {m_mean_s_gpu, m_mean_s2_gpu, m_sigma_s_gpu, m_sigma_s2_gpu, m_mix_s_gpu};
+      const float em3[3] = {m_sigma_gpu, m_mix_gpu, m_m_gpu};
+      PENG(svr_slice_em_set_state(e, patch_weight.data(), excl.data(), s5, em3));
+    }
+    return 0;
+  }
+  int pull_state() {
+    if (em_on_host) return 0;
+    double s5[5];
+    float em3[3];
+    PENG(svr_slice_em_fetch(e, scale.data(), patch_weight.data(), patch_potential.data(), nullptr, s5, em3));
+    m_mean_s_gpu = (float)s5[0]; m_mean_s2_gpu = (float)s5[1]; m_sigma_s_gpu = (float)s5[2]; m_sigma_s2_gpu = (float)s5[3]; m_mix_s_gpu = (float)s5[4];
+    m_sigma_gpu = em3[0]; m_mix_gpu = em3[1]; m_m_gpu = em3[2];
+    em_on_host = true;
+    return 0;
+  }
+
   irtkPatchBasedReconstruction(svr_ctx *engine, const int *patches_per_stack, int n_stacks, float min_i, float max_i, int lo_ = 0,
                                int hi_ = -1, const svr_collectives *c = nullptr)
       : e(engine), counts(patches_per_stack, patches_per_stack + n_stacks), n(0), m_min_intensity(min_i),
@@ -71,11 +125,6 @@ class irtkPatchBasedReconstruction {
     patch_potential.assign(n, 0.0f);
   }
 
-  int fail(int rc, const char *what) {
-    err = std::string(what) + ": " + std::to_string(rc) + " " + svr_last_error(e);
-    return rc;
-  }
-#define PENG(call) do { int rc_ = (call); if (rc_) return fail(rc_, #call); } while (0)
 
   static float G_(float x, float s) { return 0.00001f * expf(-x * x / (2.0f * s)) / sqrtf(6.28f * s); }   // PRS.cu:97-101
 
@@ -101,6 +150,7 @@ class irtkPatchBasedReconstruction {
   bool scale_pending = false;
   int mstep_pending = 0;
   int settle() {
+    if (int rc = pull_state()) return rc;              // (the device's patch-level state, if it is the current one)
     if (mstep_pending) {
       const int iter = mstep_pending;
       mstep_pending = 0;
@@ -139,6 +189,28 @@ class irtkPatchBasedReconstruction {
   }
 
   int EStep() {                                                              // PRS.cu:224-556
+    if (use_device_patch_em()) {
+      // [M-step] + E-step + the patch-level EM without a wait and without a host exchange (csrc/svr_em.inc; svr_host.cpp EStepGPU)
+      if (int rc = push_state()) return rc;
+      const int iter = mstep_pending;
+      mstep_pending = 0;
+      void *send = nullptr, *recv = nullptr;
+      if (iter > 0 && sh.on) {
+        PENG(svr_mstep_partial(e, sh.coll.world, &send, &recv));
+        if (int rc = sh.before_device_collective()) return fail(rc, "svr_stream_sync");
+        if (int rc = sh.coll.allgather_device(sh.coll.user, send, recv, 16)) return fail(rc, "allgather_device (M-step sums)");
+      }
+      size_t nf = 0;
+      PENG(svr_mstep_estep_device(e, iter, m_step, &send, &recv, &nf));
+      if (sh.on) {
+        if (int rc = sh.before_device_collective()) return fail(rc, "svr_stream_sync");
+        if (int rc = sh.coll.allgather_device(sh.coll.user, send, recv, nf)) return fail(rc, "allgather_device (patch potentials)");
+      }
+      PENG(svr_slice_em_run(e));
+      em_on_host = false;
+      scale_pending = scale_stale = false;               // (the scales travelled with the gather)
+      return 0;
+    }
     std::vector<float> pot(n, 0.0f);
     if (mstep_pending && sh.on) {
       // sharded (round 4; svr_host.cpp EStepGPU): the ranks' M-step sums meet on the device, one wait and one host exchange per SR iteration
@@ -244,6 +316,7 @@ class irtkPatchBasedReconstruction {
   }
   bool device_em = getenv("SVR_DEVICE_EM") ? atoi(getenv("SVR_DEVICE_EM")) != 0 : true;   // sharded: the M-step's sums meet on the device
   int MStepNow(int iter) {
+    if (int rc = pull_state()) return rc;
     double s5[5];
     PENG(svr_mstep_sums_fetch(e, s5, scale_pending ? scale.data() + lo : nullptr, nullptr));
     scale_pending = false;
@@ -308,11 +381,15 @@ class irtkPatchBasedReconstruction {
     int rc;
     {
       if ((rc = Scale())) return rc;
+      // (the patch weights of a device-side EM are already on the device: NULL = keep them; whatever anybody sent the engine in between
+      // is replaced by the EM's, device to device)
+      const float *pw = em_on_host ? patch_weight.data() + lo : nullptr;
+      if (!pw) PENG(svr_slice_em_apply_weights(e));
       if (!sh.on) {
-        PENG(svr_superresolution(e, i + 1, patch_weight.data() + lo, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta,
+        PENG(svr_superresolution(e, i + 1, pw, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta,
                                  m_lambda, 0, 12.0f, 0.01f));
       } else {
-        PENG(sh.superresolution(patch_weight.data() + lo, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta, m_lambda));
+        PENG(sh.superresolution(pw, m_adaptive, m_alpha, m_min_intensity, m_max_intensity, m_delta, m_lambda));
       }
       PENG(svr_simulate_slices(e, nullptr));
       if ((rc = MStep(i + 1))) return rc;
@@ -349,14 +426,16 @@ pvrh_recon *pvrh_create_sharded(svr_ctx *engine, const int *patches_per_stack, i
 int pvrh_set_unit_order(pvrh_recon *r, const int *order_or_null) {
   if (!r) return SVR_E_ARG;
   svr::irtkPatchBasedReconstruction &m = r->impl;
-  if (!order_or_null) { m.order.clear(); return SVR_OK; }
+  if (!order_or_null) { if (int rc = m.settle()) return rc; m.order.clear(); m.sem_ready = false; return SVR_OK; }
   std::vector<char> seen(m.n, 0);
   for (int k = 0; k < m.n; ++k) {
     const int i = order_or_null[k];
     if (i < 0 || i >= m.n || seen[i]) { m.err = "pvrh_set_unit_order: not a permutation of the patches"; return SVR_E_ARG; }
     seen[i] = 1;
   }
+  if (int rc = m.settle()) return rc;
   m.order.assign(order_or_null, order_or_null + m.n);
+  m.sem_ready = false;                                 // the device-side EM learns the new numbering at its next use
   return SVR_OK;
 }
 void pvrh_force_collectives(pvrh_recon *r, int on) { if (r) { (void)r->impl.settle(); r->impl.sh.force(on != 0); } }

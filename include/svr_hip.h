@@ -365,6 +365,7 @@ int svr_counters(svr_ctx *ctx, uint64_t out8[8]);
 /* (pixel, plane) units of the pixels with s != -1 whose footprint reaches the volume: [0] such pixels, [1] live units (every tap
  * evaluated), [2] dead units (every row provably below the epsilon of RC.cu:238: only its first tap is processed) -- what
  * bench.py's `flops_executed` counts */
+int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]);
 /* ---- the slice-level EM of an SR iteration on the device (csrc/svr_em.inc; round 5) -------------------------------------------------
  * The host half of irtkReconstruction::EStepGPU (irtkReconstructionGPU.cc:3282-3420: potentials down, a two-class EM over the slices on the
  * host, slice weights up) as one workgroup behind the E-step's kernels: no wait for the device and no host exchange inside an SR iteration.
@@ -386,7 +387,10 @@ int svr_slice_em_run(svr_ctx *ctx);
 int svr_slice_em_apply_weights(svr_ctx *ctx);   /* the EM's weights of this rank's slices -> the scatter's vector again (device to device) */
 int svr_slice_em_fetch(svr_ctx *ctx, float *scale_global, float *slice_weight_global, float *slice_potential_global,
                        unsigned char *slice_inside_global, double scalars5[5], float em3[3]);
-int svr_unit_counts(svr_ctx *ctx, uint64_t out3[3]);
+/* irtkPatchBasedReconstruction's form of the same EM (patchBasedRobustStatistics_gpu.cu:224-556; csrc/pvr_host.cpp uses it): the Gaussian in
+ * float with the literal 0.00001f (:97-101), and a patch reads the potential of the patch source_ref[t] (both in the reference's numbering;
+ * -1 = none, potential 0; NULL = its own) -- the reference's copy of the stacks' potentials without the stack offset (:256-276).  After setup. */
+int svr_slice_em_set_patch_form(svr_ctx *ctx, const int *source_ref_or_null);
 /* PSF launches since svr_create that were asked for on the cell path (back_mode 5 / fwd_mode 2: no float atomics, the same bits from run
  * to run) and LEFT it because the cell lists cannot hold the geometry (centre coordinates beyond int16, more than 2^18 cells or 1024
  * planes per class, slices of more than 2^20 pixels, more than 2^17 slices, a staging buffer that does not fit): out4 = {scatters that

@@ -24,11 +24,11 @@ import numpy as np
 XGMI_LINK_GBS = 76.8
 XGMI_EFF = 0.5
 HOST_EXCHANGE_MS = 0.08      # one stream synchronisation + one small collective (60-100 us measured at world 1)
-# per SR iteration.  Patch-based host: the E-step's potentials (the M-step's sums meet on the device).  SVR host since round 5: none -- the
-# slice-level EM runs on the device (csrc/svr_em.inc); what it costs instead are two SMALL device collectives on the engine's stream (the
+# per SR iteration.  Both host objects since round 5: none -- the slice- / patch-level EM runs on the device (csrc/svr_em.inc; round 4: one,
+# the E-step's potentials); what it costs instead are two SMALL device collectives on the engine's stream (the
 # M-step's 16 floats per rank, the potentials' 3 x maxn floats per rank), priced at a stated latency each
-HOST_EXCHANGES = {"svr": 0, "pvr": 1}
-SMALL_COLLECTIVES = {"svr": 2, "pvr": 1}
+HOST_EXCHANGES = {"svr": 0, "pvr": 0}      # (both host objects run their slice- / patch-level EM on the device)
+SMALL_COLLECTIVES = {"svr": 2, "pvr": 2}
 SMALL_COLLECTIVE_MS = 0.02   # an assumption (RCCL's small-message latency on one node); stated in the output
 
 
