@@ -137,7 +137,7 @@ def kernel_stats(bench, j4, j8):
     import shutil
     d = os.path.join(OUT, "stats")
     shutil.rmtree(d, ignore_errors=True)
-    p = sh(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline", "--no-s8"],
+    p = sh(["timeout", "420", "rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline", "--no-s8"],   # (timeout: rocprofv3 has been seen to hang at exit after writing its database)
            os.path.join(OUT, "stats.log"))
     jt = last_json(p.stdout)
     lines = ["# round 5: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r05/stats -o bench -- python bench.py --no-cpu-baseline --no-s8",
