@@ -13,7 +13,8 @@ out = {"note": "bench.py --workload W --shard all/8 on ONE MI355X (tools/shard_p
                "rank, sharding.shard_units), the combine reads one item_of word per wavefront, and a repetition's state is restored device to device.",
        "workloads": {}}
 for wl in sys.argv[1:] or ["S8", "P4", "PVR8spx", "PVR4"]:
-    p = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--workload", wl, "--shard", "all/8"], cwd=R, capture_output=True, text=True)
+    p = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--workload", wl, "--shard", "all/8", "--steps", "24"],   # (12 timed repetitions per rank: with 5, one slow repetition moved a rank by 4 %)
+                       cwd=R, capture_output=True, text=True)
     for line in reversed(p.stdout.strip().splitlines()):
         if line.startswith("{"):
             out["workloads"][wl] = json.loads(line)
