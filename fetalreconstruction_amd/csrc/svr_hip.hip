@@ -2323,10 +2323,14 @@ __global__ __launch_bounds__(256) void k_estep(const float *slices, const float 
   block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
 }
 // RC.cu:2903-2910
-__global__ void k_potential_finish(const double *per_slice, int ns, float *potential) {
+// (+ the sum over the slice's chunks, in chunk order like k_reduce_chunks: one launch instead of two -- these kernels last 4 us each and a
+// rank of a sharded run has little else to hide them behind)
+__global__ void k_potential_finish(const double *partial, int ns, int chunks, float *potential) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
-  double a = per_slice[2 * s], b = per_slice[2 * s + 1];
+  const double *p = partial + (size_t)s * chunks * 2;
+  double a = p[0], b = p[1];
+  for (int c = 1; c < chunks; ++c) { a += p[2 * c]; b += p[2 * c + 1]; }
   potential[s] = (b > 0) ? sqrtf((float)a / (float)b) : -1.0f;
 }
 
@@ -2384,11 +2388,20 @@ __global__ __launch_bounds__(256) void k_scale(const float *slices, const float 
   block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
 }
 // RC.cu:3229-3236
-__global__ void k_scale_finish(const double *per_slice, int ns, float *scale_vec) {
+// (+ the two moves of the reference's one-call lag, svr_calculate_scale_vector: the device's scales take the PREVIOUS host copy, the host
+// copy takes the new vector -- two device-to-device copies of ns floats until round 5, 5 us each on a stream that has nothing else to do)
+// (+ the sum over the slice's chunks, in chunk order like k_reduce_chunks)
+__global__ void k_scale_finish(const double *partial, int ns, int chunks, float *scale_vec, float *scales, float *scales_host_copy) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
-  float num = (float)per_slice[2 * s], den = (float)per_slice[2 * s + 1];
-  scale_vec[s] = (den != 0.0f) ? num / den : 1.0f;
+  const double *p = partial + (size_t)s * chunks * 2;
+  double a = p[0], b = p[1];
+  for (int c = 1; c < chunks; ++c) { a += p[2 * c]; b += p[2 * c + 1]; }
+  float num = (float)a, den = (float)b;
+  const float v = (den != 0.0f) ? num / den : 1.0f;
+  scale_vec[s] = v;
+  scales[s] = scales_host_copy[s];
+  scales_host_copy[s] = v;
 }
 
 // transformRS RC.cu:2243-2265
@@ -2814,6 +2827,7 @@ struct svr_ctx {
   unsigned char *d_siminside = nullptr;
   int *d_voxcount = nullptr;
   bool have_slices = false;
+  bool sem_weights_current = false;     // d_slice_weights holds the device-side EM's weights (svr_slice_em_run) and nobody has written it since
   float *d_scales = nullptr, *d_slice_weights = nullptr, *d_scales_host_copy = nullptr,
         *d_tmp_ns = nullptr;
   unsigned char *d_slice_inside = nullptr;
@@ -3545,6 +3559,7 @@ int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
 // stream synchronisation; `mirror` = what the device vector holds, an identical vector is not sent again
 int upload_ns(svr_ctx *ctx, float *dst, const float *src, std::vector<float> &mirror) {
   const size_t n = ctx->ns;
+  if (dst == ctx->d_slice_weights) ctx->sem_weights_current = false;
   if (mirror.size() == n && !memcmp(mirror.data(), src, n * sizeof(float))) return SVR_OK;
   if (!ctx->h_up) {
     HIPCHK(hipHostMalloc((void **)&ctx->h_up, (size_t)svr_ctx::UP_SLOTS * n * sizeof(float), hipHostMallocDefault));
@@ -3995,6 +4010,7 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   HIPCHK(hipMalloc(&ctx->d_tiles_fb2, (size_t)ctx->tiles_x * ctx->tiles_y * ctx->ns * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&ctx->d_scales, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_slice_weights, ctx->ns * sizeof(float)));
+  ctx->sem_weights_current = false;
   HIPCHK(hipMalloc(&ctx->d_scales_host_copy, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_tmp_ns, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_slice_inside, ctx->ns));
@@ -4485,10 +4501,8 @@ int launch_estep(svr_ctx *ctx, float m, float sigma, float mix, const float *em)
                      ctx->d_simweights, ctx->d_scales, ctx->disable_bias ? (const float *)nullptr : ctx->d_bias, m, sigma,
                      mix, (int)(ctx->sx * ctx->sy), ctx->d_weights, ctx->d_partial, ctx->pvr, em);
   KCHK("k_estep");
-  int r = reduce_partials(ctx, 2, 0, 0, false);
-  if (r) return r;
-  hipLaunchKernelGGL(k_potential_finish, dim3(nblk(ctx->ns)), dim3(256), 0, ctx->stream, ctx->d_per_slice,
-                     (int)ctx->ns, ctx->d_tmp_ns);
+  hipLaunchKernelGGL(k_potential_finish, dim3(nblk(ctx->ns, 64)), dim3(64), 0, ctx->stream, ctx->d_partial,
+                     (int)ctx->ns, ctx->chunks, ctx->d_tmp_ns);
   KCHK("k_potential_finish");
   t.stop();
   return SVR_OK;
@@ -4657,10 +4671,9 @@ int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
                      ctx->d_simslices, ctx->d_simweights, ctx->disable_bias ? (const float *)nullptr : ctx->d_bias,
                      (int)(ctx->sx * ctx->sy), ctx->d_partial);
   KCHK("k_scale");
-  int r = reduce_partials(ctx, 2, 0, 0, false);
-  if (r) return r;
-  hipLaunchKernelGGL(k_scale_finish, dim3(nblk(ctx->ns)), dim3(256), 0, ctx->stream, ctx->d_per_slice, (int)ctx->ns,
-                     ctx->d_tmp_ns);
+  int r;
+  hipLaunchKernelGGL(k_scale_finish, dim3(nblk(ctx->ns, 64)), dim3(64), 0, ctx->stream, ctx->d_partial, (int)ctx->ns, ctx->chunks,
+                     ctx->d_tmp_ns, ctx->d_scales, ctx->d_scales_host_copy);
   KCHK("k_scale_finish");
   t.stop();
   // Reference quirk, reproduced: CalculateScaleVectorOnX uploads h_scales -- still the PREVIOUS
@@ -4668,9 +4681,7 @@ int svr_calculate_scale_vector(svr_ctx *ctx, float *scale_vec) {
   // (RC.cu:3195).  The E-step / back-projection kernels therefore see scales that lag one call
   // behind; the M-step reads h_scales (RC.cu:3093) and sees the new ones.  h_scales is d_scales_host_copy here: both
   // moves are device-to-device, and with scale_vec == NULL (svr_get_scale_vector / svr_mstep_estep fetch it later) the
-  // call does not wait for the device.
-  HIPCHK(hipMemcpyAsync(ctx->d_scales, ctx->d_scales_host_copy, ctx->ns * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_scales_host_copy, ctx->d_tmp_ns, ctx->ns * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  // call does not wait for the device.  (Both moves happen in k_scale_finish.)
   ctx->mir_scales = ctx->mir_scales_copy;          // (empty = unknown: the next upload is not skipped)
   ctx->mir_scales_copy.clear();
   if (scale_vec) {

@@ -30,6 +30,10 @@ HOST_EXCHANGE_MS = 0.08      # one stream synchronisation + one small collective
 HOST_EXCHANGES = {"svr": 0, "pvr": 0}      # (both host objects run their slice- / patch-level EM on the device)
 SMALL_COLLECTIVES = {"svr": 2, "pvr": 2}
 SMALL_COLLECTIVE_MS = 0.02   # an assumption (RCCL's small-message latency on one node); stated in the output
+# the device-side slice- / patch-level EM behind the E-step (k_mstep_scalars_dev + k_slice_em_pack + k_slice_em: one workgroup, latency bound;
+# 3.6 + 3.5 + 17 us in the kernel trace of a P4 step, the same at S8's 511 slices): the probe times the E-step's kernels through the host
+# form, so this is added to every rank's step as a constant
+DEVICE_EM_MS = 0.025
 
 
 def build(wl):
@@ -182,12 +186,12 @@ def project_at(res, gbs_per_direction):
     W, nv = res["world"], res["Nv"]
     full, sh = res["full"], res["shards"]
     em = lambda k: k["estep"] + k["mstep"] + k["scale"]
-    one = full["backproject"] + full["regularize"] + full["forward"] + em(full)
+    one = full["backproject"] + full["regularize"] + full["forward"] + em(full) + DEVICE_EM_MS   # (one GPU runs the device EM too)
     psf = max(k["backproject"] + k["forward"] + em(k) for k in sh)
     reg_full = max(k["regularize"] for k in sh)
     ms = lambda nbytes: nbytes * (W - 1) / W / (gbs_per_direction * 1e9) * 1e3 if W > 1 else 0.0
     kind = "pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"
-    small = HOST_EXCHANGES[kind] * HOST_EXCHANGE_MS + SMALL_COLLECTIVES[kind] * SMALL_COLLECTIVE_MS
+    small = HOST_EXCHANGES[kind] * HOST_EXCHANGE_MS + SMALL_COLLECTIVES[kind] * SMALL_COLLECTIVE_MS + DEVICE_EM_MS
     mfrac = res.get("mask_fraction", 1.0)
     rs_ms, ag_ms, ar_ms = ms(2 * nv * 4 * mfrac), ms(nv * 4 * min(1.0, mfrac * 1.15)), 2 * ms(2 * nv * 4)
     slab = psf + rs_ms + reg_full / W + ag_ms + small
@@ -208,14 +212,14 @@ def project(res):
     W, nv = res["world"], res["Nv"]
     full, sh = res["full"], res["shards"]
     em = lambda k: k["estep"] + k["mstep"] + k["scale"]
-    one = full["backproject"] + full["regularize"] + full["forward"] + em(full)
+    one = full["backproject"] + full["regularize"] + full["forward"] + em(full) + DEVICE_EM_MS   # (one GPU runs the device EM too)
     psf = max(k["backproject"] + k["forward"] + em(k) for k in sh)
     reg_full = max(k["regularize"] for k in sh)
     # replicated: all-reduce of addon|cmap (2 Nv floats: reduce-scatter + all-gather of the whole message), whole-volume update
     ar = 2 * collective_ms(2 * nv * 4, W)
     kind = "pvr" if str(res.get("workload", "")).startswith("PVR") else "svr"
     nex = HOST_EXCHANGES[kind]
-    small = nex * HOST_EXCHANGE_MS + SMALL_COLLECTIVES[kind] * SMALL_COLLECTIVE_MS
+    small = nex * HOST_EXCHANGE_MS + SMALL_COLLECTIVES[kind] * SMALL_COLLECTIVE_MS + DEVICE_EM_MS
     replicated = psf + ar + reg_full + small
     # slab: reduce-scatter of addon|cmap over the mask's voxels (+ halo planes), update of the rank's slab, all-gather of the volume
     mfrac = res.get("mask_fraction", 1.0)
@@ -225,7 +229,7 @@ def project(res):
     return dict(label="PROJECTION from one-GPU per-shard kernel times; no collective was run",
                 assumptions=dict(xgmi_link_GBs_per_direction=XGMI_LINK_GBS, links_used=min(W - 1, 7), efficiency=XGMI_EFF,
                                  host_exchange_ms=HOST_EXCHANGE_MS, host_exchanges_per_step=nex, small_device_collectives_per_step=SMALL_COLLECTIVES[kind],
-                                 small_device_collective_ms=SMALL_COLLECTIVE_MS),
+                                 small_device_collective_ms=SMALL_COLLECTIVE_MS, device_em_ms=DEVICE_EM_MS),
                 one_gpu_kernels_ms=one, max_rank_psf_em_ms=psf, sum_rank_psf_ms=sum(k["backproject"] + k["forward"] for k in sh),
                 shard_overhead=sum(k["backproject"] + k["forward"] for k in sh) / (full["backproject"] + full["forward"]),
                 at_link_rates={name: project_at(res, (min(W - 1, 7) * XGMI_LINK_GBS * XGMI_EFF) if name.startswith("7 links") else rate)
