@@ -170,9 +170,11 @@ def test_bench_pvr_workload_through_the_sharded_path():
     assert a["value"] > 0 and a["config"]["comm"] == "rccl" and a["config"]["rccl_world"] == 1 and "patches" in a["config"]["workload"]
     k = a["ranks"]
     assert len(k["Va"]) == 1 and k["Va"][0] == a["config"]["Va_total"] and k["units"][0] == a["config"]["slices"]
-    assert k["backproject_ms"][0] > 0 and k["forward_ms"][0] > 0 and k["exchange_host_ms"][0] > 0
+    assert k["backproject_ms"][0] > 0 and k["forward_ms"][0] > 0
     assert k["reduce_scatter_ms"][0] > 0 and k["allgather_ms"][0] > 0 and k["collective_bytes_sent"][0] > 0       # the slab update's two collectives
-    assert k["exchanges_per_step"][0] == 1.0                 # the E-step's potentials (the scale vector rides along; the M-step's sums meet on the device)
+    # no host exchange inside an SR iteration since the patch-level EM runs on the device too (csrc/svr_em.inc, patch form; until then one:
+    # the E-step's potentials): the M-step's sums and every rank's potentials / scales meet on the device
+    assert k["exchanges_per_step"][0] == 0.0 and k["exchange_host_ms"][0] == 0.0
     assert set(a["config"]["tuned"]) >= {"gather_tile", "scatter_tile", "scatter_box"}
 
 
