@@ -3043,7 +3043,10 @@ constexpr size_t TIMER_BATCH = 256;
 inline hipEvent_t timer_event(svr_ctx *c) {
   if (!c->ev_free.empty()) { hipEvent_t e = c->ev_free.back(); c->ev_free.pop_back(); return e; }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  // timing only: nobody reads device memory on the strength of these events, so they need not write the caches back to system scope when
+  // they are recorded (hipEventDisableSystemFence: "for events that are only being used to measure timing") -- the default's fence is
+  // what made every recorded event a 5.8 us hole in the stream (profiles/r05_step_timeline_p4.txt)
+  if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { e = nullptr; (void)hipEventCreate(&e); }
   return e;
 }
 // the recorded pairs -> t_ms / t_n (waits for the last one)
