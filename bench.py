@@ -32,6 +32,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this host driver needs dmabuf IPC (RCCL's peer buffers: hipIpcGetMemHandle fails otherwise); the GPU box exports
+# it already -- kept here for a launch from a bare environment; must be set before the HIP runtime comes up (before torch is imported)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F32_PEAK_TFLOPS = 157.3      # f32 vector peak with packed FMA on gfx950 (= the f32 MFMA dense peak, same guide)
@@ -342,8 +345,21 @@ def main():
                 else:
                     box = [uid if rank == 0 else None]
                     dist.broadcast_object_list(box, src=0)
-                    comm = RcclComm(rec, rank, world, box[0])
-                    rccl_world = comm.rccl_world()
+                    try:
+                        comm, why = RcclComm(rec, rank, world, box[0]), None
+                    except Exception as ex:               # noqa: BLE001 -- ncclCommInitRank refused (every rank then falls back together)
+                        comm, why = None, repr(ex)
+                    oks = [None] * world
+                    dist.all_gather_object(oks, why)
+                    if any(w is not None for w in oks):
+                        if rank == 0:
+                            print(f"note: the RCCL communicator could not be created ({[w for w in oks if w][0]}); exchanging through gloo", file=sys.stderr)
+                        if comm is not None:
+                            comm.close()
+                        args.comm = "gloo-fallback"
+                        comm = TorchComm(device=None)
+                    else:
+                        rccl_world = comm.rccl_world()
             else:
                 comm = TorchComm(device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
         if multi:
