@@ -78,7 +78,7 @@ def test_random_geometry_against_the_oracle(seed, pvr, oracle_mod):
     rec.close()
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SVR_FUZZ_HOST_SEEDS", "4"))))                 # SVR_FUZZ_HOST_SEEDS=40: a longer hunt
 def test_cpp_host_on_random_geometry_matches_the_python_driver(seed):
     """svr::irtkReconstruction (one wait per SR iteration: deferred vectors, M-step + E-step fused) against the Python mirror
     of the operator surface (one wait per method) on a second engine: an outer iteration of three SR iterations."""
@@ -102,3 +102,41 @@ def test_cpp_host_on_random_geometry_matches_the_python_driver(seed):
     va, vb = ra.syncCPU(), rb.syncCPU()
     assert np.array_equal(np.isnan(va), np.isnan(vb)) and rel_err(np.nan_to_num(va), np.nan_to_num(vb)) < 2e-5
     ra.close(); rb.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SVR_FUZZ_PVR_SEEDS", "3"))))                  # SVR_FUZZ_PVR_SEEDS=20: a longer hunt
+def test_cpp_pvr_host_on_random_stacks_matches_the_python_loop(seed):
+    """svr::irtkPatchBasedReconstruction (csrc/pvr_host.cpp: the patch-level EM on the device, csrc/svr_em.inc patch form -- float Gaussian,
+    the potentials through the reference's offset-less copy) against the Python mirror of the loop (tests/twins/pvr.py: the EM on the host,
+    numpy float32) on random stacks cut into patches: two to three stacks of different sizes and orientations, so the stacks hold different
+    numbers of patches and most patches read another patch's potential; an outer iteration of three SR iterations."""
+    from fetalreconstruction_amd import engine as E, host
+    from tests.twins import pvr
+    rng = np.random.default_rng(7000 + seed)
+    n_stacks = int(rng.integers(2, 4))
+    orient = tuple(rng.choice(["ax", "cor", "sag"], n_stacks, replace=True))
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(n_stacks, (int(rng.integers(20, 30)), int(rng.integers(20, 30)), int(rng.integers(3, 6))),
+                                                            float(rng.uniform(0.9, 1.3)), float(rng.uniform(1.8, 2.6)), None, 1.0,
+                                                            float(rng.uniform(10.0, 12.0)), seed=100 + seed, orientations=orient)
+    P = pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (16, 16), (8, 8))
+    out = []
+    for make in (lambda r: pvr.irtkPatchBasedReconstruction(r, P.patches_per_stack, P.min_intensity, P.max_intensity),
+                 lambda r: host.irtkPatchBasedReconstruction(r, P.patches_per_stack, P.min_intensity, P.max_intensity)):
+        rec = E.Reconstruction(0)
+        rec.set_option("pvr", 1)
+        E.sync_gpu(rec, P, quality_factor=1.0)
+        d = make(rec)
+        d.reconstruct_iteration(3)
+        st = d.state() if hasattr(d, "state") else dict(scale=d.scale, patch_weight=d.patch_weight, patch_potential=d.patch_potential,
+                                                        **{k: float(getattr(d, k)) for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu",
+                                                                                            "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu", "m_mix_s_gpu")})
+        out.append((st, rec.syncCPU().copy()))
+        rec.close()
+    (a, va), (b, vb) = out
+    for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu", "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu", "m_mix_s_gpu"):
+        assert a[k] == pytest.approx(b[k], rel=2e-4, nan_ok=True), k
+    assert np.allclose(a["scale"], b["scale"], rtol=2e-5, equal_nan=True)
+    assert np.array_equal(np.asarray(a["patch_potential"]) == -1, np.asarray(b["patch_potential"]) == -1)
+    assert np.allclose(a["patch_weight"], b["patch_weight"], atol=2e-4, equal_nan=True)      # expf of the device vs numpy's float32 exp
+    assert np.allclose(a["patch_potential"], b["patch_potential"], rtol=1e-5, atol=1e-6, equal_nan=True)
+    assert np.array_equal(np.isnan(va), np.isnan(vb)) and rel_err(np.nan_to_num(vb), np.nan_to_num(va)) < 1e-4
