@@ -22,12 +22,23 @@ def _free_port():
     return p
 
 
-def _problem():
+# the default suite: two processes on the fixed problem, three on a random one; a longer hunt: SVR_TWO_RANK_WORLD=8 SVR_TWO_RANK_SEED=5
+# (recorded in round 5: worlds 2, 3, 4, 5 x seeds 1-6 and world 8 x seeds 1-3, all three forms of the update: profiles/r05_multi_process_hunt.txt)
+CASES = [(int(os.environ["SVR_TWO_RANK_WORLD"]), os.environ.get("SVR_TWO_RANK_SEED"))] if "SVR_TWO_RANK_WORLD" in os.environ else [(2, None), (3, "1")]
+
+
+def _problem(seed=None):
     from fetalreconstruction_amd import phantom
-    return phantom.make_problem(3, (40, 36, 10), 1.1, 2.2, None, 1.0, 15.0, seed=11, orientations=("ax", "cor", "sag"), name="two-rank")
+    if seed is None:
+        return phantom.make_problem(3, (40, 36, 10), 1.1, 2.2, None, 1.0, 15.0, seed=11, orientations=("ax", "cor", "sag"), name="two-rank")
+    rng = np.random.default_rng(int(seed))
+    n = int(rng.integers(2, 5))
+    return phantom.make_problem(n, (int(rng.integers(28, 44)), int(rng.integers(28, 44)), int(rng.integers(6, 12))), float(rng.uniform(0.9, 1.3)),
+                                float(rng.uniform(1.8, 2.6)), None, float(rng.uniform(0.8, 1.2)), float(rng.uniform(12.0, 16.0)), seed=int(seed),
+                                orientations=tuple(rng.choice(["ax", "cor", "sag"], n, replace=True)), name="two-rank-fuzz")
 
 
-def _worker(rank, world, port, outdir, slabs, slab_update=True):
+def _worker(rank, world, port, outdir, slabs, slab_update=True, seed=None):
     import torch                                       # before the engine's library: torch carries its own copy of the HIP runtime
     import torch.distributed as dist
     from fetalreconstruction_amd import engine as E, host, phantom
@@ -36,7 +47,7 @@ def _worker(rank, world, port, outdir, slabs, slab_update=True):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        P = _problem()
+        P = _problem(seed)
         act = (P.slices != -1).reshape(P.ns, -1).sum(1)
         work = slice_cost_weights(act, P.slice_i2w, P.slice_t, P.recon_w2i, P.slice_dim, P.vdim[0])
         order, ranges = shard_units(work, P.stack_index, world, "spatial")
@@ -61,14 +72,14 @@ def _worker(rank, world, port, outdir, slabs, slab_update=True):
 
 
 
-def _spawn(world, slabs, slab_update, outdir):
+def _spawn(world, slabs, slab_update, outdir, seed=None):
     """two worker PROCESSES of this file (not torch.multiprocessing: importing torch into the pytest process next to the engine's library
     puts two HIP runtimes into one process, which corrupts the heap at exit)"""
     import subprocess
     import sys
     port = _free_port()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), str(world), str(port), outdir, str(int(slabs)), str(int(slab_update))],
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), str(world), str(port), outdir, str(int(slabs)), str(int(slab_update)), str(seed)],
                               cwd=root, env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
@@ -76,9 +87,10 @@ def _spawn(world, slabs, slab_update, outdir):
 
 
 @pytest.mark.timeout(900)
-def test_two_processes_on_one_gpu_through_the_cpp_sharded_host():
+@pytest.mark.parametrize("WORLD,seed", CASES)
+def test_two_processes_on_one_gpu_through_the_cpp_sharded_host(WORLD, seed):
     from fetalreconstruction_amd import engine as E, host
-    P = _problem()
+    P = _problem(seed)
     rec = E.Reconstruction(0)
     E.sync_gpu(rec, P)
     ref = host.irtkReconstruction(rec, P.ns, max_intensity=P.max_intensity, min_intensity=P.min_intensity)
@@ -89,14 +101,16 @@ def test_two_processes_on_one_gpu_through_the_cpp_sharded_host():
     runs = {}
     for key, slabs, slab_update in (("slab", True, True), ("replicated", True, False), ("no device collectives", False, True)):
         with tempfile.TemporaryDirectory() as d:
-            _spawn(2, slabs, slab_update, d)
-            runs[key] = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(2)]
-    for key, (r0, r1) in runs.items():
+            _spawn(WORLD, slabs, slab_update, d, seed)
+            runs[key] = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(WORLD)]
+    for key, rr in runs.items():
+        r0 = rr[0]
         slabs = key != "no device collectives"
-        # both ranks end with the same volume and the same host state
-        for k in ("recon", "scale", "sw", "pot", "em"):
-            assert np.array_equal(r0[k], r1[k]), (slabs, k)
-        assert r0["lohi"][0] == 0 and r0["lohi"][1] == r1["lohi"][0] and r1["lohi"][1] == P.ns
+        # all ranks end with the same volume and the same host state
+        for r1 in rr[1:]:
+            for k in ("recon", "scale", "sw", "pot", "em"):
+                assert np.array_equal(r0[k], r1[k], equal_nan=True), (slabs, k)
+        assert r0["lohi"][0] == 0 and all(rr[i]["lohi"][1] == rr[i + 1]["lohi"][0] for i in range(WORLD - 1)) and rr[-1]["lohi"][1] == P.ns
         # Gaussian pass: one all-reduce; per SR iteration: reduce-scatter + all-gather (slab) or one all-reduce (replicated), ONE host exchange
         rs, ag, ar, ex = (int(v) for v in r0["counts"])
         assert (rs, ag, ar) == ((3, 3, 1) if key == "slab" else (0, 0, 4)), (key, rs, ag, ar)
@@ -109,11 +123,18 @@ def test_two_processes_on_one_gpu_through_the_cpp_sharded_host():
         assert np.array_equal(r0["recon"] == -1, v_ref == -1)
         assert np.allclose(r0["scale"], s_ref["scale"][order], rtol=1e-5) and np.allclose(r0["sw"], s_ref["slice_weight"][order], atol=1e-4)
         assert np.allclose(r0["em"], [s_ref[k] for k in ("sigma", "mix", "m", "mean_s", "mean_s2", "sigma_s", "sigma_s2", "mix_s")], rtol=1e-4)
-    # the slab update against the replicated one: rank-ordered sums either way -> the same bits
+    # the slab update against the replicated one: at world 2 a sum of two terms has one order, so the two forms give the same bits whatever the
+    # collectives do inside; beyond that the replicated form's all-reduce (gloo's here, RCCL's in the product) adds in an order of its own and the
+    # two agree to the float-sum tolerance (the rank-ordered in-process group of `-d 0 0 0` and the numpy collectives of the CPU tests keep the
+    # bits at world 3: tests/test_distributed_cpu.py)
     a, b = runs["slab"][0], runs["replicated"][0]
-    assert np.array_equal(a["recon"], b["recon"]) and np.array_equal(a["scale"], b["scale"]) and np.array_equal(a["sw"], b["sw"]) and np.array_equal(a["em"], b["em"])
+    if WORLD == 2:
+        assert np.array_equal(a["recon"], b["recon"]) and np.array_equal(a["scale"], b["scale"]) and np.array_equal(a["sw"], b["sw"]) and np.array_equal(a["em"], b["em"])
+    else:
+        assert np.abs(a["recon"] - b["recon"]).max() <= 2e-5 * np.abs(v_ref).max() and np.allclose(a["sw"], b["sw"], atol=1e-4)
 
 
 if __name__ == "__main__":
     import sys
-    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], bool(int(sys.argv[5])), bool(int(sys.argv[6])))
+    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], bool(int(sys.argv[5])), bool(int(sys.argv[6])),
+            None if sys.argv[7] == "None" else sys.argv[7])
