@@ -122,6 +122,83 @@ class RcclComm:
             pass
 
 
+def _torch_collectives(comm, n_local):
+    """svr_collectives out of a sharding.TorchComm (torch.distributed callbacks; gloo in the tests): -> (the struct, the thunks to keep alive).
+    Shared by the two host objects."""
+    views = {}
+    counts = [int(round(x)) for x in comm.allreduce_sum(np.eye(comm.world)[comm.rank] * n_local)]
+
+    def ar_pair(user, ptr, n):
+        try:
+            from .sharding import _device_view
+            if (ptr, n) not in views:
+                views[(ptr, n)] = _device_view(comm.torch, ptr, n, comm.device)
+            comm.dist.all_reduce(views[(ptr, n)], op=comm.dist.ReduceOp.SUM)
+            comm.torch.cuda.synchronize()
+            return 0
+        except Exception as ex:      # never let an exception cross the C boundary
+            print("allreduce_volume_pair failed:", ex)
+            return 1
+
+    def ar_host(user, data, n, op):
+        try:
+            a = np.ctypeslib.as_array(data, shape=(n,))
+            r = (comm.allreduce_sum, comm.allreduce_min, comm.allreduce_max)[op](a.copy())
+            a[:] = r
+            return 0
+        except Exception as ex:
+            print("allreduce_host failed:", ex)
+            return 1
+
+    def ag(user, local, n_local, out, n_global):
+        try:
+            loc = np.ctypeslib.as_array(local, shape=(n_local,)).copy() if n_local else np.zeros(0, np.float32)
+            g = comm.allgather_slices(loc, counts)
+            np.ctypeslib.as_array(out, shape=(n_global,))[:] = g
+            return 0
+        except Exception as ex:
+            print("allgather_slices failed:", ex)
+            return 1
+
+    # the two device-buffer collectives of the slab update (csrc/svr_slab.inc), staged through the host and added IN RANK ORDER
+    # (TorchComm(slabs=True): what two ranks that share one GPU can run -- RCCL refuses them -- and, like the in-process group of
+    # the command lines, bit for bit the replicated update).  on_engine_stream 0: the C++ host synchronises the engine's stream first.
+    def rs_dev(user, send, recv, n):
+        try:
+            from .sharding import _device_view
+            W = comm.world
+            mine = _device_view(comm.torch, send, W * n, comm.device or "cuda").cpu()
+            outs = [comm.torch.zeros_like(mine) for _ in range(W)]
+            comm.dist.all_gather(outs, mine)
+            acc = outs[0][comm.rank * n:(comm.rank + 1) * n].clone()
+            for r in range(1, W):
+                acc += outs[r][comm.rank * n:(comm.rank + 1) * n]
+            _device_view(comm.torch, recv, n, comm.device or "cuda").copy_(acc)
+            comm.torch.cuda.synchronize()
+            return 0
+        except Exception as ex:
+            print("reduce_scatter_device failed:", ex)
+            return 1
+
+    def ag_dev(user, send, recv, n):
+        try:
+            from .sharding import _device_view
+            W = comm.world
+            mine = _device_view(comm.torch, send, n, comm.device or "cuda").cpu()
+            outs = [comm.torch.zeros_like(mine) for _ in range(W)]
+            comm.dist.all_gather(outs, mine)
+            _device_view(comm.torch, recv, W * n, comm.device or "cuda").copy_(comm.torch.cat(outs))
+            comm.torch.cuda.synchronize()
+            return 0
+        except Exception as ex:
+            print("allgather_device failed:", ex)
+            return 1
+
+    slab_cbs = (_DEV2(rs_dev), _DEV2(ag_dev)) if getattr(comm, "slabs", False) else (_DEV2(0), _DEV2(0))
+    cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag)) + slab_cbs
+    return _Coll(C.sizeof(_Coll), None, comm.rank, comm.world, *cbs, 0), cbs
+
+
 class irtkReconstruction:
     """C++ host object over one engine; `comm` is an RcclComm (the C library's RCCL collectives), a reconstruction.TorchComm
     (torch.distributed callbacks: gloo in the CPU tests) or None."""
@@ -147,78 +224,7 @@ class irtkReconstruction:
                 coll_ptr = comm.collectives
         elif comm is not None and comm.world > 1:
             self._comm = comm
-            self._views = {}
-            counts = [int(round(x)) for x in comm.allreduce_sum(np.eye(comm.world)[comm.rank] * (self.hi - self.lo))]
-
-            def ar_pair(user, ptr, n):
-                try:
-                    from .sharding import _device_view
-                    if (ptr, n) not in self._views:
-                        self._views[(ptr, n)] = _device_view(comm.torch, ptr, n, comm.device)
-                    comm.dist.all_reduce(self._views[(ptr, n)], op=comm.dist.ReduceOp.SUM)
-                    comm.torch.cuda.synchronize()
-                    return 0
-                except Exception as ex:      # never let an exception cross the C boundary
-                    print("allreduce_volume_pair failed:", ex)
-                    return 1
-
-            def ar_host(user, data, n, op):
-                try:
-                    a = np.ctypeslib.as_array(data, shape=(n,))
-                    r = (comm.allreduce_sum, comm.allreduce_min, comm.allreduce_max)[op](a.copy())
-                    a[:] = r
-                    return 0
-                except Exception as ex:
-                    print("allreduce_host failed:", ex)
-                    return 1
-
-            def ag(user, local, n_local, out, n_global):
-                try:
-                    loc = np.ctypeslib.as_array(local, shape=(n_local,)).copy() if n_local else np.zeros(0, np.float32)
-                    g = comm.allgather_slices(loc, counts)
-                    np.ctypeslib.as_array(out, shape=(n_global,))[:] = g
-                    return 0
-                except Exception as ex:
-                    print("allgather_slices failed:", ex)
-                    return 1
-
-            # the two device-buffer collectives of the slab update (csrc/svr_slab.inc), staged through the host and added IN RANK ORDER
-            # (TorchComm(slabs=True): what two ranks that share one GPU can run -- RCCL refuses them -- and, like the in-process group of
-            # the command lines, bit for bit the replicated update).  on_engine_stream 0: the C++ host synchronises the engine's stream first.
-            def rs_dev(user, send, recv, n):
-                try:
-                    from .sharding import _device_view
-                    W = comm.world
-                    mine = _device_view(comm.torch, send, W * n, comm.device or "cuda").cpu()
-                    outs = [comm.torch.zeros_like(mine) for _ in range(W)]
-                    comm.dist.all_gather(outs, mine)
-                    acc = outs[0][comm.rank * n:(comm.rank + 1) * n].clone()
-                    for r in range(1, W):
-                        acc += outs[r][comm.rank * n:(comm.rank + 1) * n]
-                    _device_view(comm.torch, recv, n, comm.device or "cuda").copy_(acc)
-                    comm.torch.cuda.synchronize()
-                    return 0
-                except Exception as ex:
-                    print("reduce_scatter_device failed:", ex)
-                    return 1
-
-            def ag_dev(user, send, recv, n):
-                try:
-                    from .sharding import _device_view
-                    W = comm.world
-                    mine = _device_view(comm.torch, send, n, comm.device or "cuda").cpu()
-                    outs = [comm.torch.zeros_like(mine) for _ in range(W)]
-                    comm.dist.all_gather(outs, mine)
-                    _device_view(comm.torch, recv, W * n, comm.device or "cuda").copy_(comm.torch.cat(outs))
-                    comm.torch.cuda.synchronize()
-                    return 0
-                except Exception as ex:
-                    print("allgather_device failed:", ex)
-                    return 1
-
-            slab_cbs = (_DEV2(rs_dev), _DEV2(ag_dev)) if getattr(comm, "slabs", False) else (_DEV2(0), _DEV2(0))
-            self._cbs = (_AR_PAIR(ar_pair), _AR_HOST(ar_host), _AG(ag)) + slab_cbs     # keep the thunks alive
-            self._coll = _Coll(C.sizeof(_Coll), None, comm.rank, comm.world, *self._cbs, 0)
+            self._coll, self._cbs = _torch_collectives(comm, self.hi - self.lo)     # (keep the thunks alive)
         if self._coll is not None:
             coll_ptr = C.byref(self._coll)
         h = self._lib.svrh_create(rec._h, self.ns, int(self.lo), int(self.hi), coll_ptr)
@@ -358,7 +364,7 @@ class irtkPatchBasedReconstruction:
 
     def __init__(self, rec: "_engine.Reconstruction", patches_per_stack, min_intensity, max_intensity, patch_range=None, comm=None,
                  force_collectives=False):
-        """patch_range = (lo, hi) + comm (an RcclComm): the engine holds the patches [lo, hi) of the global numbering
+        """patch_range = (lo, hi) + comm (an RcclComm, or a sharding.TorchComm at world > 1): the engine holds the patches [lo, hi) of the global numbering
         (pvrh_create_sharded); patches_per_stack stays the global count per stack."""
         self._lib = _engine.load_library()
         self._lib.pvrh_create.restype = C.c_void_p
@@ -369,12 +375,18 @@ class irtkPatchBasedReconstruction:
         c = np.ascontiguousarray(patches_per_stack, np.int32)
         self.n = int(c.sum())
         self.lo, self.hi = patch_range if patch_range is not None else (0, self.n)
-        if comm is not None and not isinstance(comm, RcclComm):
-            raise TypeError("the C++ patch-based host takes the C library's communicator (host.RcclComm)")
         self._comm = comm
-        use = comm is not None and (comm.world > 1 or force_collectives)
+        self._coll = None
+        if comm is None or isinstance(comm, RcclComm):
+            use = comm is not None and (comm.world > 1 or force_collectives)
+            coll_ptr = comm.collectives if use else None
+        else:                                            # a sharding.TorchComm: torch.distributed callbacks (gloo between processes in the tests)
+            use = comm.world > 1
+            if use:
+                self._coll, self._cbs = _torch_collectives(comm, self.hi - self.lo)     # (keep the thunks alive)
+            coll_ptr = C.byref(self._coll) if use else None
         h = self._lib.pvrh_create_sharded(rec._h, c.ctypes.data_as(C.c_void_p), len(c), C.c_float(min_intensity), C.c_float(max_intensity),
-                                          int(self.lo), int(self.hi), comm.collectives if use else None)
+                                          int(self.lo), int(self.hi), coll_ptr)
         if not h:
             raise _engine.SvrError("pvrh_create_sharded failed")
         self._h = C.c_void_p(h)
@@ -393,6 +405,11 @@ class irtkPatchBasedReconstruction:
     def _ck(self, rc):
         if rc != 0:
             raise _engine.SvrError(f"host status {rc}: {self._lib.pvrh_last_error(self._h).decode()}")
+
+    def set_slab_update(self, on):
+        """sharded runs: the volume update by z-slabs (default) or all-reduce + the update replicated on every rank"""
+        self._lib.pvrh_set_slab_update.restype = None
+        self._lib.pvrh_set_slab_update(self._h, int(bool(on)))
 
     def set_unit_order(self, order):
         """order[k] = the global (stack after stack) index of patch k of this object's numbering; None = the same numbering"""

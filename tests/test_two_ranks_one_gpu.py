@@ -72,14 +72,14 @@ def _worker(rank, world, port, outdir, slabs, slab_update=True, seed=None):
 
 
 
-def _spawn(world, slabs, slab_update, outdir, seed=None):
+def _spawn(world, slabs, slab_update, outdir, seed=None, kind="svr"):
     """two worker PROCESSES of this file (not torch.multiprocessing: importing torch into the pytest process next to the engine's library
     puts two HIP runtimes into one process, which corrupts the heap at exit)"""
     import subprocess
     import sys
     port = _free_port()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), str(world), str(port), outdir, str(int(slabs)), str(int(slab_update)), str(seed)],
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), str(world), str(port), outdir, str(int(slabs)), str(int(slab_update)), str(seed), kind],
                               cwd=root, env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
@@ -134,7 +134,89 @@ def test_two_processes_on_one_gpu_through_the_cpp_sharded_host(WORLD, seed):
         assert np.abs(a["recon"] - b["recon"]).max() <= 2e-5 * np.abs(v_ref).max() and np.allclose(a["sw"], b["sw"], atol=1e-4)
 
 
+def _pvr_problem(seed):
+    from fetalreconstruction_amd import phantom
+    from tests.twins import pvr
+    rng = np.random.default_rng(500 + int(seed))
+    n = int(rng.integers(2, 4))
+    stacks, mask, mattr, rattr, rmask = phantom.make_stacks(n, (int(rng.integers(24, 34)), int(rng.integers(24, 34)), int(rng.integers(4, 7))),
+                                                            float(rng.uniform(0.9, 1.3)), float(rng.uniform(1.8, 2.6)), None, 1.0, float(rng.uniform(10.0, 13.0)),
+                                                            seed=int(seed), orientations=tuple(rng.choice(["ax", "cor", "sag"], n, replace=True)))
+    return pvr.make_pvr_problem(stacks, mask, mattr, rattr, rmask, (16, 16), (8, 8))
+
+
+def _pvr_worker(rank, world, port, outdir, slabs, slab_update, seed):
+    import torch
+    import torch.distributed as dist
+    from fetalreconstruction_amd import engine as E, host, phantom
+    from fetalreconstruction_amd.sharding import TorchComm, patch_cost_weights, shard_units
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        P = _pvr_problem(seed)
+        work = patch_cost_weights((P.slices > 0).reshape(P.ns, -1).sum(1), P.slice_i2w, P.slice_t, P.recon_w2i)
+        order, ranges = shard_units(work, P.stack_index, world, "spatial")
+        lo, hi = ranges[rank]
+        rec = E.Reconstruction(0)
+        rec.set_option("pvr", 1)
+        E.sync_gpu(rec, phantom.sub_problem(P, 0, 0, select=order[lo:hi]), quality_factor=1.0)
+        d = host.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity, (lo, hi), TorchComm(device=None, slabs=slabs))
+        d.set_unit_order(order)
+        if not slab_update:
+            d.set_slab_update(False)
+        rec.timer_enable(True)
+        d.reconstruct_iteration(3)
+        st = d.state()
+        tm = rec.timers()
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), recon=rec.syncCPU(), scale=st["scale"], sw=st["patch_weight"], pot=st["patch_potential"],
+                 em=np.array([st[k] for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu", "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu", "m_mix_s_gpu")]),
+                 order=order, lohi=np.array([lo, hi]),
+                 counts=np.array([tm["reduce_scatter"][1], tm["allgather"][1], tm["allreduce"][1], tm["exchange_host"][1]]))
+        rec.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("WORLD,seed", [(int(os.environ["SVR_TWO_RANK_WORLD"]), os.environ.get("SVR_TWO_RANK_SEED", "1"))] if "SVR_TWO_RANK_WORLD" in os.environ
+                         else [(2, "1"), (3, "2")])
+def test_processes_on_one_gpu_through_the_cpp_sharded_patch_based_host(WORLD, seed):
+    """The same for csrc/pvr_host.cpp: patches dealt spatially, the unit-order layer around the reference's within-stack indexing of the
+    potentials, the slab update and the patch-level EM on the device (csrc/svr_em.inc, patch form), between PROCESSES; against the one-rank
+    object: the volume to 1e-4 (float sums regrouped by rank and through the patch-level EM's weights), the same excluded patches, per-patch
+    vectors that are the one-rank run's in the sharded numbering, one host exchange in the whole outer iteration."""
+    from fetalreconstruction_amd import engine as E, host
+    P = _pvr_problem(seed)
+    rec = E.Reconstruction(0)
+    rec.set_option("pvr", 1)
+    E.sync_gpu(rec, P, quality_factor=1.0)
+    ref = host.irtkPatchBasedReconstruction(rec, P.patches_per_stack, P.min_intensity, P.max_intensity)
+    ref.reconstruct_iteration(3)
+    v_ref, s_ref = rec.syncCPU().copy(), ref.state()
+    rec.close()
+    for key, slabs, slab_update in (("slab", True, True), ("replicated", True, False), ("no device collectives", False, True)):
+        with tempfile.TemporaryDirectory() as d:
+            _spawn(WORLD, slabs, slab_update, d, seed, kind="pvr")
+            rr = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(WORLD)]
+        r0 = rr[0]
+        for r1 in rr[1:]:
+            for k in ("recon", "scale", "sw", "pot", "em"):
+                assert np.array_equal(r0[k], r1[k], equal_nan=True), (key, k)
+        assert r0["lohi"][0] == 0 and all(rr[i]["lohi"][1] == rr[i + 1]["lohi"][0] for i in range(WORLD - 1)) and rr[-1]["lohi"][1] == P.ns
+        rs, ag, ar, ex = (int(v) for v in r0["counts"])
+        assert (rs, ag, ar) == ((3, 3, 1) if key == "slab" else (0, 0, 4)), (key, rs, ag, ar)
+        assert ex == (1 if slabs else 2 + 2 * 3), (key, ex)            # with device collectives: the robust statistics' sums only
+        order = r0["order"]
+        assert np.abs(r0["recon"] - v_ref).max() <= 1e-4 * np.abs(v_ref).max() and np.array_equal(r0["recon"] > 0, v_ref > 0)
+        assert np.array_equal(r0["pot"] == -1, s_ref["patch_potential"][order] == -1)
+        assert np.allclose(r0["scale"], s_ref["scale"][order], rtol=2e-5) and np.allclose(r0["sw"], s_ref["patch_weight"][order], atol=2e-4)
+        assert np.allclose(r0["em"], [s_ref[k] for k in ("m_sigma_gpu", "m_mix_gpu", "m_m_gpu", "m_mean_s_gpu", "m_mean_s2_gpu", "m_sigma_s_gpu", "m_sigma_s2_gpu",
+                                                           "m_mix_s_gpu")], rtol=2e-4)
+
+
 if __name__ == "__main__":
     import sys
-    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], bool(int(sys.argv[5])), bool(int(sys.argv[6])),
-            None if sys.argv[7] == "None" else sys.argv[7])
+    seed_ = None if sys.argv[7] == "None" else sys.argv[7]
+    (_pvr_worker if len(sys.argv) > 8 and sys.argv[8] == "pvr" else _worker)(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], bool(int(sys.argv[5])),
+                                                                              bool(int(sys.argv[6])), seed_)
