@@ -300,8 +300,6 @@ def main():
         prob = workloads.get(workload) if workload != "tiny" else phantom.problem_tiny()
         pvr = workload.startswith("PVR")
         if pvr:
-            if args.comm == "torch":
-                raise SystemExit("bench.py: the patch-based host (csrc/pvr_host.cpp) takes the C library's RCCL communicator; --comm torch is SVR only")
             # work of a patch: the pixels that carry data, weighted by orientation (patches of one stack share their geometry)
             work = patch_cost_weights((prob.slices > 0).reshape(prob.ns, -1).sum(1), prob.slice_i2w, prob.slice_t, prob.recon_w2i)
         else:
