@@ -31,7 +31,7 @@ HOST_EXCHANGES = {"svr": 0, "pvr": 0}      # (both host objects run their slice-
 SMALL_COLLECTIVES = {"svr": 2, "pvr": 2}
 SMALL_COLLECTIVE_MS = 0.02   # an assumption (RCCL's small-message latency on one node); stated in the output
 # the device-side slice- / patch-level EM behind the E-step (k_mstep_scalars_dev + k_slice_em_pack + k_slice_em: one workgroup, latency bound;
-# 3.6 + 3.5 + 17 us in the kernel trace of a P4 step, the same at S8's 511 slices): the probe times the E-step's kernels through the host
+# 3.6 + 3.5 + 13-17 us in the kernel traces of a P4 step, the same at S8's 511 slices): the probe times the E-step's kernels through the host
 # form, so this is added to every rank's step as a constant
 DEVICE_EM_MS = 0.025
 
