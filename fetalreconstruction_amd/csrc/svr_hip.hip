@@ -2220,30 +2220,34 @@ __global__ void k_reduce_chunks(const double *partial, int ns, int chunks, int K
   }
   per_slice[i] = x;
 }
-// reduces per_slice[sl*K + k] over slices -> out[k]   (single block, 256 threads)
+// reduces per_slice[sl*K + k] over slices -> out[k]   (single block, 256 threads; K <= 8).  The K quantities go through the tree side by side --
+// per quantity the order of one block reduction after the other (the same bits), one set of barriers for all: the kernel is nothing but latency
 __global__ void k_reduce_slices(const double *per_slice, int ns, int K, int opmask_min,
                                 int opmask_max, double *out) {
-  __shared__ double sm[256];
+  __shared__ double sm[8][256];
+  const int t = threadIdx.x;
   for (int k = 0; k < K; ++k) {
     bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
     double x = mn ? INFINITY : (mx ? -INFINITY : 0.0);
-    for (int s = threadIdx.x; s < ns; s += 256) {
+    for (int s = t; s < ns; s += 256) {
       double y = per_slice[(size_t)s * K + k];
       x = mn ? fmin(x, y) : (mx ? fmax(x, y) : x + y);
     }
-    sm[threadIdx.x] = x;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) {
-        double y = sm[threadIdx.x + o];
-        double z = sm[threadIdx.x];
-        sm[threadIdx.x] = mn ? fmin(z, y) : (mx ? fmax(z, y) : z + y);
+    sm[k][t] = x;
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      for (int k = 0; k < K; ++k) {
+        bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
+        double y = sm[k][t + o];
+        double z = sm[k][t];
+        sm[k][t] = mn ? fmin(z, y) : (mx ? fmax(z, y) : z + y);
       }
-      __syncthreads();
     }
-    if (threadIdx.x == 0) out[k] = sm[0];
     __syncthreads();
   }
+  if (t < K) out[t] = sm[t][0];
 }
 
 // ------------------------------------------------------------------------------------------
