@@ -49,6 +49,7 @@ TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_traffic.json")     # written 
                                                                       # per pass: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
 VALU_ISSUE_PER_S = 0.6e9     # wave-instructions a SIMD issues per second: 2.4 GHz / 4 cycles per 64-lane instruction
+CLOCK_PROBE_REF_MS = 8.50    # svr_clock_probe(2^20) on the boxes of the pool that read 188-189 MVoxels/s on P4 (round 5)
 SR_PER_OUTER = 4             # rec_iterations_first (reconstruction.cc:115,187): SR iterations per outer iteration
 METRIC = "MVoxels/s per SR iteration (PSF fwd+back), 4-stack 1.0mm SVR, 1/2/4/8 GPU"
 
@@ -514,15 +515,26 @@ def main():
         # launches that left the cell path (svr_fallbacks): a non-zero entry on a benchmarked workload means float atomics (a scatter) or
         # the slower tile kernels took over without the line's kernel names saying so -- summed over the ranks
         fb = rec.fallbacks()
+        # what this box's shader clock does under a full vector load, right after the timed steps (svr_clock_probe): the pool's boxes differ by
+        # up to 16 % with one binary, and the line should say which kind of box it was measured on
+        try:
+            pms, _ = rec.clock_probe()
+            probe = {"name": torch.cuda.get_device_name(local_rank), "clock_probe_ms": pms, "clock_probe_reference_ms": CLOCK_PROBE_REF_MS,
+                     "relative_clock": CLOCK_PROBE_REF_MS / pms,
+                     "note": "2^20 packed f32 fmas per lane (eight independent chains: the vector pipe at its full issue rate) on 4 wavefronts per SIMD of the whole chip, shortest of three "
+                             "launches right after the timed steps (rank 0's device): a fixed number of shader cycles, so its time is the inverse of the clock the box sustains under a full vector load.  reference = the "
+                             "boxes that read 188-189 MVoxels/s on P4 in round 5; relative_clock well below 1 = a slow box of the pool (DESIGN 7), not a slower binary"}
+        except Exception as ex:                                   # noqa: BLE001 -- an aid, never a reason to lose the line
+            probe = {"error": repr(ex)}
         if multi:
             fbv = comm.allreduce_sum(np.array([float(fb[k]) for k in sorted(fb)]))
             fb = {k: int(round(x)) for k, x in zip(sorted(fb), fbv)}
         return dict(prob=prob, pvr=pvr, rec=rec, drv=drv, local=local, lo=lo, hi=hi, dt=dt, timers=timers, cnt=cnt, ranks=ranks, va=va, tuned=tuned,
-                    tab=tab, order=order, unit_counts=uc, cell_order=rec.get_option("cell_order"), fallbacks=fb)
+                    tab=tab, order=order, unit_counts=uc, cell_order=rec.get_option("cell_order"), fallbacks=fb, device=probe)
 
     m = measure(args.workload, not args.no_coeff_table)
     prob, pvr, rec, dt, timers, cnt, ranks, va, tuned, tab = (m[k] for k in ("prob", "pvr", "rec", "dt", "timers", "cnt", "ranks", "va", "tuned", "tab"))
-    unit_counts, cell_order, fallbacks = m["unit_counts"], m["cell_order"], m["fallbacks"]
+    unit_counts, cell_order, fallbacks, device = m["unit_counts"], m["cell_order"], m["fallbacks"], m["device"]
     comm, rccl_world = state["comm"], state["rccl_world"]
     # ---- BASELINE's multi-GPU target is quoted on S8 (configs[3]: 8 stacks of 64 x 256^2, 0.75 mm), the metric on P4: every line also
     # carries an "s8" record measured in the SAME launch after the headline -- same ranks, same communicator (svr_comm_rebind), same
@@ -628,7 +640,7 @@ def main():
                                        f"updates its own planes -> all-gather of the new volume (csrc/svr_slab.inc)" if timers["reduce_scatter"][1] else
                                        f"{'patch' if pvr else 'slice'}-sharded x{world}, 1 in-place all-reduce of addon|cmap (float[2 Nv]) per scatter pass, update replicated")
                                       if world > 1 else "1 GPU",
-                       "comm": (args.comm if multi else None), "rccl_world": rccl_world,
+                       "comm": (args.comm if multi else None), "rccl_world": rccl_world, "device": device,
                        "tuned": {"gather_tile": f"{tuned['fwd_tile_w']}x{tuned['fwd_tile_h']}", "scatter_tile": f"{tuned['tile_w']}x{tuned['tile_h']}",
                                  "scatter_box": tuned["wave_cap"], "back_mode": tuned["back_mode"], "fwd_mode": tuned["fwd_mode"],
                                  "cell": f"{tuned['cell_w']}x{tuned['cell_h']}", "gather_cell": f"{tuned['cell_gw']}x{tuned['cell_gh']}", "pin": os.environ.get("SVR_TILE_PIN"),

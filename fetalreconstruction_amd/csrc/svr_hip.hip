@@ -5472,6 +5472,50 @@ int svr_timer_add(svr_ctx *ctx, int which, double ms) {
   if (ctx->timers) { ctx->t_ms[which] += ms; ctx->t_n[which] += 1; }
   return SVR_OK;
 }
+// A fixed amount of dependent f32 work on every SIMD of the chip (4 wavefronts per SIMD, each a chain of `n` fmas): its time is a fixed number of
+// cycles over the shader clock the device sustains under a full vector load -- what differs between the boxes of a pool (power caps, temperature)
+// when the same binary reads 158 on one and 189 MVoxels/s on another.  bench.py reports it next to the headline.
+__global__ __launch_bounds__(256) void k_clock_probe(float *out, int n) {
+  // eight independent chains of packed fmas per lane: the vector pipe at its full issue rate, i.e. the power draw of the PSF kernels -- a box
+  // that holds its clock on a light load and drops it on this one is what the probe is there to show
+  f2 x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = (f2){1.0f + 1.0e-7f * (float)(threadIdx.x + k), 1.0f - 1.0e-7f * (float)(threadIdx.x + k)};
+  const f2 a = (f2){0.99999994f, 1.00000012f}, b = (f2){1.0e-9f, -1.0e-9f};
+  for (int i = 0; i < n; i += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = fma2(x[k], a, b);
+  }
+  f2 t = x[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) t = t + x[k];
+  if (t.x == 12345.678f && t.y == 1.0f) out[blockIdx.x] = t.x;   // (never: keeps the chains)
+}
+int svr_clock_probe(svr_ctx *ctx, int chain, double *ms) {
+  SVR_ENTER(ctx);
+  if (!ctx || !ms || chain <= 0) return SVR_E_ARG;
+  float *d = nullptr;
+  HIPCHK(hipMalloc(&d, 4096 * sizeof(float)));
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t e = hipEventCreate(&a);
+  if (e == hipSuccess) e = hipEventCreate(&b);
+  float best = 3.0e38f;
+  for (int rep = 0; rep < 4 && e == hipSuccess; ++rep) {   // the first launch warms the clocks up; the shortest of the rest
+    e = hipEventRecord(a, ctx->stream);
+    hipLaunchKernelGGL(k_clock_probe, dim3(1024), dim3(256), 0, ctx->stream, d, chain);   // 256 CUs x 4 workgroups of 4 wavefronts: 4 per SIMD
+    if (e == hipSuccess) e = hipEventRecord(b, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    float t = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, a, b);
+    if (rep > 0 && t < best) best = t;
+  }
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(ctx, (int)e, std::string("svr_clock_probe: ") + hipGetErrorString(e));
+  *ms = best;
+  return SVR_OK;
+}
 int svr_fallbacks(svr_ctx *ctx, uint64_t out4[4]) {
   SVR_ENTER(ctx);
   if (!ctx || !out4) return SVR_E_ARG;

@@ -38,7 +38,7 @@ EXPORTS = [
     "svr_gaussian_reconstruction_local", "svr_gaussian_reconstruction_finish",
     "svr_superresolution_backproject", "svr_superresolution_update", "svr_robust_statistics_sums",
     "svr_mstep_sums", "svr_scale_volume_sums", "svr_scale_volume_apply", "svr_timer_get",
-    "svr_unit_counts", "svr_fallbacks", "svr_slice_em_setup", "svr_slice_em_set_state", "svr_mstep_estep_device", "svr_slice_em_run", "svr_slice_em_apply_weights", "svr_slice_em_fetch", "svr_slice_em_set_patch_form", "svr_cell_stats", "svr_pair_pack", "svr_pair_unpack", "svr_timer_reset", "svr_timer_enable", "svr_timer_begin", "svr_timer_end", "svr_timer_add", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
+    "svr_unit_counts", "svr_fallbacks", "svr_clock_probe", "svr_slice_em_setup", "svr_slice_em_set_state", "svr_mstep_estep_device", "svr_slice_em_run", "svr_slice_em_apply_weights", "svr_slice_em_fetch", "svr_slice_em_set_patch_form", "svr_cell_stats", "svr_pair_pack", "svr_pair_unpack", "svr_timer_reset", "svr_timer_enable", "svr_timer_begin", "svr_timer_end", "svr_timer_add", "svr_counters", "svr_get_stream", "svr_device", "svr_device_count", "svr_combine_weights", "svr_update_stack_sizes", "svr_ncc_set_targets", "svr_ncc_set_source",
     "svr_ncc_evaluate", "svr_ncc_alloc_targets", "svr_pyr_upload", "svr_pyr_level", "svr_correct_bias", "svr_normalise_bias", "svr_normalise_bias_local",
     "svr_normalise_bias_finish", "svr_init_reg_storage_volumes", "svr_fill_reg_slices",
     "svr_update_resampled_slices_i2w", "svr_prepare_slice_to_volume_reg", "svr_register_slices_to_volume",
@@ -494,6 +494,13 @@ class Reconstruction:
         o = (C.c_uint64 * 4)()
         self._ck(self._lib.svr_fallbacks(self._h, o))
         return dict(scatter_to_atomics=int(o[0]), gather_to_tiles=int(o[1]), gauss1_to_tiles=int(o[2]), tiles_rerun=int(o[3]))
+
+    def clock_probe(self, chain=1 << 20):
+        """(ms, chain): the time of `chain` packed f32 fmas per lane (eight independent chains) on 4 wavefronts per SIMD of the whole chip
+        (svr_clock_probe) -- a fixed number of shader cycles at the vector pipe's full issue rate: boxes compare by it"""
+        ms = C.c_double()
+        self._ck(self._lib.svr_clock_probe(self._h, int(chain), C.byref(ms)))
+        return ms.value, int(chain)
 
     def counters(self):
         o = (C.c_uint64 * 8)()

@@ -398,6 +398,10 @@ int svr_slice_em_set_patch_form(svr_ctx *ctx, const int *source_ref_or_null);
  * (same bits, slower), tiles of tiled scatters re-run by a workgroup kernel}.  The first of each kind is also reported on stderr;
  * bench.py puts the four numbers into config.tuned.fallbacks and the tests of the bench workloads require zeros. */
 int svr_fallbacks(svr_ctx *ctx, uint64_t out4[4]);
+/* a measurement aid, not part of the reconstruction: the time (ms, shortest of three) of `chain` packed f32 fmas per lane (eight independent chains: the full issue rate) on four wavefronts per SIMD
+ * of the whole chip: a fixed number of shader cycles, so the time is the inverse of the clock the device sustains under a full vector load.  bench.py prints it (config.device)
+ * so that two lines from two boxes of a pool can be told apart from two lines of two binaries. */
+int svr_clock_probe(svr_ctx *ctx, int chain, double *ms);
 /* the cell lists of the current slice geometry (csrc/svr_cell.inc): out8 = {scatter items, runs, sorted pixels, staging bytes per
  * launch, gather items, gather runs, gather partial-sum bytes per launch, scatter cell size w << 32 | h} */
 int svr_cell_stats(svr_ctx *ctx, uint64_t out8[8]);
