@@ -3551,6 +3551,7 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
 
 // reduce partial[ns*chunks][K] -> per_slice[ns][K] (+ optionally -> d_out[K])
 int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
+  if (K < 1 || K > 8) return fail(ctx, SVR_E_ARG, "reduce_partials: 1..8 quantities (k_reduce_slices holds them side by side)");
   hipLaunchKernelGGL(k_reduce_chunks, dim3(nblk((size_t)ctx->ns * K)), dim3(256), 0, ctx->stream,
                      ctx->d_partial, (int)ctx->ns, ctx->chunks, K, mn, mx, ctx->d_per_slice);
   KCHK("k_reduce_chunks");
