@@ -2220,11 +2220,12 @@ __global__ void k_reduce_chunks(const double *partial, int ns, int chunks, int K
   }
   per_slice[i] = x;
 }
+constexpr int REDUCE_MAXK = 8;   // quantities reduce_partials takes side by side: k_reduce_slices' LDS rows, and what d_partial / d_per_slice are allocated for
 // reduces per_slice[sl*K + k] over slices -> out[k]   (single block, 256 threads; K <= 8).  The K quantities go through the tree side by side --
 // per quantity the order of one block reduction after the other (the same bits), one set of barriers for all: the kernel is nothing but latency
 __global__ void k_reduce_slices(const double *per_slice, int ns, int K, int opmask_min,
                                 int opmask_max, double *out) {
-  __shared__ double sm[8][256];
+  __shared__ double sm[REDUCE_MAXK][256];
   const int t = threadIdx.x;
   for (int k = 0; k < K; ++k) {
     bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
@@ -2793,7 +2794,7 @@ __global__ __launch_bounds__(256) void k_ncc(const short *targets, int tx, int t
 // context
 // ==========================================================================================
 struct RegState;   // GPU slice-to-volume registration state (svr_reg.inc)
-namespace { struct CellState; struct SlabPlan; struct SliceEm; void slice_em_free(SliceEm *); }  // sorted pixels, runs, items and staging of the scatter without atomics (svr_cell.inc)
+namespace { struct CellState; struct SlabPlan; struct SliceEm; void slice_em_free(SliceEm *); void slice_em_invalidate(SliceEm *); }  // sorted pixels, runs, items and staging of the scatter without atomics (svr_cell.inc)
 
 struct svr_ctx {
   int device = 0;
@@ -3551,7 +3552,7 @@ int launch_scatter(svr_ctx *ctx, int level, const PsfArgs &a_, TileArgs ta, cons
 
 // reduce partial[ns*chunks][K] -> per_slice[ns][K] (+ optionally -> d_out[K])
 int reduce_partials(svr_ctx *ctx, int K, int mn, int mx, bool global) {
-  if (K < 1 || K > 8) return fail(ctx, SVR_E_ARG, "reduce_partials: 1..8 quantities (k_reduce_slices holds them side by side)");
+  if (K < 1 || K > REDUCE_MAXK) return fail(ctx, SVR_E_ARG, "reduce_partials: 1..8 quantities (k_reduce_slices holds them side by side; d_partial / d_per_slice are sized for them)");
   hipLaunchKernelGGL(k_reduce_chunks, dim3(nblk((size_t)ctx->ns * K)), dim3(256), 0, ctx->stream,
                      ctx->d_partial, (int)ctx->ns, ctx->chunks, K, mn, mx, ctx->d_per_slice);
   KCHK("k_reduce_chunks");
@@ -3587,22 +3588,35 @@ int upload_ns(svr_ctx *ctx, float *dst, const float *src, std::vector<float> &mi
 
 // queue a small device -> host copy; nothing is in `dst` before down_flush.  A call that fails drops everything queued so far
 // (the destinations are the caller's memory: a later, unrelated down_flush must not write to them)
+// make room for `total` more bytes of queued copies.  With copies already in flight into the arena the stream is waited for and what
+// has arrived moves into the larger arena (round 5 refused here: a batch whose LATER items were larger than its first -- the
+// slice-level EM's vectors of the GLOBAL slice count on a rank that holds a fraction of the slices -- failed with SVR_E_STATE)
+int down_reserve(svr_ctx *ctx, size_t total) {
+  auto drop = [&](int code, const std::string &msg) { ctx->down_items.clear(); ctx->down_used = 0; return fail(ctx, code, msg); };
+  const size_t need = ctx->down_used + total;
+  if (need <= ctx->down_cap) return SVR_OK;
+  const size_t cap = std::max<size_t>(need + need / 2, (size_t)ctx->ns * 12 + 4096);
+  unsigned char *fresh = nullptr;
+  hipError_t e = hipHostMalloc((void **)&fresh, cap, hipHostMallocDefault);
+  if (e != hipSuccess) return drop((int)e, std::string("down_queue: hipHostMalloc: ") + hipGetErrorString(e));
+  if (!ctx->down_items.empty()) {
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipHostFree(fresh); return drop((int)e, std::string("down_queue: hipStreamSynchronize: ") + hipGetErrorString(e)); }
+    memcpy(fresh, ctx->h_down, ctx->down_used);
+  }
+  if (ctx->h_down) (void)hipHostFree(ctx->h_down);
+  ctx->h_down = fresh;
+  ctx->down_cap = cap;
+  return SVR_OK;
+}
 int down_queue(svr_ctx *ctx, void *dst, const void *src, size_t bytes) {
   auto drop = [&](int code, const std::string &msg) { ctx->down_items.clear(); ctx->down_used = 0; return fail(ctx, code, msg); };
-  const size_t need = ctx->down_used + ((bytes + 63) & ~(size_t)63);
-  if (need > ctx->down_cap) {
-    if (!ctx->down_items.empty()) return drop(SVR_E_STATE, "down_queue: arena too small for the queued copies");
-    const size_t cap = std::max<size_t>(need, (size_t)ctx->ns * 12 + 4096);
-    if (ctx->h_down) (void)hipHostFree(ctx->h_down);
-    ctx->h_down = nullptr; ctx->down_cap = 0;
-    const hipError_t e = hipHostMalloc((void **)&ctx->h_down, cap, hipHostMallocDefault);
-    if (e != hipSuccess) { ctx->h_down = nullptr; return drop((int)e, std::string("down_queue: hipHostMalloc: ") + hipGetErrorString(e)); }
-    ctx->down_cap = cap;
-  }
+  const size_t padded = (bytes + 63) & ~(size_t)63;
+  { const int r = down_reserve(ctx, padded); if (r) return r; }
   const hipError_t e = hipMemcpyAsync(ctx->h_down + ctx->down_used, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e != hipSuccess) return drop((int)e, std::string("down_queue: hipMemcpyAsync: ") + hipGetErrorString(e));
   ctx->down_items.push_back({dst, ctx->down_used, bytes});
-  ctx->down_used = need;
+  ctx->down_used += padded;
   return SVR_OK;
 }
 int down_flush(svr_ctx *ctx) {
@@ -4019,13 +4033,14 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   HIPCHK(hipMalloc(&ctx->d_scales, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_slice_weights, ctx->ns * sizeof(float)));
   ctx->sem_weights_current = false;
+  slice_em_invalidate(ctx->sem);                          // the slice-level EM's arrays and rank ranges were set up for the old slice count
   HIPCHK(hipMalloc(&ctx->d_scales_host_copy, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_tmp_ns, ctx->ns * sizeof(float)));
   HIPCHK(hipMalloc(&ctx->d_slice_inside, ctx->ns));
   HIPCHK(hipMalloc(&ctx->d_sc, ctx->ns * sizeof(SliceConst)));
   ctx->chunks = (int)(((size_t)ctx->sx * ctx->sy + CHUNK_PIX - 1) / CHUNK_PIX);
-  HIPCHK(hipMalloc(&ctx->d_partial, (size_t)ctx->ns * ctx->chunks * 5 * sizeof(double)));
-  HIPCHK(hipMalloc(&ctx->d_per_slice, (size_t)ctx->ns * 5 * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_partial, (size_t)ctx->ns * ctx->chunks * REDUCE_MAXK * sizeof(double)));    // (reduce_partials' guard is the same constant)
+  HIPCHK(hipMalloc(&ctx->d_per_slice, (size_t)ctx->ns * REDUCE_MAXK * sizeof(double)));
   // RC.cu:1555-1568: everything cleared once at allocation (v_PSF_sums is never cleared again)
   HIPCHK(hipMemsetAsync(ctx->d_slices, 0, fb, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_weights, 0, fb, ctx->stream));

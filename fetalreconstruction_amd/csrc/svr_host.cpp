@@ -437,6 +437,7 @@ class irtkReconstruction {
         _mstep_pending = iter;                         // runs with the E-step that follows (reconstruction.cc:1093-1108), or in settle
         return 0;
       }
+      if (int rc = settle()) return rc;                // iter == 0: the host's sigma / mix are the M-step's inputs -- what the device holds comes down first
       ENG(svr_mstep(reconstructionGPU, iter, (float)_step, &_sigma_gpu, &_mix_gpu, &_m_gpu));
       return 0;
     }

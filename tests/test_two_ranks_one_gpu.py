@@ -29,6 +29,8 @@ CASES = [(int(os.environ["SVR_TWO_RANK_WORLD"]), os.environ.get("SVR_TWO_RANK_SE
 
 def _problem(seed=None):
     from fetalreconstruction_amd import phantom
+    if seed == "many":                                    # 1120 slices of 12 x 12 pixels (tests/test_round6_gpu.py: the arena of the small results)
+        return phantom.make_problem(4, (12, 12, 280), 1.2, 0.25, 2.5, 1.0, 9.0, seed=5, orientations=("ax", "cor", "sag", "ax"), name="many-slices")
     if seed is None:
         return phantom.make_problem(3, (40, 36, 10), 1.1, 2.2, None, 1.0, 15.0, seed=11, orientations=("ax", "cor", "sag"), name="two-rank")
     rng = np.random.default_rng(int(seed))
