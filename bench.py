@@ -45,7 +45,7 @@ F32_PEAK_TFLOPS = 157.3      # f32 vector peak with packed FMA on gfx950 (= the 
 FLOPS_PER_TAP_FORMULA = 49
 FLOPS_PER_TAP_EXECUTED = 38
 TAPS = 4096
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_traffic.json")     # written by tools/prof_final.py in the same round: per workload,
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06_traffic.json")     # written by tools/prof_final.py in the same round: per workload,
                                                                       # per pass: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
 VALU_ISSUE_PER_S = 0.6e9     # wave-instructions a SIMD issues per second: 2.4 GHz / 4 cycles per 64-lane instruction
@@ -121,7 +121,10 @@ def cpu_baseline(prob):
            "coefficients": tw.coefficients, "active_pixels": va,
            "sample": (f"the whole workload ({sub.ns} slices, {va} active pixels)" if step == 1 else
                       f"every {step}th slice of the workload ({sub.ns} slices, {va} active pixels: the coefficient lists of all {ns} would need ~{act * per_px * 8 / 1e9:.0f} GB)")
-                     + f": CoeffInit once ({tw.times['CoeffInit'][0]:.2f} s, not in `value`), then the median of {n_it} SR iterations ({med:.3f} s) on {cores} threads",
+                     + f": CoeffInit once ({tw.times['CoeffInit'][0]:.2f} s, not in `value`), then the median of {n_it} SR iterations ({med:.3f} s) on {cores} threads"
+                     + f" = {va / med / 1e6 / cores:.2f} MVoxels/s per thread (BASELINE.md 2: the reference's own CPU twin, compiled against stand-in headers for the survey only, "
+                       "read 0.24 MVoxel/s on one thread of the survey's container: the same order -- the port's plausibility check, not a measurement of this box)",
+           "per_thread": va / med / 1e6 / cores, "survey_probe_per_thread": 0.24,
            "per_function_s": {k: float(np.mean(v)) for k, v in tw.times.items()},
            "port_of_gpu_kernels": port}
     tw.close()
@@ -403,26 +406,61 @@ def main():
                 drv.InitializeEMValuesGPU(); drv.InitializeRobustStatisticsGPU(); drv.EStepGPU()
 
         done = [0]
+        mode_state = {"table": False}
 
         def step():
             k = done[0] % SR_PER_OUTER
             if done[0] and k == 0:
                 em_reinit()
+                # an outer iteration brings new slice transformations, and with them new taps: the coefficient table (the default of a
+                # slice-to-volume run since round 6) is thrown away HERE, inside the timed region -- the next scatter evaluates, the next
+                # gather evaluates and writes the table (coeff_lazy), the other passes of the outer iteration stream it
+                if mode_state["table"]:
+                    rec.set_option("coeff_invalidate", 1)
             drv.sr_iteration(k)
             done[0] += 1
 
-        for i in range(args.warmup):
-            step()
+        def timed(label_steps):
+            """K steps between two barriers -> seconds"""
+            barrier()
+            t_ = time.perf_counter()
+            for i in range(label_steps):
+                step()
+            barrier()
+            return time.perf_counter() - t_
 
-        rec.timer_enable(True)       # HIP events on the engine's own stream around each hot kernel (svr_timer_*)
-        rec.timer_reset()
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        timers = rec.timers()
+        def run_mode(table_on):
+            """W untimed steps, then K timed ones with the kernel timers OFF (the figure the line reports), then the same K steps once more
+            with HIP events around each hot kernel for `kernel_ms` (the events cost 4-8 us of stream time apiece, a dozen per SR iteration:
+            ~1 % of a P4 step on one GPU, several per cent of a rank's share of it) -- the schedule restarted from the same position"""
+            if not pvr:
+                rec.set_option("coeff_table", 1 if table_on else 0)
+            mode_state["table"] = bool(table_on) and not pvr and rec.get_option("coeff_table") == 1
+            done[0] = 0
+            em_reinit()
+            if mode_state["table"]:
+                rec.set_option("coeff_invalidate", 1)
+            rec.timer_enable(False)
+            for i in range(args.warmup):
+                step()
+            d_ = timed(args.steps)
+            fits = pvr or (not table_on) or rec.get_option("coeff_table") == 1     # the table switches itself off when it does not fit the free memory
+            rec.timer_enable(True)       # HIP events on the engine's own stream around each hot kernel (svr_timer_*)
+            done[0] = 0
+            em_reinit()
+            if mode_state["table"]:
+                rec.set_option("coeff_invalidate", 1)
+            for i in range(min(args.warmup, SR_PER_OUTER)):
+                step()
+            rec.timer_reset()
+            d_t = timed(args.steps)
+            tm_ = rec.timers()
+            rec.timer_enable(False)
+            return d_, d_t, tm_, fits
+
+        table_default = (not pvr) and rec.get_option("coeff_table") == 1
+        dt, dt_timers, timers, table_fits = run_mode(table_default)
+        table_used = table_default and table_fits and rec.get_option("coeff_table") == 1
         cnt = rec.counters()
 
         def per_rank(tm):
@@ -466,46 +504,46 @@ def main():
             va = cnt["Va"]
         tuned = {k: rec.get_option(k) for k in ("fwd_tile_w", "fwd_tile_h", "tile_w", "tile_h", "wave_cap", "back_mode", "fwd_mode", "cell_w", "cell_h", "cell_gw", "cell_gh")}
 
-        # ---- the same K steps once more with the coefficient table (reported next to the headline, not as it) ------------
-        # `value` above is the reference GPU path's way: every tap evaluated in every pass.  With option coeff_table the taps of
-        # every live unit are written once per slice geometry -- what irtkReconstruction::CoeffInit keeps as _volcoeffs on the
-        # reference's CPU path (irtkReconstructionGPU.cc:2305-2673) -- and the scatter and the gather stream them from HBM.
+        # ---- the same K steps in the OTHER mode, reported next to the headline ------------------------------------------------------
+        # slice-to-volume: every tap evaluated in every pass (the reference GPU kernels' way, the headline until round 5); patch-based: the
+        # coefficient table (not its default: no gain there), written by k_coeff_build outside the timed region as in rounds 2-5
         tab = None
+        alt = None
         if with_table:
             try:
-                rec.set_option("coeff_table", 1)
-                rec.timer_reset()
-                rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
-                build_ms = rec.timers()["coeff_build"][0]
-                rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
-                done[0] = 0                                           # the same schedule from the same EM state as above
-                em_reinit()
-                for i in range(args.warmup):
-                    step()
-                on = rec.get_option("coeff_table") == 1               # it switches itself off when it does not fit the free memory
-                rec.timer_reset()
-                barrier()
-                t1 = time.perf_counter()
-                for i in range(args.steps):
-                    step()
-                barrier()
-                dt2 = time.perf_counter() - t1
-                tm2 = rec.timers()
-                if multi:
-                    dt2 = float(comm.allreduce_max(np.array([dt2]))[0])
-                    on = bool(comm.allreduce_min(np.array([1.0 if on else 0.0]))[0] > 0.5)
-                tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 16 * 1024.0, "build_ms": build_ms}
-                rec.set_option("coeff_table", 0)
+                if not pvr:
+                    d2, d2t, tm2, _ = run_mode(not table_default)
+                    if multi:
+                        d2 = float(comm.allreduce_max(np.array([d2]))[0])
+                    alt = {"table": not table_default, "dt": d2, "dt_timers": d2t, "timers": tm2}
+                    rec.set_option("coeff_table", 1 if table_default else 0)
+                else:
+                    rec.set_option("coeff_table", 1)
+                    rec.timer_enable(True)
+                    rec.timer_reset()
+                    rec.SimulateSlices()                                  # untimed: builds the table, times the shapes again
+                    build_ms = rec.timers()["coeff_build"][0]
+                    rec.SuperresolutionBackproject(np.ones(local.ns, np.float32))
+                    done[0] = 0                                           # the same schedule from the same EM state as above
+                    em_reinit()
+                    for i in range(args.warmup):
+                        step()
+                    on = rec.get_option("coeff_table") == 1               # it switches itself off when it does not fit the free memory
+                    rec.timer_reset()
+                    dt2 = timed(args.steps)
+                    tm2 = rec.timers()
+                    rec.timer_enable(False)
+                    if multi:
+                        dt2 = float(comm.allreduce_max(np.array([dt2]))[0])
+                        on = bool(comm.allreduce_min(np.array([1.0 if on else 0.0]))[0] > 0.5)
+                    tab = {"on": on, "dt": dt2, "timers": tm2, "bytes": float(cnt["Va"]) * 9 * 1024.0, "build_ms": build_ms}
+                    rec.set_option("coeff_table", 0)
             except Exception as ex:                              # the headline line must still be printed
                 if multi:
                     raise                                         # (a rank that carried on alone would leave the others in a barrier)
-                tab = None
+                tab = alt = None
                 if rank == 0:
-                    print(f"note: the coefficient-table measurement failed: {ex!r}", file=sys.stderr)
-                try:
-                    rec.set_option("coeff_table", 0)
-                except Exception:
-                    pass
+                    print(f"note: the measurement of the other mode failed: {ex!r}", file=sys.stderr)
 
         state["comm"], state["rccl_world"] = comm, rccl_world
         try:
@@ -529,11 +567,12 @@ def main():
         if multi:
             fbv = comm.allreduce_sum(np.array([float(fb[k]) for k in sorted(fb)]))
             fb = {k: int(round(x)) for k, x in zip(sorted(fb), fbv)}
-        return dict(prob=prob, pvr=pvr, rec=rec, drv=drv, local=local, lo=lo, hi=hi, dt=dt, timers=timers, cnt=cnt, ranks=ranks, va=va, tuned=tuned,
-                    tab=tab, order=order, unit_counts=uc, cell_order=rec.get_option("cell_order"), fallbacks=fb, device=probe)
+        return dict(prob=prob, pvr=pvr, rec=rec, drv=drv, local=local, lo=lo, hi=hi, dt=dt, dt_timers=dt_timers, timers=timers, cnt=cnt, ranks=ranks, va=va, tuned=tuned,
+                    tab=tab, alt=alt, table_used=table_used, order=order, unit_counts=uc, cell_order=rec.get_option("cell_order"), fallbacks=fb, device=probe)
 
     m = measure(args.workload, not args.no_coeff_table)
     prob, pvr, rec, dt, timers, cnt, ranks, va, tuned, tab = (m[k] for k in ("prob", "pvr", "rec", "dt", "timers", "cnt", "ranks", "va", "tuned", "tab"))
+    alt, table_used, dt_timers = m["alt"], m["table_used"], m["dt_timers"]
     unit_counts, cell_order, fallbacks, device = m["unit_counts"], m["cell_order"], m["fallbacks"], m["device"]
     comm, rccl_world = state["comm"], state["rccl_world"]
     # ---- BASELINE's multi-GPU target is quoted on S8 (configs[3]: 8 stacks of 64 x 256^2, 0.75 mm), the metric on P4: every line also
@@ -544,7 +583,7 @@ def main():
         del m
         rec.close()
         try:
-            m8 = measure("S8", False)
+            m8 = measure("S8", not args.no_coeff_table)
             s8 = {"workload": f"S8: {int(m8['prob'].stack_index.max()) + 1} synthetic stacks, volume {tuple(m8['prob'].vsize)}, {m8['prob'].ns} slices of "
                               f"{m8['prob'].slices.shape[2]}x{m8['prob'].slices.shape[1]}, recon {m8['prob'].vdim[0]:.3g} mm (BASELINE configs[3])",
                   "value": m8["va"] / (m8["dt"] / max(args.steps, 1)) / 1e6, "unit": "MVoxels/s", "ms_per_step": m8["dt"] / max(args.steps, 1) * 1e3,
@@ -552,7 +591,11 @@ def main():
                   "ranks": m8["ranks"], "collective_bytes_sent": m8["ranks"]["collective_bytes_sent"],
                   "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in m8["timers"].items()},
                   "fallbacks": m8["fallbacks"],
-                  "note": "measured in the same launch after the headline workload, on the same ranks and the same communicator; on the fly (no coefficient table)"}
+                  "mode": "coefficient table, rewritten every 4 steps inside the timed region" if m8["table_used"] else "every tap evaluated in every pass",
+                  "on_the_fly": ({"value": m8["va"] / (m8["alt"]["dt"] / max(args.steps, 1)) / 1e6, "ms_per_step": m8["alt"]["dt"] / max(args.steps, 1) * 1e3}
+                                 if (m8["alt"] and not m8["alt"]["table"]) else None),
+                  "note": "measured in the same launch after the headline workload, on the same ranks and the same communicator; kernel timers off in the timed steps "
+                          "(kernel_ms: the same steps once more with them)"}
             m8["rec"].close()
         except Exception as ex:                                  # the headline line must still be printed
             if multi:
@@ -563,10 +606,6 @@ def main():
         steps = max(args.steps, 1)
         ms_step = dt / steps * 1e3
         value = va / (dt / steps) / 1e6
-        bp_ms, bp_n = timers["backproject"]
-        fw_ms, fw_n = timers["forward"]
-        bp_avg = bp_ms / max(bp_n, 1) * 1e-3
-        fw_avg = fw_ms / max(fw_n, 1) * 1e-3
         vs, va_l, nv = cnt["Vs"], cnt["Va"], cnt["Nv"]
         # B_back = 4 Vs + 12 Va + 12 Nv, B_fwd = 4 Vs + 13 Va + 8 Nv algorithmic bytes per launch (this rank)
         b_back = 4.0 * vs + 12.0 * va_l + 12.0 * nv
@@ -604,24 +643,74 @@ def main():
 
         scatter_name = ("back_cell_kernel + k_cell_combine + k_cell_factors (csrc/svr_cell.inc: cell-owned planes, staged, combined in a fixed "
                         "order, no atomics)" if tuned["back_mode"] == 5 else "back_wave_kernel (wave-owned planes per slice tile, atomic flush)")
-        e_back = entry(scatter_name + " = SuperresolutionKernel3D_tex, RC.cu:408-522", bp_avg, bp_n, b_back, "back")
         gather_name = ("fwd_cell_kernel + k_cell_gather_finish + k_cell_gfactors (csrc/svr_cell.inc: the gather over the same (cell, plane) items)"
                        if tuned.get("fwd_mode") == 2 else "fwd_unit_kernel (unit-based gather per slice tile)")
-        e_fwd = entry(gather_name + " = simulateSlicesKernel3D_tex, RC.cu:298-404", fw_avg, fw_n, b_fwd, "forward")
-        dom, other = (e_back, e_fwd) if bp_avg >= fw_avg else (e_fwd, e_back)
-        roof = dict(dom)
-        roof["dead_unit_share"] = dead_share
-        roof["backproject" if dom is e_fwd else "forward"] = other
-        roof["note"] = ("The dominant kernel of the step, measured live (HIP events on the engine's stream); the other PSF pass next to it.  "
-                        "f32 VALU bound (4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; no MFMA: a scatter/gather stencil with a "
-                        "sequential epsilon-chain per row has no contraction).  `achieved` / `frac` (= `frac_executed`): the 38 flops of the "
-                        "canonical sequence on the taps that are evaluated (dead units: one tap per row) against the packed-f32 vector peak; "
-                        "`achieved_formula` / `frac_formula` credit the reference's 49-flop per-tap formula on all taps of a pixel (what rounds 1-4 "
-                        "called `frac`).  `valu_issue_frac` = "
-                        "SQ_INSTS_VALU per launch / (launch time x 1024 SIMDs x 0.6e9 wave-instructions/s): the share of VALU issue slots "
-                        "used, the figure that explains the time.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch time.  "
-                        "`traffic`: FETCH_SIZE + WRITE_SIZE per launch; counters from this round's separate rocprofv3 --pmc passes "
-                        "(profiles/r05_traffic.json, tools/prof_final.py), null when that file has no entry for the workload.")
+
+        def split(total, part):
+            """(ms, launches) of the launches of `total` that are not in `part`"""
+            return (total[0] - part[0], total[1] - part[1])
+
+        def avg_s(tm_):
+            return tm_[0] / max(tm_[1], 1) * 1e-3
+
+        bt, ft, fs = timers["backproject_table"], timers["forward_table"], timers["forward_store"]
+        bp_eval = split(timers["backproject"], bt)
+        fw_eval = split(split(timers["forward"], ft), fs)
+        e_back = entry(scatter_name + " = SuperresolutionKernel3D_tex, RC.cu:408-522", avg_s(bp_eval), bp_eval[1], b_back, "back")
+        e_fwd = entry(gather_name + " = simulateSlicesKernel3D_tex, RC.cu:298-404", avg_s(fw_eval if fw_eval[1] else fs), (fw_eval if fw_eval[1] else fs)[1], b_fwd, "forward")
+        eval_note = ("f32 VALU bound (4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; no MFMA: a scatter/gather stencil with a "
+                     "sequential epsilon-chain per row has no contraction).  `achieved` / `frac` (= `frac_executed`): the 38 flops of the "
+                     "canonical sequence on the taps that are evaluated (dead units: one tap per row) against the packed-f32 vector peak; "
+                     "`achieved_formula` / `frac_formula` credit the reference's 49-flop per-tap formula on all taps of a pixel (what rounds 1-4 "
+                     "called `frac`).  `valu_issue_frac` = SQ_INSTS_VALU per launch / (launch time x 1024 SIMDs x 0.6e9 wave-instructions/s): the "
+                     "share of VALU issue slots used, the figure that explains the time.  hbm_*: SURVEY 8d's algorithmic bytes over the same launch "
+                     "time.  `traffic`: FETCH_SIZE + WRITE_SIZE per launch; counters from this round's separate rocprofv3 --pmc passes "
+                     "(profiles/r06_traffic.json, tools/prof_final.py), null when that file has no entry for the workload.")
+        if table_used and bt[1] and ft[1]:
+            # The passes that stream the coefficient table: HBM bound.  Algorithmic bytes of a launch = the 1 KiB of every live (pixel, plane) unit
+            # (engine's own count: svr_unit_counts) + SURVEY 8d's compulsory bytes of the pass; `traffic` = what the PMC counters saw.
+            tbytes = float(unit_counts["live_units"]) * 1024.0 if unit_counts else float(va_l) * 16 * 1024.0
+
+            def tentry(kernel, tm_, alg, key, extra=""):
+                a_ = avg_s(tm_)
+                e = pmc_entry(prob.name, world, key)
+                tr = (2.0 * e["fetch_bytes"] + e["write_bytes"]) if e else None
+                return {"kernel": kernel, "bound": "hbm", "achieved": alg / a_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / a_ / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes": alg, "traffic": tr, "traffic_ratio": (tr / alg) if tr else None,
+                        "frac_counters": (tr / a_ / 1e9 / HBM_PEAK_GBS) if tr else None,
+                        "valu_issue_frac": (e["valu_insts"] / (a_ * SIMDS * VALU_ISSUE_PER_S)) if (e and e.get("valu_insts")) else None,
+                        "avg_launch_ms": a_ * 1e3, "launches": tm_[1], "note": extra}
+            on_cells = tuned.get("fwd_mode") == 2
+            e_bt = tentry("back_cell_kernel<16, false, 1> + k_cell_combine_wave + k_cell_factors (csrc/svr_cell.inc: the cell-owned scatter with the units' taps "
+                          "streamed from the coefficient table through a ring of registers) = SuperresolutionKernel3D_tex, RC.cu:408-522, over CoeffInit's "
+                          "coefficients (RG.cc:2617-2673)", bt, tbytes + b_back, "back_table")
+            e_ft = tentry("fwd_cell_kernel<16, false, 2> (the table's rows HBM -> LDS by LDS-DMA, csrc/svr_cell.inc) or fwd_unit_kernel<.., COEFF> on slice tiles "
+                          "(coarse slices: svr_simulate_slices) + k_cell_gather_finish = simulateSlicesKernel3D_tex, RC.cu:298-404" if on_cells else
+                          "fwd_unit_kernel<.., COEFF>", ft, tbytes + b_fwd, "forward_table")
+            e_fs = tentry("fwd_cell_kernel<16, false, 3>: the gather that evaluates every tap AND writes the table (coeff_lazy) = CoeffInit riding on "
+                          "simulateSlicesKernel3D_tex", fs, tbytes + b_fwd, "forward_store",
+                          "bytes WRITTEN; VALU-bound by its evaluation and write-bound by its stores at the same time") if fs[1] else None
+            step_ms = {"scatter_table": bt[0] / steps, "gather_table": ft[0] / steps, "gather_store": fs[0] / steps, "scatter_evaluate": bp_eval[0] / steps,
+                       "gather_evaluate": fw_eval[0] / steps}
+            dom, other = (e_bt, e_ft) if bt[0] >= ft[0] else (e_ft, e_bt)
+            roof = dict(dom)
+            roof["backproject_table" if dom is e_ft else "forward_table"] = other
+            roof["forward_store"] = e_fs
+            roof["evaluate"] = {"backproject": e_back if bp_eval[1] else None, "forward": e_fwd if (fw_eval[1] or fs[1]) else None, "note": eval_note}
+            roof["ms_per_step_by_kind"] = step_ms
+            roof["dead_unit_share"] = dead_share
+            roof["note"] = ("The step's dominant kernel by time, measured live (HIP events on the engine's stream, second pass of the same steps): the pass that streams "
+                            "the coefficient table -- three of four scatters and three of four gathers of an outer iteration; the fourth scatter evaluates (the table "
+                            "is thrown away with every outer iteration, inside the timed region) and the fourth gather evaluates and writes the table.  HBM bound: "
+                            "`achieved` = (1 KiB per live (pixel, plane) unit + SURVEY 8d's bytes of the pass) / launch time against the 8 TB/s peak; `traffic` / "
+                            "`frac_counters` = 2 x FETCH_SIZE (the guide's gfx950 correction for 16-byte streaming reads) + WRITE_SIZE from this round's separate "
+                            "rocprofv3 --pmc passes (profiles/r06_traffic.json).  `evaluate`: the f32-VALU-bound figures of the evaluating launches, as in rounds 1-5.")
+        else:
+            dom, other = (e_back, e_fwd) if avg_s(bp_eval) >= avg_s(fw_eval) else (e_fwd, e_back)
+            roof = dict(dom)
+            roof["dead_unit_share"] = dead_share
+            roof["backproject" if dom is e_fwd else "forward"] = other
+            roof["note"] = "The dominant kernel of the step, measured live (HIP events on the engine's stream); the other PSF pass next to it.  " + eval_note
         out = {
             "metric": METRIC,
             "value": value, "unit": "MVoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -652,7 +741,22 @@ def main():
             "s8": s8,
             "roofline": roof,
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in timers.items()},
+            "ms_per_step_with_kernel_timers": dt_timers / steps * 1e3,
+            "timing": "value / ms_per_step: K steps between two barriers with the kernel timers OFF; kernel_ms, ranks{} and roofline.avg_launch_ms: the same K steps "
+                      "once more with a HIP event pair around each hot kernel (ms_per_step_with_kernel_timers)",
         }
+        out["config"]["mode"] = ("coefficient table (svr_set_option coeff_table 1, the default of a slice-to-volume context since round 6): the taps of every live (pixel, plane) "
+                                 f"unit kept in HBM, THROWN AWAY every {SR_PER_OUTER} steps inside the timed region (an outer iteration's new slice transformations) and "
+                                 "rewritten by the next gather, which evaluates them anyway (coeff_lazy) -- irtkReconstruction::CoeffInit's _volcoeffs "
+                                 "(irtkReconstructionGPU.cc:2305-2673) on the GPU path; results bit-identical to evaluating every tap in every pass" if table_used else
+                                 "every tap evaluated in every pass (the reference GPU kernels' way)")
+        if alt is not None and not alt["table"]:
+            out["on_the_fly"] = {"value": va / (alt["dt"] / steps) / 1e6, "unit": "MVoxels/s", "ms_per_step": alt["dt"] / steps * 1e3,
+                                 "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in alt["timers"].items() if k in ("backproject", "forward", "regularize", "estep", "mstep", "scale")},
+                                 "note": "the same K steps with svr_set_option(coeff_table, 0): every tap evaluated in every pass like the reference's GPU kernels -- the headline "
+                                         "of rounds 1-5; same results bit for bit"}
+        elif alt is not None:
+            out["coeff_table"] = {"value": va / (alt["dt"] / steps) / 1e6, "unit": "MVoxels/s", "ms_per_step": alt["dt"] / steps * 1e3}
         # the volume update (Prep + regulariser, RC.cu:1944-1969, 2046-2117): the one HBM-bound kernel of the step; SURVEY 8d: 24 B / voxel
         up_ms, up_n = timers["regularize"]
         if up_n:

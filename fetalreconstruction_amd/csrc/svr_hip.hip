@@ -147,6 +147,8 @@ struct PsfArgs {
   const float2 *volm;       // SVR gather: {V m, m} per voxel, packed by k_pack_volm right before the pass (NULL: vol + mask)
   float *simslices, *simweights;
   unsigned char *siminside;
+  unsigned char *slice_inside;  // [slice]: some pixel of the slice has siminside == 1 (k_slice_inside; the cell gather's finish sets it itself: siminside only ever
+                                // goes from 0 to 1 between two Gaussian passes, so the per-slice flag needs no pass of its own)
   // back
   const float *weights, *slice_weights;
   float *addon, *cmap;
@@ -955,6 +957,31 @@ __device__ __forceinline__ float4 load_stream(const float4 *p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// 16 bytes per lane from global memory straight into the LDS (LDS-DMA, gfx950: global_load_lds_dwordx4): lane l's 16 bytes land at
+// lds_dst + 16 l (lds_dst: wave-uniform LDS byte address).  No VGPR is the destination, so nothing the compiler can copy, spill or wait for:
+// the data is in flight for as long as the kernel likes, and the kernel counts its completion itself (glds_wait) before it reads the LDS.
+// M0 holds the destination and is compiler-reserved: saved and restored inside the statement.  (hipcc does not count this load in its
+// own s_waitcnt bookkeeping; an uncounted older operation only makes the compiler's counted waits stricter, never looser: vmcnt is in order.)
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// wait until at most N vector-memory operations of this wavefront are outstanding (N an immediate), then the LDS may be read
+template <int N>
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)p; }   // (a generic pointer into the LDS: aperture in the high half, LDS byte address in the low)
+
+#ifndef SVR_COEFF_STORE_NT
+#define SVR_COEFF_STORE_NT 1
+#endif
+__device__ __forceinline__ void store_stream(float4 *p, float a, float b, float c, float d) {
+#if SVR_COEFF_STORE_NT
+  __builtin_nontemporal_store((nt_f4){a, b, c, d}, reinterpret_cast<nt_f4 *>(p));
+#else
+  *p = make_float4(a, b, c, d);
+#endif
+}
 // The coefficient table (svr_ctx::d_coeff): one wavefront per PSF pixel, four of its NS units per pass -- slot = unit,
 // lane = row, exactly the decomposition of the scatter and the gather.  A unit's NS x NS taps (skipped ones as -0.0f) go
 // out as NS/4 x 16 float4: [tap quad q][row y], so that the 16 lanes of a slot write and later read 256 contiguous bytes
@@ -989,8 +1016,7 @@ __global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, u
     if (!dead && u < NS && y < NS) {
       float4 *dst = coeff + ((size_t)w * NS + u) * (QUADS * 16) + y;
 #pragma unroll
-      for (int q = 0; q < QUADS; ++q)
-        __builtin_nontemporal_store((nt_f4){out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]}, reinterpret_cast<nt_f4 *>(dst + q * 16));
+      for (int q = 0; q < QUADS; ++q) store_stream(dst + q * 16, out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
     }
   }
 }
@@ -2934,7 +2960,13 @@ struct svr_ctx {
   size_t coeff_order_cap = 0;
   size_t coeff_cap = 0;        // pixels the allocation holds
   bool coeff_valid = false;
-  int coeff_mode = 0;          // option "coeff_table": 0 = evaluate on the fly, 1 = stream the table (SVR only; falls back to 0 if it does not fit)
+  int coeff_mode = 1;          // option "coeff_table": 0 = evaluate on the fly, 1 = stream the table (falls back to 0 if it does not fit).  Round 6: ON by
+                               // default for slice-to-volume runs (written by the first gather of the SR iterations, coeff_lazy: P4 +7 %, S8 +5 % with one
+                               // table per four SR iterations INSIDE the timed region), off for the patch-based path (no gain there: DESIGN 5.1b)
+  bool coeff_user = false;     // svr_set_option("coeff_table") was called: the "pvr" option leaves the mode alone
+  int coeff_lazy = 1;          // option "coeff_lazy" (round 6): 1 = the table is written by the first gather of the SR iterations after a new slice geometry
+                               // (fwd_cell_kernel<.., 3>: the evaluation that pass needs anyway) instead of by k_coeff_build; passes before it evaluate
+  bool coeff_full = false;     // the table holds every pixel with s != -1 (k_coeff_build), not only the PSF pixels of the gather that wrote it
   int wave_groups = 1, wave_cap = 2096;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (14 LDS granules of 1280 B with the static part: 9 wavefronts per CU)
 
   // reductions
@@ -3037,6 +3069,8 @@ inline int back_mode_eff(const svr_ctx *ctx) { return ctx->back_mode; }
 void reg_free(RegState *r);
 void cell_free(CellState *c);
 void cell_invalidate(svr_ctx *ctx);
+void cell_pids_invalidate(svr_ctx *ctx);
+void cell_gf_invalidate(svr_ctx *ctx);
 
 template <class T>
 void free_dev(T *&p) {
@@ -3059,8 +3093,10 @@ inline void timers_resolve(svr_ctx *c) {
   for (const auto &sp : c->ev_pending) {
     float ms = 0;
     if (sp.a && sp.b && hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-      c->t_ms[sp.which] += ms;
-      c->t_n[sp.which] += 1;
+      const int w = sp.which & 255, also = (sp.which >> 8) - 1;      // (ScopedTimer::also: the same pair counted under a second name)
+      c->t_ms[w] += ms;
+      c->t_n[w] += 1;
+      if (also >= 0 && also < SVR_T_COUNT) { c->t_ms[also] += ms; c->t_n[also] += 1; }
     }
     if (sp.a) c->ev_free.push_back(sp.a);
     if (sp.b) c->ev_free.push_back(sp.b);
@@ -3083,6 +3119,7 @@ struct ScopedTimer {
       if (a) (void)hipEventRecord(a, c->stream);
     }
   }
+  void also(int w2) { which = (which & 255) | ((w2 + 1) << 8); }   // the same interval under a second name (what kind of pass it was)
   void stop() {
     if (a) timer_close(c, which, a);
     a = nullptr;
@@ -3275,10 +3312,13 @@ PsfArgs make_args(svr_ctx *ctx) {
   a.recon = ctx->recon(); a.volw = ctx->volw(); a.voxcount = ctx->d_voxcount;
   a.vol = ctx->recon(); a.simslices = ctx->d_simslices; a.simweights = ctx->d_simweights;
   a.siminside = ctx->d_siminside;
+  a.slice_inside = ctx->d_slice_inside;
   a.weights = ctx->d_weights; a.slice_weights = ctx->d_slice_weights;
   a.addon = ctx->addon(); a.cmap = ctx->cmap();
   return a;
 }
+
+void give_coeff(const svr_ctx *ctx, PsfArgs &a) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }   // the table goes to a pass's arguments
 
 // bias-path buffers: slice-grid {bias, wb, wresidual, buffer} (RC.cu:1510-1539) and volume
 // {bias, volume_weights, maskC} (RC.cu:1203-1214, 1129-1157); created on first use after
@@ -3408,11 +3448,17 @@ struct TileSample {
 int coeff_order(svr_ctx *ctx, uint32_t n_active, const uint32_t **list);
 // (Re)build the coefficient table if the option is on and the table does not match the current PSF pixels / geometry.
 // Returns with ctx->coeff_valid set, or with the mode switched off when the table does not fit the free memory.
-int ensure_coeff(svr_ctx *ctx) {
-  if (!ctx->coeff_mode || ctx->coeff_valid) return SVR_OK;
+__global__ void k_coeff_ids(const uint32_t *list, uint32_t n, uint32_t *coeff_id) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) coeff_id[list[i]] = i;
+}
+// Can the table be left to the first gather of the SR iterations (coeff_lazy)?  Support 16 on the cell gather.
+bool coeff_lazy_ok(const svr_ctx *ctx) { return ctx->coeff_lazy && !ctx->pvr && ctx->fwd_mode == 2; }
+// The table's memory and the pixels' places in it (*list = the active pixels in table order).  Returns with ctx->d_coeff set, or with the mode
+// switched off when the table does not fit the free memory.
+int coeff_prepare(svr_ctx *ctx, const uint32_t **list) {
   // every pixel with s != -1: the Gaussian pass walks them all, the PSF pixels of the SR iterations are a subset
   const size_t npx = ctx->n_active;
-  if (!npx) return SVR_OK;
   if (npx > ctx->coeff_cap) {
     free_dev(ctx->d_coeff);
     ctx->coeff_cap = 0;
@@ -3430,16 +3476,26 @@ int ensure_coeff(svr_ctx *ctx) {
     ctx->coeff_cap = npx;
   }
   if (!ctx->d_coeff_id) HIPCHK(hipMalloc(&ctx->d_coeff_id, ctx->np * sizeof(uint32_t)));
-  PsfArgs a = make_args(ctx);
-  a.list = ctx->d_active;
-  a.n = (uint32_t)npx;
+  *list = ctx->d_active;
   // The pixels get their places in the table in the order of the scatter's cell lists (cell, slice, band, position): what a
   // (cell, plane) item of the scatter or a slice tile of the gather reads next then lies within a few megabytes instead of one
   // KiB per slice all over the table (a TLB miss per unit); pixels the cell lists dropped (footprint beyond the volume) follow.
   if (!getenv("SVR_COEFF_UNSORTED")) {
-    const int r = coeff_order(ctx, (uint32_t)npx, &a.list);
+    const int r = coeff_order(ctx, (uint32_t)npx, list);
     if (r) return r;
   }
+  return SVR_OK;
+}
+// (Re)build the coefficient table if the option is on and the table does not match the current PSF pixels / geometry.
+// Returns with ctx->coeff_valid set, or with the mode switched off when the table does not fit the free memory.
+int ensure_coeff(svr_ctx *ctx) {
+  if (!ctx->coeff_mode || ctx->coeff_valid) return SVR_OK;
+  const size_t npx = ctx->n_active;
+  if (!npx) return SVR_OK;
+  PsfArgs a = make_args(ctx);
+  a.n = (uint32_t)npx;
+  { const int r = coeff_prepare(ctx, &a.list); if (r) return r; }
+  if (!ctx->coeff_mode) return SVR_OK;
   ScopedTimer tb(ctx, SVR_T_COEFF_BUILD);
   {
     const int rr = pixel_list_in_pieces(a, [&](const PsfArgs &ap, uint32_t off) {
@@ -3452,7 +3508,14 @@ int ensure_coeff(svr_ctx *ctx) {
   }
   tb.stop();
   ctx->coeff_valid = true;
+  ctx->coeff_full = true;
+  cell_pids_invalidate(ctx);                               // (the records' table ids: svr_cell.inc cell_pids)
   return SVR_OK;
+}
+// a pass other than the gather of the SR iterations: with coeff_lazy it does not build the table -- it evaluates until that gather has written it
+int ensure_coeff_unless_lazy(svr_ctx *ctx) {
+  if (ctx->coeff_mode && !ctx->coeff_valid && coeff_lazy_ok(ctx)) return SVR_OK;
+  return ensure_coeff(ctx);
 }
 
 int launch_slot(svr_ctx *ctx, bool pvr, const PsfArgs &a, const TileArgs &ta_, uint32_t *fb, uint32_t *cnt) {
@@ -3723,10 +3786,13 @@ int svr_set_option(svr_ctx *ctx, const char *name, int value) {
     ctx->fwd_tune_pending = ctx->back_tune_pending = value != 0;
     return SVR_OK;
   }
-  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; cell_invalidate(ctx); free_dev(ctx->d_coeff); ctx->coeff_cap = 0; return SVR_OK; }
+  if (!strcmp(name, "pvr")) { ctx->pvr = value ? 1 : 0; if (!ctx->coeff_user) ctx->coeff_mode = value ? 0 : 1; ctx->sc_dirty = true; ctx->psf_list_valid = false; ctx->coeff_valid = false; cell_invalidate(ctx); free_dev(ctx->d_coeff); ctx->coeff_cap = 0; return SVR_OK; }
+  if (!strcmp(name, "coeff_lazy")) { ctx->coeff_lazy = value ? 1 : 0; return SVR_OK; }
+  if (!strcmp(name, "coeff_invalidate")) { ctx->coeff_valid = false; return SVR_OK; }   // (what a new slice geometry does to the table: bench.py's outer iterations)
   if (!strcmp(name, "coeff_table")) {
     if ((value ? 1 : 0) != ctx->coeff_mode) ctx->fwd_tune_pending = ctx->back_tune_pending = ctx->fwd_autotune != 0;   // other shapes win
     ctx->coeff_mode = value ? 1 : 0;
+    ctx->coeff_user = true;
     if (!value) { free_dev(ctx->d_coeff); ctx->coeff_cap = 0; ctx->coeff_valid = false; cell_invalidate(ctx); }
     return SVR_OK;
   }
@@ -3809,7 +3875,7 @@ int svr_get_option(svr_ctx *ctx, const char *name, int *value) {
   cell_sizes(ctx, csw, csh, cgw, cgh);                   // the cell sizes in effect (0 = automatic resolved)
   const struct { const char *n; int v; } tab[] = {
       {"back_mode", back_mode_eff(ctx)}, {"reg_mode", ctx->reg_mode}, {"fwd_mode", ctx->fwd_mode}, {"gauss_mode", ctx->gauss_mode}, {"pvr_mode", ctx->pvr_mode},
-      {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
+      {"pvr", ctx->pvr}, {"coeff_table", ctx->coeff_mode}, {"coeff_lazy", ctx->coeff_lazy}, {"coeff_valid", ctx->coeff_valid ? 1 : 0}, {"tile_w", ctx->tile_w}, {"tile_h", ctx->tile_h},
       {"fwd_tile_w", ctx->fwd_tw}, {"fwd_tile_h", ctx->fwd_th}, {"wave_cap", ctx->wave_cap}, {"cell_w", csw}, {"cell_h", csh}, {"cell_gw", cgw}, {"cell_gh", cgh}, {"cell_split", ctx->cell_split}, {"cell_order", ctx->cell_order}, {"cell_balance", ctx->cell_balance}, {"cell_combine", ctx->cell_combine}, {"fwd_autotune", ctx->fwd_autotune}, {"cell_qx", ctx->cell_qx}, {"fwd_unit_cap", ctx->fwd_unit_cap}, {"reg_batch", ctx->reg_batch}, {"reg_blind", ctx->reg_blind}};
   for (const auto &e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return SVR_OK; }
@@ -4048,6 +4114,7 @@ int svr_init_storage_volumes(svr_ctx *ctx, const uint32_t size[3], const float d
   HIPCHK(hipMemsetAsync(ctx->d_simweights, 0, fb, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_psf_sums, 0, fb, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_siminside, 0, np, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_slice_inside, 0, ctx->ns, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_voxcount, 0, np * sizeof(int), ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
@@ -4196,19 +4263,20 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
     HIPCHK(hipMemsetAsync(ctx->d_simweights, 0, fb, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_simslices, 0, fb, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_siminside, 0, ctx->np, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_slice_inside, 0, ctx->ns, ctx->stream));
   }
   HIPCHK(hipMemsetAsync(ctx->d_voxcount, 0, ctx->np * sizeof(int), ctx->stream));
   ctx->recon_cur = ctx->d_recon_volw;      // recon | volw as one allocation again (the pair a sharded run all-reduces); the old volume is not read
   HIPCHK(hipMemsetAsync(ctx->d_recon_volw, 0, 2 * ctx->nv * sizeof(float), ctx->stream));
   const bool tiled = ctx->gauss_mode == 1 && (!ctx->pvr || ctx->pvr_mode == 1);
   if (tiled) {
-    r = ensure_coeff(ctx);
+    r = ensure_coeff_unless_lazy(ctx);
     if (r) return r;
   }
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_active;
   a.n = ctx->n_active;
-  if (tiled && ctx->coeff_mode && ctx->coeff_valid) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
+  if (tiled && ctx->coeff_mode && ctx->coeff_valid && ctx->coeff_full) give_coeff(ctx, a);   // (every pixel with s != -1: a table written by a gather does not hold them all)
   ScopedTimer t(ctx, SVR_T_GAUSS);
   if (a.n && tiled) {
     // pass 1 = the unit-based walk of the gather (sume, gate, v_PSF_sums, voxel-count flag), pass 2 = the scatter of the
@@ -4288,6 +4356,8 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   }
   t.stop();
   ctx->psf_list_valid = false;
+  if (!ctx->coeff_full) ctx->coeff_valid = false;          // new v_PSF_sums: a table written by a gather holds the PSF pixels of that gather
+  cell_gf_invalidate(ctx);                                 // ... and the gather's 1 / v_PSF_sums per sorted pixel
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
 }
@@ -4322,10 +4392,14 @@ int svr_gaussian_reconstruction(svr_ctx *ctx, int *voxel_num) {
 // 6 x 5 and 3.07 for 4 x 4; S8 (d 0.56) 6 x 5 26.8 against 28.6 / 28.4 for 6 x 4 / 8 x 4; patches (support 12: smaller boxes) 8 x 4
 // 8.1 against 9.0-9.5 ms.  On the fly: 6 x 4 (round 2: 4.21 against 4.60 ms for 4 x 4 on P4).  Near-ties all (2-6 %): a rule that
 // repeats is worth more than the last per cent -- the table line of round 3 moved by 4 % from run to run with the trials' picks.
-void tile_shape_rule(const svr_ctx *ctx, bool table, int &w, int &h) {
+double pixel_density(const svr_ctx *ctx) {              // voxel area / pixel area in the slice plane
   double d = 1.0;
   if (ctx->slice_dims.size() >= 3 && ctx->slice_dims[0] > 0 && ctx->slice_dims[1] > 0)
     d = (double)ctx->vdim[0] * ctx->vdim[1] / ((double)ctx->slice_dims[0] * ctx->slice_dims[1]);
+  return d;
+}
+void tile_shape_rule(const svr_ctx *ctx, bool table, int &w, int &h) {
+  const double d = pixel_density(ctx);
   if (ctx->pvr) { w = 8; h = 4; }
   else if (table && d < 0.65) { w = 6; h = 5; }
   else { w = 6; h = 4; }
@@ -4339,12 +4413,31 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   if (r) return r;
   r = ensure_psf_list(ctx);
   if (r) return r;
-  r = ensure_coeff(ctx);
-  if (r) return r;
+  // Round 6 (coeff_lazy): with the table wanted and not there, THIS pass writes it -- it evaluates every tap of every PSF pixel anyway
+  // (fwd_cell_kernel<.., 3>); needs the cell gather.  Otherwise k_coeff_build, as before.
+  bool store = false;
+  CellState *gcs = nullptr;
+  if (ctx->coeff_mode && !ctx->coeff_valid && coeff_lazy_ok(ctx) && ctx->n_psf && ctx->n_active) {
+    if ((r = cell_prepare_gather(ctx, gcs))) return r;
+    if (gcs->usable) {
+      const uint32_t *order = nullptr;
+      if ((r = coeff_prepare(ctx, &order))) return r;
+      if (ctx->coeff_mode) {                                // (0: the table does not fit)
+        hipLaunchKernelGGL(k_coeff_ids, dim3(nblk(ctx->n_active)), dim3(256), 0, ctx->stream, order, (uint32_t)ctx->n_active, ctx->d_coeff_id);
+        KCHK("k_coeff_ids");
+        cell_pids_invalidate(ctx);
+        store = true;
+      }
+    }
+  }
+  if (!store) {
+    r = ensure_coeff(ctx);
+    if (r) return r;
+  }
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
-  if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1)) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
+  if (store || (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1))) give_coeff(ctx, a);
   if (!ctx->pvr && ctx->fwd_mode >= 1 && a.n) {
     if (!ctx->d_volm) HIPCHK(hipMalloc(&ctx->d_volm, ctx->nv * sizeof(float2)));
     hipLaunchKernelGGL(k_pack_volm, dim3(nblk(ctx->nv)), dim3(256), 0, ctx->stream, ctx->recon(), ctx->d_mask, ctx->d_volm, ctx->nv);
@@ -4358,11 +4451,14 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   }
   // fwd_mode 2 (the default for SVR on the fly): the gather over the (cell, plane) items of the scatter without atomics
   bool cells = false;
-  CellState *gcs = nullptr;
   // (with the coefficient table: the cell gather for support 12 only -- PVR8spx 24.5 -> 20.7 ms; for support 16 its ring and its 16
   // box values do not fit the registers and the unit gather streams the table faster: P4 2.76 against 3.04 ms)
   // ... and there only on large cells, i.e. fine volumes: PVR4 (9 x 6) 8.1 ms on tiles against 8.5 ms on cells)
-  bool table_on_cells = false;
+  // Round 6: support 16 takes the cell gather too -- the table's rows land in the LDS by LDS-DMA instead of in a ring of registers (fwd_cell_kernel,
+  // COEFF == 2): P4 2.39 against 2.84 ms; option fwd_mode 1 keeps the tile kernel reachable
+  // ... where the slices' pixels are not much coarser than the voxels (the density of tile_shape_rule): S8 (d 0.56, a 174 GB table) 28.1 ms on the
+  // cells whatever their size (6 x 4 .. 12 x 6) against 26.9 ms on 6 x 5 slice tiles
+  bool table_on_cells = a.coeff && !ctx->pvr && (store || ctx->fwd_mode_user || pixel_density(ctx) >= 0.65);
   if (a.coeff && ctx->pvr) {
     int sw, sh, gw, gh;
     cell_sizes(ctx, sw, sh, gw, gh);
@@ -4376,8 +4472,9 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   auto launch_forward = [&]() -> int {
     const bool tiled_ = ctx->pvr ? ctx->pvr_mode == 1 : ctx->fwd_mode >= 1;
     if (cells) {
-      const int rr = launch_cell_gather(ctx, *gcs, a);
+      const int rr = launch_cell_gather(ctx, *gcs, a, store);
       if (rr) return rr;
+      if (store) { ctx->coeff_valid = true; ctx->coeff_full = false; }   // (the PSF pixels' live units: what the SR iterations' passes read)
     } else if (a.n && tiled_) {
       { const int rr = ensure_tiles_fwd(ctx); if (rr) return rr; }
       TileArgs ta;
@@ -4453,12 +4550,15 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
     a.list = ctx->d_psf_list; a.n = ctx->n_psf;
   }
   ScopedTimer t(ctx, SVR_T_FORWARD);
+  if (store) t.also(SVR_T_FORWARD_STORE); else if (a.coeff) t.also(SVR_T_FORWARD_TABLE);
   r = launch_forward();
   if (r) return r;
   t.stop();
-  hipLaunchKernelGGL(k_slice_inside, dim3(ctx->ns), dim3(256), 0, ctx->stream, ctx->d_siminside,
-                     (int)(ctx->sx * ctx->sy), ctx->d_slice_inside);
-  KCHK("k_slice_inside");
+  if (!cells) {                                            // (the cell gather's finish raises the slices' flags itself)
+    hipLaunchKernelGGL(k_slice_inside, dim3(ctx->ns), dim3(256), 0, ctx->stream, ctx->d_siminside,
+                       (int)(ctx->sx * ctx->sy), ctx->d_slice_inside);
+    KCHK("k_slice_inside");
+  }
   // slice_inside == NULL: the flags stay on the device (svr_get_slice_inside, svr_mstep_estep) and the call does not wait
   if (slice_inside) {
     if ((r = down_queue(ctx, slice_inside, ctx->d_slice_inside, ctx->ns))) return r;
@@ -4838,17 +4938,20 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   }
   r = ensure_psf_list(ctx);
   if (r) return r;
-  r = ensure_coeff(ctx);
+  r = ensure_coeff_unless_lazy(ctx);
   if (r) return r;
-  HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream));   // RC.cu:2202-2203
+  // RC.cu:2202-2203 -- not needed where the cell scatter runs: its combine writes EVERY voxel of addon | cmap (0 outside the mask); decided below
+  bool need_clear = true;
   ctx->prep_pending = false;
   ctx->cmap_from_scatter = true;
   PsfArgs a = make_args(ctx);
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
-  if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 4)) { a.coeff = ctx->d_coeff; a.coeff_id = ctx->d_coeff_id; }
+  if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 4)) give_coeff(ctx, a);
   ScopedTimer t(ctx, SVR_T_BACKPROJECT);
+  if (a.coeff) t.also(SVR_T_BACKPROJECT_TABLE);
   const bool tiled = ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 1;
+  if (!(a.n && tiled)) { need_clear = false; HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream)); }
   if (a.n && tiled) {
     TileArgs ta;
     ta.tiles_x = ctx->tiles_x; ta.tiles_y = ctx->tiles_y; ta.dbg = ctx->dbg_back;
@@ -4859,6 +4962,8 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
       cells = ctx->cell->usable;
       if (!cells) ctx->note_fallback(0, "the scatter left the cell path (the cell lists cannot hold this geometry): back_mode 4, float atomics, last bits depend on the run");
     }
+    need_clear = !cells;
+    if (need_clear) { need_clear = false; HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream)); }
     if (cells) r = launch_cell_scatter(ctx, a, 0, ctx->addon(), ctx->cmap());
     else if (!(r = ensure_tiles_back(ctx))) r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, back_mode_eff(ctx)), a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
     if (r) return r;
@@ -5169,7 +5274,11 @@ int svr_debug_set(svr_ctx *ctx, int which, const void *host_in, size_t bytes) {
   if (bytes != b) return fail(ctx, SVR_E_ARG, "svr_debug_set: size mismatch");
   HIPCHK(hipMemcpyAsync(p, host_in, b, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) ctx->psf_list_valid = false;
+  if (which == SVR_BUF_PSF_SUMS || which == SVR_BUF_SLICES) { ctx->psf_list_valid = false; if (!ctx->coeff_full) ctx->coeff_valid = false; cell_gf_invalidate(ctx); }
+  if (which == SVR_BUF_SIMINSIDE) {                      // (the per-slice flags follow: the cell gather only ever raises them)
+    hipLaunchKernelGGL(k_slice_inside, dim3(ctx->ns), dim3(256), 0, ctx->stream, ctx->d_siminside, (int)(ctx->sx * ctx->sy), ctx->d_slice_inside);
+    KCHK("k_slice_inside");
+  }
   if (which == SVR_BUF_SLICES) { ctx->coeff_valid = false; cell_invalidate(ctx); }   // the table and the cell lists cover the pixels with s != -1
   if (which == SVR_BUF_MASK) ctx->mbox_valid = false;                               // (a mask set behind svr_set_mask's back: the whole pair is exchanged)
   if (which == SVR_BUF_MASK && ctx->slab) ctx->slab->valid = false;

@@ -25,28 +25,26 @@
 #include <vector>
 
 #include "../../include/svr_host.h"
+#include "svr_rccl_abi.h"
 
 namespace {
 
-// the slice of rccl.h this file uses (ABI of NCCL 2.x / RCCL: enums and the opaque handles)
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclInt32 = 2, ncclFloat32 = 7, ncclFloat64 = 8 };
-enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 };
+// the slice of rccl.h this file uses (ABI of NCCL 2.x / RCCL: enums, the opaque handles, the prototypes): csrc/svr_rccl_abi.h, checked
+// against /opt/rocm/include/rccl/rccl.h at compile time by tests/rccl_abi_check.cpp
+using namespace svr_rccl_abi;
 
 struct Rccl {
   void *h = nullptr;
-  int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  int (*CommDestroy)(ncclComm_t) = nullptr;
-  int (*CommCount)(ncclComm_t, int *) = nullptr;
-  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
+  GetUniqueId_fn GetUniqueId = nullptr;
+  CommInitRank_fn CommInitRank = nullptr;
+  CommDestroy_fn CommDestroy = nullptr;
+  CommCount_fn CommCount = nullptr;
+  AllReduce_fn AllReduce = nullptr;
+  AllGather_fn AllGather = nullptr;
+  ReduceScatter_fn ReduceScatter = nullptr;
+  GroupStart_fn GroupStart = nullptr;
+  GroupEnd_fn GroupEnd = nullptr;
+  GetErrorString_fn GetErrorString = nullptr;
   std::string err;
 };
 Rccl g_rccl;

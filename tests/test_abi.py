@@ -66,3 +66,33 @@ def test_host_threads_follow_the_override_and_the_cpu_quota():
     forced = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, check=True,
                                 env={**os.environ, "SVR_HOST_THREADS": "3"}).stdout)
     assert forced == 3
+
+
+def test_the_hand_written_slice_of_rccl_h_matches_the_image_s_header(tmp_path):
+    """csrc/svr_rccl.cpp binds librccl by dlsym against prototypes and enum values written out by hand (csrc/svr_rccl_abi.h: the library must
+    build and load without RCCL).  tests/rccl_abi_check.cpp puts them next to /opt/rocm/include/rccl/rccl.h and static_asserts that they
+    agree -- the first real N > 1 run should not be the first time anyone finds out.  With a control: the same check must FAIL to compile
+    once a value of the hand-written header is changed."""
+    import shutil
+    import subprocess
+    import pytest
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr) or not shutil.which("g++"):
+        pytest.skip("no RCCL header / compiler in this image")
+    src = os.path.join(ROOT, "tests", "rccl_abi_check.cpp")
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+    ok = subprocess.run(cmd + [src], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-3000:]
+    # the control: a changed enum value, and a changed prototype, each break the compilation
+    abi = open(os.path.join(ROOT, "fetalreconstruction_amd", "csrc", "svr_rccl_abi.h")).read()
+    chk = open(src).read().replace('#include "../fetalreconstruction_amd/csrc/svr_rccl_abi.h"', '#include "svr_rccl_abi.h"')
+    for old, new, what in (("ncclFloat32 = 7", "ncclFloat32 = 6", "ncclDataType_t values"),
+                           ("typedef int (*AllGather_fn)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);",
+                            "typedef int (*AllGather_fn)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);", "ncclAllGather")):
+        assert old in abi
+        d = tmp_path / what.replace(" ", "_")
+        d.mkdir()
+        (d / "svr_rccl_abi.h").write_text(abi.replace(old, new))
+        (d / "check.cpp").write_text(chk)
+        bad = subprocess.run(cmd + ["-I" + str(d), str(d / "check.cpp")], capture_output=True, text=True)
+        assert bad.returncode != 0 and what in bad.stderr, (what, bad.stderr[-1500:])

@@ -29,19 +29,26 @@ def _last_json(text):
 
 @pytest.mark.gpu
 def test_bench_line_and_two_ranks_on_one_gpu():
-    one = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+    # (5 steps: the fifth starts an outer iteration -- the table is thrown away and rewritten inside the timed region)
+    one = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     a = _last_json(one.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline"):
         assert key in a, key
-    assert a["n_gpus"] == 1 and a["steps"] == 3 and a["value"] > 0 and a["dtype"] == "f32" and a["roofline"]["frac"] > 0
-    assert a["scaling"] == "strong" and a["roofline"]["bound"] == "valu_f32" and a["roofline"]["hbm_frac"] > 0
-    assert a["roofline"]["algorithmic_bytes"] > 0 and "traffic" in a["roofline"]
-    # the second measurement of the same steps with the coefficient table, next to the headline
-    t = a["coeff_table"]
-    assert t["fits"] and t["value"] > 0 and t["ms_per_step"] > 0 and t["roofline"]["bound"] == "hbm" and t["table_bytes_rank0"] > 0
+    assert a["n_gpus"] == 1 and a["steps"] == 5 and a["value"] > 0 and a["dtype"] == "f32" and a["roofline"]["frac"] > 0
+    # round 6: the line's mode is the product's default -- the coefficient table, thrown away and rewritten inside the timed region with every
+    # outer iteration -- and its dominant kernel streams the table: HBM bound, algorithmic bytes and the kind of every pass in the line
+    assert a["scaling"] == "strong" and a["config"]["mode"].startswith("coefficient table") and a["roofline"]["bound"] == "hbm"
+    r = a["roofline"]
+    assert r["algorithmic_bytes"] > 0 and "traffic" in r and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-9
+    assert r["launches"] > 0 and r["forward_store"]["launches"] >= 1 and r["evaluate"]["backproject"]["bound"] == "valu_f32"
+    assert set(r["ms_per_step_by_kind"]) == {"scatter_table", "gather_table", "gather_store", "scatter_evaluate", "gather_evaluate"}
+    assert a["ms_per_step_with_kernel_timers"] > 0 and "timers OFF" in a["timing"]
+    # ... and the same steps with every tap evaluated in every pass (the headline of rounds 1-5) next to it
+    t = a["on_the_fly"]
+    assert t["value"] > 0 and t["ms_per_step"] > 0 and t["kernel_ms"]["backproject"] > 0
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",

@@ -666,11 +666,22 @@ def test_coefficient_table_against_the_oracle(tiny, oracle_mod):
     instead of evaluating them -- irtkReconstruction::CoeffInit's _volcoeffs (RG.cc:2305-2673) on the GPU path.  Against the
     oracle like the on-the-fly kernels; the gather bit-identical to the on-the-fly gather (same taps, same order of sums)."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    assert rec.get_option("coeff_table") == 1 and rec.get_option("coeff_lazy") == 1     # round 6: the default of a slice-to-volume context
+    rec.set_option("coeff_table", 0)                                     # the reference of this test: every tap evaluated
     run_to_state(dg, "sim")
     sim0, sw0 = rec.debug_get(E.BUF_SIMSLICES).copy(), rec.debug_get(E.BUF_SIMWEIGHTS).copy()
     rec.set_option("coeff_table", 1)
-    rec.SimulateSlices()
+    assert rec.get_option("coeff_valid") == 0
+    rec.SimulateSlices()                                                 # ... this gather evaluates too, and WRITES the table (coeff_lazy)
+    assert rec.get_option("coeff_valid") == 1
     assert np.array_equal(rec.debug_get(E.BUF_SIMSLICES), sim0) and np.array_equal(rec.debug_get(E.BUF_SIMWEIGHTS), sw0)
+    rec.SimulateSlices()                                                 # ... and this one reads it
+    assert np.array_equal(rec.debug_get(E.BUF_SIMSLICES), sim0) and np.array_equal(rec.debug_get(E.BUF_SIMWEIGHTS), sw0)
+    rec.set_option("coeff_lazy", 0); rec.set_option("coeff_invalidate", 1)
+    rec.SimulateSlices()                                                 # the table written by k_coeff_build instead: the same bits
+    assert rec.get_option("coeff_valid") == 1 and rec.timers()["coeff_build"][1] >= 0
+    assert np.array_equal(rec.debug_get(E.BUF_SIMSLICES), sim0) and np.array_equal(rec.debug_get(E.BUF_SIMWEIGHTS), sw0)
+    rec.set_option("coeff_lazy", 1)
     run_to_state(do, "sim")
     assert np.array_equal(rec.debug_get(E.BUF_SIMINSIDE), orc.siminside)
     assert rel_err(rec.debug_get(E.BUF_SIMSLICES), orc.simslices) < TOL_SUM
@@ -725,9 +736,12 @@ def test_coefficient_table_at_full_size(workload):
         sim, sw, si = (rec.debug_get(b).copy() for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE))
         rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
         return sim, sw, si, rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy()
+    rec.set_option("coeff_table", 0)
     ref = both()
     rec.set_option("coeff_table", 1)
+    both()                                                               # (its gather writes the table, its scatter reads it)
     tab = both()
+    assert rec.get_option("coeff_table") != 1 or rec.get_option("coeff_valid") == 1
     if rec.get_option("coeff_table") != 1:                               # P4: 19 GB, S8: 174 GB
         assert workload == "S8"
         pytest.skip("the 174 GB table of S8 does not fit the free memory of this device")
@@ -740,6 +754,8 @@ def test_coefficient_table_at_full_size(workload):
         ti = np.stack([np.linalg.inv(m.astype(np.float64)) for m in t]).astype(np.float32)
         rec.SetSliceMatrices(t.reshape(P.ns, 16), ti.reshape(P.ns, 16), P.slice_i2w, P.slice_w2i, P.slice_i2w, P.slice_w2i, P.recon_i2w, P.recon_w2i)
         rec.GaussianReconstruction()
+        assert rec.get_option("coeff_valid") == 0                        # new matrices: the table follows
+        both()
         tab2 = both()
         rec.set_option("coeff_table", 0)
         ref2 = both()

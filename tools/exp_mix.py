@@ -1,14 +1,16 @@
-"""Dev experiment (round 6): the MIXED pass -- `coeff_planes` of every 32 planes stream the coefficient table, the others' items
-evaluate, in the same launch of the cell kernels -- against the two pure forms.  Same addon | cmap | simulated slices bit for bit?
-Time per launch of the scatter and of the gather.  usage: exp_mix.py [P4|S8|PVR4|PVR8spx] [planes ...]   (planes: 0 = on the fly)"""
+"""Dev experiment (round 6): the three forms of the PSF passes -- coeff_table 0 (every tap evaluated), 1 (every tap of a live unit from the
+table), 2 (the HALF table: the right half of a row from the table, the left half evaluated while it is in flight).  Same addon | cmap |
+simulated slices bit for bit?  Time per launch of the scatter and of the gather.  usage: exp_mix.py [P4|S8] [modes ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fetalreconstruction_amd import engine as E, workloads
 from fetalreconstruction_amd.host import irtkReconstruction
 
+OPTS = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}
+sys.argv = [a for a in sys.argv if "=" not in a]
 name = sys.argv[1] if len(sys.argv) > 1 else "P4"
-planes = [int(a) for a in sys.argv[2:]] or [0, 32, 24, 20, 16, 12]
+planes = [int(a) for a in sys.argv[2:]] or [0, 1]
 reps = int(os.environ.get("REPS", "6"))
 P = workloads.get(name)
 pvr = name.startswith("PVR")
@@ -34,9 +36,9 @@ ones = np.ones(P.ns, np.float32)
 ref = None
 rec.timer_enable(True)
 for m in planes:
-    rec.set_option("coeff_table", 1 if m else 0)
-    if m:
-        rec.set_option("coeff_planes", m)
+    rec.set_option("coeff_table", m)
+    for k, v in OPTS.items():
+        rec.set_option(k, v)
     if os.environ.get("FWD_MODE"):
         rec.set_option("fwd_mode", int(os.environ["FWD_MODE"]))
     rec.SimulateSlices()
@@ -50,9 +52,15 @@ for m in planes:
     same = "-" if ref is None else str([bool(np.array_equal(a, b, equal_nan=True)) for a, b in zip(out, ref)])
     if ref is None:
         ref = out
+    if m:                                   # the gather that writes the table (coeff_lazy), and the separate build (k_coeff_build)
+        rec.timer_reset(); rec.set_option("coeff_invalidate", 1); rec.SimulateSlices()
+        st_ms = rec.timers()["forward"][0]
+        rec.set_option("coeff_lazy", 0); rec.timer_reset(); rec.set_option("coeff_invalidate", 1); rec.SimulateSlices()
+        tt = rec.timers(); bl_ms = tt["coeff_build"][0]; rec.set_option("coeff_lazy", 1)
+        print(f"[{name}] the gather that writes the table: {st_ms:.3f} ms; k_coeff_build: {bl_ms:.3f} ms", flush=True)
     bt = t["backproject"][0] / t["backproject"][1]
     ft = t["forward"][0] / t["forward"][1]
     cb = t.get("coeff_build", (0.0, 0))
-    print(f"[{name}] planes {m:2d}/32 (table on: {rec.get_option('coeff_table')}): scatter {bt:.3f} ms, gather {ft:.3f} ms, sum {bt + ft:.3f}; "
+    print(f"[{name}] {OPTS} cells {rec.get_option('cell_w')}x{rec.get_option('cell_h')} / {rec.get_option('cell_gw')}x{rec.get_option('cell_gh')} coeff_table {m} (in effect: {rec.get_option('coeff_table')}): scatter {bt:.3f} ms, gather {ft:.3f} ms, sum {bt + ft:.3f}; "
           f"build {cb[0] / max(cb[1], 1):.3f} ms x{cb[1]}; same bits as the first line {same}", flush=True)
 rec.close()
