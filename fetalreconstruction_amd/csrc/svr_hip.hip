@@ -2967,6 +2967,9 @@ struct svr_ctx {
   int coeff_lazy = 1;          // option "coeff_lazy" (round 6): 1 = the table is written by the first gather of the SR iterations after a new slice geometry
                                // (fwd_cell_kernel<.., 3>: the evaluation that pass needs anyway) instead of by k_coeff_build; passes before it evaluate
   bool coeff_full = false;     // the table holds every pixel with s != -1 (k_coeff_build), not only the PSF pixels of the gather that wrote it
+  const uint32_t *coeff_list = nullptr;   // the active pixels in table order (d_coeff_order, or d_active), while coeff_ids_valid
+  bool coeff_ids_valid = false;   // d_coeff_order / d_coeff_id match the current cell lists (cell_invalidate resets): a table thrown away without a new
+                                  // geometry (svr_set_option coeff_invalidate) keeps its pixels' places
   int wave_groups = 1, wave_cap = 2096;      // back_wave_kernel: wavefronts per tile, box voxels of a wavefront's four planes (14 LDS granules of 1280 B with the static part: 9 wavefronts per CU)
 
   // reductions
@@ -3475,7 +3478,8 @@ int coeff_prepare(svr_ctx *ctx, const uint32_t **list) {
     }
     ctx->coeff_cap = npx;
   }
-  if (!ctx->d_coeff_id) HIPCHK(hipMalloc(&ctx->d_coeff_id, ctx->np * sizeof(uint32_t)));
+  if (!ctx->d_coeff_id) { HIPCHK(hipMalloc(&ctx->d_coeff_id, ctx->np * sizeof(uint32_t))); ctx->coeff_ids_valid = false; }
+  if (ctx->coeff_ids_valid && ctx->coeff_list) { *list = ctx->coeff_list; return SVR_OK; }
   *list = ctx->d_active;
   // The pixels get their places in the table in the order of the scatter's cell lists (cell, slice, band, position): what a
   // (cell, plane) item of the scatter or a slice tile of the gather reads next then lies within a few megabytes instead of one
@@ -3484,6 +3488,7 @@ int coeff_prepare(svr_ctx *ctx, const uint32_t **list) {
     const int r = coeff_order(ctx, (uint32_t)npx, list);
     if (r) return r;
   }
+  ctx->coeff_list = *list;
   return SVR_OK;
 }
 // (Re)build the coefficient table if the option is on and the table does not match the current PSF pixels / geometry.
@@ -3509,7 +3514,8 @@ int ensure_coeff(svr_ctx *ctx) {
   tb.stop();
   ctx->coeff_valid = true;
   ctx->coeff_full = true;
-  cell_pids_invalidate(ctx);                               // (the records' table ids: svr_cell.inc cell_pids)
+  if (!ctx->coeff_ids_valid) cell_pids_invalidate(ctx);    // (the records' table ids: svr_cell.inc cell_pids)
+  ctx->coeff_ids_valid = true;
   return SVR_OK;
 }
 // a pass other than the gather of the SR iterations: with coeff_lazy it does not build the table -- it evaluates until that gather has written it
@@ -4423,9 +4429,12 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
       const uint32_t *order = nullptr;
       if ((r = coeff_prepare(ctx, &order))) return r;
       if (ctx->coeff_mode) {                                // (0: the table does not fit)
-        hipLaunchKernelGGL(k_coeff_ids, dim3(nblk(ctx->n_active)), dim3(256), 0, ctx->stream, order, (uint32_t)ctx->n_active, ctx->d_coeff_id);
-        KCHK("k_coeff_ids");
-        cell_pids_invalidate(ctx);
+        if (!ctx->coeff_ids_valid) {
+          hipLaunchKernelGGL(k_coeff_ids, dim3(nblk(ctx->n_active)), dim3(256), 0, ctx->stream, order, (uint32_t)ctx->n_active, ctx->d_coeff_id);
+          KCHK("k_coeff_ids");
+          cell_pids_invalidate(ctx);
+          ctx->coeff_ids_valid = true;
+        }
         store = true;
       }
     }

@@ -311,6 +311,16 @@ class OracleReconstruction:
                  "canon_outside", "canon_dmax", "canon_over_env_max", "canon_flips_explained", "canon_flips")
         return {k: float(v) for k, v in zip(names, out)}
 
+    def flip_pixels(self, pixels):
+        """orc_flip_pixels over pixels [(slice, py, px), ...] (np.argwhere order) -> flips, open decisions, flipped PSF mass per pixel (literal
+        against canonical walk; whatever this instance's own mode is)"""
+        pix = np.ascontiguousarray(np.asarray(pixels, np.int32).reshape(-1, 3)[:, [0, 2, 1]])
+        n = len(pix)
+        flips, open_, mass = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        if n:
+            lib().orc_flip_pixels(C.byref(self.g), n, _p(pix), _p(flips), _p(open_), _p(mass))
+        return flips, open_, mass
+
     def psf_values(self, sl, px, py):
         v = np.zeros(4096, np.float32)
         lib().orc_psf_values(C.byref(self.g), int(sl), int(px), int(py), _p(v))

@@ -735,6 +735,43 @@ void orc_fastmath_census(const orc_geom *g, int n, const int *pix3, double *out1
   out16[8] = out16[0] > 0 ? esum / out16[0] : 0;
 }
 
+/* Per pixel: where the two walks of the epsilon-skip part -- the LITERAL sequence (RC.cu:112-130 with libm) against the CANONICAL one the device
+ * implements.  flips[i] = taps processed by one walk and skipped by the other; open_[i] = decisions of the literal walk that the reference's own
+ * --use_fast_math error envelope leaves open (orc_fastmath_census); mass[i] = sum over the flipped taps of max(literal, canonical) PSF value --
+ * what a flip can move in or out of the pixel's sums (v_PSF_sums directly; a forward projection or a scatter by that times the volume's /
+ * the factor's magnitude).  The whole-workload LITERAL comparisons attribute every element beyond their tolerance to such a pixel
+ * (tests/test_bench_size_oracle.py, tests/test_full_workload_oracle.py).  Test infrastructure. */
+void orc_flip_pixels(const orc_geom *g, int n, const int *pix3, int *flips, int *open_, float *mass) {
+  const int S = psf_support(g), Cn = psf_centre(g);
+  const double eps = g->pvr ? (double)0.00001f : PSF_EPSILON;
+  for (int i = 0; i < n; ++i) {
+    const int sl = pix3[3 * i], px = pix3[3 * i + 1], py = pix3[3 * i + 2];
+    slice_psf sp; slice_setup(g, sl, &sp);
+    pixel_psf pp; pixel_setup(g, sl, &sp, px, py, &pp);
+    int nf = 0, no = 0;
+    double m = 0;
+    for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) {
+      float gz[16];
+      canon_gauss_row(&sp, canon_rowz(&sp, &pp, y - Cn, z - Cn), S, gz);
+      float oldL = FLT_MAX, oldC = FLT_MAX;
+      double eold = 0;
+      for (int xx = 0; xx < S; ++xx) {
+        float ofs[3];
+        const float vl = psf_literal(g, &sp, &pp, xx - Cn, y - Cn, z - Cn, ofs);
+        const float vc = psf_canon(g, &sp, &pp, xx - Cn, y - Cn, z - Cn, gz[xx], ofs);
+        const psf_env en = psf_literal_envelope(g, &sp, &pp, xx - Cn, y - Cn, z - Cn);
+        const double d = fabs((double)oldL - (double)vl);
+        const int keepL = !(d < eps), keepC = !(fabs((double)oldC - (double)vc) < eps);
+        if (oldL != FLT_MAX && fabs(d - eps) <= eold + en.e) ++no;
+        if (keepL != keepC) { ++nf; const float mx = vl > vc ? vl : vc; if (isfinite(mx)) m += (double)mx; }
+        if (keepL) { oldL = vl; eold = en.e; }
+        if (keepC) oldC = vc;
+      }
+    }
+    flips[i] = nf; open_[i] = no; mass[i] = (float)m;
+  }
+}
+
 /* ================================ regulariser ============================== */
 static const int DIRS[13][3] = { /* RC.cu:666-680 */
     {1, 0, -1}, {0, 1, -1}, {1, 1, -1}, {1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {1, 1, 0},
