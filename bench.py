@@ -750,6 +750,21 @@ def main():
                                  "rewritten by the next gather, which evaluates them anyway (coeff_lazy) -- irtkReconstruction::CoeffInit's _volcoeffs "
                                  "(irtkReconstructionGPU.cc:2305-2673) on the GPU path; results bit-identical to evaluating every tap in every pass" if table_used else
                                  "every tap evaluated in every pass (the reference GPU kernels' way)")
+        if world > 1:
+            # the first line from real hardware should explain itself: the step this N was PROJECTED to take from one-GPU per-rank kernel times
+            # (tools/shard_curve.py -> profiles/r06_shard_projection.json; slab update, 7 links x 76.8 GB/s x 0.5), next to the one just measured
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r06_shard_projection.json")))["curves"][prob.name][str(world)]
+                proj = {"source": "profiles/r06_shard_projection.json: per-rank kernel times measured rank after rank on ONE GPU + stated link rates; no collective was run",
+                        "default_mode_step_ms": (pj.get("table") or pj.get("on_the_fly"))["slab"]["step_ms"] if table_used else pj["on_the_fly"]["slab"]["step_ms"],
+                        "on_the_fly_step_ms": pj["on_the_fly"]["slab"]["step_ms"],
+                        "note": "the table's projection holds its steady passes only: the step of an outer iteration that rewrites the table is in the measurement, not in the projection"}
+                out["projection"] = proj
+                out["speedup_vs_projection"] = {"default_mode": proj["default_mode_step_ms"] / ms_step,
+                                                "on_the_fly": (proj["on_the_fly_step_ms"] / (alt["dt"] / steps * 1e3)) if (alt is not None and not alt["table"]) else None}
+            except Exception as ex:                                # noqa: BLE001 -- no projection for this workload / N: say so, keep the line
+                out["projection"] = {"error": f"no committed projection for {prob.name} at N = {world}: {ex!r}"}
+                out["speedup_vs_projection"] = None
         if alt is not None and not alt["table"]:
             out["on_the_fly"] = {"value": va / (alt["dt"] / steps) / 1e6, "unit": "MVoxels/s", "ms_per_step": alt["dt"] / steps * 1e3,
                                  "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in alt["timers"].items() if k in ("backproject", "forward", "regularize", "estep", "mstep", "scale")},

@@ -24,6 +24,9 @@ SRC_CELL = os.path.join(HERE, "csrc", "svr_cell.inc")     # the scatter without 
 SRC_SORT = os.path.join(HERE, "csrc", "svr_sort.hip")     # radix sort / prefix sum from hipCUB for its work lists (own translation unit)
 SRC_EM = os.path.join(HERE, "csrc", "svr_em.inc")         # the slice-level EM on the device, #included by svr_hip.hip
 SRC_REGUL = os.path.join(HERE, "csrc", "svr_regul.inc")     # the fused volume update (Prep + edge-preserving regulariser), #included by svr_hip.hip
+SRC_TILE = os.path.join(HERE, "csrc", "svr_tile.inc")     # the tile kernels of rounds 1-2 (fallbacks, the table's gather on coarse slices), #included by svr_hip.hip
+SRC_SMALL = os.path.join(HERE, "csrc", "svr_small.inc")   # list compaction, reductions, EM / volume / bias kernels, the NCC cost, #included by svr_hip.hip
+SRC_RCCL_ABI = os.path.join(HERE, "csrc", "svr_rccl_abi.h")   # the hand-written slice of rccl.h (checked by tests/rccl_abi_check.cpp)
 SRC_SHARD = os.path.join(HERE, "csrc", "svr_shard.h")     # unit ranges + the one exchange per step, shared by the two host objects       # SLICO superpixel patches of the PVR command line
 INC = os.path.join(os.path.dirname(HERE), "include", "svr_hip.h")
 INC_HOST = os.path.join(os.path.dirname(HERE), "include", "svr_host.h")
@@ -55,7 +58,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_PYR, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_SHARD, SRC_REGUL, SRC_EM, SRC_CELL, SRC_SORT, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
+    return any(os.path.getmtime(f) > t for f in (SRC, SRC_REG, SRC_PYR, SRC_HOST, SRC_IO, SRC_PVR_HOST, SRC_IRTK, SRC_RCCL, SRC_PREP, SRC_SLIC, SRC_SHARD, SRC_REGUL, SRC_EM, SRC_CELL, SRC_TILE, SRC_SMALL, SRC_RCCL_ABI, SRC_SORT, SRC_CLI, SRC_PVR_CLI, INC, INC_HOST,
                                                __file__)) or not (os.path.exists(CLI) and os.path.exists(PVR_CLI))
 
 

@@ -714,165 +714,6 @@ __device__ __forceinline__ uint32_t xcd_run_index(uint32_t b, uint32_t n) {
   return base + (q & 7u) * R + (q >> 3);
 }
 
-// Walks the linear index i = z * Pxy + y * Px + x of an LDS box in steps of the workgroup size without
-// a division per element (an emulated integer division costs ~40 VALU instructions; the box loops of the
-// tile kernels run 20-30 elements per thread).
-struct BoxWalk {
-  int x, y, z, r;                 // r = y * Px + x
-  int Px, Pxy, tx, ty, tz, tr, wx, wy;
-  __device__ __forceinline__ void init(int i0, int stride, int Px_, int Pxy_) {
-    Px = Px_; Pxy = Pxy_;
-    z = i0 / Pxy; r = i0 - z * Pxy; y = r / Px; x = r - y * Px;
-    tz = stride / Pxy; tr = stride - tz * Pxy; ty = tr / Px; tx = tr - ty * Px;
-    wy = Pxy / Px; wx = Pxy - wy * Px;
-  }
-  __device__ __forceinline__ void step() {
-    z += tz; r += tr; x += tx; y += ty;
-    if (x >= Px) { x -= Px; ++y; }
-    if (r >= Pxy) {
-      r -= Pxy; ++z; x -= wx; y -= wy;
-      if (x < 0) { x += Px; --y; }
-    }
-  }
-};
-
-__global__ __launch_bounds__(TILE_WAVES * 64) void back_tiled_kernel(PsfArgs a, TileArgs ta) {
-  constexpr bool GAUSS1_ACT = false;
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // addon[cap] | cmap[cap]
-  __shared__ int sh_lo[3], sh_hi[3];
-  __shared__ uint32_t sh_pix[64];
-  const int TILE_W = ta.tw, TILE_H = ta.th;
-  __shared__ int sh_npix;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const VolGeom &vg = a.vg;
-  const uint32_t t = ta.tiles[blockIdx.x];
-  const int per_slice = ta.tiles_x * ta.tiles_y;
-  const uint32_t sl = t / per_slice;
-  const int r = t - sl * per_slice;
-  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
-  const SliceConst &S = a.sc[sl];
-  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
-
-  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
-  __syncthreads();
-  if (wave == 0) {
-    // lane = pixel of the tile: activity, centre voxel, footprint bounds
-    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
-    bool act = false;
-    uint32_t idx = 0;
-    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
-      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = pixel_active(a.slices, GAUSS1_ACT ? (const float *)nullptr : a.psf_sums, a.flag, idx);
-    }
-    unsigned long long b = __ballot(act);
-    if (act) {
-      sh_pix[__popcll(b & ((1ull << lane) - 1ull))] = idx;
-      PixelState P = pixel_setup(S, vg, px, py);
-      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
-      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
-      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
-    }
-    if (lane == 0) sh_npix = __popcll(b);
-  }
-  __syncthreads();
-  const int npix = sh_npix;
-  // box of saturated coordinates that can receive a tap (see DESIGN.md "tile box")
-  const int lox = max(sh_lo[0] - PSF_CENTRE, 0), hix = min(max(sh_hi[0] + 8, 0), vg.vx - 1);
-  const int loy = max(sh_lo[1] - PSF_CENTRE, 0), hiy = min(max(sh_hi[1] + 8, 0), vg.vy - 1);
-  const int loz = max(sh_lo[2] - PSF_CENTRE, 0), hiz = min(max(sh_hi[2] + 8, 0), vg.vz - 1);
-  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
-  if (Dx <= 0 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
-  // LDS pitches chosen so the 64 (y,z) rows of one ds_add hit every bank exactly twice:
-  // odd x-pitch (16 y rows -> 16 distinct banks) and plane pitch = 16 mod 32 (z planes alternate halves)
-  const int Px = Dx | 1;
-  const int Pxy = ((Px * Dy + 15) & ~31) + 16;
-  const long long vox = (long long)Pxy * Dz;
-  const bool in_lds = vox <= (long long)ta.cap;
-  float *t_addon = tile, *t_cmap = tile + ta.cap;
-  if (in_lds) {
-    for (int i = threadIdx.x; i < (int)vox; i += TILE_WAVES * 64) { t_addon[i] = 0.0f; t_cmap[i] = 0.0f; }
-  }
-  __syncthreads();
-
-  const RowConst RC = load_row_const(S);
-  const float scale = a.scales[sl], slicew = a.slice_weights[sl];
-  for (int k = wave; k < npix; k += TILE_WAVES) {
-    const uint32_t idx = __builtin_amdgcn_readfirstlane(sh_pix[k]);
-    const uint32_t rem = idx - sl * n2;
-    const int py = (int)(rem / (uint32_t)a.sx);
-    const int px = (int)(rem - (uint32_t)py * (uint32_t)a.sx);
-    const PixelState P = pixel_setup(S, vg, px, py);
-    const float sume = a.psf_sums[idx];
-    const float w = a.weights[idx];
-    const float ss = a.simslices[idx];
-    float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * scale : a.slices[idx] * scale;   // RC.cu:439-442
-    float f1, f0;
-    if (ta.gauss) {                          // RC.cu:278-282: volw += psf/sume, recon += psf/sume * s
-      f1 = 1.0f / sume;
-      f0 = f1 * e;
-    } else {
-      e = (ss > 0.0f) ? (e - ss) : 0.0f;     // RC.cu:444-447
-      f1 = (w * slicew) / sume;
-      f0 = f1 * e;
-    }
-    for (int q = 0; q < 4; ++q) {
-      float out[16];
-      eval_row(RC, P, lane, q, out);
-      const uint32_t az = sat0(P.czi + 4 * q + (lane >> 4) - PSF_CENTRE);
-      const uint32_t ay = sat0(P.cyi + (lane & 15) - PSF_CENTRE);
-      const bool rowin = az < (uint32_t)vg.vz && ay < (uint32_t)vg.vy;
-      if (in_lds) {
-        const int rbase = ((int)ay - loy) * Px + ((int)az - loz) * Pxy - lox;
-#pragma unroll
-        for (int x = 0; x < 16; ++x) {
-          const uint32_t ax = sat0(P.cxi + x - PSF_CENTRE);
-          if (rowin && ax < (uint32_t)vg.vx && !(out[x] < 0.0f)) {
-            if (ta.dbg == 1) {
-              t_addon[rbase + (int)ax] += out[x] * f0;
-              t_cmap[rbase + (int)ax] += out[x] * f1;
-            } else if (ta.dbg == 2) {
-              if (out[x] * f0 == 123.456f) t_addon[0] = 1.0f;
-            } else {
-              atomicAdd(t_addon + rbase + (int)ax, out[x] * f0);
-              atomicAdd(t_cmap + rbase + (int)ax, out[x] * f1);
-            }
-          }
-        }
-      } else {
-        // footprint box larger than the LDS accumulator (strongly oblique tile): direct scatter
-#pragma unroll
-        for (int x = 0; x < 16; ++x) {
-          const uint32_t ax = sat0(P.cxi + x - PSF_CENTRE);
-          if (rowin && ax < (uint32_t)vg.vx && !(out[x] < 0.0f)) {
-            const uint32_t vi = ax + ay * (uint32_t)vg.vx + az * (uint32_t)(vg.vx * vg.vy);
-            if (a.mask[vi] != 0.0f) {
-              unsafeAtomicAdd(a.addon + vi, out[x] * f0);
-              unsafeAtomicAdd(a.cmap + vi, out[x] * f1);
-            }
-          }
-        }
-      }
-    }
-  }
-  if (!in_lds || ta.dbg == 3) return;
-  __syncthreads();
-  // flush: one pair of device-scope atomics per touched, in-mask voxel of the box
-  BoxWalk bw;
-  bw.init(threadIdx.x, TILE_WAVES * 64, Px, Pxy);
-  for (int i = threadIdx.x; i < (int)vox; i += TILE_WAVES * 64, bw.step()) {
-    const float c = t_cmap[i], ad = t_addon[i];
-    if (c != 0.0f || ad != 0.0f) {
-      const int z = bw.z, y = bw.y, x = bw.x;
-      const uint32_t vi = (uint32_t)(x + lox) + (uint32_t)(y + loy) * (uint32_t)vg.vx +
-                          (uint32_t)(z + loz) * (uint32_t)(vg.vx * vg.vy);
-      if (a.mask[vi] != 0.0f) {
-        unsafeAtomicAdd(a.addon + vi, ad);
-        unsafeAtomicAdd(a.cmap + vi, c);
-      }
-    }
-  }
-}
 
 struct PixelRec {      // per tile pixel, in LDS
   int cx, cy, cz;
@@ -880,27 +721,6 @@ struct PixelRec {      // per tile pixel, in LDS
   float f0, f1;
 };
 
-// ------------------------------------------------------------------------------------------
-// Slot-owned back-projection with dead-unit shortcut: the production scatter of round 2
-// ------------------------------------------------------------------------------------------
-// Ownership: a 16-lane slot owns one absolute plane of the tile's box, its lanes are the 16
-// rows of the (pixel, plane offset) unit it is working on, so the accumulation is a plain LDS read-add-write -- plus:
-//  * OWNED AXIS PER SLICE.  The planes are y- or z-planes of the volume, whichever axis is closer to the slice normal
-//    (SliceConst::own); the lanes run over the other one.  Rows are along x either way (the epsilon-skip chain runs
-//    along x in the reference, RC.cu:233-239), and every row is evaluated with its true (y, z) offsets, so the values
-//    do not depend on the choice.  Below, "z" / "y" name the owned / lane axis.
-//  * DEAD UNITS.  A row whose 16 taps are provably below the epsilon of the skip test has only its first tap processed
-//    by the reference (oldPSF starts at FLT_MAX).  With the planes across the slice normal, a unit more than ~4.8
-//    sigma_z away from the slice is dead as a whole (unit_is_dead: 5 of 16 for 2.5 mm slices on a 1 mm grid) and costs
-//    one tap per lane instead of 16, two units at a time in the two halves of the packed evaluator.
-//  * PER-PLANE PITCH.  A plane that only receives dead units needs the columns of the first taps only: x pitch
-//    (spread of the centre voxels + 1) instead of (spread + 16).
-//  * TWO PHASES, planes dealt round-robin: live planes to the slots, then dead planes to the slots, so every wavefront
-//    of the workgroup has the same share of both (with planes in z order the outer wavefronts only held dead planes and
-//    one SIMD of four idled) and a box with more planes than slots needs no other kernel.
-//  * {addon, cmap} interleaved as float2: one ds_read_b64 / ds_write_b64 and one v_pk_fma_f32 per tap.
-// Tiles whose box does not fit go to the fallback list (the caller re-runs them with the large-box instance, then with
-// back_tiled_kernel).
 #define SLOT_MAXP 48      // planes of a box the plane tables are sized for
 struct RowWalk {       // i = y * P + x walked in steps of `stride` without a division per element
   int x, y, tx, ty, P;
@@ -1021,617 +841,7 @@ __global__ __launch_bounds__(256) void k_coeff_build(PsfArgs a, float4 *coeff, u
   }
 }
 
-#ifndef SVR_WPE_SLOT
-#define SVR_WPE_SLOT 4
-#endif
-template <int WAVES, int NS = PSF_SUPPORT, bool PVR = false>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SVR_WPE_SLOT, SVR_WPE_SLOT))) void back_slot_kernel(PsfArgs a, TileArgs ta, uint32_t *fallback_tiles,
-                                                                uint32_t *fallback_count) {
-  constexpr int SLOTS = WAVES * 4;
-  constexpr int T = WAVES * 64;
-  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  f2 *box = reinterpret_cast<f2 *>(tile);               // {addon, cmap} per box voxel, [plane][y][x], pitch per plane
-  __shared__ int sh_lo[3], sh_hi[3];
-  __shared__ PixelRec sh_px[64];                        // cy = centre on the lane axis, cz = centre on the owned axis
-  __shared__ uint32_t sh_dead[64];                      // bit z: unit (pixel, z) is dead
-  __shared__ unsigned char sh_list[SLOT_MAXP][64];      // per plane: live units from the front, dead units from the back
-  __shared__ unsigned char sh_nl[SLOT_MAXP], sh_nd[SLOT_MAXP];
-  __shared__ unsigned char sh_order[SLOT_MAXP];         // planes with live units (ascending), then planes with dead units only
-  __shared__ int sh_off[SLOT_MAXP];
-  __shared__ int sh_npix, sh_nlive, sh_nused, sh_vox;
-  const int TILE_W = ta.tw, TILE_H = ta.th;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const VolGeom &vg = a.vg;
-  const uint32_t t = ta.tiles[blockIdx.x];
-  const int per_slice = ta.tiles_x * ta.tiles_y;
-  const uint32_t sl = t / per_slice;
-  const int r = t - sl * per_slice;
-  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
-  const SliceConst &S = a.sc[sl];
-  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
-  const bool swap = S.own == 1;                         // slots own y-planes, lanes run over z
-  const int F = swap ? 1 : 2;                           // the owned volume axis
-  const int vgy = swap ? vg.vz : vg.vy, vgz = swap ? vg.vy : vg.vz;
-  const uint32_t sty = swap ? (uint32_t)(vg.vx * vg.vy) : (uint32_t)vg.vx;   // volume strides of the lane / owned axis
-  const uint32_t stz = swap ? (uint32_t)vg.vx : (uint32_t)(vg.vx * vg.vy);
 
-  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
-  if (threadIdx.x < 64) sh_dead[threadIdx.x] = 0u;
-  __syncthreads();
-  if (wave == 0) {
-    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
-    bool act = false;
-    uint32_t idx = 0;
-    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
-      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = pixel_active(a.slices, a.psf_sums, a.flag, idx);
-    }
-    unsigned long long b = __ballot(act);
-    if (act) {
-      PixelState P = pixel_setup(S, vg, px, py);
-      const float sume = a.psf_sums[idx];
-      const float ss = a.simslices[idx];
-      float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * a.scales[sl] : a.slices[idx] * a.scales[sl];
-      float f1;
-      if (ta.gauss) {                                          // RC.cu:278-282
-        f1 = 1.0f / sume;
-      } else {
-        e = (ss > 0.0f) ? (e - ss) : 0.0f;                     // RC.cu:439-447
-        f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
-      }
-      PixelRec R;
-      R.cx = P.cxi; R.cy = swap ? P.czi : P.cyi; R.cz = swap ? P.cyi : P.czi;
-      R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
-      sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
-      atomicMin(&sh_lo[0], R.cx); atomicMax(&sh_hi[0], R.cx);
-      atomicMin(&sh_lo[1], R.cy); atomicMax(&sh_hi[1], R.cy);
-      atomicMin(&sh_lo[2], R.cz); atomicMax(&sh_hi[2], R.cz);
-    }
-    if (lane == 0) sh_npix = __popcll(b);
-  }
-  __syncthreads();
-  const int npix = sh_npix;
-  // unsaturated box coordinates: negative positions alias to 0 at flush time (RC.cu:508),
-  // positions beyond the high end are dropped (RC.cu:509)
-  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
-  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vgy - 1);
-  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vgz - 1);
-  const int Dy = hiy - loy + 1, Dz = hiz - loz + 1;
-  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
-  const int PL = (hix - lox + 1) | 1;                   // pitch of a plane that takes whole rows (odd: 16 y rows -> distinct banks)
-  const int PD = (sh_hi[0] - sh_lo[0] + 1) | 1;         // pitch of a plane that only takes first taps
-  const RowConst RC = load_row_const(S);
-  if (!PVR && ta.dbg != 4) {
-    for (int i = threadIdx.x; i < npix * NS; i += T) {  // which (pixel, z) units are dead
-      const int k = i / NS, z = i % NS;
-      const PixelRec R = sh_px[k];
-      if (unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(z - NC))) atomicOr(&sh_dead[k], 1u << z);
-    }
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < min(Dz, SLOT_MAXP)) {
-    // units landing on absolute plane loz + threadIdx.x, in pixel order
-    const int P = loz + (int)threadIdx.x;
-    int nl = 0, nd = 0;
-    for (int k = 0; k < npix; ++k) {
-      const int z = P - sh_px[k].cz + NC;
-      if (z >= 0 && z < NS) {
-        if ((sh_dead[k] >> z) & 1u) sh_list[threadIdx.x][63 - nd++] = (unsigned char)k;
-        else sh_list[threadIdx.x][nl++] = (unsigned char)k;
-      }
-    }
-    sh_nl[threadIdx.x] = (unsigned char)nl;
-    sh_nd[threadIdx.x] = (unsigned char)nd;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int off = 0, n = 0;
-    const int np = min(Dz, SLOT_MAXP);
-    for (int p = 0; p < np; ++p)
-      if (sh_nl[p]) { sh_order[n++] = (unsigned char)p; sh_off[p] = off; off += PL * Dy; }
-    sh_nlive = n;
-    for (int p = 0; p < np; ++p)
-      if (!sh_nl[p] && sh_nd[p]) { sh_order[n++] = (unsigned char)p; sh_off[p] = off; off += PD * Dy; }
-    sh_nused = n;
-    sh_vox = off;
-  }
-  __syncthreads();
-  const int vox = sh_vox, nlive = sh_nlive, nused = sh_nused;
-  if (Dz > SLOT_MAXP || vox > ta.cap) {
-    if (threadIdx.x == 0) fallback_tiles[atomicAdd(fallback_count, 1u)] = t;
-    return;
-  }
-  for (int i = threadIdx.x; i < vox; i += T) box[i] = (f2){0.0f, 0.0f};
-  __syncthreads();
-
-  const int slot = threadIdx.x >> 4;
-  const int y = lane & 15;
-  const float fyl = (float)(y - NC);                    // lane-axis offset of this lane's rows
-  // phase 1: planes with live units, dealt round-robin to the slots
-  for (int j = slot; j < nlive; j += SLOTS) {
-    const int p = sh_order[j];
-    const int P = loz + p;                              // <= hiz: plane in bounds
-    const int nl = sh_nl[p], nd = sh_nd[p];
-    f2 *pb = box + sh_off[p] - lox;
-    for (int i = 0; i < nl; ++i) {
-      const PixelRec R = sh_px[sh_list[p][i]];
-      const float fzu = (float)(P - R.cz);              // owned-axis offset of the unit
-      const int ay = R.cy + y - NC;                     // may be negative: aliases to 0 at flush
-      const bool rowok = y < NS && ay < vgy;
-      const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
-      // all NS x positions are inside the box by construction, so the read-add-write is unconditional (skipped taps add 0)
-#ifdef SVR_SLOT_PREFETCH
-      f2 acc[NS];
-      if (rowok) {
-#pragma unroll
-        for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
-      }
-#endif
-      float out[NS];
-      eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fzu : fyl, swap ? fyl : fzu, out);
-      if (rowok) {
-        const f2 ff = (f2){R.f0, R.f1};
-#ifndef SVR_SLOT_PREFETCH
-        f2 acc[NS];
-#pragma unroll
-        for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
-#endif
-#pragma unroll
-        for (int x = 0; x < NS; ++x) pb[rb + x] = fma2(bc2(out[x]), ff, acc[x]);
-      }
-    }
-    if (!PVR) {
-      // dead units sharing a live plane: the first tap of every row, two units per pass
-      for (int i = 0; i < nd; i += 2) {
-        const bool two = i + 1 < nd;
-        const PixelRec Ra = sh_px[sh_list[p][63 - i]];
-        const PixelRec Rb = sh_px[sh_list[p][two ? 63 - i - 1 : 63 - i]];
-        const float fua = (float)(P - Ra.cz), fub = (float)(P - Rb.cz);
-        const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
-        const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
-                             __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
-        const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
-                             __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
-        const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
-                             __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
-        f2 xs[1], ys[1], t0[1];
-        xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
-        ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
-        eval_pairs_xyz<1, false>(RC, xs, ys, t0);
-        const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);        // always processed: |FLT_MAX - v| is not <= eps
-        const int aya = Ra.cy + y - NC, ayb = Rb.cy + y - NC;
-        if (aya < vgy) {
-          f2 *q = pb + (aya - loy) * PL + Ra.cx - NC;
-          *q = fma2(bc2(v.x), (f2){Ra.f0, Ra.f1}, *q);
-        }
-        if (two && ayb < vgy) {
-          f2 *q = pb + (ayb - loy) * PL + Rb.cx - NC;
-          *q = fma2(bc2(v.y), (f2){Rb.f0, Rb.f1}, *q);
-        }
-      }
-    }
-  }
-  if (!PVR) {
-    // phase 2: planes with dead units only (narrow pitch), dealt round-robin to the slots
-    for (int j = nlive + slot; j < nused; j += SLOTS) {
-      const int p = sh_order[j];
-      const int P = loz + p;
-      const int nd = sh_nd[p];
-      f2 *pb = box + sh_off[p] - lox;
-      for (int i = 0; i < nd; i += 2) {
-        const bool two = i + 1 < nd;
-        const PixelRec Ra = sh_px[sh_list[p][63 - i]];
-        const PixelRec Rb = sh_px[sh_list[p][two ? 63 - i - 1 : 63 - i]];
-        const float fua = (float)(P - Ra.cz), fub = (float)(P - Rb.cz);
-        const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
-        const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
-                             __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
-        const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
-                             __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
-        const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
-                             __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
-        f2 xs[1], ys[1], t0[1];
-        xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
-        ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
-        eval_pairs_xyz<1, false>(RC, xs, ys, t0);
-        const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);
-        const int aya = Ra.cy + y - NC, ayb = Rb.cy + y - NC;
-        if (aya < vgy) {
-          f2 *q = pb + (aya - loy) * PD + Ra.cx - NC;
-          *q = fma2(bc2(v.x), (f2){Ra.f0, Ra.f1}, *q);
-        }
-        if (two && ayb < vgy) {
-          f2 *q = pb + (ayb - loy) * PD + Rb.cx - NC;
-          *q = fma2(bc2(v.y), (f2){Rb.f0, Rb.f1}, *q);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (ta.dbg == 3) return;                              // timing experiments: no flush
-  // flush: one pair of device-scope atomics per touched, in-mask voxel of the box; the float->uint saturation of the
-  // reference (negative -> 0, RC.cu:508) is applied here, which sums exactly the taps that alias
-  RowWalk wl, wd;
-  wl.init(threadIdx.x, T, PL);
-  wd.init(threadIdx.x, T, PD);
-  for (int j = 0; j < nused; ++j) {
-    const int p = sh_order[j];
-    const bool live = j < nlive;
-    RowWalk w;                                           // (field by field: selecting the struct goes through scratch)
-    w.x = live ? wl.x : wd.x; w.y = live ? wl.y : wd.y; w.tx = live ? wl.tx : wd.tx; w.ty = live ? wl.ty : wd.ty; w.P = live ? wl.P : wd.P;
-    const int n = w.P * Dy;
-    const f2 *pl = box + sh_off[p];
-    for (int i = threadIdx.x; i < n; i += T, w.step()) {
-      const f2 v = pl[i];
-      if (v.x != 0.0f || v.y != 0.0f) {
-        const int gx = w.x + lox;
-        if (gx < vg.vx) {                                // beyond the high end: out of bounds
-          const uint32_t vi = sat0(gx) + sat0(w.y + loy) * sty + sat0(p + loz) * stz;
-          if (a.mask[vi] != 0.0f) {
-            unsafeAtomicAdd(a.addon + vi, v.x);
-            unsafeAtomicAdd(a.cmap + vi, v.y);
-          }
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-owned back-projection: one wavefront = one workgroup = four planes of a tile's box
-// ------------------------------------------------------------------------------------------
-// The slots of back_slot_kernel never talk to each other: a slot owns a plane, a wavefront four of them.  So the
-// workgroup is cut down to ONE wavefront that owns four planes of the tile's box (positions 4 g .. 4 g + 3 of the plane
-// order: planes with live units first, then planes with dead units only), and the grid is tiles x groups.  What that
-// buys: no workgroup barrier, no wavefront waiting for the slowest of its workgroup, ~16 KiB of LDS per wavefront
-// instead of 50-75 KiB per workgroup (9 independent wavefronts per CU, placed on whichever SIMD is free), and the
-// cheap wavefronts (dead planes) leave early instead of holding a workgroup's LDS.  The price is the tile set-up
-// (pixel records, dead-unit test: ~4 % of a wavefront's work) repeated by every group.  `groups` is a launch
-// parameter: planes beyond 4 * groups are dealt round-robin to the same wavefronts.
-// pixels of a tile (larger tiles go to the workgroup kernels): 32 when the taps are evaluated, 64 -- one per lane -- when
-// they come from the coefficient table (the flush, not the evaluation, is what a table pass waits for: larger tiles)
-#ifndef SVR_WAVE_MAXPIX_EVAL
-#define SVR_WAVE_MAXPIX_EVAL 32
-#endif
-#define WAVE_MAXPIX (COEFF ? 64 : SVR_WAVE_MAXPIX_EVAL)
-template <int NS = PSF_SUPPORT, bool PVR = false, bool COEFF = false>
-#ifndef SVR_WPE_WAVE
-#define SVR_WPE_WAVE 3    // 170 VGPRs: the LDS box allows 8-10 wavefronts per CU anyway
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SVR_WPE_WAVE, SVR_WPE_WAVE)))
-void back_wave_kernel(PsfArgs a, TileArgs ta, int groups, uint32_t *fallback_tiles, uint32_t *fallback_count) {
-  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;   // taps span [centre - NC, centre + NH]
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  f2 *box = reinterpret_cast<f2 *>(tile);               // {addon, cmap} per box voxel of this wavefront's four planes
-  __shared__ PixelRec sh_px[WAVE_MAXPIX];               // cy = centre on the lane axis, cz = centre on the owned axis
-  __shared__ unsigned char sh_list[4][WAVE_MAXPIX];     // per slot: live units from the front, dead units from the back
-  __shared__ uint32_t sh_pid[COEFF ? WAVE_MAXPIX : 1];  // COEFF: the pixels' ids in the coefficient table
-  const int TILE_W = ta.tw, TILE_H = ta.th;
-  const int lane = threadIdx.x;
-  const VolGeom &vg = a.vg;
-  const uint32_t bt = blockIdx.x / (uint32_t)groups;
-  const int grp = (int)(blockIdx.x - bt * (uint32_t)groups);
-  const uint32_t t = ta.tiles[bt];                      // (the XCD-aware run order of the gather buys the scatter nothing: measured)
-  const int per_slice = ta.tiles_x * ta.tiles_y;
-  const uint32_t sl = t / per_slice;
-  const int r = t - sl * per_slice;
-  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
-  const SliceConst &S = a.sc[sl];
-  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
-  const bool swap = S.own == 1;                         // slots own y-planes, lanes run over z
-  const int F = swap ? 1 : 2;
-  const int vgy = swap ? vg.vz : vg.vy, vgz = swap ? vg.vy : vg.vz;
-  const uint32_t sty = swap ? (uint32_t)(vg.vx * vg.vy) : (uint32_t)vg.vx;
-  const uint32_t stz = swap ? (uint32_t)vg.vx : (uint32_t)(vg.vx * vg.vy);
-
-  // lane = pixel of the tile
-  int cx = 0, cy = 0, cz = 0;
-  bool act = false;
-  {
-    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
-    uint32_t idx = 0;
-    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
-      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = pixel_active(a.slices, a.psf_sums, a.flag, idx);
-    }
-    const unsigned long long b = __ballot(act);
-    if (act) {
-      PixelState P = pixel_setup(S, vg, px, py);
-      const float sume = a.psf_sums[idx];
-      const float ss = a.simslices[idx];
-      float e = a.bias ? a.slices[idx] * expf(-a.bias[idx]) * a.scales[sl] : a.slices[idx] * a.scales[sl];
-      float f1;
-      if (ta.gauss) {                                          // RC.cu:278-282
-        f1 = 1.0f / sume;
-      } else {
-        e = (ss > 0.0f) ? (e - ss) : 0.0f;                     // RC.cu:439-447
-        f1 = (a.weights[idx] * a.slice_weights[sl]) / sume;
-      }
-      PixelRec R;
-      cx = P.cxi; cy = swap ? P.czi : P.cyi; cz = swap ? P.cyi : P.czi;
-      R.cx = cx; R.cy = cy; R.cz = cz;
-      R.bx = P.bx; R.by = P.by; R.bz = P.bz; R.f1 = f1; R.f0 = f1 * e;
-      sh_px[__popcll(b & ((1ull << lane) - 1ull))] = R;
-      if (COEFF) sh_pid[__popcll(b & ((1ull << lane) - 1ull))] = a.coeff_id[idx];
-    }
-  }
-  const int npix = __popcll(__ballot(act));
-  if (npix == 0) return;
-  int lo[3], hi[3];
-  {
-    int mn[3] = {act ? cx : INT_MAX, act ? cy : INT_MAX, act ? cz : INT_MAX};
-    int mx[3] = {act ? cx : INT_MIN, act ? cy : INT_MIN, act ? cz : INT_MIN};
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        mn[k] = min(mn[k], __shfl_xor(mn[k], o, 64));
-        mx[k] = max(mx[k], __shfl_xor(mx[k], o, 64));
-      }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { lo[k] = __builtin_amdgcn_readfirstlane(mn[k]); hi[k] = __builtin_amdgcn_readfirstlane(mx[k]); }
-  }
-  __syncthreads();
-  // unsaturated box coordinates: negative positions alias to 0 at flush time (RC.cu:508), positions beyond the high
-  // end are dropped (RC.cu:509)
-  const int lox = lo[0] - NC, hix = hi[0] + NH;
-  const int loy = lo[1] - NC, hiy = min(hi[1] + NH, vgy - 1);
-  const int loz = lo[2] - NC, hiz = min(hi[2] + NH, vgz - 1);
-  const int Dy = hiy - loy + 1, Dz = hiz - loz + 1;
-  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // every tap of every pixel is out of bounds
-  const int PL = (hix - lox + 1) | 1;                   // x pitch (odd: 16 y rows -> distinct banks)
-  const int PP = PL * Dy;                               // voxels of one plane
-  if (Dz > 64 || 4 * PP > ta.cap || TILE_W * TILE_H > WAVE_MAXPIX) {                     // more planes than lanes / planes larger than this launch's box:
-    if (lane == 0 && grp == 0) fallback_tiles[atomicAdd(fallback_count, 1u)] = t;   // the workgroup kernels take the tile
-    return;
-  }
-  const RowConst RC = load_row_const(S);
-  // dead (pixel, z) units: lane k < npix ends up with the NS bits of its pixel
-  uint32_t deadbits = 0u;
-  if (!PVR && ta.dbg != 4) {
-    static_assert(PVR || NS == 16, "four pixels of 16 units per pass of the dead-unit test");
-    for (int m = 0; m * 4 < npix; ++m) {
-      const int k = m * 4 + (lane >> 4), z = lane & 15;
-      const PixelRec R = sh_px[min(k, npix - 1)];
-      const bool d = k < npix && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(z - NC));
-      const unsigned long long bd = __ballot(d);
-      if ((lane >> 2) == m) deadbits = (uint32_t)(bd >> (16 * (lane & 3))) & 0xFFFFu;
-    }
-  }
-  // planes: lane p < Dz counts the live and the dead units landing on absolute plane loz + p
-  int nl = 0, nd = 0;
-  for (int k = 0; k < npix; ++k) {
-    const int czk = sh_px[k].cz;
-    const uint32_t dk = (uint32_t)__shfl((int)deadbits, k, 64);
-    const int z = loz + lane - czk + NC;
-    if (lane < Dz && z >= 0 && z < NS) {
-      if ((dk >> z) & 1u) ++nd; else ++nl;
-    }
-  }
-  const unsigned long long mlive = __ballot(nl > 0), mdead = __ballot(nl == 0 && nd > 0);
-  const int nlive = __popcll(mlive), nused = nlive + __popcll(mdead);
-  if (grp * 4 >= nused) return;                         // nothing left for this group
-  // position of plane `lane` in the order [planes with live units, ascending | planes with dead units only, ascending]
-  const unsigned long long below = (1ull << lane) - 1ull;
-  const int pos = nl > 0 ? __popcll(mlive & below) : (nd > 0 ? nlive + __popcll(mdead & below) : -1);
-  const int mycz = lane < npix ? sh_px[lane].cz : 0;
-  const int slot = lane >> 4;
-  const int y = lane & 15;
-  const float fyl = (float)(y - NC);
-  for (int j0 = grp * 4; j0 < nused; j0 += groups * 4) {
-    // this pass: order positions j0 .. j0 + 3, one per slot
-    int pl[4];
-    int p = -1, mynl = 0, mynd = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const unsigned long long m = __ballot(pos == j0 + q);
-      pl[q] = m ? (int)__builtin_ctzll(m) : -1;
-      const int src = m ? pl[q] : 0;
-      const int a_nl = __shfl(nl, src, 64), a_nd = __shfl(nd, src, 64);
-      if (slot == q) { p = pl[q]; mynl = m ? a_nl : 0; mynd = m ? a_nd : 0; }
-      // unit lists of the plane: lane k < npix files its pixel
-      bool isl = false, isd = false;
-      if (m && lane < npix) {
-        const int z = loz + pl[q] - mycz + NC;
-        if (z >= 0 && z < NS) {
-          isd = (deadbits >> z) & 1u;
-          isl = !isd;
-        }
-      }
-      const unsigned long long bl = __ballot(isl), bdd = __ballot(isd);
-      if (isl) sh_list[q][__popcll(bl & below)] = (unsigned char)lane;
-      if (isd) sh_list[q][WAVE_MAXPIX - 1 - __popcll(bdd & below)] = (unsigned char)lane;
-    }
-    for (int i = lane; i < 4 * PP; i += 64) box[i] = ta.dbg == 5 ? (f2){1.0f, 1.0f} : (f2){0.0f, 0.0f};
-    __syncthreads();
-
-    if (p >= 0 && ta.dbg < 5) {                         // (timing experiments 5 / 6: flush of a full / an empty box only)
-      const int P = loz + p;                            // <= hiz: plane in bounds
-      f2 *pb = box + slot * PP - lox;
-      // One live unit: the row's accumulators are fetched before its taps are there (their LDS latency hides behind the
-      // evaluation; the registers are free: the box, not the register file, sets the occupancy).  A lane without a row
-      // reads the plane's first words and writes nothing.
-      auto add_unit = [&](const PixelRec &R, const float (&out)[NS], const f2 (&acc)[NS], bool rowok, int rb) {
-        if (rowok) {
-          // all NS x positions are inside the box by construction: unconditional read-add-write (skipped taps add 0)
-          const f2 ff = (f2){R.f0, R.f1};
-#pragma unroll
-          for (int x = 0; x < NS; ++x) pb[rb + x] = fma2(bc2(out[x]), ff, acc[x]);
-        }
-      };
-      if (COEFF) {
-        // the taps come from the coefficient table (what eval_row_t returns, written by k_coeff_build): a ring of three
-        // units per slot keeps 3 KiB per slot in flight -- the pass waits for HBM, not for the ALUs
-        float4 ring[3][NS / 4];
-        auto request = [&](int i, float4 (&dst)[NS / 4]) {
-          const int k1 = sh_list[slot][i];
-          const float4 *src = a.coeff + ((size_t)sh_pid[k1] * NS + (size_t)(P - sh_px[k1].cz + NC)) * (NS / 4 * 16) + (y < NS ? y : 0);
-#pragma unroll
-          for (int q = 0; q < NS / 4; ++q) dst[q] = load_stream(src + q * 16);
-        };
-#pragma unroll
-        for (int r3 = 0; r3 < 3; ++r3) if (r3 < mynl) request(r3, ring[r3]);
-        for (int i0 = 0; i0 < mynl; i0 += 3) {
-#pragma unroll
-          for (int r3 = 0; r3 < 3; ++r3) {
-            const int i = i0 + r3;
-            if (i < mynl) {
-              const PixelRec R = sh_px[sh_list[slot][i]];
-              const int ay = R.cy + y - NC;               // may be negative: aliases to 0 at flush
-              const bool rowok = y < NS && ay < vgy;
-              const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
-              f2 acc[NS];
-#pragma unroll
-              for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
-              float out[NS];
-#pragma unroll
-              for (int q = 0; q < NS / 4; ++q) { out[4 * q] = ring[r3][q].x; out[4 * q + 1] = ring[r3][q].y; out[4 * q + 2] = ring[r3][q].z; out[4 * q + 3] = ring[r3][q].w; }
-              if (i + 3 < mynl) request(i + 3, ring[r3]);
-              add_unit(R, out, acc, rowok, rb);
-            }
-          }
-        }
-      } else {
-        for (int i = 0; i < mynl; ++i) {
-          const PixelRec R = sh_px[sh_list[slot][i]];
-          const float fzu = (float)(P - R.cz);          // owned-axis offset of the unit
-          const int ay = R.cy + y - NC;                 // may be negative: aliases to 0 at flush
-          const bool rowok = y < NS && ay < vgy;
-          const int rb = rowok ? (ay - loy) * PL + R.cx - NC : lox;
-          f2 acc[NS];
-#pragma unroll
-          for (int x = 0; x < NS; ++x) acc[x] = pb[rb + x];
-          float out[NS];
-          eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fzu : fyl, swap ? fyl : fzu, out);
-          add_unit(R, out, acc, rowok, rb);
-        }
-      }
-      if (!PVR) {
-        // dead units: the first tap of every row, two units per pass in the two halves of the packed evaluator
-        for (int i = 0; i < mynd; i += 2) {
-          const bool two = i + 1 < mynd;
-          const PixelRec Ra = sh_px[sh_list[slot][WAVE_MAXPIX - 1 - i]];
-          const PixelRec Rb = sh_px[sh_list[slot][two ? WAVE_MAXPIX - 2 - i : WAVE_MAXPIX - 1 - i]];
-          const float fua = (float)(P - Ra.cz), fub = (float)(P - Rb.cz);
-          const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
-          const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
-                               __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
-          const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
-                               __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
-          const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
-                               __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
-          f2 xs[1], ys[1], t0[1];
-          xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
-          ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
-          eval_pairs_xyz<1, false>(RC, xs, ys, t0);
-          const f2 v = t0[0] * gauss_first_tap2<NC>(RC, rowz);      // always processed: |FLT_MAX - v| is not <= eps
-          const int aya = Ra.cy + y - NC, ayb = Rb.cy + y - NC;
-          if (aya < vgy) {
-            f2 *q = pb + (aya - loy) * PL + Ra.cx - NC;
-            *q = fma2(bc2(v.x), (f2){Ra.f0, Ra.f1}, *q);
-          }
-          if (two && ayb < vgy) {
-            f2 *q = pb + (ayb - loy) * PL + Rb.cx - NC;
-            *q = fma2(bc2(v.y), (f2){Rb.f0, Rb.f1}, *q);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (ta.dbg != 3 && ta.dbg != 7) {
-      // flush: one pair of device-scope atomics per touched, in-mask voxel; the float->uint saturation of the reference
-      // (negative -> 0, RC.cu:508) is applied here, which sums exactly the taps that alias
-      // the lane's elements i = lane + 64 u of a plane sit at the same in-plane voxel offset on all four planes: work
-      // the offsets out once (saturation of negative coordinates and the bound in x included; -1 = nothing to flush)
-      constexpr int FLUSH_U = COEFF ? 10 : 8;           // plane voxels per lane of the unrolled flush (table mode: 8 x 4 / 8 x 8 tiles, planes of up to 640)
-      RowWalk w0;
-      w0.init(lane, 64, PL);
-      if (PP <= 64 * FLUSH_U) {
-        int eoff[FLUSH_U];
-        {
-          RowWalk w = w0;
-#pragma unroll
-          for (int u = 0; u < FLUSH_U; ++u) {
-            const bool ok = lane + 64 * u < PP && w.x + lox < vg.vx;    // beyond the high end: out of bounds
-            eoff[u] = ok ? (int)(sat0(w.x + lox) + sat0(w.y + loy) * sty) : -1;
-            w.step();
-          }
-        }
-        if (COEFF) {
-          // table mode: the pass waits for memory, so the mask is only asked about voxels that have something to flush
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (pl[q] < 0) continue;
-            const f2 *pq = box + q * PP + lane;
-            const float *mz = a.mask + sat0(pl[q] + loz) * stz;
-            float *az_ = a.addon + sat0(pl[q] + loz) * stz, *cz_ = a.cmap + sat0(pl[q] + loz) * stz;
-            f2 v[FLUSH_U];
-            float mk[FLUSH_U];
-#pragma unroll
-            for (int u = 0; u < FLUSH_U; ++u) {                 // all mask words of the plane in flight together
-              v[u] = lane + 64 * u < PP ? pq[64 * u] : (f2){0.0f, 0.0f};
-              const bool ok = eoff[u] >= 0 && (v[u].x != 0.0f || v[u].y != 0.0f);
-              mk[u] = ok ? mz[eoff[u]] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < FLUSH_U; ++u) {
-              if (mk[u] != 0.0f) {
-                unsafeAtomicAdd(az_ + eoff[u], v[u].x);
-                unsafeAtomicAdd(cz_ + eoff[u], v[u].y);
-              }
-            }
-          }
-        } else {
-        // the mask words of all four planes first (unconditional, mostly L2 hits, all in flight together), then the box:
-          // two dependent phases per pass instead of three per plane
-          float mk[4][FLUSH_U];
-  #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float *mz = a.mask + sat0(max(pl[q], 0) + loz) * stz;
-  #pragma unroll
-            for (int u = 0; u < FLUSH_U; ++u) mk[q][u] = (pl[q] >= 0 && eoff[u] >= 0) ? mz[eoff[u]] : 0.0f;
-          }
-  #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (pl[q] < 0) continue;
-            const f2 *pq = box + q * PP + lane;
-            float *az_ = a.addon + sat0(pl[q] + loz) * stz, *cz_ = a.cmap + sat0(pl[q] + loz) * stz;
-            f2 v[FLUSH_U];
-  #pragma unroll
-            for (int u = 0; u < FLUSH_U; ++u) v[u] = lane + 64 * u < PP ? pq[64 * u] : (f2){0.0f, 0.0f};
-  #pragma unroll
-            for (int u = 0; u < FLUSH_U; ++u) {
-              if (mk[q][u] != 0.0f && (v[u].x != 0.0f || v[u].y != 0.0f)) {
-                unsafeAtomicAdd(az_ + eoff[u], v[u].x);
-                unsafeAtomicAdd(cz_ + eoff[u], v[u].y);
-              }
-            }
-          }
-        }
-      } else {
-        for (int q = 0; q < 4; ++q) {
-          if (pl[q] < 0) continue;
-          RowWalk w = w0;
-          const f2 *pq = box + q * PP;
-          const uint32_t zoff = sat0(pl[q] + loz) * stz;
-          for (int i = lane; i < PP; i += 64, w.step()) {
-            const f2 v = pq[i];
-            if ((v.x != 0.0f || v.y != 0.0f) && w.x + lox < vg.vx) {
-              const uint32_t vi = sat0(w.x + lox) + sat0(w.y + loy) * sty + zoff;
-              if (a.mask[vi] != 0.0f) {
-                unsafeAtomicAdd(a.addon + vi, v.x);
-                unsafeAtomicAdd(a.cmap + vi, v.y);
-              }
-            }
-          }
-        }
-      }
-    }
-    if (j0 + groups * 4 < nused) __syncthreads();        // another pass reuses the box and the lists
-  }
-}
 
 // getReconValueFromTexture (R2/reconVolume.cu:170-187): linear filter at the un-offset coordinate =
 // 0.125 * sum over {p-1,p}^3 with zero border
@@ -1650,23 +860,6 @@ __device__ __forceinline__ float pvr_tex(const float *vol, const VolGeom &vg, in
   return v;
 }
 
-// ------------------------------------------------------------------------------------------
-// Unit-based forward projection: the production gather of round 2 (simulateSlicesKernel3D_tex RC.cu:298-404)
-// ------------------------------------------------------------------------------------------
-// Work item = a (pixel, plane offset) UNIT of 16 rows, as in the scatter: a 16-lane slot evaluates one unit, a wavefront
-// four at a time, the eight wavefronts of the workgroup take the tile's units off one list -- live units first, then the
-// dead ones (unit_is_dead: every row provably below the epsilon of the skip test, only the first tap of each row is
-// processed).  The planes run across the slice normal (SliceConst::own) so that dead rows come as whole units.
-//   * The tile's box of the volume sits in LDS as float2 {V * m, m} (m = 1 inside the mask and the volume, else 0):
-//     a tap is one ds_read_b64 and one v_pk_fma_f32 into {sum psf V, sum psf} -- no sentinel test, no branch per tap;
-//     skipped taps add 0.  siminside (any processed tap on a mask voxel, RC.cu:391-394) is kept exactly with one
-//     compare per tap whose result stays in scalar registers.
-//   * Every unit leaves {sum psf V, sum psf, hit} in LDS; the pixel's 16 partial sums are added in a fixed order, so
-//     the result does not depend on the tile shape, on which wavefront took which unit, or on the run.
-//   * GAUSS1 turns the walk into pass 1 of gaussianReconstructionKernel3D_tex (RC.cu:228-258): the box holds
-//     {in bounds, in mask}, the sums become {sume (double, like the oracle), -}, plus the `sume > 0.5` gate, v_PSF_sums
-//     and the sliceVoxel_count flag.
-// Registers: no accumulator array, the row's 16 values and the packed evaluator: ~90 VGPRs, no scratch.
 // Sum over the 16 lanes of a slot, result in the slot's first lane: four DPP row shifts folded into the additions
 // (v_add_f32_dpp) instead of four dependent ds_bpermute round trips through the LDS crossbar.  Lanes shifted in from
 // beyond the row read 0 (bound_ctrl), so the tree is ((v0 + v8) + (v4 + v12)) + ... -- fixed, the same for every unit.
@@ -1689,321 +882,7 @@ __device__ __forceinline__ double row_sum16(double v) {
   v += row_shl_d<8>(v); v += row_shl_d<4>(v); v += row_shl_d<2>(v); v += row_shl_d<1>(v);
   return v;
 }
-#ifndef FWDU_WAVES
-#define FWDU_WAVES 8
-#endif
-#define FWDU_MAXPIX 32     // pixels of a tile (8 x 4 at most)
-// NS = PSF support (16 SVR, 12 PVR); PVR = patch-to-volume constants: the evaluator's sinc_pi branch, the volume read through the
-// 8-voxel texture average of getReconValueFromTexture (R2/reconVolume.cu:170-187), pass-1 gate `sume > 1e-5 or NaN` with the superpixel
-// test (R2/patchBasedPSFReconstruction_gpu.cu:95-110); no dead-unit shortcut (the bound is derived for the SVR constants).
-template <bool GAUSS1, int NS = PSF_SUPPORT, bool PVR = false, bool COEFF = false>
-__global__ __launch_bounds__(FWDU_WAVES * 64) void fwd_unit_kernel(PsfArgs a, TileArgs ta) {
-  constexpr int NC = (NS - 1) / 2, NH = NS - 1 - NC;
-  constexpr int US = 16;                                // stride of the per-pixel unit tables (k << 4 | u)
-  constexpr int T = FWDU_WAVES * 64;
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  f2 *box = reinterpret_cast<f2 *>(tile);               // {V m, m} (GAUSS1: {in bounds, in mask}) per box voxel [z][y][x]
-  __shared__ int sh_lo[3], sh_hi[3];
-  __shared__ PixelRec sh_px[FWDU_MAXPIX];
-  __shared__ uint32_t sh_idx[FWDU_MAXPIX];
-  __shared__ uint32_t sh_pid[COEFF ? FWDU_MAXPIX : 1];           // COEFF: the pixels' ids in the coefficient table
-  __shared__ uint32_t sh_dead[FWDU_MAXPIX];                      // bit u: unit (pixel, u) is dead
-  __shared__ unsigned short sh_units[FWDU_MAXPIX * US];          // (pixel << 4 | u): live units from the front, dead units from the back
-  __shared__ f2 sh_part[FWDU_MAXPIX * US];                       // per unit {sum psf V, sum psf}
-  __shared__ double sh_partd[GAUSS1 ? FWDU_MAXPIX * US : 1];     // GAUSS1: per unit sume in double
-  __shared__ uint32_t sh_hit[FWDU_MAXPIX];                       // bit u: unit (pixel, u) had a processed tap on a mask voxel
-  __shared__ int sh_npix, sh_nlive, sh_ndead;
-  const int TILE_W = ta.tw, TILE_H = ta.th;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const VolGeom &vg = a.vg;
-  const uint32_t t = ta.tiles[xcd_run_index(blockIdx.x, ta.ntiles)];
-  const int per_slice = ta.tiles_x * ta.tiles_y;
-  const uint32_t sl = t / per_slice;
-  const int r = t - sl * per_slice;
-  const int ty = r / ta.tiles_x, tx = r - ty * ta.tiles_x;
-  const SliceConst &S = a.sc[sl];
-  const uint32_t n2 = (uint32_t)(a.sx * a.sy);
-  const bool swap = S.own == 1;                         // units are y-planes, lanes run over z
-  const int F = swap ? 1 : 2;
-
-  if (threadIdx.x < 3) { sh_lo[threadIdx.x] = INT_MAX; sh_hi[threadIdx.x] = INT_MIN; }
-  if (threadIdx.x < FWDU_MAXPIX) { sh_dead[threadIdx.x] = 0u; sh_hit[threadIdx.x] = 0u; }
-  if (threadIdx.x == 0) { sh_nlive = 0; sh_ndead = 0; }
-  __syncthreads();
-  if (wave == 0) {
-    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
-    bool act = false;
-    uint32_t idx = 0;
-    if (lane < TILE_W * TILE_H && px < a.sx && py < a.sy) {
-      idx = (uint32_t)px + (uint32_t)py * a.sx + sl * n2;
-      act = pixel_active(a.slices, GAUSS1 ? (const float *)nullptr : a.psf_sums, a.flag, idx);
-    }
-    unsigned long long b = __ballot(act);
-    if (act) {
-      PixelState P = pixel_setup(S, vg, px, py);
-      PixelRec R;
-      R.cx = P.cxi; R.cy = P.cyi; R.cz = P.czi; R.bx = P.bx; R.by = P.by; R.bz = P.bz;
-      R.f1 = GAUSS1 ? 0.0f : 1.0f / a.psf_sums[idx]; R.f0 = 0.0f;
-      const int k = __popcll(b & ((1ull << lane) - 1ull));
-      sh_px[k] = R;
-      sh_idx[k] = idx;
-      if (COEFF) sh_pid[k] = a.coeff_id[idx];
-      atomicMin(&sh_lo[0], P.cxi); atomicMax(&sh_hi[0], P.cxi);
-      atomicMin(&sh_lo[1], P.cyi); atomicMax(&sh_hi[1], P.cyi);
-      atomicMin(&sh_lo[2], P.czi); atomicMax(&sh_hi[2], P.czi);
-    }
-    if (lane == 0) sh_npix = __popcll(b);
-  }
-  __syncthreads();
-  const int npix = sh_npix;
-  // the box in unsaturated coordinates (x, y, z of the volume); the float->uint saturation of the reference (negative ->
-  // 0, RC.cu:382) is applied when the box is filled
-  const int lox = sh_lo[0] - NC, hix = sh_hi[0] + NH;
-  const int loy = sh_lo[1] - NC, hiy = min(sh_hi[1] + NH, vg.vy - 1);
-  const int loz = sh_lo[2] - NC, hiz = min(sh_hi[2] + NH, vg.vz - 1);
-  const int Dx = hix - lox + 1, Dy = hiy - loy + 1, Dz = hiz - loz + 1;
-  if (lox > vg.vx - 1 || Dy <= 0 || Dz <= 0) return;   // nothing in bounds: no pixel gets a weight > 0
-  const int Px = Dx | 1;
-  const int Pxy = Px * Dy + ((Px * Dy) & 1 ? 0 : 1);    // odd pitches: the 16 rows of a unit spread over the banks either way
-  const bool in_lds = (long long)Pxy * Dz <= (long long)ta.cap;
-  const uint32_t sxy = (uint32_t)(vg.vx * vg.vy);
-  const RowConst RC = load_row_const(S);
-  if (in_lds) {
-    const int vox = Pxy * Dz;
-    BoxWalk bw;
-    bw.init(threadIdx.x, T, Px, Pxy);
-    for (int i = threadIdx.x; i < vox; i += T, bw.step()) {
-      const int gx = bw.x + lox;
-      f2 v = (f2){0.0f, 0.0f};
-      if (bw.y < Dy && bw.x < Dx && gx < vg.vx) {
-        const uint32_t vi = sat0(gx) + sat0(bw.y + loy) * (uint32_t)vg.vx + sat0(bw.z + loz) * sxy;
-        // (SVR: the volume word is fetched whether or not the voxel is in the mask -- two independent loads instead of a
-        // dependent pair; the PVR texture average is eight loads and stays behind the mask test)
-        if (!GAUSS1 && a.volm) {                            // one 8-byte load of the packed pair (PVR: of the texture average)
-          const float2 t = a.volm[vi];
-          v = (f2){t.x, t.y};
-        } else {
-          const float vraw = (GAUSS1 || PVR) ? 0.0f : a.vol[vi];
-          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-          v = GAUSS1 ? (f2){1.0f, m}
-                     : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(bw.y + loy), (int)sat0(bw.z + loz)) : vraw) : 0.0f, m};
-        }
-      }
-      box[i] = v;
-    }
-  }
-  // units: dead test, then the list (live from the front, dead from the back); units whose rows all lie beyond the
-  // volume's high end take no part.  The live list is in (pixel, unit) order -- ballot + per-wavefront offsets, not an
-  // atomic counter -- so that the four slots of a wavefront, and the wavefronts of a round, work on neighbouring units:
-  // with the coefficient table that makes a round's reads 32 consecutive KiB instead of 32 scattered ones.
-  {
-    static_assert(FWDU_MAXPIX * 16 <= T, "one unit per thread");
-    __shared__ int sh_wlive[FWDU_WAVES];
-    const int i = threadIdx.x;
-    const int k = i / NS, u = i % NS;
-    bool live = false;
-    if (i < npix * NS) {
-      const PixelRec R = sh_px[k];
-      const int cu = swap ? R.cy : R.cz;
-      const bool inb = cu + u - NC < (swap ? vg.vy : vg.vz);      // negatives alias to 0: "in bounds"
-      if (inb) {
-        const bool dead = !PVR && ta.dbg != 4 && unit_is_dead(RC, R.bx, R.by, R.bz, F, (float)(u - NC));
-        if (dead) {
-          atomicOr(&sh_dead[k], 1u << u);
-          sh_units[FWDU_MAXPIX * US - 1 - atomicAdd(&sh_ndead, 1)] = (unsigned short)(k << 4 | u);
-        } else {
-          live = true;
-        }
-      } else {
-        sh_part[k * US + u] = (f2){0.0f, 0.0f};
-        if (GAUSS1) sh_partd[k * US + u] = 0.0;
-      }
-    }
-    const unsigned long long bl = __ballot(live);
-    if (lane == 0) sh_wlive[wave] = __popcll(bl);
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < FWDU_WAVES; ++w) { const int c = sh_wlive[w]; base += w < wave ? c : 0; tot += c; }
-    if (live) sh_units[base + __popcll(bl & ((1ull << lane) - 1ull))] = (unsigned short)(k << 4 | u);
-    if (threadIdx.x == 0) sh_nlive = tot;
-  }
-  __syncthreads();
-  const int nlive = sh_nlive, ndead = sh_ndead;
-  const int slot = lane >> 4, y = lane & 15;
-  const float fyl = (float)(y - NC);
-  // ---- live units: all 16 taps of every row --------------------------------------------------------------
-  // siminside needs no bookkeeping in the gather proper: it is only written where the pixel's weight is > 0
-  // (RC.cu:398-403), and a positive weight is a processed tap on a mask voxel.  Pass 1 of the Gaussian reconstruction
-  // needs "any processed tap on a mask voxel" next to a sum that ignores the mask: one compare pair per tap, combined
-  // in scalar registers (bitwise, no branch).
-  auto live_unit = [&](const int j0) {
-    const int j = j0 + slot;
-    const bool valid = j < nlive;
-    const int ku = sh_units[valid ? j : j0];
-    const int k = ku >> 4, u = ku & 15;
-    const PixelRec R = sh_px[k];
-    const float fu = (float)(u - NC);
-    const int ay = R.cy + (swap ? u : y) - NC, az = R.cz + (swap ? y : u) - NC;
-    const bool rowok = valid && y < NS && ay < vg.vy && az < vg.vz;      // negatives alias to 0: always "in bounds"
-    float out[NS];
-    if (COEFF) {
-      // the unit's taps from the coefficient table (what eval_row_t returns, written by k_coeff_build).  Sixteen
-      // wavefronts per CU keep enough of these 1 KiB reads in flight; a three-round prefetch ring was measured and lost
-      // (3.55 against 3.43 ms)
-      const float4 *src = a.coeff + ((size_t)sh_pid[k] * NS + (size_t)u) * (NS / 4 * 16) + (y < NS ? y : 0);
-#pragma unroll
-      for (int q = 0; q < NS / 4; ++q) {
-        const float4 c = load_stream(src + q * 16);
-        out[4 * q] = c.x; out[4 * q + 1] = c.y; out[4 * q + 2] = c.z; out[4 * q + 3] = c.w;
-      }
-    } else {
-      eval_row_t<NS, PVR, true>(RC, R.bx, R.by, R.bz, swap ? fu : fyl, swap ? fyl : fu, out);
-    }
-    f2 acc = (f2){0.0f, 0.0f};
-    double accd = 0.0;
-    bool hit = false;
-    if (in_lds) {                                              // (wave-uniform)
-      const f2 *pb = box + (rowok ? (ay - loy) * Px + (az - loz) * Pxy + R.cx - NC - lox : 0);
-      f2 v[NS];
-#pragma unroll
-      for (int x = 0; x < NS; ++x) v[x] = pb[x];
-#pragma unroll
-      for (int x = 0; x < NS; ++x) {
-        if (GAUSS1) {
-          accd += (double)(out[x] * v[x].x);                   // RC.cu:241-245 (in bounds, no mask test)
-          hit = hit | ((v[x].y != 0.0f) & (__float_as_uint(out[x]) != 0x80000000u));   // processed, on a mask voxel
-        } else {
-          acc = fma2(bc2(out[x]), v[x], acc);
-        }
-      }
-    } else {
-      // the tile's box does not fit the LDS: every tap from global memory (strongly oblique tiles of fine volumes)
-      for (int x = 0; x < NS; ++x) {
-        const int gx = R.cx + x - NC;
-        f2 v = (f2){0.0f, 0.0f};
-        if (rowok && gx < vg.vx) {
-          const uint32_t vi = sat0(gx) + sat0(ay) * (uint32_t)vg.vx + sat0(az) * sxy;
-          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-          v = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? (PVR ? pvr_tex(a.vol, vg, (int)sat0(gx), (int)sat0(ay), (int)sat0(az)) : a.vol[vi]) : 0.0f, m};
-        }
-        if (GAUSS1) {
-          accd += (double)(out[x] * v.x);
-          hit = hit | ((v.y != 0.0f) & (__float_as_uint(out[x]) != 0x80000000u));
-        } else {
-          acc = fma2(bc2(out[x]), v, acc);
-        }
-      }
-    }
-    if (!rowok) { acc = (f2){0.0f, 0.0f}; accd = 0.0; hit = false; }
-    // reduce over the 16 lanes of the slot (the sum lands in its first lane, y == 0)
-    if (GAUSS1) accd = row_sum16(accd);
-    else { acc.x = row_sum16(acc.x); acc.y = row_sum16(acc.y); }
-    if (GAUSS1) {
-      const bool anyhit = ((uint32_t)(__ballot(hit) >> (16 * slot)) & 0xFFFFu) != 0u;
-      if (valid && y == 0) {
-        sh_partd[k * US + u] = accd;
-        if (anyhit) atomicOr(&sh_hit[k], 1u << u);
-      }
-    } else if (valid && y == 0) {
-      sh_part[k * US + u] = acc;
-    }
-  };
-  for (int j0 = wave * 4; j0 < nlive; j0 += FWDU_WAVES * 4) live_unit(j0);
-  // ---- dead units: the first tap of every row, two units per pass ------------------------------------------
-  for (int j0 = wave * 8; !PVR && j0 < ndead; j0 += FWDU_WAVES * 8) {
-    const int ja = j0 + 2 * slot, jb = ja + 1;
-    const bool va = ja < ndead, vb = jb < ndead;
-    const int kua = sh_units[FWDU_MAXPIX * US - 1 - (va ? ja : j0)], kub = sh_units[FWDU_MAXPIX * US - 1 - (vb ? jb : j0)];
-    const PixelRec Ra = sh_px[kua >> 4], Rb = sh_px[kub >> 4];
-    const float fua = (float)((kua & 15) - NC), fub = (float)((kub & 15) - NC);
-    const float fya = swap ? fua : fyl, fza = swap ? fyl : fua, fyb = swap ? fub : fyl, fzb = swap ? fyl : fub;
-    const f2 rowx = (f2){__builtin_fmaf(RC.Lp[1], fya, __builtin_fmaf(RC.Lp[2], fza, Ra.bx)),
-                         __builtin_fmaf(RC.Lp[1], fyb, __builtin_fmaf(RC.Lp[2], fzb, Rb.bx))};
-    const f2 rowy = (f2){__builtin_fmaf(RC.Lp[4], fya, __builtin_fmaf(RC.Lp[5], fza, Ra.by)),
-                         __builtin_fmaf(RC.Lp[4], fyb, __builtin_fmaf(RC.Lp[5], fzb, Rb.by))};
-    const f2 rowz = (f2){__builtin_fmaf(RC.Lp[7], fya, __builtin_fmaf(RC.Lp[8], fza, Ra.bz)),
-                         __builtin_fmaf(RC.Lp[7], fyb, __builtin_fmaf(RC.Lp[8], fzb, Rb.bz))};
-    f2 xs[1], ys[1], t0[1];
-    xs[0] = fma2(bc2(RC.Lp[0]), bc2((float)(-NC)), rowx);
-    ys[0] = fma2(bc2(RC.Lp[3]), bc2((float)(-NC)), rowy);
-    eval_pairs_xyz<1, false>(RC, xs, ys, t0);
-    const f2 v = t0[0] * gauss_first_tap2<PSF_CENTRE>(RC, rowz);   // always processed: |FLT_MAX - v| is not <= eps (SVR only)
-    f2 wa = (f2){0.0f, 0.0f}, wb = (f2){0.0f, 0.0f};
-    {
-      const int aya = Ra.cy + (int)fya, aza = Ra.cz + (int)fza, ayb = Rb.cy + (int)fyb, azb = Rb.cz + (int)fzb;
-      if (in_lds) {
-        if (va && aya < vg.vy && aza < vg.vz) wa = box[(aya - loy) * Px + (aza - loz) * Pxy + Ra.cx - NC - lox];
-        if (vb && ayb < vg.vy && azb < vg.vz) wb = box[(ayb - loy) * Px + (azb - loz) * Pxy + Rb.cx - NC - lox];
-      } else {
-        if (va && aya < vg.vy && aza < vg.vz && Ra.cx - NC < vg.vx) {
-          const uint32_t vi = sat0(Ra.cx - NC) + sat0(aya) * (uint32_t)vg.vx + sat0(aza) * sxy;
-          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-          wa = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
-        }
-        if (vb && ayb < vg.vy && azb < vg.vz && Rb.cx - NC < vg.vx) {
-          const uint32_t vi = sat0(Rb.cx - NC) + sat0(ayb) * (uint32_t)vg.vx + sat0(azb) * sxy;
-          const float m = a.mask[vi] != 0.0f ? 1.0f : 0.0f;
-          wb = GAUSS1 ? (f2){1.0f, m} : (f2){m != 0.0f ? a.vol[vi] : 0.0f, m};
-        }
-      }
-    }
-    f2 acca = bc2(v.x) * wa, accb = bc2(v.y) * wb;
-    double da = (double)acca.x, db = (double)accb.x;
-    const bool hita = wa.y != 0.0f, hitb = wb.y != 0.0f;        // the processed first tap lands on a mask voxel
-    if (GAUSS1) { da = row_sum16(da); db = row_sum16(db); }
-    else {
-      acca.x = row_sum16(acca.x); acca.y = row_sum16(acca.y);
-      accb.x = row_sum16(accb.x); accb.y = row_sum16(accb.y);
-    }
-    const bool anya = GAUSS1 && ((uint32_t)(__ballot(hita) >> (16 * slot)) & 0xFFFFu) != 0u;
-    const bool anyb = GAUSS1 && ((uint32_t)(__ballot(hitb) >> (16 * slot)) & 0xFFFFu) != 0u;
-    if (y == 0) {
-      if (va) {
-        if (GAUSS1) sh_partd[(kua >> 4) * US + (kua & 15)] = da; else sh_part[(kua >> 4) * US + (kua & 15)] = acca;
-        if (anya) atomicOr(&sh_hit[kua >> 4], 1u << (kua & 15));
-      }
-      if (vb) {
-        if (GAUSS1) sh_partd[(kub >> 4) * US + (kub & 15)] = db; else sh_part[(kub >> 4) * US + (kub & 15)] = accb;
-        if (anyb) atomicOr(&sh_hit[kub >> 4], 1u << (kub & 15));
-      }
-    }
-  }
-  __syncthreads();
-  // ---- the pixel's partial sums in unit order ------------------------------------------------------------------
-  if ((int)threadIdx.x < npix) {
-    const int k = threadIdx.x;
-    const uint32_t idx = sh_idx[k];
-    const bool inside = sh_hit[k] != 0u;
-    if (GAUSS1) {
-      double sd = 0.0;
-      for (int u = 0; u < NS; ++u) sd += sh_partd[k * US + u];
-      float sume = (float)sd;
-      bool pass = sume > 0.5f;                                // also drops NaN (RC.cu:251-258)
-      if (PVR) {
-        const uint32_t rem = idx % (uint32_t)(a.sx * a.sy);
-        const uint32_t ppx = rem % (uint32_t)a.sx, ppy = rem / (uint32_t)a.sx;
-        if (a.spx && a.spx[(size_t)sl * 4096 + ppx + 64 * ppy] != '1') sume = 0.0f;   // superpixel test of pass 1
-        pass = (sume > 0.00001f) || (sume != sume);
-      }
-      a.flag_out[idx] = pass ? 1 : 0;
-      if (pass) {
-        a.psf_sums[idx] = sume;
-        if (inside) a.voxcount[idx] = 1;                      // RC.cu:291-294
-      }
-    } else {
-      f2 sm = (f2){0.0f, 0.0f};
-      for (int u = 0; u < NS; ++u) sm = sm + sh_part[k * US + u];
-      const float w = sm.y * sh_px[k].f1;                     // sum psf / sume
-      if (w > 0.0f) {                                         // RC.cu:398-403
-        a.simslices[idx] = sm.x / sm.y;
-        a.simweights[idx] = w;
-        a.siminside[idx] = 1;                                 // w > 0: a processed tap landed on a mask voxel
-      }
-    }
-  }
-}
+#include "svr_tile.inc"    // the tile kernels of rounds 1-2: back_tiled_kernel, back_slot_kernel, back_wave_kernel (back_mode 1 / 3 / 4), fwd_unit_kernel (fwd_mode 1)
 
 // ------------------------------------------------------------------------------------------
 // Patch-to-volume (PVR) PSF kernels -- first correct version
@@ -2169,650 +1048,7 @@ __global__ __launch_bounds__(64) void k_probe_pixel(PsfArgs a, uint32_t idx, flo
   if (lane == 0) { centre[0] = P.cxi; centre[1] = P.cyi; centre[2] = P.czi; }
 }
 
-// ------------------------------------------------------------------------------------------
-// list compaction
-// ------------------------------------------------------------------------------------------
-// keep pixel i if slices[i] != -1 (and psf_sums[i] != 0 when psf_sums given)
-// (one atomic on the counter per workgroup of 1024 and chunk, not per wavefront: 524 k wavefronts queueing on one address took
-// 3.4 ms on S8's 33.5 M slice pixels, 0.34 ms on P4)
-__global__ __launch_bounds__(1024) void k_compact(const float *slices, const float *psf_sums, uint32_t n, uint32_t *list,
-                                                  uint32_t *counter) {
-  __shared__ uint32_t sh_cnt[16], sh_base;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint64_t c0 = (uint64_t)blockIdx.x * 1024u; c0 < n; c0 += (uint64_t)gridDim.x * 1024u) {
-    const uint64_t i = c0 + threadIdx.x;
-    bool keep = false;
-    if (i < n) {
-      keep = slices[i] != -1.0f;
-      if (keep && psf_sums) keep = psf_sums[i] != 0.0f;
-    }
-    const unsigned long long b = __ballot(keep);
-    if (lane == 0) sh_cnt[wave] = (uint32_t)__popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t tot = 0;
-      for (int w = 0; w < 16; ++w) { const uint32_t t = sh_cnt[w]; sh_cnt[w] = tot; tot += t; }
-      sh_base = tot ? atomicAdd(counter, tot) : 0u;
-    }
-    __syncthreads();
-    if (keep) list[sh_base + sh_cnt[wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)i;
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// block reduction helpers (256 threads)
-// ------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void block_reduce_store(double v[K], const int op[K], double *out) {
-  __shared__ double sm[4][K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    double x = v[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      double y = __shfl_xor(x, o, 64);
-      x = op[k] == 0 ? x + y : (op[k] == 1 ? fmin(x, y) : fmax(x, y));
-    }
-    v[k] = x;
-  }
-  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0)
-    for (int k = 0; k < K; ++k) sm[w][k] = v[k];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 0; k < K; ++k) {
-      double x = sm[0][k];
-      for (int i = 1; i < 4; ++i) {
-        double y = sm[i][k];
-        x = op[k] == 0 ? x + y : (op[k] == 1 ? fmin(x, y) : fmax(x, y));
-      }
-      out[k] = x;
-    }
-  }
-}
-
-// sums partial[(sl*chunks + c)*K + k] over c (per slice) -> per_slice[sl*K + k]
-__global__ void k_reduce_chunks(const double *partial, int ns, int chunks, int K, int opmask_min,
-                                int opmask_max, double *per_slice) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns * K) return;
-  int sl = i / K, k = i - sl * K;
-  bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
-  double x = partial[((size_t)sl * chunks) * K + k];
-  for (int c = 1; c < chunks; ++c) {
-    double y = partial[((size_t)sl * chunks + c) * K + k];
-    x = mn ? fmin(x, y) : (mx ? fmax(x, y) : x + y);
-  }
-  per_slice[i] = x;
-}
-constexpr int REDUCE_MAXK = 8;   // quantities reduce_partials takes side by side: k_reduce_slices' LDS rows, and what d_partial / d_per_slice are allocated for
-// reduces per_slice[sl*K + k] over slices -> out[k]   (single block, 256 threads; K <= 8).  The K quantities go through the tree side by side --
-// per quantity the order of one block reduction after the other (the same bits), one set of barriers for all: the kernel is nothing but latency
-__global__ void k_reduce_slices(const double *per_slice, int ns, int K, int opmask_min,
-                                int opmask_max, double *out) {
-  __shared__ double sm[REDUCE_MAXK][256];
-  const int t = threadIdx.x;
-  for (int k = 0; k < K; ++k) {
-    bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
-    double x = mn ? INFINITY : (mx ? -INFINITY : 0.0);
-    for (int s = t; s < ns; s += 256) {
-      double y = per_slice[(size_t)s * K + k];
-      x = mn ? fmin(x, y) : (mx ? fmax(x, y) : x + y);
-    }
-    sm[k][t] = x;
-  }
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) {
-      for (int k = 0; k < K; ++k) {
-        bool mn = (opmask_min >> k) & 1, mx = (opmask_max >> k) & 1;
-        double y = sm[k][t + o];
-        double z = sm[k][t];
-        sm[k][t] = mn ? fmin(z, y) : (mx ? fmax(z, y) : z + y);
-      }
-    }
-    __syncthreads();
-  }
-  if (t < K) out[t] = sm[t][0];
-}
-
-// ------------------------------------------------------------------------------------------
-// EM kernels over the slice grid: grid = (chunks, ns), 256 threads, CHUNK_PIX pixels per block
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float G_(float x, float s) {   // RC.cu:62-65
-  return SVR_STEP * expf(-x * x / (2.0f * s)) / (sqrtf(6.28f * s));
-}
-
-// InitializeEMValuesKernel RC.cu:3241-3267
-// pvr: InitializeEMValuesKernel of R2/patchBasedRobustStatistics_gpu.cu:55-76 also zeroes s == 0
-__global__ void k_init_em(const float *slices, float *weights, size_t n, int pvr) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const float s = slices[i];
-    weights[i] = (s != -1.0f && !(pvr && s == 0.0f)) ? 1.0f : 0.0f;
-  }
-}
-
-// EStepKernel3D_tex RC.cu:2766-2813 fused with the slice-potential transform RC.cu:2816-2841
-__global__ __launch_bounds__(256) void k_estep(const float *slices, const float *simslices,
-                                               const float *simweights, const float *scales,
-                                               const float *bias, float m_, float sigma_, float mix_, int n2,
-                                               float *weights, double *partial, int pvr, const float *em) {
-  if (em) { sigma_ = em[0]; mix_ = em[1]; m_ = em[2]; }   // svr_mstep_estep: the M-step's scalars never left the device
-  const int sl = blockIdx.y;
-  const float scale = scales[sl];
-  if (pvr) {
-    // EStepKernel of R2/patchBasedRobustStatistics_gpu.cu:106-150: gated on the pixel's current WEIGHT
-    // (not the simulated weight), weights are not cleared first, __step = 1e-5f (reconConfig.cuh:120),
-    // the mixture in double through the `1.0 - _mix` literal
-    const float step = 0.00001f;
-    const float m = m_ * step;
-    double v[2] = {0.0, 0.0};
-    const size_t base = (size_t)sl * n2;
-    for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX); i += 256) {
-      const float s = slices[base + i];
-      float w = weights[base + i];
-      if (!(s == -1.0f || w <= 0.0f)) {
-        float patchVal = s * scale;
-        patchVal -= simslices[base + i];
-        const float g = step * expf(-patchVal * patchVal / (2.0f * sigma_)) / (sqrtf(6.28f * sigma_));
-        w = (float)((double)(g * mix_) / ((double)(g * mix_) + (double)m * (1.0 - (double)mix_)));
-        weights[base + i] = w;
-      }
-      if ((double)simweights[base + i] > 0.99) {        // transformPatchPotential :152-168
-        const double t = 1.0 - (double)w;
-        v[0] += (double)(float)(t * t);
-        v[1] += 1.0;
-      }
-    }
-    const int op[2] = {0, 0};
-    block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
-    return;
-  }
-  const float m = m_ * SVR_STEP;   // M_ RC.cu:67-70
-  double v[2] = {0.0, 0.0};
-  const size_t base = (size_t)sl * n2;
-  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
-       i += 256) {
-    float s = slices[base + i], sw = simweights[base + i];
-    float w = 0.0f;                                    // weights are cleared first RC.cu:2881
-    if (!(s == -1.0f || sw <= 0.0f)) {
-      float sliceVal = bias ? s * expf(-bias[base + i]) * scale : s * scale;   // RC.cu:2792-2795
-      sliceVal -= simslices[base + i];
-      float g = G_(sliceVal, sigma_);
-      w = (g * mix_) / (g * mix_ + m * (1.0f - mix_));
-    }
-    weights[base + i] = w;
-    if ((double)sw > 0.99) {                           // transformSlicePotential RC.cu:2822
-      double t = 1.0 - (double)w;
-      v[0] += (double)(float)(t * t);
-      v[1] += 1.0;
-    }
-  }
-  const int op[2] = {0, 0};
-  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
-}
-// RC.cu:2903-2910
-// (+ the sum over the slice's chunks, in chunk order like k_reduce_chunks: one launch instead of two -- these kernels last 4 us each and a
-// rank of a sharded run has little else to hide them behind)
-__global__ void k_potential_finish(const double *partial, int ns, int chunks, float *potential) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ns) return;
-  const double *p = partial + (size_t)s * chunks * 2;
-  double a = p[0], b = p[1];
-  for (int c = 1; c < chunks; ++c) { a += p[2 * c]; b += p[2 * c + 1]; }
-  potential[s] = (b > 0) ? sqrtf((float)a / (float)b) : -1.0f;
-}
-
-// transformMStep3DNoBias RC.cu:2966-3000; reduce identity (0,0,0,0,0) RC.cu:3103
-__global__ __launch_bounds__(256) void k_mstep(const float *slices, const float *weights,
-                                               const float *simslices, const float *simweights,
-                                               const float *scales, const float *bias, int n2,
-                                               double *partial) {
-  const int sl = blockIdx.y;
-  const float scale = scales[sl];
-  double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const size_t base = (size_t)sl * n2;
-  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
-       i += 256) {
-    float s = slices[base + i];
-    // transformMStep3D tests sw against the double 0.99, the NoBias twin against 0.99f (RC.cu:2947,2985)
-    const float sw = simweights[base + i];
-    if (s != -1.0f && (bias ? (double)sw > 0.99 : sw > 0.99f)) {
-      float w = weights[base + i];
-      float e = bias ? (s * expf(-bias[base + i]) * scale) - simslices[base + i] : (s * scale) - simslices[base + i];
-      v[0] += (double)(e * e * w);
-      v[1] += (double)w;
-      v[2] += 1.0;
-      v[3] = fmin(v[3], (double)e);
-      v[4] = fmax(v[4], (double)e);
-    }
-  }
-  const int op[5] = {0, 0, 0, 1, 2};
-  block_reduce_store<5>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 5);
-}
-
-// transformScalenoBias RC.cu:3142-3165
-__global__ __launch_bounds__(256) void k_scale(const float *slices, const float *weights,
-                                               const float *simslices, const float *simweights,
-                                               const float *bias, int n2, double *partial) {
-  const int sl = blockIdx.y;
-  double v[2] = {0.0, 0.0};
-  const size_t base = (size_t)sl * n2;
-  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
-       i += 256) {
-    float s = slices[base + i];
-    if (!(s == -1.0f || simweights[base + i] <= 0.99f)) {
-      float w = weights[base + i], ss = simslices[base + i];
-      if (bias) {                                        // transformScale RC.cu:3133-3136
-        float eb = expf(-bias[base + i]);
-        v[0] += (double)(w * s * eb * ss);
-        v[1] += (double)(w * s * eb * s * eb);
-      } else {
-        v[0] += (double)(w * s * ss);
-        v[1] += (double)(w * s * s);
-      }
-    }
-  }
-  const int op[2] = {0, 0};
-  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
-}
-// RC.cu:3229-3236
-// (+ the two moves of the reference's one-call lag, svr_calculate_scale_vector: the device's scales take the PREVIOUS host copy, the host
-// copy takes the new vector -- two device-to-device copies of ns floats until round 5, 5 us each on a stream that has nothing else to do)
-// (+ the sum over the slice's chunks, in chunk order like k_reduce_chunks)
-__global__ void k_scale_finish(const double *partial, int ns, int chunks, float *scale_vec, float *scales, float *scales_host_copy) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ns) return;
-  const double *p = partial + (size_t)s * chunks * 2;
-  double a = p[0], b = p[1];
-  for (int c = 1; c < chunks; ++c) { a += p[2 * c]; b += p[2 * c + 1]; }
-  float num = (float)a, den = (float)b;
-  const float v = (den != 0.0f) ? num / den : 1.0f;
-  scale_vec[s] = v;
-  scales[s] = scales_host_copy[s];
-  scales_host_copy[s] = v;
-}
-
-// transformRS RC.cu:2243-2265
-__global__ __launch_bounds__(256) void k_robust(const float *slices, const unsigned char *siminside,
-                                                const float *simslices, const float *simweights, int n2,
-                                                double *partial) {
-  const int sl = blockIdx.y;
-  double v[2] = {0.0, 0.0};
-  const size_t base = (size_t)sl * n2;
-  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
-       i += 256) {
-    float s = slices[base + i];
-    if (s != -1.0f && siminside[base + i] == 1 && (double)simweights[base + i] > 0.99) {
-      float sval = s - simslices[base + i];
-      v[0] += (double)(sval * sval);
-      v[1] += 1.0;
-    }
-  }
-  const int op[2] = {0, 0};
-  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
-}
-
-// ScaleVolumeKernel RC.cu:3386-3413
-__global__ __launch_bounds__(256) void k_scalevol(const float *slices, const float *weights,
-                                                  const float *simslices, const float *simweights,
-                                                  const float *slice_weights, int n2, double *partial) {
-  const int sl = blockIdx.y;
-  const float slicew = slice_weights[sl];
-  double v[2] = {0.0, 0.0};
-  const size_t base = (size_t)sl * n2;
-  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX);
-       i += 256) {
-    float s = slices[base + i];
-    if (s == -1.0f) continue;
-    if ((double)simweights[base + i] <= 0.99) continue;
-    float ss = simslices[base + i], w = weights[base + i];
-    v[0] += (double)(w * slicew * s * ss);
-    v[1] += (double)(w * slicew * ss * ss);
-  }
-  const int op[2] = {0, 0};
-  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
-}
-
-// per-slice any(siminside == 1)  (thrust::count per slice, RC.cu:2742-2752)
-__global__ __launch_bounds__(256) void k_slice_inside(const unsigned char *siminside, int n2,
-                                                      unsigned char *slice_inside) {
-  const int sl = blockIdx.x;
-  int any = 0;
-  for (int i = threadIdx.x; i < n2; i += 256) any |= (siminside[(size_t)sl * n2 + i] == 1);
-  any = __syncthreads_or(any);
-  if (threadIdx.x == 0) slice_inside[sl] = any ? 1 : 0;
-}
-// count_if(sliceVoxel_count > 0) RC.cu:2472-2474
-__global__ void k_count_positive(const int *v, size_t n, unsigned long long *out) {
-  // grid-stride: a thread counts its own, a wavefront adds up and touches the counter once (an atomic per 64 elements: 3.5 ms on S8)
-  unsigned int cnt = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) cnt += v[i] > 0 ? 1u : 0u;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);
-}
-// RestoreSliceIntensitiesKernel RC.cu:3349-3367
-__global__ void k_restore(float *slices, const float *stack_factors, const int *stack_index, int n2,
-                          size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float factor = stack_factors[stack_index[i / n2]];
-  float s = slices[i];
-  if (s > 0) slices[i] = s / factor;
-}
-
-// ------------------------------------------------------------------------------------------
-// volume kernels
-// ------------------------------------------------------------------------------------------
-// equalizeVol RC.cu:2312-2327
-__global__ void k_equalize(float *recon, const float *volw, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float b = volw[i];
-  float a = recon[i];
-  recon[i] = (b != 0) ? a / b : a;
-}
-// AdaptiveRegularizationPrep RC.cu:1944-1969: recon is left untouched (it is the regulariser's
-// `original`, RC.cu:2138-2141); the updated volume goes to snap.
-__global__ void k_reg_prep(int adaptive, float alpha, const float *recon, float *addon, float *cmap,
-                           float min_i, float max_i, float *snap, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float ad = addon[i];
-  if (!adaptive) {
-    float c = cmap[i];
-    if (c != 0) {
-      ad = ad / c;
-      addon[i] = ad;
-      cmap[i] = 1.0f;
-    }
-  }
-  float r = recon[i] + ad * alpha;
-  if ((double)r < (double)min_i * 0.9) r = (float)((double)min_i * 0.9);
-  if ((double)r > (double)max_i * 1.1) r = (float)((double)max_i * 1.1);
-  snap[i] = r;
-}
-
-__constant__ int c_dirs[13][3] = {{1, 0, -1}, {0, 1, -1}, {1, 1, -1}, {1, -1, -1}, {1, 0, 0},
-                                  {0, 1, 0},  {1, 1, 0},  {1, -1, 0}, {1, 0, 1},   {0, 1, 1},
-                                  {1, 1, 1},  {1, -1, 1}, {0, 0, 1}};   // RC.cu:666-680
-
-__device__ __forceinline__ float reg_b(float f, float sqf, float o_p, float o_p2, float c_p, float c_p2,
-                                       float delta) {
-  // AdaptiveRegularization1 RC.cu:2046-2057
-  if (c_p <= 0 || c_p2 <= 0) return 0.0f;
-  float diff = (o_p2 - o_p) * sqf / delta;
-  return (float)((double)f / sqrt(1.0 + (double)(diff * diff)));
-}
-// AdaptiveRegularizationKernel RC.cu:2061-2117; neighbours read `snap` (post-Prep snapshot)
-__global__ __launch_bounds__(256) void k_regularize(int vx, int vy, int vz, float delta, float alpha,
-                                                    float lambda, const float *snap,
-                                                    const float *original, const float *cmap,
-                                                    float *out) {
-  int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  int z = blockIdx.z;
-  if (x >= vx || y >= vy) return;
-  size_t p = (size_t)x + (size_t)y * vx + (size_t)z * vx * vy;
-  float val = 0, valW = 0, sum = 0;
-  float o_p = original[p], c_p = cmap[p], r_p = snap[p];
-#pragma unroll
-  for (int i = 0; i < 13; ++i) {
-    const int dx = c_dirs[i][0], dy = c_dirs[i][1], dz = c_dirs[i][2];
-    const float f = 1.0f / (float)(abs(dx) + abs(dy) + abs(dz));   // RC.cu:682-692
-    const float sqf = sqrtf(f);
-    int x2 = x + dx, y2 = y + dy, z2 = z + dz;
-    bool in2 = x2 >= 0 && x2 < vx && y2 >= 0 && y2 < vy && z2 >= 0 && z2 < vz;
-    float o2 = 0, c2 = 0;
-    if (in2) {
-      size_t p2 = (size_t)x2 + (size_t)y2 * vx + (size_t)z2 * vx * vy;
-      o2 = original[p2];
-      c2 = cmap[p2];
-      float bi = reg_b(f, sqf, o_p, o2, c_p, c2, delta);
-      val += bi * snap[p2] * c2;
-      valW += bi * c2;
-      sum += bi;
-    }
-    int x3 = x - dx, y3 = y - dy, z3 = z - dz;
-    bool in3 = x3 >= 0 && x3 < vx && y3 >= 0 && y3 < vy && z3 >= 0 && z3 < vz;
-    if (in3 && in2) {
-      size_t p3 = (size_t)x3 + (size_t)y3 * vx + (size_t)z3 * vx * vy;
-      float o3 = original[p3], c3 = cmap[p3];
-      float bi = reg_b(f, sqf, o3, o2, c3, c2, delta);   // (pos3, pos2): RC.cu:2095
-      val += bi * snap[p3] * c3;
-      valW += bi * c3;
-      sum += bi;
-    }
-  }
-  val -= sum * r_p * c_p;
-  valW -= sum * c_p;
-  float k = alpha * lambda / (delta * delta);
-  val = r_p * c_p + k * val;
-  valW = c_p + k * valW;
-  out[p] = (valW > 0.0f) ? val / valW : 0.0f;
-}
-#include "svr_regul.inc"
-// maskVolumeKernel RC.cu:3313-3326
-// {V m, m} per voxel (m = 1 inside the mask, else 0): what the gather's LDS boxes hold, packed once per pass so that a
-// box voxel is one 8-byte load instead of two loads and a select
-__global__ void k_pack_volm(const float *vol, const float *mask, float2 *out, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float m = mask[i] != 0.0f ? 1.0f : 0.0f;
-  out[i] = make_float2(m != 0.0f ? vol[i] : 0.0f, m);
-}
-
-// the patch-based gather reads the volume through getReconValueFromTexture's 8-voxel average (pvr_tex, reconVolume.cu:170-187):
-// taken once per voxel and pass here instead of once per box voxel of every tile (eight loads each); same operations, same bits
-__global__ void k_pack_volm_pvr(const float *vol, const float *mask, float2 *out, VolGeom vg) {
-  const size_t n = (size_t)vg.vx * vg.vy * vg.vz;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float m = mask[i] != 0.0f ? 1.0f : 0.0f;
-  const int X = (int)(i % (size_t)vg.vx), Y = (int)((i / (size_t)vg.vx) % (size_t)vg.vy), Z = (int)(i / ((size_t)vg.vx * vg.vy));
-  out[i] = make_float2(m != 0.0f ? pvr_tex(vol, vg, X, Y, Z) : 0.0f, m);
-}
-
-__global__ void k_mask_volume(float *recon, const float *mask, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && mask[i] == 0) recon[i] = -1.0f;
-}
-// scaleVolumeKernel RC.cu:3415-3423
-__global__ void k_scale_volume(float *recon, float scale, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && recon[i] > 0) recon[i] = recon[i] * scale;
-}
-
-
-// ------------------------------------------------------------------------------------------
-// bias correction: CorrectBias RC.cu:1837-1942, NormaliseBias RC.cu:2519-2652
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect_(int M, int x) { return max(0, min(M - 1, x)); }   // RC.cu:53-56
-
-// calculateResidual3D_adv RC.cu:1687-1731
-__global__ void k_bias_residual(const float *slices, const float *bias, const float *weights,
-                                const float *simweights, const float *simslices, const float *scales, int n2,
-                                size_t n, float *wb, float *wr) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  float s = slices[idx];
-  if (s == -1.0f) return;
-  float wbo = 0.0f, wro = 0.0f;
-  if ((double)simweights[idx] > 0.99) {
-    float eb = expf(-bias[idx]);
-    float sliceVal = s * (eb * scales[idx / n2]);
-    wbo = weights[idx] * sliceVal;
-    float ss = simslices[idx];
-    if (((double)ss > 1.0) && ((double)sliceVal > 1.0)) wro = logf(sliceVal / ss) * wbo;
-  }
-  if (wbo > 0) { wb[idx] = wbo; wr[idx] = wro; }
-}
-
-// GaussianConvolutionKernel<float> RC.cu:909-985: one 1-D pass (recursive Gaussian weights, border
-// repeat); the output is only written where the result != 0, so `out` keeps its previous content
-// elsewhere -- the reference relies on that when it reuses its buffer (RC.cu:1886-1891).
-__global__ void k_gauss_conv_slices(const float *in, float *out, const SliceConst *sc, int sx, int sy, int ns,
-                                    float sigma, int horizontal) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), sl = blockIdx.z;
-  if (x >= sx || y >= sy) return;
-  const size_t base = (size_t)sl * sx * sy;
-  const float sigma2 = sigma / sc[sl].dim[0];
-  int klength = 2 * (int)roundf(4 * sigma2) + 1;
-  klength -= 1 - klength % 2;
-  const int half = (klength - 1) / 2;
-  float g0 = (float)(1.0 / (sqrt(2.0 * M_PI) * sigma2));
-  float g1 = (float)exp(-0.5 / (sigma2 * sigma2));
-  const float g2 = g1 * g1;
-  const size_t idx = base + x + (size_t)y * sx;
-  float sum = g0 * in[idx];
-  float sum_coeff = g0;
-  for (int i = 1; i <= half; ++i) {
-    g0 *= g1;
-    g1 *= g2;
-    const size_t a = horizontal ? base + reflect_(sx, x + i) + (size_t)y * sx : base + x + (size_t)reflect_(sy, y + i) * sx;
-    sum += g0 * in[a];
-    const size_t b = horizontal ? base + reflect_(sx, x - i) + (size_t)y * sx : base + x + (size_t)reflect_(sy, y - i) * sx;
-    sum += g0 * in[b];
-    sum_coeff += 2 * g0;
-  }
-  const float outv = sum / sum_coeff;
-  if (outv != 0) out[idx] = outv;
-}
-
-// updateBiasField3D_adv RC.cu:1734-1758
-__global__ void k_bias_update(const float *slices, float *bias, const float *wb, const float *wr, size_t n) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  if (slices[idx] == -1.0f) return;
-  float w = wb[idx];
-  if (w > 0) bias[idx] = bias[idx] + wr[idx] / w;
-}
-// per-slice {count(s > -1), sum(bias)}  (count_if + reduce, RC.cu:1904-1909)
-__global__ __launch_bounds__(256) void k_bias_mean(const float *slices, const float *bias, int n2, double *partial) {
-  const int sl = blockIdx.y;
-  double v[2] = {0.0, 0.0};
-  const size_t base = (size_t)sl * n2;
-  for (int i = blockIdx.x * CHUNK_PIX + threadIdx.x; i < min(n2, (int)(blockIdx.x + 1) * CHUNK_PIX); i += 256) {
-    if (slices[base + i] > -1.0f) v[0] += 1.0;
-    v[1] += (double)bias[base + i];
-  }
-  const int op[2] = {0, 0};
-  block_reduce_store<2>(v, op, partial + ((size_t)sl * gridDim.x + blockIdx.x) * 2);
-}
-// transformBiasMean RC.cu:1760-1783 with the mean of RC.cu:1911-1921
-__global__ void k_bias_sub_mean(const float *slices, float *bias, const double *per_slice, int n2, size_t n) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  if (slices[idx] == -1.0f) return;
-  const int sl = (int)(idx / n2);
-  const double num = per_slice[2 * sl], sum = per_slice[2 * sl + 1];
-  const float mean = num > 0 ? (float)(sum / num) : -1.0f;
-  if (mean == -1.0f) return;
-  if (mean != 0) bias[idx] = bias[idx] - mean;
-}
-
-// GaussianConvolutionKernel3D RC.cu:988-1093, one direction; written unless NaN
-__global__ void k_gauss_conv3d(const float *in, float *out, float sigma, int dir, float dimd, int vx, int vy, int vz) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
-  if (x >= vx || y >= vy) return;
-  const float sigma2 = sigma / dimd;
-  int klength = 2 * (int)roundf(4 * sigma2) + 1;
-  klength -= 1 - klength % 2;
-  const int half = (klength - 1) / 2;
-  float g0 = (float)(1.0 / (sqrt(2.0 * M_PI) * sigma2));
-  float g1 = (float)exp(-0.5 / (sigma2 * sigma2));
-  const float g2 = g1 * g1;
-  const size_t sxy = (size_t)vx * vy;
-  const size_t idx = x + (size_t)y * vx + (size_t)z * sxy;
-  float sum = g0 * in[idx];
-  float sum_coeff = g0;
-  for (int i = 1; i <= half; ++i) {
-    g0 *= g1;
-    g1 *= g2;
-    size_t a, b;
-    if (dir == 0) { a = reflect_(vx, x + i) + (size_t)y * vx + (size_t)z * sxy; b = reflect_(vx, x - i) + (size_t)y * vx + (size_t)z * sxy; }
-    else if (dir == 1) { a = x + (size_t)reflect_(vy, y + i) * vx + (size_t)z * sxy; b = x + (size_t)reflect_(vy, y - i) * vx + (size_t)z * sxy; }
-    else { a = x + (size_t)y * vx + (size_t)reflect_(vz, z + i) * sxy; b = x + (size_t)y * vx + (size_t)reflect_(vz, z - i) * sxy; }
-    sum += g0 * in[a];
-    sum += g0 * in[b];
-    sum_coeff += 2 * g0;
-  }
-  const float outv = sum / sum_coeff;
-  if (outv == outv) out[idx] = outv;
-}
-// divS RC.cu:1786-1797
-__global__ void k_div_s(float *a, const float *b, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { float d = b[i]; a[i] = (d != 0) ? a[i] / d : 0; }
-}
-// divexp RC.cu:2505-2516
-__global__ void k_divexp(float *recon, const float *bias, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { float a = recon[i]; if (a != -1.0f) recon[i] = a / expf(-bias[i]); }
-}
-
-// ------------------------------------------------------------------------------------------
-// slice-to-volume NCC cost (the CPU-default registration metric):
-// irtkImageRigidRegistrationWithPadding::Evaluate + irtkCrossCorrelationSimilarityMetric.
-// One workgroup per (target slice, candidate transform): every target pixel >= 0 is mapped into the
-// source volume, trilinearly interpolated in double in EvaluateInside's operation order, rounded
-// like IRTK's round(), and the six integer moments are accumulated exactly in int64 and reduced
-// with wavefront shuffles -- order-independent, so the moments equal the serial CPU loop's.
-// ------------------------------------------------------------------------------------------
-__global__ void k_f32_to_i16(const float *in, short *out, size_t n) {   // static_cast<short>(float): truncation
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (short)in[i];
-}
-
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-__global__ __launch_bounds__(256) void k_ncc(const short *targets, int tx, int ty, const int *target_index,
-                                             const double *mats, const short *source, int vx, int vy, int vz,
-                                             long long *sums) {
-  __shared__ long long sm[4][6];
-  const int e = blockIdx.x;
-  const short *tgt = targets + (size_t)target_index[e] * tx * ty;
-  const double *M = mats + 16 * (size_t)e;
-  const double m00 = M[0], m01 = M[1], m03 = M[3], m10 = M[4], m11 = M[5], m13 = M[7], m20 = M[8], m21 = M[9],
-               m23 = M[11];
-  const double sx2 = vx - 1, sy2 = vy - 1, sz2 = vz - 1;
-  const size_t o3 = vx, o5 = (size_t)vx * vy;
-  long long a_n = 0, a_x = 0, a_y = 0, a_x2 = 0, a_y2 = 0, a_xy = 0;
-  for (int p = threadIdx.x; p < tx * ty; p += 256) {
-    const int tv = tgt[p];
-    if (tv < 0) continue;
-    const int j = p / tx, i = p - j * tx;
-    const double X = m00 * i + m01 * j + m03, Y = m10 * i + m11 * j + m13, Z = m20 * i + m21 * j + m23;
-    if ((X > 0) && (X < sx2) && (Y > 0) && (Y < sy2) && (Z > 0) && (Z < sz2)) {
-      const int a = (int)X, b = (int)Y, c = (int)Z;
-      const double t1 = X - a, u1 = Y - b, v1 = Z - c, t2 = 1 - t1, u2 = 1 - u1, v2 = 1 - v1;
-      const short *q = source + a + (size_t)b * o3 + (size_t)c * o5;
-      const double value = (t1 * (u2 * (v2 * q[1] + v1 * q[o5 + 1]) + u1 * (v2 * q[o3 + 1] + v1 * q[o5 + o3 + 1])) +
-                            t2 * (u2 * (v2 * q[0] + v1 * q[o5]) + u1 * (v2 * q[o3] + v1 * q[o5 + o3])));
-      if (value >= 0) {
-        const int sv = value > 0 ? (int)(value + 0.5) : (int)(value - 0.5);   // irtkCommon.h:85-88
-        a_n += 1; a_x += tv; a_y += sv; a_x2 += (long long)tv * tv; a_y2 += (long long)sv * sv;
-        a_xy += (long long)tv * sv;
-      }
-    }
-  }
-  long long v[6] = {a_n, a_x, a_y, a_x2, a_y2, a_xy};
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    v[k] = wave_sum_i64(v[k]);
-    if (lane == 0) sm[w][k] = v[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) sums[6 * (size_t)e + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-}
+#include "svr_small.inc"   // list compaction, reductions, the EM / scale / bias / volume kernels, the NCC cost of the IRTK registration
 
 }  // namespace
 
@@ -2963,6 +1199,7 @@ struct svr_ctx {
   int coeff_mode = 1;          // option "coeff_table": 0 = evaluate on the fly, 1 = stream the table (falls back to 0 if it does not fit).  Round 6: ON by
                                // default for slice-to-volume runs (written by the first gather of the SR iterations, coeff_lazy: P4 +7 %, S8 +5 % with one
                                // table per four SR iterations INSIDE the timed region), off for the patch-based path (no gain there: DESIGN 5.1b)
+  bool legacy_ok = false;      // option "legacy_kernels": back_mode 0 / 1 / 3 and fwd_mode 0 may be asked for (tests)
   bool coeff_user = false;     // svr_set_option("coeff_table") was called: the "pvr" option leaves the mode alone
   int coeff_lazy = 1;          // option "coeff_lazy" (round 6): 1 = the table is written by the first gather of the SR iterations after a new slice geometry
                                // (fwd_cell_kernel<.., 3>: the evaluation that pass needs anyway) instead of by k_coeff_build; passes before it evaluate
@@ -3772,11 +2009,23 @@ int svr_create(int device, svr_ctx **out) {
 int svr_set_option(svr_ctx *ctx, const char *name, int value) {
   SVR_ENTER(ctx);
   if (!ctx || !name) return SVR_E_ARG;
-  if (!strcmp(name, "back_mode")) { ctx->back_mode = value; ctx->back_mode_user = true; return SVR_OK; }
+  // Round 6: the scatter generations before the wave-owned tile kernel (0 = a wavefront per pixel with device atomics per tap, 1 = LDS atomics per tile,
+  // 3 = the workgroup's slot kernel as a mode of its own) and the wave-per-pixel gather (fwd_mode 0) stay in the library for the tests that pin the
+  // generations against each other and as the tile path's own re-run kernels -- asking for one by option needs "legacy_kernels" 1 first.
+  if (!strcmp(name, "legacy_kernels")) { ctx->legacy_ok = value != 0; return SVR_OK; }
+  if (!strcmp(name, "back_mode")) {
+    if (value < 0 || value > 5 || value == 2) return fail(ctx, SVR_E_ARG, "back_mode: 5 (cells), 4 (tile fallback); 0 / 1 / 3 behind legacy_kernels");
+    if (value < 4 && !ctx->legacy_ok && !ctx->pvr) return fail(ctx, SVR_E_ARG, "back_mode 0 / 1 / 3: set option legacy_kernels 1 first (kept for the tests; the product runs 5 with 4 as its fallback)");
+    ctx->back_mode = value; ctx->back_mode_user = true; return SVR_OK;
+  }
   if (!strcmp(name, "sr_no_wait")) { ctx->sr_no_wait = value != 0; return SVR_OK; }   // svr_superresolution_backproject / _update / svr_slab_finish return without waiting for the device (a sharded run whose collectives share the stream)
   if (!strcmp(name, "reg_tile")) { if (value < -1 || value > 2) return fail(ctx, SVR_E_ARG, "reg_tile: -1 .. 2"); ctx->reg_tile = value; return SVR_OK; }
   if (!strcmp(name, "reg_mode")) { if (value < 0 || value > 1) return fail(ctx, SVR_E_ARG, "reg_mode: 0 or 1"); ctx->reg_mode = value; return SVR_OK; }
-  if (!strcmp(name, "fwd_mode")) { ctx->fwd_mode = value; ctx->fwd_mode_user = true; return SVR_OK; }      // >= 1: unit-based gather, 0: wave-per-pixel kernel
+  if (!strcmp(name, "fwd_mode")) {                         // 2: cell gather, 1: unit-based gather per slice tile (fallback), 0: wave-per-pixel kernel (legacy_kernels)
+    if (value < 0 || value > 2) return fail(ctx, SVR_E_ARG, "fwd_mode: 2 (cells), 1 (tile fallback); 0 behind legacy_kernels");
+    if (value == 0 && !ctx->legacy_ok && !ctx->pvr) return fail(ctx, SVR_E_ARG, "fwd_mode 0: set option legacy_kernels 1 first (kept for the tests; the product runs 2 with 1 as its fallback)");
+    ctx->fwd_mode = value; ctx->fwd_mode_user = true; return SVR_OK;
+  }
   if (!strcmp(name, "pvr_mode")) { ctx->pvr_mode = value; return SVR_OK; }
   if (!strcmp(name, "gauss_mode")) { ctx->gauss_mode = value; return SVR_OK; }
   if (!strcmp(name, "fwd_unit_cap")) { ctx->fwd_unit_cap = std::max(2048, value); return SVR_OK; }

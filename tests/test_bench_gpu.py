@@ -298,3 +298,34 @@ def test_m_step_sums_meeting_on_the_device_give_the_host_exchanges_bits(tiny, mo
     for a, b in zip(out["0"][:3], out["1"][:3]):
         assert np.array_equal(a, b)
     assert out["0"][3] == out["1"][3]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_the_scale_step_s_command_shape_at_four_ranks_on_one_gpu():
+    """The exact command the driver's SCALE step runs -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- at N = 4 with the default workload (P4, then the s8 record in the same launch), on
+    the one GPU of this box: `--share-gpu --comm torch --backend gloo` (RCCL refuses several ranks on one device; gloo carries the collectives,
+    host-staged).  No hardware claim -- what is asserted is the line: every rank's record, the s8 record's, the bytes the volume collectives
+    send, the communicator fields, the projection the line is compared with, and that four ranks cover the fixed workload."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--comm", "torch", "--backend", "gloo",
+                        "--share-gpu", "--no-cpu-baseline", "--no-coeff-table"], cwd=ROOT, capture_output=True, text=True, timeout=1400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = _last_json(r.stdout)
+    assert a["n_gpus"] == 4 and a["steps"] == 2 and a["scaling"] == "strong" and a["value"] > 0 and a["config"]["workload"].startswith("P4")
+    assert a["config"]["comm"] == "torch" and a["config"]["rccl_world"] is None and "sharded x4" in a["config"]["parallelism"]
+    k = a["ranks"]
+    assert len(k["Va"]) == 4 and sum(k["Va"]) == a["config"]["Va_total"] and sum(k["units"]) == a["config"]["slices"] == 280
+    assert min(k["backproject_ms"]) > 0 and min(k["forward_ms"]) > 0 and len(k["collective_bytes_sent"]) == 4 and min(k["collective_bytes_sent"]) > 0
+    assert max(k["Va"]) < 0.4 * a["config"]["Va_total"]                  # work-balanced shares of a fixed workload
+    s8 = a["s8"]
+    assert "error" not in s8, s8
+    assert s8["n_gpus"] == 4 and len(s8["ranks"]["Va"]) == 4 and sum(s8["ranks"]["Va"]) == s8["Va_total"] and sum(s8["ranks"]["units"]) == 512
+    assert s8["collective_bytes_sent"] == s8["ranks"]["collective_bytes_sent"] and min(s8["collective_bytes_sent"]) > 1e6
+    assert a["config"]["tuned"]["fallbacks"] == dict(scatter_to_atomics=0, gather_to_tiles=0, gauss1_to_tiles=0, tiles_rerun=0)
+    # the projection this N was given (profiles/r06_shard_projection.json) travels with the measurement
+    assert "projection" in a and ("default_mode_step_ms" in a["projection"] or "error" in a["projection"])
+    if "error" not in a["projection"]:
+        assert a["speedup_vs_projection"]["default_mode"] > 0

@@ -113,7 +113,7 @@ def test_gaussian_reconstruction_parity(tiny, oracle_mod, gauss_mode, fwd_mode):
     + the LDS scatter, 0 = wave-per-pixel kernel with atomics."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
     rec.set_option("gauss_mode", gauss_mode)
-    rec.set_option("fwd_mode", fwd_mode)
+    rec.set_option("legacy_kernels", 1); rec.set_option("fwd_mode", fwd_mode)
     run_to_state(dg, "gauss")
     run_to_state(do, "gauss")
     ps = rec.debug_get(E.BUF_PSF_SUMS)
@@ -144,7 +144,7 @@ def test_forward_projection_parity(tiny, oracle_mod, fwd_mode):
     """fwd_mode 2 = the gather over the (cell, plane) items of the scatter without atomics (csrc/svr_cell.inc), 1 = unit-based
     gather per slice tile (float2 {V m, m} box, dead-unit shortcut), 0 = wave-per-pixel kernel."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
-    rec.set_option("fwd_mode", fwd_mode)
+    rec.set_option("legacy_kernels", 1); rec.set_option("fwd_mode", fwd_mode)
     run_to_state(dg, "sim")
     run_to_state(do, "sim")
     assert np.array_equal(dg._slice_inside_gpu, do._slice_inside_gpu)
@@ -180,7 +180,7 @@ def test_backprojection_parity(tiny, oracle_mod, back_mode):
     """back_mode 4 = wave-owned LDS planes with the dead-unit shortcut (default), 3 = the workgroup kernel for every tile,
     1 = LDS tiles with ds_add_f32, 0 = direct atomics."""
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
-    rec.set_option("back_mode", back_mode)
+    rec.set_option("legacy_kernels", 1); rec.set_option("back_mode", back_mode)
     run_to_state(dg, "scale")
     run_to_state(do, "scale")
     # identical inputs for the scatter: copy the oracle's per-pixel state onto the device
@@ -297,7 +297,7 @@ def test_slices_of_different_thickness_side_by_side_in_the_cell_lists(tiny, orac
         rec = E.Reconstruction(0)
         E.sync_gpu(rec, P)
         assert rec.get_option("back_mode") == 5 and rec.get_option("fwd_mode") == 2      # the defaults: the cell kernels
-        rec.set_option("back_mode", modes[0]); rec.set_option("fwd_mode", modes[1]); rec.set_option("gauss_mode", 1 if modes[0] >= 3 else 0)
+        rec.set_option("legacy_kernels", 1); rec.set_option("back_mode", modes[0]); rec.set_option("fwd_mode", modes[1]); rec.set_option("gauss_mode", 1 if modes[0] >= 3 else 0)
         for r in ((rec, orc) if tab == 0 else (rec,)):
             r.UpdateScaleVector(ones, ones)
             r.InitializeEMValues()
@@ -352,7 +352,7 @@ def test_deferred_reads_and_the_fused_m_e_step_give_the_separate_calls_bits(tiny
 
     a, b = fresh(), fresh()
     for r in (a, b):
-        r.set_option("back_mode", 5)                                       # the scatter without atomics: the two engines stay bit-identical
+        r.set_option("legacy_kernels", 1); r.set_option("back_mode", 5)                                       # the scatter without atomics: the two engines stay bit-identical
     for buf in (E.BUF_RECONSTRUCTED, E.BUF_VOL_WEIGHTS, E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS, E.BUF_SIMINSIDE, E.BUF_PSF_SUMS):
         b.debug_set(buf, a.debug_get(buf))                                 # (the Gaussian pass of the patch-based path adds with atomics)
     sigma = a.InitializeRobustStatistics()
@@ -417,8 +417,8 @@ def test_volume_boundary_quirks_on_device(oracle_mod, shift, back_mode):
     P.slices[...] = 100.0
     P.slices[:, ::3, ::2] = 140.0
     E, rec, orc, dg, do = _drivers(P, oracle_mod)
-    rec.set_option("back_mode", back_mode)
-    rec.set_option("fwd_mode", 1 if back_mode >= 3 else 0)
+    rec.set_option("legacy_kernels", 1); rec.set_option("back_mode", back_mode)
+    rec.set_option("legacy_kernels", 1); rec.set_option("fwd_mode", 1 if back_mode >= 3 else 0)
     rec.set_option("gauss_mode", 1 if back_mode >= 3 else 0)
     run_to_state(dg, "sim")
     run_to_state(do, "sim")
@@ -537,6 +537,7 @@ def test_lists_go_out_in_pieces(tiny, oracle_mod, monkeypatch, modes):
     monkeypatch.setenv("SVR_LIST_PIECE", "40")
     monkeypatch.setenv("SVR_FWD_PIECE", "48")
     E, rec, orc, dg, do = _drivers(tiny, oracle_mod)
+    rec.set_option("legacy_kernels", 1)                                    # (the generations before the tile fallback are asked for by name here)
     for k, v in modes.items():
         rec.set_option(k, v)
     dg.reconstruct_iteration(2)
@@ -633,6 +634,7 @@ def test_kernel_variants_agree_at_full_size():
     rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
     rec.InitializeEMValues()
     out = {}
+    rec.set_option("legacy_kernels", 1)
     for name, opts in (("units", dict(gauss_mode=1, fwd_mode=1)), ("simple", dict(gauss_mode=0, fwd_mode=0))):
         for k, v in opts.items():
             rec.set_option(k, v)
@@ -649,11 +651,11 @@ def test_kernel_variants_agree_at_full_size():
         assert np.allclose(ps, ref[0], rtol=2e-6, atol=0)
         assert rel_err(vol, ref[1]) < TOL_SUM and rel_err(vw, ref[2]) < TOL_SUM     # float atomics in run-dependent order
         assert np.abs(sw - ref[4]).max() < 3e-6 and rel_err(sim, ref[3]) < 5e-6
-    rec.set_option("fwd_mode", 1)
+    rec.set_option("legacy_kernels", 1); rec.set_option("fwd_mode", 1)
     rec.set_option("gauss_mode", 1)
     res = {}
     for bm in (5, 4, 3, 0):
-        rec.set_option("back_mode", bm)
+        rec.set_option("legacy_kernels", 1); rec.set_option("back_mode", bm)
         rec.SuperresolutionBackproject(np.ones(P.ns, np.float32))
         res[bm] = (rec.debug_get(E.BUF_ADDON).copy(), rec.debug_get(E.BUF_CONFIDENCE_MAP).copy())
     for bm in (5, 4, 3):
@@ -870,7 +872,7 @@ def test_cell_gather_gives_the_tile_gathers_bits(tiny, workload):
     rec.GaussianReconstruction()
     out = {}
     for mode in (1, 2):
-        rec.set_option("fwd_mode", mode)
+        rec.set_option("legacy_kernels", 1); rec.set_option("fwd_mode", mode)
         for b in (E.BUF_SIMSLICES, E.BUF_SIMWEIGHTS):
             rec.debug_set(b, np.zeros(P.slices.shape, np.float32))
         rec.debug_set(E.BUF_SIMINSIDE, np.zeros(P.slices.shape, np.uint8))
@@ -892,7 +894,7 @@ def test_cell_pass_one_gives_the_tile_kernels_bits(tiny, workload):
     out = {}
     for mode in (1, 2):
         rec = _engine(P)
-        rec.set_option("fwd_mode", mode)
+        rec.set_option("legacy_kernels", 1); rec.set_option("fwd_mode", mode)
         rec.UpdateScaleVector(np.ones(P.ns), np.ones(P.ns))
         rec.InitializeEMValues()
         n = rec.GaussianReconstruction()
