@@ -37,7 +37,8 @@ int main(int argc, char **argv) {
   std::vector<int> force_excluded, devices, packages;
   int iterations = 4, levels = 3, rec_first = 4, rec_last = 13, num_stacks_tuner = 0;
   double resolution = 0.75, average = 700, delta = 150, lambda = 0.02, last_lambda = 0.01, smooth_mask = 4;
-  bool no_matching = false, use_gpu_reg = false, no_registration = false, coeff_table = false;
+  bool no_matching = false, use_gpu_reg = false, no_registration = false;
+  int coeff_table = -1;                                                   // -1: the engine's default (on since round 6), 1 / 0: --coeffTable / --noCoeffTable
   // ---- options (main.cc:164-211) ---------------------------------------------------------------------
   auto is_opt = [](const char *s) { return s[0] == '-' && !(s[1] >= '0' && s[1] <= '9') && s[1] != '.'; };
   for (int i = 1; i < argc; ++i) {
@@ -79,7 +80,8 @@ int main(int argc, char **argv) {
     else if (o == "--no_registration") no_registration = true;
     else if (o == "--tfolder") tfolder = one();
     else if (o == "--sfolder") sfolder = one();
-    else if (o == "--coeffTable") coeff_table = true;                     // not a reference option: keep the PSF taps in HBM (CoeffInit on the GPU path)
+    else if (o == "--coeffTable") coeff_table = 1;                        // not a reference option: keep the PSF taps in HBM (CoeffInit on the GPU path); the default since round 6
+    else if (o == "--noCoeffTable") coeff_table = 0;                      // ... every tap evaluated in every pass, like the reference's GPU kernels: same volume, bit for bit
     else if (o == "--debug") debug = opt_bool(true);
     else if (o == "--saveSliceTransformations") save_slice_transformations = true;   // main.cc:211, 1213-1217
     else if (o == "--dumpProblem") dump_name = one();                     // test hooks: what the engine is about to receive [--dryRun: stop there]
@@ -91,7 +93,7 @@ int main(int argc, char **argv) {
              "       [--iterations 4] [--resolution 0.75] [--multires 3] [--average 700] [--delta 150] [--lambda 0.02]\n"
              "       [--lastIterLambda 0.01] [--smooth_mask 4] [--no_intensity_matching] [--force_exclude i ..]\n"
              "       [--rec_iterations_first 4] [--rec_iterations_last 13] [--packages p_1 ..] [--useGPUReg] [--no_registration] [--tfolder dir] [--sfolder dir]\n"
-             "       [--saveSliceTransformations] [--coeffTable] [-d device_1 .. device_N]\n");
+             "       [--saveSliceTransformations] [--coeffTable | --noCoeffTable] [-d device_1 .. device_N]\n");
       return 0;
     } else {
       die("option " + o + " is not supported by this build (see csrc/svr_cli.cpp)");
@@ -329,7 +331,7 @@ int main(int argc, char **argv) {
   par([&](int r) {
     const int nl = rhi[r] - rlo[r];
     const size_t o = (size_t)rlo[r];
-    if (coeff_table) ENGR(r, svr_set_option(ctxs[r], "coeff_table", 1));
+    if (coeff_table >= 0) ENGR(r, svr_set_option(ctxs[r], "coeff_table", coeff_table));
     ENGR(r, svr_set_option(ctxs[r], "tune_tiles", 32768));                // a run is a few dozen PSF launches: cheap tuning trials
     ENGR(r, svr_init_reconstruction_volume(ctxs[r], vsize, vdim, nullptr, 12.0f));
     ENGR(r, svr_set_mask(ctxs[r], vsize, vdim, maskf.data(), 12.0f));

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Round-5 evidence (the round-2 script, re-pointed), run on the GPU box from the repo root (one gpurun call):
+"""Round-6 evidence (the round-2 script, re-pointed), run on the GPU box from the repo root (one gpurun call):
 
   1. bench lines: P4 (with the CPU baseline) and S8
-  2. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`      -> profiles/r05_kernel_stats_p4.txt
+  2. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`      -> profiles/r06_kernel_stats_p4.txt
   3. rocprofv3 --kernel-trace --pmc passes (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE -- each its own pass) over
-     tools/run_sr_kernels.py on P4 and on S8                                -> profiles/r05_pmc_p4.txt, r05_pmc_s8.txt
-  4. profiles/r05_traffic.json: FETCH_SIZE / WRITE_SIZE of the scatter and the gather per launch (KB -> bytes), which
-     bench.py reads for roofline.traffic; then the P4 bench line again with it           -> profiles/r05_bench_p4.json
+     tools/run_sr_kernels.py on P4 and on S8                                -> profiles/r06_pmc_p4.txt, r06_pmc_s8.txt
+  4. profiles/r06_traffic.json: FETCH_SIZE / WRITE_SIZE of the scatter and the gather per launch (KB -> bytes), which
+     bench.py reads for roofline.traffic; then the P4 bench line again with it           -> profiles/r06_bench_p4.json
 """
 import csv
 import glob
@@ -18,7 +18,7 @@ import subprocess
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r05"
+TAG = "r06"
 OUT = os.path.join(R, "gpurun_out", TAG)
 PROF = os.path.join(R, "profiles")
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -49,12 +49,12 @@ def pmc(workload, tag, opts=()):
     p = sh([sys.executable, os.path.join(R, "tools", "pmc.py"), d, "--filter", "k", "--", sys.executable,
             os.path.join(R, "tools", "run_sr_kernels.py"), workload, *opts])
     txt = p.stdout
-    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} {' '.join(opts)} (1 GPU), round 5.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
+    head = (f"# rocprofv3 PMC counters of the SR kernels on {workload} {' '.join(opts)} (1 GPU), round 6.  tools/pmc.py over tools/run_sr_kernels.py: one\n"
             "# rocprofv3 --kernel-trace --pmc <set> pass per counter set (SQ set A, SQ set B, FETCH_SIZE, WRITE_SIZE), nothing else in\n"
             "# the pass.  Per kernel: mean over the last half of its dispatches.  SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are in\n"
             "# quad-cycles summed over the SIMDs, FETCH_SIZE / WRITE_SIZE in KB (uncalibrated for this access pattern: narrow LDS-staged\n"
             "# reads and float atomics -- MI355X_MICROARCH.md calibrates only wide streaming reads -- so they are reported as counted).\n")
-    open(os.path.join(PROF, f"r05_pmc_{tag}.txt"), "w").write(head + txt)
+    open(os.path.join(PROF, f"r06_pmc_{tag}.txt"), "w").write(head + txt)
     vals = {}
     cur = None
     for line in txt.splitlines():
@@ -72,18 +72,21 @@ def stats_only():
     """2. alone: the kernel trace of the bench command (headline workload only: `--no-s8`, so that the per-kernel averages are P4's)"""
     os.makedirs(OUT, exist_ok=True)
     bench = os.path.join(R, "bench.py")
-    j4 = json.load(open(os.path.join(PROF, "r05_bench_p4.json"))) if os.path.exists(os.path.join(PROF, "r05_bench_p4.json")) else None
-    j8 = json.load(open(os.path.join(PROF, "r05_bench_s8.json"))) if os.path.exists(os.path.join(PROF, "r05_bench_s8.json")) else None
+    j4 = json.load(open(os.path.join(PROF, "r06_bench_p4.json"))) if os.path.exists(os.path.join(PROF, "r06_bench_p4.json")) else None
+    j8 = json.load(open(os.path.join(PROF, "r06_bench_s8.json"))) if os.path.exists(os.path.join(PROF, "r06_bench_s8.json")) else None
     kernel_stats(bench, j4, j8)
 
 
 def main():
     if "--stats-only" in sys.argv:
         return stats_only()
+    if "--timeline-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        return timeline(os.path.join(R, "bench.py"))
     os.makedirs(OUT, exist_ok=True)
     bench = os.path.join(R, "bench.py")
     # 3. PMC first (the traffic file must exist before the final bench line)
-    traffic = {"source": "profiles/r05_pmc_<workload>.txt (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes; "
+    traffic = {"source": "profiles/r06_pmc_<workload>.txt (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes; "
                          "per pass the kernels of one scatter / gather launch summed)"}
 
     def collect(vals, pats):
@@ -93,43 +96,64 @@ def main():
         return {"kernels": ks, "fetch_bytes": sum(vals[k]["FETCH_SIZE"] for k in ks) * 1024.0, "write_bytes": sum(vals[k]["WRITE_SIZE"] for k in ks) * 1024.0,
                 "valu_insts": sum(vals[k].get("SQ_INSTS_VALU", 0.0) for k in ks)}
 
-    todo = [("P4", "p4", ()), ("S8", "s8", ()), ("PVR4", "pvr4", ()), ("PVR8spx", "pvr8spx", ())]
+    # slice-to-volume workloads: the default (coefficient table: the passes that stream it, and the gather that writes it) and coeff_table=0 (every
+    # tap evaluated); patch-based workloads: their default (evaluated)
+    todo = [("P4", "p4", ()), ("P4", "p4_on_the_fly", ("coeff_table=0",)), ("S8", "s8", ()), ("S8", "s8_on_the_fly", ("coeff_table=0",)),
+            ("PVR4", "pvr4", ()), ("PVR8spx", "pvr8spx", ())]
     v8 = {}
     for wl, tag, opts in todo:
         v = pmc(wl, tag, opts)
         if wl == "S8":
             v8 = v
-        nsup, isp = ("12", "true") if wl.startswith("PVR") else ("16", "false")
-        e = {}
-        e["back"] = collect(v, ("back_cell_kernel<%s, %s, false>" % (nsup, isp), "k_cell_combine", "k_cell_factors")) or collect(v, ("back_wave_kernel<%s, %s, false>" % (nsup, isp),))
-        e["forward"] = collect(v, ("fwd_cell_kernel<%s, %s, false, false>" % (nsup, isp), "k_cell_gather_finish", "k_cell_gfactors")) or collect(v, ("fwd_unit_kernel<false, %s, %s, false>" % (nsup, isp),))
-        e["update"] = collect(v, ("k_regul_fused",))
+        pv = wl.startswith("PVR")
+        nsup, isp = ("12", "true") if pv else ("16", "false")
+        e = traffic.setdefault(wl, {})
+        if pv or opts:
+            e["back"] = collect(v, ("back_cell_kernel<%s, %s, 0>" % (nsup, isp), "k_cell_combine", "k_cell_factors")) or collect(v, ("back_wave_kernel<%s, %s, false>" % (nsup, isp),))
+            e["forward"] = collect(v, ("fwd_cell_kernel<%s, %s, 0, false>" % (nsup, isp), "k_cell_gather_finish", "k_cell_gfactors")) or collect(v, ("fwd_unit_kernel<false, %s, %s, false>" % (nsup, isp),))
+        else:
+            e["back_table"] = collect(v, ("back_cell_kernel<16, false, 1>", "k_cell_combine", "k_cell_factors"))
+            e["forward_table"] = collect(v, ("fwd_cell_kernel<16, false, 2, false>", "k_cell_gather_finish")) or collect(v, ("fwd_unit_kernel<false, 16, false, true>",))
+            e["forward_store"] = collect(v, ("fwd_cell_kernel<16, false, 3, false>", "k_cell_gather_finish"))
+        e["update"] = e.get("update") or collect(v, ("k_regul_fused",))
         traffic[wl] = {k: x for k, x in e.items() if x}
-    vt = pmc("P4", "p4_table", ("coeff_table=1",))           # the COEFF instantiations streaming the coefficient table
-    for key, pats in (("back_table", ("back_cell_kernel<16, false, true", "k_cell_combine", "k_cell_factors")),
-                      ("forward_table", ("fwd_unit_kernel<false, 16, false, true",))):
-        x = collect(vt, pats) or (collect(vt, ("back_wave_kernel<16, false, true",)) if key == "back_table" else None)
-        if x:
-            traffic["P4"][key] = x
-    if traffic.get("P4", {}).get("back"):
-        json.dump(traffic, open(os.path.join(PROF, "r05_traffic.json"), "w"), indent=1)
+    if traffic.get("P4", {}).get("back_table") or traffic.get("P4", {}).get("back"):
+        json.dump(traffic, open(os.path.join(PROF, "r06_traffic.json"), "w"), indent=1)
     # 1. bench lines
     b4 = sh([sys.executable, bench], os.path.join(OUT, "bench_p4.log"), cwd=R)
     j4 = last_json(b4.stdout)
     if j4:
-        json.dump(j4, open(os.path.join(PROF, "r05_bench_p4.json"), "w"), indent=1)
+        json.dump(j4, open(os.path.join(PROF, "r06_bench_p4.json"), "w"), indent=1)
     b8 = sh([sys.executable, bench, "--workload", "S8", "--no-cpu-baseline"], os.path.join(OUT, "bench_s8.log"), cwd=R)
     j8 = last_json(b8.stdout)
     if j8:
-        json.dump(j8, open(os.path.join(PROF, "r05_bench_s8.json"), "w"), indent=1)
+        json.dump(j8, open(os.path.join(PROF, "r06_bench_s8.json"), "w"), indent=1)
     for wl in ("PVR4", "PVR8spx"):
         bp = sh([sys.executable, bench, "--workload", wl, "--no-cpu-baseline"], os.path.join(OUT, f"bench_{wl.lower()}.log"), cwd=R)
         jp = last_json(bp.stdout)
         if jp:
-            json.dump(jp, open(os.path.join(PROF, f"r05_bench_{wl.lower()}.json"), "w"), indent=1)
+            json.dump(jp, open(os.path.join(PROF, f"r06_bench_{wl.lower()}.json"), "w"), indent=1)
     kernel_stats(bench, j4, j8)
+    timeline(bench)
     print(json.dumps(traffic.get("P4")))
     print("S8 pmc kernels:", list(v8)[:6])
+
+
+def timeline(bench):
+    """5. every dispatch of one outer iteration of the bench's schedule on P4: three steps that stream the table, one whose scatter evaluates and whose
+    gather writes it (profiles/r06_step_timeline_p4.txt)"""
+    import shutil
+    d = os.path.join(OUT, "tl")
+    shutil.rmtree(d, ignore_errors=True)
+    sh(["timeout", "420", "rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable, bench, "--steps", "8", "--warmup", "2",
+        "--no-cpu-baseline", "--no-s8", "--no-coeff-table"], os.path.join(OUT, "tl.log"))
+    p = subprocess.run([sys.executable, os.path.join(R, "tools", "step_timeline.py"), d, "4"], capture_output=True, text=True, env=dict(ENV, STEP_FROM="4"))
+    head = ("# round 6, final binary: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-s8 --no-coeff-table;\n"
+            "# STEP_FROM=4 python tools/step_timeline.py DIR 4   (P4, one MI355X, the default mode: steps 5-8 of the first timed pass -- kernel timers OFF -- i.e. one outer\n"
+            "# iteration of the schedule: its first step follows InitializeEMValues / InitializeRobustStatistics / EStep and the throwing away of the coefficient table,\n"
+            "# its scatter evaluates and its gather evaluates and writes the table; the other three stream it)\n")
+    open(os.path.join(PROF, "r06_step_timeline_p4.txt"), "w").write(head + p.stdout)
+    print(p.stdout[:1500])
 
 
 def kernel_stats(bench, j4, j8):
@@ -140,7 +164,7 @@ def kernel_stats(bench, j4, j8):
     p = sh(["timeout", "420", "rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline", "--no-s8"],   # (timeout: rocprofv3 has been seen to hang at exit after writing its database)
            os.path.join(OUT, "stats.log"))
     jt = last_json(p.stdout)
-    lines = ["# round 5: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r05/stats -o bench -- python bench.py --no-cpu-baseline --no-s8",
+    lines = ["# round 6: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r05/stats -o bench -- python bench.py --no-cpu-baseline --no-s8",
              "# (tools/prof_final.py; rocprofv3 of this image writes a rocpd database: `top_kernels` view below.  --no-s8: the default command also measures S8",
              "#  after the headline workload in the same launch -- with it the per-kernel averages below would mix P4's 3 ms launches with S8's 33 ms ones)"]
     if jt:
@@ -160,22 +184,20 @@ def kernel_stats(bench, j4, j8):
             lines.append("%7s %14s %12s %7s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
             lines += ["%7d %14.1f %12.1f %7.2f  %s" % (k, t, a, pc, short(n)) for n, k, t, a, pc in rows[:24]]
             # the on-the-fly instantiations; the bench times its K steps on the fly first, then the same K with the table
-            for pat in ("back_cell_kernel<16, false, false>", "fwd_cell_kernel<16, false, false, false>"):
+            for pat in ("back_cell_kernel<16, false, 1>", "fwd_cell_kernel<16, false, 2, false>", "fwd_cell_kernel<16, false, 3, false>", "back_cell_kernel<16, false, 0>", "fwd_cell_kernel<16, false, 0, false>"):
                 dd = [r[0] / 1e3 for r in c.execute("select (end - start) from kernels where name like ? order by start", ("%" + pat + "%",)).fetchall()]
                 if dd and jt:
                     k = jt["steps"]
                     w = jt["warmup"]
-                    onfly = dd[:-1] if pat.startswith("fwd") else dd      # (the table phase starts with one on-the-fly gather... none for the scatter)
                     lines.append("# %s dispatches in order, us: %s" % (pat, " ".join("%.0f" % v for v in dd)))
-                    timed = [v for v in dd if True][-(k):] if len(dd) >= k else dd
-                    lines.append("#   the last %d dispatches: average %.1f us (kernel trace) vs the bench line's HIP-event figure for the whole pass" % (len(timed), sum(timed) / max(len(timed), 1)))
+                    lines.append("#   %d dispatches, average %.1f us (kernel trace; the bench line's HIP-event figures per kind of pass: roofline.*.avg_launch_ms)" % (len(dd), sum(dd) / max(len(dd), 1)))
         except Exception as ex:
             lines.append("# could not read the rocpd database: %r" % (ex,))
     else:
         csvs = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
         if csvs:
             lines += open(csvs[0]).read().splitlines()[:30]
-    open(os.path.join(PROF, "r05_kernel_stats_p4.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(PROF, "r06_kernel_stats_p4.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))
 
 

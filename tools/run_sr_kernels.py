@@ -36,4 +36,8 @@ for _ in range(20):          # the volume update (k_regul_fused) on the scatter'
 rec.UpdateReconstructed(rec.vsize, v0)
 for _ in range(40):
     rec.SimulateSlices()
+if not pvr and rec.get_option("coeff_table") == 1:
+    for _ in range(8):       # the gather that evaluates and WRITES the coefficient table (coeff_lazy): once per new slice geometry in a run, eight times here
+        rec.set_option("coeff_invalidate", 1)
+        rec.SimulateSlices()
 print("tuned: scatter mode %d tiles %dx%d box %d, gather tiles %dx%d box %d" % tuple(rec.get_option(k) for k in ("back_mode", "tile_w", "tile_h", "wave_cap", "fwd_tile_w", "fwd_tile_h", "fwd_unit_cap")), flush=True)
