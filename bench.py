@@ -657,7 +657,7 @@ def main():
         bp_eval = split(timers["backproject"], bt)
         fw_eval = split(split(timers["forward"], ft), fs)
         e_back = entry(scatter_name + " = SuperresolutionKernel3D_tex, RC.cu:408-522", avg_s(bp_eval), bp_eval[1], b_back, "back")
-        e_fwd = entry(gather_name + " = simulateSlicesKernel3D_tex, RC.cu:298-404", avg_s(fw_eval if fw_eval[1] else fs), (fw_eval if fw_eval[1] else fs)[1], b_fwd, "forward")
+        e_fwd = entry(gather_name + " = simulateSlicesKernel3D_tex, RC.cu:298-404", avg_s(fw_eval), fw_eval[1], b_fwd, "forward") if fw_eval[1] else None
         eval_note = ("f32 VALU bound (4096 PSF taps per pixel, ~5e3 flop per algorithmic byte; no MFMA: a scatter/gather stencil with a "
                      "sequential epsilon-chain per row has no contraction).  `achieved` / `frac` (= `frac_executed`): the 38 flops of the "
                      "canonical sequence on the taps that are evaluated (dead units: one tap per row) against the packed-f32 vector peak; "
@@ -696,7 +696,8 @@ def main():
             roof = dict(dom)
             roof["backproject_table" if dom is e_ft else "forward_table"] = other
             roof["forward_store"] = e_fs
-            roof["evaluate"] = {"backproject": e_back if bp_eval[1] else None, "forward": e_fwd if (fw_eval[1] or fs[1]) else None, "note": eval_note}
+            roof["evaluate"] = {"backproject": e_back if bp_eval[1] else None, "forward": e_fwd, "note": eval_note
+                                + "  (forward: null when every evaluating gather of the timed steps was the one that writes the table: roofline.forward_store)"}
             roof["ms_per_step_by_kind"] = step_ms
             roof["dead_unit_share"] = dead_share
             roof["note"] = ("The step's dominant kernel by time, measured live (HIP events on the engine's stream, second pass of the same steps): the pass that streams "
@@ -706,7 +707,7 @@ def main():
                             "`frac_counters` = 2 x FETCH_SIZE (the guide's gfx950 correction for 16-byte streaming reads) + WRITE_SIZE from this round's separate "
                             "rocprofv3 --pmc passes (profiles/r06_traffic.json).  `evaluate`: the f32-VALU-bound figures of the evaluating launches, as in rounds 1-5.")
         else:
-            dom, other = (e_back, e_fwd) if avg_s(bp_eval) >= avg_s(fw_eval) else (e_fwd, e_back)
+            dom, other = (e_back, e_fwd) if (e_fwd is None or avg_s(bp_eval) >= avg_s(fw_eval)) else (e_fwd, e_back)
             roof = dict(dom)
             roof["dead_unit_share"] = dead_share
             roof["backproject" if dom is e_fwd else "forward"] = other

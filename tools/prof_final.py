@@ -55,6 +55,10 @@ def pmc(workload, tag, opts=()):
             "# quad-cycles summed over the SIMDs, FETCH_SIZE / WRITE_SIZE in KB (uncalibrated for this access pattern: narrow LDS-staged\n"
             "# reads and float atomics -- MI355X_MICROARCH.md calibrates only wide streaming reads -- so they are reported as counted).\n")
     open(os.path.join(PROF, f"r06_pmc_{tag}.txt"), "w").write(head + txt)
+    return parse_pmc(txt)
+
+
+def parse_pmc(txt):
     vals = {}
     cur = None
     for line in txt.splitlines():
@@ -77,21 +81,16 @@ def stats_only():
     kernel_stats(bench, j4, j8)
 
 
-def main():
-    if "--stats-only" in sys.argv:
-        return stats_only()
-    if "--timeline-only" in sys.argv:
-        os.makedirs(OUT, exist_ok=True)
-        return timeline(os.path.join(R, "bench.py"))
-    os.makedirs(OUT, exist_ok=True)
-    bench = os.path.join(R, "bench.py")
-    # 3. PMC first (the traffic file must exist before the final bench line)
+def build_traffic(get):
+    """profiles/r06_traffic.json from the PMC passes (get(workload, tag, opts) -> {kernel: {counter: value}}: a fresh rocprofv3 run, or a committed
+    profiles/r06_pmc_<tag>.txt read back: --traffic-only)"""
     traffic = {"source": "profiles/r06_pmc_<workload>.txt (rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE, separate passes, KB -> bytes; "
                          "per pass the kernels of one scatter / gather launch summed)"}
 
     def collect(vals, pats):
+        """the kernels of one pass; the FIRST pattern names its main kernel and must be there"""
         ks = [n for n in vals if any(p_ in n for p_ in pats)]
-        if not ks or not all("FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k] for k in ks):
+        if not ks or not any(pats[0] in n for n in ks) or not all("FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k] for k in ks):
             return None
         return {"kernels": ks, "fetch_bytes": sum(vals[k]["FETCH_SIZE"] for k in ks) * 1024.0, "write_bytes": sum(vals[k]["WRITE_SIZE"] for k in ks) * 1024.0,
                 "valu_insts": sum(vals[k].get("SQ_INSTS_VALU", 0.0) for k in ks)}
@@ -100,11 +99,10 @@ def main():
     # tap evaluated); patch-based workloads: their default (evaluated)
     todo = [("P4", "p4", ()), ("P4", "p4_on_the_fly", ("coeff_table=0",)), ("S8", "s8", ()), ("S8", "s8_on_the_fly", ("coeff_table=0",)),
             ("PVR4", "pvr4", ()), ("PVR8spx", "pvr8spx", ())]
-    v8 = {}
     for wl, tag, opts in todo:
-        v = pmc(wl, tag, opts)
-        if wl == "S8":
-            v8 = v
+        v = get(wl, tag, opts)
+        if not v:
+            continue
         pv = wl.startswith("PVR")
         nsup, isp = ("12", "true") if pv else ("16", "false")
         e = traffic.setdefault(wl, {})
@@ -119,6 +117,25 @@ def main():
         traffic[wl] = {k: x for k, x in e.items() if x}
     if traffic.get("P4", {}).get("back_table") or traffic.get("P4", {}).get("back"):
         json.dump(traffic, open(os.path.join(PROF, "r06_traffic.json"), "w"), indent=1)
+    return traffic
+
+
+def main():
+    if "--stats-only" in sys.argv:
+        return stats_only()
+    if "--traffic-only" in sys.argv:                       # from the committed PMC summaries (no GPU)
+        def read_back(wl, tag, opts):
+            f = os.path.join(PROF, f"r06_pmc_{tag}.txt")
+            return parse_pmc(open(f).read()) if os.path.exists(f) else None
+        print(json.dumps(build_traffic(read_back).get("S8")))
+        return
+    if "--timeline-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        return timeline(os.path.join(R, "bench.py"))
+    os.makedirs(OUT, exist_ok=True)
+    bench = os.path.join(R, "bench.py")
+    # 3. PMC first (the traffic file must exist before the final bench line)
+    traffic = build_traffic(lambda wl, tag, opts: pmc(wl, tag, opts))
     # 1. bench lines
     b4 = sh([sys.executable, bench], os.path.join(OUT, "bench_p4.log"), cwd=R)
     j4 = last_json(b4.stdout)
@@ -136,7 +153,7 @@ def main():
     kernel_stats(bench, j4, j8)
     timeline(bench)
     print(json.dumps(traffic.get("P4")))
-    print("S8 pmc kernels:", list(v8)[:6])
+
 
 
 def timeline(bench):
@@ -164,7 +181,7 @@ def kernel_stats(bench, j4, j8):
     p = sh(["timeout", "420", "rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, bench, "--no-cpu-baseline", "--no-s8"],   # (timeout: rocprofv3 has been seen to hang at exit after writing its database)
            os.path.join(OUT, "stats.log"))
     jt = last_json(p.stdout)
-    lines = ["# round 6: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r05/stats -o bench -- python bench.py --no-cpu-baseline --no-s8",
+    lines = ["# round 6: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d gpurun_out/r06/stats -o bench -- python bench.py --no-cpu-baseline --no-s8",
              "# (tools/prof_final.py; rocprofv3 of this image writes a rocpd database: `top_kernels` view below.  --no-s8: the default command also measures S8",
              "#  after the headline workload in the same launch -- with it the per-kernel averages below would mix P4's 3 ms launches with S8's 33 ms ones)"]
     if jt:
