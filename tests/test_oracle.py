@@ -82,6 +82,30 @@ def test_literal_and_canonical_psf_agree(tiny, oracle_mod):
     assert flips <= 2e-4 * kept                 # epsilon-skip ties
 
 
+def test_flip_pixels_is_the_two_census_walks_compared(tiny, oracle_mod):
+    """orc_flip_pixels (what the whole-workload LITERAL comparisons attribute their outliers to, round 6): per pixel the number of taps the literal walk
+    processes and the canonical one skips or the other way round -- the xor of the two tap_census keep masks -- and the PSF mass behind them; on the
+    pixels with a flip, v_PSF_sums of the two modes differ by no more than that mass (+ the two sequences' value differences)."""
+    lit = oracle_mod.OracleReconstruction(tiny, oracle_mod.LITERAL)
+    can = oracle_mod.OracleReconstruction(tiny, oracle_mod.CANON)
+    act = np.argwhere(tiny.slices != -1)
+    pick = act[np.random.default_rng(5).choice(len(act), 400, replace=False)]
+    flips, open_, mass = can.flip_pixels(pick)
+    f2, _, m2 = lit.flip_pixels(pick)
+    assert np.array_equal(flips, f2) and np.array_equal(mass, m2)          # (both sequences are walked whatever the instance's own mode)
+    for (sl, py, px), f, m in zip(pick, flips, mass):
+        _, bl, vl, _ = lit.tap_census(sl, px, py, with_vals=True)
+        _, bc, vc, _ = can.tap_census(sl, px, py, with_vals=True)
+        assert popcount_xor(bl, bc) == f
+        if f:
+            kl = np.unpackbits(bl.view(np.uint8), bitorder="little").astype(bool)
+            kc = np.unpackbits(bc.view(np.uint8), bitorder="little").astype(bool)
+            x = kl != kc
+            assert abs(float(np.maximum(np.where(kl, vl, 0), np.where(kc, vc, 0))[x].sum()) - m) <= 1e-5 * max(m, 1e-6) + 1e-7
+            assert abs(float(vl[kl].sum()) - float(vc[kc].sum())) <= 1.05 * m + 3e-3 * max(float(vl[kl].sum()), 1.0)
+    assert (open_ >= 0).all() and flips.sum() <= 2e-4 * 4096 * len(pick)
+
+
 def test_literal_and_canonical_pipeline_agree(tiny, oracle_mod):
     outs = []
     for mode in (oracle_mod.LITERAL, oracle_mod.CANON):
