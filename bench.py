@@ -210,8 +210,8 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12, help="timed steps (a multiple of the schedule's 4 SR iterations per outer iteration: one step in four then rewrites the coefficient table, whatever the warm-up)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="P4", choices=["P4", "P4s", "S8", "S8h", "tiny", "PVR4", "PVR8spx"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coeff-table", action="store_true", help="skip the second measurement with the coefficient table")
@@ -413,8 +413,8 @@ def main():
             if done[0] and k == 0:
                 em_reinit()
                 # an outer iteration brings new slice transformations, and with them new taps: the coefficient table (the default of a
-                # slice-to-volume run since round 6) is thrown away HERE, inside the timed region -- the next scatter evaluates, the next
-                # gather evaluates and writes the table (coeff_lazy), the other passes of the outer iteration stream it
+                # slice-to-volume run since round 6) is thrown away HERE, inside the timed region -- the next scatter evaluates and writes
+                # the table (coeff_lazy), the other passes of the outer iteration stream it
                 if mode_state["table"]:
                     rec.set_option("coeff_invalidate", 1)
             drv.sr_iteration(k)
@@ -653,8 +653,8 @@ def main():
         def avg_s(tm_):
             return tm_[0] / max(tm_[1], 1) * 1e-3
 
-        bt, ft, fs = timers["backproject_table"], timers["forward_table"], timers["forward_store"]
-        bp_eval = split(timers["backproject"], bt)
+        bt, ft, fs, bs = timers["backproject_table"], timers["forward_table"], timers["forward_store"], timers["backproject_store"]
+        bp_eval = split(split(timers["backproject"], bt), bs)
         fw_eval = split(split(timers["forward"], ft), fs)
         e_back = entry(scatter_name + " = SuperresolutionKernel3D_tex, RC.cu:408-522", avg_s(bp_eval), bp_eval[1], b_back, "back")
         e_fwd = entry(gather_name + " = simulateSlicesKernel3D_tex, RC.cu:298-404", avg_s(fw_eval), fw_eval[1], b_fwd, "forward") if fw_eval[1] else None
@@ -690,19 +690,24 @@ def main():
             e_fs = tentry("fwd_cell_kernel<16, false, 3>: the gather that evaluates every tap AND writes the table (coeff_lazy) = CoeffInit riding on "
                           "simulateSlicesKernel3D_tex", fs, tbytes + b_fwd, "forward_store",
                           "bytes WRITTEN; VALU-bound by its evaluation and write-bound by its stores at the same time") if fs[1] else None
-            step_ms = {"scatter_table": bt[0] / steps, "gather_table": ft[0] / steps, "gather_store": fs[0] / steps, "scatter_evaluate": bp_eval[0] / steps,
-                       "gather_evaluate": fw_eval[0] / steps}
+            e_bs = tentry("back_cell_kernel<16, false, 3>: the scatter that evaluates every tap AND writes the table (coeff_lazy: whichever PSF pass comes first after a "
+                          "new slice geometry -- in these steps the scatter, in the reconstruction loop pass 2 of the Gaussian reconstruction) = CoeffInit riding on "
+                          "SuperresolutionKernel3D_tex", bs, tbytes + b_back, "back_store",
+                          "bytes WRITTEN; VALU-bound by its evaluation and write-bound by its stores at the same time") if bs[1] else None
+            step_ms = {"scatter_table": bt[0] / steps, "gather_table": ft[0] / steps, "gather_store": fs[0] / steps, "scatter_store": bs[0] / steps,
+                       "scatter_evaluate": bp_eval[0] / steps, "gather_evaluate": fw_eval[0] / steps}
             dom, other = (e_bt, e_ft) if bt[0] >= ft[0] else (e_ft, e_bt)
             roof = dict(dom)
             roof["backproject_table" if dom is e_ft else "forward_table"] = other
             roof["forward_store"] = e_fs
+            roof["backproject_store"] = e_bs
             roof["evaluate"] = {"backproject": e_back if bp_eval[1] else None, "forward": e_fwd, "note": eval_note
                                 + "  (forward: null when every evaluating gather of the timed steps was the one that writes the table: roofline.forward_store)"}
             roof["ms_per_step_by_kind"] = step_ms
             roof["dead_unit_share"] = dead_share
             roof["note"] = ("The step's dominant kernel by time, measured live (HIP events on the engine's stream, second pass of the same steps): the pass that streams "
-                            "the coefficient table -- three of four scatters and three of four gathers of an outer iteration; the fourth scatter evaluates (the table "
-                            "is thrown away with every outer iteration, inside the timed region) and the fourth gather evaluates and writes the table.  HBM bound: "
+                            "the coefficient table -- three of four scatters and all four gathers of an outer iteration; the table is thrown away with every outer "
+                            "iteration, inside the timed region, and the scatter that follows evaluates and writes it (`backproject_store`).  HBM bound: "
                             "`achieved` = (1 KiB per live (pixel, plane) unit + SURVEY 8d's bytes of the pass) / launch time against the 8 TB/s peak; `traffic` / "
                             "`frac_counters` = 2 x FETCH_SIZE (the guide's gfx950 correction for 16-byte streaming reads) + WRITE_SIZE from this round's separate "
                             "rocprofv3 --pmc passes (profiles/r06_traffic.json).  `evaluate`: the f32-VALU-bound figures of the evaluating launches, as in rounds 1-5.")
@@ -748,7 +753,7 @@ def main():
         }
         out["config"]["mode"] = ("coefficient table (svr_set_option coeff_table 1, the default of a slice-to-volume context since round 6): the taps of every live (pixel, plane) "
                                  f"unit kept in HBM, THROWN AWAY every {SR_PER_OUTER} steps inside the timed region (an outer iteration's new slice transformations) and "
-                                 "rewritten by the next gather, which evaluates them anyway (coeff_lazy) -- irtkReconstruction::CoeffInit's _volcoeffs "
+                                 "rewritten by the next PSF pass, which evaluates them anyway (coeff_lazy; here the step's scatter) -- irtkReconstruction::CoeffInit's _volcoeffs "
                                  "(irtkReconstructionGPU.cc:2305-2673) on the GPU path; results bit-identical to evaluating every tap in every pass" if table_used else
                                  "every tap evaluated in every pass (the reference GPU kernels' way)")
         if world > 1:

@@ -1755,6 +1755,23 @@ int ensure_coeff(svr_ctx *ctx) {
   ctx->coeff_ids_valid = true;
   return SVR_OK;
 }
+// The evaluating cell pass that is about to run writes the table (coeff_lazy): memory, the pixels' places and ids.  *store = the pass should store.
+int coeff_begin_store(svr_ctx *ctx, bool *store) {
+  *store = false;
+  if (!(ctx->coeff_mode && !ctx->coeff_valid && coeff_lazy_ok(ctx) && ctx->n_active)) return SVR_OK;
+  const uint32_t *order = nullptr;
+  int r = coeff_prepare(ctx, &order);
+  if (r) return r;
+  if (!ctx->coeff_mode) return SVR_OK;                     // (the table does not fit)
+  if (!ctx->coeff_ids_valid) {
+    hipLaunchKernelGGL(k_coeff_ids, dim3(nblk(ctx->n_active)), dim3(256), 0, ctx->stream, order, (uint32_t)ctx->n_active, ctx->d_coeff_id);
+    KCHK("k_coeff_ids");
+    cell_pids_invalidate(ctx);
+    ctx->coeff_ids_valid = true;
+  }
+  *store = true;
+  return SVR_OK;
+}
 // a pass other than the gather of the SR iterations: with coeff_lazy it does not build the table -- it evaluates until that gather has written it
 int ensure_coeff_unless_lazy(svr_ctx *ctx) {
   if (ctx->coeff_mode && !ctx->coeff_valid && coeff_lazy_ok(ctx)) return SVR_OK;
@@ -2532,6 +2549,7 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   a.list = ctx->d_active;
   a.n = ctx->n_active;
   if (tiled && ctx->coeff_mode && ctx->coeff_valid && ctx->coeff_full) give_coeff(ctx, a);   // (every pixel with s != -1: a table written by a gather does not hold them all)
+  bool stored = false;
   ScopedTimer t(ctx, SVR_T_GAUSS);
   if (a.n && tiled) {
     // pass 1 = the unit-based walk of the gather (sume, gate, v_PSF_sums, voxel-count flag), pass 2 = the scatter of the
@@ -2586,7 +2604,12 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
       cells = ctx->cell->usable;
       if (!cells) ctx->note_fallback(0, "the scatter left the cell path (the cell lists cannot hold this geometry): back_mode 4, float atomics, last bits depend on the run");
     }
-    if (cells) r = launch_cell_scatter(ctx, a, 1, ctx->recon(), ctx->volw());
+    if (cells) {
+      // (coeff_lazy: pass 2 evaluates every unit the SR iterations will read -- it writes the table, and the SimulateSlices that follows streams it)
+      if (!a.coeff && !ctx->pvr && (r = coeff_begin_store(ctx, &stored))) return r;
+      if (stored) give_coeff(ctx, a);
+      r = launch_cell_scatter(ctx, a, 1, ctx->recon(), ctx->volw(), stored);
+    }
     else {
       // the tiles of the pixels that passed the gate (the tiled scatters only)
       HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
@@ -2611,7 +2634,8 @@ int svr_gaussian_reconstruction_local(svr_ctx *ctx) {
   }
   t.stop();
   ctx->psf_list_valid = false;
-  if (!ctx->coeff_full) ctx->coeff_valid = false;          // new v_PSF_sums: a table written by a gather holds the PSF pixels of that gather
+  if (stored) { ctx->coeff_valid = true; ctx->coeff_full = false; }   // (written by pass 2 for the new v_PSF_sums)
+  else if (!ctx->coeff_full) ctx->coeff_valid = false;     // new v_PSF_sums: a table written by an earlier pass holds the PSF pixels of that pass
   cell_gf_invalidate(ctx);                                 // ... and the gather's 1 / v_PSF_sums per sorted pixel
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SVR_OK;
@@ -2674,19 +2698,7 @@ int svr_simulate_slices(svr_ctx *ctx, uint8_t *slice_inside) {
   CellState *gcs = nullptr;
   if (ctx->coeff_mode && !ctx->coeff_valid && coeff_lazy_ok(ctx) && ctx->n_psf && ctx->n_active) {
     if ((r = cell_prepare_gather(ctx, gcs))) return r;
-    if (gcs->usable) {
-      const uint32_t *order = nullptr;
-      if ((r = coeff_prepare(ctx, &order))) return r;
-      if (ctx->coeff_mode) {                                // (0: the table does not fit)
-        if (!ctx->coeff_ids_valid) {
-          hipLaunchKernelGGL(k_coeff_ids, dim3(nblk(ctx->n_active)), dim3(256), 0, ctx->stream, order, (uint32_t)ctx->n_active, ctx->d_coeff_id);
-          KCHK("k_coeff_ids");
-          cell_pids_invalidate(ctx);
-          ctx->coeff_ids_valid = true;
-        }
-        store = true;
-      }
-    }
+    if (gcs->usable && (r = coeff_begin_store(ctx, &store))) return r;
   }
   if (!store) {
     r = ensure_coeff(ctx);
@@ -3196,8 +3208,10 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   }
   r = ensure_psf_list(ctx);
   if (r) return r;
+  // (coeff_lazy: a scatter that finds no table evaluates -- and, on the cell path, writes it: whichever PSF pass comes first after a new geometry does)
   r = ensure_coeff_unless_lazy(ctx);
   if (r) return r;
+  bool store = false;
   // RC.cu:2202-2203 -- not needed where the cell scatter runs: its combine writes EVERY voxel of addon | cmap (0 outside the mask); decided below
   bool need_clear = true;
   ctx->prep_pending = false;
@@ -3206,9 +3220,16 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
   a.list = ctx->d_psf_list;
   a.n = ctx->n_psf;
   if (ctx->coeff_mode && ctx->coeff_valid && (ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 4)) give_coeff(ctx, a);
-  ScopedTimer t(ctx, SVR_T_BACKPROJECT);
-  if (a.coeff) t.also(SVR_T_BACKPROJECT_TABLE);
   const bool tiled = ctx->pvr ? ctx->pvr_mode == 1 : back_mode_eff(ctx) >= 1;
+  if (!a.coeff && a.n && tiled && back_mode_eff(ctx) == 5 && !ctx->pvr) {
+    if ((r = cell_prepare(ctx))) return r;
+    if (ctx->cell->usable) {
+      if ((r = coeff_begin_store(ctx, &store))) return r;
+      if (store) give_coeff(ctx, a);
+    }
+  }
+  ScopedTimer t(ctx, SVR_T_BACKPROJECT);
+  if (store) t.also(SVR_T_BACKPROJECT_STORE); else if (a.coeff) t.also(SVR_T_BACKPROJECT_TABLE);
   if (!(a.n && tiled)) { need_clear = false; HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream)); }
   if (a.n && tiled) {
     TileArgs ta;
@@ -3222,7 +3243,10 @@ int svr_superresolution_backproject(svr_ctx *ctx, const float *slice_weight) {
     }
     need_clear = !cells;
     if (need_clear) { need_clear = false; HIPCHK(hipMemsetAsync(ctx->d_addon_cmap, 0, 2 * ctx->nv * sizeof(float), ctx->stream)); }
-    if (cells) r = launch_cell_scatter(ctx, a, 0, ctx->addon(), ctx->cmap());
+    if (cells) {
+      r = launch_cell_scatter(ctx, a, 0, ctx->addon(), ctx->cmap(), store);
+      if (!r && store) { ctx->coeff_valid = true; ctx->coeff_full = false; }   // (the PSF pixels' live units: what the SR iterations' passes read)
+    }
     else if (!(r = ensure_tiles_back(ctx))) r = launch_scatter(ctx, ctx->pvr ? 4 : std::min(4, back_mode_eff(ctx)), a, ta, ctx->d_tiles, ctx->n_tiles, MODE_BACK);
     if (r) return r;
   } else if (a.n && ctx->pvr) {

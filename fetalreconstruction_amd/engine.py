@@ -25,7 +25,7 @@ BUF_SLICES, BUF_WEIGHTS, BUF_SIMSLICES, BUF_SIMWEIGHTS, BUF_PSF_SUMS, BUF_BIAS =
 BUF_SIMINSIDE, BUF_VOXEL_COUNT = 20, 21
 T_BACKPROJECT, T_FORWARD, T_GAUSS, T_REGULARIZE, T_ESTEP, T_MSTEP, T_SCALE, T_REGISTER = range(8)
 TIMER_NAMES = ("backproject", "forward", "gauss", "regularize", "estep", "mstep", "scale", "register", "allreduce", "exchange_host", "coeff_build", "reduce_scatter", "allgather",
-               "backproject_table", "forward_table", "forward_store")
+               "backproject_table", "forward_table", "forward_store", "backproject_store")
 
 EXPORTS = [
     "svr_create", "svr_destroy", "svr_last_error", "svr_set_flags", "svr_set_option", "svr_get_option", "svr_set_spx_masks", "svr_init_reconstruction_volume",

@@ -346,9 +346,9 @@ enum svr_timer {
   SVR_T_COEFF_BUILD = 10,   /* k_coeff_build: writing the coefficient table (option coeff_table), once per slice geometry */
   SVR_T_REDUCE_SCATTER = 11, SVR_T_ALLGATHER = 12,   /* the two collectives of the slab update (svr_slab_*), HIP events like SVR_T_ALLREDUCE */
   /* round 6: SVR_T_BACKPROJECT / SVR_T_FORWARD by the kind of pass (the same intervals, counted a second time): the passes that stream the
-   * coefficient table, and the gather that evaluates and writes it (coeff_lazy) */
-  SVR_T_BACKPROJECT_TABLE = 13, SVR_T_FORWARD_TABLE = 14, SVR_T_FORWARD_STORE = 15,
-  SVR_T_COUNT = 16
+   * coefficient table, and the gather / the scatter that evaluates and writes it (coeff_lazy: whichever PSF pass comes first after a new geometry) */
+  SVR_T_BACKPROJECT_TABLE = 13, SVR_T_FORWARD_TABLE = 14, SVR_T_FORWARD_STORE = 15, SVR_T_BACKPROJECT_STORE = 16,
+  SVR_T_COUNT = 17
 };
 /* HIP events on the engine's stream around work a caller enqueues there itself (the volume all-reduce); no-ops while the
  * timers are off.  svr_timer_end waits for the stream. */
