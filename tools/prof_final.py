@@ -113,6 +113,7 @@ def build_traffic(get):
             e["back_table"] = collect(v, ("back_cell_kernel<16, false, 1>", "k_cell_combine", "k_cell_factors"))
             e["forward_table"] = collect(v, ("fwd_cell_kernel<16, false, 2, false>", "k_cell_gather_finish")) or collect(v, ("fwd_unit_kernel<false, 16, false, true>",))
             e["forward_store"] = collect(v, ("fwd_cell_kernel<16, false, 3, false>", "k_cell_gather_finish"))
+            e["back_store"] = collect(v, ("back_cell_kernel<16, false, 3>", "k_cell_combine", "k_cell_factors"))
         e["update"] = e.get("update") or collect(v, ("k_regul_fused",))
         traffic[wl] = {k: x for k, x in e.items() if x}
     if traffic.get("P4", {}).get("back_table") or traffic.get("P4", {}).get("back"):
@@ -162,13 +163,13 @@ def timeline(bench):
     import shutil
     d = os.path.join(OUT, "tl")
     shutil.rmtree(d, ignore_errors=True)
-    sh(["timeout", "420", "rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable, bench, "--steps", "8", "--warmup", "2",
+    sh(["timeout", "420", "rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable, bench, "--steps", "8", "--warmup", "4",
         "--no-cpu-baseline", "--no-s8", "--no-coeff-table"], os.path.join(OUT, "tl.log"))
-    p = subprocess.run([sys.executable, os.path.join(R, "tools", "step_timeline.py"), d, "4"], capture_output=True, text=True, env=dict(ENV, STEP_FROM="4"))
-    head = ("# round 6, final binary: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-s8 --no-coeff-table;\n"
-            "# STEP_FROM=4 python tools/step_timeline.py DIR 4   (P4, one MI355X, the default mode: steps 5-8 of the first timed pass -- kernel timers OFF -- i.e. one outer\n"
+    p = subprocess.run([sys.executable, os.path.join(R, "tools", "step_timeline.py"), d, "4"], capture_output=True, text=True, env=dict(ENV, STEP_FROM="5"))
+    head = ("# round 6, final binary: cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-s8 --no-coeff-table;\n"
+            "# STEP_FROM=5 python tools/step_timeline.py DIR 4   (P4, one MI355X, the default mode: the first four steps of the first timed pass -- kernel timers OFF -- i.e. one outer\n"
             "# iteration of the schedule: its first step follows InitializeEMValues / InitializeRobustStatistics / EStep and the throwing away of the coefficient table,\n"
-            "# its scatter evaluates and its gather evaluates and writes the table; the other three stream it)\n")
+            "# its scatter evaluates and writes the table; every other pass streams it)\n")
     open(os.path.join(PROF, "r06_step_timeline_p4.txt"), "w").write(head + p.stdout)
     print(p.stdout[:1500])
 
@@ -201,7 +202,7 @@ def kernel_stats(bench, j4, j8):
             lines.append("%7s %14s %12s %7s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
             lines += ["%7d %14.1f %12.1f %7.2f  %s" % (k, t, a, pc, short(n)) for n, k, t, a, pc in rows[:24]]
             # the on-the-fly instantiations; the bench times its K steps on the fly first, then the same K with the table
-            for pat in ("back_cell_kernel<16, false, 1>", "fwd_cell_kernel<16, false, 2, false>", "fwd_cell_kernel<16, false, 3, false>", "back_cell_kernel<16, false, 0>", "fwd_cell_kernel<16, false, 0, false>"):
+            for pat in ("back_cell_kernel<16, false, 1>", "fwd_cell_kernel<16, false, 2, false>", "back_cell_kernel<16, false, 3>", "fwd_cell_kernel<16, false, 3, false>", "back_cell_kernel<16, false, 0>", "fwd_cell_kernel<16, false, 0, false>"):
                 dd = [r[0] / 1e3 for r in c.execute("select (end - start) from kernels where name like ? order by start", ("%" + pat + "%",)).fetchall()]
                 if dd and jt:
                     k = jt["steps"]

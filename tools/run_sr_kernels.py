@@ -40,4 +40,7 @@ if not pvr and rec.get_option("coeff_table") == 1:
     for _ in range(8):       # the gather that evaluates and WRITES the coefficient table (coeff_lazy): once per new slice geometry in a run, eight times here
         rec.set_option("coeff_invalidate", 1)
         rec.SimulateSlices()
+    for _ in range(8):       # ... and the scatter that does (when it is the first PSF pass after the table went)
+        rec.set_option("coeff_invalidate", 1)
+        rec.SuperresolutionBackproject(sw)
 print("tuned: scatter mode %d tiles %dx%d box %d, gather tiles %dx%d box %d" % tuple(rec.get_option(k) for k in ("back_mode", "tile_w", "tile_h", "wave_cap", "fwd_tile_w", "fwd_tile_h", "fwd_unit_cap")), flush=True)
