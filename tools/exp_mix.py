@@ -1,6 +1,7 @@
-"""Dev experiment (round 6): the three forms of the PSF passes -- coeff_table 0 (every tap evaluated), 1 (every tap of a live unit from the
-table), 2 (the HALF table: the right half of a row from the table, the left half evaluated while it is in flight).  Same addon | cmap |
-simulated slices bit for bit?  Time per launch of the scatter and of the gather.  usage: exp_mix.py [P4|S8] [modes ...]"""
+"""Dev experiment (round 6): the forms of the two PSF passes on one workload -- coeff_table 0 (every tap evaluated) and 1 (the taps of a live unit streamed
+from the coefficient table; the gather through the LDS) -- timed per launch and compared bit for bit (addon | cmap | simulated slices / weights), plus the
+gather that evaluates and writes the table against k_coeff_build.  usage: exp_mix.py [P4|S8|PVR4|PVR8spx] [modes ...] [option=value ...]
+(the wavefront-mix, half-table and shared-box variants this script first measured are recorded in profiles/r06_plane_mix_experiment.txt)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
